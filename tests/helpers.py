@@ -1,0 +1,75 @@
+"""Shared helpers for the parity tests (bridges product-side and oracle-side types)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import whisper_ref
+from whisperjav_amd import dims as pdims
+from whisperjav_amd import weights as pweights
+
+
+def oracle_dims(d: pdims.WhisperDims) -> whisper_ref.WhisperDims:
+    return whisper_ref.WhisperDims(**d.as_dict())
+
+
+def small_dims(n_mels=80, d_model=128, heads=2, layers=2, n_vocab=51865) -> pdims.WhisperDims:
+    return pdims.custom_dims(n_mels, d_model, heads, layers, n_vocab)
+
+
+def make_oracle(d: pdims.WhisperDims, seed=1234, emulate_bf16=False):
+    w = pweights.synth_weights(d, seed=seed)
+    rnd = whisper_ref.bf16_round if emulate_bf16 else None
+    return whisper_ref.WhisperOracle(oracle_dims(d), w, act_round=rnd), w
+
+
+def hf_state_dict(d: pdims.WhisperDims, w):
+    """Map openai-style names onto transformers' WhisperForConditionalGeneration names."""
+    sd = {}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    sd["model.encoder.conv1.weight"] = t(w["encoder.conv1.weight"])
+    sd["model.encoder.conv1.bias"] = t(w["encoder.conv1.bias"])
+    sd["model.encoder.conv2.weight"] = t(w["encoder.conv2.weight"])
+    sd["model.encoder.conv2.bias"] = t(w["encoder.conv2.bias"])
+    sd["model.encoder.embed_positions.weight"] = t(w["encoder.positional_embedding"])
+    sd["model.encoder.layer_norm.weight"] = t(w["encoder.ln_post.weight"])
+    sd["model.encoder.layer_norm.bias"] = t(w["encoder.ln_post.bias"])
+    sd["model.decoder.embed_tokens.weight"] = t(w["decoder.token_embedding.weight"])
+    sd["model.decoder.embed_positions.weight"] = t(w["decoder.positional_embedding"])
+    sd["model.decoder.layer_norm.weight"] = t(w["decoder.ln.weight"])
+    sd["model.decoder.layer_norm.bias"] = t(w["decoder.ln.bias"])
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+
+    def attn(src, dst):
+        for a, b in (("query", "q_proj"), ("key", "k_proj"), ("value", "v_proj"), ("out", "out_proj")):
+            sd[f"{dst}.{b}.weight"] = t(w[f"{src}.{a}.weight"])
+            if a != "key":
+                sd[f"{dst}.{b}.bias"] = t(w[f"{src}.{a}.bias"])
+
+    def ln(src, dst):
+        sd[dst + ".weight"] = t(w[src + ".weight"])
+        sd[dst + ".bias"] = t(w[src + ".bias"])
+
+    for i in range(d.n_audio_layer):
+        s, h = f"encoder.blocks.{i}", f"model.encoder.layers.{i}"
+        attn(s + ".attn", h + ".self_attn")
+        ln(s + ".attn_ln", h + ".self_attn_layer_norm")
+        ln(s + ".mlp_ln", h + ".final_layer_norm")
+        ln(s + ".mlp.0", h + ".fc1")
+        ln(s + ".mlp.2", h + ".fc2")
+    for i in range(d.n_text_layer):
+        s, h = f"decoder.blocks.{i}", f"model.decoder.layers.{i}"
+        attn(s + ".attn", h + ".self_attn")
+        attn(s + ".cross_attn", h + ".encoder_attn")
+        ln(s + ".attn_ln", h + ".self_attn_layer_norm")
+        ln(s + ".cross_attn_ln", h + ".encoder_attn_layer_norm")
+        ln(s + ".mlp_ln", h + ".final_layer_norm")
+        ln(s + ".mlp.0", h + ".fc1")
+        ln(s + ".mlp.2", h + ".fc2")
+    return sd
+
+
+def synth_mel(batch, n_mels, seed=7, frames=3000):
+    """Log-mel-shaped random input in the value range Whisper sees ([-1, 1.5])."""
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((batch, n_mels, frames), dtype=np.float32) * 0.4).clip(-1.0, 1.5)

@@ -1,0 +1,230 @@
+"""Whisper weights: synthetic generation, checkpoint import and the HBM blob layout.
+
+The HIP engine consumes ONE contiguous device blob plus a table of byte offsets whose order
+is fixed by ``include/wjhip.h`` (``WJ_T_*`` enumerators): matrices in the engine's compute
+dtype (bf16 or fp32, row-major ``[out, in]`` = K-contiguous for both MFMA operands), vectors
+(biases, LayerNorm, positional tables) always fp32, every tensor 256-byte aligned.  One blob
+means one RCCL broadcast over xGMI at start-up (``whisperjav_amd.sharding``) and no per-tensor
+allocation.
+
+Weight names follow openai-whisper's state dict (``encoder.blocks.0.attn.query.weight`` ...),
+which is what ``whisper.load_model`` (reference: whisperjav/modules/whisper_pro_asr.py:182)
+yields; the fused tensors the engine wants (QKV, cross K/V, im2col-ordered conv kernels) are
+assembled here.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from .dims import WhisperDims
+
+ALIGN = 256
+
+# ---- canonical tensor order (must match include/wjhip.h) ------------------------------------
+GLOBAL_TENSORS = (
+    "ENC_CONV1_W", "ENC_CONV1_B", "ENC_CONV2_W", "ENC_CONV2_B", "ENC_POS",
+    "ENC_LNPOST_W", "ENC_LNPOST_B", "DEC_TOK_EMB", "DEC_POS", "DEC_LN_W", "DEC_LN_B",
+)
+ENC_LAYER_TENSORS = (
+    "LN1_W", "LN1_B", "QKV_W", "QKV_B", "OUT_W", "OUT_B",
+    "LN2_W", "LN2_B", "FC1_W", "FC1_B", "FC2_W", "FC2_B",
+)
+DEC_LAYER_TENSORS = (
+    "LN1_W", "LN1_B", "QKV_W", "QKV_B", "OUT_W", "OUT_B",
+    "LNX_W", "LNX_B", "CQ_W", "CQ_B", "CKV_W", "CKV_B", "COUT_W", "COUT_B",
+    "LN2_W", "LN2_B", "FC1_W", "FC1_B", "FC2_W", "FC2_B",
+)
+
+
+def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.ndarray:
+    half = channels // 2
+    inc = np.log(max_timescale) / (half - 1)
+    inv = np.exp(-inc * np.arange(half, dtype=np.float32)).astype(np.float32)
+    t = np.arange(length, dtype=np.float32)[:, None] * inv[None, :]
+    return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
+
+
+def round_to_bf16(a: np.ndarray) -> np.ndarray:
+    """fp32 array rounded (RNE) to the nearest bf16-representable fp32 value."""
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return t.to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def synth_weights(dims: WhisperDims, seed: int = 1234, bf16_exact: bool = True) -> Dict[str, np.ndarray]:
+    """Seeded random weights with trained-like statistics (there are no checkpoints offline).
+
+    Variances are chosen so activations stay O(1) through the stack, attention scores have
+    unit-ish spread and logits have a std of ~1.8 over the vocabulary (top-2 gap ~0.4), so
+    greedy/beam decisions are numerically well separated -- a uniform-logit random model would
+    make token parity meaningless.  With ``bf16_exact`` every matrix is pre-rounded to bf16 so
+    the fp32 oracle and the bf16 engine see bit-identical parameters.
+    """
+    rng = np.random.default_rng(seed)
+    w: Dict[str, np.ndarray] = {}
+
+    def mat(name, shape, fan_in, gain=1.0):
+        a = rng.standard_normal(shape, dtype=np.float32) * np.float32(gain / np.sqrt(fan_in))
+        w[name] = round_to_bf16(a) if bf16_exact else a
+
+    def vec(name, n, scale=0.1, base=0.0):
+        w[name] = (base + scale * rng.standard_normal(n, dtype=np.float32)).astype(np.float32)
+
+    d = dims.n_audio_state
+    mat("encoder.conv1.weight", (d, dims.n_mels, 3), 3 * dims.n_mels)
+    vec("encoder.conv1.bias", d)
+    mat("encoder.conv2.weight", (d, d, 3), 3 * d)
+    vec("encoder.conv2.bias", d)
+    w["encoder.positional_embedding"] = sinusoids(dims.n_audio_ctx, d)
+
+    def block(prefix, dm, cross):
+        vec(prefix + "attn_ln.weight", dm, 0.1, 1.0)
+        vec(prefix + "attn_ln.bias", dm)
+        names = ["attn"] + (["cross_attn"] if cross else [])
+        for a in names:
+            mat(f"{prefix}{a}.query.weight", (dm, dm), dm)
+            vec(f"{prefix}{a}.query.bias", dm)
+            mat(f"{prefix}{a}.key.weight", (dm, dm), dm)
+            mat(f"{prefix}{a}.value.weight", (dm, dm), dm)
+            vec(f"{prefix}{a}.value.bias", dm)
+            mat(f"{prefix}{a}.out.weight", (dm, dm), dm, 0.5)
+            vec(f"{prefix}{a}.out.bias", dm)
+        if cross:
+            vec(prefix + "cross_attn_ln.weight", dm, 0.1, 1.0)
+            vec(prefix + "cross_attn_ln.bias", dm)
+        vec(prefix + "mlp_ln.weight", dm, 0.1, 1.0)
+        vec(prefix + "mlp_ln.bias", dm)
+        mat(prefix + "mlp.0.weight", (4 * dm, dm), dm)
+        vec(prefix + "mlp.0.bias", 4 * dm)
+        mat(prefix + "mlp.2.weight", (dm, 4 * dm), 4 * dm, 0.5)
+        vec(prefix + "mlp.2.bias", dm)
+
+    for i in range(dims.n_audio_layer):
+        block(f"encoder.blocks.{i}.", d, False)
+    vec("encoder.ln_post.weight", d, 0.1, 1.0)
+    vec("encoder.ln_post.bias", d)
+
+    dt = dims.n_text_state
+    a = rng.standard_normal((dims.n_vocab, dt), dtype=np.float32) * np.float32(0.05)
+    w["decoder.token_embedding.weight"] = round_to_bf16(a) if bf16_exact else a
+    w["decoder.positional_embedding"] = (0.05 * rng.standard_normal(
+        (dims.n_text_ctx, dt), dtype=np.float32)).astype(np.float32)
+    for i in range(dims.n_text_layer):
+        block(f"decoder.blocks.{i}.", dt, True)
+    vec("decoder.ln.weight", dt, 0.1, 1.0)
+    vec("decoder.ln.bias", dt)
+    return w
+
+
+# ---- blob packing ---------------------------------------------------------------------------
+def _im2col_conv(wt: np.ndarray) -> np.ndarray:
+    """Conv1d kernel ``[out, in, 3]`` -> GEMM operand ``[out, 3*in]`` with K index = tap*in + c."""
+    return np.ascontiguousarray(wt.transpose(0, 2, 1).reshape(wt.shape[0], -1))
+
+
+def engine_tensors(dims: WhisperDims, w: Dict[str, np.ndarray]) -> List[Tuple[str, np.ndarray, bool]]:
+    """Flatten a state dict into the canonical ``(label, array, is_matrix)`` list."""
+    out: List[Tuple[str, np.ndarray, bool]] = []
+    d = dims.n_audio_state
+    zeros = lambda n: np.zeros(n, dtype=np.float32)  # noqa: E731
+
+    g = {
+        "ENC_CONV1_W": (_im2col_conv(w["encoder.conv1.weight"]), True),
+        "ENC_CONV1_B": (w["encoder.conv1.bias"], False),
+        "ENC_CONV2_W": (_im2col_conv(w["encoder.conv2.weight"]), True),
+        "ENC_CONV2_B": (w["encoder.conv2.bias"], False),
+        "ENC_POS": (w["encoder.positional_embedding"], False),
+        "ENC_LNPOST_W": (w["encoder.ln_post.weight"], False),
+        "ENC_LNPOST_B": (w["encoder.ln_post.bias"], False),
+        "DEC_TOK_EMB": (w["decoder.token_embedding.weight"], True),
+        "DEC_POS": (w["decoder.positional_embedding"], False),
+        "DEC_LN_W": (w["decoder.ln.weight"], False),
+        "DEC_LN_B": (w["decoder.ln.bias"], False),
+    }
+    for name in GLOBAL_TENSORS:
+        arr, is_mat = g[name]
+        out.append((name, arr, is_mat))
+
+    def attn_fused(p):
+        qkv_w = np.concatenate([w[p + "query.weight"], w[p + "key.weight"], w[p + "value.weight"]], 0)
+        qkv_b = np.concatenate([w[p + "query.bias"], zeros(w[p + "key.weight"].shape[0]),
+                                w[p + "value.bias"]], 0)
+        return qkv_w, qkv_b
+
+    for i in range(dims.n_audio_layer):
+        p = f"encoder.blocks.{i}."
+        qkv_w, qkv_b = attn_fused(p + "attn.")
+        t = {
+            "LN1_W": (w[p + "attn_ln.weight"], False), "LN1_B": (w[p + "attn_ln.bias"], False),
+            "QKV_W": (qkv_w, True), "QKV_B": (qkv_b, False),
+            "OUT_W": (w[p + "attn.out.weight"], True), "OUT_B": (w[p + "attn.out.bias"], False),
+            "LN2_W": (w[p + "mlp_ln.weight"], False), "LN2_B": (w[p + "mlp_ln.bias"], False),
+            "FC1_W": (w[p + "mlp.0.weight"], True), "FC1_B": (w[p + "mlp.0.bias"], False),
+            "FC2_W": (w[p + "mlp.2.weight"], True), "FC2_B": (w[p + "mlp.2.bias"], False),
+        }
+        for name in ENC_LAYER_TENSORS:
+            out.append((f"enc{i}.{name}", t[name][0], t[name][1]))
+
+    for i in range(dims.n_text_layer):
+        p = f"decoder.blocks.{i}."
+        qkv_w, qkv_b = attn_fused(p + "attn.")
+        ckv_w = np.concatenate([w[p + "cross_attn.key.weight"], w[p + "cross_attn.value.weight"]], 0)
+        ckv_b = np.concatenate([zeros(d), w[p + "cross_attn.value.bias"]], 0)
+        t = {
+            "LN1_W": (w[p + "attn_ln.weight"], False), "LN1_B": (w[p + "attn_ln.bias"], False),
+            "QKV_W": (qkv_w, True), "QKV_B": (qkv_b, False),
+            "OUT_W": (w[p + "attn.out.weight"], True), "OUT_B": (w[p + "attn.out.bias"], False),
+            "LNX_W": (w[p + "cross_attn_ln.weight"], False), "LNX_B": (w[p + "cross_attn_ln.bias"], False),
+            "CQ_W": (w[p + "cross_attn.query.weight"], True), "CQ_B": (w[p + "cross_attn.query.bias"], False),
+            "CKV_W": (ckv_w, True), "CKV_B": (ckv_b, False),
+            "COUT_W": (w[p + "cross_attn.out.weight"], True), "COUT_B": (w[p + "cross_attn.out.bias"], False),
+            "LN2_W": (w[p + "mlp_ln.weight"], False), "LN2_B": (w[p + "mlp_ln.bias"], False),
+            "FC1_W": (w[p + "mlp.0.weight"], True), "FC1_B": (w[p + "mlp.0.bias"], False),
+            "FC2_W": (w[p + "mlp.2.weight"], True), "FC2_B": (w[p + "mlp.2.bias"], False),
+        }
+        for name in DEC_LAYER_TENSORS:
+            out.append((f"dec{i}.{name}", t[name][0], t[name][1]))
+    return out
+
+
+def expected_tensor_count(dims: WhisperDims) -> int:
+    return (len(GLOBAL_TENSORS) + len(ENC_LAYER_TENSORS) * dims.n_audio_layer
+            + len(DEC_LAYER_TENSORS) * dims.n_text_layer)
+
+
+def pack_blob(dims: WhisperDims, w: Dict[str, np.ndarray], dtype: str = "bfloat16"
+              ) -> Tuple[torch.Tensor, np.ndarray]:
+    """Pack a state dict into (host uint8 blob, int64 byte offsets) for ``wj_whisper_create``.
+
+    ``dtype``: ``"bfloat16"`` (matrices stored bf16) or ``"float32"``.
+    """
+    if dtype not in ("bfloat16", "float32"):
+        raise ValueError("dtype must be 'bfloat16' or 'float32'")
+    tensors = engine_tensors(dims, w)
+    assert len(tensors) == expected_tensor_count(dims)
+    offsets = np.zeros(len(tensors), dtype=np.int64)
+    cursor = 0
+    sizes = []
+    for idx, (_, arr, is_mat) in enumerate(tensors):
+        item = 2 if (is_mat and dtype == "bfloat16") else 4
+        nbytes = int(arr.size) * item
+        offsets[idx] = cursor
+        sizes.append(nbytes)
+        cursor += (nbytes + ALIGN - 1) // ALIGN * ALIGN
+    blob = torch.zeros(cursor, dtype=torch.uint8)
+    for (label, arr, is_mat), off, nbytes in zip(tensors, offsets, sizes):
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+        if is_mat and dtype == "bfloat16":
+            t = t.to(torch.bfloat16)
+        blob[off:off + nbytes] = t.reshape(-1).view(torch.uint8)
+    return blob, offsets
+
+
+def load_openai_checkpoint(path: str) -> Tuple[WhisperDims, Dict[str, np.ndarray]]:
+    """Import an openai-whisper ``.pt`` checkpoint (``{"dims": ..., "model_state_dict": ...}``)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    dims = WhisperDims(**{k: int(v) for k, v in ckpt["dims"].items()})
+    sd = {k: v.float().numpy() for k, v in ckpt["model_state_dict"].items()}
+    return dims, sd
