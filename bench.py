@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on the MI355X hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input per GPU: B windows of 30 s,
+16 kHz synthetic Japanese-speech-shaped audio already resident in HBM ->
+HIP log-mel -> Whisper large-v3 encoder (+ cross K/V) -> device-resident greedy decode of
+`decode_tokens` tokens per window (BASELINE cfg2: "Whisper large-v3 ja, 30 s chunk, mel + encoder +
+greedy decode, no VAD").  Weights are seeded random tensors of the large-v3 geometry (no checkpoints
+offline), packed once on rank 0 and broadcast to every rank over RCCL; after that there is no
+collective in the timed region (weak scaling: every GPU gets its own B windows).
+
+value = whole-job audio seconds processed per wall second (RTFx; /3600 = audio-hours per second).
+Prints ONE JSON line on rank 0 (plus human-readable notes on stderr).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from whisperjav_amd import dims as pdims  # noqa: E402
+from whisperjav_amd import sharding, synth  # noqa: E402
+from whisperjav_amd import weights as pweights  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3}   # dense peaks
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def stage_model(tag, count, ms, dims, B, n_dec, prompt_len, dtype):
+    """Algorithmic work of one launch of a launch class -> (bound, achieved, unit, work_per_launch)."""
+    if count == 0 or ms <= 0:
+        return None
+    esz = 2 if dtype == "bfloat16" else 4
+    d, H, T, V = dims.n_audio_state, dims.n_audio_head, dims.n_audio_ctx, dims.n_vocab
+    M = B * T
+    per = ms / count * 1e-3
+    flops = {
+        "conv1_gemm": 2.0 * B * 2 * T * d * 3 * dims.n_mels,
+        "conv2_gemm": 2.0 * M * d * 3 * d,
+        "enc_qk_gemm": 2.0 * M * 2 * d * d,
+        "enc_v_gemm": 2.0 * M * d * d,
+        "enc_out_gemm": 2.0 * M * d * d,
+        "enc_fc1_gemm": 2.0 * M * 4 * d * d,
+        "enc_fc2_gemm": 2.0 * M * 4 * d * d,
+        "cross_kv_gemm": 2.0 * M * 2 * d * d,
+        "enc_attention": 4.0 * B * H * T * T * 64,
+    }
+    avg_keys = prompt_len + (n_dec + 1) / 2.0
+    byts = {
+        "dec_cross_attn": B * H * T * 64 * 2.0 * esz,          # K and V of every resident window
+        "dec_self_attn": B * H * avg_keys * 64 * 2.0 * esz,
+        "dec_qkv_gemm": 3.0 * d * d * esz,
+        "dec_out_gemm": 1.0 * d * d * esz,
+        "dec_cq_gemm": 1.0 * d * d * esz,
+        "dec_cout_gemm": 1.0 * d * d * esz,
+        "dec_fc1_gemm": 4.0 * d * d * esz,
+        "dec_fc2_gemm": 4.0 * d * d * esz,
+        "dec_logits_gemm": 1.0 * V * d * esz + B * V * 4.0,
+        "dec_sample": B * V * 4.0 * 2,
+        "enc_layernorm": M * d * (4.0 + esz),
+        "dec_layernorm": B * d * (4.0 + esz),
+        "mel_to_rows": B * dims.n_mels * 2 * T * (4.0 + esz),
+    }
+    if tag in flops:
+        return {"bound": "mfma", "achieved": flops[tag] / per / 1e12, "unit": "TFLOP/s",
+                "peak": MFMA_PEAK_TFLOPS[dtype], "work": flops[tag]}
+    if tag in byts:
+        return {"bound": "hbm", "achieved": byts[tag] / per / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "work": byts[tag]}
+    return None
+
+
+def cpu_baseline(dims, w, audio, n_mels, decode_tokens, sample_tokens):
+    """The oracle (a CPU port of the reference's upstream math) timed on this host's cores for ONE
+    30 s window: full log-mel + full encoder + `sample_tokens` cached decode steps, the decode time
+    scaled linearly to `decode_tokens`."""
+    from oracle import decoding, logmel, whisper_ref
+    threads = torch.get_num_threads()
+    oracle = whisper_ref.WhisperOracle(whisper_ref.WhisperDims(**dims.as_dict()), w)
+    toks = pdims.special_tokens(dims.n_vocab)
+    prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
+    t0 = time.perf_counter()
+    mel = logmel.window_features(audio, n_mels, "fw")
+    t_mel = time.perf_counter() - t0
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        enc = oracle.encode(torch.from_numpy(mel[None]))
+        t_enc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        decoding.greedy_decode(oracle, enc, prompt, sample_tokens, decoding.FilterConfig(max_initial_timestamp_index=50))
+        t_dec = time.perf_counter() - t0
+    total = t_mel + t_enc + t_dec * (decode_tokens + len(prompt) - 1) / (sample_tokens + len(prompt) - 1)
+    return {"value": 30.0 / total, "unit": "x real-time (audio-s per wall-s)", "cores": threads, "kind": "port",
+            "sample": (f"1 window of 30 s: log-mel + full large-v3-shaped encoder + {sample_tokens} of {decode_tokens} "
+                       f"cached greedy decode steps (decode scaled linearly), PyTorch-CPU fp32 oracle, "
+                       f"{threads} threads; mel {t_mel:.2f}s enc {t_enc:.2f}s dec({sample_tokens}) {t_dec:.2f}s")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32, help="30 s windows per GPU per step")
+    ap.add_argument("--decode-tokens", type=int, default=224, help="new tokens per window (n_text_ctx // 2)")
+    ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-sample-tokens", type=int, default=32)
+    args = ap.parse_args()
+
+    info = sharding.init_distributed()
+    if args.gpus != info.world:
+        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={info.world}; using WORLD_SIZE")
+    from whisperjav_amd import engine, hipbind
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(info.local_rank)
+    dev = torch.device("cuda", info.local_rank)
+    dims = pdims.dims_for(args.model)
+    B, n_dec = args.batch, args.decode_tokens
+
+    # ---- weights: packed once on rank 0, ONE RCCL broadcast, then no collectives -------------
+    t0 = time.perf_counter()
+    w = blob = offsets = None
+    if info.rank == 0:
+        w = pweights.synth_weights(dims, seed=1234)
+        blob, offsets = pweights.pack_blob(dims, w, args.dtype)
+    dev_blob, offsets = sharding.broadcast_blob(blob, offsets, dev)
+    del blob
+    model = engine.HipWhisper(dims, blob=dev_blob, offsets=offsets, dtype=args.dtype, device=info.local_rank,
+                              max_batch=B, max_beam=1)
+    log(f"[bench] rank {info.rank}: weights ready in {time.perf_counter() - t0:.1f}s, workspace "
+        f"{model.workspace_bytes / 2**30:.1f} GiB, blob {dev_blob.numel() / 2**30:.2f} GiB")
+
+    # ---- synthetic audio resident in HBM ---------------------------------------------------------
+    distinct = [synth.speech_like(30.0, seed=1234 + 17 * info.rank + i) for i in range(min(B, 4))]
+    clips = [distinct[i % len(distinct)] for i in range(B)]
+    pcm = torch.from_numpy(np.concatenate(clips)).to(dev)
+    offs = [i * 480000 for i in range(B + 1)]
+    fe = engine.HipLogMel(dims.n_mels, "fw", device=info.local_rank)
+    prompt = np.tile(np.array(model.sot_prompt("ja", "transcribe"), dtype=np.int32), (B, 1))
+    toks = model.tokens
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    opts = engine.DecodeOptions(max_new_tokens=n_dec, suppress_tokens=suppress, max_initial_timestamp=1.0)
+    decoded = {"n": None}
+
+    def step():
+        mel = fe.from_device(pcm, offs)
+        model.encode(mel)
+        res = model.decode_greedy(prompt, opts)
+        decoded["n"] = res.n_tokens
+
+    for _ in range(args.warmup):
+        step()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    audio_s = 30.0 * B * info.world * args.steps
+    rtfx = audio_s / elapsed
+
+    # ---- live per-launch-class timing with HIP events (eager replay of one step) ---------------
+    stages, roofline = {}, None
+    if not args.no_profile and info.rank == 0:
+        ctx = hipbind.context(info.local_rank)
+        n_prof = min(n_dec, 48)   # the per-launch averages do not need all 224 eager steps
+        popts = engine.DecodeOptions(max_new_tokens=n_prof, suppress_tokens=suppress, max_initial_timestamp=1.0)
+        ctx.profile_start()
+        mel = fe.from_device(pcm, offs)
+        model.encode(mel)
+        model.decode_greedy(prompt, popts)
+        prof = ctx.profile_stop()
+        total_ms = sum(ms for _, ms in prof.values())
+        for tag, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+            entry = {"launches": cnt, "ms_total": round(ms, 3), "share": round(ms / total_ms, 4),
+                     "us_per_launch": round(1e3 * ms / cnt, 2)}
+            sm = stage_model(tag, cnt, ms, dims, B, n_prof, prompt.shape[1], args.dtype)
+            if sm:
+                entry.update({"bound": sm["bound"], "achieved": round(sm["achieved"], 2), "unit": sm["unit"],
+                              "frac": round(sm["achieved"] / sm["peak"], 4)})
+            stages[tag] = entry
+        dom = next(iter(stages))
+        if "bound" in stages[dom]:
+            e = stages[dom]
+            roofline = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"],
+                        "peak": HBM_PEAK_GBS if e["bound"] == "hbm" else MFMA_PEAK_TFLOPS[args.dtype],
+                        "unit": e["unit"], "frac": e["frac"], "traffic": None,
+                        "share_of_step": e["share"], "us_per_launch": e["us_per_launch"]}
+        enc = [k for k in stages if k.startswith("enc_") and stages[k].get("bound") == "mfma"]
+        if enc:
+            fl = sum(stages[k]["achieved"] * stages[k]["ms_total"] for k in enc)
+            ms = sum(stages[k]["ms_total"] for k in enc)
+            stages["_encoder_mfma_aggregate"] = {"achieved": round(fl / ms, 2), "unit": "TFLOP/s",
+                                                 "frac": round(fl / ms / MFMA_PEAK_TFLOPS[args.dtype], 4)}
+
+    cpu = None
+    if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(dims, w, clips[0], dims.n_mels, n_dec, args.cpu_sample_tokens)
+
+    if info.rank == 0:
+        line = {
+            "metric": "audio-hours/sec (RTF) end-to-end, Whisper large-v3 ja",
+            "value": round(rtfx, 2), "unit": "x real-time (audio-s per wall-s)",
+            "audio_hours_per_sec": round(rtfx / 3600.0, 5),
+            "n_gpus": info.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+            "config": {"workload": (f"cfg2: Whisper {args.model} geometry (seeded random weights), {B} x 30 s 16 kHz "
+                                    f"windows per GPU per step resident in HBM: log-mel + encoder + greedy decode of "
+                                    f"{n_dec} tokens/window with timestamp rules, no VAD"),
+                       "windows_per_gpu": B, "decode_tokens": n_dec, "compute_type": args.dtype,
+                       "parallelism": f"scene-parallel x{info.world}, one RCCL weight broadcast, no data-path collective"},
+            "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
+        }
+        print(json.dumps(line), flush=True)
+    model.close()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,203 @@
+/*
+ * wjhip.h -- C ABI of libwjhip.so, the MI355X (gfx950) implementation of WhisperJAV's
+ * balanced/fidelity hot path: log-mel -> VAD scorer -> Whisper encoder -> decode.
+ *
+ * The reference (meizhong986/WhisperJAV v1.8.14) has NO native boundary: every FLOP of this
+ * path runs inside third-party wheels that the reference calls through Python objects
+ * (SURVEY.md section 8b).  Each entry point below therefore cites the *Python call site* it
+ * replaces; whisperjav_amd/ (ctypes) re-creates those Python seams on top of this header.
+ *
+ * Conventions: plain pointers and sizes only (no torch / HIP types); every `*_dev` pointer is
+ * a device (HBM) address on the context's GPU; `stream` is a hipStream_t passed as void*
+ * (NULL = the context's own stream); every function returns 0 on success or a negative
+ * WJ_E_* code, with a thread-local message available from wj_last_error().  No exceptions
+ * cross the boundary; nothing runs at exit (the reference leaves via os._exit,
+ * whisperjav/main.py:2490-2494).  One context per process per GPU, spawn-safe.
+ */
+#ifndef WJHIP_H
+#define WJHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WJ_ABI_VERSION 1
+
+enum {
+  WJ_OK = 0,
+  WJ_E_INVALID = -1,   /* bad argument */
+  WJ_E_HIP = -2,       /* HIP runtime error (message has the hipError string) */
+  WJ_E_NOMEM = -3,
+  WJ_E_STATE = -4,     /* call sequence error */
+  WJ_E_UNSUPPORTED = -5
+};
+
+enum { WJ_F32 = 0, WJ_BF16 = 1 };          /* compute/storage type of matrices & activations */
+enum { WJ_MEL_FW = 0, WJ_MEL_OW = 1 };     /* faster-whisper vs openai-whisper mel semantics */
+
+typedef struct wj_ctx wj_ctx;
+typedef struct wj_whisper wj_whisper;
+typedef struct wj_vad wj_vad;
+
+/* ---- context ------------------------------------------------------------------------- */
+int wj_abi_version(void);
+const char* wj_last_error(void);
+/* Replaces: device selection at whisperjav/utils/device_detector.py:84-157 (returns "cpu" on
+ * AMD today).  Creates a HIP context + stream on `device_ordinal`. */
+int wj_init(int device_ordinal, wj_ctx** out);
+int wj_shutdown(wj_ctx* ctx);
+int wj_sync(wj_ctx* ctx);
+/* device properties for roofline reporting: out[0]=CU count, out[1]=clock kHz, out[2]=HBM bytes (lo32), out[3]=(hi32) */
+int wj_device_info(wj_ctx* ctx, int64_t out[4]);
+
+/* ---- profiler --------------------------------------------------------------------------
+ * Kernel time per launch class, measured with hipEvent pairs recorded on the stream the kernels
+ * are launched on (used by bench.py for the live roofline figures).  While a profile is open the
+ * decode loop runs eagerly (events cannot be timed inside a captured graph). */
+int wj_profile_start(wj_ctx* ctx);
+int wj_profile_tags(void);
+const char* wj_profile_tag_name(int tag);
+int wj_profile_stop(wj_ctx* ctx, double* total_ms, int64_t* counts, int n_tags);
+
+/* ---- log-mel ---------------------------------------------------------------------------
+ * Replaces: faster_whisper.feature_extractor.FeatureExtractor.__call__ (entered from
+ * whisperjav/modules/faster_whisper_pro_asr.py:819) [WJ_MEL_FW] and
+ * whisper.audio.log_mel_spectrogram (entered from whisperjav/modules/whisper_pro_asr.py:433)
+ * [WJ_MEL_OW].
+ *
+ * Batched over `n_clips` clips resident in HBM: clip i is pcm_dev[offsets[i] .. offsets[i+1])
+ * (float32 mono 16 kHz; offsets is a HOST array of n_clips+1 sample offsets).
+ * Frames per clip: FW: (n+160)/160, OW: (n+480000)/160  (wj_logmel_frames()).
+ * out_dev receives float32 [n_clips][n_mels][out_frames]; frames past a clip's own count are
+ * filled with 0.0 (FW pad_or_trim semantics) / are real zero-audio frames (OW), frames beyond
+ * out_frames are dropped.  scratch is managed by the context. */
+int64_t wj_logmel_frames(int64_t n_samples, int mode);
+int wj_logmel_f32(wj_ctx* ctx, const float* pcm_dev, const int64_t* offsets_host, int n_clips,
+                  int n_mels, int mode, int out_frames, float* out_dev, void* stream);
+
+/* ---- Whisper model -------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+  int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} wj_whisper_dims;
+
+/* Canonical order of the offset table (byte offsets into the weight blob).  Matrices are
+ * [out,in] row-major in the model dtype; vectors are always float32.  Per-layer groups
+ * follow the globals: all encoder layers, then all decoder layers. */
+enum {
+  WJ_T_ENC_CONV1_W = 0, /* [d, 3*n_mels]  K index = tap*n_mels + c */
+  WJ_T_ENC_CONV1_B, WJ_T_ENC_CONV2_W /* [d, 3*d] */, WJ_T_ENC_CONV2_B,
+  WJ_T_ENC_POS /* f32 [n_audio_ctx, d] */, WJ_T_ENC_LNPOST_W, WJ_T_ENC_LNPOST_B,
+  WJ_T_DEC_TOK_EMB /* [n_vocab, d] */, WJ_T_DEC_POS /* f32 [n_text_ctx, d] */,
+  WJ_T_DEC_LN_W, WJ_T_DEC_LN_B,
+  WJ_T_N_GLOBAL
+};
+enum { /* per encoder layer */
+  WJ_TE_LN1_W = 0, WJ_TE_LN1_B, WJ_TE_QKV_W /* [3d,d] q;k;v */, WJ_TE_QKV_B, WJ_TE_OUT_W, WJ_TE_OUT_B,
+  WJ_TE_LN2_W, WJ_TE_LN2_B, WJ_TE_FC1_W, WJ_TE_FC1_B, WJ_TE_FC2_W, WJ_TE_FC2_B,
+  WJ_TE_N
+};
+enum { /* per decoder layer */
+  WJ_TD_LN1_W = 0, WJ_TD_LN1_B, WJ_TD_QKV_W, WJ_TD_QKV_B, WJ_TD_OUT_W, WJ_TD_OUT_B,
+  WJ_TD_LNX_W, WJ_TD_LNX_B, WJ_TD_CQ_W, WJ_TD_CQ_B, WJ_TD_CKV_W /* [2d,d] k;v */, WJ_TD_CKV_B,
+  WJ_TD_COUT_W, WJ_TD_COUT_B, WJ_TD_LN2_W, WJ_TD_LN2_B, WJ_TD_FC1_W, WJ_TD_FC1_B,
+  WJ_TD_FC2_W, WJ_TD_FC2_B,
+  WJ_TD_N
+};
+
+/* Replaces: faster_whisper.WhisperModel(...) (whisperjav/modules/faster_whisper_pro_asr.py:247-253)
+ * and whisper.load_model (whisperjav/modules/whisper_pro_asr.py:182).
+ * The blob stays owned by the caller (it is typically a torch uint8 tensor that was
+ * RCCL-broadcast to every rank); it must outlive the model.
+ * max_batch = windows resident at once (encoder outputs + cross K/V are kept for all of them);
+ * max_rows  = decode rows (windows x beams) the KV cache is sized for. */
+int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const void* blob_dev,
+                      int64_t blob_bytes, const int64_t* offsets_host, int n_offsets,
+                      int max_batch, int max_rows, wj_whisper** out);
+int wj_whisper_free(wj_whisper* m);
+int64_t wj_whisper_workspace_bytes(const wj_whisper* m);
+
+/* Replaces: ctranslate2 Whisper.encode / whisper.model.AudioEncoder.forward (+ the per-window
+ * cross-attention K/V projection the decoders cache).  mel_dev: float32 [batch][n_mels][3000]
+ * (the layout wj_logmel_f32 writes).  Results stay resident in the model (slots 0..batch-1).
+ * n_layers < 0 runs the full stack; 0..L-1 stops early WITHOUT the final LayerNorm (used by the
+ * layer-bisection parity tests).  enc_out_dev (optional, may be NULL): float32 [batch][1500][d]. */
+int wj_whisper_encode(wj_whisper* m, const float* mel_dev, int batch, int n_layers,
+                      float* enc_out_dev, void* stream);
+
+typedef struct {
+  int32_t max_new_tokens;         /* <= n_text_ctx/2 */
+  int32_t suppress_blank;         /* faster_whisper.py:292 / whisper DecodingOptions */
+  int32_t without_timestamps;
+  int32_t max_initial_timestamp_index; /* round(max_initial_timestamp / 0.02); <0 = none */
+  int32_t eot, no_timestamps, timestamp_begin, blank, no_speech;
+  const uint8_t* suppress_mask_dev;   /* [n_vocab] 1 = always suppressed (may be NULL) */
+} wj_decode_opts;
+
+/* Greedy decode, fully device resident (one host sync at the end; per-step launches are
+ * replayed from a hipGraph).  Replaces: ctranslate2 Whisper.generate(beam_size=1) /
+ * whisper.decoding.GreedyDecoder (temperature 0) for `batch` windows previously encoded.
+ * prompts_host: int32 [batch][prompt_len] (sot, language, task[, notimestamps]); all rows use
+ * the same prompt_len.  Outputs (HOST pointers): tokens_out [batch][max_new_tokens] (eot padded),
+ * n_tokens_out [batch] (count before eot), sum_logprob_out [batch], no_speech_prob_out [batch],
+ * token_logprob_out [batch][max_new_tokens] (optional, may be NULL). */
+int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_host, int prompt_len,
+                             const wj_decode_opts* opts, int32_t* tokens_out, int32_t* n_tokens_out,
+                             float* sum_logprob_out, float* no_speech_prob_out,
+                             float* token_logprob_out, void* stream);
+
+/* Step-wise decoder for host-driven search (beam search with CTranslate2's patience /
+ * repetition-penalty / no-repeat-ngram processors lives in whisperjav_amd/search.py).
+ * rows = batch*beam, row r belongs to window r / beam.
+ *   wj_decode_open : resets the KV cache for `rows` rows.
+ *   wj_decode_step : feeds one token per row (tokens_host[rows]) after re-binding each row's
+ *                    history to parent_host[r] (NULL = identity), and leaves float32 logits
+ *                    [rows][n_vocab] in the model's logits buffer (wj_decode_logits_dev).
+ *   wj_decode_topk : masked log-softmax + top-k per row on device.  ban_dev: uint8 [rows][n_vocab]
+ *                    or NULL; penal_*: optional repetition penalty lists.  Outputs on host. */
+int wj_decode_open(wj_whisper* m, int batch, int beam, void* stream);
+int wj_decode_step(wj_whisper* m, const int32_t* tokens_host, const int32_t* parent_host,
+                   int want_logits, void* stream);
+float* wj_decode_logits_dev(wj_whisper* m);
+/* compact copy of the last step's logits: dst_dev float32 [rows][n_vocab] */
+int wj_decode_logits_copy(wj_whisper* m, int rows, float* dst_dev, void* stream);
+int wj_decode_topk(wj_whisper* m, int rows, int k, const uint8_t* ban_dev,
+                   int32_t* ids_out_host, float* logprob_out_host, float* lse_out_host, void* stream);
+
+/* ---- VAD scorer -------------------------------------------------------------------------
+ * Replaces: the per-window forward of the silero-vad JIT model inside
+ * silero_vad.get_speech_timestamps (called at
+ * whisperjav/modules/speech_segmentation/backends/silero_v6.py:205-210 and silero.py:269-273).
+ * Architecture (silero-vad v5/v6, 16 kHz): 64-sample context + 512-sample chunk -> reflect pad
+ * 64 -> conv-STFT(256, hop 128) magnitude [129 x 4] -> 4 x (Conv1d k3 + ReLU) with strides
+ * 1,2,2,1 -> LSTM cell(128) -> ReLU -> Conv1d(128->1) -> sigmoid.  State resets per stream.
+ * weights_host: float32 blob in the order documented in whisperjav_amd/vad_weights.py. */
+int wj_vad_create(wj_ctx* ctx, const float* weights_host, int64_t n_floats, wj_vad** out);
+int wj_vad_free(wj_vad* v);
+/* Scores `n_streams` independent audio streams in lock-step (one wavefront per stream).
+ * Stream i = pcm_dev[offsets[i]..offsets[i+1]); probs_dev receives float32, stream i's
+ * ceil(n_i/512) window probabilities at probs_dev[prob_offsets[i] ...]. */
+int wj_vad_scores(wj_vad* v, const float* pcm_dev, const int64_t* offsets_host,
+                  const int64_t* prob_offsets_host, int n_streams, float* probs_dev, void* stream);
+
+/* ---- kernel-level entry points (parity tests and micro-benchmarks only) ----------------- */
+/* C[M,N] = A[M,K] . W[N,K]^T + bias, plain row-major output in `dtype` (out_f32=0) or float32. */
+int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev,
+              void* c_dev, int M, int N, int K, int act_gelu, int out_f32, int variant, void* stream);
+int wj_k_layernorm(wj_ctx* ctx, int dtype, const float* x_dev, const float* w_dev, const float* b_dev,
+                   void* out_dev, int M, int D, void* stream);
+/* encoder self-attention: qkv in the engine's head-split layouts built from a
+ * row-major float32 [B][T][3*D] tensor by the call itself. out: dtype [B][T][D]. */
+int wj_k_attention_enc(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, void* out_dev, int B, int T,
+                       int H, void* stream);
+/* decode attention over a K/V set shared by `nb` query rows: q float32 [G][nb][H*64],
+ * k,v float32 [G][H][n_keys][64]; out float32 [G][nb][H*64]. */
+int wj_k_attention_dec(wj_ctx* ctx, int dtype, const float* q_dev, const float* k_dev, const float* v_dev,
+                       float* out_dev, int G, int nb, int H, int n_keys, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WJHIP_H */

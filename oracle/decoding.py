@@ -1,0 +1,147 @@
+"""Oracle: Whisper token search on the CPU (TEST INFRASTRUCTURE, never shipped).
+
+Restates, over the fp32 ``whisper_ref`` model:
+
+  * the logit filters of openai-whisper 20250625 ``whisper/decoding.py`` -- ``SuppressBlank``,
+    ``SuppressTokens``, ``ApplyTimestampRules`` -- which CTranslate2 4.7.1 re-implements for
+    faster-whisper's ``WhisperModel.generate`` (reference call sites:
+    whisperjav/modules/faster_whisper_pro_asr.py:819, whisperjav/modules/whisper_pro_asr.py:433);
+  * greedy decoding (``GreedyDecoder`` at temperature 0 == CTranslate2 ``beam_size=1``):
+    log-softmax of the filtered logits, arg-max, cumulative log-probability that includes the
+    EOT token, ``avg_logprob = sum / (n_tokens + 1)``;
+  * CTranslate2-style beam search with patience / length penalty / repetition penalty /
+    no-repeat-ngram (``beam_search``), restated from the published algorithm
+    (CTranslate2 ``src/decoding.cc``).  PARITY UNPINNED: no upstream binary or golden vectors are
+    available offline, see DESIGN.md.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .whisper_ref import CachedDecoder, WhisperOracle
+
+NEG_INF = float("-inf")
+
+
+@dataclass
+class TokenLayout:
+    eot: int
+    sot: int
+    no_speech: int
+    no_timestamps: int
+    timestamp_begin: int
+    blank: int = 220
+
+    @staticmethod
+    def for_vocab(n_vocab: int) -> "TokenLayout":
+        num_lang = n_vocab - 51765 - 1
+        sot = 50258
+        translate = sot + 1 + num_lang
+        return TokenLayout(eot=50257, sot=sot, no_speech=translate + 4, no_timestamps=translate + 5,
+                           timestamp_begin=translate + 6)
+
+
+@dataclass
+class FilterConfig:
+    suppress_blank: bool = True
+    suppress_tokens: Sequence[int] = field(default_factory=tuple)
+    without_timestamps: bool = False
+    max_initial_timestamp_index: Optional[int] = 50   # 1.0 s / 0.02
+
+
+def filter_logits(logits: torch.Tensor, history: Sequence[Sequence[int]], sample_begin: int,
+                  lay: TokenLayout, cfg: FilterConfig) -> torch.Tensor:
+    """Apply Whisper's filters to ``logits`` [R, V]; ``history[r]`` is row r's full token list."""
+    out = logits.clone().float()
+    tb = lay.timestamp_begin
+    for r, toks in enumerate(history):
+        sampled = list(toks[sample_begin:])
+        row = out[r]
+        if cfg.suppress_blank and not sampled:
+            row[lay.blank] = NEG_INF
+            row[lay.eot] = NEG_INF
+        if len(cfg.suppress_tokens):
+            row[list(cfg.suppress_tokens)] = NEG_INF
+        if cfg.without_timestamps:
+            continue
+        row[lay.no_timestamps] = NEG_INF
+        last_ts = len(sampled) >= 1 and sampled[-1] >= tb
+        penult_ts = len(sampled) < 2 or sampled[-2] >= tb
+        if last_ts:
+            if penult_ts:
+                row[tb:] = NEG_INF          # pair closed: no third timestamp
+            else:
+                row[:lay.eot] = NEG_INF     # pair open: text is not allowed
+        stamps = [t for t in sampled if t >= tb]
+        if stamps:
+            floor = stamps[-1] if (last_ts and not penult_ts) else stamps[-1] + 1
+            row[tb:floor] = NEG_INF
+        if not sampled:
+            row[:tb] = NEG_INF
+            if cfg.max_initial_timestamp_index is not None:
+                row[tb + cfg.max_initial_timestamp_index + 1:] = NEG_INF
+        lp = torch.log_softmax(row, dim=-1)
+        if torch.logsumexp(lp[tb:], dim=-1) > lp[:tb].max():
+            row[:tb] = NEG_INF
+    return out
+
+
+@dataclass
+class GreedyOut:
+    tokens: List[List[int]]
+    sum_logprob: np.ndarray
+    token_logprob: List[List[float]]
+    no_speech_prob: np.ndarray
+
+    def avg_logprob(self) -> np.ndarray:
+        return np.array([s / (len(t) + 1) for s, t in zip(self.sum_logprob, self.tokens)], dtype=np.float32)
+
+
+def greedy_decode(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], max_new_tokens: int,
+                  cfg: Optional[FilterConfig] = None, forced: Optional[Sequence[Sequence[int]]] = None) -> GreedyOut:
+    """Greedy decode every window of ``xa`` [B, T, D].  ``forced`` (teacher forcing) feeds the given
+    tokens instead of the arg-max while still reporting what the model would have scored them."""
+    cfg = cfg or FilterConfig()
+    lay = TokenLayout.for_vocab(model.dims.n_vocab)
+    B = xa.shape[0]
+    P = len(prompt)
+    dec = CachedDecoder(model, xa)
+    hist = [list(prompt) for _ in range(B)]
+    done = [False] * B
+    sums = np.zeros(B, dtype=np.float64)
+    tlp: List[List[float]] = [[] for _ in range(B)]
+    nsp = np.zeros(B, dtype=np.float32)
+    with torch.no_grad():
+        logits = None
+        for p in range(P):
+            logits = dec.step(torch.tensor([[h[p]] for h in hist]))
+            if p == 0:
+                nsp = torch.softmax(logits.float(), dim=-1)[:, lay.no_speech].numpy().astype(np.float32)
+        for i in range(max_new_tokens):
+            filt = filter_logits(logits, hist, P, lay, cfg)
+            lp = torch.log_softmax(filt, dim=-1)
+            nxt = lp.argmax(dim=-1).tolist()
+            for r in range(B):
+                if done[r]:
+                    hist[r].append(lay.eot)
+                    continue
+                tok = nxt[r] if forced is None else int(forced[r][i]) if i < len(forced[r]) else lay.eot
+                sums[r] += float(lp[r, tok])
+                tlp[r].append(float(lp[r, tok]))
+                hist[r].append(tok)
+                if tok == lay.eot:
+                    done[r] = True
+            if all(done) or i + 1 == max_new_tokens:
+                break
+            logits = dec.step(torch.tensor([[h[-1]] for h in hist]))
+    toks = []
+    for r in range(B):
+        seq = hist[r][P:]
+        if lay.eot in seq:
+            seq = seq[:seq.index(lay.eot)]
+        toks.append(seq)
+    return GreedyOut(toks, sums.astype(np.float32), tlp, nsp)

@@ -1,0 +1,86 @@
+"""Generate the committed golden vectors (run in the build container, CPU only):
+
+    python tests/golden/make_golden.py [--large]
+
+The upstream wheels that implement this path (faster-whisper / ctranslate2 / openai-whisper) are not
+installable offline and the reference's tests pin no numeric value at this boundary,
+so the vectors are produced by the CPU oracle -- itself pinned against transformers' independent
+Whisper / feature-extractor implementations (tests/test_oracle_*.py) -- on seeded synthetic weights
+and audio that both sides can regenerate bit-identically:
+
+  * golden_small.npz    : 2-layer d=128 model, fp32 oracle: mel, encoder probes, greedy tokens/log-probs
+  * golden_large_v3.npz : the BASELINE cfg2 geometry (large-v3: 128 mels, d=1280, 32+32 layers,
+                          vocab 51866), one 30 s window of synthetic speech: encoder probes and
+                          the first greedy tokens with their log-probs (timestamps on)
+  * golden_logmel.npz   : log-mel probes of the synthetic clip under both upstream semantics
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import decoding, logmel, whisper_ref  # noqa: E402
+from tests import helpers  # noqa: E402
+from whisperjav_amd import dims as pdims, synth, weights as pweights  # noqa: E402
+
+PROBE_T = np.array([0, 1, 7, 311, 749, 1200, 1499])
+PROBE_D = np.array([0, 1, 5, 63, 64, 100, 127])
+
+
+def probes(enc: torch.Tensor) -> np.ndarray:
+    d = enc.shape[-1]
+    cols = np.unique(np.minimum(np.concatenate([PROBE_D, [d // 2, d - 1]]), d - 1))
+    return enc[0][PROBE_T][:, cols].numpy(), cols
+
+
+def run(dims: pdims.WhisperDims, seed: int, n_new: int, out_name: str, mel: np.ndarray):
+    t0 = time.time()
+    w = pweights.synth_weights(dims, seed=seed)
+    oracle = whisper_ref.WhisperOracle(helpers.oracle_dims(dims), w)
+    print(f"[{out_name}] weights {time.time() - t0:.1f}s", flush=True)
+    lay = decoding.TokenLayout.for_vocab(dims.n_vocab)
+    toks = pdims.special_tokens(dims.n_vocab)
+    prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
+    suppress = (1, 2, 7, 8, 9, 10, 14, 25, toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev,
+                toks.no_speech)
+    cfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=50)
+    with torch.no_grad():
+        t0 = time.time()
+        enc = oracle.encode(torch.from_numpy(mel))
+        print(f"[{out_name}] encode {time.time() - t0:.1f}s", flush=True)
+        t0 = time.time()
+        res = decoding.greedy_decode(oracle, enc, prompt, n_new, cfg)
+        print(f"[{out_name}] decode {time.time() - t0:.1f}s", flush=True)
+    pv, cols = probes(enc)
+    np.savez_compressed(
+        os.path.join(HERE, out_name), seed=seed, dims=np.array(list(dims.as_dict().values())),
+        prompt=np.array(prompt), suppress=np.array(suppress), tokens=np.array(res.tokens[0]),
+        token_logprob=np.array(res.token_logprob[0], dtype=np.float32), sum_logprob=res.sum_logprob,
+        no_speech_prob=res.no_speech_prob, enc_probe=pv.astype(np.float32), probe_t=PROBE_T, probe_d=cols,
+        enc_mean=np.float32(enc.mean()), enc_abs_mean=np.float32(enc.abs().mean()), eot=lay.eot)
+    print(f"[{out_name}] tokens {res.tokens[0]} lp {np.round(res.token_logprob[0], 4)}")
+
+
+def main():
+    audio = synth.speech_like(30.0, seed=1234)
+    fw128 = logmel.window_features(audio, 128, "fw")
+    fw80 = logmel.window_features(audio, 80, "fw")
+    ow128 = logmel.window_features(audio[: 16000 * 11], 128, "ow")
+    cols = np.array([0, 1, 2, 100, 1000, 1099, 1100, 1101, 1500, 2998, 2999])
+    np.savez_compressed(os.path.join(HERE, "golden_logmel.npz"), cols=cols, fw128=fw128[:, cols], fw80=fw80[:, cols],
+                        ow128=ow128[:, cols], fw128_sum=np.float64(fw128.astype(np.float64).sum()),
+                        frames_fw=np.int64(logmel.logmel_fw(audio, 128).shape[1]))
+    small = helpers.small_dims()
+    run(small, 21, 24, "golden_small.npz", fw80[None])
+    if "--large" in sys.argv:
+        run(pdims.dims_for("large-v3"), 1234, 16, "golden_large_v3.npz", fw128[None])
+
+
+if __name__ == "__main__":
+    main()

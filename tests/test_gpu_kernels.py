@@ -1,0 +1,137 @@
+"""Kernel-level parity on a real MI355X: every HIP kernel family against a plain PyTorch-CPU fp32
+restatement of the same op, through the C ABI (wj_k_* entry points).  Inputs are asymmetric random
+matrices so operand / fragment transposes cannot cancel out."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DIAG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _diag(name, payload):
+    os.makedirs(DIAG, exist_ok=True)
+    with open(os.path.join(DIAG, "diag_kernels.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **payload}) + "\n")
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _stats(got, ref):
+    d = (got - ref).abs()
+    return {"max_abs": float(d.max()), "mean_abs": float(d.mean()), "ref_rms": float(ref.pow(2).mean().sqrt())}
+
+
+GEMM_SHAPES = [
+    (300, 256, 128),     # M tail
+    (1500, 384, 240),    # K tail (240 = 3.75 x 64) like conv1 at 80 mels
+    (130, 136, 72),      # everything ragged
+    (64, 1280, 1280),    # decode-sized
+    (5, 1003, 128),      # N not a multiple of 4 (logits path, f32 out)
+    (320, 512, 640),     # beam-sized M
+]
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm(hip, dtype, shape, variant):
+    from whisperjav_amd import engine
+    M, N, K = shape
+    if dtype == "float32" and variant == 2:
+        pytest.skip("the fp32 compute type has a single GEMM kernel")
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.3 + 0.05
+    bias = torch.randn(N, generator=g)
+    out_f32 = (N % 4) != 0
+    if dtype == "bfloat16":
+        a, w = _bf(a), _bf(w)
+    ref = a @ w.T + bias
+    got = engine.k_gemm(a.cuda(), w.cuda(), bias.cuda(), dtype, out_f32=out_f32, variant=variant).cpu()
+    st = _stats(got, ref)
+    _diag("gemm", {"dtype": dtype, "shape": shape, "variant": variant, **st})
+    if dtype == "float32" or out_f32:
+        assert torch.allclose(got, ref, atol=2e-3, rtol=1e-4), st
+    else:  # bf16 output rounding: 2^-8 relative
+        assert torch.allclose(got, ref, atol=2e-2, rtol=8e-3), st
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_gemm_gelu(hip, dtype):
+    from whisperjav_amd import engine
+    g = torch.Generator().manual_seed(5)
+    a, w, bias = torch.randn(200, 96, generator=g), torch.randn(160, 96, generator=g) * 0.2, torch.randn(160, generator=g)
+    if dtype == "bfloat16":
+        a, w = _bf(a), _bf(w)
+    ref = torch.nn.functional.gelu(a @ w.T + bias)
+    got = engine.k_gemm(a.cuda(), w.cuda(), bias.cuda(), dtype, gelu=True, variant=1).cpu()
+    tol = dict(atol=1e-4, rtol=1e-4) if dtype == "float32" else dict(atol=2e-2, rtol=8e-3)
+    assert torch.allclose(got, ref, **tol), _stats(got, ref)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("D", [128, 384, 1280])
+def test_layernorm(hip, dtype, D):
+    from whisperjav_amd import engine
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(37, D, generator=g) * 3 + 0.5
+    w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
+    got = engine.k_layernorm(x.cuda(), w.cuda(), b.cuda(), dtype).cpu()
+    tol = dict(atol=2e-5, rtol=1e-5) if dtype == "float32" else dict(atol=3e-2, rtol=8e-3)
+    assert torch.allclose(got, ref, **tol), _stats(got, ref)
+
+
+def _attn_ref(q, k, v, heads):
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    qh = q.view(B, Tq, heads, 64).permute(0, 2, 1, 3)
+    kh = k.view(B, Tk, heads, 64).permute(0, 2, 1, 3)
+    vh = v.view(B, Tk, heads, 64).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, dim=-1)
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B, Tq, D)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("B,T,H", [(2, 200, 2), (1, 1500, 3), (1, 129, 1)])
+def test_attention_encoder(hip, dtype, B, T, H):
+    from whisperjav_amd import engine
+    g = torch.Generator().manual_seed(T + H)
+    qkv = torch.randn(B, T, 3 * H * 64, generator=g)
+    qkv[..., : H * 64] *= 1.5   # sharper softmax
+    if dtype == "bfloat16":
+        qkv = _bf(qkv)
+    D = H * 64
+    ref = _attn_ref(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], H)
+    got = engine.k_attention_enc(qkv.cuda(), H, dtype).cpu()
+    st = _stats(got, ref)
+    _diag("attention_enc", {"dtype": dtype, "B": B, "T": T, "H": H, **st})
+    tol = dict(atol=2e-5, rtol=1e-4) if dtype == "float32" else dict(atol=2e-2, rtol=2e-2)
+    assert torch.allclose(got, ref, **tol), st
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("G,nb,H,n_keys", [(3, 1, 2, 1500), (2, 5, 2, 1500), (4, 1, 3, 37), (1, 8, 1, 5)])
+def test_attention_decode(hip, dtype, G, nb, H, n_keys):
+    from whisperjav_amd import engine
+    g = torch.Generator().manual_seed(G * 100 + nb * 10 + n_keys)
+    q = torch.randn(G, nb, H * 64, generator=g) * 1.5
+    k = torch.randn(G, H, n_keys, 64, generator=g)
+    v = torch.randn(G, H, n_keys, 64, generator=g)
+    if dtype == "bfloat16":
+        q, k, v = _bf(q), _bf(k), _bf(v)
+    qh = q.view(G, nb, H, 64).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ k.transpose(-1, -2) * 0.125, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(G, nb, H * 64)
+    got = engine.k_attention_dec(q.cuda(), k.cuda(), v.cuda(), dtype).cpu()
+    st = _stats(got, ref)
+    _diag("attention_dec", {"dtype": dtype, "G": G, "nb": nb, "n_keys": n_keys, **st})
+    tol = dict(atol=2e-5, rtol=1e-4) if dtype == "float32" else dict(atol=1e-2, rtol=8e-3)
+    assert torch.allclose(got, ref, **tol), st

@@ -1,0 +1,403 @@
+// attention.hip -- encoder self-attention (flash style, MFMA bf16 / exact fp32) and decode-step
+// attention (HBM-bound streaming of K/V shared by the beams of one window).
+//
+// Encoder layouts (written by the QKV GEMM epilogues, see gemm.hip):
+//   Q, K : [B][H][Tpad][64]     Vt : [B][H][64][Tpad]     Tpad = round_up(T, 64), pad = zeros
+// bf16 kernel, per workgroup = 128 query rows of one (b, h), 4 waves x 32 rows:
+//   S^T = K . Q^T   (A = K fragment with a permuted key order, B = Q fragment held in VGPRs)
+//   so that after the MFMA a lane already holds, for ITS query column, 8 *consecutive* keys per
+//   32-key step -- exactly the B operand of  O^T += Vt . P^T  with no cross-lane movement, and
+//   the online-softmax statistics (m, l, alpha) are lane-local per query.
+#include "kernels.hpp"
+
+namespace wj {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ int aswz(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) << 3); }
+
+__global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                            const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
+                                                            int T, int Tpad, int H) {
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * 64 * 64];  // [buf][K|Vt][64][64] = 32 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int64_t bh = (int64_t)b * H + h;
+  const bf16_t* Qp = Q + bh * Tpad * 64;
+  const bf16_t* Kp = K + bh * Tpad * 64;
+  const bf16_t* Vp = Vt + bh * 64 * Tpad;
+
+  bf16x8_t qf[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[f][ks] = *reinterpret_cast<const bf16x8_t*>(Qp + (int64_t)(q0 + f * 16 + li) * 64 + ks * 32 + lg * 8);
+
+  f32x4_t o[2][4];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    m_run[f] = -INFINITY;
+    l_run[f] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[f][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int nt = Tpad / 64;
+  uint4 rk0, rk1, rv0, rv1;  // individually named: an indexed array would live in scratch
+#define WJ_ALOAD1(i, kt)                                                                          \
+  {                                                                                               \
+    const int idx = tid + (i) * 256;                                                              \
+    const int row = idx >> 3, ch = idx & 7;                                                       \
+    rk##i = *reinterpret_cast<const uint4*>(Kp + (int64_t)((kt) * 64 + row) * 64 + ch * 8);       \
+    rv##i = *reinterpret_cast<const uint4*>(Vp + (int64_t)row * Tpad + (kt) * 64 + ch * 8);       \
+  }
+#define WJ_ALOAD(kt) WJ_ALOAD1(0, kt) WJ_ALOAD1(1, kt)
+#define WJ_ASTORE1(i, buf)                                                                        \
+  {                                                                                               \
+    const int idx = tid + (i) * 256;                                                              \
+    const int row = idx >> 3, ch = idx & 7;                                                       \
+    *reinterpret_cast<uint4*>(&lds[((buf) * 2 + 0) * 4096 + aswz(row, ch)]) = rk##i;              \
+    *reinterpret_cast<uint4*>(&lds[((buf) * 2 + 1) * 4096 + aswz(row, ch)]) = rv##i;              \
+  }
+#define WJ_ASTORE(buf) WJ_ASTORE1(0, buf) WJ_ASTORE1(1, buf)
+
+  WJ_ALOAD(0)
+  WJ_ASTORE(0)
+  __syncthreads();
+
+  for (int kt = 0; kt < nt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nt) { WJ_ALOAD(kt + 1) }
+    const bf16_t* lk = &lds[(cur * 2 + 0) * 4096];
+    const bf16_t* lv = &lds[(cur * 2 + 1) * 4096];
+
+    // ---- S^T = K . Q^T for 4 blocks of 16 (permuted) keys ----
+    f32x4_t st[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      // A-operand row li of block kb is key  32*(kb>>1) + 8*(li>>2) + 4*(kb&1) + (li&3)
+      const int krow = 32 * (kb >> 1) + 8 * (li >> 2) + 4 * (kb & 1) + (li & 3);
+      st[0][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      st[1][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&lk[aswz(krow, ks * 4 + lg)]);
+        st[0][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], st[0][kb], 0, 0, 0);
+        st[1][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], st[1][kb], 0, 0, 0);
+      }
+    }
+    // lane (q = li, lg) now holds, for block kb, keys  kt*64 + 32*(kb>>1) + 8*lg + 4*(kb&1) + r
+    bf16x8_t pf[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 64 + 32 * (kb >> 1) + 8 * lg + 4 * (kb & 1) + r;
+          const float s = key < T ? st[f][kb][r] * 0.125f : -INFINITY;
+          st[f][kb][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[f], mx);
+      const float alpha = __expf(m_run[f] - m_new);
+      m_run[f] = m_new;
+      float psum = 0.f;
+      float p[4][4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[kb][r] = __expf(st[f][kb][r] - m_new);
+          psum += p[kb][r];
+        }
+      l_run[f] = l_run[f] * alpha + psum;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[f][d][r] *= alpha;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8_t v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = (__bf16)p[2 * s2][r];
+          v[4 + r] = (__bf16)p[2 * s2 + 1][r];
+        }
+        pf[f][s2] = v;
+      }
+    }
+    // ---- O^T += Vt . P^T ----
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(&lv[aswz(d * 16 + li, s2 * 4 + lg)]);
+        o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][s2], o[0][d], 0, 0, 0);
+        o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][s2], o[1][d], 0, 0, 0);
+      }
+    if (kt + 1 < nt) { WJ_ASTORE(cur ^ 1) }
+    __syncthreads();
+  }
+#undef WJ_ALOAD
+#undef WJ_ASTORE
+#undef WJ_ALOAD1
+#undef WJ_ASTORE1
+
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    float l = l_run[f];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int t = q0 + f * 16 + li;
+    if (t < T) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        float v[4] = {o[f][d][0] * inv, o[f][d][1] * inv, o[f][d][2] * inv, o[f][d][3] * inv};
+        st4(out + ((int64_t)b * T + t) * (H * 64) + h * 64 + d * 16 + lg * 4, v);
+      }
+    }
+  }
+}
+
+// Exact fp32 encoder attention: one query row per lane, K / Vt tiles broadcast from LDS.
+__global__ __launch_bounds__(64) void attn_enc_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                          const float* __restrict__ Vt, float* __restrict__ out, int T,
+                                                          int Tpad, int H) {
+  __shared__ __attribute__((aligned(16))) float ks[32][64];
+  __shared__ __attribute__((aligned(16))) float vs[64][32];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int t = blockIdx.x * 64 + lane;
+  const int64_t bh = (int64_t)b * H + h;
+  const float* Qp = Q + bh * Tpad * 64;
+  const float* Kp = K + bh * Tpad * 64;
+  const float* Vp = Vt + bh * 64 * Tpad;
+  float q[64], o[64];
+#pragma unroll
+  for (int d = 0; d < 64; d += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(Qp + (int64_t)t * 64 + d);
+    q[d] = v.x * 0.125f; q[d + 1] = v.y * 0.125f; q[d + 2] = v.z * 0.125f; q[d + 3] = v.w * 0.125f;
+    o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < T; k0 += 32) {
+    __syncthreads();
+    for (int i = lane; i < 32 * 16; i += 64) {  // K tile: 32 keys x 64 dims, float4 granules
+      const int r = i >> 4, c4 = (i & 15) * 4;
+      *reinterpret_cast<float4*>(&ks[r][c4]) = *reinterpret_cast<const float4*>(Kp + (int64_t)(k0 + r) * 64 + c4);
+    }
+    for (int i = lane; i < 64 * 8; i += 64) {   // Vt tile: 64 dims x 32 keys
+      const int r = i >> 3, c4 = (i & 7) * 4;
+      *reinterpret_cast<float4*>(&vs[r][c4]) = *reinterpret_cast<const float4*>(Vp + (int64_t)r * Tpad + k0 + c4);
+    }
+    __syncthreads();
+    const int kn = min(32, T - k0);
+    for (int j = 0; j < kn; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) s = fmaf(q[d], ks[j][d], s);
+      const float m_new = fmaxf(m, s);
+      const float alpha = expf(m - m_new);
+      const float p = expf(s - m_new);
+      l = l * alpha + p;
+      m = m_new;
+#pragma unroll
+      for (int d = 0; d < 64; ++d) o[d] = fmaf(p, vs[d][j], o[d] * alpha);
+    }
+  }
+  if (t < T) {
+    const float inv = 1.0f / l;
+    float* op = out + ((int64_t)b * T + t) * (H * 64) + h * 64;
+#pragma unroll
+    for (int d = 0; d < 64; d += 4)
+      *reinterpret_cast<float4*>(op + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+  }
+}
+
+int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt, void* out, int B, int T, int Tpad,
+                         int H, hipStream_t s) {
+  if (Tpad % 128 || Tpad < T) { set_error("attention_enc: Tpad must be a multiple of 128 and >= T"); return WJ_E_INVALID; }
+  if (dtype == WJ_F32) {
+    dim3 grid(Tpad / 64, H, B);
+    hipLaunchKernelGGL(attn_enc_f32_kernel, grid, dim3(64), 0, s, (const float*)Q, (const float*)K, (const float*)Vt,
+                       (float*)out, T, Tpad, H);
+  } else {
+    dim3 grid(Tpad / 128, H, B);
+    hipLaunchKernelGGL(attn_enc_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)Vt, (bf16_t*)out, T, Tpad, H);
+  }
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// decode-step attention: NB query rows (the beams of one window, or 1 row for self-attention)
+// share one K/V set; HBM-bound.  lane = (key-in-octet kk, 8-wide feature chunk c): a wave reads
+// 8 keys x 128 B = 1 KiB per instruction, fully coalesced.  Two passes (scores -> LDS, exact
+// max; then exp / P.V), fp32 throughout.
+// --------------------------------------------------------------------------------------------
+template <typename T, int NB, int NW, bool SELF>
+__global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 3, c = lane & 7;
+  const int h = blockIdx.x, gi = blockIdx.y;
+  const int n_keys = a.n_keys_ptr ? (*a.n_keys_ptr + 1) : a.n_keys;
+  const int kpad = (n_keys + 7) & ~7;
+  float* sc = smem;                         // [NB][kpad]
+  float* red_m = sc + NB * kpad;            // [NW][NB]
+  float* red_l = red_m + NW * NB;           // [NW][NB]
+  float* red_o = red_l + NW * NB;           // [NW][NB][64]
+  const int D = a.H * 64;
+  const T* Kb = reinterpret_cast<const T*>(a.K);
+  const T* Vb = reinterpret_cast<const T*>(a.V);
+  const int grp = (!SELF && a.group_of) ? a.group_of[gi] : gi;
+  const int32_t* rmap = (SELF && a.row_map) ? a.row_map + (int64_t)gi * a.kv_stride : nullptr;
+
+  float qf[NB][8];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    ld8(reinterpret_cast<const T*>(a.q) + (int64_t)(gi * NB + b) * D + h * 64 + c * 8, qf[b]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[b][e] *= 0.125f;
+  }
+
+  float lmax[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) lmax[b] = -INFINITY;
+
+  for (int j0 = wave * 8; j0 < n_keys; j0 += NW * 8) {
+    const int j = j0 + kk;
+    const bool valid = j < n_keys;
+    float kv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      const int64_t prow = SELF ? (rmap ? rmap[j] : gi) : grp;
+      ld8(Kb + ((prow * a.H + h) * a.kv_stride + j) * 64 + c * 8, kv);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = fmaf(qf[b][e], kv[e], s);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      if (valid) {
+        if (c == 0) sc[b * kpad + j] = s;
+        lmax[b] = fmaxf(lmax[b], s);
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float v = lmax[b];
+    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    if (lane == 0) red_m[wave * NB + b] = v;
+  }
+  __syncthreads();
+  float mx[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float v = red_m[b];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v = fmaxf(v, red_m[w * NB + b]);
+    mx[b] = v;
+  }
+
+  float lsum[NB], o[NB][8];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    lsum[b] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[b][e] = 0.f;
+  }
+  for (int j0 = wave * 8; j0 < n_keys; j0 += NW * 8) {
+    const int j = j0 + kk;
+    if (j < n_keys) {
+      const int64_t prow = SELF ? (rmap ? rmap[j] : gi) : grp;
+      float vv[8];
+      ld8(Vb + ((prow * a.H + h) * a.kv_stride + j) * 64 + c * 8, vv);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float p = expf(sc[b * kpad + j] - mx[b]);
+        lsum[b] += p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[b][e] = fmaf(p, vv[e], o[b][e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float l = lsum[b];
+    l += __shfl_xor(l, 8, 64);
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = o[b][e];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (kk == 0) red_o[(wave * NB + b) * 64 + c * 8 + e] = v;
+    }
+    if (lane == 0) red_l[wave * NB + b] = l;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < NB * 64; idx += NW * 64) {
+    const int b = idx >> 6, d = idx & 63;
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      num += red_o[(w * NB + b) * 64 + d];
+      den += red_l[w * NB + b];
+    }
+    Elem<T>::st(reinterpret_cast<T*>(a.out) + (int64_t)(gi * NB + b) * D + h * 64 + d, num / den);
+  }
+}
+
+template <typename T, int NB, int NW, bool SELF>
+static int launch_dec_inst(const DecAttnArgs& a, int kmax, hipStream_t s) {
+  const int kpad = (kmax + 7) & ~7;
+  const size_t smem = sizeof(float) * ((size_t)NB * kpad + 2 * NW * NB + (size_t)NW * NB * 64);
+  hipLaunchKernelGGL((attn_dec_kernel<T, NB, NW, SELF>), dim3(a.H, a.G), dim3(NW * 64), smem, s, a);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+template <typename T>
+static int launch_dec_T(const DecAttnArgs& a, hipStream_t s) {
+  const bool self = a.n_keys_ptr != nullptr;
+  if (self) {
+    if (a.nb != 1) { set_error("attention_dec: self attention expects nb == 1"); return WJ_E_INVALID; }
+    return launch_dec_inst<T, 1, 1, true>(a, a.kv_stride, s);
+  }
+  switch (a.nb) {
+    case 1: return launch_dec_inst<T, 1, 4, false>(a, a.n_keys, s);
+    case 2: return launch_dec_inst<T, 2, 4, false>(a, a.n_keys, s);
+    case 3: return launch_dec_inst<T, 3, 4, false>(a, a.n_keys, s);
+    case 4: return launch_dec_inst<T, 4, 4, false>(a, a.n_keys, s);
+    case 5: return launch_dec_inst<T, 5, 4, false>(a, a.n_keys, s);
+    case 6: return launch_dec_inst<T, 6, 4, false>(a, a.n_keys, s);
+    case 8: return launch_dec_inst<T, 8, 4, false>(a, a.n_keys, s);
+    default: set_error("attention_dec: unsupported beam count %d (1-6, 8)", a.nb); return WJ_E_INVALID;
+  }
+}
+
+int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s) {
+  if (a.G <= 0) return WJ_OK;
+  return dtype == WJ_F32 ? launch_dec_T<float>(a, s) : launch_dec_T<bf16_t>(a, s);
+}
+
+}  // namespace wj

@@ -1,0 +1,785 @@
+// engine.hip -- host-side runtime of libwjhip: context, Whisper model object (weights view,
+// HBM-resident workspaces, KV caches), encoder / decoder launch sequences, hipGraph-replayed greedy
+// decode loop, and the C ABI declared in include/wjhip.h.
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace wj {
+static thread_local char g_err[1024] = {0};
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+}  // namespace wj
+
+using namespace wj;
+
+struct wj_profiler {
+  struct Pair { int tag; hipEvent_t a, b; };
+  std::vector<Pair> pairs;
+  int open_tag = -1;
+  hipEvent_t open_a = nullptr;
+};
+static const char* kProfNames[PT_COUNT] = {
+    "mel_to_rows", "conv1_gemm", "conv2_gemm", "enc_layernorm", "enc_qk_gemm", "enc_v_gemm", "enc_attention",
+    "enc_out_gemm", "enc_fc1_gemm", "enc_fc2_gemm", "cross_kv_gemm", "dec_embed", "dec_layernorm", "dec_qkv_gemm",
+    "dec_self_attn", "dec_out_gemm", "dec_cq_gemm", "dec_cross_attn", "dec_cout_gemm", "dec_fc1_gemm", "dec_fc2_gemm",
+    "dec_logits_gemm", "dec_sample", "dec_misc"};
+namespace wj {
+void prof_begin(wj_ctx* ctx, int tag, hipStream_t s) {
+  wj_profiler* p = ctx->prof;
+  if (!p) return;
+  hipEvent_t a = nullptr;
+  if (hipEventCreate(&a) != hipSuccess) return;
+  (void)hipEventRecord(a, s);
+  p->open_tag = tag;
+  p->open_a = a;
+}
+void prof_end(wj_ctx* ctx, hipStream_t s) {
+  wj_profiler* p = ctx->prof;
+  if (!p || p->open_tag < 0) return;
+  hipEvent_t b = nullptr;
+  if (hipEventCreate(&b) != hipSuccess) return;
+  (void)hipEventRecord(b, s);
+  p->pairs.push_back({p->open_tag, p->open_a, b});
+  p->open_tag = -1;
+}
+}  // namespace wj
+#define PROF(tag, call)                 \
+  do {                                  \
+    prof_begin(m->ctx, (tag), s);       \
+    int _prc = (call);                  \
+    prof_end(m->ctx, s);                \
+    if (_prc) return _prc;              \
+  } while (0)
+
+int wj_ctx::ensure_scratch(size_t bytes) {
+  if (bytes <= scratch_bytes) return WJ_OK;
+  if (scratch) {
+    WJ_HIP(hipStreamSynchronize(stream));
+    WJ_HIP(hipFree(scratch));
+    scratch = nullptr;
+    scratch_bytes = 0;
+  }
+  const size_t want = align_up(bytes, (size_t)1 << 20);
+  WJ_HIP(hipMalloc(&scratch, want));
+  scratch_bytes = want;
+  return WJ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model object
+// ------------------------------------------------------------------------------------------------
+struct wj_whisper {
+  wj_ctx* ctx = nullptr;
+  wj_whisper_dims d{};
+  int dtype = WJ_BF16;
+  size_t esz = 2;
+  const char* blob = nullptr;
+  std::vector<int64_t> off;
+  int max_batch = 0, max_rows = 0;
+  int Tpad = 0;      // encoder positions padded to a multiple of 128
+  int frames = 0;    // 2 * n_audio_ctx
+  std::vector<void*> allocs;
+  size_t alloc_bytes = 0;
+
+  // encoder workspaces (all windows of a batch at once; 288 GB of HBM make chunking unnecessary)
+  void* mel_rows = nullptr;   // T   [B][frames+2][n_mels]
+  void* conv1_out = nullptr;  // T   [B][frames+2][d]
+  float* x = nullptr;         // f32 [B][ctx][d]        residual stream
+  void* h = nullptr;          // T   [B*ctx][d]         LayerNorm output / encoder output
+  void* q = nullptr;          // T   [B][H][Tpad][64]
+  void* k = nullptr;          // T   [B][H][Tpad][64]
+  void* vt = nullptr;         // T   [B][H][64][Tpad]
+  void* attn = nullptr;       // T   [B*ctx][d]
+  void* ff = nullptr;         // T   [B*ctx][4d]
+  // per-window state kept for decoding
+  void* cross_k = nullptr;    // T   [L][max_batch][H][ctx][64]
+  void* cross_v = nullptr;
+  // decoder workspaces
+  float* dx = nullptr;        // f32 [R][d]
+  void* dh = nullptr;         // T   [R][d]
+  void* dq = nullptr;         // T   [R][d]
+  void* dattn = nullptr;      // T   [R][d]
+  void* dff = nullptr;        // T   [R][4d]
+  float* logits = nullptr;    // f32 [R][ldl]
+  int64_t ldl = 0;
+  void* self_k = nullptr;     // T   [L][max_rows][H][n_text_ctx][64]
+  void* self_v = nullptr;
+  int32_t* tokens = nullptr;  // [max_rows][tok_stride]
+  int64_t tok_stride = 0;
+  int* pos = nullptr;         // device scalar: index of the token being fed
+  float* sum_lp = nullptr;    // [R]
+  float* tok_lp = nullptr;    // [R][tok_stride]
+  int32_t* finished = nullptr;
+  float* nsp = nullptr;       // [R] no-speech probability
+  int32_t* row_map[2] = {nullptr, nullptr};  // [max_rows][n_text_ctx]
+  int cur_map = 0;
+  int32_t* parent = nullptr;  // [R]
+  int32_t* step_tok = nullptr;  // [R] staging for wj_decode_step
+  int32_t* topk_ids = nullptr;  // [R][16]
+  float* topk_lp = nullptr;
+  float* topk_lse = nullptr;
+  // step-wise decode state
+  int open_batch = 0, open_beam = 0, open_rows = 0, host_pos = 0;
+
+  const void* W(int idx) const { return blob + off[idx]; }
+  const float* F(int idx) const { return reinterpret_cast<const float*>(blob + off[idx]); }
+  int enc_base(int l) const { return WJ_T_N_GLOBAL + l * WJ_TE_N; }
+  int dec_base(int l) const { return WJ_T_N_GLOBAL + d.n_audio_layer * WJ_TE_N + l * WJ_TD_N; }
+  int64_t cross_layer_elems() const { return (int64_t)max_batch * d.n_text_head * d.n_audio_ctx * 64; }
+  int64_t self_layer_elems() const { return (int64_t)max_rows * d.n_text_head * d.n_text_ctx * 64; }
+  void* at(void* base, int64_t elems) const { return reinterpret_cast<char*>(base) + elems * (int64_t)esz; }
+};
+
+static int dev_alloc(wj_whisper* m, void** p, size_t bytes, bool zero) {
+  bytes = align_up(bytes ? bytes : 256, 256);
+  WJ_HIP(hipMalloc(p, bytes));
+  m->allocs.push_back(*p);
+  m->alloc_bytes += bytes;
+  if (zero) WJ_HIP(hipMemsetAsync(*p, 0, bytes, m->ctx->stream));
+  return WJ_OK;
+}
+#define WJ_ALLOC(field, bytes, zero)                                        \
+  do {                                                                      \
+    int _rc = dev_alloc(m, reinterpret_cast<void**>(&m->field), (bytes), (zero)); \
+    if (_rc) { wj_whisper_free(m); return _rc; }                            \
+  } while (0)
+#define WJ_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc) return _rc;        \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// encoder
+// ------------------------------------------------------------------------------------------------
+static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, float* enc_out, hipStream_t s) {
+  const wj_whisper_dims& d = m->d;
+  const int D = d.n_audio_state, H = d.n_audio_head, C = d.n_mels, T = d.n_audio_ctx, F = m->frames;
+  const int dt = m->dtype;
+  PROF(PT_MEL_ROWS, launch_mel_to_rows(dt, mel, m->mel_rows, B, C, F, s));
+  {  // conv1 (k=3, pad 1) as a GEMM over the overlapping [t-1, t, t+1] row window + GELU
+    GemmArgs g;
+    g.A = m->mel_rows; g.lda = C; g.a_batch = (int64_t)(F + 2) * C;
+    g.W = m->W(WJ_T_ENC_CONV1_W); g.ldw = 3 * C; g.bias = m->F(WJ_T_ENC_CONV1_B);
+    g.M = F; g.N = D; g.K = 3 * C; g.nbatch = B;
+    g.out = m->at(m->conv1_out, D); g.ldc = D; g.c_batch = (int64_t)(F + 2) * D;
+    PROF(PT_CONV1, launch_gemm(dt, EPI_GELU_T, g, s, 1));
+  }
+  {  // conv2 (k=3, stride 2, pad 1) + GELU + positional embedding -> fp32 residual stream
+    GemmArgs g;
+    g.A = m->conv1_out; g.lda = 2 * D; g.a_batch = (int64_t)(F + 2) * D;
+    g.W = m->W(WJ_T_ENC_CONV2_W); g.ldw = 3 * D; g.bias = m->F(WJ_T_ENC_CONV2_B);
+    g.M = T; g.N = D; g.K = 3 * D; g.nbatch = B;
+    g.out = m->x; g.ldc = D; g.c_batch = (int64_t)T * D; g.pos = m->F(WJ_T_ENC_POS);
+    PROF(PT_CONV2, launch_gemm(dt, EPI_GELU_POS_F32, g, s, 1));
+  }
+  const int L = n_layers < 0 ? d.n_audio_layer : n_layers;
+  const int M = B * T;
+  for (int l = 0; l < L; ++l) {
+    const int b0 = m->enc_base(l);
+    PROF(PT_E_LN, launch_layernorm(dt, m->x, m->F(b0 + WJ_TE_LN1_W), m->F(b0 + WJ_TE_LN1_B), m->h, M, D, s));
+    {
+      GemmArgs g;
+      g.A = m->h; g.lda = D; g.a_batch = (int64_t)T * D;
+      g.W = m->W(b0 + WJ_TE_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TE_QKV_B);
+      g.M = T; g.N = 2 * D; g.K = D; g.nbatch = B;
+      g.out = m->q; g.out2 = m->k; g.D = D; g.H = H; g.Tpad = m->Tpad;
+      PROF(PT_E_QK, launch_gemm(dt, EPI_QK_HEADS, g, s, 1));
+      GemmArgs v = g;
+      v.W = reinterpret_cast<const char*>(m->W(b0 + WJ_TE_QKV_W)) + (int64_t)2 * D * D * m->esz;
+      v.bias = m->F(b0 + WJ_TE_QKV_B) + 2 * D;
+      v.N = D; v.out = m->vt; v.out2 = nullptr;
+      PROF(PT_E_V, launch_gemm(dt, EPI_VT, v, s, 1));
+    }
+    PROF(PT_E_ATTN, launch_attention_enc(dt, m->q, m->k, m->vt, m->attn, B, T, m->Tpad, H, s));
+    {
+      GemmArgs g;
+      g.A = m->attn; g.lda = D; g.W = m->W(b0 + WJ_TE_OUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TE_OUT_B);
+      g.M = M; g.N = D; g.K = D; g.out = m->x; g.ldc = D;
+      PROF(PT_E_OUT, launch_gemm(dt, EPI_RESID_F32, g, s, 1));
+    }
+    PROF(PT_E_LN, launch_layernorm(dt, m->x, m->F(b0 + WJ_TE_LN2_W), m->F(b0 + WJ_TE_LN2_B), m->h, M, D, s));
+    {
+      GemmArgs g;
+      g.A = m->h; g.lda = D; g.W = m->W(b0 + WJ_TE_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TE_FC1_B);
+      g.M = M; g.N = 4 * D; g.K = D; g.out = m->ff; g.ldc = 4 * D;
+      PROF(PT_E_FC1, launch_gemm(dt, EPI_GELU_T, g, s, 1));
+      GemmArgs g2;
+      g2.A = m->ff; g2.lda = 4 * D; g2.W = m->W(b0 + WJ_TE_FC2_W); g2.ldw = 4 * D; g2.bias = m->F(b0 + WJ_TE_FC2_B);
+      g2.M = M; g2.N = D; g2.K = 4 * D; g2.out = m->x; g2.ldc = D;
+      PROF(PT_E_FC2, launch_gemm(dt, EPI_RESID_F32, g2, s, 1));
+    }
+  }
+  if (n_layers >= 0) {  // bisection mode: raw residual stream, no final norm, no cross K/V
+    if (enc_out) WJ_HIP(hipMemcpyAsync(enc_out, m->x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, s));
+    return WJ_OK;
+  }
+  PROF(PT_E_LN, launch_layernorm(dt, m->x, m->F(WJ_T_ENC_LNPOST_W), m->F(WJ_T_ENC_LNPOST_B), m->h, M, D, s));
+  if (enc_out)
+    WJ_TRY(launch_layernorm(WJ_F32, m->x, m->F(WJ_T_ENC_LNPOST_W), m->F(WJ_T_ENC_LNPOST_B), enc_out, M, D, s));
+  // cross-attention K/V of every decoder layer, computed once per window and kept in HBM
+  for (int l = 0; l < d.n_text_layer; ++l) {
+    const int b0 = m->dec_base(l);
+    GemmArgs g;
+    g.A = m->h; g.lda = D; g.a_batch = (int64_t)T * D;
+    g.W = m->W(b0 + WJ_TD_CKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CKV_B);
+    g.M = T; g.N = 2 * D; g.K = D; g.nbatch = B;
+    g.out = m->at(m->cross_k, l * m->cross_layer_elems());
+    g.out2 = m->at(m->cross_v, l * m->cross_layer_elems());
+    g.D = D; g.H = d.n_text_head; g.Tpad = T;
+    PROF(PT_E_CKV, launch_gemm(dt, EPI_CKV, g, s, 1));
+  }
+  return WJ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder: one token per row
+// ------------------------------------------------------------------------------------------------
+static int run_decoder_step(wj_whisper* m, int R, int n_windows, int beam, bool want_logits, hipStream_t s) {
+  const wj_whisper_dims& d = m->d;
+  const int D = d.n_text_state, H = d.n_text_head, dt = m->dtype;
+  PROF(PT_D_EMBED, launch_embed(dt, m->W(WJ_T_DEC_TOK_EMB), m->F(WJ_T_DEC_POS), m->tokens, m->tok_stride, m->pos, m->dx, R, D, s));
+  for (int l = 0; l < d.n_text_layer; ++l) {
+    const int b0 = m->dec_base(l);
+    void* sk = m->at(m->self_k, l * m->self_layer_elems());
+    void* sv = m->at(m->self_v, l * m->self_layer_elems());
+    PROF(PT_D_LN, launch_layernorm(dt, m->dx, m->F(b0 + WJ_TD_LN1_W), m->F(b0 + WJ_TD_LN1_B), m->dh, R, D, s));
+    {
+      GemmArgs g;
+      g.A = m->dh; g.lda = D; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
+      g.M = R; g.N = 3 * D; g.K = D; g.out = m->dq; g.out2 = sk; g.out3 = sv;
+      g.D = D; g.H = H; g.pos_ptr = m->pos; g.cache_len = d.n_text_ctx;
+      PROF(PT_D_QKV, launch_gemm(dt, EPI_QKV_DEC, g, s));
+    }
+    {
+      DecAttnArgs a;
+      a.q = m->dq; a.K = sk; a.V = sv; a.out = m->dattn; a.G = R; a.nb = 1; a.H = H;
+      a.n_keys_ptr = m->pos; a.kv_stride = d.n_text_ctx; a.row_map = m->row_map[m->cur_map];
+      PROF(PT_D_SELF, launch_attention_dec(dt, a, s));
+    }
+    {
+      GemmArgs g;
+      g.A = m->dattn; g.lda = D; g.W = m->W(b0 + WJ_TD_OUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_OUT_B);
+      g.M = R; g.N = D; g.K = D; g.out = m->dx; g.ldc = D;
+      PROF(PT_D_OUT, launch_gemm(dt, EPI_RESID_F32, g, s));
+    }
+    PROF(PT_D_LN, launch_layernorm(dt, m->dx, m->F(b0 + WJ_TD_LNX_W), m->F(b0 + WJ_TD_LNX_B), m->dh, R, D, s));
+    {
+      GemmArgs g;
+      g.A = m->dh; g.lda = D; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
+      g.M = R; g.N = D; g.K = D; g.out = m->dq; g.ldc = D;
+      PROF(PT_D_CQ, launch_gemm(dt, EPI_T, g, s));
+    }
+    {
+      DecAttnArgs a;
+      a.q = m->dq; a.K = m->at(m->cross_k, l * m->cross_layer_elems());
+      a.V = m->at(m->cross_v, l * m->cross_layer_elems());
+      a.out = m->dattn; a.G = n_windows; a.nb = beam; a.H = H; a.n_keys = d.n_audio_ctx; a.kv_stride = d.n_audio_ctx;
+      PROF(PT_D_CROSS, launch_attention_dec(dt, a, s));
+    }
+    {
+      GemmArgs g;
+      g.A = m->dattn; g.lda = D; g.W = m->W(b0 + WJ_TD_COUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_COUT_B);
+      g.M = R; g.N = D; g.K = D; g.out = m->dx; g.ldc = D;
+      PROF(PT_D_COUT, launch_gemm(dt, EPI_RESID_F32, g, s));
+    }
+    PROF(PT_D_LN, launch_layernorm(dt, m->dx, m->F(b0 + WJ_TD_LN2_W), m->F(b0 + WJ_TD_LN2_B), m->dh, R, D, s));
+    {
+      GemmArgs g;
+      g.A = m->dh; g.lda = D; g.W = m->W(b0 + WJ_TD_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_FC1_B);
+      g.M = R; g.N = 4 * D; g.K = D; g.out = m->dff; g.ldc = 4 * D;
+      PROF(PT_D_FC1, launch_gemm(dt, EPI_GELU_T, g, s));
+      GemmArgs g2;
+      g2.A = m->dff; g2.lda = 4 * D; g2.W = m->W(b0 + WJ_TD_FC2_W); g2.ldw = 4 * D; g2.bias = m->F(b0 + WJ_TD_FC2_B);
+      g2.M = R; g2.N = D; g2.K = 4 * D; g2.out = m->dx; g2.ldc = D;
+      PROF(PT_D_FC2, launch_gemm(dt, EPI_RESID_F32, g2, s));
+    }
+  }
+  if (want_logits) {
+    PROF(PT_D_LN, launch_layernorm(dt, m->dx, m->F(WJ_T_DEC_LN_W), m->F(WJ_T_DEC_LN_B), m->dh, R, D, s));
+    GemmArgs g;
+    g.A = m->dh; g.lda = D; g.W = m->W(WJ_T_DEC_TOK_EMB); g.ldw = D;
+    g.M = R; g.N = d.n_vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
+    PROF(PT_D_LOGITS, launch_gemm(dt, EPI_F32, g, s));
+  }
+  return WJ_OK;
+}
+
+__global__ void init_rows_kernel(int32_t* map0, int32_t* map1, int R, int stride) {
+  const int r = blockIdx.x;
+  for (int j = threadIdx.x; j < stride; j += 256) {
+    map0[(int64_t)r * stride + j] = r;
+    map1[(int64_t)r * stride + j] = r;
+  }
+}
+__global__ void put_tokens_kernel(int32_t* tokens, int64_t stride, const int* pos_ptr, const int32_t* src, int R) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < R) tokens[(int64_t)r * stride + *pos_ptr] = src[r];
+}
+
+static int reset_decode_state(wj_whisper* m, int R, hipStream_t s) {
+  WJ_HIP(hipMemsetAsync(m->pos, 0, sizeof(int), s));
+  WJ_HIP(hipMemsetAsync(m->sum_lp, 0, sizeof(float) * R, s));
+  WJ_HIP(hipMemsetAsync(m->finished, 0, sizeof(int32_t) * R, s));
+  WJ_HIP(hipMemsetAsync(m->tok_lp, 0, sizeof(float) * (size_t)R * m->tok_stride, s));
+  hipLaunchKernelGGL(init_rows_kernel, dim3(R), dim3(256), 0, s, m->row_map[0], m->row_map[1], R, m->d.n_text_ctx);
+  WJ_LAUNCH_CHECK();
+  m->cur_map = 0;
+  return WJ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int wj_abi_version(void) { return WJ_ABI_VERSION; }
+const char* wj_last_error(void) { return wj::get_error(); }
+
+int wj_init(int device_ordinal, wj_ctx** out) {
+  WJ_REQUIRE(out != nullptr, "wj_init: out is NULL");
+  int n = 0;
+  WJ_HIP(hipGetDeviceCount(&n));
+  WJ_REQUIRE(device_ordinal >= 0 && device_ordinal < n, "wj_init: device %d not present (%d visible)", device_ordinal, n);
+  WJ_HIP(hipSetDevice(device_ordinal));
+  hipDeviceProp_t prop;
+  WJ_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("wj_init: libwjhip is built for gfx950 (MI355X) only; device %d is %s", device_ordinal, prop.gcnArchName);
+    return WJ_E_UNSUPPORTED;
+  }
+  wj_ctx* c = new wj_ctx();
+  c->device = device_ordinal;
+  c->cu_count = prop.multiProcessorCount;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete c;
+    return WJ_E_HIP;
+  }
+  *out = c;
+  return WJ_OK;
+}
+
+int wj_shutdown(wj_ctx* ctx) {
+  if (!ctx) return WJ_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return WJ_OK;
+}
+
+int wj_sync(wj_ctx* ctx) {
+  WJ_REQUIRE(ctx != nullptr, "wj_sync: ctx is NULL");
+  WJ_HIP(hipStreamSynchronize(ctx->stream));
+  return WJ_OK;
+}
+
+int wj_device_info(wj_ctx* ctx, int64_t out[4]) {
+  WJ_REQUIRE(ctx && out, "wj_device_info: NULL argument");
+  hipDeviceProp_t prop;
+  WJ_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  out[0] = prop.multiProcessorCount;
+  out[1] = prop.clockRate;
+  out[2] = (int64_t)(prop.totalGlobalMem & 0xffffffffull);
+  out[3] = (int64_t)(prop.totalGlobalMem >> 32);
+  return WJ_OK;
+}
+
+int wj_profile_start(wj_ctx* ctx) {
+  WJ_REQUIRE(ctx != nullptr, "wj_profile_start: ctx is NULL");
+  if (!ctx->prof) ctx->prof = new wj_profiler();
+  return WJ_OK;
+}
+
+int wj_profile_tags(void) { return PT_COUNT; }
+const char* wj_profile_tag_name(int tag) { return (tag >= 0 && tag < PT_COUNT) ? kProfNames[tag] : ""; }
+
+int wj_profile_stop(wj_ctx* ctx, double* total_ms, int64_t* counts, int n_tags) {
+  WJ_REQUIRE(ctx && total_ms && counts && n_tags >= PT_COUNT, "wj_profile_stop: bad arguments");
+  wj_profiler* p = ctx->prof;
+  WJ_REQUIRE(p != nullptr, "wj_profile_stop: profiler not started");
+  WJ_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n_tags; ++i) { total_ms[i] = 0.0; counts[i] = 0; }
+  for (auto& pr : p->pairs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(pr.b) == hipSuccess && hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
+      total_ms[pr.tag] += ms;
+      counts[pr.tag] += 1;
+    }
+    (void)hipEventDestroy(pr.a);
+    (void)hipEventDestroy(pr.b);
+  }
+  delete p;
+  ctx->prof = nullptr;
+  return WJ_OK;
+}
+
+int64_t wj_logmel_frames(int64_t n_samples, int mode) {
+  if (n_samples <= 0) return 0;
+  return (n_samples + (mode == WJ_MEL_FW ? 160 : 480000)) / 160;
+}
+
+int wj_logmel_f32(wj_ctx* ctx, const float* pcm_dev, const int64_t* offsets_host, int n_clips, int n_mels, int mode,
+                  int out_frames, float* out_dev, void* stream) {
+  WJ_REQUIRE(ctx && pcm_dev && offsets_host && out_dev, "wj_logmel_f32: NULL argument");
+  WJ_HIP(hipSetDevice(ctx->device));
+  return logmel_run(ctx, pcm_dev, offsets_host, n_clips, n_mels, mode, out_frames, out_dev, ctx->pick(stream));
+}
+
+int wj_whisper_free(wj_whisper* m) {
+  if (!m) return WJ_OK;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  for (void* p : m->allocs) (void)hipFree(p);
+  delete m;
+  return WJ_OK;
+}
+
+int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const void* blob_dev, int64_t blob_bytes,
+                      const int64_t* offsets_host, int n_offsets, int max_batch, int max_rows, wj_whisper** out) {
+  WJ_REQUIRE(ctx && dims && blob_dev && offsets_host && out, "wj_whisper_create: NULL argument");
+  WJ_REQUIRE(dtype == WJ_F32 || dtype == WJ_BF16, "wj_whisper_create: dtype must be WJ_F32 or WJ_BF16");
+  const wj_whisper_dims& d = *dims;
+  WJ_REQUIRE(d.n_audio_state == d.n_text_state && d.n_audio_head == d.n_text_head,
+             "wj_whisper_create: encoder/decoder width mismatch");
+  WJ_REQUIRE(d.n_audio_state == 64 * d.n_audio_head, "wj_whisper_create: head_dim must be 64 (d=%d, heads=%d)",
+             d.n_audio_state, d.n_audio_head);
+  WJ_REQUIRE(d.n_audio_state <= 1280, "wj_whisper_create: d_model must be <= 1280");
+  WJ_REQUIRE(d.n_mels == 80 || d.n_mels == 128, "wj_whisper_create: n_mels must be 80 or 128");
+  WJ_REQUIRE(d.n_audio_ctx % 4 == 0 && d.n_audio_ctx > 0 && d.n_text_ctx >= 8, "wj_whisper_create: bad context sizes");
+  WJ_REQUIRE(max_batch >= 1 && max_rows >= max_batch, "wj_whisper_create: need max_rows >= max_batch >= 1");
+  const int expect = WJ_T_N_GLOBAL + d.n_audio_layer * WJ_TE_N + d.n_text_layer * WJ_TD_N;
+  WJ_REQUIRE(n_offsets == expect, "wj_whisper_create: offset table has %d entries, expected %d", n_offsets, expect);
+  for (int i = 0; i < n_offsets; ++i)
+    WJ_REQUIRE(offsets_host[i] >= 0 && offsets_host[i] < blob_bytes && offsets_host[i] % 256 == 0,
+               "wj_whisper_create: offset %d (%lld) outside the blob or not 256-byte aligned", i, (long long)offsets_host[i]);
+  WJ_HIP(hipSetDevice(ctx->device));
+
+  wj_whisper* m = new wj_whisper();
+  m->ctx = ctx;
+  m->d = d;
+  m->dtype = dtype;
+  m->esz = dtype == WJ_BF16 ? 2 : 4;
+  m->blob = reinterpret_cast<const char*>(blob_dev);
+  m->off.assign(offsets_host, offsets_host + n_offsets);
+  m->max_batch = max_batch;
+  m->max_rows = max_rows;
+  m->Tpad = (d.n_audio_ctx + 127) / 128 * 128;
+  m->frames = 2 * d.n_audio_ctx;
+  const size_t e = m->esz;
+  const int D = d.n_audio_state, H = d.n_audio_head, T = d.n_audio_ctx, F = m->frames;
+  const size_t B = max_batch, R = max_rows;
+  WJ_ALLOC(mel_rows, B * (F + 2) * d.n_mels * e, true);
+  WJ_ALLOC(conv1_out, B * (F + 2) * D * e, true);
+  WJ_ALLOC(x, B * T * D * sizeof(float), false);
+  WJ_ALLOC(h, B * T * D * e, false);
+  WJ_ALLOC(q, B * H * m->Tpad * 64 * e, true);
+  WJ_ALLOC(k, B * H * m->Tpad * 64 * e, true);
+  WJ_ALLOC(vt, B * H * 64 * m->Tpad * e, true);
+  WJ_ALLOC(attn, B * T * D * e, false);
+  WJ_ALLOC(ff, B * T * 4 * D * e, false);
+  WJ_ALLOC(cross_k, (size_t)d.n_text_layer * m->cross_layer_elems() * e, false);
+  WJ_ALLOC(cross_v, (size_t)d.n_text_layer * m->cross_layer_elems() * e, false);
+  WJ_ALLOC(dx, R * D * sizeof(float), false);
+  WJ_ALLOC(dh, R * D * e, false);
+  WJ_ALLOC(dq, R * D * e, false);
+  WJ_ALLOC(dattn, R * D * e, false);
+  WJ_ALLOC(dff, R * 4 * D * e, false);
+  m->ldl = (d.n_vocab + 63) / 64 * 64;
+  WJ_ALLOC(logits, R * m->ldl * sizeof(float), false);
+  WJ_ALLOC(self_k, (size_t)d.n_text_layer * m->self_layer_elems() * e, true);
+  WJ_ALLOC(self_v, (size_t)d.n_text_layer * m->self_layer_elems() * e, true);
+  m->tok_stride = d.n_text_ctx + 8;
+  WJ_ALLOC(tokens, R * m->tok_stride * sizeof(int32_t), true);
+  WJ_ALLOC(pos, 256, true);
+  WJ_ALLOC(sum_lp, R * sizeof(float), true);
+  WJ_ALLOC(tok_lp, R * m->tok_stride * sizeof(float), true);
+  WJ_ALLOC(finished, R * sizeof(int32_t), true);
+  WJ_ALLOC(nsp, R * sizeof(float), true);
+  WJ_ALLOC(row_map[0], R * d.n_text_ctx * sizeof(int32_t), true);
+  WJ_ALLOC(row_map[1], R * d.n_text_ctx * sizeof(int32_t), true);
+  WJ_ALLOC(parent, R * sizeof(int32_t), true);
+  WJ_ALLOC(step_tok, R * sizeof(int32_t), true);
+  WJ_ALLOC(topk_ids, R * 16 * sizeof(int32_t), true);
+  WJ_ALLOC(topk_lp, R * 16 * sizeof(float), true);
+  WJ_ALLOC(topk_lse, R * sizeof(float), true);
+  hipError_t se = hipStreamSynchronize(ctx->stream);
+  if (se != hipSuccess) {
+    set_error("wj_whisper_create: %s", hipGetErrorString(se));
+    wj_whisper_free(m);
+    return WJ_E_HIP;
+  }
+  *out = m;
+  return WJ_OK;
+}
+
+int64_t wj_whisper_workspace_bytes(const wj_whisper* m) { return m ? (int64_t)m->alloc_bytes : 0; }
+
+int wj_whisper_encode(wj_whisper* m, const float* mel_dev, int batch, int n_layers, float* enc_out_dev, void* stream) {
+  WJ_REQUIRE(m && mel_dev, "wj_whisper_encode: NULL argument");
+  WJ_REQUIRE(batch >= 1 && batch <= m->max_batch, "wj_whisper_encode: batch %d outside 1..%d", batch, m->max_batch);
+  WJ_REQUIRE(n_layers <= m->d.n_audio_layer, "wj_whisper_encode: n_layers too large");
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  return run_encoder(m, mel_dev, batch, n_layers, enc_out_dev, m->ctx->pick(stream));
+}
+
+int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_host, int prompt_len,
+                             const wj_decode_opts* opts, int32_t* tokens_out, int32_t* n_tokens_out,
+                             float* sum_logprob_out, float* no_speech_prob_out, float* token_logprob_out,
+                             void* stream) {
+  WJ_REQUIRE(m && prompts_host && opts && tokens_out && n_tokens_out && sum_logprob_out, "wj_whisper_decode_greedy: NULL argument");
+  WJ_REQUIRE(batch >= 1 && batch <= m->max_batch, "decode_greedy: batch %d outside 1..%d", batch, m->max_batch);
+  const int max_new = opts->max_new_tokens;
+  WJ_REQUIRE(prompt_len >= 1 && max_new >= 1 && prompt_len + max_new <= m->d.n_text_ctx,
+             "decode_greedy: prompt_len %d + max_new_tokens %d exceeds n_text_ctx %d", prompt_len, max_new, m->d.n_text_ctx);
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  const int R = batch;
+  WJ_TRY(reset_decode_state(m, R, s));
+  // prompt -> device history (row stride tok_stride)
+  {
+    std::vector<int32_t> hist((size_t)R * m->tok_stride, opts->eot);
+    for (int r = 0; r < R; ++r)
+      for (int j = 0; j < prompt_len; ++j) hist[(size_t)r * m->tok_stride + j] = prompts_host[(size_t)r * prompt_len + j];
+    WJ_HIP(hipMemcpyAsync(m->tokens, hist.data(), hist.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    WJ_HIP(hipStreamSynchronize(s));
+  }
+  // prompt positions 0 .. prompt_len-2 only fill the KV cache (position 0 also yields no_speech_prob)
+  for (int p = 0; p + 1 < prompt_len; ++p) {
+    const bool ns = (p == 0) && no_speech_prob_out != nullptr;
+    WJ_TRY(run_decoder_step(m, R, R, 1, ns, s));
+    if (ns) WJ_TRY(launch_no_speech_prob(m->logits, m->ldl, R, m->d.n_vocab, opts->no_speech, m->nsp, s));
+    WJ_TRY(launch_advance_pos(m->pos, s));
+  }
+  GreedyArgs ga;
+  ga.logits = m->logits; ga.ldl = m->ldl; ga.R = R; ga.V = m->d.n_vocab;
+  ga.tokens = m->tokens; ga.tok_stride = m->tok_stride; ga.pos_ptr = m->pos; ga.sample_begin = prompt_len;
+  ga.sum_logprob = m->sum_lp; ga.token_logprob = m->tok_lp; ga.finished = m->finished; ga.opts = *opts;
+
+  // One decode iteration = ~11 launches per layer; capture it once and replay it from a hipGraph so
+  // the loop is not host-launch bound.  Every step-dependent scalar lives in device memory (m->pos).
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  const char* env = getenv("WJ_NO_GRAPH");
+  bool use_graph = !(env && env[0] == '1') && !prof_on(m->ctx);
+  if (use_graph) {
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      int rc = run_decoder_step(m, R, R, 1, true, s);
+      if (!rc) rc = launch_greedy_sample(ga, s);
+      if (!rc) rc = launch_advance_pos(m->pos, s);
+      e = hipStreamEndCapture(s, &graph);
+      if (rc || e != hipSuccess || graph == nullptr) use_graph = false;
+      else if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) use_graph = false;
+    } else {
+      use_graph = false;
+    }
+    if (!use_graph) {
+      (void)hipGetLastError();
+      if (exec) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
+      if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+    }
+  }
+  std::vector<int32_t> fin(R);
+  for (int i = 0; i < max_new; ++i) {
+    if (use_graph) {
+      WJ_HIP(hipGraphLaunch(exec, s));
+    } else {
+      WJ_TRY(run_decoder_step(m, R, R, 1, true, s));
+      PROF(PT_D_SAMPLE, launch_greedy_sample(ga, s));
+      PROF(PT_D_MISC, launch_advance_pos(m->pos, s));
+    }
+    if ((i & 15) == 15 && i + 1 < max_new) {  // early exit once every row has emitted EOT
+      WJ_HIP(hipMemcpyAsync(fin.data(), m->finished, sizeof(int32_t) * R, hipMemcpyDeviceToHost, s));
+      WJ_HIP(hipStreamSynchronize(s));
+      bool all = true;
+      for (int r = 0; r < R; ++r) all = all && fin[r];
+      if (all) break;
+    }
+  }
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
+
+  std::vector<int32_t> hist((size_t)R * m->tok_stride);
+  std::vector<float> lps((size_t)R * m->tok_stride);
+  WJ_HIP(hipMemcpyAsync(hist.data(), m->tokens, hist.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(lps.data(), m->tok_lp, lps.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(sum_logprob_out, m->sum_lp, sizeof(float) * R, hipMemcpyDeviceToHost, s));
+  if (no_speech_prob_out) WJ_HIP(hipMemcpyAsync(no_speech_prob_out, m->nsp, sizeof(float) * R, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipStreamSynchronize(s));
+  for (int r = 0; r < R; ++r) {
+    int n = 0;
+    bool done = false;
+    for (int j = 0; j < max_new; ++j) {
+      const int32_t t = hist[(size_t)r * m->tok_stride + prompt_len + j];
+      if (!done && t == opts->eot) done = true;
+      tokens_out[(size_t)r * max_new + j] = done ? opts->eot : t;
+      if (token_logprob_out) token_logprob_out[(size_t)r * max_new + j] = lps[(size_t)r * m->tok_stride + prompt_len + j];
+      if (!done) ++n;
+    }
+    n_tokens_out[r] = n;
+  }
+  return WJ_OK;
+}
+
+int wj_decode_open(wj_whisper* m, int batch, int beam, void* stream) {
+  WJ_REQUIRE(m != nullptr, "wj_decode_open: NULL model");
+  WJ_REQUIRE(batch >= 1 && batch <= m->max_batch && beam >= 1 && batch * beam <= m->max_rows,
+             "wj_decode_open: batch %d x beam %d does not fit (max_batch %d, max_rows %d)", batch, beam, m->max_batch, m->max_rows);
+  WJ_REQUIRE(beam <= 6 || beam == 8, "wj_decode_open: beam must be 1..6 or 8");
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  m->open_batch = batch;
+  m->open_beam = beam;
+  m->open_rows = batch * beam;
+  m->host_pos = 0;
+  return reset_decode_state(m, m->open_rows, s);
+}
+
+int wj_decode_step(wj_whisper* m, const int32_t* tokens_host, const int32_t* parent_host, int want_logits, void* stream) {
+  WJ_REQUIRE(m && tokens_host, "wj_decode_step: NULL argument");
+  WJ_REQUIRE(m->open_rows > 0, "wj_decode_step: call wj_decode_open first");
+  WJ_REQUIRE(m->host_pos < m->d.n_text_ctx, "wj_decode_step: context of %d tokens exhausted", m->d.n_text_ctx);
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  const int R = m->open_rows;
+  WJ_HIP(hipMemcpyAsync(m->step_tok, tokens_host, sizeof(int32_t) * R, hipMemcpyHostToDevice, s));
+  if (parent_host) {
+    WJ_HIP(hipMemcpyAsync(m->parent, parent_host, sizeof(int32_t) * R, hipMemcpyHostToDevice, s));
+    WJ_TRY(launch_rebind_rows(m->row_map[m->cur_map], m->row_map[m->cur_map ^ 1], m->parent, m->pos, R, m->d.n_text_ctx, s));
+    m->cur_map ^= 1;
+  }
+  hipLaunchKernelGGL(put_tokens_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, s, m->tokens, m->tok_stride, m->pos, m->step_tok, R);
+  WJ_LAUNCH_CHECK();
+  WJ_TRY(run_decoder_step(m, R, m->open_batch, m->open_beam, want_logits != 0, s));
+  WJ_TRY(launch_advance_pos(m->pos, s));
+  WJ_HIP(hipStreamSynchronize(s));  // host buffers may be reused by the caller
+  m->host_pos += 1;
+  return WJ_OK;
+}
+
+float* wj_decode_logits_dev(wj_whisper* m) { return m ? m->logits : nullptr; }
+
+int wj_decode_logits_copy(wj_whisper* m, int rows, float* dst_dev, void* stream) {
+  WJ_REQUIRE(m && dst_dev && rows >= 1 && rows <= m->max_rows, "wj_decode_logits_copy: bad arguments");
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  WJ_HIP(hipMemcpy2DAsync(dst_dev, sizeof(float) * m->d.n_vocab, m->logits, sizeof(float) * m->ldl,
+                          sizeof(float) * m->d.n_vocab, rows, hipMemcpyDeviceToDevice, s));
+  return WJ_OK;
+}
+
+int wj_decode_topk(wj_whisper* m, int rows, int k, const uint8_t* ban_dev, int32_t* ids_out_host,
+                   float* logprob_out_host, float* lse_out_host, void* stream) {
+  WJ_REQUIRE(m && ids_out_host && logprob_out_host, "wj_decode_topk: NULL argument");
+  WJ_REQUIRE(rows >= 1 && rows <= m->max_rows && k >= 1 && k <= 16, "wj_decode_topk: rows/k out of range");
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  WJ_TRY(launch_topk_logprob(m->logits, m->ldl, rows, m->d.n_vocab, k, ban_dev, m->topk_ids, m->topk_lp, m->topk_lse, s));
+  WJ_HIP(hipMemcpyAsync(ids_out_host, m->topk_ids, sizeof(int32_t) * rows * k, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(logprob_out_host, m->topk_lp, sizeof(float) * rows * k, hipMemcpyDeviceToHost, s));
+  if (lse_out_host) WJ_HIP(hipMemcpyAsync(lse_out_host, m->topk_lse, sizeof(float) * rows, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipStreamSynchronize(s));
+  return WJ_OK;
+}
+
+// ---- kernel-level entry points (tests / micro-benchmarks) ---------------------------------------
+int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev, int M,
+              int N, int K, int act_gelu, int out_f32, int variant, void* stream) {
+  WJ_REQUIRE(ctx && a_dev && w_dev && c_dev, "wj_k_gemm: NULL argument");
+  WJ_HIP(hipSetDevice(ctx->device));
+  GemmArgs g;
+  g.A = a_dev; g.lda = K; g.W = w_dev; g.ldw = K; g.bias = bias_dev; g.M = M; g.N = N; g.K = K; g.out = c_dev; g.ldc = N;
+  Epi e = out_f32 ? EPI_F32 : (act_gelu ? EPI_GELU_T : EPI_T);
+  WJ_REQUIRE(!(out_f32 && act_gelu), "wj_k_gemm: gelu with f32 output is not a fused variant");
+  return launch_gemm(dtype, e, g, ctx->pick(stream), variant);
+}
+
+int wj_k_layernorm(wj_ctx* ctx, int dtype, const float* x_dev, const float* w_dev, const float* b_dev, void* out_dev, int M,
+                   int D, void* stream) {
+  WJ_REQUIRE(ctx && x_dev && w_dev && b_dev && out_dev, "wj_k_layernorm: NULL argument");
+  WJ_HIP(hipSetDevice(ctx->device));
+  return launch_layernorm(dtype, x_dev, w_dev, b_dev, out_dev, M, D, ctx->pick(stream));
+}
+
+}  // extern "C"
+
+// helpers for the attention test entry points --------------------------------------------------------
+template <typename T>
+__global__ void qkv_split_kernel(const float* __restrict__ qkv, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vt,
+                                 int Tn, int Tpad, int H) {
+  const int b = blockIdx.y, t = blockIdx.x, D = H * 64;
+  const float* row = qkv + ((int64_t)b * Tn + t) * 3 * D;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const int h = c >> 6, dd = c & 63;
+    const int64_t bh = (int64_t)b * H + h;
+    Elem<T>::st(Q + (bh * Tpad + t) * 64 + dd, row[c]);
+    Elem<T>::st(K + (bh * Tpad + t) * 64 + dd, row[D + c]);
+    Elem<T>::st(Vt + (bh * 64 + dd) * Tpad + t, row[2 * D + c]);
+  }
+}
+template <typename T>
+__global__ void T_to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = Elem<T>::ld(in + i);
+}
+
+extern "C" {
+
+int wj_k_attention_enc(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, void* out_dev, int B, int T, int H, void* stream) {
+  WJ_REQUIRE(ctx && qkv_f32_dev && out_dev, "wj_k_attention_enc: NULL argument");
+  WJ_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->pick(stream);
+  const int Tpad = (T + 127) / 128 * 128;
+  const size_t esz = dtype == WJ_BF16 ? 2 : 4;
+  const size_t one = align_up((size_t)B * H * Tpad * 64 * esz, 256);
+  WJ_TRY(ctx->ensure_scratch(3 * one));
+  char* base = reinterpret_cast<char*>(ctx->scratch);
+  WJ_HIP(hipMemsetAsync(base, 0, 3 * one, s));
+  if (dtype == WJ_F32)
+    hipLaunchKernelGGL(qkv_split_kernel<float>, dim3(T, B), dim3(256), 0, s, qkv_f32_dev, (float*)base, (float*)(base + one),
+                       (float*)(base + 2 * one), T, Tpad, H);
+  else
+    hipLaunchKernelGGL(qkv_split_kernel<bf16_t>, dim3(T, B), dim3(256), 0, s, qkv_f32_dev, (bf16_t*)base,
+                       (bf16_t*)(base + one), (bf16_t*)(base + 2 * one), T, Tpad, H);
+  WJ_LAUNCH_CHECK();
+  return launch_attention_enc(dtype, base, base + one, base + 2 * one, out_dev, B, T, Tpad, H, s);
+}
+
+int wj_k_attention_dec(wj_ctx* ctx, int dtype, const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev,
+                       int G, int nb, int H, int n_keys, void* stream) {
+  WJ_REQUIRE(ctx && q_dev && k_dev && v_dev && out_dev, "wj_k_attention_dec: NULL argument");
+  WJ_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->pick(stream);
+  const size_t esz = dtype == WJ_BF16 ? 2 : 4;
+  const int64_t nq = (int64_t)G * nb * H * 64, nkv = (int64_t)G * H * n_keys * 64;
+  const size_t bq = align_up(nq * esz, 256), bkv = align_up(nkv * esz, 256);
+  WJ_TRY(ctx->ensure_scratch(2 * bq + 2 * bkv));
+  char* base = reinterpret_cast<char*>(ctx->scratch);
+  void *tq = base, *tk = base + bq, *tv = base + bq + bkv, *to = base + bq + 2 * bkv;
+  WJ_TRY(launch_f32_to_T(dtype, q_dev, tq, nq, s));
+  WJ_TRY(launch_f32_to_T(dtype, k_dev, tk, nkv, s));
+  WJ_TRY(launch_f32_to_T(dtype, v_dev, tv, nkv, s));
+  DecAttnArgs a;
+  a.q = tq; a.K = tk; a.V = tv; a.out = to; a.G = G; a.nb = nb; a.H = H; a.n_keys = n_keys; a.kv_stride = n_keys;
+  WJ_TRY(launch_attention_dec(dtype, a, s));
+  const int blocks = (int)min((int64_t)1024, ceil_div64(nq, 256));
+  if (dtype == WJ_F32)
+    hipLaunchKernelGGL(T_to_f32_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)to, out_dev, nq);
+  else
+    hipLaunchKernelGGL(T_to_f32_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)to, out_dev, nq);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,384 @@
+// gemm.hip -- C[M,N] = A[M,K] . W[N,K]^T with fused epilogues, gfx950.
+//
+// Three kernels:
+//   * gemm_bf16_tile  : 128x128x64 tile, 4 waves (2x2), v_mfma_f32_16x16x32_bf16, register-prefetched
+//                       global->LDS staging with an XOR-swizzled LDS image, double-buffered LDS.
+//                       Used for the encoder (M = batch*1500) and the cross-K/V projection.
+//   * gemm_bf16_skinny: decode-step GEMM (M = hypotheses <= a few hundred).  HBM-bound on W: one
+//                       workgroup owns 16 output columns, its 8 waves split K, W fragments go
+//                       straight from HBM to VGPRs (streamed once), partials meet in LDS.
+//   * gemm_f32        : exact-fp32 VALU kernel (fmaf chains, k ascending) for the float32 compute
+//                       type that carries the 1e-3 log-prob parity bar.
+//
+// Both operands are K-contiguous ([M][K] activations, [N][K] = PyTorch Linear weights), so every
+// MFMA fragment is one 16-byte load and no transposition is ever needed.  Accumulators use the
+// "NM" orientation (mfma(W_frag, A_frag)): a lane ends up with 4 consecutive output columns of
+// one row, i.e. one 8-byte (bf16) / 16-byte (fp32) store.  EPI_VT flips the operand order so a
+// lane holds 4 consecutive rows instead (V is written transposed per head for the attention
+// kernel's P.V operand).
+#include "kernels.hpp"
+
+namespace wj {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// --------------------------------------------------------------------------------------------
+// epilogues
+// --------------------------------------------------------------------------------------------
+template <int EPI, typename T>
+__device__ __forceinline__ void epi_nm(const GemmArgs& g, int z, int m, int n, float v[4]) {
+  // v[j] belongs to (row m, column n + j); n % 4 == 0; caller guarantees m < M and n < N.
+  if constexpr (EPI == EPI_F32) {
+    float* o = reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n + j < g.N) o[j] = v[j] + (g.bias ? g.bias[n + j] : 0.0f);
+    return;
+  } else {
+    if (g.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if constexpr (EPI == EPI_T || EPI == EPI_GELU_T) {
+      if constexpr (EPI == EPI_GELU_T) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_exact(v[j]);
+      }
+      st4(reinterpret_cast<T*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n, v);
+    } else if constexpr (EPI == EPI_RESID_F32) {
+      float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch +
+                                            (int64_t)m * g.ldc + n);
+      float4 x = *o;
+      x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
+      *o = x;
+    } else if constexpr (EPI == EPI_GELU_POS_F32) {
+      const float4 p = *reinterpret_cast<const float4*>(g.pos + (int64_t)m * g.N + n);
+      float4 x;
+      x.x = gelu_exact(v[0]) + p.x; x.y = gelu_exact(v[1]) + p.y;
+      x.z = gelu_exact(v[2]) + p.z; x.w = gelu_exact(v[3]) + p.w;
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch +
+                                 (int64_t)m * g.ldc + n) = x;
+    } else if constexpr (EPI == EPI_QK_HEADS || EPI == EPI_CKV) {
+      const int which = n >= g.D;
+      const int nn = n - which * g.D;
+      const int h = nn >> 6, dd = nn & 63;
+      T* base = reinterpret_cast<T*>(which ? g.out2 : g.out);
+      st4(base + (((int64_t)z * g.H + h) * g.Tpad + m) * 64 + dd, v);
+    } else if constexpr (EPI == EPI_QKV_DEC) {
+      const int which = n / g.D;
+      const int nn = n - which * g.D;
+      if (which == 0) {
+        st4(reinterpret_cast<T*>(g.out) + (int64_t)m * g.D + nn, v);
+      } else {
+        const int h = nn >> 6, dd = nn & 63;
+        const int pos = *g.pos_ptr;
+        T* base = reinterpret_cast<T*>(which == 1 ? g.out2 : g.out3);
+        st4(base + (((int64_t)m * g.H + h) * g.cache_len + pos) * 64 + dd, v);
+      }
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void epi_vt(const GemmArgs& g, int z, int m, int n, float v[4]) {
+  // v[i] belongs to (row m + i, column n); m % 4 == 0; m < M (M % 4 == 0), n < N.
+  const float b = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] += b;
+  const int h = n >> 6, dd = n & 63;
+  st4(reinterpret_cast<T*>(g.out) + (((int64_t)z * g.H + h) * 64 + dd) * g.Tpad + m, v);
+}
+
+// --------------------------------------------------------------------------------------------
+// bf16 MFMA, 128x128x64 tile
+// --------------------------------------------------------------------------------------------
+constexpr int TBM = 128, TBN = 128, TBK = 64;
+
+// Predicated 16-byte load: the address is always valid (callers clamp it) and the VALUE is
+// selected.  Writing `p ? *ptr : zero` instead lets the compiler select between the global pointer
+// and a stack slot, which turns every load into a flat_load plus a scratch store.
+__device__ __forceinline__ uint4 ldg16_pred(const void* p, bool pred) {
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  v.x = pred ? v.x : 0u; v.y = pred ? v.y : 0u; v.z = pred ? v.z : 0u; v.w = pred ? v.w : 0u;
+  return v;
+}
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * TBK + ((chunk ^ (row & 7)) << 3); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * TBM * TBK];  // [buf][A|W][128][64] = 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int z = blockIdx.z;
+  const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)z * g.a_batch;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  const int nk = (g.K + TBK - 1) / TBK;
+  // staging registers are individually named (an indexed array ends up in scratch memory)
+#define WJ_GLOAD1(i, k0)                                                                      \
+  {                                                                                           \
+    const int idx = tid + (i) * 256;                                                          \
+    const int row = idx >> 3, ch = idx & 7;                                                   \
+    const int k = (k0) + ch * 8;                                                              \
+    const bool kin = k < g.K;                                                                 \
+    const int kc = kin ? k : 0;                                                               \
+    ra##i = ldg16_pred(A + (int64_t)min(m0 + row, g.M - 1) * g.lda + kc, kin && m0 + row < g.M); \
+    rb##i = ldg16_pred(W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + kc, kin && n0 + row < g.N); \
+  }
+#define WJ_GLOAD(k0) WJ_GLOAD1(0, k0) WJ_GLOAD1(1, k0) WJ_GLOAD1(2, k0) WJ_GLOAD1(3, k0)
+#define WJ_SSTORE1(i, buf)                                                                    \
+  {                                                                                           \
+    const int idx = tid + (i) * 256;                                                          \
+    const int row = idx >> 3, ch = idx & 7;                                                   \
+    const int off = swz(row, ch);                                                             \
+    *reinterpret_cast<uint4*>(&lds[((buf) * 2 + 0) * TBM * TBK + off]) = ra##i;               \
+    *reinterpret_cast<uint4*>(&lds[((buf) * 2 + 1) * TBM * TBK + off]) = rb##i;               \
+  }
+#define WJ_SSTORE(buf) WJ_SSTORE1(0, buf) WJ_SSTORE1(1, buf) WJ_SSTORE1(2, buf) WJ_SSTORE1(3, buf)
+
+  WJ_GLOAD(0)
+  WJ_SSTORE(0)
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) { WJ_GLOAD((kt + 1) * TBK) }
+    const bf16_t* la = &lds[(cur * 2 + 0) * TBM * TBK];
+    const bf16_t* lb = &lds[(cur * 2 + 1) * TBM * TBK];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], wf[4];
+      const int ch = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + (lane & 15);
+        af[i] = *reinterpret_cast<const bf16x8_t*>(&la[swz(row, ch)]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + (lane & 15);
+        wf[j] = *reinterpret_cast<const bf16x8_t*>(&lb[swz(row, ch)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (EPI == EPI_VT)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) { WJ_SSTORE(cur ^ 1) }
+    __syncthreads();
+  }
+#undef WJ_GLOAD
+#undef WJ_SSTORE
+#undef WJ_GLOAD1
+#undef WJ_SSTORE1
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if constexpr (EPI == EPI_VT) {
+        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
+        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+        if (m < g.M && n < g.N) epi_vt<bf16_t>(g, z, m, n, v);
+      } else {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, z, m, n, v);
+      }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// bf16 MFMA, skinny (decode) kernel: 16 output columns per workgroup, 8 waves split K
+// --------------------------------------------------------------------------------------------
+template <int EPI, int MT>
+__global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float red[8 * MT * 16 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt0 = blockIdx.x * 16;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+  const int ksteps = (g.K + 31) / 32;
+  const int per = (ksteps + 7) / 8;
+  const int ks_begin = wave * per;
+  const int ks_end = min(ksteps, ks_begin + per);
+  const int wrow = nt0 + (lane & 15);
+  const int kq = (lane >> 4) * 8;
+
+  for (int mc = 0; mc < g.M; mc += MT * 16) {
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+      const int k = ks * 32 + kq;
+      const bool kin = k < g.K;
+      const int kc = kin ? k : 0;
+      const uint4 wv = ldg16_pred(W + (int64_t)min(wrow, g.N - 1) * g.ldw + kc, kin && wrow < g.N);
+      const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wv);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int arow = mc + t * 16 + (lane & 15);
+        const uint4 av = ldg16_pred(A + (int64_t)min(arow, g.M - 1) * g.lda + kc, kin && arow < g.M);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, av), acc[t], 0, 0, 0);
+      }
+    }
+    // partials -> LDS: red[wave][m_local][n_local]
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      float* p = &red[((wave * MT * 16) + t * 16 + (lane & 15)) * 16 + (lane >> 4) * 4];
+      *reinterpret_cast<float4*>(p) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    }
+    __syncthreads();
+    for (int o = tid; o < MT * 64; o += 512) {
+      const int mm = o >> 2, q = o & 3;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        const float4 p = *reinterpret_cast<const float4*>(&red[((w * MT * 16) + mm) * 16 + q * 4]);
+        v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+      }
+      const int m = mc + mm, n = nt0 + q * 4;
+      if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, 0, m, n, v);
+    }
+    __syncthreads();
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// fp32 VALU kernel (parity compute type)
+// --------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[16][68];
+  __shared__ __attribute__((aligned(16))) float Bs[16][68];
+  const int tid = threadIdx.x;
+  const int ty = tid >> 4, tx = tid & 15;
+  const int z = blockIdx.z;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const float* __restrict__ A = reinterpret_cast<const float*>(g.A) + (int64_t)z * g.a_batch;
+  const float* __restrict__ W = reinterpret_cast<const float*>(g.W);
+  const int lrow = tid >> 2, lk = (tid & 3) * 4;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int k0 = 0; k0 < g.K; k0 += 16) {
+    const bool kin = k0 + lk < g.K;
+    const int kc = kin ? k0 + lk : 0;
+    const uint4 au = ldg16_pred(A + (int64_t)min(m0 + lrow, g.M - 1) * g.lda + kc, kin && m0 + lrow < g.M);
+    const uint4 bu = ldg16_pred(W + (int64_t)min(n0 + lrow, g.N - 1) * g.ldw + kc, kin && n0 + lrow < g.N);
+    const float4 a = make_float4(__uint_as_float(au.x), __uint_as_float(au.y), __uint_as_float(au.z), __uint_as_float(au.w));
+    const float4 b = make_float4(__uint_as_float(bu.x), __uint_as_float(bu.y), __uint_as_float(bu.z), __uint_as_float(bu.w));
+    As[lk + 0][lrow] = a.x; As[lk + 1][lrow] = a.y; As[lk + 2][lrow] = a.z; As[lk + 3][lrow] = a.w;
+    Bs[lk + 0][lrow] = b.x; Bs[lk + 1][lrow] = b.y; Bs[lk + 2][lrow] = b.z; Bs[lk + 3][lrow] = b.w;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 a4 = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
+      const float4 b4 = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+      const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  if constexpr (EPI == EPI_VT) {
+    const int m = m0 + ty * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      float v[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+      if (m < g.M && n < g.N) epi_vt<float>(g, z, m, n, v);
+    }
+  } else {
+    const int n = n0 + tx * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + ty * 4 + i;
+      float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+      if (m < g.M && n < g.N) epi_nm<EPI, float>(g, z, m, n, v);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// dispatch
+// --------------------------------------------------------------------------------------------
+template <int EPI>
+static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) {
+  if (dtype == WJ_F32) {
+    dim3 grid(ceil_div(a.N, 64), ceil_div(a.M, 64), a.nbatch);
+    hipLaunchKernelGGL(gemm_f32_kernel<EPI>, grid, dim3(256), 0, s, a);
+    WJ_LAUNCH_CHECK();
+    return WJ_OK;
+  }
+  const bool skinny_ok = (EPI != EPI_VT) && a.nbatch == 1;
+  bool skinny = skinny_ok && a.M <= 512;
+  if (variant == 1) skinny = false;
+  if (variant == 2) {
+    if (!skinny_ok) { set_error("skinny GEMM does not support this epilogue/batching"); return WJ_E_INVALID; }
+    skinny = true;
+  }
+  if (skinny) {
+    if constexpr (EPI != EPI_VT) {
+      dim3 grid(ceil_div(a.N, 16));
+      if (a.M <= 16) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, 1>), grid, dim3(512), 0, s, a);
+      else if (a.M <= 32) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, 2>), grid, dim3(512), 0, s, a);
+      else if (a.M <= 64) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, 4>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, 8>), grid, dim3(512), 0, s, a);
+      WJ_LAUNCH_CHECK();
+    }
+    return WJ_OK;
+  }
+  dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), a.nbatch);
+  hipLaunchKernelGGL(gemm_bf16_tile_kernel<EPI>, grid, dim3(256), 0, s, a);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int variant) {
+  const int kalign = dtype == WJ_BF16 ? 8 : 4;
+  if (a.K % kalign || a.lda % kalign || a.ldw % kalign || a.a_batch % kalign) {
+    set_error("gemm: K/lda/ldw/a_batch must be multiples of %d elements (K=%d lda=%lld ldw=%lld)", kalign, a.K,
+              (long long)a.lda, (long long)a.ldw);
+    return WJ_E_INVALID;
+  }
+  if (epi != EPI_F32 && (a.N % 4)) { set_error("gemm: N must be a multiple of 4 for this epilogue"); return WJ_E_INVALID; }
+  if (epi == EPI_VT && (a.M % 4)) { set_error("gemm: M must be a multiple of 4 for EPI_VT"); return WJ_E_INVALID; }
+  if (a.M <= 0 || a.N <= 0) return WJ_OK;
+  switch (epi) {
+    case EPI_T: return launch_epi<EPI_T>(dtype, a, s, variant);
+    case EPI_GELU_T: return launch_epi<EPI_GELU_T>(dtype, a, s, variant);
+    case EPI_F32: return launch_epi<EPI_F32>(dtype, a, s, variant);
+    case EPI_RESID_F32: return launch_epi<EPI_RESID_F32>(dtype, a, s, variant);
+    case EPI_GELU_POS_F32: return launch_epi<EPI_GELU_POS_F32>(dtype, a, s, variant);
+    case EPI_QK_HEADS: return launch_epi<EPI_QK_HEADS>(dtype, a, s, variant);
+    case EPI_VT: return launch_epi<EPI_VT>(dtype, a, s, variant);
+    case EPI_QKV_DEC: return launch_epi<EPI_QKV_DEC>(dtype, a, s, variant);
+    case EPI_CKV: return launch_epi<EPI_CKV>(dtype, a, s, variant);
+    default: set_error("gemm: unknown epilogue %d", (int)epi); return WJ_E_INVALID;
+  }
+}
+
+}  // namespace wj

@@ -1,0 +1,112 @@
+// kernels.hpp -- internal launcher interface between the engine and the kernel translation units.
+#pragma once
+
+#include "common.hpp"
+
+namespace wj {
+
+// ---------------- GEMM: C = A[M,K] . W[N,K]^T (+bias) with fused epilogues ------------------
+enum Epi : int {
+  EPI_T = 0,         // out T  [z][M][ldc]  = acc + bias
+  EPI_GELU_T,        // out T               = gelu(acc + bias)
+  EPI_F32,           // out f32 [z][M][ldc] = acc + bias            (N tail safe)
+  EPI_RESID_F32,     // out f32 [z][M][ldc] += acc + bias           (residual stream)
+  EPI_GELU_POS_F32,  // out f32 [z][M][ldc] = gelu(acc + bias) + pos[m][n]   (conv2 + positional)
+  EPI_QK_HEADS,      // n <  D : out [z][h][m][64] (Q) ; n >= D : out2 [z][h][m][64] (K); rows/head = Tpad
+  EPI_VT,            // out [z][h][dd][Tpad]  (V transposed per head; "MN" accumulator orientation)
+  EPI_QKV_DEC,       // decode step: n<D: out T [M][D]; then K,V -> caches out2/out3 [m][h][cache_len][64] at *pos_ptr
+  EPI_CKV,           // cross K/V: n<D: out [z][h][m][64] ; n>=D: out2 [z][h][m][64]; rows/head = Tpad
+  EPI_COUNT
+};
+
+struct GemmArgs {
+  const void* A = nullptr;   // T, row stride lda (elements), batch stride a_batch
+  int64_t lda = 0, a_batch = 0;
+  const void* W = nullptr;   // T [N][ldw]
+  int64_t ldw = 0;
+  const float* bias = nullptr;
+  int M = 0, N = 0, K = 0, nbatch = 1;
+  void* out = nullptr;
+  int64_t ldc = 0, c_batch = 0;
+  void* out2 = nullptr;
+  void* out3 = nullptr;
+  const float* pos = nullptr;   // [M][N] fp32
+  int D = 0, H = 0, Tpad = 0;
+  const int* pos_ptr = nullptr;
+  int cache_len = 0;
+};
+
+// variant: 0 = auto; 1 = force tiled MFMA kernel; 2 = force skinny (decode) kernel
+int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int variant = 0);
+
+// ---------------- normalisation / elementwise ------------------------------------------------
+int launch_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, int M, int D,
+                     hipStream_t s);
+// mel f32 [B][n_mels][frames] -> engine layout T [B][frames+2][n_mels] (row 0 and frames+1 stay zero)
+int launch_mel_to_rows(int dtype, const float* mel, void* out, int B, int n_mels, int frames, hipStream_t s);
+// decoder embedding: x[r][:] = tok_emb[token[r]][:] + pos_emb[*pos][:]
+int launch_embed(int dtype, const void* tok_emb, const float* pos_emb, const int32_t* tokens, int64_t tok_stride,
+                 const int* pos_ptr, float* x, int R, int D, hipStream_t s);
+int launch_f32_to_T(int dtype, const float* in, void* out, int64_t n, hipStream_t s);
+
+// ---------------- attention --------------------------------------------------------------------
+// encoder: Q,K [B][H][Tpad][64], Vt [B][H][64][Tpad] (T dtype) -> out T [B][T][H*64]
+int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt, void* out, int B, int T,
+                         int Tpad, int H, hipStream_t s);
+// decode: q T [G*nb][H*64]; K,V laid out [group][H][kv_stride][64]. n_keys from n_keys_ptr (device,
+// +1 applied when SELF) or the constant n_keys.  row_map (device, may be NULL): for SELF attention,
+// src_row[r][j] = physical cache row holding position j of logical row r (beam indirection).
+struct DecAttnArgs {
+  const void* q = nullptr;
+  const void* K = nullptr;
+  const void* V = nullptr;
+  void* out = nullptr;
+  int G = 0, nb = 1, H = 0;
+  int n_keys = 0;
+  const int* n_keys_ptr = nullptr;   // if set: n_keys = *ptr + 1
+  int kv_stride = 0;                 // positions allocated per (group, head)
+  const int32_t* row_map = nullptr;  // [G][kv_stride]
+  const int32_t* group_of = nullptr; // [G] window slot per group (cross attention), NULL = identity
+};
+int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s);
+
+// ---------------- sampling -----------------------------------------------------------------------
+struct GreedyArgs {
+  const float* logits = nullptr;  // [R][ldl]
+  int64_t ldl = 0;
+  int R = 0, V = 0;
+  int32_t* tokens = nullptr;      // [R][tok_stride] full history (prompt + sampled)
+  int64_t tok_stride = 0;
+  const int* pos_ptr = nullptr;   // device: index of the LAST token fed (history length - 1)
+  int sample_begin = 0;           // prompt length
+  float* sum_logprob = nullptr;   // [R]
+  float* token_logprob = nullptr; // [R][tok_stride] or NULL
+  int32_t* finished = nullptr;    // [R]
+  wj_decode_opts opts;
+};
+int launch_greedy_sample(const GreedyArgs& a, hipStream_t s);
+int launch_no_speech_prob(const float* logits, int64_t ldl, int R, int V, int no_speech_id, float* out,
+                          hipStream_t s);
+// masked log-softmax + top-k (k <= 16) per row
+int launch_topk_logprob(const float* logits, int64_t ldl, int R, int V, int k, const uint8_t* ban,
+                        int32_t* ids, float* logprobs, float* lse, hipStream_t s);
+int launch_advance_pos(int* pos_ptr, hipStream_t s);
+// row_map update for beam search: new_map[r][0..pos-1] = old_map[parent[r]][..]; new_map[r][pos] = r
+int launch_rebind_rows(const int32_t* old_map, int32_t* new_map, const int32_t* parent, const int* pos_ptr,
+                       int R, int stride, hipStream_t s);
+
+// ---------------- profiler (engine.hip) -------------------------------------------------------
+enum ProfTag : int {
+  PT_MEL_ROWS = 0, PT_CONV1, PT_CONV2, PT_E_LN, PT_E_QK, PT_E_V, PT_E_ATTN, PT_E_OUT, PT_E_FC1, PT_E_FC2, PT_E_CKV,
+  PT_D_EMBED, PT_D_LN, PT_D_QKV, PT_D_SELF, PT_D_OUT, PT_D_CQ, PT_D_CROSS, PT_D_COUT, PT_D_FC1, PT_D_FC2, PT_D_LOGITS,
+  PT_D_SAMPLE, PT_D_MISC, PT_COUNT
+};
+void prof_begin(wj_ctx* ctx, int tag, hipStream_t s);
+void prof_end(wj_ctx* ctx, hipStream_t s);
+inline bool prof_on(const wj_ctx* ctx) { return ctx->prof != nullptr; }
+
+// ---------------- log-mel ----------------------------------------------------------------------
+int logmel_run(wj_ctx* ctx, const float* pcm, const int64_t* offsets_host, int n_clips, int n_mels, int mode,
+               int out_frames, float* out, hipStream_t s);
+
+}  // namespace wj

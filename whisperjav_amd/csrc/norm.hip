@@ -1,0 +1,155 @@
+// norm.hip -- LayerNorm, layout/convert helpers, decoder embedding, decode-state bookkeeping.
+// All HBM-bound elementwise work: one wavefront per row, 64-lane coalesced strides.
+#include "kernels.hpp"
+
+namespace wj {
+
+// One wave per row; two-pass (mean, then centred variance) in registers like torch's CPU kernel.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, T* __restrict__ out, int M,
+                                                        int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * D;
+  float v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    v[i] = c < D ? xr[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    const float d = c < D ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+  T* o = out + (int64_t)row * D;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < D) Elem<T>::st(o + c, (v[i] - mean) * rstd * w[c] + b[c]);
+  }
+}
+
+int launch_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, int M, int D,
+                     hipStream_t s) {
+  if (D > 64 * 20 || D <= 0) { set_error("layernorm: D=%d unsupported (max 1280)", D); return WJ_E_INVALID; }
+  if (M <= 0) return WJ_OK;
+  dim3 grid(ceil_div(M, 4));
+  if (dtype == WJ_F32)
+    hipLaunchKernelGGL((layernorm_kernel<float, 20>), grid, dim3(256), 0, s, x, w, b, (float*)out, M, D);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t, 20>), grid, dim3(256), 0, s, x, w, b, (bf16_t*)out, M, D);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+// mel f32 [B][C][F] -> rows T [B][F+2][C] (pad rows untouched = zero); 32x32 LDS transpose tiles
+template <typename T>
+__global__ __launch_bounds__(256) void mel_to_rows_kernel(const float* __restrict__ mel, T* __restrict__ out, int C,
+                                                          int F) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int f0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, f = f0 + tx;
+    tile[r][tx] = (c < C && f < F) ? mel[((int64_t)b * C + c) * F + f] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int f = f0 + r, c = c0 + tx;
+    if (c < C && f < F) Elem<T>::st(out + ((int64_t)b * (F + 2) + f + 1) * C + c, tile[tx][r]);
+  }
+}
+
+int launch_mel_to_rows(int dtype, const float* mel, void* out, int B, int n_mels, int frames, hipStream_t s) {
+  dim3 grid(ceil_div(frames, 32), ceil_div(n_mels, 32), B);
+  if (dtype == WJ_F32)
+    hipLaunchKernelGGL(mel_to_rows_kernel<float>, grid, dim3(256), 0, s, mel, (float*)out, n_mels, frames);
+  else
+    hipLaunchKernelGGL(mel_to_rows_kernel<bf16_t>, grid, dim3(256), 0, s, mel, (bf16_t*)out, n_mels, frames);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_kernel(const T* __restrict__ emb, const float* __restrict__ pos_emb,
+                                                    const int32_t* __restrict__ tokens, int64_t tok_stride,
+                                                    const int* __restrict__ pos_ptr, float* __restrict__ x, int D) {
+  const int r = blockIdx.x;
+  const int pos = *pos_ptr;
+  const int tok = tokens[(int64_t)r * tok_stride + pos];
+  const T* e = emb + (int64_t)tok * D;
+  const float* p = pos_emb + (int64_t)pos * D;
+  for (int c = threadIdx.x; c < D; c += 256) x[(int64_t)r * D + c] = Elem<T>::ld(e + c) + p[c];
+}
+
+int launch_embed(int dtype, const void* tok_emb, const float* pos_emb, const int32_t* tokens, int64_t tok_stride,
+                 const int* pos_ptr, float* x, int R, int D, hipStream_t s) {
+  if (dtype == WJ_F32)
+    hipLaunchKernelGGL(embed_kernel<float>, dim3(R), dim3(256), 0, s, (const float*)tok_emb, pos_emb, tokens,
+                       tok_stride, pos_ptr, x, D);
+  else
+    hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(R), dim3(256), 0, s, (const bf16_t*)tok_emb, pos_emb, tokens,
+                       tok_stride, pos_ptr, x, D);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void f32_to_T_kernel(const float* __restrict__ in, T* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    Elem<T>::st(out + i, in[i]);
+}
+
+int launch_f32_to_T(int dtype, const float* in, void* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return WJ_OK;
+  const int blocks = (int)min((int64_t)4096, ceil_div64(n, 256));
+  if (dtype == WJ_F32)
+    hipLaunchKernelGGL(f32_to_T_kernel<float>, dim3(blocks), dim3(256), 0, s, in, (float*)out, n);
+  else
+    hipLaunchKernelGGL(f32_to_T_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, in, (bf16_t*)out, n);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+__global__ void advance_pos_kernel(int* pos) { if (threadIdx.x == 0) *pos += 1; }
+
+int launch_advance_pos(int* pos_ptr, hipStream_t s) {
+  hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, s, pos_ptr);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+// Beam search re-binding: logical row r continues the history of old logical row parent[r].
+// row_map[r][j] = physical KV-cache row that holds position j of r's history.
+__global__ __launch_bounds__(256) void rebind_rows_kernel(const int32_t* __restrict__ old_map,
+                                                          int32_t* __restrict__ new_map,
+                                                          const int32_t* __restrict__ parent,
+                                                          const int* __restrict__ pos_ptr, int stride) {
+  const int r = blockIdx.x;
+  const int pos = *pos_ptr;
+  const int p = parent[r];
+  for (int j = threadIdx.x; j < stride; j += 256) {
+    int32_t v = r;
+    if (j < pos) v = old_map[(int64_t)p * stride + j];
+    new_map[(int64_t)r * stride + j] = v;
+  }
+}
+
+int launch_rebind_rows(const int32_t* old_map, int32_t* new_map, const int32_t* parent, const int* pos_ptr, int R,
+                       int stride, hipStream_t s) {
+  hipLaunchKernelGGL(rebind_rows_kernel, dim3(R), dim3(256), 0, s, old_map, new_map, parent, pos_ptr, stride);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+}  // namespace wj

@@ -1,0 +1,254 @@
+// sampler.hip -- vocabulary-wide passes of the decode step: Whisper's logit filters
+// (SuppressTokens, SuppressBlank, ApplyTimestampRules), log-softmax, greedy pick, no-speech
+// probability and masked top-k for host-driven beam search.  One workgroup per hypothesis row;
+// everything is fp32 and deterministic (ties break to the lowest token id).
+//
+// The filter semantics restate whisper/decoding.py (openai-whisper 20250625: SuppressBlank,
+// SuppressTokens, ApplyTimestampRules, GreedyDecoder.update) which CTranslate2 4.7.1 mirrors for
+// faster-whisper (reference call sites: whisperjav/modules/faster_whisper_pro_asr.py:819,
+// whisperjav/modules/whisper_pro_asr.py:433).
+#include "kernels.hpp"
+
+namespace wj {
+
+struct ArgMax {
+  float v;
+  int i;
+};
+__device__ __forceinline__ ArgMax amax(ArgMax a, ArgMax b) {
+  if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+  return a;
+}
+__device__ __forceinline__ ArgMax wave_amax(ArgMax a) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ArgMax b;
+    b.v = __shfl_xor(a.v, o, 64);
+    b.i = __shfl_xor(a.i, o, 64);
+    a = amax(a, b);
+  }
+  return a;
+}
+
+struct RowRules {
+  int first, ts_rules, last_ts, penult_ts, ts_floor;
+};
+
+__device__ __forceinline__ bool token_allowed(int v, const RowRules& rr, const wj_decode_opts& o) {
+  if (o.suppress_mask_dev && o.suppress_mask_dev[v]) return false;
+  if (rr.first && o.suppress_blank && (v == o.blank || v == o.eot)) return false;
+  if (rr.ts_rules) {
+    if (v == o.no_timestamps) return false;
+    if (rr.last_ts) {
+      if (rr.penult_ts) {
+        if (v >= o.timestamp_begin) return false;   // a pair just closed: text (or EOT) must follow
+      } else {
+        if (v < o.eot) return false;                // an opening timestamp must be closed (or EOT)
+      }
+    }
+    if (rr.ts_floor >= 0 && v >= o.timestamp_begin && v < rr.ts_floor) return false;
+    if (rr.first) {
+      if (v < o.timestamp_begin) return false;
+      if (o.max_initial_timestamp_index >= 0 && v > o.timestamp_begin + o.max_initial_timestamp_index) return false;
+    }
+  }
+  return true;
+}
+
+constexpr int SB = 256;  // sampler block size
+
+__global__ __launch_bounds__(SB) void greedy_sample_kernel(const GreedyArgs a) {
+  __shared__ float s_f[4][SB / 64];
+  __shared__ int s_i[2][SB / 64];
+  __shared__ RowRules s_rr;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int len = *a.pos_ptr + 1;  // tokens in the history (prompt + sampled so far)
+  int32_t* tok = a.tokens + (int64_t)r * a.tok_stride;
+  const wj_decode_opts& o = a.opts;
+  if (a.finished[r]) {
+    if (tid == 0) {
+      tok[len] = o.eot;
+      if (a.token_logprob) a.token_logprob[(int64_t)r * a.tok_stride + len] = 0.f;
+    }
+    return;
+  }
+  if (tid == 0) {
+    RowRules rr;
+    const int ns = len - a.sample_begin;
+    rr.first = ns == 0;
+    rr.ts_rules = !o.without_timestamps;
+    rr.last_ts = ns >= 1 && tok[len - 1] >= o.timestamp_begin;
+    rr.penult_ts = ns < 2 || tok[len - 2] >= o.timestamp_begin;
+    int ts_last = -1;
+    for (int i = a.sample_begin; i < len; ++i)
+      if (tok[i] >= o.timestamp_begin) ts_last = tok[i];
+    rr.ts_floor = -1;
+    if (ts_last >= 0) rr.ts_floor = (rr.last_ts && !rr.penult_ts) ? ts_last : ts_last + 1;
+    s_rr = rr;
+  }
+  __syncthreads();
+  const RowRules rr = s_rr;
+  const float* x = a.logits + (int64_t)r * a.ldl;
+
+  // pass A: maxima
+  ArgMax best_all = {-INFINITY, 0x7fffffff}, best_ts = {-INFINITY, 0x7fffffff};
+  float max_text = -INFINITY;
+  for (int v = tid; v < a.V; v += SB) {
+    if (!token_allowed(v, rr, o)) continue;
+    const float xv = x[v];
+    best_all = amax(best_all, ArgMax{xv, v});
+    if (v >= o.timestamp_begin) best_ts = amax(best_ts, ArgMax{xv, v});
+    else max_text = fmaxf(max_text, xv);
+  }
+  best_all = wave_amax(best_all);
+  best_ts = wave_amax(best_ts);
+  max_text = wave_max(max_text);
+  if (lane == 0) {
+    s_f[0][wave] = best_all.v; s_i[0][wave] = best_all.i;
+    s_f[1][wave] = best_ts.v;  s_i[1][wave] = best_ts.i;
+    s_f[2][wave] = max_text;
+  }
+  __syncthreads();
+  best_all = ArgMax{s_f[0][0], s_i[0][0]};
+  best_ts = ArgMax{s_f[1][0], s_i[1][0]};
+  max_text = s_f[2][0];
+#pragma unroll
+  for (int w = 1; w < SB / 64; ++w) {
+    best_all = amax(best_all, ArgMax{s_f[0][w], s_i[0][w]});
+    best_ts = amax(best_ts, ArgMax{s_f[1][w], s_i[1][w]});
+    max_text = fmaxf(max_text, s_f[2][w]);
+  }
+  __syncthreads();
+
+  // pass B: partition sums relative to the global max
+  float sum_all = 0.f, sum_ts = 0.f;
+  for (int v = tid; v < a.V; v += SB) {
+    if (!token_allowed(v, rr, o)) continue;
+    const float e = expf(x[v] - best_all.v);
+    sum_all += e;
+    if (v >= o.timestamp_begin) sum_ts += e;
+  }
+  sum_all = wave_sum(sum_all);
+  sum_ts = wave_sum(sum_ts);
+  if (lane == 0) { s_f[0][wave] = sum_all; s_f[1][wave] = sum_ts; }
+  __syncthreads();
+  if (tid == 0) {
+    sum_all = 0.f; sum_ts = 0.f;
+    for (int w = 0; w < SB / 64; ++w) { sum_all += s_f[0][w]; sum_ts += s_f[1][w]; }
+    const float lse = best_all.v + logf(sum_all);
+    int token = best_all.i;
+    float lp = best_all.v - lse;
+    if (rr.ts_rules && sum_ts > 0.f) {
+      // "if the probability mass on timestamps exceeds every single text token, emit a timestamp"
+      const float ts_lp = best_all.v + logf(sum_ts) - lse;
+      const float text_lp = max_text - lse;
+      if (ts_lp > text_lp) {
+        token = best_ts.i;
+        lp = best_ts.v - (best_all.v + logf(sum_ts));   // renormalised over timestamps only
+      }
+    }
+    tok[len] = token;
+    a.sum_logprob[r] += lp;
+    if (a.token_logprob) a.token_logprob[(int64_t)r * a.tok_stride + len] = lp;
+    if (token == o.eot) a.finished[r] = 1;
+  }
+}
+
+int launch_greedy_sample(const GreedyArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(greedy_sample_kernel, dim3(a.R), dim3(SB), 0, s, a);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+__global__ __launch_bounds__(SB) void no_speech_kernel(const float* __restrict__ logits, int64_t ldl, int V, int ns_id,
+                                                       float* __restrict__ out) {
+  __shared__ float s_f[SB / 64];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = logits + (int64_t)r * ldl;
+  float mx = -INFINITY;
+  for (int v = tid; v < V; v += SB) mx = fmaxf(mx, x[v]);
+  mx = wave_max(mx);
+  if (lane == 0) s_f[wave] = mx;
+  __syncthreads();
+  mx = s_f[0];
+  for (int w = 1; w < SB / 64; ++w) mx = fmaxf(mx, s_f[w]);
+  __syncthreads();
+  float sum = 0.f;
+  for (int v = tid; v < V; v += SB) sum += expf(x[v] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) s_f[wave] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    sum = 0.f;
+    for (int w = 0; w < SB / 64; ++w) sum += s_f[w];
+    out[r] = expf(x[ns_id] - mx) / sum;
+  }
+}
+
+int launch_no_speech_prob(const float* logits, int64_t ldl, int R, int V, int no_speech_id, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(no_speech_kernel, dim3(R), dim3(SB), 0, s, logits, ldl, V, no_speech_id, out);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+// masked log-softmax + top-k by k rounds of block arg-max (k <= 16), lowest id wins ties
+__global__ __launch_bounds__(SB) void topk_logprob_kernel(const float* __restrict__ logits, int64_t ldl, int V, int k,
+                                                          const uint8_t* __restrict__ ban, int32_t* __restrict__ ids,
+                                                          float* __restrict__ logprobs, float* __restrict__ lse_out) {
+  __shared__ float s_f[SB / 64];
+  __shared__ int s_i[SB / 64];
+  __shared__ int s_sel[16];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = logits + (int64_t)r * ldl;
+  const uint8_t* bm = ban ? ban + (int64_t)r * V : nullptr;
+  float mx = -INFINITY;
+  for (int v = tid; v < V; v += SB)
+    if (!bm || !bm[v]) mx = fmaxf(mx, x[v]);
+  mx = wave_max(mx);
+  if (lane == 0) s_f[wave] = mx;
+  __syncthreads();
+  mx = s_f[0];
+  for (int w = 1; w < SB / 64; ++w) mx = fmaxf(mx, s_f[w]);
+  __syncthreads();
+  float sum = 0.f;
+  for (int v = tid; v < V; v += SB)
+    if (!bm || !bm[v]) sum += expf(x[v] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) s_f[wave] = sum;
+  __syncthreads();
+  sum = 0.f;
+  for (int w = 0; w < SB / 64; ++w) sum += s_f[w];
+  const float lse = mx + logf(sum);
+  __syncthreads();
+  if (tid == 0 && lse_out) lse_out[r] = lse;
+  for (int round = 0; round < k; ++round) {
+    ArgMax best = {-INFINITY, 0x7fffffff};
+    for (int v = tid; v < V; v += SB) {
+      if (bm && bm[v]) continue;
+      bool taken = false;
+      for (int q = 0; q < round; ++q) taken |= (s_sel[q] == v);
+      if (!taken) best = amax(best, ArgMax{x[v], v});
+    }
+    best = wave_amax(best);
+    if (lane == 0) { s_f[wave] = best.v; s_i[wave] = best.i; }
+    __syncthreads();
+    if (tid == 0) {
+      ArgMax b = {s_f[0], s_i[0]};
+      for (int w = 1; w < SB / 64; ++w) b = amax(b, ArgMax{s_f[w], s_i[w]});
+      s_sel[round] = b.i;
+      ids[(int64_t)r * k + round] = b.i == 0x7fffffff ? -1 : b.i;
+      logprobs[(int64_t)r * k + round] = b.v - lse;
+    }
+    __syncthreads();
+  }
+}
+
+int launch_topk_logprob(const float* logits, int64_t ldl, int R, int V, int k, const uint8_t* ban, int32_t* ids,
+                        float* logprobs, float* lse, hipStream_t s) {
+  if (k < 1 || k > 16) { set_error("topk: k must be in 1..16"); return WJ_E_INVALID; }
+  hipLaunchKernelGGL(topk_logprob_kernel, dim3(R), dim3(SB), 0, s, logits, ldl, V, k, ban, ids, logprobs, lse);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+}  // namespace wj

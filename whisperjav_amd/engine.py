@@ -1,0 +1,322 @@
+"""Python face of the HIP engine: device-resident log-mel, Whisper encode / decode, VAD scoring.
+
+PyTorch is used for plumbing only (HBM allocation, host<->device copies, the RCCL weight
+broadcast in ``sharding.py``); every FLOP of the path runs in libwjhip's hand-written gfx950
+kernels through the C ABI (``include/wjhip.h``).  Nothing here falls back to PyTorch or NumPy math:
+without the library or without an MI355X the constructors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import hipbind
+from .dims import SpecialTokens, WhisperDims, special_tokens
+from .hipbind import DTYPES, WJ_MEL_FW, WJ_MEL_OW, check
+
+N_FRAMES = 3000
+MEL_MODES = {"fw": WJ_MEL_FW, "ow": WJ_MEL_OW}
+
+
+def _require_gpu(device: int) -> torch.device:
+    if not torch.cuda.is_available():
+        raise hipbind.WjError("no ROCm device visible: the HIP path has no CPU fallback")
+    return torch.device("cuda", device)
+
+
+def _ptr(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def _torch_sync() -> None:
+    torch.cuda.current_stream().synchronize()
+
+
+class HipLogMel:
+    """Batched log-mel extractor (``wj_logmel_f32``).
+
+    ``mode='fw'`` reproduces faster-whisper's FeatureExtractor (+ zero ``pad_or_trim`` of the frame
+    axis), ``mode='ow'`` openai-whisper's ``log_mel_spectrogram(padding=N_SAMPLES)``.
+    """
+
+    def __init__(self, n_mels: int = 128, mode: str = "fw", device: int = 0):
+        if mode not in MEL_MODES:
+            raise ValueError(f"mode must be one of {sorted(MEL_MODES)}")
+        self.n_mels, self.mode, self.device = int(n_mels), mode, int(device)
+        self.dev = _require_gpu(device)
+        self.ctx = hipbind.context(device)
+        self._lib = hipbind.lib()
+
+    def frames(self, n_samples: int) -> int:
+        return int(self._lib.wj_logmel_frames(int(n_samples), MEL_MODES[self.mode]))
+
+    def from_device(self, pcm: torch.Tensor, offsets: Sequence[int], out_frames: int = N_FRAMES) -> torch.Tensor:
+        """pcm: float32 CUDA tensor holding all clips back to back; offsets: n_clips+1 sample offsets."""
+        if pcm.dtype != torch.float32 or not pcm.is_cuda or not pcm.is_contiguous():
+            raise ValueError("pcm must be a contiguous float32 CUDA tensor")
+        n = len(offsets) - 1
+        off = (C.c_int64 * (n + 1))(*[int(o) for o in offsets])
+        out = torch.empty((n, self.n_mels, out_frames), dtype=torch.float32, device=self.dev)
+        _torch_sync()
+        check(self._lib.wj_logmel_f32(self.ctx.handle, _ptr(pcm), off, n, self.n_mels, MEL_MODES[self.mode],
+                                      int(out_frames), _ptr(out), None), "wj_logmel_f32")
+        self.ctx.sync()
+        return out
+
+    def __call__(self, clips: Sequence[np.ndarray], out_frames: int = N_FRAMES) -> torch.Tensor:
+        arrs = [np.ascontiguousarray(c, dtype=np.float32).reshape(-1) for c in clips]
+        offsets = np.concatenate([[0], np.cumsum([a.shape[0] for a in arrs])]).astype(np.int64)
+        pcm = torch.from_numpy(np.concatenate(arrs)).to(self.dev)
+        return self.from_device(pcm, offsets.tolist(), out_frames)
+
+
+@dataclass
+class DecodeOptions:
+    """Per-call decode options (a subset of faster-whisper's ``transcribe`` kwargs that reach the
+    token loop; see ``FasterWhisperProASR._prepare_whisper_params``,
+    /root/reference/whisperjav/modules/faster_whisper_pro_asr.py:340-436)."""
+    max_new_tokens: int = 224
+    suppress_blank: bool = True
+    without_timestamps: bool = False
+    max_initial_timestamp: Optional[float] = 1.0
+    suppress_tokens: Sequence[int] = field(default_factory=tuple)
+
+
+@dataclass
+class GreedyResult:
+    tokens: np.ndarray          # int32 [B, max_new] (eot padded)
+    n_tokens: np.ndarray        # int32 [B]
+    sum_logprob: np.ndarray     # float32 [B]
+    no_speech_prob: np.ndarray  # float32 [B]
+    token_logprob: np.ndarray   # float32 [B, max_new]
+
+    def avg_logprob(self) -> np.ndarray:
+        """``cum_logprob / (len + 1)`` as faster-whisper / openai-whisper report it."""
+        return self.sum_logprob / (self.n_tokens.astype(np.float32) + 1.0)
+
+
+class HipWhisper:
+    """A Whisper model resident in HBM (``wj_whisper_*``)."""
+
+    def __init__(self, dims: WhisperDims, weights: Union[Dict[str, np.ndarray], None] = None, *,
+                 blob: Optional[torch.Tensor] = None, offsets: Optional[np.ndarray] = None,
+                 dtype: str = "bfloat16", device: int = 0, max_batch: int = 8, max_beam: int = 1):
+        from . import weights as W
+        if dtype not in DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(DTYPES)}")
+        self.dims, self.dtype, self.device = dims, dtype, int(device)
+        self.dev = _require_gpu(device)
+        self.ctx = hipbind.context(device)
+        self._lib = hipbind.lib()
+        self.tokens: SpecialTokens = special_tokens(dims.n_vocab)
+        if blob is None:
+            if weights is None:
+                raise ValueError("either weights or (blob, offsets) is required")
+            host_blob, offsets = W.pack_blob(dims, weights, dtype)
+            blob = host_blob.to(self.dev)
+        elif offsets is None:
+            raise ValueError("offsets are required with a pre-packed blob")
+        if not blob.is_cuda or blob.dtype != torch.uint8:
+            raise ValueError("blob must be a uint8 CUDA tensor")
+        self.blob = blob  # keeps the HBM alive; the library only borrows it
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.max_batch, self.max_beam = int(max_batch), int(max_beam)
+        cd = hipbind.WhisperDimsC(**dims.as_dict())
+        handle = C.c_void_p()
+        off = (C.c_int64 * len(self.offsets))(*self.offsets.tolist())
+        _torch_sync()
+        check(self._lib.wj_whisper_create(self.ctx.handle, C.byref(cd), DTYPES[dtype], _ptr(blob), blob.numel(), off,
+                                          len(self.offsets), self.max_batch, self.max_batch * self.max_beam,
+                                          C.byref(handle)), "wj_whisper_create")
+        self.handle = handle
+        self._suppress_mask: Optional[torch.Tensor] = None
+        self._suppress_key = None
+
+    # ---- lifetime -------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._lib.wj_whisper_free(self.handle)
+            self.handle = None
+
+    def __del__(self):  # the reference may never call cleanup() (os._exit); both paths are fine
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self._lib.wj_whisper_workspace_bytes(self.handle))
+
+    # ---- encoder --------------------------------------------------------------------------
+    def encode(self, mel: torch.Tensor, n_layers: int = -1, want_output: bool = False) -> Optional[torch.Tensor]:
+        """mel: float32 CUDA ``[B, n_mels, 3000]``.  Leaves encoder output + cross K/V resident."""
+        d = self.dims
+        if mel.dtype != torch.float32 or not mel.is_cuda or not mel.is_contiguous():
+            raise ValueError("mel must be a contiguous float32 CUDA tensor")
+        if mel.dim() != 3 or mel.shape[1] != d.n_mels or mel.shape[2] != 2 * d.n_audio_ctx:
+            raise ValueError(f"mel must be [B, {d.n_mels}, {2 * d.n_audio_ctx}], got {tuple(mel.shape)}")
+        B = mel.shape[0]
+        out = None
+        if want_output:
+            out = torch.empty((B, d.n_audio_ctx, d.n_audio_state), dtype=torch.float32, device=self.dev)
+        _torch_sync()
+        check(self._lib.wj_whisper_encode(self.handle, _ptr(mel), B, int(n_layers),
+                                          _ptr(out) if out is not None else None, None), "wj_whisper_encode")
+        self.ctx.sync()
+        return out
+
+    # ---- decoding -------------------------------------------------------------------------
+    def _mask_for(self, suppress: Sequence[int]) -> Optional[torch.Tensor]:
+        key = tuple(sorted(set(int(t) for t in suppress if t >= 0)))
+        if not key:
+            return None
+        if self._suppress_key != key:
+            m = torch.zeros(self.dims.n_vocab, dtype=torch.uint8)
+            m[list(key)] = 1
+            self._suppress_mask = m.to(self.dev)
+            self._suppress_key = key
+            _torch_sync()
+        return self._suppress_mask
+
+    def _opts(self, o: DecodeOptions) -> hipbind.DecodeOptsC:
+        t = self.tokens
+        mask = self._mask_for(o.suppress_tokens)
+        idx = -1
+        if o.max_initial_timestamp is not None:
+            idx = int(round(float(o.max_initial_timestamp) / 0.02))
+        return hipbind.DecodeOptsC(
+            max_new_tokens=int(o.max_new_tokens), suppress_blank=int(bool(o.suppress_blank)),
+            without_timestamps=int(bool(o.without_timestamps)), max_initial_timestamp_index=idx,
+            eot=t.eot, no_timestamps=t.no_timestamps, timestamp_begin=t.timestamp_begin, blank=t.blank,
+            no_speech=t.no_speech, suppress_mask_dev=mask.data_ptr() if mask is not None else None)
+
+    def decode_greedy(self, prompts: np.ndarray, options: Optional[DecodeOptions] = None) -> GreedyResult:
+        """Greedy decode of the windows currently resident (rows of ``prompts`` = windows)."""
+        o = options or DecodeOptions()
+        prompts = np.ascontiguousarray(prompts, dtype=np.int32)
+        if prompts.ndim != 2:
+            raise ValueError("prompts must be [batch, prompt_len]")
+        B, P = prompts.shape
+        oc = self._opts(o)
+        n = o.max_new_tokens
+        toks = np.empty((B, n), dtype=np.int32)
+        ntok = np.empty(B, dtype=np.int32)
+        slp = np.empty(B, dtype=np.float32)
+        nsp = np.empty(B, dtype=np.float32)
+        tlp = np.empty((B, n), dtype=np.float32)
+        as_i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+        as_f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        check(self._lib.wj_whisper_decode_greedy(self.handle, B, as_i(prompts), P, C.byref(oc), as_i(toks), as_i(ntok),
+                                                 as_f(slp), as_f(nsp), as_f(tlp), None), "wj_whisper_decode_greedy")
+        return GreedyResult(toks, ntok, slp, nsp, tlp)
+
+    def sot_prompt(self, language: str = "ja", task: str = "transcribe", without_timestamps: bool = False) -> List[int]:
+        from .dims import language_index
+        t = self.tokens
+        seq = [t.sot, t.language_token(language_index(language)), t.transcribe if task == "transcribe" else t.translate]
+        if without_timestamps:
+            seq.append(t.no_timestamps)
+        return seq
+
+    # ---- step-wise API for host-driven search (beam search lives in search.py) --------------
+    def open(self, batch: int, beam: int) -> None:
+        check(self._lib.wj_decode_open(self.handle, int(batch), int(beam), None), "wj_decode_open")
+        self._rows = batch * beam
+
+    def step(self, tokens: np.ndarray, parents: Optional[np.ndarray] = None, want_logits: bool = True) -> None:
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        if tokens.shape != (self._rows,):
+            raise ValueError(f"tokens must have shape ({self._rows},)")
+        pp = None
+        if parents is not None:
+            parents = np.ascontiguousarray(parents, dtype=np.int32)
+            pp = parents.ctypes.data_as(C.POINTER(C.c_int32))
+        check(self._lib.wj_decode_step(self.handle, tokens.ctypes.data_as(C.POINTER(C.c_int32)), pp,
+                                       int(want_logits), None), "wj_decode_step")
+
+    def logits(self) -> torch.Tensor:
+        """Copy of the device logits of the last step: float32 CUDA ``[rows, n_vocab]``."""
+        out = torch.empty((self._rows, self.dims.n_vocab), dtype=torch.float32, device=self.dev)
+        _torch_sync()
+        check(self._lib.wj_decode_logits_copy(self.handle, self._rows, _ptr(out), None), "wj_decode_logits_copy")
+        self.ctx.sync()
+        return out
+
+    def topk(self, k: int, ban: Optional[torch.Tensor] = None):
+        rows = self._rows
+        ids = np.empty((rows, k), dtype=np.int32)
+        lps = np.empty((rows, k), dtype=np.float32)
+        lse = np.empty(rows, dtype=np.float32)
+        if ban is not None:
+            if ban.dtype != torch.uint8 or not ban.is_cuda or ban.shape != (rows, self.dims.n_vocab):
+                raise ValueError("ban must be a uint8 CUDA tensor [rows, n_vocab]")
+            _torch_sync()
+        check(self._lib.wj_decode_topk(self.handle, rows, int(k), _ptr(ban) if ban is not None else None,
+                                       ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       lps.ctypes.data_as(C.POINTER(C.c_float)),
+                                       lse.ctypes.data_as(C.POINTER(C.c_float)), None), "wj_decode_topk")
+        return ids, lps, lse
+
+
+# ---- kernel-level entry points used by the parity tests ----------------------------------------
+def k_gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: str, gelu=False, out_f32=False,
+           variant=0, device: int = 0) -> torch.Tensor:
+    """C = A @ W^T (+bias); a [M,K], w [N,K] float32 CUDA tensors, converted to ``dtype`` first."""
+    ctx = hipbind.context(device)
+    lib = hipbind.lib()
+    td = torch.bfloat16 if dtype == "bfloat16" else torch.float32
+    A, Wt = a.to(td).contiguous(), w.to(td).contiguous()
+    M, K = A.shape
+    N = Wt.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else td, device=a.device)
+    _torch_sync()
+    check(lib.wj_k_gemm(ctx.handle, DTYPES[dtype], _ptr(A), _ptr(Wt), _ptr(bias) if bias is not None else None,
+                        _ptr(out), M, N, K, int(gelu), int(out_f32), int(variant), None), "wj_k_gemm")
+    ctx.sync()
+    return out.float()
+
+
+def k_layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, dtype: str, device: int = 0) -> torch.Tensor:
+    ctx = hipbind.context(device)
+    lib = hipbind.lib()
+    td = torch.bfloat16 if dtype == "bfloat16" else torch.float32
+    M, D = x.shape
+    out = torch.empty((M, D), dtype=td, device=x.device)
+    _torch_sync()
+    check(lib.wj_k_layernorm(ctx.handle, DTYPES[dtype], _ptr(x.contiguous()), _ptr(w), _ptr(b), _ptr(out), M, D, None),
+          "wj_k_layernorm")
+    ctx.sync()
+    return out.float()
+
+
+def k_attention_enc(qkv: torch.Tensor, heads: int, dtype: str, device: int = 0) -> torch.Tensor:
+    """qkv float32 CUDA [B, T, 3*D] -> attention output float32 [B, T, D]."""
+    ctx = hipbind.context(device)
+    lib = hipbind.lib()
+    td = torch.bfloat16 if dtype == "bfloat16" else torch.float32
+    B, T, D3 = qkv.shape
+    out = torch.empty((B, T, D3 // 3), dtype=td, device=qkv.device)
+    _torch_sync()
+    check(lib.wj_k_attention_enc(ctx.handle, DTYPES[dtype], _ptr(qkv.contiguous()), _ptr(out), B, T, heads, None),
+          "wj_k_attention_enc")
+    ctx.sync()
+    return out.float()
+
+
+def k_attention_dec(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dtype: str, device: int = 0) -> torch.Tensor:
+    """q [G, nb, H*64], k/v [G, H, n_keys, 64] float32 CUDA -> out float32 [G, nb, H*64]."""
+    ctx = hipbind.context(device)
+    lib = hipbind.lib()
+    G, nb, D = q.shape
+    H, n_keys = k.shape[1], k.shape[2]
+    out = torch.empty((G, nb, D), dtype=torch.float32, device=q.device)
+    _torch_sync()
+    check(lib.wj_k_attention_dec(ctx.handle, DTYPES[dtype], _ptr(q.contiguous()), _ptr(k.contiguous()),
+                                 _ptr(v.contiguous()), _ptr(out), G, nb, H, n_keys, None), "wj_k_attention_dec")
+    ctx.sync()
+    return out

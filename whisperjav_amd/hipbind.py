@@ -1,0 +1,155 @@
+"""ctypes binding of libwjhip.so (the C ABI in include/wjhip.h).
+
+There is deliberately NO fallback: if the library is missing, was built for another ABI version,
+or no gfx950 device is visible, the calls raise.  ``lib()`` only needs the shared object (it can be
+loaded without a GPU, e.g. to check the exported symbols); anything that touches a device goes
+through ``Context``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional
+
+ABI_VERSION = 1
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwjhip.so"
+_lib: Optional[C.CDLL] = None
+
+WJ_F32, WJ_BF16 = 0, 1
+WJ_MEL_FW, WJ_MEL_OW = 0, 1
+DTYPES = {"float32": WJ_F32, "bfloat16": WJ_BF16}
+
+
+class WjError(RuntimeError):
+    """A libwjhip call failed (message from wj_last_error())."""
+
+
+class WhisperDimsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_mels", "n_audio_ctx", "n_audio_state", "n_audio_head", "n_audio_layer",
+        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")]
+
+
+class DecodeOptsC(C.Structure):
+    _fields_ = [
+        ("max_new_tokens", C.c_int32), ("suppress_blank", C.c_int32), ("without_timestamps", C.c_int32),
+        ("max_initial_timestamp_index", C.c_int32), ("eot", C.c_int32), ("no_timestamps", C.c_int32),
+        ("timestamp_begin", C.c_int32), ("blank", C.c_int32), ("no_speech", C.c_int32),
+        ("suppress_mask_dev", C.c_void_p),
+    ]
+
+
+# every exported symbol of include/wjhip.h with its ctypes signature (restype, argtypes)
+_P, _I, _I64, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGNATURES = {
+    "wj_abi_version": (_I, []),
+    "wj_last_error": (C.c_char_p, []),
+    "wj_init": (_I, [_I, C.POINTER(_P)]),
+    "wj_shutdown": (_I, [_P]),
+    "wj_sync": (_I, [_P]),
+    "wj_device_info": (_I, [_P, C.POINTER(_I64)]),
+    "wj_profile_start": (_I, [_P]),
+    "wj_profile_tags": (_I, []),
+    "wj_profile_tag_name": (C.c_char_p, [_I]),
+    "wj_profile_stop": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I]),
+    "wj_logmel_frames": (_I64, [_I64, _I]),
+    "wj_logmel_f32": (_I, [_P, _P, C.POINTER(_I64), _I, _I, _I, _I, _P, _P]),
+    "wj_whisper_create": (_I, [_P, C.POINTER(WhisperDimsC), _I, _P, _I64, C.POINTER(_I64), _I, _I, _I, C.POINTER(_P)]),
+    "wj_whisper_free": (_I, [_P]),
+    "wj_whisper_workspace_bytes": (_I64, [_P]),
+    "wj_whisper_encode": (_I, [_P, _P, _I, _I, _P, _P]),
+    "wj_whisper_decode_greedy": (_I, [_P, _I, C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _P]),
+    "wj_decode_open": (_I, [_P, _I, _I, _P]),
+    "wj_decode_step": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _P]),
+    "wj_decode_logits_dev": (_P, [_P]),
+    "wj_decode_logits_copy": (_I, [_P, _I, _P, _P]),
+    "wj_decode_topk": (_I, [_P, _I, _I, _P, C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F), _P]),
+    "wj_vad_create": (_I, [_P, C.POINTER(_F), _I64, C.POINTER(_P)]),
+    "wj_vad_free": (_I, [_P]),
+    "wj_vad_scores": (_I, [_P, _P, C.POINTER(_I64), C.POINTER(_I64), _I, _P, _P]),
+    "wj_k_gemm": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "wj_k_layernorm": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P]),
+    "wj_k_attention_enc": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
+    "wj_k_attention_dec": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("WJHIP_LIB", _LIB_PATH))
+
+
+def lib() -> C.CDLL:
+    """Load libwjhip.so (once) and attach signatures.  Raises if it is absent or mismatched."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        raise WjError(f"{path} not found: build it with `python -m whisperjav_amd.build` "
+                      "(there is no CPU fallback for the HIP path)")
+    handle = C.CDLL(str(path), mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError => the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = handle.wj_abi_version()
+    if got != ABI_VERSION:
+        raise WjError(f"libwjhip ABI version {got}, binding expects {ABI_VERSION}: rebuild the library")
+    _lib = handle
+    return handle
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().wj_last_error()
+        raise WjError(f"{what or 'libwjhip call'} failed (code {rc}): {msg.decode(errors='replace') if msg else ''}")
+
+
+class Context:
+    """One HIP context + stream on one GPU (``wj_init``)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = lib()
+        handle = _P()
+        check(self._lib.wj_init(int(device), C.byref(handle)), "wj_init")
+        self.handle = handle
+        self.device = int(device)
+
+    def sync(self) -> None:
+        check(self._lib.wj_sync(self.handle), "wj_sync")
+
+    def device_info(self) -> dict:
+        out = (_I64 * 4)()
+        check(self._lib.wj_device_info(self.handle, out), "wj_device_info")
+        return {"cu_count": int(out[0]), "clock_khz": int(out[1]), "hbm_bytes": int(out[2]) | (int(out[3]) << 32)}
+
+    def profile_start(self) -> None:
+        check(self._lib.wj_profile_start(self.handle), "wj_profile_start")
+
+    def profile_stop(self) -> dict:
+        """{launch class: (count, total_ms)} measured with HIP events on the engine stream."""
+        n = self._lib.wj_profile_tags()
+        ms = (C.c_double * n)()
+        cnt = (_I64 * n)()
+        check(self._lib.wj_profile_stop(self.handle, ms, cnt, n), "wj_profile_stop")
+        return {self._lib.wj_profile_tag_name(i).decode(): (int(cnt[i]), float(ms[i]))
+                for i in range(n) if cnt[i]}
+
+    def close(self) -> None:
+        if self.handle:
+            self._lib.wj_shutdown(self.handle)
+            self.handle = None
+
+
+_contexts = {}
+
+
+def context(device: int = 0) -> Context:
+    """Process-wide context per device ordinal (created lazily, spawn-safe: nothing at import)."""
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = _contexts[device] = Context(device)
+    return ctx
