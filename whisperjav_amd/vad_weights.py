@@ -1,0 +1,75 @@
+"""Silero-VAD (v5/v6, 16 kHz) parameters: synthetic generation, TorchScript import, HBM blob layout.
+
+Blob order (float32, see ``wj_vad_create`` in include/wjhip.h and the ``V_*`` offsets in
+csrc/vad.hip).  Every matrix is stored INPUT-major so that the lanes of a wavefront (= output
+channels) read consecutive addresses:
+
+    stft    [256 taps][258 ch]        conv1 [129][3][128] + b[128]     conv2 [128][3][64] + b[64]
+    conv3   [64][3][64] + b[64]       conv4 [64][3][128] + b[128]
+    w_ih^T  [128][512]  w_hh^T [128][512]  b_ih + b_hh [512]           out_w [128]  out_b [1]
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+CHANNELS = ((129, 128), (128, 64), (64, 64), (64, 128))
+BLOB_FLOATS = 256 * 258 + sum(i * 3 * o + o for i, o in CHANNELS) + 2 * 128 * 512 + 512 + 128 + 1
+
+
+def synth_weights(seed: int = 4321) -> Dict[str, np.ndarray]:
+    """Seeded parameters with the real model's shapes.  The STFT basis is the true windowed Fourier
+    basis (as in the published model); the rest is scaled so probabilities spread over (0, 1) and
+    react to signal energy, which is enough to exercise the hysteresis state machine."""
+    rng = np.random.default_rng(seed)
+    n = np.arange(256)
+    window = np.sqrt(0.5 - 0.5 * np.cos(2 * np.pi * n / 256))      # sqrt-hann, as in conv-STFT front ends
+    k = np.arange(129)[:, None]
+    basis = np.concatenate([np.cos(2 * np.pi * k * n / 256), -np.sin(2 * np.pi * k * n / 256)], 0) * window
+    w: Dict[str, np.ndarray] = {"stft.forward_basis_buffer": basis[:, None, :].astype(np.float32)}
+    for i, (cin, cout) in enumerate(CHANNELS):
+        w[f"encoder.{i}.weight"] = (rng.standard_normal((cout, cin, 3)) * (1.2 / np.sqrt(3 * cin))).astype(np.float32)
+        w[f"encoder.{i}.bias"] = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+    for name in ("weight_ih", "weight_hh"):
+        w[f"rnn.{name}"] = (rng.standard_normal((512, 128)) * (1.0 / np.sqrt(128))).astype(np.float32)
+    for name in ("bias_ih", "bias_hh"):
+        w[f"rnn.{name}"] = (rng.standard_normal(512) * 0.1).astype(np.float32)
+    w["out.weight"] = (rng.standard_normal((1, 128, 1)) * 0.9).astype(np.float32)
+    w["out.bias"] = np.array([-0.3], dtype=np.float32)
+    return w
+
+
+def from_jit_state_dict(sd) -> Dict[str, np.ndarray]:
+    """Map the TorchScript state dict of ``silero_vad.load_silero_vad()`` (16 kHz branch) onto our
+    names.  The key names follow the published v5/v6 checkpoints; unverified offline."""
+    def g(key):
+        return np.asarray(sd[key].detach().cpu().float().numpy() if hasattr(sd[key], "detach") else sd[key],
+                          dtype=np.float32)
+    out = {"stft.forward_basis_buffer": g("_model.stft.forward_basis_buffer")}
+    for i in range(4):
+        out[f"encoder.{i}.weight"] = g(f"_model.encoder.{i}.reparam_conv.weight")
+        out[f"encoder.{i}.bias"] = g(f"_model.encoder.{i}.reparam_conv.bias")
+    for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+        out[f"rnn.{name}"] = g(f"_model.decoder.rnn.{name}")
+    out["out.weight"] = g("_model.decoder.decoder.2.weight")
+    out["out.bias"] = g("_model.decoder.decoder.2.bias")
+    return out
+
+
+def pack(w: Dict[str, np.ndarray]) -> np.ndarray:
+    """Flatten to the blob layout consumed by ``wj_vad_create``."""
+    parts = [np.ascontiguousarray(w["stft.forward_basis_buffer"][:, 0, :].T)]           # [256][258]
+    for i, (cin, cout) in enumerate(CHANNELS):
+        wt = w[f"encoder.{i}.weight"]                                                     # [out][in][3]
+        assert wt.shape == (cout, cin, 3)
+        parts.append(np.ascontiguousarray(wt.transpose(1, 2, 0)))                         # [in][3][out]
+        parts.append(w[f"encoder.{i}.bias"])
+    parts.append(np.ascontiguousarray(w["rnn.weight_ih"].T))                             # [128][512]
+    parts.append(np.ascontiguousarray(w["rnn.weight_hh"].T))
+    parts.append(w["rnn.bias_ih"] + w["rnn.bias_hh"])
+    parts.append(w["out.weight"].reshape(128))
+    parts.append(w["out.bias"].reshape(1))
+    blob = np.concatenate([np.asarray(p, dtype=np.float32).reshape(-1) for p in parts])
+    assert blob.shape[0] == BLOB_FLOATS, (blob.shape, BLOB_FLOATS)
+    return blob
