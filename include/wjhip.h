@@ -186,6 +186,10 @@ int wj_vad_scores(wj_vad* v, const float* pcm_dev, const int64_t* offsets_host,
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, plain row-major output in `dtype` (out_f32=0) or float32. */
 int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev,
               void* c_dev, int M, int N, int K, int act_gelu, int out_f32, int variant, void* stream);
+/* same launch repeated `reps` times between two hipEvents on the context stream (micro-benchmarks) */
+int wj_k_gemm_timed(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev,
+                    void* c_dev, int M, int N, int K, int act_gelu, int out_f32, int variant, int reps,
+                    float* ms_per_launch);
 int wj_k_layernorm(wj_ctx* ctx, int dtype, const float* x_dev, const float* w_dev, const float* b_dev,
                    void* out_dev, int M, int D, void* stream);
 /* encoder self-attention: qkv in the engine's head-split layouts built from a

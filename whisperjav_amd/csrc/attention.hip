@@ -272,29 +272,39 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
     for (int e = 0; e < 8; ++e) qf[b][e] *= 0.125f;
   }
 
+  // Addresses are clamped to the last valid key instead of predicating the loads (a predicated
+  // load makes the compiler select between a global and a stack pointer -> flat loads); U key octets
+  // are fetched per wave before any of them is consumed so that enough bytes are in flight to cover
+  // HBM latency.
+  constexpr int U = 4;
   float lmax[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) lmax[b] = -INFINITY;
 
-  for (int j0 = wave * 8; j0 < n_keys; j0 += NW * 8) {
-    const int j = j0 + kk;
-    const bool valid = j < n_keys;
-    float kv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (valid) {
+  for (int j0 = wave * 8; j0 < n_keys; j0 += NW * 8 * U) {
+    float kv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = min(j0 + u * NW * 8 + kk, n_keys - 1);
       const int64_t prow = SELF ? (rmap ? rmap[j] : gi) : grp;
-      ld8(Kb + ((prow * a.H + h) * a.kv_stride + j) * 64 + c * 8, kv);
+      ld8(Kb + ((prow * a.H + h) * a.kv_stride + j) * 64 + c * 8, kv[u]);
     }
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      float s = 0.f;
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * NW * 8 + kk;
+      const bool valid = j < n_keys;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s = fmaf(qf[b][e], kv[e], s);
-      s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 4, 64);
-      if (valid) {
-        if (c == 0) sc[b * kpad + j] = s;
-        lmax[b] = fmaxf(lmax[b], s);
+      for (int b = 0; b < NB; ++b) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(qf[b][e], kv[u][e], s);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (valid) {
+          if (c == 0) sc[b * kpad + j] = s;
+          lmax[b] = fmaxf(lmax[b], s);
+        }
       }
     }
   }
@@ -323,18 +333,25 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[b][e] = 0.f;
   }
-  for (int j0 = wave * 8; j0 < n_keys; j0 += NW * 8) {
-    const int j = j0 + kk;
-    if (j < n_keys) {
+  for (int j0 = wave * 8; j0 < n_keys; j0 += NW * 8 * U) {
+    float vv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = min(j0 + u * NW * 8 + kk, n_keys - 1);
       const int64_t prow = SELF ? (rmap ? rmap[j] : gi) : grp;
-      float vv[8];
-      ld8(Vb + ((prow * a.H + h) * a.kv_stride + j) * 64 + c * 8, vv);
+      ld8(Vb + ((prow * a.H + h) * a.kv_stride + j) * 64 + c * 8, vv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * NW * 8 + kk;
+      const bool valid = j < n_keys;
+      const int jc = min(j, n_keys - 1);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const float p = expf(sc[b * kpad + j] - mx[b]);
+        const float p = valid ? expf(sc[b * kpad + jc] - mx[b]) : 0.f;
         lsum[b] += p;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[b][e] = fmaf(p, vv[e], o[b][e]);
+        for (int e = 0; e < 8; ++e) o[b][e] = fmaf(p, vv[u][e], o[b][e]);
       }
     }
   }

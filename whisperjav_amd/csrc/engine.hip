@@ -706,6 +706,34 @@ int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, cons
   return launch_gemm(dtype, e, g, ctx->pick(stream), variant);
 }
 
+int wj_k_gemm_timed(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev,
+                    int M, int N, int K, int act_gelu, int out_f32, int variant, int reps, float* ms_per_launch) {
+  WJ_REQUIRE(ctx && a_dev && w_dev && c_dev && ms_per_launch && reps >= 1, "wj_k_gemm_timed: bad arguments");
+  WJ_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  GemmArgs g;
+  g.A = a_dev; g.lda = K; g.W = w_dev; g.ldw = K; g.bias = bias_dev; g.M = M; g.N = N; g.K = K; g.out = c_dev; g.ldc = N;
+  Epi e = out_f32 ? EPI_F32 : (act_gelu ? EPI_GELU_T : EPI_T);
+  int rc = launch_gemm(dtype, e, g, s, variant);  // warm-up + argument validation
+  if (rc) return rc;
+  hipEvent_t e0, e1;
+  WJ_HIP(hipEventCreate(&e0));
+  WJ_HIP(hipEventCreate(&e1));
+  WJ_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < reps; ++i) {
+    rc = launch_gemm(dtype, e, g, s, variant);
+    if (rc) return rc;
+  }
+  WJ_HIP(hipEventRecord(e1, s));
+  WJ_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  WJ_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = ms / reps;
+  return WJ_OK;
+}
+
 int wj_k_layernorm(wj_ctx* ctx, int dtype, const float* x_dev, const float* w_dev, const float* b_dev, void* out_dev, int M,
                    int D, void* stream) {
   WJ_REQUIRE(ctx && x_dev && w_dev && b_dev && out_dev, "wj_k_layernorm: NULL argument");

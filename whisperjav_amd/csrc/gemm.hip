@@ -16,6 +16,8 @@
 // one row, i.e. one 8-byte (bf16) / 16-byte (fp32) store.  EPI_VT flips the operand order so a
 // lane holds 4 consecutive rows instead (V is written transposed per head for the attention
 // kernel's P.V operand).
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace wj {
@@ -106,7 +108,7 @@ __device__ __forceinline__ uint4 ldg16_pred(const void* p, bool pred) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * TBK + ((chunk ^ (row & 7)) << 3); }
 
-template <int EPI>
+template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * TBM * TBK];  // [buf][A|W][128][64] = 64 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,13 +148,38 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
   }
 #define WJ_SSTORE(buf) WJ_SSTORE1(0, buf) WJ_SSTORE1(1, buf) WJ_SSTORE1(2, buf) WJ_SSTORE1(3, buf)
 
-  WJ_GLOAD(0)
-  WJ_SSTORE(0)
+  // GLDS: LDS-DMA staging (global_load_lds_dwordx4): each wave instruction deposits 64 x 16 B =
+  // 8 tile rows, lane-linear, so the XOR swizzle is applied to the per-lane SOURCE address (lane ->
+  // physical chunk p = lane & 7 of row r0 + lane / 8 fetches logical chunk p ^ (row & 7)).  Requires
+  // K % 64 == 0 (no zero fill on this path); out-of-range rows read a clamped (valid) row and are
+  // dropped by the epilogue.
+#define WJ_GLDS_STAGE(buf, k0)                                                                     \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                  \
+    const int r0 = (wave * 4 + q) * 8;                                                             \
+    const int row = r0 + (lane >> 3);                                                              \
+    const int c = (lane & 7) ^ (row & 7);                                                          \
+    const bf16_t* ga = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + (k0) + c * 8;                 \
+    const bf16_t* gw = W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + (k0) + c * 8;                 \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,            \
+        (__attribute__((address_space(3))) void*)(&lds[((buf) * 2 + 0) * TBM * TBK + r0 * TBK]), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,            \
+        (__attribute__((address_space(3))) void*)(&lds[((buf) * 2 + 1) * TBM * TBK + r0 * TBK]), 16, 0, 0); \
+  }
+
+  if constexpr (GLDS) {
+    WJ_GLDS_STAGE(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    WJ_GLOAD(0)
+    WJ_SSTORE(0)
+  }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) { WJ_GLOAD((kt + 1) * TBK) }
+    if (kt + 1 < nk) {
+      if constexpr (GLDS) { WJ_GLDS_STAGE(cur ^ 1, (kt + 1) * TBK) } else { WJ_GLOAD((kt + 1) * TBK) }
+    }
     const bf16_t* la = &lds[(cur * 2 + 0) * TBM * TBK];
     const bf16_t* lb = &lds[(cur * 2 + 1) * TBM * TBK];
 #pragma unroll
@@ -179,9 +206,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) { WJ_SSTORE(cur ^ 1) }
+    if constexpr (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of tile kt+1 has landed
+    } else {
+      if (kt + 1 < nk) { WJ_SSTORE(cur ^ 1) }
+    }
     __syncthreads();
   }
+#undef WJ_GLDS_STAGE
 #undef WJ_GLOAD
 #undef WJ_SSTORE
 #undef WJ_GLOAD1
@@ -335,7 +367,7 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
   }
   const bool skinny_ok = (EPI != EPI_VT) && a.nbatch == 1;
   bool skinny = skinny_ok && a.M <= 512;
-  if (variant == 1) skinny = false;
+  if (variant == 1 || variant == 3 || variant == 4) skinny = false;
   if (variant == 2) {
     if (!skinny_ok) { set_error("skinny GEMM does not support this epilogue/batching"); return WJ_E_INVALID; }
     skinny = true;
@@ -352,7 +384,16 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
     return WJ_OK;
   }
   dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), a.nbatch);
-  hipLaunchKernelGGL(gemm_bf16_tile_kernel<EPI>, grid, dim3(256), 0, s, a);
+  static const int tile_mode = [] {   // WJ_GEMM_TILE=reg|glds overrides the default staging path
+    const char* e = getenv("WJ_GEMM_TILE");
+    if (e && !strcmp(e, "reg")) return 1;
+    if (e && !strcmp(e, "glds")) return 2;
+    return 0;
+  }();
+  bool glds = (a.K % TBK) == 0 && (variant == 3 || (variant != 4 && tile_mode == 2));
+  if (variant == 3 && (a.K % TBK)) { set_error("gemm: the LDS-DMA tile kernel needs K %% 64 == 0"); return WJ_E_INVALID; }
+  if (glds) hipLaunchKernelGGL((gemm_bf16_tile_kernel<EPI, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_bf16_tile_kernel<EPI, false>), grid, dim3(256), 0, s, a);
   WJ_LAUNCH_CHECK();
   return WJ_OK;
 }

@@ -36,7 +36,8 @@ struct GemmArgs {
   int cache_len = 0;
 };
 
-// variant: 0 = auto; 1 = force tiled MFMA kernel; 2 = force skinny (decode) kernel
+// variant: 0 = auto; 1 = tiled MFMA kernel (default staging); 2 = skinny (decode) kernel;
+//          3 = tiled kernel with LDS-DMA staging; 4 = tiled kernel with register staging
 int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int variant = 0);
 
 // ---------------- normalisation / elementwise ------------------------------------------------

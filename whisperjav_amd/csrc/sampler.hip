@@ -55,7 +55,7 @@ __device__ __forceinline__ bool token_allowed(int v, const RowRules& rr, const w
   return true;
 }
 
-constexpr int SB = 256;  // sampler block size
+constexpr int SB = 1024;  // sampler block size (one workgroup per row sweeps the 51.9k-entry vocabulary)
 
 __global__ __launch_bounds__(SB) void greedy_sample_kernel(const GreedyArgs a) {
   __shared__ float s_f[4][SB / 64];

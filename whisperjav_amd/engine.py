@@ -281,6 +281,25 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype
     return out.float()
 
 
+def k_gemm_timed(M: int, N: int, K: int, dtype: str = "bfloat16", variant: int = 0, reps: int = 20,
+                 gelu: bool = False, device: int = 0) -> float:
+    """Average milliseconds per launch of an [M,K] x [N,K]^T GEMM on uniform random [-1, 1) operands."""
+    ctx = hipbind.context(device)
+    lib = hipbind.lib()
+    td = torch.bfloat16 if dtype == "bfloat16" else torch.float32
+    dev = torch.device("cuda", device)
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = (torch.rand((M, K), device=dev, generator=g) * 2 - 1).to(td)
+    Wt = (torch.rand((N, K), device=dev, generator=g) * 2 - 1).to(td)
+    bias = torch.rand(N, device=dev, generator=g)
+    out = torch.empty((M, N), dtype=td, device=dev)
+    ms = C.c_float()
+    _torch_sync()
+    check(lib.wj_k_gemm_timed(ctx.handle, DTYPES[dtype], _ptr(A), _ptr(Wt), _ptr(bias), _ptr(out), M, N, K, int(gelu), 0,
+                              int(variant), int(reps), C.byref(ms)), "wj_k_gemm_timed")
+    return float(ms.value)
+
+
 def k_layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, dtype: str, device: int = 0) -> torch.Tensor:
     ctx = hipbind.context(device)
     lib = hipbind.lib()

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "wj_vad_free": (_I, [_P]),
     "wj_vad_scores": (_I, [_P, _P, C.POINTER(_I64), C.POINTER(_I64), _I, _P, _P]),
     "wj_k_gemm": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "wj_k_gemm_timed": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "wj_k_layernorm": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P]),
     "wj_k_attention_enc": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
     "wj_k_attention_dec": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
