@@ -166,6 +166,18 @@ int wj_decode_logits_copy(wj_whisper* m, int rows, float* dst_dev, void* stream)
 int wj_decode_topk(wj_whisper* m, int rows, int k, const uint8_t* ban_dev,
                    int32_t* ids_out_host, float* logprob_out_host, float* lse_out_host, void* stream);
 
+/* Beam-search scoring of the last step's logits (modified in place):
+ *   CTranslate2's RepetitionPenalty on pen_host[r][0..maxp) (distinct token ids, -1 padded),
+ *   NoRepeatNgram bans ban_host[r][0..maxb) (-1 padded), then suppress mask / suppress_blank /
+ *   Whisper timestamp rules driven by row_rules_host[r] = {first_step, last_was_timestamp,
+ *   penultimate_was_timestamp, timestamp_floor (-1 = none)}, log-softmax over what is left, top-k.
+ * ids / log-probs go to host arrays [rows][k] (id -1, -inf when fewer than k tokens are allowed). */
+int wj_decode_topk_rules(wj_whisper* m, int rows, int k, const wj_decode_opts* opts, const int32_t* row_rules_host,
+                         const int32_t* ban_host, int maxb, const int32_t* pen_host, int maxp, float penalty,
+                         int32_t* ids_out_host, float* logprob_out_host, void* stream);
+/* softmax probability of the no-speech token in the last step's (unfiltered) logits */
+int wj_decode_no_speech(wj_whisper* m, int rows, int no_speech_id, float* out_host, void* stream);
+
 /* ---- VAD scorer -------------------------------------------------------------------------
  * Replaces: the per-window forward of the silero-vad JIT model inside
  * silero_vad.get_speech_timestamps (called at

@@ -145,3 +145,90 @@ def greedy_decode(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int],
             seq = seq[:seq.index(lay.eot)]
         toks.append(seq)
     return GreedyOut(toks, sums.astype(np.float32), tlp, nsp)
+
+
+# --------------------------------------------------------------------------------------------------
+# CTranslate2-style beam search (literal restatement: flatten beam x vocab, top 2*beam, refill)
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class BeamConfig:
+    beam_size: int = 5
+    patience: float = 1.0
+    length_penalty: float = 1.0
+    repetition_penalty: float = 1.0
+    no_repeat_ngram_size: int = 0
+    max_new_tokens: int = 224
+
+
+def _apply_ct2_processors(logits: torch.Tensor, seqs: Sequence[Sequence[int]], cfg: BeamConfig) -> torch.Tensor:
+    """RepetitionPenalty then NoRepeatNgram over the decoded sequences (start token included)."""
+    out = logits.clone().float()
+    for r, seq in enumerate(seqs):
+        if cfg.repetition_penalty != 1.0 and len(seq):
+            idx = torch.tensor(sorted(set(seq)))
+            vals = out[r, idx]
+            out[r, idx] = torch.where(vals < 0, vals * cfg.repetition_penalty, vals / cfg.repetition_penalty)
+        n = cfg.no_repeat_ngram_size
+        if n > 0 and len(seq) >= n:
+            tail = list(seq[len(seq) - n + 1:]) if n > 1 else []
+            for i in range(len(seq) - n + 1):
+                if list(seq[i:i + n - 1]) == tail:
+                    out[r, seq[i + n - 1]] = NEG_INF
+    return out
+
+
+def beam_search(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], bcfg: BeamConfig,
+                fcfg: Optional[FilterConfig] = None):
+    """One window (xa [1, T, D]).  Returns (hypotheses best-first [(tokens, score, cum_logprob)], no_speech_prob)."""
+    fcfg = fcfg or FilterConfig()
+    lay = TokenLayout.for_vocab(model.dims.n_vocab)
+    K, V = bcfg.beam_size, model.dims.n_vocab
+    P = len(prompt)
+    max_new = min(bcfg.max_new_tokens, model.dims.n_text_ctx - P)
+    max_candidates = int(round(K * bcfg.patience))
+    with torch.no_grad():
+        dec = CachedDecoder(model, xa.expand(K, -1, -1).contiguous())
+        nsp = 0.0
+        for p in range(P - 1):
+            lg = dec.step(torch.full((K, 1), prompt[p]))
+            if p == 0:
+                nsp = float(torch.softmax(lg[0].float(), -1)[lay.no_speech])
+        seqs: List[List[int]] = [[] for _ in range(K)]           # generated tokens per beam
+        scores = torch.full((K,), NEG_INF)
+        scores[0] = 0.0
+        feed = torch.full((K, 1), prompt[-1])
+        finished: List = []
+        for step in range(max_new):
+            logits = dec.step(feed)
+            if P == 1 and step == 0:
+                nsp = float(torch.softmax(logits[0].float(), -1)[lay.no_speech])
+            logits = _apply_ct2_processors(logits, [[prompt[-1]] + s for s in seqs], bcfg)
+            hist = [list(prompt) + s for s in seqs]
+            logits = filter_logits(logits, hist, P, lay, fcfg)
+            lp = torch.log_softmax(logits, dim=-1) + scores[:, None]
+            flat = lp.reshape(-1)
+            top_s, top_i = torch.topk(flat, 2 * K)
+            cand = [(float(s), int(i) // V, int(i) % V) for s, i in zip(top_s, top_i) if s > NEG_INF]
+            last = step == max_new - 1
+            nxt, secondary = [], K
+            for k in range(min(K, len(cand))):
+                s, b, t = cand[k]
+                use = cand[k]
+                if t == lay.eot or last:
+                    finished.append((s, seqs[b] + ([] if t == lay.eot else [t])))
+                    for j in range(secondary, len(cand)):
+                        if cand[j][2] != lay.eot:
+                            use, secondary = cand[j], j + 1
+                            break
+                nxt.append(use)
+            if last or len(finished) >= max_candidates:
+                break
+            parents = [b for _, b, _ in nxt] + [0] * (K - len(nxt))
+            new_scores = [s for s, _, _ in nxt] + [NEG_INF] * (K - len(nxt))
+            new_seqs = [seqs[b] + [t] for _, b, t in nxt] + [list(seqs[0]) for _ in range(K - len(nxt))]
+            dec.reorder(torch.tensor(parents))
+            seqs, scores = new_seqs, torch.tensor(new_scores)
+            feed = torch.tensor([[t] for _, _, t in nxt] + [[lay.eot]] * (K - len(nxt)))
+    lpn = bcfg.length_penalty
+    ranked = sorted(((s / (max(len(t), 1) ** lpn) if lpn != 0 else s, s, t) for s, t in finished), key=lambda x: -x[0])
+    return [(t, n, s) for n, s, t in ranked], nsp

@@ -304,3 +304,46 @@ def test_golden_large_v3_window(hip, dtype):
     else:
         assert d_probe < 0.25 and d_mean < 5e-3
         assert common >= 3 and d_lp < 0.2
+
+
+# ---------------------------------------------------------------------------------------------
+# beam search through the device scorer (wj_decode_topk_rules) vs the oracle's CTranslate2 restatement
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("beam,patience,rep,ngram", [(2, 1.2, 1.5, 3), (5, 1.2, 1.5, 3), (3, 1.0, 1.0, 0)])
+def test_beam_search_matches_oracle(hip, dtype, beam, patience, rep, ngram):
+    from whisperjav_amd import engine, search
+    d = helpers.small_dims()
+    oracle, w = helpers.make_oracle(d, seed=33, emulate_bf16=(dtype == "bfloat16"))
+    model = engine.HipWhisper(d, w, dtype=dtype, max_batch=2, max_beam=beam)
+    mel = torch.from_numpy(helpers.synth_mel(2, d.n_mels, seed=19))
+    toks = model.tokens
+    prompt = model.sot_prompt("ja", "transcribe")
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    opts = search.SearchOptions(beam_size=beam, patience=patience, length_penalty=1.0, repetition_penalty=rep,
+                                no_repeat_ngram_size=ngram, suppress_tokens=suppress, max_initial_timestamp_index=0,
+                                max_new_tokens=16)
+    model.encode(mel.cuda())
+    got = search.beam_search(search.HipStepScorer(model, opts), [prompt, prompt], opts, eot=toks.eot,
+                             timestamp_begin=toks.timestamp_begin)
+    fcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=0)
+    bcfg = decoding.BeamConfig(beam, patience, 1.0, rep, ngram, 16)
+    with torch.no_grad():
+        xa = oracle.encode(mel)
+    worst = 0.0
+    for wdx in range(2):
+        ref, nsp = decoding.beam_search(oracle, xa[wdx:wdx + 1], prompt, bcfg, fcfg)
+        if dtype == "float32":
+            assert got[wdx].sequences[0] == ref[0][0], (got[wdx].sequences[0], ref[0][0])
+            assert abs(got[wdx].cum_logprobs[0] - ref[0][2]) < 1e-3
+            assert abs(got[wdx].no_speech_prob - nsp) < 1e-5
+        else:
+            common = 0
+            for a, b in zip(got[wdx].sequences[0], ref[0][0]):
+                if a != b:
+                    break
+                common += 1
+            assert common >= min(3, len(ref[0][0]))
+        worst = max(worst, abs(got[wdx].cum_logprobs[0] - ref[0][2]))
+    _diag("beam", {"dtype": dtype, "beam": beam, "cum_logprob_diff": worst})
+    model.close()

@@ -1,0 +1,121 @@
+"""Host beam-search bookkeeping (whisperjav_amd/search.py) against the oracle's literal CTranslate2
+restatement, on the CPU: the product code is driven by a NumPy scorer that evaluates the oracle
+model, so any disagreement is in the search logic itself (candidate merge, EOT refill, patience,
+length penalty, rule state, n-gram bans, penalty lists)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoding, whisper_ref
+from tests import helpers
+from whisperjav_amd import dims as pdims, search
+
+
+class OracleScorer:
+    """StepScorer double: same contract as the HIP scorer, arithmetic by the CPU oracle."""
+
+    def __init__(self, oracle, xa, lay, fcfg):
+        self.oracle, self.xa, self.lay, self.fcfg = oracle, xa, lay, fcfg
+
+    def open(self, batch, beam):
+        idx = torch.arange(batch).repeat_interleave(beam)
+        self.dec = whisper_ref.CachedDecoder(self.oracle, self.xa[idx].contiguous())
+        self.rows = batch * beam
+        self.logits = None
+
+    def step(self, tokens, parents, want_logits):
+        if parents is not None:
+            self.dec.reorder(torch.from_numpy(np.asarray(parents, dtype=np.int64)))
+        with torch.no_grad():
+            self.logits = self.dec.step(torch.from_numpy(np.asarray(tokens, dtype=np.int64))[:, None])
+
+    def no_speech(self):
+        return torch.softmax(self.logits.float(), -1)[:, self.lay.no_speech].numpy()
+
+    def score(self, k, row_rules, bans, pens, penalty):
+        x = self.logits.clone().float()
+        tb, lay, cfg = self.lay.timestamp_begin, self.lay, self.fcfg
+        for r in range(self.rows):
+            for t in pens[r]:
+                if t >= 0:
+                    x[r, t] = x[r, t] * penalty if x[r, t] < 0 else x[r, t] / penalty
+            for t in bans[r]:
+                if t >= 0:
+                    x[r, t] = float("-inf")
+            first, last_ts, penult_ts, floor = (int(v) for v in row_rules[r])
+            if len(cfg.suppress_tokens):
+                x[r, list(cfg.suppress_tokens)] = float("-inf")
+            if first and cfg.suppress_blank:
+                x[r, lay.blank] = x[r, lay.eot] = float("-inf")
+            if not cfg.without_timestamps:
+                x[r, lay.no_timestamps] = float("-inf")
+                if last_ts:
+                    if penult_ts:
+                        x[r, tb:] = float("-inf")
+                    else:
+                        x[r, :lay.eot] = float("-inf")
+                if floor >= 0:
+                    x[r, tb:floor] = float("-inf")
+                if first:
+                    x[r, :tb] = float("-inf")
+                    if cfg.max_initial_timestamp_index is not None:
+                        x[r, tb + cfg.max_initial_timestamp_index + 1:] = float("-inf")
+                lp = torch.log_softmax(x[r], -1)
+                if torch.logsumexp(lp[tb:], -1) > lp[:tb].max():
+                    x[r, :tb] = float("-inf")
+        lp = torch.log_softmax(x, -1)
+        vals, ids = torch.topk(lp, k, dim=-1)
+        ids = torch.where(torch.isinf(vals), torch.full_like(ids, -1), ids)
+        return ids.numpy().astype(np.int32), vals.numpy().astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    d = helpers.small_dims(n_mels=80, d_model=64, heads=1, layers=1, n_vocab=51865)
+    oracle, _ = helpers.make_oracle(d, seed=5)
+    mel = torch.from_numpy(helpers.synth_mel(2, d.n_mels, seed=2))
+    with torch.no_grad():
+        xa = oracle.encode(mel)
+    return d, oracle, xa
+
+
+@pytest.mark.parametrize("beam,patience,lp,rep,ngram,no_ts", [
+    (2, 1.2, 1.0, 1.5, 3, False),     # the reference's "balanced" defaults (faster_whisper.py:276-315)
+    (5, 1.2, 1.0, 1.5, 3, False),     # BASELINE cfg3
+    (3, 1.0, 0.0, 1.0, 0, True),
+    (4, 2.0, 1.0, 1.3, 2, False),
+])
+def test_beam_search_matches_oracle(setup, beam, patience, lp, rep, ngram, no_ts):
+    d, oracle, xa = setup
+    lay = decoding.TokenLayout.for_vocab(d.n_vocab)
+    toks = pdims.special_tokens(d.n_vocab)
+    prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe] + ([toks.no_timestamps] if no_ts else [])
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    fcfg = decoding.FilterConfig(suppress_tokens=suppress, without_timestamps=no_ts, max_initial_timestamp_index=0)
+    opts = search.SearchOptions(beam_size=beam, patience=patience, length_penalty=lp, repetition_penalty=rep,
+                                no_repeat_ngram_size=ngram, suppress_tokens=suppress, without_timestamps=no_ts,
+                                max_initial_timestamp_index=0, max_new_tokens=14, num_hypotheses=beam)
+    got = search.beam_search(OracleScorer(oracle, xa, lay, fcfg), [prompt, prompt], opts, eot=lay.eot,
+                             timestamp_begin=lay.timestamp_begin)
+    bcfg = decoding.BeamConfig(beam, patience, lp, rep, ngram, 14)
+    for w in range(2):
+        ref, nsp = decoding.beam_search(oracle, xa[w:w + 1], prompt, bcfg, fcfg)
+        assert got[w].sequences[0] == ref[0][0], (w, got[w].sequences, [r[0] for r in ref])
+        assert abs(got[w].scores[0] - ref[0][1]) < 1e-4
+        assert abs(got[w].cum_logprobs[0] - ref[0][2]) < 1e-4
+        assert abs(got[w].no_speech_prob - nsp) < 1e-6
+        n = min(len(got[w].sequences), len(ref))
+        assert [s for s in got[w].sequences[:n]] == [r[0] for r in ref[:n]]
+
+
+def test_rule_helpers():
+    tb = 50365
+    assert search.timestamp_state([], tb) == (1, 0, 1, -1)
+    assert search.timestamp_state([tb + 5], tb) == (0, 1, 1, tb + 6)
+    assert search.timestamp_state([tb + 5, 100], tb) == (0, 0, 1, tb + 6)
+    assert search.timestamp_state([tb + 5, 100, tb + 9], tb) == (0, 1, 0, tb + 9)
+    assert search.timestamp_state([tb + 5, 100, tb + 9, tb + 9], tb) == (0, 1, 1, tb + 10)
+    assert search.ngram_bans([1, 2, 3, 1, 2], 3) == [3]
+    assert search.ngram_bans([1, 2, 1, 2, 1], 2) == [2]
+    assert search.ngram_bans([7, 7, 7], 1) == [7]
+    assert search.ngram_bans([1, 2], 3) == []

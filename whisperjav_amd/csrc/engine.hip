@@ -694,6 +694,44 @@ int wj_decode_topk(wj_whisper* m, int rows, int k, const uint8_t* ban_dev, int32
   return WJ_OK;
 }
 
+int wj_decode_topk_rules(wj_whisper* m, int rows, int k, const wj_decode_opts* opts, const int32_t* row_rules_host,
+                         const int32_t* ban_host, int maxb, const int32_t* pen_host, int maxp, float penalty,
+                         int32_t* ids_out_host, float* logprob_out_host, void* stream) {
+  WJ_REQUIRE(m && opts && row_rules_host && ids_out_host && logprob_out_host, "wj_decode_topk_rules: NULL argument");
+  WJ_REQUIRE(rows >= 1 && rows <= m->max_rows && k >= 1 && k <= 16, "wj_decode_topk_rules: rows/k out of range");
+  WJ_REQUIRE(maxb >= 0 && maxp >= 0 && (maxb == 0 || ban_host) && (maxp == 0 || pen_host),
+             "wj_decode_topk_rules: list pointers do not match their lengths");
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  const size_t b_rules = align_up(sizeof(int32_t) * 4 * rows, 256);
+  const size_t b_ban = align_up(sizeof(int32_t) * (size_t)maxb * rows, 256);
+  const size_t b_pen = align_up(sizeof(int32_t) * (size_t)maxp * rows, 256);
+  WJ_TRY(m->ctx->ensure_scratch(b_rules + b_ban + b_pen));
+  char* base = reinterpret_cast<char*>(m->ctx->scratch);
+  int32_t* d_rules = reinterpret_cast<int32_t*>(base);
+  int32_t* d_ban = reinterpret_cast<int32_t*>(base + b_rules);
+  int32_t* d_pen = reinterpret_cast<int32_t*>(base + b_rules + b_ban);
+  WJ_HIP(hipMemcpyAsync(d_rules, row_rules_host, sizeof(int32_t) * 4 * rows, hipMemcpyHostToDevice, s));
+  if (maxb) WJ_HIP(hipMemcpyAsync(d_ban, ban_host, sizeof(int32_t) * (size_t)maxb * rows, hipMemcpyHostToDevice, s));
+  if (maxp) WJ_HIP(hipMemcpyAsync(d_pen, pen_host, sizeof(int32_t) * (size_t)maxp * rows, hipMemcpyHostToDevice, s));
+  WJ_TRY(launch_topk_rules(m->logits, m->ldl, rows, m->d.n_vocab, k, *opts, d_rules, d_ban, maxb, d_pen, maxp, penalty,
+                           m->topk_ids, m->topk_lp, s));
+  WJ_HIP(hipMemcpyAsync(ids_out_host, m->topk_ids, sizeof(int32_t) * rows * k, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(logprob_out_host, m->topk_lp, sizeof(float) * rows * k, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipStreamSynchronize(s));
+  return WJ_OK;
+}
+
+int wj_decode_no_speech(wj_whisper* m, int rows, int no_speech_id, float* out_host, void* stream) {
+  WJ_REQUIRE(m && out_host && rows >= 1 && rows <= m->max_rows, "wj_decode_no_speech: bad arguments");
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  WJ_TRY(launch_no_speech_prob(m->logits, m->ldl, rows, m->d.n_vocab, no_speech_id, m->nsp, s));
+  WJ_HIP(hipMemcpyAsync(out_host, m->nsp, sizeof(float) * rows, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipStreamSynchronize(s));
+  return WJ_OK;
+}
+
 // ---- kernel-level entry points (tests / micro-benchmarks) ---------------------------------------
 int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev, int M,
               int N, int K, int act_gelu, int out_f32, int variant, void* stream) {

@@ -257,17 +257,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(const GemmArgs g)
     f32x4_t acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int ks = ks_begin; ks < ks_end; ++ks) {
-      const int k = ks * 32 + kq;
-      const bool kin = k < g.K;
-      const int kc = kin ? k : 0;
-      const uint4 wv = ldg16_pred(W + (int64_t)min(wrow, g.N - 1) * g.ldw + kc, kin && wrow < g.N);
-      const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wv);
+    // UNR k-steps of W and A fragments are requested before the first MFMA of the group so that
+    // each wave keeps several 1 KiB loads in flight (the kernel is latency / HBM bound, not MFMA bound)
+    constexpr int UNR = MT <= 2 ? 4 : (MT == 4 ? 3 : 2);
+    for (int ks0 = ks_begin; ks0 < ks_end; ks0 += UNR) {
+      uint4 wv[UNR], av[UNR][MT];
 #pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const int arow = mc + t * 16 + (lane & 15);
-        const uint4 av = ldg16_pred(A + (int64_t)min(arow, g.M - 1) * g.lda + kc, kin && arow < g.M);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, av), acc[t], 0, 0, 0);
+      for (int u = 0; u < UNR; ++u) {
+        const int k = (ks0 + u) * 32 + kq;
+        const bool kin = (ks0 + u) < ks_end && k < g.K;
+        const int kc = kin ? k : 0;
+        wv[u] = ldg16_pred(W + (int64_t)min(wrow, g.N - 1) * g.ldw + kc, kin && wrow < g.N);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int arow = mc + t * 16 + (lane & 15);
+          av[u][t] = ldg16_pred(A + (int64_t)min(arow, g.M - 1) * g.lda + kc, kin && arow < g.M);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wv[u]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, av[u][t]), acc[t], 0, 0, 0);
       }
     }
     // partials -> LDS: red[wave][m_local][n_local]
@@ -390,7 +402,7 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
     if (e && !strcmp(e, "glds")) return 2;
     return 0;
   }();
-  bool glds = (a.K % TBK) == 0 && (variant == 3 || (variant != 4 && tile_mode == 2));
+  bool glds = (a.K % TBK) == 0 && (variant == 3 || (variant != 4 && tile_mode != 1));
   if (variant == 3 && (a.K % TBK)) { set_error("gemm: the LDS-DMA tile kernel needs K %% 64 == 0"); return WJ_E_INVALID; }
   if (glds) hipLaunchKernelGGL((gemm_bf16_tile_kernel<EPI, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((gemm_bf16_tile_kernel<EPI, false>), grid, dim3(256), 0, s, a);

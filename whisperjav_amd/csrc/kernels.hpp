@@ -91,6 +91,10 @@ int launch_no_speech_prob(const float* logits, int64_t ldl, int R, int V, int no
 // masked log-softmax + top-k (k <= 16) per row
 int launch_topk_logprob(const float* logits, int64_t ldl, int R, int V, int k, const uint8_t* ban,
                         int32_t* ids, float* logprobs, float* lse, hipStream_t s);
+// beam search: logits processors + timestamp rules + masked log-softmax + top-k (see sampler.hip)
+int launch_topk_rules(float* logits, int64_t ldl, int R, int V, int k, const wj_decode_opts& o, const int32_t* row_rules,
+                      const int32_t* ban, int maxb, const int32_t* pen, int maxp, float penalty, int32_t* ids,
+                      float* logprobs, hipStream_t s);
 int launch_advance_pos(int* pos_ptr, hipStream_t s);
 // row_map update for beam search: new_map[r][0..pos-1] = old_map[parent[r]][..]; new_map[r][pos] = r
 int launch_rebind_rows(const int32_t* old_map, int32_t* new_map, const int32_t* parent, const int* pos_ptr,

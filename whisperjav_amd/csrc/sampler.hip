@@ -251,4 +251,119 @@ int launch_topk_logprob(const float* logits, int64_t ldl, int R, int V, int k, c
   return WJ_OK;
 }
 
+// --------------------------------------------------------------------------------------------
+// Beam-search scoring: CTranslate2-style logits processors + Whisper timestamp rules + masked
+// log-softmax + top-k, one workgroup per hypothesis row.  The host (whisperjav_amd/search.py) owns
+// the beam bookkeeping and sends, per row: the timestamp-rule state, the tokens banned this step
+// (no-repeat-ngram, -1 padded) and the distinct tokens subject to the repetition penalty.
+// The logits buffer is modified in place (it is recomputed every step).
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SB) void topk_rules_kernel(float* __restrict__ logits, int64_t ldl, int V, int k,
+                                                        const wj_decode_opts o, const int32_t* __restrict__ row_rules,
+                                                        const int32_t* __restrict__ ban, int maxb,
+                                                        const int32_t* __restrict__ pen, int maxp, float penalty,
+                                                        int32_t* __restrict__ ids, float* __restrict__ logprobs) {
+  __shared__ float s_f[4][SB / 64];
+  __shared__ int s_i[2][SB / 64];
+  __shared__ int s_sel[16];
+  __shared__ float s_stat[4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* x = logits + (int64_t)r * ldl;
+  if (penalty != 1.0f)
+    for (int i = tid; i < maxp; i += SB) {
+      const int t = pen[(int64_t)r * maxp + i];
+      if (t >= 0 && t < V) { const float v = x[t]; x[t] = v < 0.f ? v * penalty : v / penalty; }
+    }
+  __syncthreads();
+  for (int i = tid; i < maxb; i += SB) {
+    const int t = ban[(int64_t)r * maxb + i];
+    if (t >= 0 && t < V) x[t] = -INFINITY;
+  }
+  __syncthreads();
+  RowRules rr;
+  rr.first = row_rules[r * 4 + 0];
+  rr.last_ts = row_rules[r * 4 + 1];
+  rr.penult_ts = row_rules[r * 4 + 2];
+  rr.ts_floor = row_rules[r * 4 + 3];
+  rr.ts_rules = !o.without_timestamps;
+
+  ArgMax best_all = {-INFINITY, 0x7fffffff};
+  float max_text = -INFINITY;
+  for (int v = tid; v < V; v += SB) {
+    if (!token_allowed(v, rr, o)) continue;
+    const float xv = x[v];
+    best_all = amax(best_all, ArgMax{xv, v});
+    if (v < o.timestamp_begin) max_text = fmaxf(max_text, xv);
+  }
+  best_all = wave_amax(best_all);
+  max_text = wave_max(max_text);
+  if (lane == 0) { s_f[0][wave] = best_all.v; s_i[0][wave] = best_all.i; s_f[2][wave] = max_text; }
+  __syncthreads();
+  best_all = ArgMax{s_f[0][0], s_i[0][0]};
+  max_text = s_f[2][0];
+  for (int w = 1; w < SB / 64; ++w) {
+    best_all = amax(best_all, ArgMax{s_f[0][w], s_i[0][w]});
+    max_text = fmaxf(max_text, s_f[2][w]);
+  }
+  __syncthreads();
+  float sum_all = 0.f, sum_ts = 0.f;
+  for (int v = tid; v < V; v += SB) {
+    if (!token_allowed(v, rr, o)) continue;
+    const float e = expf(x[v] - best_all.v);
+    sum_all += e;
+    if (v >= o.timestamp_begin) sum_ts += e;
+  }
+  sum_all = wave_sum(sum_all);
+  sum_ts = wave_sum(sum_ts);
+  if (lane == 0) { s_f[0][wave] = sum_all; s_f[1][wave] = sum_ts; }
+  __syncthreads();
+  if (tid == 0) {
+    sum_all = 0.f; sum_ts = 0.f;
+    for (int w = 0; w < SB / 64; ++w) { sum_all += s_f[0][w]; sum_ts += s_f[1][w]; }
+    const float lse = best_all.v + logf(sum_all);
+    float ts_only = 0.f, norm = lse;
+    if (rr.ts_rules && sum_ts > 0.f) {
+      const float ts_lp = best_all.v + logf(sum_ts) - lse;
+      if (ts_lp > max_text - lse) { ts_only = 1.f; norm = best_all.v + logf(sum_ts); }
+    }
+    s_stat[0] = norm;
+    s_stat[1] = ts_only;
+  }
+  __syncthreads();
+  const float norm = s_stat[0];
+  const bool ts_only = s_stat[1] != 0.f;
+  for (int round = 0; round < k; ++round) {
+    ArgMax best = {-INFINITY, 0x7fffffff};
+    for (int v = tid; v < V; v += SB) {
+      if (ts_only && v < o.timestamp_begin) continue;
+      if (!token_allowed(v, rr, o)) continue;
+      bool taken = false;
+      for (int q = 0; q < round; ++q) taken |= (s_sel[q] == v);
+      if (!taken) best = amax(best, ArgMax{x[v], v});
+    }
+    best = wave_amax(best);
+    if (lane == 0) { s_f[0][wave] = best.v; s_i[0][wave] = best.i; }
+    __syncthreads();
+    if (tid == 0) {
+      ArgMax b = {s_f[0][0], s_i[0][0]};
+      for (int w = 1; w < SB / 64; ++w) b = amax(b, ArgMax{s_f[0][w], s_i[0][w]});
+      s_sel[round] = b.i;
+      const bool none = b.i == 0x7fffffff || b.v == -INFINITY;
+      ids[(int64_t)r * k + round] = none ? -1 : b.i;
+      logprobs[(int64_t)r * k + round] = none ? -INFINITY : b.v - norm;
+    }
+    __syncthreads();
+  }
+}
+
+int launch_topk_rules(float* logits, int64_t ldl, int R, int V, int k, const wj_decode_opts& o, const int32_t* row_rules,
+                      const int32_t* ban, int maxb, const int32_t* pen, int maxp, float penalty, int32_t* ids,
+                      float* logprobs, hipStream_t s) {
+  if (k < 1 || k > 16) { set_error("topk_rules: k must be in 1..16"); return WJ_E_INVALID; }
+  hipLaunchKernelGGL(topk_rules_kernel, dim3(R), dim3(SB), 0, s, logits, ldl, V, k, o, row_rules, ban, maxb, pen, maxp,
+                     penalty, ids, logprobs);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
 }  // namespace wj

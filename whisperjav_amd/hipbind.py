@@ -66,6 +66,9 @@ _SIGNATURES = {
     "wj_decode_logits_dev": (_P, [_P]),
     "wj_decode_logits_copy": (_I, [_P, _I, _P, _P]),
     "wj_decode_topk": (_I, [_P, _I, _I, _P, C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F), _P]),
+    "wj_decode_topk_rules": (_I, [_P, _I, _I, C.POINTER(DecodeOptsC), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I,
+                                  C.POINTER(C.c_int32), _I, _F, C.POINTER(C.c_int32), C.POINTER(_F), _P]),
+    "wj_decode_no_speech": (_I, [_P, _I, _I, C.POINTER(_F), _P]),
     "wj_vad_create": (_I, [_P, C.POINTER(_F), _I64, C.POINTER(_P)]),
     "wj_vad_free": (_I, [_P]),
     "wj_vad_scores": (_I, [_P, _P, C.POINTER(_I64), C.POINTER(_I64), _I, _P, _P]),
