@@ -1,0 +1,196 @@
+"""HipFasterWhisperProASR / HipWhisperModel host logic with fakes (no GPU): the plugin surface the
+reference's pipelines call (balanced_pipeline.py:398-403,483,497,580) and faster-whisper's long-form
+window loop."""
+import wave
+from dataclasses import asdict
+
+import numpy as np
+import pytest
+import torch
+
+from whisperjav_amd import asr, dims as pdims, engine, segmenters, whisper_model as wm
+
+
+class FakeWhisper:
+    def __init__(self, script):
+        self.script, self.calls, self.closed = script, [], 0
+
+    def transcribe_many(self, clips, **params):
+        self.calls.append((len(clips), [len(c) for c in clips], params))
+        return [self.script(i, c) for i, c in enumerate(clips)], [None] * len(clips)
+
+    def close(self):
+        self.closed += 1
+
+
+class FakeSegmenter:
+    name = "silero-fake"
+
+    def __init__(self, groups):
+        self.groups, self.cleaned = groups, 0
+
+    def segment(self, audio, sample_rate=16000, **kw):
+        segs = [[segmenters.SpeechSegment(a, b, int(a * sample_rate), int(b * sample_rate)) for a, b in g] for g in self.groups]
+        flat = [s for g in segs for s in g]
+        return segmenters.SegmentationResult(flat, segs, self.name, len(audio) / sample_rate, {})
+
+    def cleanup(self):
+        self.cleaned += 1
+
+
+def _wav(tmp_path, seconds=10.0):
+    path = tmp_path / "scene_0001.wav"
+    pcm = (np.sin(np.arange(int(16000 * seconds)) * 0.05) * 8000).astype("<i2")
+    with wave.open(str(path), "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000); wf.writeframes(pcm.tobytes())
+    return path
+
+
+def _seg(i, start, end, text, lp=-0.3):
+    return wm.Segment(id=i, seek=0, start=start, end=end, text=text, tokens=[1, 2], avg_logprob=lp,
+                      compression_ratio=1.0, no_speech_prob=0.01)
+
+
+CONFIG = {"decoder": {"task": "transcribe", "language": "ja", "beam_size": 2, "patience": 1.2, "suppress_tokens": None,
+                      "logprob_threshold": -1.0, "no_repeat_ngram_size": 3.0, "temperature": [0.0], "fp16": True,
+                      "post_model_filter_enabled": True, "logprob_margin": 0.0},
+          "provider": {"repetition_penalty": 1.5, "hallucination_silence_threshold": None, "word_timestamps": True},
+          "vad": {"threshold": 0.28}, "speech_segmenter": {"backend": "silero-v6.2-hip"}}
+
+
+def test_transcribe_to_srt_batches_groups_and_shifts_timestamps(tmp_path):
+    groups = [[(1.0, 2.0), (2.2, 3.0)], [(5.0, 6.5)]]
+    script = lambda i, clip: [_seg(1, 0.1, 0.9, f" text{i} "), _seg(2, 1.0, 1.5, "ご視聴ありがとうございました"),
+                              _seg(3, 1.6, 1.9, "Thank you", lp=-0.9), _seg(4, 2.0, 2.1, "   ")]
+    fake = FakeWhisper(script)
+    a = asr.HipFasterWhisperProASR({"model_name": "large-v3"}, CONFIG, "transcribe", whisper_model=fake,
+                                   segmenter=FakeSegmenter(groups))
+    assert a.model_name == "large-v3"
+    out = a.transcribe_to_srt(_wav(tmp_path), tmp_path / "out" / "scene_0001.srt", task="transcribe")
+    text = out.read_text(encoding="utf-8")
+    assert len(fake.calls) == 1 and fake.calls[0][0] == 2            # both VAD groups in ONE engine call
+    assert fake.calls[0][1] == [int(3.0 * 16000) - int(1.0 * 16000), int(6.5 * 16000) - int(5.0 * 16000)]
+    params = fake.calls[0][2]
+    assert params["log_prob_threshold"] == -1.0 and "logprob_threshold" not in params
+    assert params["no_repeat_ngram_size"] == 3 and isinstance(params["no_repeat_ngram_size"], int)
+    assert params["temperature"] == 0.0 and "fp16" not in params and params["vad_filter"] is False
+    assert "suppress_tokens" not in params and "hallucination_silence_threshold" not in params
+    # group 0 starts at 1.0 s, group 1 at 5.0 s; high-suppress phrase dropped, low-suppress penalised past the gate
+    assert "00:00:01,100 --> 00:00:01,900" in text and "00:00:05,100 --> 00:00:05,900" in text
+    assert "ありがとう" not in text and "Thank you" not in text
+    assert a.get_filter_statistics() == {"logprob_filtered": 2, "nonverbal_filtered": 0}
+    assert a.get_last_vad_segments() == [{"start_sec": 1.0, "end_sec": 2.0}, {"start_sec": 2.2, "end_sec": 3.0},
+                                         {"start_sec": 5.0, "end_sec": 6.5}]
+    a.reset_statistics()
+    assert a.get_filter_statistics() == {"logprob_filtered": 0, "nonverbal_filtered": 0}
+    a.cleanup(); a.cleanup()
+    assert fake.closed == 1
+
+
+def test_no_speech_returns_empty_and_none_backend_transcribes_everything(tmp_path):
+    fake = FakeWhisper(lambda i, c: [_seg(1, 0.0, 1.0, "x")])
+    a = asr.HipFasterWhisperProASR({}, CONFIG, "transcribe", whisper_model=fake, segmenter=FakeSegmenter([]))
+    res = a.transcribe(_wav(tmp_path))
+    assert res == {"segments": [], "text": "", "language": "ja"} and not fake.calls
+    none = FakeSegmenter([]); none.name = "none"
+    b = asr.HipFasterWhisperProASR({}, CONFIG, "transcribe", whisper_model=fake, segmenter=none)
+    res = b.transcribe(_wav(tmp_path))
+    assert len(res["segments"]) == 1 and fake.calls[-1][1] == [160000]
+
+
+# ---- HipWhisperModel long-form loop with an engine double -----------------------------------------
+class FakeEngine:
+    """Returns scripted token sequences per window and records the mel windows it was asked to encode."""
+
+    def __init__(self, dims, scripts):
+        self.dims, self.tokens = dims, pdims.special_tokens(dims.n_vocab)
+        self.scripts, self.encoded, self.decodes = scripts, [], 0
+
+    def encode(self, mel):
+        self.encoded.append(mel.clone())
+
+    def decode_greedy(self, prompts, options):
+        B = prompts.shape[0]
+        n = options.max_new_tokens
+        toks = np.full((B, n), self.tokens.eot, dtype=np.int32)
+        ntok = np.zeros(B, dtype=np.int32)
+        for r in range(B):
+            seq = self.scripts[min(self.decodes, len(self.scripts) - 1)]
+            toks[r, : len(seq)] = seq
+            ntok[r] = len(seq)
+        self.decodes += 1
+        return engine.GreedyResult(toks, ntok, np.full(B, -2.0, np.float32), np.full(B, 0.01, np.float32),
+                                   np.zeros((B, n), np.float32))
+
+    def close(self):
+        pass
+
+
+class FakeFrontEnd:
+    def frames(self, n):
+        return (n + 160) // 160
+
+    def __call__(self, clips, out_frames):
+        out = torch.zeros((len(clips), 80, out_frames))
+        for i, c in enumerate(clips):
+            out[i, :, : self.frames(len(c))] = 1.0 + i
+        return out
+
+
+def _model(scripts):
+    d = pdims.custom_dims(80, 128, 2, 2, 51865)
+    m = wm.HipWhisperModel.__new__(wm.HipWhisperModel)
+    m.dims, m.model, m.fe = d, FakeEngine(d, scripts), FakeFrontEnd()
+    m.tokens, m.tokenizer = m.model.tokens, wm.IdTokenizer()
+    m.max_batch, m.max_beam, m.max_length, m._warned, m.compute_type = 8, 1, 448, set(), "float32"
+    return m
+
+
+def test_long_form_seek_follows_timestamps():
+    tb = pdims.special_tokens(51865).timestamp_begin
+    # window 1 ends on an unfinished pair at 20.0 s -> seek to 20 s; window 2 (remaining 25 s) closes with a single stamp
+    scripts = [[tb, 11, tb + 500, tb + 500, 12, tb + 1000, tb + 1000, 13], [tb + 50, 21, tb + 400]]
+    m = _model(scripts)
+    audio = np.zeros(16000 * 45, dtype=np.float32)
+    segs, info = m.transcribe(audio, beam_size=1, temperature=0.0, condition_on_previous_text=False, language="ja")
+    segs = list(segs)
+    assert [(round(s.start, 2), round(s.end, 2)) for s in segs] == [(0.0, 10.0), (10.0, 20.0), (20.0, 28.0)]
+    assert segs[2].seek == 2000 and segs[0].seek == 0
+    assert info.duration == pytest.approx(45.0) and info.language == "ja"
+    assert asdict(segs[0])["avg_logprob"] == pytest.approx(-2.0 / 9)
+    w0, w1 = m.model.encoded
+    assert w0.shape == (1, 80, 3000) and torch.all(w0 == 1.0)
+    # second window: 4500 - 2000 = 2500 content frames, zero padded to 3000 (pad_or_trim)
+    assert torch.all(w1[0, :, :2500] == 1.0) and torch.all(w1[0, :, 2500:] == 0.0)
+
+
+def test_transcribe_many_batches_clips_and_rejects_unknown_kwargs():
+    tb = pdims.special_tokens(51865).timestamp_begin
+    m = _model([[tb, 5, tb + 100]])
+    clips = [np.zeros(16000 * 3, np.float32), np.zeros(16000 * 6, np.float32), np.zeros(16000 * 2, np.float32)]
+    segs, infos = m.transcribe_many(clips, beam_size=1, temperature=[0.0], condition_on_previous_text=False)
+    assert len(m.model.encoded) == 1 and m.model.encoded[0].shape[0] == 3      # one encoder batch for all clips
+    assert [len(s) for s in segs] == [1, 1, 1] and [round(i.duration) for i in infos] == [3, 6, 2]
+    enc = m.model.encoded[0]
+    assert torch.all(enc[0, :, :300] == 1.0) and torch.all(enc[0, :, 300:] == 0.0)   # content_frames = frames - 1
+    assert torch.all(enc[1, :, :600] == 2.0) and torch.all(enc[1, :, 600:] == 0.0)
+    with pytest.raises(TypeError):
+        m.transcribe(clips[0], not_an_option=1)
+    with pytest.raises(ValueError):
+        m.transcribe(clips[0], vad_filter=True)
+
+
+def test_no_speech_gate_skips_window():
+    tb = pdims.special_tokens(51865).timestamp_begin
+    m = _model([[tb, 5, tb + 100]])
+    m.model.decode_greedy_orig = m.model.decode_greedy
+
+    def silent(prompts, options):
+        res = m.model.decode_greedy_orig(prompts, options)
+        res.no_speech_prob[:] = 0.9
+        res.sum_logprob[:] = -20.0
+        return res
+    m.model.decode_greedy = silent
+    segs, _ = m.transcribe(np.zeros(16000 * 4, np.float32), beam_size=1, temperature=0.0, no_speech_threshold=0.6,
+                           log_prob_threshold=-1.0)
+    assert list(segs) == []

@@ -347,3 +347,68 @@ def test_beam_search_matches_oracle(hip, dtype, beam, patience, rep, ngram):
         worst = max(worst, abs(got[wdx].cum_logprobs[0] - ref[0][2]))
     _diag("beam", {"dtype": dtype, "beam": beam, "cum_logprob_diff": worst})
     model.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# end-to-end through the reference-shaped surfaces
+# ---------------------------------------------------------------------------------------------
+def test_whisper_model_shim_end_to_end(hip):
+    """HipWhisperModel.transcribe (faster-whisper's call contract) == oracle greedy on the same window,
+    and transcribe_many == per-clip transcribe."""
+    from whisperjav_amd import synth, weights as pweights, whisper_model as wm
+    d = helpers.small_dims()
+    w = pweights.synth_weights(d, seed=21)
+    oracle = whisper_ref.WhisperOracle(helpers.oracle_dims(d), w)
+    model = wm.HipWhisperModel("tiny", compute_type="float32", weights=w, dims=d, max_batch=4, max_beam=2)
+    audio = synth.speech_like(9.0, seed=31)
+    kw = dict(task="transcribe", language="ja", beam_size=1, temperature=0.0, condition_on_previous_text=False,
+              suppress_tokens=[], max_new_tokens=20, no_speech_threshold=None, max_initial_timestamp=0.0,
+              word_timestamps=True, log_progress=False, vad_filter=False)
+    segs, info = model.transcribe(audio, **kw)
+    segs = list(segs)
+    assert info.duration == pytest.approx(9.0) and len(segs) >= 1
+    got = [t for s in segs for t in s.tokens]
+    # oracle on faster-whisper's window: content_frames = frames - 1, zero padded features
+    feat = olm.logmel_fw(audio, d.n_mels)
+    win = np.zeros((1, d.n_mels, 3000), dtype=np.float32)
+    win[0, :, : feat.shape[1] - 1] = feat[:, :-1]
+    toks = model.tokens
+    sup = tuple(sorted({toks.transcribe, toks.translate, toks.sot, toks.sot_prev, toks.sot_lm}))
+    cfg = decoding.FilterConfig(suppress_tokens=sup, max_initial_timestamp_index=0)
+    with torch.no_grad():
+        ref = decoding.greedy_decode(oracle, oracle.encode(torch.from_numpy(win)), model.model.sot_prompt("ja"), 20, cfg)
+    assert ref.tokens[0][: len(got)] == got or got == ref.tokens[0]
+    assert abs(segs[0].avg_logprob - float(ref.avg_logprob()[0])) < 1e-3
+    many, _ = model.transcribe_many([audio, audio[: 16000 * 4]], **kw)
+    assert [t for s in many[0] for t in s.tokens] == got
+    beam, _ = model.transcribe(audio, **dict(kw, beam_size=2, patience=1.2, repetition_penalty=1.5, no_repeat_ngram_size=3))
+    assert len(list(beam)) >= 1
+    model.close()
+
+
+def test_asr_adapter_with_hip_vad_writes_srt(hip, tmp_path):
+    """Scene WAV -> HIP Silero-class segmenter -> grouped windows -> batched decode -> SRT."""
+    import wave
+    from whisperjav_amd import asr, segmenters, synth, weights as pweights, whisper_model as wm
+    d = helpers.small_dims()
+    audio = synth.speech_like(20.0, seed=4)
+    path = tmp_path / "scene_0000.wav"
+    with wave.open(str(path), "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000)
+        wf.writeframes((np.clip(audio, -1, 1) * 32767).astype("<i2").tobytes())
+    model = wm.HipWhisperModel("tiny", compute_type="bfloat16", weights=pweights.synth_weights(d, seed=21), dims=d,
+                               max_batch=8, max_beam=2)
+    seg = segmenters.HipSileroV6SpeechSegmenter(threshold=0.5, speech_pad_ms=100, max_group_duration_s=6.0)
+    params = {"decoder": {"task": "transcribe", "language": "ja", "beam_size": 2, "patience": 1.2, "suppress_tokens": None,
+                          "temperature": [0.0], "max_initial_timestamp": 0.0, "no_speech_threshold": None,
+                          "logprob_threshold": -1.0, "condition_on_previous_text": False, "max_new_tokens": 24},
+              "provider": {"repetition_penalty": 1.5, "no_repeat_ngram_size": 3}, "vad": {"threshold": 0.5},
+              "speech_segmenter": {"backend": "silero-v6.2-hip"}}
+    a = asr.HipFasterWhisperProASR({"model_name": "tiny"}, params, "transcribe", whisper_model=model, segmenter=seg)
+    out = a.transcribe_to_srt(path, tmp_path / "scene_0000.srt")
+    text = out.read_text(encoding="utf-8")
+    vad = a.get_last_vad_segments()
+    _diag("asr_adapter", {"vad_segments": len(vad), "srt_bytes": len(text)})
+    assert len(vad) >= 1 and all(0 <= v["start_sec"] < v["end_sec"] <= 20.0 for v in vad)
+    assert "-->" in text
+    a.cleanup()

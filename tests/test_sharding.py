@@ -1,0 +1,79 @@
+"""Scene-parallel sharding: world_size-2 gloo processes on the CPU (the GPU path uses the same code with
+backend nccl = RCCL).  Covers the single weight broadcast, the LPT plan and the gather/merge of results."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from whisperjav_amd import sharding
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    info = sharding.init_distributed("gloo")
+    assert (info.rank, info.world) == (rank, world)
+    dev = torch.device("cpu")
+    blob = offsets = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(7)
+        blob = torch.randint(0, 255, (1 << 16,), dtype=torch.uint8, generator=g)
+        offsets = np.arange(0, 1 << 16, 256, dtype=np.int64)[:40]
+    got_blob, got_off = sharding.broadcast_blob(blob, offsets, dev)
+    # every rank computes the same deterministic plan and works only on its own scenes
+    durations = [29.0, 3.5, 12.0, 28.5, 7.25, 0.8, 19.0, 19.0, 5.5]
+    plan = sharding.assign_lpt(durations, world)
+    mine = {i: f"scene{i}:rank{rank}:{durations[i]}" for i in plan[rank]}
+    gathered = sharding.gather_objects(mine, dst=0)
+    t = sharding.max_over_ranks(1.0 + rank, dev)
+    sharding.barrier()
+    if rank == 0:
+        merged = sharding.merge_by_index(plan, gathered)
+        torch.save({"blob_sum": int(got_blob.sum()), "off": got_off, "merged": merged, "plan": plan, "tmax": t},
+                   os.path.join(out_dir, "rank0.pt"))
+    else:
+        torch.save({"blob_sum": int(got_blob.sum()), "off": got_off, "tmax": t}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_roundtrip(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
+    assert r0["blob_sum"] == r1["blob_sum"] and np.array_equal(r0["off"], r1["off"]) and len(r0["off"]) == 40
+    assert r0["tmax"] == r1["tmax"] == 2.0
+    assert [m.split(":")[0] for m in r0["merged"]] == [f"scene{i}" for i in range(9)]
+    ranks = {int(m.split("rank")[1].split(":")[0]) for m in r0["merged"]}
+    assert ranks == {0, 1}
+
+
+def test_lpt_plan_properties():
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 4, 8):
+        costs = rng.uniform(0.5, 29.0, size=300).tolist()
+        plan = sharding.assign_lpt(costs, world)
+        assert sorted(i for p in plan for i in p) == list(range(300))          # a partition
+        loads = [sum(costs[i] for i in p) for p in plan]
+        assert max(loads) - min(loads) <= max(costs) + 1e-9                     # LPT balance bound
+        assert plan == sharding.assign_lpt(costs, world)                        # deterministic
+    assert sharding.assign_lpt([], 4) == [[], [], [], []]
+    assert sharding.assign_lpt([5.0], 2) == [[0], []]
+
+
+def test_single_process_paths_are_noops():
+    os.environ.pop("WORLD_SIZE", None); os.environ.pop("RANK", None)
+    blob = torch.arange(64, dtype=torch.uint8)
+    b, o = sharding.broadcast_blob(blob, np.array([0, 32]), torch.device("cpu"))
+    assert torch.equal(b, blob) and o.tolist() == [0, 32]
+    assert sharding.gather_objects({"a": 1}) == [{"a": 1}]
+    assert sharding.max_over_ranks(3.5, torch.device("cpu")) == 3.5

@@ -1,0 +1,295 @@
+"""``FasterWhisperProASR``-shaped ASR module running on the MI355X engine.
+
+Duck-type of /root/reference/whisperjav/modules/faster_whisper_pro_asr.py (class at :31): the
+pipelines only use ``transcribe_to_srt(audio_path, output_srt_path, task=...)``,
+``reset_statistics()``, ``get_last_vad_segments()``, ``get_filter_statistics()``, ``cleanup()`` and the
+attribute ``model_name`` (pipelines/balanced_pipeline.py:398-403,483,497,580), and construct it as
+``(model_config, params, task, tracer=None)`` (:34).  This class keeps that surface and the per-scene
+semantics -- speech segmentation, per-group transcription, high/low suppress lists, optional
+post-model log-prob gate, timestamps shifted by the group start -- but hands ALL VAD groups of a
+scene to the engine in one batched call instead of a Python loop of batch-1 upstream calls.
+"""
+from __future__ import annotations
+
+import datetime
+import logging
+import wave
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Union
+
+import numpy as np
+
+logger = logging.getLogger("whisperjav")
+
+try:  # inside WhisperJAV the reference's own helpers are used unchanged
+    from whisperjav.modules.segment_filters import SegmentFilterConfig, SegmentFilterHelper  # type: ignore
+    from whisperjav.modules.vad_failover import should_force_full_transcribe  # type: ignore
+except Exception:
+    from dataclasses import dataclass
+
+    @dataclass
+    class SegmentFilterConfig:  # logprob gate only; the nonverbal tables live in the reference
+        enabled: bool = True
+        logprob_threshold: Optional[float] = None
+        logprob_margin: float = 0.0
+        drop_nonverbal_vocals: bool = False
+        short_segment_window: float = 1.6
+
+    class SegmentFilterHelper:
+        def __init__(self, config: SegmentFilterConfig):
+            self.enabled = bool(config.enabled)
+            self.threshold = config.logprob_threshold
+            self.margin = max(0.0, config.logprob_margin or 0.0)
+            self.short_window = max(0.4, float(config.short_segment_window or 1.6))
+            if config.drop_nonverbal_vocals:
+                logger.warning("drop_nonverbal_vocals needs whisperjav.modules.segment_filters; ignored standalone")
+
+        def should_filter(self, avg_logprob: float, duration: float, text: str):
+            if not self.enabled:
+                return False, None, None
+            thr = self.threshold
+            if thr is not None and self.margin > 0 and duration <= self.short_window:
+                thr = thr - self.margin
+            if thr is not None and avg_logprob < thr:
+                return True, "logprob", thr
+            return False, None, thr
+
+    def should_force_full_transcribe(vad_segments, audio_duration, min_duration_for_fallback=120.0,
+                                     min_coverage_ratio=0.01) -> bool:
+        if audio_duration <= 0 or audio_duration < min_duration_for_fallback:
+            return False
+        flat = [s for g in (vad_segments or []) for s in (g or [])]
+        if not flat:
+            return True
+        speech = sum(max(0.0, float(s.get("end_sec", 0.0)) - float(s.get("start_sec", 0.0))) for s in flat)
+        if speech / audio_duration < min_coverage_ratio:
+            return True
+        return len(flat) <= 2 and audio_duration >= 4 * min_duration_for_fallback
+
+
+def read_audio(path: Union[str, Path]):
+    """float32 mono samples + rate; soundfile when present, stdlib ``wave`` for the PCM16 scene files."""
+    try:
+        import soundfile as sf
+        data, sr = sf.read(str(path), dtype="float32")
+        if data.ndim > 1:
+            data = np.mean(data, axis=1)
+        return data, sr
+    except ImportError:
+        with wave.open(str(path), "rb") as wf:
+            if wf.getsampwidth() != 2:
+                raise ValueError("without soundfile only PCM16 WAV files can be read")
+            sr, ch = wf.getframerate(), wf.getnchannels()
+            pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+        if ch > 1:
+            pcm = pcm.reshape(-1, ch).mean(axis=1)
+        return pcm, sr
+
+
+def _srt_time(seconds: float) -> str:
+    td = datetime.timedelta(seconds=max(0.0, seconds))
+    total_ms = int(round(td.total_seconds() * 1000))
+    h, rem = divmod(total_ms, 3600000)
+    m, rem = divmod(rem, 60000)
+    s, ms = divmod(rem, 1000)
+    return f"{h:02d}:{m:02d}:{s:02d},{ms:03d}"
+
+
+def compose_srt(segments: List[Dict[str, Any]]) -> str:
+    try:
+        import srt
+        subs = [srt.Subtitle(index=i, start=datetime.timedelta(seconds=s["start"]),
+                             end=datetime.timedelta(seconds=s["end"]), content=s["text"])
+                for i, s in enumerate(segments, 1)]
+        return srt.compose(subs)
+    except ImportError:
+        return "".join(f"{i}\n{_srt_time(s['start'])} --> {_srt_time(s['end'])}\n{s['text']}\n\n"
+                       for i, s in enumerate(segments, 1))
+
+
+class HipFasterWhisperProASR:
+    """Speech segmenter + batched Whisper transcription of one scene file on the MI355X."""
+
+    def __init__(self, model_config: Dict, params: Dict, task: str, tracer=None, *, whisper_model=None,
+                 segmenter=None):
+        self.tracer = tracer
+        self.model_name = model_config.get("model_name", "large-v2")
+        self.device = model_config.get("device", "cuda")
+        self.compute_type = model_config.get("compute_type", "auto")
+        decoder_params = params["decoder"]
+        vad_params = params.get("vad", {}) or {}
+        provider_params = params.get("provider", {}) or {}
+        seg_cfg = params.get("speech_segmenter", {}) or {}
+        backend = seg_cfg.get("backend", "silero-v6.2-hip")
+        if not backend.startswith("silero"):
+            vad_params = {}
+        self.vad_threshold = vad_params.get("threshold", 0.28)
+        self.min_speech_duration_ms = vad_params.get("min_speech_duration_ms", 100)
+        merged = {**vad_params, **seg_cfg} if backend.startswith("silero") else dict(seg_cfg)
+        merged.pop("backend", None)
+        if segmenter is not None:
+            self._external_segmenter = segmenter
+        else:
+            try:
+                self._external_segmenter = self._create_segmenter(backend, merged)
+            except Exception as e:
+                logger.error(f"Failed to create Speech Segmenter '{backend}': {e}")
+                raise ValueError(f"Speech Segmenter not configured - this is an architecture violation: {e}")
+        self.whisper_params: Dict[str, Any] = {}
+        self.whisper_params.update(decoder_params)
+        self.whisper_params.update(provider_params)
+        raw_thr = self.whisper_params.get("logprob_threshold", -1.0)
+        self.logprob_threshold = float(raw_thr) if raw_thr is not None else None
+        self.logprob_margin = float(self.whisper_params.get("logprob_margin", 0.0) or 0.0)
+        self.drop_nonverbal_vocals = bool(self.whisper_params.get("drop_nonverbal_vocals", False))
+        enabled = self.whisper_params.get("post_model_filter_enabled")
+        self.post_model_filter_enabled = False if enabled is None else bool(enabled)
+        self._segment_filter = SegmentFilterHelper(SegmentFilterConfig(
+            enabled=self.post_model_filter_enabled, logprob_threshold=self.logprob_threshold,
+            logprob_margin=self.logprob_margin, drop_nonverbal_vocals=self.drop_nonverbal_vocals))
+        for key in ("logprob_margin", "drop_nonverbal_vocals", "post_model_filter_enabled"):
+            self.whisper_params.pop(key, None)
+        self.whisper_params["task"] = task
+        self.task = task
+        self.suppress_low = ["Thank you", "視聴", "Thanks for"]
+        self.suppress_high = ["視聴ありがとうございました", "ご視聴ありがとうございました", "字幕作成者", "提供", "スポンサー"]
+        self._reset_runtime_statistics()
+        self._last_full_results: List[Dict] = []
+        if whisper_model is not None:
+            self.whisper_model = whisper_model
+        else:
+            from .whisper_model import HipWhisperModel
+            self.whisper_model = HipWhisperModel(self.model_name, device="cuda", compute_type=self.compute_type)
+
+    @staticmethod
+    def _create_segmenter(backend: str, config: Dict[str, Any]):
+        from . import segmenters
+        try:  # inside WhisperJAV: go through the reference's factory (registry entry in INTEGRATION.md)
+            from whisperjav.modules.speech_segmentation import SpeechSegmenterFactory  # type: ignore
+            return SpeechSegmenterFactory.create(backend, config=config)
+        except ImportError:
+            cls_path = segmenters.REGISTRY_ENTRIES.get(backend, segmenters.REGISTRY_ENTRIES["silero-v6.2-hip"])
+            cls = getattr(segmenters, cls_path.rsplit(".", 1)[1])
+            if "v3.1" in backend or "v4.0" in backend:
+                config = dict(config, version="v3.1" if "v3.1" in backend else "v4.0")
+            return cls(**config)
+
+    # ---- statistics hooks used by the pipelines -------------------------------------------------
+    def _reset_runtime_statistics(self) -> None:
+        self._filter_statistics = {"logprob_filtered": 0, "nonverbal_filtered": 0}
+        self._last_vad_segments: List[Dict] = []
+
+    def reset_statistics(self) -> None:
+        self._reset_runtime_statistics()
+
+    def get_filter_statistics(self) -> Dict[str, int]:
+        return dict(self._filter_statistics)
+
+    def get_last_vad_segments(self) -> List[Dict]:
+        return list(self._last_vad_segments)
+
+    # ---- parameters -------------------------------------------------------------------------------
+    def _prepare_whisper_params(self) -> Dict[str, Any]:
+        """Same normalisation as the reference (faster_whisper_pro_asr.py:340-436)."""
+        p = dict(self.whisper_params)
+        if "logprob_threshold" in p:
+            p["log_prob_threshold"] = p.pop("logprob_threshold")
+        if "suppress_tokens" in p:
+            tok = p["suppress_tokens"]
+            if isinstance(tok, tuple):
+                p["suppress_tokens"] = list(tok)
+            elif isinstance(tok, int):
+                p["suppress_tokens"] = [tok]
+            elif tok is not None and not isinstance(tok, list):
+                del p["suppress_tokens"]
+        if "no_repeat_ngram_size" in p and p["no_repeat_ngram_size"] is not None:
+            try:
+                p["no_repeat_ngram_size"] = int(p["no_repeat_ngram_size"])
+            except (ValueError, TypeError):
+                del p["no_repeat_ngram_size"]
+        if isinstance(p.get("temperature"), list):
+            t = p["temperature"]
+            p["temperature"] = tuple(t) if len(t) > 1 else t[0]
+        for key in ("fp16", "verbose", "vad", "vad_threshold", "hallucination_silence_threshold"):
+            p.pop(key, None)
+        p.setdefault("log_progress", False)
+        p["vad_filter"] = p.get("vad_filter", False)
+        return {k: v for k, v in p.items() if v is not None}
+
+    # ---- transcription ----------------------------------------------------------------------------
+    def transcribe(self, audio_path: Union[str, Path], **kwargs) -> Dict:
+        self._last_full_results = []
+        audio_path = Path(audio_path)
+        if "task" in kwargs:
+            runtime_task = kwargs.pop("task")
+            if runtime_task != self.task:
+                self.whisper_params["task"] = runtime_task
+                self.task = runtime_task
+        audio, sr = read_audio(audio_path)
+        result = self._external_segmenter.segment(audio, sample_rate=sr)
+        vad_groups = result.to_legacy_format()
+        duration = len(audio) / sr if sr else 0.0
+        self._last_vad_segments = [{"start_sec": round(s["start_sec"], 3), "end_sec": round(s["end_sec"], 3)}
+                                   for g in vad_groups for s in g]
+        language = self.whisper_params.get("language", "ja")
+        if not vad_groups:
+            if self._external_segmenter.name == "none" or should_force_full_transcribe(vad_groups, duration):
+                spans = [(0.0, duration)]
+            else:
+                return {"segments": [], "text": "", "language": language}
+        elif should_force_full_transcribe(vad_groups, duration):
+            spans = [(0.0, duration)]
+        else:
+            spans = [(g[0]["start_sec"], g[-1]["end_sec"]) for g in vad_groups if g]
+        clips, kept = [], []
+        for start, end in spans:
+            clip = audio[int(start * sr): int(end * sr)]
+            if len(clip) > 200:
+                clips.append(clip)
+                kept.append(start)
+        if not clips:
+            return {"segments": [], "text": "", "language": language}
+        params = self._prepare_whisper_params()
+        per_clip, _ = self.whisper_model.transcribe_many(clips, **params)
+        all_segments: List[Dict] = []
+        for start, segs in zip(kept, per_clip):
+            all_segments.extend(self._filter_group(segs, start))
+        return {"segments": all_segments, "text": " ".join(s["text"] for s in all_segments), "language": language}
+
+    def _filter_group(self, segs, start_sec: float) -> List[Dict]:
+        out = []
+        for seg in segs:
+            text = (seg.text or "").strip()
+            if not text:
+                continue
+            if any(s in text for s in self.suppress_high):
+                continue
+            avg_lp = seg.avg_logprob
+            for word in self.suppress_low:
+                if word in text:
+                    avg_lp -= 0.15
+            drop, reason, _ = self._segment_filter.should_filter(
+                avg_logprob=avg_lp, duration=max(0.0, float(seg.end - seg.start)), text=text)
+            if drop:
+                key = "logprob_filtered" if reason == "logprob" else "nonverbal_filtered"
+                self._filter_statistics[key] += 1
+                continue
+            out.append({"start": seg.start + start_sec, "end": seg.end + start_sec, "text": text, "avg_logprob": avg_lp})
+        return out
+
+    def transcribe_to_srt(self, audio_path: Union[str, Path], output_srt_path: Union[str, Path], **kwargs) -> Path:
+        output_srt_path = Path(output_srt_path)
+        result = self.transcribe(Path(audio_path), **kwargs)
+        output_srt_path.parent.mkdir(parents=True, exist_ok=True)
+        with open(output_srt_path, "w", encoding="utf-8") as f:
+            f.write(compose_srt(result.get("segments", [])))
+        return output_srt_path
+
+    def cleanup(self) -> None:
+        """Idempotent; the reference may skip it entirely (os._exit, main.py:2490-2494)."""
+        model, self.whisper_model = getattr(self, "whisper_model", None), None
+        if model is not None and hasattr(model, "close"):
+            model.close()
+        seg = getattr(self, "_external_segmenter", None)
+        if seg is not None and hasattr(seg, "cleanup"):
+            seg.cleanup()

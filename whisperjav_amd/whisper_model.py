@@ -1,0 +1,447 @@
+"""``faster_whisper.WhisperModel``-shaped shim over the HIP engine.
+
+WhisperJAV enters the upstream model through exactly two calls
+(/root/reference/whisperjav/modules/faster_whisper_pro_asr.py):
+
+    WhisperModel(model_size_or_path, device, compute_type, cpu_threads, num_workers)      # :247-253
+    segments, info = model.transcribe(audio_float32_16k, **params)                        # :819-822
+
+with ``params`` produced by ``_prepare_whisper_params`` (:340-436).  ``HipWhisperModel`` accepts
+the same arguments and yields ``Segment`` objects with the fields the reference consumes
+(``start, end, text, avg_logprob, words``; ``dataclasses.asdict`` works, :883-887).
+
+The long-form logic below restates faster-whisper 1.2.1 ``transcribe.py`` (``generate_segments``,
+``generate_with_fallback``, ``get_prompt``, ``_split_segments_by_timestamps``), which is not vendored
+in the reference: 30 s windows advanced by the last timestamp token, no-speech / log-prob gates,
+segments cut at consecutive timestamp pairs.  Beyond the drop-in call, ``transcribe_many`` runs the
+SAME per-clip procedure for many clips at once (one encoder batch + one batched decode per round),
+which is how the MI355X is kept busy: every VAD group of a scene (or file) becomes one row.
+
+Not implemented (documented in DESIGN.md): sampling temperatures > 0 (the fallback ladder stops at
+its zero-temperature entry), word-level timestamps (``words`` is None).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import zlib
+from dataclasses import dataclass, field
+from typing import Any, Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import dims as pdims
+
+logger = logging.getLogger("whisperjav")
+
+SAMPLE_RATE = 16000
+HOP = 160
+N_FRAMES = 3000
+TIME_PRECISION = 0.02
+INPUT_STRIDE = 2           # mel frames per encoder position
+FRAMES_PER_SECOND = 100
+
+
+@dataclass
+class Word:
+    start: float
+    end: float
+    word: str
+    probability: float
+
+
+@dataclass
+class Segment:
+    id: int
+    seek: int
+    start: float
+    end: float
+    text: str
+    tokens: List[int]
+    avg_logprob: float
+    compression_ratio: float
+    no_speech_prob: float
+    words: Optional[List[Word]] = None
+    temperature: Optional[float] = None
+
+
+@dataclass
+class TranscriptionInfo:
+    language: str
+    language_probability: float
+    duration: float
+    duration_after_vad: float
+    all_language_probs: Optional[List[Tuple[str, float]]] = None
+    transcription_options: Dict[str, Any] = field(default_factory=dict)
+    vad_options: Optional[Dict[str, Any]] = None
+
+
+class IdTokenizer:
+    """Stand-in used when no ``tokenizer.json`` is available (synthetic weights): renders token ids."""
+
+    real = False
+
+    def decode(self, tokens: Sequence[int]) -> str:
+        return "".join(f"<{t}>" for t in tokens)
+
+    def encode(self, text: str) -> List[int]:
+        raise ValueError("this model was loaded without a tokenizer.json; text prompts cannot be encoded")
+
+    def non_speech_tokens(self) -> List[int]:
+        return []
+
+
+class HfTokenizer:
+    """``tokenizer.json`` of a CTranslate2 / HF Whisper model directory via the ``tokenizers`` package."""
+
+    real = True
+
+    def __init__(self, path: str):
+        import tokenizers
+        self._tok = tokenizers.Tokenizer.from_file(path)
+
+    def decode(self, tokens: Sequence[int]) -> str:
+        return self._tok.decode(list(tokens), skip_special_tokens=False)
+
+    def encode(self, text: str) -> List[int]:
+        return self._tok.encode(text, add_special_tokens=False).ids
+
+    def non_speech_tokens(self) -> List[int]:
+        symbols = list('"#()*+/:;<=>@[\\]^_`{|}~「」『』')
+        symbols += "<< >> <<< >>> -- --- -( -[ (' (\" (( )) ((( ))) [[ ]] {{ }} ♪♪ ♪♪♪".split()
+        miscellaneous = set("♩♪♫♬♭♮♯")
+        result = {self.encode(" -")[0], self.encode(" '")[0]}
+        for symbol in symbols + list(miscellaneous):
+            for toks in (self.encode(symbol), self.encode(" " + symbol)):
+                if len(toks) == 1 or symbol in miscellaneous:
+                    result.add(toks[0])
+        return sorted(result)
+
+
+def compression_ratio(text: str) -> float:
+    raw = text.encode("utf-8")
+    return len(raw) / len(zlib.compress(raw)) if raw else 0.0
+
+
+@dataclass
+class TranscribeOptions:
+    task: str = "transcribe"
+    language: Optional[str] = "ja"
+    beam_size: int = 5
+    best_of: int = 5
+    patience: float = 1.0
+    length_penalty: float = 1.0
+    repetition_penalty: float = 1.0
+    no_repeat_ngram_size: int = 0
+    temperature: Union[float, Sequence[float]] = (0.0, 0.2, 0.4, 0.6, 0.8, 1.0)
+    compression_ratio_threshold: Optional[float] = 2.4
+    log_prob_threshold: Optional[float] = -1.0
+    no_speech_threshold: Optional[float] = 0.6
+    condition_on_previous_text: bool = True
+    prompt_reset_on_temperature: float = 0.5
+    initial_prompt: Optional[Union[str, Iterable[int]]] = None
+    prefix: Optional[str] = None
+    suppress_blank: bool = True
+    suppress_tokens: Optional[Sequence[int]] = (-1,)
+    without_timestamps: bool = False
+    max_initial_timestamp: float = 1.0
+    word_timestamps: bool = False
+    max_new_tokens: Optional[int] = None
+    hotwords: Optional[str] = None
+    chunk_length: Optional[int] = None
+    multilingual: bool = False
+    log_progress: bool = False
+    vad_filter: bool = False
+    vad_parameters: Optional[dict] = None
+    clip_timestamps: Union[str, List[float]] = "0"
+    hallucination_silence_threshold: Optional[float] = None
+    language_detection_threshold: Optional[float] = 0.5
+    language_detection_segments: int = 1
+    prepend_punctuations: Optional[str] = None
+    append_punctuations: Optional[str] = None
+
+
+_KNOWN = set(TranscribeOptions.__dataclass_fields__)
+
+
+def split_segments_by_timestamps(tokens: Sequence[int], time_offset: float, segment_size: int,
+                                 segment_duration: float, seek: int, timestamp_begin: int):
+    """faster-whisper ``_split_segments_by_timestamps``: cut a window's tokens at consecutive timestamp
+    pairs; return (segments, new_seek, single_timestamp_ending)."""
+    tokens = list(tokens)
+    out = []
+    single_ending = len(tokens) >= 2 and tokens[-2] < timestamp_begin <= tokens[-1]
+    pairs = [i for i in range(1, len(tokens)) if tokens[i] >= timestamp_begin and tokens[i - 1] >= timestamp_begin]
+    if pairs:
+        cuts = list(pairs)
+        if single_ending:
+            cuts.append(len(tokens))
+        last = 0
+        for cut in cuts:
+            piece = tokens[last:cut]
+            t0 = piece[0] - timestamp_begin
+            t1 = piece[-1] - timestamp_begin
+            out.append({"seek": seek, "start": time_offset + t0 * TIME_PRECISION,
+                        "end": time_offset + t1 * TIME_PRECISION, "tokens": piece})
+            last = cut
+        if single_ending:
+            seek += segment_size
+        else:
+            seek += (tokens[last - 1] - timestamp_begin) * INPUT_STRIDE
+    else:
+        duration = segment_duration
+        stamps = [t for t in tokens if t >= timestamp_begin]
+        if stamps and stamps[-1] != timestamp_begin:
+            duration = (stamps[-1] - timestamp_begin) * TIME_PRECISION
+        out.append({"seek": seek, "start": time_offset, "end": time_offset + duration, "tokens": tokens})
+        seek += segment_size
+    return out, seek, single_ending
+
+
+@dataclass
+class _ClipState:
+    index: int
+    n_frames_content: int
+    duration: float
+    seek: int = 0
+    all_tokens: List[int] = field(default_factory=list)
+    prompt_reset_since: int = 0
+    segments: List[Segment] = field(default_factory=list)
+    next_id: int = 0
+
+    @property
+    def active(self) -> bool:
+        return self.seek < self.n_frames_content
+
+
+class HipWhisperModel:
+    """Drop-in for ``faster_whisper.WhisperModel`` (constructor + ``transcribe``)."""
+
+    def __init__(self, model_size_or_path: str = "large-v3", device: str = "cuda", device_index: int = 0,
+                 compute_type: str = "bfloat16", cpu_threads: int = 0, num_workers: int = 1,
+                 weights: Optional[Dict[str, np.ndarray]] = None, dims: Optional[pdims.WhisperDims] = None,
+                 max_batch: int = 32, max_beam: int = 5, blob=None, offsets=None, **_unused):
+        from . import engine, weights as W
+        if device not in ("cuda", "auto", "hip"):
+            raise ValueError(f"HipWhisperModel runs on the MI355X only (device={device!r}); there is no CPU path")
+        ct = {"auto": "bfloat16", "default": "bfloat16", "bfloat16": "bfloat16", "float16": "bfloat16",
+              "float32": "float32", "int8": "bfloat16", "int8_float16": "bfloat16", "int8_bfloat16": "bfloat16"}
+        if compute_type not in ct:
+            raise ValueError(f"unsupported compute_type {compute_type!r}")
+        self.compute_type = ct[compute_type]
+        self.tokenizer: Any = IdTokenizer()
+        if blob is None and weights is None:
+            dims, weights = self._load_checkpoint(model_size_or_path)
+        elif dims is None:
+            dims = pdims.dims_for(model_size_or_path)
+        self.dims = dims
+        self.model = engine.HipWhisper(dims, weights, blob=blob, offsets=offsets, dtype=self.compute_type,
+                                       device=device_index, max_batch=max_batch, max_beam=max_beam)
+        self.fe = engine.HipLogMel(dims.n_mels, "fw", device=device_index)
+        self.tokens = self.model.tokens
+        self.max_batch, self.max_beam = max_batch, max_beam
+        self.max_length = dims.n_text_ctx
+        self._warned = set()
+
+    # ---- loading ---------------------------------------------------------------------------
+    def _load_checkpoint(self, path: str):
+        from . import weights as W
+        if os.path.isdir(path):
+            tok = os.path.join(path, "tokenizer.json")
+            if os.path.exists(tok):
+                self.tokenizer = HfTokenizer(tok)
+            for name in ("model.pt", "whisper.pt"):
+                cand = os.path.join(path, name)
+                if os.path.exists(cand):
+                    return W.load_openai_checkpoint(cand)
+            raise FileNotFoundError(f"{path} holds no openai-format checkpoint (model.pt); convert the CTranslate2 "
+                                    "model with tools described in INTEGRATION.md")
+        if os.path.isfile(path):
+            return W.load_openai_checkpoint(path)
+        raise FileNotFoundError(
+            f"model {path!r}: no local checkpoint found and this environment has no network; pass weights=/dims= "
+            "(e.g. whisperjav_amd.weights.synth_weights) or a directory with model.pt + tokenizer.json")
+
+    def close(self) -> None:
+        self.model.close()
+
+    def _warn_once(self, key: str, msg: str) -> None:
+        if key not in self._warned:
+            self._warned.add(key)
+            logger.warning(msg)
+
+    # ---- option plumbing -------------------------------------------------------------------
+    def _options(self, kw: Dict[str, Any]) -> TranscribeOptions:
+        unknown = set(kw) - _KNOWN
+        if unknown:
+            raise TypeError(f"transcribe() got unexpected keyword argument(s): {sorted(unknown)}")
+        o = TranscribeOptions(**kw)
+        if o.length_penalty is None:
+            o.length_penalty = 1.0
+        if o.word_timestamps:
+            self._warn_once("words", "word_timestamps=True: word-level alignment is not implemented on the HIP path "
+                                     "yet; segments carry start/end/text/avg_logprob and words=None")
+        if o.vad_filter:
+            raise ValueError("vad_filter=True is not supported: WhisperJAV runs its own speech segmenter "
+                             "(faster_whisper_pro_asr.py passes vad_filter=False)")
+        return o
+
+    def _suppressed(self, o: TranscribeOptions) -> Tuple[int, ...]:
+        t = self.tokens
+        sup = list(o.suppress_tokens or [])
+        if -1 in sup:
+            sup = [x for x in sup if x >= 0] + list(self.tokenizer.non_speech_tokens())
+        sup += [t.transcribe, t.translate, t.sot, t.sot_prev, t.sot_lm]
+        return tuple(sorted(set(sup)))
+
+    def _prompt(self, o: TranscribeOptions, previous: Sequence[int], first_window: bool) -> List[int]:
+        t = self.tokens
+        prompt: List[int] = []
+        hot = o.hotwords if (o.hotwords and not o.prefix) else None
+        if previous or hot:
+            prompt.append(t.sot_prev)
+            if hot:
+                ht = self.tokenizer.encode(" " + hot.strip())
+                prompt.extend(ht[: self.max_length // 2 - 1])
+            if previous:
+                prompt.extend(list(previous)[-(self.max_length // 2 - 1):])
+        lang = o.language or "ja"
+        prompt.extend([t.sot, t.language_token(pdims.language_index(lang)),
+                       t.transcribe if o.task == "transcribe" else t.translate])
+        if o.without_timestamps:
+            prompt.append(t.no_timestamps)
+        if o.prefix and first_window:
+            pt = self.tokenizer.encode(" " + o.prefix.strip())
+            if not o.without_timestamps:
+                prompt.append(t.timestamp_begin)
+            prompt.extend(pt[: self.max_length // 2 - 1])
+        return prompt
+
+    # ---- decoding of one batch of windows ------------------------------------------------------
+    def _decode_windows(self, prompts: List[List[int]], o: TranscribeOptions, suppress: Tuple[int, ...]):
+        """Returns per window (tokens, avg_logprob, no_speech_prob, temperature, compression_ratio)."""
+        from . import engine, search
+        temps = o.temperature if isinstance(o.temperature, (list, tuple)) else [o.temperature]
+        if any(float(x) > 0 for x in temps[1:]) or float(temps[0]) > 0:
+            self._warn_once("temp", "temperature fallback with sampling (temperature > 0) is not implemented on the HIP "
+                                    "path; only the zero-temperature entry is evaluated")
+        P = len(prompts[0])
+        max_new = (self.max_length - P) if o.max_new_tokens is None else int(o.max_new_tokens)
+        max_new = max(1, min(max_new, self.max_length - P))
+        mit = int(round(float(o.max_initial_timestamp) / TIME_PRECISION))
+        greedy = (o.beam_size == 1 and float(o.repetition_penalty) == 1.0 and int(o.no_repeat_ngram_size) == 0)
+        out = []
+        if greedy:
+            res = self.model.decode_greedy(
+                np.array(prompts, dtype=np.int32),
+                engine.DecodeOptions(max_new_tokens=max_new, suppress_blank=o.suppress_blank,
+                                     without_timestamps=o.without_timestamps, suppress_tokens=suppress,
+                                     max_initial_timestamp=mit * TIME_PRECISION))
+            for r in range(len(prompts)):
+                toks = res.tokens[r, : res.n_tokens[r]].tolist()
+                out.append((toks, float(res.sum_logprob[r]) / (len(toks) + 1), float(res.no_speech_prob[r])))
+        else:
+            so = search.SearchOptions(beam_size=int(o.beam_size), patience=float(o.patience),
+                                      length_penalty=float(o.length_penalty),
+                                      repetition_penalty=float(o.repetition_penalty),
+                                      no_repeat_ngram_size=int(o.no_repeat_ngram_size), suppress_blank=o.suppress_blank,
+                                      suppress_tokens=suppress, without_timestamps=o.without_timestamps,
+                                      max_initial_timestamp_index=mit, max_new_tokens=max_new)
+            results = search.beam_search(search.HipStepScorer(self.model, so), prompts, so, eot=self.tokens.eot,
+                                         timestamp_begin=self.tokens.timestamp_begin, n_text_ctx=self.max_length)
+            for wr in results:
+                out.append((wr.sequences[0], wr.avg_logprob(0), wr.no_speech_prob))
+        final = []
+        for toks, avg_lp, nsp in out:
+            text = self.tokenizer.decode([t for t in toks if t < self.tokens.eot]).strip()
+            final.append((toks, avg_lp, nsp, float(temps[0]), compression_ratio(text)))
+        return final
+
+    # ---- public API ------------------------------------------------------------------------------
+    def transcribe(self, audio: np.ndarray, **kwargs) -> Tuple[Iterator[Segment], TranscriptionInfo]:
+        """faster-whisper's call contract for ONE clip: ``(segment iterator, info)``."""
+        segs, infos = self.transcribe_many([audio], **kwargs)
+        return iter(segs[0]), infos[0]
+
+    def transcribe_many(self, audios: Sequence[np.ndarray], **kwargs) -> Tuple[List[List[Segment]], List[TranscriptionInfo]]:
+        """The same per-clip procedure for many clips, batched across clips window by window."""
+        import torch
+        o = self._options(dict(kwargs))
+        suppress = self._suppressed(o)
+        clips = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in audios]
+        if any(len(c) <= 200 for c in clips):
+            raise ValueError("every clip must be longer than 200 samples (12.5 ms)")
+        # features of every clip in ONE launch; frame axis padded so any 3000-frame window can be sliced
+        frames = [self.fe.frames(len(c)) for c in clips]
+        width = max(frames) + N_FRAMES
+        feats = self.fe(clips, out_frames=width)                   # [n, n_mels, width], zero padded (pad_or_trim)
+        states = [_ClipState(i, frames[i] - 1, len(clips[i]) / SAMPLE_RATE) for i in range(len(clips))]
+        initial: List[int] = []
+        if o.initial_prompt is not None:
+            initial = (self.tokenizer.encode(" " + o.initial_prompt.strip()) if isinstance(o.initial_prompt, str)
+                       else list(o.initial_prompt))
+            for st in states:
+                st.all_tokens.extend(initial)
+        tb = self.tokens.timestamp_begin
+
+        while True:
+            active = [st for st in states if st.active]
+            if not active:
+                break
+            for lo in range(0, len(active), self.max_batch):
+                batch = active[lo: lo + self.max_batch]
+                # windows with equal prompt lengths decode together (the common case: no previous text)
+                groups: Dict[int, List[Tuple[_ClipState, List[int], int]]] = {}
+                mel = torch.empty((len(batch), self.dims.n_mels, N_FRAMES), dtype=torch.float32, device=feats.device)
+                sizes = []
+                for j, st in enumerate(batch):
+                    size = min(N_FRAMES, st.n_frames_content - st.seek)
+                    sizes.append(size)
+                    mel[j] = feats[st.index, :, st.seek: st.seek + N_FRAMES]
+                    if size < N_FRAMES:
+                        mel[j, :, size:] = 0.0
+                self.model.encode(mel)
+                prompts = [self._prompt(o, st.all_tokens[st.prompt_reset_since:], st.seek == 0) for st in batch]
+                for j, p in enumerate(prompts):
+                    groups.setdefault(len(p), []).append((batch[j], p, j))
+                if len(groups) == 1:
+                    decoded = self._decode_windows(prompts, o, suppress)
+                else:   # heterogeneous prompt lengths: decode group by group against re-encoded slots
+                    decoded = [None] * len(batch)
+                    for _, members in groups.items():
+                        idx = [j for _, _, j in members]
+                        self.model.encode(mel[idx].contiguous())
+                        res = self._decode_windows([p for _, p, _ in members], o, suppress)
+                        for j, r in zip(idx, res):
+                            decoded[j] = r
+                for j, st in enumerate(batch):
+                    toks, avg_lp, nsp, temp, cr = decoded[j]
+                    size = sizes[j]
+                    time_offset = st.seek * HOP / SAMPLE_RATE
+                    seg_duration = size * HOP / SAMPLE_RATE
+                    if o.no_speech_threshold is not None:
+                        skip = nsp > o.no_speech_threshold
+                        if o.log_prob_threshold is not None and avg_lp > o.log_prob_threshold:
+                            skip = False
+                        if skip:
+                            st.seek += size
+                            continue
+                    prev_seek = st.seek
+                    pieces, st.seek, _ = split_segments_by_timestamps(toks, time_offset, size, seg_duration, st.seek, tb)
+                    for piece in pieces:
+                        text = self.tokenizer.decode([t for t in piece["tokens"] if t < self.tokens.eot])
+                        if piece["start"] == piece["end"] or not text.strip():
+                            continue
+                        st.all_tokens.extend(piece["tokens"])
+                        st.next_id += 1
+                        st.segments.append(Segment(id=st.next_id, seek=prev_seek, start=piece["start"], end=piece["end"],
+                                                   text=text, tokens=piece["tokens"], avg_logprob=avg_lp,
+                                                   compression_ratio=cr, no_speech_prob=nsp, words=None,
+                                                   temperature=temp))
+                    if not o.condition_on_previous_text or temp > o.prompt_reset_on_temperature:
+                        st.prompt_reset_since = len(st.all_tokens)
+        infos = [TranscriptionInfo(language=o.language or "ja", language_probability=1.0, duration=st.duration,
+                                   duration_after_vad=st.duration, transcription_options=dict(kwargs))
+                 for st in states]
+        return [st.segments for st in states], infos
