@@ -148,6 +148,10 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
                              float* sum_logprob_out, float* no_speech_prob_out,
                              float* token_logprob_out, void* stream);
 
+/* diagnostics of the last wj_whisper_decode_greedy call: out[0] = 1 if the step was replayed from a
+ * hipGraph, out[1] = number of concurrent row chains */
+int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[2]);
+
 /* Step-wise decoder for host-driven search (beam search with CTranslate2's patience /
  * repetition-penalty / no-repeat-ngram processors lives in whisperjav_amd/search.py).
  * rows = batch*beam, row r belongs to window r / beam.

@@ -129,6 +129,7 @@ struct wj_whisper {
   float* topk_lse = nullptr;
   // step-wise decode state
   int open_batch = 0, open_beam = 0, open_rows = 0, host_pos = 0;
+  int last_used_graph = 0, last_chains = 1;   // diagnostics of the last greedy decode
 
   const void* W(int idx) const { return blob + off[idx]; }
   const float* F(int idx) const { return reinterpret_cast<const float*>(blob + off[idx]); }
@@ -244,71 +245,86 @@ static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, flo
 // ------------------------------------------------------------------------------------------------
 // decoder: one token per row
 // ------------------------------------------------------------------------------------------------
-static int run_decoder_step(wj_whisper* m, int R, int n_windows, int beam, bool want_logits, hipStream_t s) {
+// Rows [row0, row0 + R) (windows [row0 / beam, ...)) advance by one token.  Rows are independent, so the
+// greedy loop runs several disjoint row slices ("chains") concurrently on forked streams: each of the
+// ~355 kernels of a step is latency bound and fills at most a third of the chip, two chains overlap.
+static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int beam, bool want_logits, hipStream_t s) {
   const wj_whisper_dims& d = m->d;
   const int D = d.n_text_state, H = d.n_text_head, dt = m->dtype;
-  PROF(PT_D_EMBED, launch_embed(dt, m->W(WJ_T_DEC_TOK_EMB), m->F(WJ_T_DEC_POS), m->tokens, m->tok_stride, m->pos, m->dx, R, D, s));
+  const int win0 = row0 / beam;
+  float* dx = m->dx + (int64_t)row0 * D;
+  void* dh = m->at(m->dh, (int64_t)row0 * D);
+  void* dq = m->at(m->dq, (int64_t)row0 * D);
+  void* dattn = m->at(m->dattn, (int64_t)row0 * D);
+  void* dff = m->at(m->dff, (int64_t)row0 * 4 * D);
+  const int64_t self_row = (int64_t)H * d.n_text_ctx * 64;      // cache elements per row
+  const int64_t cross_win = (int64_t)H * d.n_audio_ctx * 64;    // cross K (or V) elements per window
+  PROF(PT_D_EMBED, launch_embed(dt, m->W(WJ_T_DEC_TOK_EMB), m->F(WJ_T_DEC_POS), m->tokens + (int64_t)row0 * m->tok_stride,
+                                m->tok_stride, m->pos, dx, R, D, s));
   for (int l = 0; l < d.n_text_layer; ++l) {
     const int b0 = m->dec_base(l);
     void* sk = m->at(m->self_k, l * m->self_layer_elems());
     void* sv = m->at(m->self_v, l * m->self_layer_elems());
-    PROF(PT_D_LN, launch_layernorm(dt, m->dx, m->F(b0 + WJ_TD_LN1_W), m->F(b0 + WJ_TD_LN1_B), m->dh, R, D, s));
+    PROF(PT_D_LN, launch_layernorm(dt, dx, m->F(b0 + WJ_TD_LN1_W), m->F(b0 + WJ_TD_LN1_B), dh, R, D, s));
     {
       GemmArgs g;
-      g.A = m->dh; g.lda = D; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
-      g.M = R; g.N = 3 * D; g.K = D; g.out = m->dq; g.out2 = sk; g.out3 = sv;
+      g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
+      g.M = R; g.N = 3 * D; g.K = D; g.out = dq;
+      g.out2 = m->at(sk, row0 * self_row); g.out3 = m->at(sv, row0 * self_row);
       g.D = D; g.H = H; g.pos_ptr = m->pos; g.cache_len = d.n_text_ctx;
       PROF(PT_D_QKV, launch_gemm(dt, EPI_QKV_DEC, g, s));
     }
     {
-      DecAttnArgs a;
-      a.q = m->dq; a.K = sk; a.V = sv; a.out = m->dattn; a.G = R; a.nb = 1; a.H = H;
-      a.n_keys_ptr = m->pos; a.kv_stride = d.n_text_ctx; a.row_map = m->row_map[m->cur_map];
+      DecAttnArgs a;   // K/V bases stay absolute: the row map holds absolute physical rows
+      a.q = dq; a.K = sk; a.V = sv; a.out = dattn; a.G = R; a.nb = 1; a.H = H;
+      a.n_keys_ptr = m->pos; a.kv_stride = d.n_text_ctx;
+      a.row_map = m->row_map[m->cur_map] + (int64_t)row0 * d.n_text_ctx;
       PROF(PT_D_SELF, launch_attention_dec(dt, a, s));
     }
     {
       GemmArgs g;
-      g.A = m->dattn; g.lda = D; g.W = m->W(b0 + WJ_TD_OUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_OUT_B);
-      g.M = R; g.N = D; g.K = D; g.out = m->dx; g.ldc = D;
+      g.A = dattn; g.lda = D; g.W = m->W(b0 + WJ_TD_OUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_OUT_B);
+      g.M = R; g.N = D; g.K = D; g.out = dx; g.ldc = D;
       PROF(PT_D_OUT, launch_gemm(dt, EPI_RESID_F32, g, s));
     }
-    PROF(PT_D_LN, launch_layernorm(dt, m->dx, m->F(b0 + WJ_TD_LNX_W), m->F(b0 + WJ_TD_LNX_B), m->dh, R, D, s));
+    PROF(PT_D_LN, launch_layernorm(dt, dx, m->F(b0 + WJ_TD_LNX_W), m->F(b0 + WJ_TD_LNX_B), dh, R, D, s));
     {
       GemmArgs g;
-      g.A = m->dh; g.lda = D; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
-      g.M = R; g.N = D; g.K = D; g.out = m->dq; g.ldc = D;
+      g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
+      g.M = R; g.N = D; g.K = D; g.out = dq; g.ldc = D;
       PROF(PT_D_CQ, launch_gemm(dt, EPI_T, g, s));
     }
     {
       DecAttnArgs a;
-      a.q = m->dq; a.K = m->at(m->cross_k, l * m->cross_layer_elems());
-      a.V = m->at(m->cross_v, l * m->cross_layer_elems());
-      a.out = m->dattn; a.G = n_windows; a.nb = beam; a.H = H; a.n_keys = d.n_audio_ctx; a.kv_stride = d.n_audio_ctx;
+      a.q = dq;
+      a.K = m->at(m->cross_k, l * m->cross_layer_elems() + win0 * cross_win);
+      a.V = m->at(m->cross_v, l * m->cross_layer_elems() + win0 * cross_win);
+      a.out = dattn; a.G = n_windows; a.nb = beam; a.H = H; a.n_keys = d.n_audio_ctx; a.kv_stride = d.n_audio_ctx;
       PROF(PT_D_CROSS, launch_attention_dec(dt, a, s));
     }
     {
       GemmArgs g;
-      g.A = m->dattn; g.lda = D; g.W = m->W(b0 + WJ_TD_COUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_COUT_B);
-      g.M = R; g.N = D; g.K = D; g.out = m->dx; g.ldc = D;
+      g.A = dattn; g.lda = D; g.W = m->W(b0 + WJ_TD_COUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_COUT_B);
+      g.M = R; g.N = D; g.K = D; g.out = dx; g.ldc = D;
       PROF(PT_D_COUT, launch_gemm(dt, EPI_RESID_F32, g, s));
     }
-    PROF(PT_D_LN, launch_layernorm(dt, m->dx, m->F(b0 + WJ_TD_LN2_W), m->F(b0 + WJ_TD_LN2_B), m->dh, R, D, s));
+    PROF(PT_D_LN, launch_layernorm(dt, dx, m->F(b0 + WJ_TD_LN2_W), m->F(b0 + WJ_TD_LN2_B), dh, R, D, s));
     {
       GemmArgs g;
-      g.A = m->dh; g.lda = D; g.W = m->W(b0 + WJ_TD_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_FC1_B);
-      g.M = R; g.N = 4 * D; g.K = D; g.out = m->dff; g.ldc = 4 * D;
+      g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_FC1_B);
+      g.M = R; g.N = 4 * D; g.K = D; g.out = dff; g.ldc = 4 * D;
       PROF(PT_D_FC1, launch_gemm(dt, EPI_GELU_T, g, s));
       GemmArgs g2;
-      g2.A = m->dff; g2.lda = 4 * D; g2.W = m->W(b0 + WJ_TD_FC2_W); g2.ldw = 4 * D; g2.bias = m->F(b0 + WJ_TD_FC2_B);
-      g2.M = R; g2.N = D; g2.K = 4 * D; g2.out = m->dx; g2.ldc = D;
+      g2.A = dff; g2.lda = 4 * D; g2.W = m->W(b0 + WJ_TD_FC2_W); g2.ldw = 4 * D; g2.bias = m->F(b0 + WJ_TD_FC2_B);
+      g2.M = R; g2.N = D; g2.K = 4 * D; g2.out = dx; g2.ldc = D;
       PROF(PT_D_FC2, launch_gemm(dt, EPI_RESID_F32, g2, s));
     }
   }
   if (want_logits) {
-    PROF(PT_D_LN, launch_layernorm(dt, m->dx, m->F(WJ_T_DEC_LN_W), m->F(WJ_T_DEC_LN_B), m->dh, R, D, s));
+    PROF(PT_D_LN, launch_layernorm(dt, dx, m->F(WJ_T_DEC_LN_W), m->F(WJ_T_DEC_LN_B), dh, R, D, s));
     GemmArgs g;
-    g.A = m->dh; g.lda = D; g.W = m->W(WJ_T_DEC_TOK_EMB); g.ldw = D;
-    g.M = R; g.N = d.n_vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
+    g.A = dh; g.lda = D; g.W = m->W(WJ_T_DEC_TOK_EMB); g.ldw = D;
+    g.M = R; g.N = d.n_vocab; g.K = D; g.out = m->logits + (int64_t)row0 * m->ldl; g.ldc = m->ldl;
     PROF(PT_D_LOGITS, launch_gemm(dt, EPI_F32, g, s));
   }
   return WJ_OK;
@@ -558,14 +574,46 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
   // prompt positions 0 .. prompt_len-2 only fill the KV cache (position 0 also yields no_speech_prob)
   for (int p = 0; p + 1 < prompt_len; ++p) {
     const bool ns = (p == 0) && no_speech_prob_out != nullptr;
-    WJ_TRY(run_decoder_step(m, R, R, 1, ns, s));
+    WJ_TRY(run_decoder_step(m, 0, R, R, 1, ns, s));
     if (ns) WJ_TRY(launch_no_speech_prob(m->logits, m->ldl, R, m->d.n_vocab, opts->no_speech, m->nsp, s));
     WJ_TRY(launch_advance_pos(m->pos, s));
   }
-  GreedyArgs ga;
-  ga.logits = m->logits; ga.ldl = m->ldl; ga.R = R; ga.V = m->d.n_vocab;
-  ga.tokens = m->tokens; ga.tok_stride = m->tok_stride; ga.pos_ptr = m->pos; ga.sample_begin = prompt_len;
-  ga.sum_logprob = m->sum_lp; ga.token_logprob = m->tok_lp; ga.finished = m->finished; ga.opts = *opts;
+  // ---- one decode iteration as `chains` independent row slices on forked streams ---------------------
+  int chains = 2;
+  if (const char* ce = getenv("WJ_DECODE_CHAINS")) chains = atoi(ce);
+  if (chains < 1) chains = 1;
+  if (chains > 4) chains = 4;
+  if (prof_on(m->ctx)) chains = 1;            // event pairs are recorded on one stream
+  while (chains > 1 && R < 2 * chains) --chains;
+  hipStream_t side[4] = {s, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int c = 1; c < chains; ++c) {
+    WJ_HIP(hipStreamCreateWithFlags(&side[c], hipStreamNonBlocking));
+    WJ_HIP(hipEventCreateWithFlags(&ev_join[c], hipEventDisableTiming));
+  }
+  if (chains > 1) WJ_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  auto iteration = [&](void) -> int {
+    if (chains > 1) WJ_HIP(hipEventRecord(ev_fork, s));
+    for (int c = chains - 1; c >= 0; --c) {
+      const int r0 = (int)((int64_t)R * c / chains), r1 = (int)((int64_t)R * (c + 1) / chains);
+      hipStream_t cs = side[c];
+      if (c > 0) WJ_HIP(hipStreamWaitEvent(cs, ev_fork, 0));
+      WJ_TRY(run_decoder_step(m, r0, r1 - r0, r1 - r0, 1, true, cs));
+      GreedyArgs ga;
+      ga.logits = m->logits + (int64_t)r0 * m->ldl; ga.ldl = m->ldl; ga.R = r1 - r0; ga.V = m->d.n_vocab;
+      ga.tokens = m->tokens + (int64_t)r0 * m->tok_stride; ga.tok_stride = m->tok_stride; ga.pos_ptr = m->pos;
+      ga.sample_begin = prompt_len; ga.sum_logprob = m->sum_lp + r0; ga.token_logprob = m->tok_lp + (int64_t)r0 * m->tok_stride;
+      ga.finished = m->finished + r0; ga.opts = *opts;
+      {
+        hipStream_t s = cs;   // PROF records on the chain's own stream
+        PROF(PT_D_SAMPLE, launch_greedy_sample(ga, s));
+      }
+      if (c > 0) WJ_HIP(hipEventRecord(ev_join[c], cs));
+    }
+    for (int c = 1; c < chains; ++c) WJ_HIP(hipStreamWaitEvent(s, ev_join[c], 0));
+    PROF(PT_D_MISC, launch_advance_pos(m->pos, s));
+    return WJ_OK;
+  };
 
   // One decode iteration = ~11 launches per layer; capture it once and replay it from a hipGraph so
   // the loop is not host-launch bound.  Every step-dependent scalar lives in device memory (m->pos).
@@ -576,9 +624,7 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
   if (use_graph) {
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
-      int rc = run_decoder_step(m, R, R, 1, true, s);
-      if (!rc) rc = launch_greedy_sample(ga, s);
-      if (!rc) rc = launch_advance_pos(m->pos, s);
+      int rc = iteration();
       e = hipStreamEndCapture(s, &graph);
       if (rc || e != hipSuccess || graph == nullptr) use_graph = false;
       else if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) use_graph = false;
@@ -591,14 +637,14 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
       if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
     }
   }
+  m->last_used_graph = use_graph ? 1 : 0;
+  m->last_chains = chains;
   std::vector<int32_t> fin(R);
   for (int i = 0; i < max_new; ++i) {
     if (use_graph) {
       WJ_HIP(hipGraphLaunch(exec, s));
     } else {
-      WJ_TRY(run_decoder_step(m, R, R, 1, true, s));
-      PROF(PT_D_SAMPLE, launch_greedy_sample(ga, s));
-      PROF(PT_D_MISC, launch_advance_pos(m->pos, s));
+      WJ_TRY(iteration());
     }
     if ((i & 15) == 15 && i + 1 < max_new) {  // early exit once every row has emitted EOT
       WJ_HIP(hipMemcpyAsync(fin.data(), m->finished, sizeof(int32_t) * R, hipMemcpyDeviceToHost, s));
@@ -608,6 +654,12 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
       if (all) break;
     }
   }
+  WJ_HIP(hipStreamSynchronize(s));
+  for (int c = 1; c < chains; ++c) {
+    (void)hipStreamDestroy(side[c]);
+    (void)hipEventDestroy(ev_join[c]);
+  }
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (exec) (void)hipGraphExecDestroy(exec);
   if (graph) (void)hipGraphDestroy(graph);
 
@@ -662,7 +714,7 @@ int wj_decode_step(wj_whisper* m, const int32_t* tokens_host, const int32_t* par
   }
   hipLaunchKernelGGL(put_tokens_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, s, m->tokens, m->tok_stride, m->pos, m->step_tok, R);
   WJ_LAUNCH_CHECK();
-  WJ_TRY(run_decoder_step(m, R, m->open_batch, m->open_beam, want_logits != 0, s));
+  WJ_TRY(run_decoder_step(m, 0, R, m->open_batch, m->open_beam, want_logits != 0, s));
   WJ_TRY(launch_advance_pos(m->pos, s));
   WJ_HIP(hipStreamSynchronize(s));  // host buffers may be reused by the caller
   m->host_pos += 1;
@@ -670,6 +722,13 @@ int wj_decode_step(wj_whisper* m, const int32_t* tokens_host, const int32_t* par
 }
 
 float* wj_decode_logits_dev(wj_whisper* m) { return m ? m->logits : nullptr; }
+
+int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[2]) {
+  WJ_REQUIRE(m && out, "wj_whisper_last_decode_info: NULL argument");
+  out[0] = m->last_used_graph;
+  out[1] = m->last_chains;
+  return WJ_OK;
+}
 
 int wj_decode_logits_copy(wj_whisper* m, int rows, float* dst_dev, void* stream) {
   WJ_REQUIRE(m && dst_dev && rows >= 1 && rows <= m->max_rows, "wj_decode_logits_copy: bad arguments");

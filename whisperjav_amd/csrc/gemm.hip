@@ -114,7 +114,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int z = blockIdx.z;
-  const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+  // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (each XCD has its own 4 MiB L2).
+  // Remap so every XCD walks a CONTIGUOUS run of tiles in m-major order: the n-tiles that share one
+  // A row-panel then hit the same L2 instead of fetching the panel once per XCD (PMC before the remap:
+  // ~5x the algorithmic bytes on the fc2 GEMM).  Bijective for any tile count.
+  const int nx = gridDim.x, ntiles = gridDim.x * gridDim.y;
+  const int lin = blockIdx.y * nx + blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  const int m0 = (tile / nx) * TBM, n0 = (tile % nx) * TBN;
   const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)z * g.a_batch;
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
 

@@ -215,6 +215,11 @@ class HipWhisper:
                                                  as_f(slp), as_f(nsp), as_f(tlp), None), "wj_whisper_decode_greedy")
         return GreedyResult(toks, ntok, slp, nsp, tlp)
 
+    def last_decode_info(self) -> dict:
+        out = (C.c_int32 * 2)()
+        check(self._lib.wj_whisper_last_decode_info(self.handle, out), "wj_whisper_last_decode_info")
+        return {"hip_graph": bool(out[0]), "chains": int(out[1])}
+
     def sot_prompt(self, language: str = "ja", task: str = "transcribe", without_timestamps: bool = False) -> List[int]:
         from .dims import language_index
         t = self.tokens

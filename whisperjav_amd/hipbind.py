@@ -61,6 +61,7 @@ _SIGNATURES = {
     "wj_whisper_encode": (_I, [_P, _P, _I, _I, _P, _P]),
     "wj_whisper_decode_greedy": (_I, [_P, _I, C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _P]),
+    "wj_whisper_last_decode_info": (_I, [_P, C.POINTER(C.c_int32)]),
     "wj_decode_open": (_I, [_P, _I, _I, _P]),
     "wj_decode_step": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _P]),
     "wj_decode_logits_dev": (_P, [_P]),
