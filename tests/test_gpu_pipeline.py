@@ -412,3 +412,31 @@ def test_asr_adapter_with_hip_vad_writes_srt(hip, tmp_path):
     assert len(vad) >= 1 and all(0 <= v["start_sec"] < v["end_sec"] <= 20.0 for v in vad)
     assert "-->" in text
     a.cleanup()
+
+
+def test_decode_chains_are_equivalent(hip, monkeypatch):
+    """The greedy loop splits the rows into concurrent chains on forked streams (captured into one
+    hipGraph); results must not depend on the number of chains."""
+    from whisperjav_amd import engine
+    d, oracle, model = _engine_and_oracle("float32", max_batch=6)
+    mel = torch.from_numpy(helpers.synth_mel(6, d.n_mels, seed=23))
+    prompt = np.tile(np.array(model.sot_prompt("ja"), dtype=np.int32), (6, 1))
+    opts = engine.DecodeOptions(max_new_tokens=20, max_initial_timestamp=1.0)
+    model.encode(mel.cuda())
+    outs = []
+    for chains in ("1", "2", "3"):
+        monkeypatch.setenv("WJ_DECODE_CHAINS", chains)
+        res = model.decode_greedy(prompt, opts)
+        info = model.last_decode_info()
+        assert info["chains"] == int(chains) and info["hip_graph"] is True, info
+        outs.append(res)
+    for res in outs[1:]:
+        assert np.array_equal(res.tokens, outs[0].tokens)
+        assert np.array_equal(res.token_logprob, outs[0].token_logprob)
+        assert np.array_equal(res.sum_logprob, outs[0].sum_logprob)
+    with torch.no_grad():
+        ref = decoding.greedy_decode(oracle, oracle.encode(mel), model.sot_prompt("ja"), 20,
+                                     decoding.FilterConfig(max_initial_timestamp_index=50))
+    for r in range(6):
+        assert outs[1].tokens[r, : outs[1].n_tokens[r]].tolist() == ref.tokens[r]
+    model.close()
