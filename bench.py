@@ -110,6 +110,90 @@ def cpu_baseline(dims, w, audio, n_mels, decode_tokens, sample_tokens):
                        f"{threads} threads; mel {t_mel:.2f}s enc {t_enc:.2f}s dec({sample_tokens}) {t_dec:.2f}s")}
 
 
+def split_scenes(audio, max_s=29.0, min_s=4.0, sr=16000):
+    """Stand-in for the reference's auditok scene detector (auditok is not installable offline;
+    whisperjav/modules/scene_detection_backends/auditok_backend.py:229-322 stays the production step before the
+    path): cut at the quietest 100 ms frame inside each [min_s, max_s] look-ahead window."""
+    frame = sr // 10
+    n = len(audio) // frame
+    energy = (audio[: n * frame].reshape(n, frame) ** 2).mean(axis=1)
+    cuts, pos = [0], 0
+    while len(audio) - pos * frame > max_s * sr:
+        lo, hi = pos + int(min_s * 10), pos + int(max_s * 10)
+        pos = lo + int(np.argmin(energy[lo:hi]))
+        cuts.append(pos * frame)
+    cuts.append(len(audio))
+    return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] - cuts[i] > 400]
+
+
+def run_cfg3(args, info, dims):
+    """BASELINE cfg3: mode=balanced -- scenes <= 29 s -> Silero-class VAD on the GPU -> groups <= 6 s ->
+    batched beam-5 transcription (patience 1.2, repetition penalty 1.5, no-repeat-3-gram,
+    condition_on_previous_text=False), 10 min of noisy synthetic audio on one GPU."""
+    from whisperjav_amd import segmenters, vad
+    from whisperjav_amd.whisper_model import HipWhisperModel
+    minutes = args.minutes
+    audio = synth.speech_like(60.0 * minutes, seed=1234, noisy=True)
+    w = pweights.synth_weights(dims, seed=1234)
+    model = HipWhisperModel(args.model, compute_type=args.dtype, weights=w, dims=dims, max_batch=args.batch,
+                            max_beam=5, device_index=info.local_rank)
+    del w
+    seg = segmenters.HipSileroV6SpeechSegmenter(threshold=0.5, min_speech_duration_ms=100, min_silence_duration_ms=300,
+                                               speech_pad_ms=400, chunk_threshold_s=2.5, max_group_duration_s=6.0,
+                                               device=info.local_rank)
+    kw = dict(task="transcribe", language="ja", beam_size=5, best_of=2, patience=1.2, temperature=[0.0],
+              repetition_penalty=1.5, no_repeat_ngram_size=3, condition_on_previous_text=False, suppress_blank=True,
+              max_initial_timestamp=0.0, no_speech_threshold=None, log_prob_threshold=-1.0,
+              max_new_tokens=args.max_new_tokens, word_timestamps=False)
+
+    def once():
+        t0 = time.perf_counter()
+        scenes = split_scenes(audio)
+        t1 = time.perf_counter()
+        seg._ensure_model()
+        probs = seg._model.scores([audio[a:b] for a, b in scenes])          # every scene scored concurrently
+        groups = []
+        for (a, b), p in zip(scenes, probs):
+            regions = vad.regions_from_probs(p, b - a, threshold=seg.threshold,
+                                             min_speech_duration_ms=seg.min_speech_duration_ms,
+                                             max_speech_duration_s=seg.max_speech_duration_s,
+                                             min_silence_duration_ms=seg.min_silence_duration_ms,
+                                             speech_pad_ms=seg.speech_pad_ms)
+            segs = [segmenters.SpeechSegment(r["start"] / 16000, r["end"] / 16000, r["start"], r["end"]) for r in regions]
+            for g in segmenters.group_segments(segs, seg.max_group_duration_s, seg.chunk_threshold_s):
+                groups.append((a + g[0].start_sample, a + g[-1].end_sample))
+        t2 = time.perf_counter()
+        clips = [audio[a:b] for a, b in groups if b - a > 400]
+        out, _ = model.transcribe_many(clips, **kw)
+        t3 = time.perf_counter()
+        return {"scenes": len(scenes), "groups": len(clips), "segments": sum(len(x) for x in out),
+                "speech_s": sum(len(c) for c in clips) / 16000.0, "t_scene": t1 - t0, "t_vad": t2 - t1, "t_asr": t3 - t2}
+
+    for _ in range(args.warmup):
+        once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = None
+    for _ in range(args.steps):
+        stats = once()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rtfx = 60.0 * minutes * args.steps / elapsed
+    line = {"metric": "audio-hours/sec (RTF) end-to-end, Whisper large-v3 ja", "value": round(rtfx, 2),
+            "unit": "x real-time (audio-s per wall-s)", "audio_hours_per_sec": round(rtfx / 3600.0, 5), "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+            "config": {"workload": (f"cfg3: mode=balanced on {minutes} min of noisy synthetic audio: energy-gate scenes <= 29 s, "
+                                    f"HIP Silero-class VAD, groups <= 6 s, Whisper {args.model} geometry (seeded random "
+                                    f"weights), beam 5 / patience 1.2 / repetition penalty 1.5 / no-repeat-3-gram, "
+                                    f"max_new_tokens={args.max_new_tokens}, host-driven beam search"),
+                       "windows_per_batch": args.batch, "compute_type": args.dtype, **stats},
+            "roofline": None, "cpu_baseline": None}
+    print(json.dumps(line), flush=True)
+    model.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +206,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-sample-tokens", type=int, default=32)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
+    ap.add_argument("--minutes", type=float, default=10.0, help="cfg3: synthetic audio length")
+    ap.add_argument("--max-new-tokens", type=int, default=64, help="cfg3: transcribe(max_new_tokens=...)")
     args = ap.parse_args()
 
     info = sharding.init_distributed()
@@ -133,6 +220,8 @@ def main():
     torch.cuda.set_device(info.local_rank)
     dev = torch.device("cuda", info.local_rank)
     dims = pdims.dims_for(args.model)
+    if args.workload == "cfg3":
+        return run_cfg3(args, info, dims)
     B, n_dec = args.batch, args.decode_tokens
 
     # ---- weights: packed once on rank 0, ONE RCCL broadcast, then no collectives -------------

@@ -248,7 +248,9 @@ static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, flo
 // Rows [row0, row0 + R) (windows [row0 / beam, ...)) advance by one token.  Rows are independent, so the
 // greedy loop runs several disjoint row slices ("chains") concurrently on forked streams: each of the
 // ~355 kernels of a step is latency bound and fills at most a third of the chip, two chains overlap.
-static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int beam, bool want_logits, hipStream_t s) {
+static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int beam, bool want_logits, hipStream_t s,
+                            int* pos = nullptr) {
+  if (!pos) pos = m->pos;
   const wj_whisper_dims& d = m->d;
   const int D = d.n_text_state, H = d.n_text_head, dt = m->dtype;
   const int win0 = row0 / beam;
@@ -260,7 +262,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   const int64_t self_row = (int64_t)H * d.n_text_ctx * 64;      // cache elements per row
   const int64_t cross_win = (int64_t)H * d.n_audio_ctx * 64;    // cross K (or V) elements per window
   PROF(PT_D_EMBED, launch_embed(dt, m->W(WJ_T_DEC_TOK_EMB), m->F(WJ_T_DEC_POS), m->tokens + (int64_t)row0 * m->tok_stride,
-                                m->tok_stride, m->pos, dx, R, D, s));
+                                m->tok_stride, pos, dx, R, D, s));
   for (int l = 0; l < d.n_text_layer; ++l) {
     const int b0 = m->dec_base(l);
     void* sk = m->at(m->self_k, l * m->self_layer_elems());
@@ -271,13 +273,13 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
       g.M = R; g.N = 3 * D; g.K = D; g.out = dq;
       g.out2 = m->at(sk, row0 * self_row); g.out3 = m->at(sv, row0 * self_row);
-      g.D = D; g.H = H; g.pos_ptr = m->pos; g.cache_len = d.n_text_ctx;
+      g.D = D; g.H = H; g.pos_ptr = pos; g.cache_len = d.n_text_ctx;
       PROF(PT_D_QKV, launch_gemm(dt, EPI_QKV_DEC, g, s));
     }
     {
       DecAttnArgs a;   // K/V bases stay absolute: the row map holds absolute physical rows
       a.q = dq; a.K = sk; a.V = sv; a.out = dattn; a.G = R; a.nb = 1; a.H = H;
-      a.n_keys_ptr = m->pos; a.kv_stride = d.n_text_ctx;
+      a.n_keys_ptr = pos; a.kv_stride = d.n_text_ctx;
       a.row_map = m->row_map[m->cur_map] + (int64_t)row0 * d.n_text_ctx;
       PROF(PT_D_SELF, launch_attention_dec(dt, a, s));
     }
@@ -578,7 +580,11 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
     if (ns) WJ_TRY(launch_no_speech_prob(m->logits, m->ldl, R, m->d.n_vocab, opts->no_speech, m->nsp, s));
     WJ_TRY(launch_advance_pos(m->pos, s));
   }
-  // ---- one decode iteration as `chains` independent row slices on forked streams ---------------------
+  // ---- the decode loop as `chains` INDEPENDENT row slices --------------------------------------------
+  // Each chain owns a row range, its own step counter (m->pos + c) and its own stream, and replays its
+  // own hipGraph of one decode iteration: the ~355 kernels of a step are latency bound and fill at most
+  // a third of the chip, so chains on different hardware queues overlap.  (Forking one graph into
+  // branches does not: ROCm replays the branches of a graph back to back -- measured +3 %.)
   int chains = 2;
   if (const char* ce = getenv("WJ_DECODE_CHAINS")) chains = atoi(ce);
   if (chains < 1) chains = 1;
@@ -586,67 +592,67 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
   if (prof_on(m->ctx)) chains = 1;            // event pairs are recorded on one stream
   while (chains > 1 && R < 2 * chains) --chains;
   hipStream_t side[4] = {s, nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
-  for (int c = 1; c < chains; ++c) {
-    WJ_HIP(hipStreamCreateWithFlags(&side[c], hipStreamNonBlocking));
-    WJ_HIP(hipEventCreateWithFlags(&ev_join[c], hipEventDisableTiming));
+  hipEvent_t ev_start = nullptr;
+  for (int c = 1; c < chains; ++c) WJ_HIP(hipStreamCreateWithFlags(&side[c], hipStreamNonBlocking));
+  if (chains > 1) {   // the side streams start after the prompt steps; every chain gets a copy of the counter
+    for (int c = 1; c < chains; ++c)
+      WJ_HIP(hipMemcpyAsync(m->pos + c, m->pos, sizeof(int), hipMemcpyDeviceToDevice, s));
+    WJ_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+    WJ_HIP(hipEventRecord(ev_start, s));
+    for (int c = 1; c < chains; ++c) WJ_HIP(hipStreamWaitEvent(side[c], ev_start, 0));
   }
-  if (chains > 1) WJ_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-  auto iteration = [&](void) -> int {
-    if (chains > 1) WJ_HIP(hipEventRecord(ev_fork, s));
-    for (int c = chains - 1; c >= 0; --c) {
-      const int r0 = (int)((int64_t)R * c / chains), r1 = (int)((int64_t)R * (c + 1) / chains);
-      hipStream_t cs = side[c];
-      if (c > 0) WJ_HIP(hipStreamWaitEvent(cs, ev_fork, 0));
-      WJ_TRY(run_decoder_step(m, r0, r1 - r0, r1 - r0, 1, true, cs));
-      GreedyArgs ga;
-      ga.logits = m->logits + (int64_t)r0 * m->ldl; ga.ldl = m->ldl; ga.R = r1 - r0; ga.V = m->d.n_vocab;
-      ga.tokens = m->tokens + (int64_t)r0 * m->tok_stride; ga.tok_stride = m->tok_stride; ga.pos_ptr = m->pos;
-      ga.sample_begin = prompt_len; ga.sum_logprob = m->sum_lp + r0; ga.token_logprob = m->tok_lp + (int64_t)r0 * m->tok_stride;
-      ga.finished = m->finished + r0; ga.opts = *opts;
-      {
-        hipStream_t s = cs;   // PROF records on the chain's own stream
-        PROF(PT_D_SAMPLE, launch_greedy_sample(ga, s));
-      }
-      if (c > 0) WJ_HIP(hipEventRecord(ev_join[c], cs));
-    }
-    for (int c = 1; c < chains; ++c) WJ_HIP(hipStreamWaitEvent(s, ev_join[c], 0));
-    PROF(PT_D_MISC, launch_advance_pos(m->pos, s));
+  auto iteration = [&](int c) -> int {
+    const int r0 = (int)((int64_t)R * c / chains), r1 = (int)((int64_t)R * (c + 1) / chains);
+    hipStream_t s = side[c];   // shadows the outer stream: PROF records on the chain's stream
+    int* pos = m->pos + c;
+    WJ_TRY(run_decoder_step(m, r0, r1 - r0, r1 - r0, 1, true, s, pos));
+    GreedyArgs ga;
+    ga.logits = m->logits + (int64_t)r0 * m->ldl; ga.ldl = m->ldl; ga.R = r1 - r0; ga.V = m->d.n_vocab;
+    ga.tokens = m->tokens + (int64_t)r0 * m->tok_stride; ga.tok_stride = m->tok_stride; ga.pos_ptr = pos;
+    ga.sample_begin = prompt_len; ga.sum_logprob = m->sum_lp + r0; ga.token_logprob = m->tok_lp + (int64_t)r0 * m->tok_stride;
+    ga.finished = m->finished + r0; ga.opts = *opts;
+    PROF(PT_D_SAMPLE, launch_greedy_sample(ga, s));
+    PROF(PT_D_MISC, launch_advance_pos(pos, s));
     return WJ_OK;
   };
 
-  // One decode iteration = ~11 launches per layer; capture it once and replay it from a hipGraph so
-  // the loop is not host-launch bound.  Every step-dependent scalar lives in device memory (m->pos).
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  // One decode iteration = ~11 launches per layer; capture it once per chain and replay it from a
+  // hipGraph so the loop is not host-launch bound.  Every step-dependent scalar lives in device memory.
+  hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t exec[4] = {nullptr, nullptr, nullptr, nullptr};
   const char* env = getenv("WJ_NO_GRAPH");
   bool use_graph = !(env && env[0] == '1') && !prof_on(m->ctx);
-  if (use_graph) {
-    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  for (int c = 0; c < chains && use_graph; ++c) {
+    hipError_t e = hipStreamBeginCapture(side[c], hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
-      int rc = iteration();
-      e = hipStreamEndCapture(s, &graph);
-      if (rc || e != hipSuccess || graph == nullptr) use_graph = false;
-      else if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) use_graph = false;
+      int rc = iteration(c);
+      e = hipStreamEndCapture(side[c], &graph[c]);
+      if (rc || e != hipSuccess || graph[c] == nullptr) use_graph = false;
+      else if (hipGraphInstantiate(&exec[c], graph[c], nullptr, nullptr, 0) != hipSuccess) use_graph = false;
     } else {
       use_graph = false;
     }
-    if (!use_graph) {
-      (void)hipGetLastError();
-      if (exec) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
-      if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+  }
+  if (!use_graph) {
+    (void)hipGetLastError();
+    for (int c = 0; c < 4; ++c) {
+      if (exec[c]) { (void)hipGraphExecDestroy(exec[c]); exec[c] = nullptr; }
+      if (graph[c]) { (void)hipGraphDestroy(graph[c]); graph[c] = nullptr; }
     }
   }
   m->last_used_graph = use_graph ? 1 : 0;
   m->last_chains = chains;
   std::vector<int32_t> fin(R);
   for (int i = 0; i < max_new; ++i) {
-    if (use_graph) {
-      WJ_HIP(hipGraphLaunch(exec, s));
-    } else {
-      WJ_TRY(iteration());
+    for (int c = 0; c < chains; ++c) {
+      if (use_graph) {
+        WJ_HIP(hipGraphLaunch(exec[c], side[c]));
+      } else {
+        WJ_TRY(iteration(c));
+      }
     }
     if ((i & 15) == 15 && i + 1 < max_new) {  // early exit once every row has emitted EOT
+      for (int c = 1; c < chains; ++c) WJ_HIP(hipStreamSynchronize(side[c]));
       WJ_HIP(hipMemcpyAsync(fin.data(), m->finished, sizeof(int32_t) * R, hipMemcpyDeviceToHost, s));
       WJ_HIP(hipStreamSynchronize(s));
       bool all = true;
@@ -654,14 +660,13 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
       if (all) break;
     }
   }
-  WJ_HIP(hipStreamSynchronize(s));
-  for (int c = 1; c < chains; ++c) {
-    (void)hipStreamDestroy(side[c]);
-    (void)hipEventDestroy(ev_join[c]);
+  for (int c = 0; c < chains; ++c) WJ_HIP(hipStreamSynchronize(side[c]));
+  for (int c = 1; c < chains; ++c) (void)hipStreamDestroy(side[c]);
+  if (ev_start) (void)hipEventDestroy(ev_start);
+  for (int c = 0; c < 4; ++c) {
+    if (exec[c]) (void)hipGraphExecDestroy(exec[c]);
+    if (graph[c]) (void)hipGraphDestroy(graph[c]);
   }
-  if (ev_fork) (void)hipEventDestroy(ev_fork);
-  if (exec) (void)hipGraphExecDestroy(exec);
-  if (graph) (void)hipGraphDestroy(graph);
 
   std::vector<int32_t> hist((size_t)R * m->tok_stride);
   std::vector<float> lps((size_t)R * m->tok_stride);

@@ -122,7 +122,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
   const int lin = blockIdx.y * nx + blockIdx.x;
   const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
-  const int m0 = (tile / nx) * TBM, n0 = (tile % nx) * TBN;
+  // inside the run, walk groups of GM row-panels column by column: the ~64 tiles an XCD has in
+  // flight then form an 8 x 8 patch and re-use both the A and the W panels ~8x from L2
+  constexpr int GM = 8;
+  const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
+  const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
+  const int m0 = (first_m + in_group % gsz) * TBM, n0 = (in_group / gsz) * TBN;
   const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)z * g.a_batch;
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
 
