@@ -582,10 +582,11 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
   }
   // ---- the decode loop as `chains` INDEPENDENT row slices --------------------------------------------
   // Each chain owns a row range, its own step counter (m->pos + c) and its own stream, and replays its
-  // own hipGraph of one decode iteration: the ~355 kernels of a step are latency bound and fill at most
-  // a third of the chip, so chains on different hardware queues overlap.  (Forking one graph into
-  // branches does not: ROCm replays the branches of a graph back to back -- measured +3 %.)
-  int chains = 2;
+  // own hipGraph of one decode iteration.  Measured on MI355X / ROCm 7.2 (profiles/): the
+  // ~355 short kernels of a step do NOT overlap across streams (2 chains +2 %, 4 chains -26 %; forked
+  // branches inside one graph +3 %), i.e. the per-kernel cost is dispatch latency, so the default is one
+  // chain and WJ_DECODE_CHAINS keeps the experiment reproducible.
+  int chains = 1;
   if (const char* ce = getenv("WJ_DECODE_CHAINS")) chains = atoi(ce);
   if (chains < 1) chains = 1;
   if (chains > 4) chains = 4;
