@@ -232,3 +232,78 @@ def beam_search(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], b
     lpn = bcfg.length_penalty
     ranked = sorted(((s / (max(len(t), 1) ** lpn) if lpn != 0 else s, s, t) for s, t in finished), key=lambda x: -x[0])
     return [(t, n, s) for n, s, t in ranked], nsp
+
+
+# --------------------------------------------------------------------------------------------------
+# openai-whisper beam search (whisper/decoding.py BeamSearchDecoder + MaximumLikelihoodRanker), literal
+# --------------------------------------------------------------------------------------------------
+def beam_search_openai(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], beam_size: int,
+                       patience: Optional[float], length_penalty: Optional[float], sample_len: int,
+                       fcfg: Optional[FilterConfig] = None):
+    """One window.  Returns (tokens of the selected hypothesis, sum_logprob, avg_logprob, no_speech_prob)."""
+    fcfg = fcfg or FilterConfig()
+    lay = TokenLayout.for_vocab(model.dims.n_vocab)
+    K, P = beam_size, len(prompt)
+    max_candidates = round(K * (patience or 1.0))
+    with torch.no_grad():
+        dec = CachedDecoder(model, xa.expand(K, -1, -1).contiguous())
+        nsp = 0.0
+        for p in range(P - 1):
+            lg = dec.step(torch.full((K, 1), prompt[p]))
+            if p == 0:
+                nsp = float(torch.softmax(lg[0].float(), -1)[lay.no_speech])
+        tokens = [list(prompt) for _ in range(K)]
+        sum_lp = [0.0] * K
+        finished: dict = {}
+        feed = torch.full((K, 1), prompt[-1])
+        for i in range(sample_len):
+            logits = dec.step(feed)
+            if P == 1 and i == 0:
+                nsp = float(torch.softmax(logits[0].float(), -1)[lay.no_speech])
+            logits = filter_logits(logits, tokens, P, lay, fcfg)
+            logprobs = torch.log_softmax(logits.float(), dim=-1)
+            scores, sources, newly = {}, {}, {}
+            for j in range(K):
+                vals, idx = logprobs[j].topk(K + 1)
+                for lp, tok in zip(vals.tolist(), idx.tolist()):
+                    if lp == NEG_INF:
+                        continue
+                    seq = tuple(tokens[j] + [tok])
+                    scores[seq] = sum_lp[j] + lp
+                    sources[seq] = j
+            nxt, src = [], []
+            for seq in sorted(scores, key=scores.get, reverse=True):
+                if seq[-1] == lay.eot:
+                    newly[seq] = scores[seq]
+                else:
+                    nxt.append(seq)
+                    src.append(sources[seq])
+                    if len(nxt) == K:
+                        break
+            while len(nxt) < K:
+                nxt.append(nxt[-1]); src.append(src[-1])
+            sum_lp = [scores[s] for s in nxt]
+            tokens = [list(s) for s in nxt]
+            dec.reorder(torch.tensor(src))
+            feed = torch.tensor([[s[-1]] for s in nxt])
+            for seq in sorted(newly, key=newly.get, reverse=True):
+                if len(finished) >= max_candidates:
+                    break
+                finished[seq] = newly[seq]
+            if len(finished) >= max_candidates:
+                break
+    cand = dict(finished)
+    if len(cand) < K:
+        for j in np.argsort(sum_lp)[::-1]:
+            cand[tuple(tokens[j] + [lay.eot])] = sum_lp[j]
+            if len(cand) >= K:
+                break
+    seqs = [list(s[P:]) for s in cand]
+    seqs = [s[: s.index(lay.eot)] if lay.eot in s else s for s in seqs]
+    totals = list(cand.values())
+
+    def score(lp, n):
+        pen = n if length_penalty is None else ((5 + n) / 6) ** length_penalty
+        return lp / pen if pen else NEG_INF
+    best = int(np.argmax([score(lp, len(s)) for lp, s in zip(totals, seqs)]))
+    return seqs[best], totals[best], totals[best] / (len(seqs[best]) + 1), nsp

@@ -194,3 +194,55 @@ def test_no_speech_gate_skips_window():
     segs, _ = m.transcribe(np.zeros(16000 * 4, np.float32), beam_size=1, temperature=0.0, no_speech_threshold=0.6,
                            log_prob_threshold=-1.0)
     assert list(segs) == []
+
+
+# ---- fidelity flavour (openai-whisper call contract) ------------------------------------------------
+def _ow_model(scripts):
+    d = pdims.custom_dims(80, 128, 2, 2, 51865)
+    m = wm.HipOpenAIWhisperModel.__new__(wm.HipOpenAIWhisperModel)
+    m.dims, m.model = d, FakeEngine(d, scripts)
+
+    class OwFrontEnd(FakeFrontEnd):
+        def frames(self, n):
+            return (n + 480000) // 160
+    m.fe = OwFrontEnd()
+    m.tokens, m.tokenizer = m.model.tokens, wm.IdTokenizer()
+    m.max_batch, m.max_beam, m.max_length, m._warned, m.compute_type = 8, 1, 448, set(), "float32"
+    return m
+
+
+def test_openai_flavour_returns_dict_and_uses_padded_mel_semantics():
+    tb = pdims.special_tokens(51865).timestamp_begin
+    m = _ow_model([[tb, 5, tb + 100, tb + 100, tb + 100]])
+    res = m.transcribe(np.zeros(16000 * 2, np.float32), verbose=None, fp16=True, temperature=(0.0,), beam_size=None,
+                       logprob_threshold=-1.0, no_speech_threshold=0.6, condition_on_previous_text=False,
+                       suppress_tokens="-1", language="ja", task="transcribe")
+    assert set(res) == {"text", "segments", "language"} and res["language"] == "ja"
+    # [tb,5,tb+100] is a real segment; the trailing pair [tb+100, tb+100] is instantaneous -> kept with cleared text
+    assert [(s["start"], s["end"], s["text"]) for s in res["segments"]] == [(0.0, 2.0, "<5>"), (2.0, 2.0, "")]
+    assert res["segments"][1]["tokens"] == [] and res["segments"][0]["id"] == 0
+    enc = m.model.encoded[0]
+    assert torch.all(enc[0, :, :200] == 1.0) and torch.all(enc[0, :, 200:] == 0.0)   # content = frames - 3000, zero pad
+    assert m._suppressed(m._options({})).count(m.tokens.no_speech) == 1               # ow also suppresses <|nospeech|>
+
+
+def test_fidelity_asr_module_gate_on_by_default(tmp_path):
+    class DictModel:
+        def __init__(self):
+            self.calls = []
+
+        def transcribe(self, audio, **params):
+            self.calls.append(params)
+            return {"text": "x", "language": "ja", "segments": [
+                {"id": 0, "seek": 0, "start": 0.0, "end": 1.0, "text": " good ", "avg_logprob": -0.2, "tokens": [1]},
+                {"id": 1, "seek": 0, "start": 1.0, "end": 2.0, "text": " bad ", "avg_logprob": -1.7, "tokens": [2]}]}
+    cfg = {"decoder": {"task": "transcribe", "language": "ja", "beam_size": 5, "fp16": True, "temperature": [0.0, 0.2],
+                       "logprob_threshold": -1.0}, "provider": {}, "vad": {}, "speech_segmenter": {"backend": "silero-v6.2-hip"}}
+    model = DictModel()
+    a = asr.HipWhisperProASR({"model_name": "large-v2"}, cfg, "transcribe", whisper_model=model,
+                             segmenter=FakeSegmenter([[(0.5, 3.0)]]))
+    res = a.transcribe(_wav(tmp_path))
+    assert [s["text"] for s in res["segments"]] == ["good"]                  # post-model log-prob gate is ON in fidelity
+    assert res["segments"][0]["start"] == pytest.approx(0.5)
+    assert a.get_filter_statistics()["logprob_filtered"] == 1
+    assert model.calls[0]["temperature"] == (0.0, 0.2) and model.calls[0]["fp16"] is True and "verbose" in model.calls[0]

@@ -440,3 +440,35 @@ def test_decode_chains_are_equivalent(hip, monkeypatch):
     for r in range(6):
         assert outs[1].tokens[r, : outs[1].n_tokens[r]].tolist() == ref.tokens[r]
     model.close()
+
+
+def test_fidelity_flavour_end_to_end(hip):
+    """openai-whisper call contract on the engine: 'ow' log-mel semantics + BeamSearchDecoder-style search,
+    checked against the oracle's literal restatement on the same window."""
+    from whisperjav_amd import synth, weights as pweights, whisper_model as wm
+    d = helpers.small_dims()
+    w = pweights.synth_weights(d, seed=21)
+    oracle = whisper_ref.WhisperOracle(helpers.oracle_dims(d), w)
+    model = wm.HipOpenAIWhisperModel("tiny", compute_type="float32", weights=w, dims=d, max_batch=2, max_beam=3)
+    audio = synth.speech_like(7.0, seed=13)
+    res = model.transcribe(audio, verbose=None, fp16=False, temperature=(0.0,), beam_size=3, patience=None,
+                           length_penalty=None, suppress_tokens=[], condition_on_previous_text=False,
+                           no_speech_threshold=None, logprob_threshold=None, language="ja", task="transcribe",
+                           sample_len=18)
+    assert set(res) == {"text", "segments", "language"} and len(res["segments"]) >= 1
+    got = [t for s in res["segments"] for t in s["tokens"]]
+    mel = olm.logmel_ow(audio, d.n_mels)
+    content = mel.shape[1] - 3000
+    win = np.zeros((1, d.n_mels, 3000), dtype=np.float32)
+    win[0, :, :content] = mel[:, :content]
+    toks = model.tokens
+    sup = tuple(sorted({toks.transcribe, toks.translate, toks.sot, toks.sot_prev, toks.sot_lm, toks.no_speech}))
+    cfg = decoding.FilterConfig(suppress_tokens=sup, max_initial_timestamp_index=50)
+    with torch.no_grad():
+        xa = oracle.encode(torch.from_numpy(win))
+        seq, total, avg, nsp = decoding.beam_search_openai(oracle, xa, model.model.sot_prompt("ja"), 3, None, None, 18, cfg)
+    first_window = [t for s in res["segments"] if s["seek"] == 0 for t in s["tokens"]]
+    assert seq[: len(first_window)] == first_window or first_window == seq, (first_window, seq)
+    assert abs(res["segments"][0]["avg_logprob"] - avg) < 1e-3
+    _diag("fidelity", {"tokens": len(got), "avg_logprob_diff": abs(res["segments"][0]["avg_logprob"] - avg)})
+    model.close()

@@ -119,3 +119,24 @@ def test_rule_helpers():
     assert search.ngram_bans([1, 2, 1, 2, 1], 2) == [2]
     assert search.ngram_bans([7, 7, 7], 1) == [7]
     assert search.ngram_bans([1, 2], 3) == []
+
+
+@pytest.mark.parametrize("beam,patience,lp", [(2, None, None), (5, 2.0, None), (3, 1.0, 1.0)])
+def test_openai_beam_search_matches_oracle(setup, beam, patience, lp):
+    """fidelity-mode search (openai-whisper BeamSearchDecoder) on the same scorer contract."""
+    d, oracle, xa = setup
+    lay = decoding.TokenLayout.for_vocab(d.n_vocab)
+    toks = pdims.special_tokens(d.n_vocab)
+    prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    fcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=50)
+    opts = search.SearchOptions(beam_size=beam, patience=patience or 1.0, length_penalty=-1 if lp is None else lp,
+                                suppress_tokens=suppress, max_initial_timestamp_index=50, max_new_tokens=12)
+    got = search.beam_search_openai(OracleScorer(oracle, xa, lay, fcfg), [prompt, prompt], opts, eot=lay.eot,
+                                    timestamp_begin=lay.timestamp_begin)
+    for w in range(2):
+        seq, total, avg, nsp = decoding.beam_search_openai(oracle, xa[w:w + 1], prompt, beam, patience, lp, 12, fcfg)
+        assert got[w].sequences[0] == seq, (w, got[w].sequences[0], seq)
+        assert abs(got[w].cum_logprobs[0] - total) < 1e-4
+        assert abs(got[w].avg_logprob(0) - avg) < 1e-4
+        assert abs(got[w].no_speech_prob - nsp) < 1e-6

@@ -293,3 +293,56 @@ class HipFasterWhisperProASR:
         seg = getattr(self, "_external_segmenter", None)
         if seg is not None and hasattr(seg, "cleanup"):
             seg.cleanup()
+
+
+class HipWhisperProASR(HipFasterWhisperProASR):
+    """``WhisperProASR``-shaped module for the fidelity pipeline
+    (/root/reference/whisperjav/modules/whisper_pro_asr.py:31-576): openai-whisper call contract
+    (``model.transcribe(chunk, **params) -> dict``), post-model log-prob gate ON by default (:123-127),
+    ``fp16`` / ``verbose`` accepted."""
+
+    def __init__(self, model_config: Dict, params: Dict, task: str, tracer=None, *, whisper_model=None, segmenter=None):
+        params = dict(params)
+        decoder = dict(params.get("decoder", {}))
+        if decoder.get("post_model_filter_enabled") is None and \
+                (params.get("provider") or {}).get("post_model_filter_enabled") is None:
+            decoder["post_model_filter_enabled"] = True
+        params["decoder"] = decoder
+        if whisper_model is None:
+            from .whisper_model import HipOpenAIWhisperModel
+            whisper_model = HipOpenAIWhisperModel(model_config.get("model_name", "large-v2"), device="cuda",
+                                                  compute_type="bfloat16" if decoder.get("fp16", True) else "float32")
+        super().__init__(model_config, params, task, tracer, whisper_model=whisper_model, segmenter=segmenter)
+
+    def _prepare_whisper_params(self) -> Dict[str, Any]:
+        p = dict(self.whisper_params)
+        if isinstance(p.get("temperature"), list):
+            p["temperature"] = tuple(p["temperature"])
+        p.setdefault("verbose", None)
+        return {k: v for k, v in p.items() if v is not None or k == "verbose"}
+
+    def transcribe(self, audio_path, **kwargs):
+        # the dict-returning model is adapted to the (segments, info) batch interface of the base class
+        model = self.whisper_model
+        if not hasattr(model, "transcribe_many"):
+            class _Adapter:
+                def __init__(self, inner):
+                    self.inner = inner
+
+                def transcribe_many(self, clips, **params):
+                    from .whisper_model import Segment
+                    out = []
+                    for c in clips:
+                        res = self.inner.transcribe(c, **params)
+                        out.append([Segment(id=s.get("id", 0), seek=s.get("seek", 0), start=s["start"], end=s["end"],
+                                            text=s["text"], tokens=s.get("tokens", []),
+                                            avg_logprob=s.get("avg_logprob", 0.0),
+                                            compression_ratio=s.get("compression_ratio", 0.0),
+                                            no_speech_prob=s.get("no_speech_prob", 0.0)) for s in res["segments"]])
+                    return out, [None] * len(clips)
+
+                def close(self):
+                    if hasattr(self.inner, "close"):
+                        self.inner.close()
+            self.whisper_model = _Adapter(model)
+        return super().transcribe(audio_path, **kwargs)

@@ -203,6 +203,99 @@ def beam_search(scorer: StepScorer, prompts: Sequence[Sequence[int]], opts: Sear
     return results
 
 
+def beam_search_openai(scorer: StepScorer, prompts: Sequence[Sequence[int]], opts: SearchOptions, *, eot: int,
+                       timestamp_begin: int, n_text_ctx: int = 448) -> List[WindowResult]:
+    """openai-whisper's ``BeamSearchDecoder`` + ``MaximumLikelihoodRanker`` (fidelity mode,
+    /root/reference/whisperjav/modules/whisper_pro_asr.py:433 -> ``whisper.decoding.DecodingTask``):
+    all beams start as copies (score 0), each step every beam proposes its top ``beam + 1`` tokens, candidates
+    are de-duplicated by token sequence, the best ``beam`` unfinished ones continue, EOT-terminated ones are
+    collected until ``round(beam * patience)`` are finished; ranking by ``sum_logprob / length`` (or the GNMT
+    penalty when ``length_penalty`` is given, pass ``length_penalty=None`` via ``opts.length_penalty = -1``)."""
+    B, K, P = len(prompts), int(opts.beam_size), len(prompts[0])
+    sample_len = min(int(opts.max_new_tokens), n_text_ctx // 2)
+    max_candidates = int(round(K * float(opts.patience)))
+    R = B * K
+    scorer.open(B, K)
+    nsp = np.zeros(B, dtype=np.float32)
+    for p in range(P - 1):
+        col = np.repeat(np.array([pr[p] for pr in prompts], dtype=np.int32), K)
+        scorer.step(col, None, want_logits=(p == 0))
+        if p == 0:
+            nsp = scorer.no_speech()[::K].copy()
+    seqs: List[List[List[int]]] = [[[] for _ in range(K)] for _ in range(B)]
+    sums = np.zeros((B, K), dtype=np.float64)
+    finished: List[dict] = [dict() for _ in range(B)]
+    feed = np.repeat(np.array([pr[-1] for pr in prompts], dtype=np.int32), K)
+    parents: Optional[np.ndarray] = None
+    empty = np.full((R, 1), -1, dtype=np.int32)
+    for step in range(sample_len):
+        scorer.step(feed, parents, want_logits=True)
+        if P == 1 and step == 0:
+            nsp = scorer.no_speech()[::K].copy()
+        rules = np.zeros((R, 4), dtype=np.int32)
+        for w in range(B):
+            for b in range(K):
+                rules[w * K + b] = timestamp_state(seqs[w][b], timestamp_begin)
+        ids, lps = scorer.score(K + 1, rules, empty, empty, 1.0)
+        new_parents = np.arange(R, dtype=np.int32)
+        new_feed = np.full(R, eot, dtype=np.int32)
+        for w in range(B):
+            scores, sources = {}, {}
+            for b in range(K):
+                prefix = seqs[w][b]
+                for j in range(K + 1):
+                    tok = int(ids[w * K + b, j])
+                    if tok < 0:
+                        continue
+                    key = tuple(prefix + [tok])
+                    scores[key] = float(sums[w, b] + float(lps[w * K + b, j]))
+                    sources[key] = b
+            nxt, newly = [], {}
+            for key in sorted(scores, key=scores.get, reverse=True):
+                if key[-1] == eot:
+                    newly[key] = scores[key]
+                else:
+                    nxt.append(key)
+                    if len(nxt) == K:
+                        break
+            while len(nxt) < K:     # degenerate step (everything masked): keep copies alive
+                nxt.append(nxt[-1] if nxt else tuple(seqs[w][0]) + (eot,))
+            for k, key in enumerate(nxt):
+                new_parents[w * K + k] = w * K + sources.get(key, 0)
+                new_feed[w * K + k] = key[-1]
+                sums[w, k] = scores.get(key, float("-inf"))
+            seqs[w] = [list(key) for key in nxt]
+            for key in sorted(newly, key=newly.get, reverse=True):
+                if len(finished[w]) >= max_candidates:
+                    break
+                finished[w][key] = newly[key]
+        feed, parents = new_feed, new_parents
+        if all(len(f) >= max_candidates for f in finished):
+            break
+    results: List[WindowResult] = []
+    lp = opts.length_penalty
+    for w in range(B):
+        cand = dict(finished[w])
+        if len(cand) < K:     # not enough finished sequences: add the best unfinished ones (+EOT)
+            for b in np.argsort(sums[w])[::-1]:
+                cand[tuple(seqs[w][b] + [eot])] = float(sums[w, b])
+                if len(cand) >= K:
+                    break
+        hyps = []
+        for key, total in cand.items():
+            toks = list(key)
+            toks = toks[: toks.index(eot)] if eot in toks else toks
+            length = len(toks)
+            penalty = float(length) if (lp is None or lp < 0) else ((5 + length) / 6) ** float(lp)
+            hyps.append((total / penalty if penalty else float("-inf"), total, toks))
+        best = max(range(len(hyps)), key=lambda i: hyps[i][0])   # first maximum, like np.argmax
+        order = [best] + [i for i in sorted(range(len(hyps)), key=lambda i: -hyps[i][0]) if i != best]
+        order = order[: max(1, int(opts.num_hypotheses))]
+        results.append(WindowResult([hyps[i][2] for i in order], [hyps[i][0] for i in order], [hyps[i][1] for i in order],
+                                    float(nsp[w])))
+    return results
+
+
 class HipStepScorer:
     """``StepScorer`` over a resident ``engine.HipWhisper`` (windows already encoded)."""
 

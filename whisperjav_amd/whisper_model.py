@@ -218,6 +218,9 @@ class _ClipState:
 class HipWhisperModel:
     """Drop-in for ``faster_whisper.WhisperModel`` (constructor + ``transcribe``)."""
 
+    MEL_MODE = "fw"      # faster-whisper feature semantics
+    FLAVOR = "fw"
+
     def __init__(self, model_size_or_path: str = "large-v3", device: str = "cuda", device_index: int = 0,
                  compute_type: str = "bfloat16", cpu_threads: int = 0, num_workers: int = 1,
                  weights: Optional[Dict[str, np.ndarray]] = None, dims: Optional[pdims.WhisperDims] = None,
@@ -238,7 +241,7 @@ class HipWhisperModel:
         self.dims = dims
         self.model = engine.HipWhisper(dims, weights, blob=blob, offsets=offsets, dtype=self.compute_type,
                                        device=device_index, max_batch=max_batch, max_beam=max_beam)
-        self.fe = engine.HipLogMel(dims.n_mels, "fw", device=device_index)
+        self.fe = engine.HipLogMel(dims.n_mels, self.MEL_MODE, device=device_index)
         self.tokens = self.model.tokens
         self.max_batch, self.max_beam = max_batch, max_beam
         self.max_length = dims.n_text_ctx
@@ -277,7 +280,7 @@ class HipWhisperModel:
         if unknown:
             raise TypeError(f"transcribe() got unexpected keyword argument(s): {sorted(unknown)}")
         o = TranscribeOptions(**kw)
-        if o.length_penalty is None:
+        if o.length_penalty is None and self.FLAVOR == "fw":
             o.length_penalty = 1.0
         if o.word_timestamps:
             self._warn_once("words", "word_timestamps=True: word-level alignment is not implemented on the HIP path "
@@ -293,6 +296,8 @@ class HipWhisperModel:
         if -1 in sup:
             sup = [x for x in sup if x >= 0] + list(self.tokenizer.non_speech_tokens())
         sup += [t.transcribe, t.translate, t.sot, t.sot_prev, t.sot_lm]
+        if self.FLAVOR == "ow":
+            sup.append(t.no_speech)      # whisper/decoding.py _get_suppress_tokens adds <|nospeech|> as well
         return tuple(sorted(set(sup)))
 
     def _prompt(self, o: TranscribeOptions, previous: Sequence[int], first_window: bool) -> List[int]:
@@ -327,10 +332,16 @@ class HipWhisperModel:
             self._warn_once("temp", "temperature fallback with sampling (temperature > 0) is not implemented on the HIP "
                                     "path; only the zero-temperature entry is evaluated")
         P = len(prompts[0])
-        max_new = (self.max_length - P) if o.max_new_tokens is None else int(o.max_new_tokens)
+        if self.FLAVOR == "ow":
+            max_new = self.max_length // 2                      # DecodingOptions.sample_len default
+            if o.max_new_tokens is not None:
+                max_new = min(max_new, int(o.max_new_tokens))
+        else:
+            max_new = (self.max_length - P) if o.max_new_tokens is None else int(o.max_new_tokens)
         max_new = max(1, min(max_new, self.max_length - P))
         mit = int(round(float(o.max_initial_timestamp) / TIME_PRECISION))
-        greedy = (o.beam_size == 1 and float(o.repetition_penalty) == 1.0 and int(o.no_repeat_ngram_size) == 0)
+        beam = int(o.beam_size or 1)
+        greedy = (beam == 1 and float(o.repetition_penalty) == 1.0 and int(o.no_repeat_ngram_size) == 0)
         out = []
         if greedy:
             res = self.model.decode_greedy(
@@ -342,14 +353,16 @@ class HipWhisperModel:
                 toks = res.tokens[r, : res.n_tokens[r]].tolist()
                 out.append((toks, float(res.sum_logprob[r]) / (len(toks) + 1), float(res.no_speech_prob[r])))
         else:
-            so = search.SearchOptions(beam_size=int(o.beam_size), patience=float(o.patience),
-                                      length_penalty=float(o.length_penalty),
+            lp = o.length_penalty
+            so = search.SearchOptions(beam_size=beam, patience=float(o.patience or 1.0),
+                                      length_penalty=(-1.0 if lp is None else float(lp)),
                                       repetition_penalty=float(o.repetition_penalty),
                                       no_repeat_ngram_size=int(o.no_repeat_ngram_size), suppress_blank=o.suppress_blank,
                                       suppress_tokens=suppress, without_timestamps=o.without_timestamps,
                                       max_initial_timestamp_index=mit, max_new_tokens=max_new)
-            results = search.beam_search(search.HipStepScorer(self.model, so), prompts, so, eot=self.tokens.eot,
-                                         timestamp_begin=self.tokens.timestamp_begin, n_text_ctx=self.max_length)
+            fn = search.beam_search_openai if self.FLAVOR == "ow" else search.beam_search
+            results = fn(search.HipStepScorer(self.model, so), prompts, so, eot=self.tokens.eot,
+                         timestamp_begin=self.tokens.timestamp_begin, n_text_ctx=self.max_length)
             for wr in results:
                 out.append((wr.sequences[0], wr.avg_logprob(0), wr.no_speech_prob))
         final = []
@@ -376,7 +389,8 @@ class HipWhisperModel:
         frames = [self.fe.frames(len(c)) for c in clips]
         width = max(frames) + N_FRAMES
         feats = self.fe(clips, out_frames=width)                   # [n, n_mels, width], zero padded (pad_or_trim)
-        states = [_ClipState(i, frames[i] - 1, len(clips[i]) / SAMPLE_RATE) for i in range(len(clips))]
+        tail = 1 if self.FLAVOR == "fw" else N_FRAMES    # fw: features[:, :-1]; ow: mel minus the 30 s of padding
+        states = [_ClipState(i, max(1, frames[i] - tail), len(clips[i]) / SAMPLE_RATE) for i in range(len(clips))]
         initial: List[int] = []
         if o.initial_prompt is not None:
             initial = (self.tokenizer.encode(" " + o.initial_prompt.strip()) if isinstance(o.initial_prompt, str)
@@ -432,6 +446,11 @@ class HipWhisperModel:
                     for piece in pieces:
                         text = self.tokenizer.decode([t for t in piece["tokens"] if t < self.tokens.eot])
                         if piece["start"] == piece["end"] or not text.strip():
+                            if self.FLAVOR == "ow":   # whisper.transcribe keeps the slot with cleared text/tokens
+                                st.next_id += 1
+                                st.segments.append(Segment(id=st.next_id, seek=prev_seek, start=piece["start"],
+                                                           end=piece["end"], text="", tokens=[], avg_logprob=avg_lp,
+                                                           compression_ratio=cr, no_speech_prob=nsp, temperature=temp))
                             continue
                         st.all_tokens.extend(piece["tokens"])
                         st.next_id += 1
@@ -445,3 +464,46 @@ class HipWhisperModel:
                                    duration_after_vad=st.duration, transcription_options=dict(kwargs))
                  for st in states]
         return [st.segments for st in states], infos
+
+
+class HipOpenAIWhisperModel(HipWhisperModel):
+    """Drop-in for the object ``whisper.load_model(name, device)`` returns, as used by the fidelity pipeline
+    (/root/reference/whisperjav/modules/whisper_pro_asr.py:182,433): ``transcribe(audio, **kw) -> dict`` with
+    ``{"text", "segments": [{id, seek, start, end, text, tokens, temperature, avg_logprob, compression_ratio,
+    no_speech_prob}], "language"}``.  Restates openai-whisper 20250625 ``whisper/transcribe.py``: log-mel with
+    30 s of zero audio appended, windows zero-padded to 3000 frames, ``DecodingTask`` search (greedy or
+    ``BeamSearchDecoder`` + ``MaximumLikelihoodRanker``), ``sample_len`` 224, the same timestamp slicing."""
+
+    MEL_MODE = "ow"
+    FLAVOR = "ow"
+
+    _RENAMES = {"logprob_threshold": "log_prob_threshold"}
+    _DROPPED = ("verbose", "fp16", "carry_initial_prompt", "sample_len")
+
+    def _options(self, kw: Dict[str, Any]) -> TranscribeOptions:
+        kw = dict(kw)
+        sample_len = kw.get("sample_len")
+        for k in self._DROPPED:
+            kw.pop(k, None)
+        for a, b in self._RENAMES.items():
+            if a in kw:
+                kw[b] = kw.pop(a)
+        if isinstance(kw.get("suppress_tokens"), str):
+            kw["suppress_tokens"] = [int(t) for t in kw["suppress_tokens"].split(",") if t.strip()]
+        if kw.get("beam_size") is None:
+            kw["beam_size"] = 1
+        kw.setdefault("length_penalty", None)
+        kw.setdefault("no_speech_threshold", 0.6)
+        kw.setdefault("condition_on_previous_text", True)
+        if sample_len is not None:
+            kw["max_new_tokens"] = int(sample_len)
+        return super()._options(kw)
+
+    def transcribe(self, audio, **kwargs) -> Dict[str, Any]:      # type: ignore[override]
+        segs, infos = self.transcribe_many([audio], **kwargs)
+        segments = [{"id": i, "seek": s.seek, "start": s.start, "end": s.end, "text": s.text, "tokens": s.tokens,
+                     "temperature": s.temperature, "avg_logprob": s.avg_logprob,
+                     "compression_ratio": s.compression_ratio, "no_speech_prob": s.no_speech_prob}
+                    for i, s in enumerate(segs[0])]
+        tokens = [t for s in segs[0] for t in s.tokens if t < self.tokens.eot]
+        return {"text": self.tokenizer.decode(tokens), "segments": segments, "language": infos[0].language}
