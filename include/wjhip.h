@@ -52,6 +52,10 @@ int wj_sync(wj_ctx* ctx);
 /* device properties for roofline reporting: out[0]=CU count, out[1]=clock kHz, out[2]=HBM bytes (lo32), out[3]=(hi32) */
 int wj_device_info(wj_ctx* ctx, int64_t out[4]);
 
+/* Run-time tunables of the decode step ("dec_ks_attn", "dec_ks_fc2", "dec_tile_min_m", "decode_chains");
+ * defaults come from the sweeps under profiles/. */
+int wj_tune(const char* key, int value);
+
 /* ---- profiler --------------------------------------------------------------------------
  * Kernel time per launch class, measured with hipEvent pairs recorded on the stream the kernels
  * are launched on (used by bench.py for the live roofline figures).  While a profile is open the

@@ -77,6 +77,17 @@ int wj_ctx::ensure_scratch(size_t bytes) {
 // ------------------------------------------------------------------------------------------------
 // model object
 // ------------------------------------------------------------------------------------------------
+static constexpr int kDecKsMax = 16;
+
+// run-time tunables (wj_tune): defaults chosen from the MI355X sweeps recorded in profiles/
+struct Tunables {
+  int dec_ks_attn = 1;      // split-K factor of the attention out-projection GEMMs of the decode step
+  int dec_ks_fc2 = 4;       // split-K factor of the decode fc2 GEMM (K = 4d)
+  int dec_tile_min_m = 0;   // rows from which the split-K decode GEMMs use the 128x128 tile kernel (0 = never)
+  int decode_chains = 1;    // concurrent row chains in the greedy loop
+};
+static Tunables g_tune;
+
 struct wj_whisper {
   wj_ctx* ctx = nullptr;
   wj_whisper_dims d{};
@@ -109,6 +120,7 @@ struct wj_whisper {
   void* dq = nullptr;         // T   [R][d]
   void* dattn = nullptr;      // T   [R][d]
   void* dff = nullptr;        // T   [R][4d]
+  float* partial = nullptr;   // f32 [R][KS_MAX][d] split-K slabs of the decode GEMMs (per row slice)
   float* logits = nullptr;    // f32 [R][ldl]
   int64_t ldl = 0;
   void* self_k = nullptr;     // T   [L][max_rows][H][n_text_ctx][64]
@@ -261,13 +273,44 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   void* dff = m->at(m->dff, (int64_t)row0 * 4 * D);
   const int64_t self_row = (int64_t)H * d.n_text_ctx * 64;      // cache elements per row
   const int64_t cross_win = (int64_t)H * d.n_audio_ctx * 64;    // cross K (or V) elements per window
+  // Residual-writing GEMMs (attention out-projections, fc2) can run split-K: each K slice writes a raw fp32
+  // slab and the LayerNorm that always follows folds  x += bias + sum(slabs)  in a fixed order (deterministic).
+  // This keeps the per-workgroup A traffic at M*K/ksplit and multiplies the number of workgroups streaming W.
+  const int ks_attn = g_tune.dec_ks_attn, ks_fc2 = g_tune.dec_ks_fc2, tile_min_m = g_tune.dec_tile_min_m;
+  float* slab = m->partial + (int64_t)row0 * kDecKsMax * D;
+  int pend_ks = 0;
+  const float* pend_bias = nullptr;
+  auto resid_gemm = [&](int tag, const void* A, int K, const void* W, const float* bias, int ks) -> int {
+    GemmArgs g;
+    g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = R; g.N = D; g.K = K; g.ldc = D;
+    if (dt == WJ_BF16 && ks > 1 && ks <= kDecKsMax && K % (64 * ks) == 0) {
+      g.out = slab; g.ksplit = ks;
+      pend_ks = ks; pend_bias = bias;
+      const int variant = (tile_min_m > 0 && R >= tile_min_m) ? 3 : 2;
+      PROF(tag, launch_gemm(dt, EPI_PARTIAL_F32, g, s, variant));
+    } else {
+      g.bias = bias; g.out = dx;
+      PROF(tag, launch_gemm(dt, EPI_RESID_F32, g, s));
+    }
+    return WJ_OK;
+  };
+  auto norm = [&](const float* w, const float* b) -> int {
+    if (pend_ks) {
+      const int ks = pend_ks;
+      pend_ks = 0;
+      PROF(PT_D_LN, launch_layernorm_resid(dt, dx, slab, ks, pend_bias, w, b, dh, R, D, s));
+    } else {
+      PROF(PT_D_LN, launch_layernorm(dt, dx, w, b, dh, R, D, s));
+    }
+    return WJ_OK;
+  };
   PROF(PT_D_EMBED, launch_embed(dt, m->W(WJ_T_DEC_TOK_EMB), m->F(WJ_T_DEC_POS), m->tokens + (int64_t)row0 * m->tok_stride,
                                 m->tok_stride, pos, dx, R, D, s));
   for (int l = 0; l < d.n_text_layer; ++l) {
     const int b0 = m->dec_base(l);
     void* sk = m->at(m->self_k, l * m->self_layer_elems());
     void* sv = m->at(m->self_v, l * m->self_layer_elems());
-    PROF(PT_D_LN, launch_layernorm(dt, dx, m->F(b0 + WJ_TD_LN1_W), m->F(b0 + WJ_TD_LN1_B), dh, R, D, s));
+    WJ_TRY(norm(m->F(b0 + WJ_TD_LN1_W), m->F(b0 + WJ_TD_LN1_B)));
     {
       GemmArgs g;
       g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
@@ -283,13 +326,8 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       a.row_map = m->row_map[m->cur_map] + (int64_t)row0 * d.n_text_ctx;
       PROF(PT_D_SELF, launch_attention_dec(dt, a, s));
     }
-    {
-      GemmArgs g;
-      g.A = dattn; g.lda = D; g.W = m->W(b0 + WJ_TD_OUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_OUT_B);
-      g.M = R; g.N = D; g.K = D; g.out = dx; g.ldc = D;
-      PROF(PT_D_OUT, launch_gemm(dt, EPI_RESID_F32, g, s));
-    }
-    PROF(PT_D_LN, launch_layernorm(dt, dx, m->F(b0 + WJ_TD_LNX_W), m->F(b0 + WJ_TD_LNX_B), dh, R, D, s));
+    WJ_TRY(resid_gemm(PT_D_OUT, dattn, D, m->W(b0 + WJ_TD_OUT_W), m->F(b0 + WJ_TD_OUT_B), ks_attn));
+    WJ_TRY(norm(m->F(b0 + WJ_TD_LNX_W), m->F(b0 + WJ_TD_LNX_B)));
     {
       GemmArgs g;
       g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
@@ -304,26 +342,18 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       a.out = dattn; a.G = n_windows; a.nb = beam; a.H = H; a.n_keys = d.n_audio_ctx; a.kv_stride = d.n_audio_ctx;
       PROF(PT_D_CROSS, launch_attention_dec(dt, a, s));
     }
-    {
-      GemmArgs g;
-      g.A = dattn; g.lda = D; g.W = m->W(b0 + WJ_TD_COUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_COUT_B);
-      g.M = R; g.N = D; g.K = D; g.out = dx; g.ldc = D;
-      PROF(PT_D_COUT, launch_gemm(dt, EPI_RESID_F32, g, s));
-    }
-    PROF(PT_D_LN, launch_layernorm(dt, dx, m->F(b0 + WJ_TD_LN2_W), m->F(b0 + WJ_TD_LN2_B), dh, R, D, s));
+    WJ_TRY(resid_gemm(PT_D_COUT, dattn, D, m->W(b0 + WJ_TD_COUT_W), m->F(b0 + WJ_TD_COUT_B), ks_attn));
+    WJ_TRY(norm(m->F(b0 + WJ_TD_LN2_W), m->F(b0 + WJ_TD_LN2_B)));
     {
       GemmArgs g;
       g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_FC1_B);
       g.M = R; g.N = 4 * D; g.K = D; g.out = dff; g.ldc = 4 * D;
       PROF(PT_D_FC1, launch_gemm(dt, EPI_GELU_T, g, s));
-      GemmArgs g2;
-      g2.A = dff; g2.lda = 4 * D; g2.W = m->W(b0 + WJ_TD_FC2_W); g2.ldw = 4 * D; g2.bias = m->F(b0 + WJ_TD_FC2_B);
-      g2.M = R; g2.N = D; g2.K = 4 * D; g2.out = dx; g2.ldc = D;
-      PROF(PT_D_FC2, launch_gemm(dt, EPI_RESID_F32, g2, s));
     }
+    WJ_TRY(resid_gemm(PT_D_FC2, dff, 4 * D, m->W(b0 + WJ_TD_FC2_W), m->F(b0 + WJ_TD_FC2_B), ks_fc2));
   }
   if (want_logits) {
-    PROF(PT_D_LN, launch_layernorm(dt, dx, m->F(WJ_T_DEC_LN_W), m->F(WJ_T_DEC_LN_B), dh, R, D, s));
+    WJ_TRY(norm(m->F(WJ_T_DEC_LN_W), m->F(WJ_T_DEC_LN_B)));
     GemmArgs g;
     g.A = dh; g.lda = D; g.W = m->W(WJ_T_DEC_TOK_EMB); g.ldw = D;
     g.M = R; g.N = d.n_vocab; g.K = D; g.out = m->logits + (int64_t)row0 * m->ldl; g.ldc = m->ldl;
@@ -443,6 +473,16 @@ int wj_profile_stop(wj_ctx* ctx, double* total_ms, int64_t* counts, int n_tags) 
   return WJ_OK;
 }
 
+int wj_tune(const char* key, int value) {
+  WJ_REQUIRE(key != nullptr, "wj_tune: NULL key");
+  if (!strcmp(key, "dec_ks_attn")) g_tune.dec_ks_attn = value;
+  else if (!strcmp(key, "dec_ks_fc2")) g_tune.dec_ks_fc2 = value;
+  else if (!strcmp(key, "dec_tile_min_m")) g_tune.dec_tile_min_m = value;
+  else if (!strcmp(key, "decode_chains")) g_tune.decode_chains = value;
+  else { set_error("wj_tune: unknown key %s", key); return WJ_E_INVALID; }
+  return WJ_OK;
+}
+
 int64_t wj_logmel_frames(int64_t n_samples, int mode) {
   if (n_samples <= 0) return 0;
   return (n_samples + (mode == WJ_MEL_FW ? 160 : 480000)) / 160;
@@ -514,6 +554,7 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   WJ_ALLOC(dq, R * D * e, false);
   WJ_ALLOC(dattn, R * D * e, false);
   WJ_ALLOC(dff, R * 4 * D * e, false);
+  WJ_ALLOC(partial, R * (size_t)kDecKsMax * D * sizeof(float), false);
   m->ldl = (d.n_vocab + 63) / 64 * 64;
   WJ_ALLOC(logits, R * m->ldl * sizeof(float), false);
   WJ_ALLOC(self_k, (size_t)d.n_text_layer * m->self_layer_elems() * e, true);
@@ -586,7 +627,7 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
   // ~355 short kernels of a step do NOT overlap across streams (2 chains +2 %, 4 chains -26 %; forked
   // branches inside one graph +3 %), i.e. the per-kernel cost is dispatch latency, so the default is one
   // chain and WJ_DECODE_CHAINS keeps the experiment reproducible.
-  int chains = 1;
+  int chains = g_tune.decode_chains;
   if (const char* ce = getenv("WJ_DECODE_CHAINS")) chains = atoi(ce);
   if (chains < 1) chains = 1;
   if (chains > 4) chains = 4;

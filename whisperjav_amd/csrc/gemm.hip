@@ -31,7 +31,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 template <int EPI, typename T>
 __device__ __forceinline__ void epi_nm(const GemmArgs& g, int z, int m, int n, float v[4]) {
   // v[j] belongs to (row m, column n + j); n % 4 == 0; caller guarantees m < M and n < N.
-  if constexpr (EPI == EPI_F32) {
+  if constexpr (EPI == EPI_PARTIAL_F32) {   // z = K-slice index
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + ((int64_t)z * g.M + m) * g.ldc + n) =
+        make_float4(v[0], v[1], v[2], v[3]);
+    return;
+  } else if constexpr (EPI == EPI_F32) {
     float* o = reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -128,8 +132,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
   const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
   const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
   const int m0 = (first_m + in_group % gsz) * TBM, n0 = (in_group / gsz) * TBN;
-  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)z * g.a_batch;
-  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+  // split-K (EPI_PARTIAL_F32): blockIdx.z selects a K slice instead of a batch entry
+  const int kslice = (EPI == EPI_PARTIAL_F32) ? g.K / g.ksplit : g.K;
+  const int64_t koff = (EPI == EPI_PARTIAL_F32) ? (int64_t)z * kslice : 0;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + ((EPI == EPI_PARTIAL_F32) ? koff : (int64_t)z * g.a_batch);
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W) + koff;
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -138,14 +145,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-  const int nk = (g.K + TBK - 1) / TBK;
+  const int nk = (kslice + TBK - 1) / TBK;
   // staging registers are individually named (an indexed array ends up in scratch memory)
 #define WJ_GLOAD1(i, k0)                                                                      \
   {                                                                                           \
     const int idx = tid + (i) * 256;                                                          \
     const int row = idx >> 3, ch = idx & 7;                                                   \
     const int k = (k0) + ch * 8;                                                              \
-    const bool kin = k < g.K;                                                                 \
+    const bool kin = k < kslice;                                                              \
     const int kc = kin ? k : 0;                                                               \
     ra##i = ldg16_pred(A + (int64_t)min(m0 + row, g.M - 1) * g.lda + kc, kin && m0 + row < g.M); \
     rb##i = ldg16_pred(W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + kc, kin && n0 + row < g.N); \
@@ -259,10 +266,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(const GemmArgs g)
   const int nt0 = blockIdx.x * 16;
   const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A);
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
-  const int ksteps = (g.K + 31) / 32;
+  // split-K (EPI_PARTIAL_F32): blockIdx.y selects one of g.ksplit K slices; the 8 waves split that slice
+  const int kz = (EPI == EPI_PARTIAL_F32) ? blockIdx.y : 0;
+  const int ksteps_all = (g.K + 31) / 32;
+  const int ksteps = (EPI == EPI_PARTIAL_F32) ? ksteps_all / g.ksplit : ksteps_all;
   const int per = (ksteps + 7) / 8;
-  const int ks_begin = wave * per;
-  const int ks_end = min(ksteps, ks_begin + per);
+  const int ks_begin = kz * ksteps + wave * per;
+  const int ks_end = min(kz * ksteps + ksteps, ks_begin + per);
   const int wrow = nt0 + (lane & 15);
   const int kq = (lane >> 4) * 8;
 
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(const GemmArgs g)
         v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
       }
       const int m = mc + mm, n = nt0 + q * 4;
-      if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, 0, m, n, v);
+      if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, kz, m, n, v);
     }
     __syncthreads();
   }
@@ -384,6 +394,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 // --------------------------------------------------------------------------------------------
 template <int EPI>
 static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) {
+  if (EPI == EPI_PARTIAL_F32) {
+    if (dtype != WJ_BF16) { set_error("gemm: split-K partial output is a bf16-path feature"); return WJ_E_INVALID; }
+    if (a.ksplit < 1 || a.nbatch != 1 || (a.K % (32 * a.ksplit))) {
+      set_error("gemm: split-K needs nbatch == 1 and K %% (32 * ksplit) == 0 (K=%d ksplit=%d)", a.K, a.ksplit);
+      return WJ_E_INVALID;
+    }
+  }
   if (dtype == WJ_F32) {
     dim3 grid(ceil_div(a.N, 64), ceil_div(a.M, 64), a.nbatch);
     hipLaunchKernelGGL(gemm_f32_kernel<EPI>, grid, dim3(256), 0, s, a);
@@ -399,7 +416,7 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
   }
   if (skinny) {
     if constexpr (EPI != EPI_VT) {
-      dim3 grid(ceil_div(a.N, 16));
+      dim3 grid(ceil_div(a.N, 16), EPI == EPI_PARTIAL_F32 ? a.ksplit : 1);
       if (a.M <= 16) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, 1>), grid, dim3(512), 0, s, a);
       else if (a.M <= 32) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, 2>), grid, dim3(512), 0, s, a);
       else if (a.M <= 64) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, 4>), grid, dim3(512), 0, s, a);
@@ -408,14 +425,15 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
     }
     return WJ_OK;
   }
-  dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), a.nbatch);
+  dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), EPI == EPI_PARTIAL_F32 ? a.ksplit : a.nbatch);
   static const int tile_mode = [] {   // WJ_GEMM_TILE=reg|glds overrides the default staging path
     const char* e = getenv("WJ_GEMM_TILE");
     if (e && !strcmp(e, "reg")) return 1;
     if (e && !strcmp(e, "glds")) return 2;
     return 0;
   }();
-  bool glds = (a.K % TBK) == 0 && (variant == 3 || (variant != 4 && tile_mode != 1));
+  const int kchunk = EPI == EPI_PARTIAL_F32 ? a.K / a.ksplit : a.K;
+  bool glds = (kchunk % TBK) == 0 && (variant == 3 || (variant != 4 && tile_mode != 1));
   if (variant == 3 && (a.K % TBK)) { set_error("gemm: the LDS-DMA tile kernel needs K %% 64 == 0"); return WJ_E_INVALID; }
   if (glds) hipLaunchKernelGGL((gemm_bf16_tile_kernel<EPI, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((gemm_bf16_tile_kernel<EPI, false>), grid, dim3(256), 0, s, a);
@@ -443,6 +461,7 @@ int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int varian
     case EPI_VT: return launch_epi<EPI_VT>(dtype, a, s, variant);
     case EPI_QKV_DEC: return launch_epi<EPI_QKV_DEC>(dtype, a, s, variant);
     case EPI_CKV: return launch_epi<EPI_CKV>(dtype, a, s, variant);
+    case EPI_PARTIAL_F32: return launch_epi<EPI_PARTIAL_F32>(dtype, a, s, variant);
     default: set_error("gemm: unknown epilogue %d", (int)epi); return WJ_E_INVALID;
   }
 }

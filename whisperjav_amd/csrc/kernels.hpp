@@ -16,6 +16,7 @@ enum Epi : int {
   EPI_VT,            // out [z][h][dd][Tpad]  (V transposed per head; "MN" accumulator orientation)
   EPI_QKV_DEC,       // decode step: n<D: out T [M][D]; then K,V -> caches out2/out3 [m][h][cache_len][64] at *pos_ptr
   EPI_CKV,           // cross K/V: n<D: out [z][h][m][64] ; n>=D: out2 [z][h][m][64]; rows/head = Tpad
+  EPI_PARTIAL_F32,   // split-K slab: out f32 [ksplit][M][ldc] = raw partial sums (no bias); reduced by the consumer
   EPI_COUNT
 };
 
@@ -34,6 +35,7 @@ struct GemmArgs {
   int D = 0, H = 0, Tpad = 0;
   const int* pos_ptr = nullptr;
   int cache_len = 0;
+  int ksplit = 1;               // EPI_PARTIAL_F32: K is cut into ksplit slices (grid.z resp. grid.y)
 };
 
 // variant: 0 = auto; 1 = tiled MFMA kernel (default staging); 2 = skinny (decode) kernel;
@@ -43,6 +45,10 @@ int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int varian
 // ---------------- normalisation / elementwise ------------------------------------------------
 int launch_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, int M, int D,
                      hipStream_t s);
+// residual update fused with LayerNorm: x[m][:] += bias + sum_s partial[s][m][:]  (fixed order -> deterministic),
+// then out = LayerNorm(x).  Consumer side of the split-K decode GEMMs.
+int launch_layernorm_resid(int dtype, float* x, const float* partial, int ksplit, const float* bias, const float* w,
+                           const float* b, void* out, int M, int D, hipStream_t s);
 // mel f32 [B][n_mels][frames] -> engine layout T [B][frames+2][n_mels] (row 0 and frames+1 stay zero)
 int launch_mel_to_rows(int dtype, const float* mel, void* out, int B, int n_mels, int frames, hipStream_t s);
 // decoder embedding: x[r][:] = tok_emb[token[r]][:] + pos_emb[*pos][:]

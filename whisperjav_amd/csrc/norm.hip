@@ -63,6 +63,73 @@ int launch_layernorm(int dtype, const float* x, const float* w, const float* b, 
   return WJ_OK;
 }
 
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_resid_kernel(float* __restrict__ x, const float* __restrict__ partial,
+                                                              int ksplit, const float* __restrict__ bias,
+                                                              const float* __restrict__ w, const float* __restrict__ b,
+                                                              T* __restrict__ out, int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float* xr = x + (int64_t)row * D;
+  float v[MAXV], g[MAXV], be[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = min(lane + i * 64, D - 1);
+    v[i] = xr[c] + bias[c];
+    g[i] = w[c];
+    be[i] = b[c];
+  }
+  for (int s = 0; s < ksplit; ++s) {
+    const float* pr = partial + ((int64_t)s * M + row) * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) v[i] += pr[min(lane + i * 64, D - 1)];
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < D) xr[c] = v[i];
+    sum += c < D ? v[i] : 0.f;
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const float d = (lane + i * 64 < D) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+  T* o = out + (int64_t)row * D;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < D) Elem<T>::st(o + c, (v[i] - mean) * rstd * g[i] + be[i]);
+  }
+}
+
+int launch_layernorm_resid(int dtype, float* x, const float* partial, int ksplit, const float* bias, const float* w,
+                           const float* b, void* out, int M, int D, hipStream_t s) {
+  if (D > 64 * 20 || D <= 0) { set_error("layernorm: D=%d unsupported (max 1280)", D); return WJ_E_INVALID; }
+  if (M <= 0) return WJ_OK;
+  dim3 grid(ceil_div(M, 4));
+#define WJ_LNR(NV)                                                                                              \
+  do {                                                                                                          \
+    if (dtype == WJ_F32)                                                                                        \
+      hipLaunchKernelGGL((layernorm_resid_kernel<float, NV>), grid, dim3(256), 0, s, x, partial, ksplit, bias, w, b, \
+                         (float*)out, M, D);                                                                    \
+    else                                                                                                        \
+      hipLaunchKernelGGL((layernorm_resid_kernel<bf16_t, NV>), grid, dim3(256), 0, s, x, partial, ksplit, bias, w, b, \
+                         (bf16_t*)out, M, D);                                                                   \
+  } while (0)
+  if (D <= 64 * 6) WJ_LNR(6);
+  else if (D <= 64 * 12) WJ_LNR(12);
+  else WJ_LNR(20);
+#undef WJ_LNR
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
 // mel f32 [B][C][F] -> rows T [B][F+2][C] (pad rows untouched = zero); 32x32 LDS transpose tiles
 template <typename T>
 __global__ __launch_bounds__(256) void mel_to_rows_kernel(const float* __restrict__ mel, T* __restrict__ out, int C,

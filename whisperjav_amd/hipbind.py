@@ -49,6 +49,7 @@ _SIGNATURES = {
     "wj_shutdown": (_I, [_P]),
     "wj_sync": (_I, [_P]),
     "wj_device_info": (_I, [_P, C.POINTER(_I64)]),
+    "wj_tune": (_I, [C.c_char_p, _I]),
     "wj_profile_start": (_I, [_P]),
     "wj_profile_tags": (_I, []),
     "wj_profile_tag_name": (C.c_char_p, [_I]),
@@ -105,6 +106,10 @@ def lib() -> C.CDLL:
         raise WjError(f"libwjhip ABI version {got}, binding expects {ABI_VERSION}: rebuild the library")
     _lib = handle
     return handle
+
+
+def tune(key: str, value: int) -> None:
+    check(lib().wj_tune(key.encode(), int(value)), "wj_tune")
 
 
 def check(rc: int, what: str = "") -> None:
