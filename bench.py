@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32, help="30 s windows per GPU per step")
+    ap.add_argument("--batch", type=int, default=128, help="30 s windows per GPU per step")
     ap.add_argument("--decode-tokens", type=int, default=224, help="new tokens per window (n_text_ctx // 2)")
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
@@ -289,11 +289,16 @@ def main():
                               "frac": round(sm["achieved"] / sm["peak"], 4)})
             stages[tag] = entry
         dom = next(iter(stages))
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", f"r01_pmc_cross_attn_b{B}.json")
+        if dom == "dec_cross_attn" and os.path.exists(pmc_file) and args.dtype == "bfloat16":
+            traffic = json.load(open(pmc_file))["hbm_read_bytes_per_launch"]   # rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction
         if "bound" in stages[dom]:
             e = stages[dom]
             roofline = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"],
                         "peak": HBM_PEAK_GBS if e["bound"] == "hbm" else MFMA_PEAK_TFLOPS[args.dtype],
-                        "unit": e["unit"], "frac": e["frac"], "traffic": None,
+                        "unit": e["unit"], "frac": e["frac"], "traffic": traffic,
+                        "algorithmic_bytes_per_launch": B * dims.n_text_head * dims.n_audio_ctx * 64 * 2 * (2 if args.dtype == "bfloat16" else 4) if dom == "dec_cross_attn" else None,
                         "share_of_step": e["share"], "us_per_launch": e["us_per_launch"]}
         enc = [k for k in stages if k.startswith("enc_") and stages[k].get("bound") == "mfma"]
         if enc:

@@ -23,8 +23,15 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * 64 * 64];  // [buf][K|Vt][64][64] = 32 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // XCD-aware order: workgroup i runs on XCD i % 8 with a private L2.  Without the remap the ~12 query
+  // blocks of one (window, head) are spread over all XCDs and each L2 fetches that head's K/V separately
+  // (PMC: 4x the algorithmic bytes); with it each XCD walks whole heads and K/V is fetched once.
+  const int nqb = gridDim.x, total = gridDim.x * gridDim.y * gridDim.z;
+  const int lin = blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7;
+  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  const int qb = id % nqb, h = (id / nqb) % H, b = id / (nqb * H);
+  const int q0 = qb * 128 + wave * 32;
   const int64_t bh = (int64_t)b * H + h;
   const bf16_t* Qp = Q + bh * Tpad * 64;
   const bf16_t* Kp = K + bh * Tpad * 64;
@@ -93,6 +100,8 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
     }
     // lane (q = li, lg) now holds, for block kb, keys  kt*64 + 32*(kb>>1) + 8*lg + 4*(kb&1) + r
     bf16x8_t pf[2][2];
+    const bool tail = (kt + 1) * 64 > T;     // only the last key tile contains padding keys
+    constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e): softmax in base 2
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       float mx = -INFINITY;
@@ -100,15 +109,18 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kt * 64 + 32 * (kb >> 1) + 8 * lg + 4 * (kb & 1) + r;
-          const float s = key < T ? st[f][kb][r] * 0.125f : -INFINITY;
+          float s = st[f][kb][r] * kScaleLog2;
+          if (tail) {
+            const int key = kt * 64 + 32 * (kb >> 1) + 8 * lg + 4 * (kb & 1) + r;
+            s = key < T ? s : -INFINITY;
+          }
           st[f][kb][r] = s;
           mx = fmaxf(mx, s);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[f], mx);
-      const float alpha = __expf(m_run[f] - m_new);
+      const float alpha = exp2f(m_run[f] - m_new);
       m_run[f] = m_new;
       float psum = 0.f;
       float p[4][4];
@@ -116,14 +128,16 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p[kb][r] = __expf(st[f][kb][r] - m_new);
+          p[kb][r] = exp2f(st[f][kb][r] - m_new);
           psum += p[kb][r];
         }
       l_run[f] = l_run[f] * alpha + psum;
+      if (alpha != 1.0f) {     // wave-divergent at worst; the running max rarely moves after the first tiles
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+        for (int d = 0; d < 4; ++d)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[f][d][r] *= alpha;
+          for (int r = 0; r < 4; ++r) o[f][d][r] *= alpha;
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8_t v;

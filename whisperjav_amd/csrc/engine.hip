@@ -81,9 +81,9 @@ static constexpr int kDecKsMax = 16;
 
 // run-time tunables (wj_tune): defaults chosen from the MI355X sweeps recorded in profiles/
 struct Tunables {
-  int dec_ks_attn = 1;      // split-K factor of the attention out-projection GEMMs of the decode step
-  int dec_ks_fc2 = 4;       // split-K factor of the decode fc2 GEMM (K = 4d)
-  int dec_tile_min_m = 0;   // rows from which the split-K decode GEMMs use the 128x128 tile kernel (0 = never)
+  int dec_ks_attn = 4;      // split-K factor of the attention out-projection GEMMs of the decode step
+  int dec_ks_fc2 = 8;       // split-K factor of the decode fc2 GEMM (K = 4d)
+  int dec_tile_min_m = 128; // rows from which the split-K decode GEMMs use the 128x128 tile kernel (0 = never)
   int decode_chains = 1;    // concurrent row chains in the greedy loop
 };
 static Tunables g_tune;
