@@ -53,7 +53,7 @@ int wj_sync(wj_ctx* ctx);
 int wj_device_info(wj_ctx* ctx, int64_t out[4]);
 
 /* Run-time tunables of the decode step ("dec_ks_attn", "dec_ks_fc2", "dec_tile_min_m", "decode_chains");
- * defaults come from the sweeps under profiles/. */
+ * "attn_enc_variant"); defaults come from the sweeps under profiles/. */
 int wj_tune(const char* key, int value);
 
 /* ---- profiler --------------------------------------------------------------------------
@@ -216,6 +216,8 @@ int wj_k_layernorm(wj_ctx* ctx, int dtype, const float* x_dev, const float* w_de
  * row-major float32 [B][T][3*D] tensor by the call itself. out: dtype [B][T][D]. */
 int wj_k_attention_enc(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, void* out_dev, int B, int T,
                        int H, void* stream);
+int wj_k_attention_enc_timed(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, void* out_dev, int B, int T,
+                             int H, int reps, float* ms_per_launch);
 /* decode attention over a K/V set shared by `nb` query rows: q float32 [G][nb][H*64],
  * k,v float32 [G][H][n_keys][64]; out float32 [G][nb][H*64]. */
 int wj_k_attention_dec(wj_ctx* ctx, int dtype, const float* q_dev, const float* k_dev, const float* v_dev,

@@ -18,12 +18,13 @@ toks = model.tokens
 suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
 opts = engine.DecodeOptions(max_new_tokens=TOK, suppress_tokens=suppress, max_initial_timestamp=1.0)
 rows = []
-configs = [(64, 1, 1, 0), (64, 1, 4, 0), (64, 1, 8, 0), (64, 2, 4, 0), (64, 4, 8, 0), (64, 5, 10, 0),
-           (128, 1, 1, 0), (128, 1, 4, 0), (128, 2, 8, 0), (128, 4, 8, 0), (128, 5, 10, 0), (128, 4, 8, 128), (128, 10, 16, 128),
-           (128, 5, 8, 128)]
+# (batch, ks_attn, ks_fc2, tile_min_m, ks_proj, proj_min_m)
+configs = [(64, 4, 8, 128, 0, 96), (64, 4, 8, 128, 4, 64), (64, 4, 8, 64, 4, 64), (64, 4, 8, 64, 0, 96),
+           (128, 4, 8, 128, 0, 96), (128, 4, 8, 128, 2, 96), (128, 4, 8, 128, 4, 96), (128, 4, 8, 128, 5, 96)]
 ref_tokens = {}
-for B, ka, kf, tm in configs:
+for B, ka, kf, tm, kp, pm in configs:
     hipbind.tune("dec_ks_attn", ka); hipbind.tune("dec_ks_fc2", kf); hipbind.tune("dec_tile_min_m", tm)
+    hipbind.tune("dec_ks_proj", kp); hipbind.tune("dec_proj_min_m", pm)
     prompt = np.tile(np.array(model.sot_prompt("ja"), dtype=np.int32), (B, 1))
     model.decode_greedy(prompt, engine.DecodeOptions(max_new_tokens=4, suppress_tokens=suppress))   # warm
     best = 1e9
@@ -35,7 +36,7 @@ for B, ka, kf, tm in configs:
         same = float((res.tokens == ref_tokens[key]).mean())
     else:
         ref_tokens[key] = res.tokens.copy()
-    rows.append({"B": B, "ks_attn": ka, "ks_fc2": kf, "tile_min_m": tm, "ms_per_step": round(1e3 * best / (TOK + 2), 3),
+    rows.append({"B": B, "ks_attn": ka, "ks_fc2": kf, "tile_min_m": tm, "ks_proj": kp, "proj_min_m": pm, "ms_per_step": round(1e3 * best / (TOK + 2), 3),
                  "token_agreement_vs_first_config": same})
     print(rows[-1], flush=True)
 json.dump(rows, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "decode_sweep.json"), "w"), indent=1)

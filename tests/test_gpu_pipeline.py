@@ -472,3 +472,71 @@ def test_fidelity_flavour_end_to_end(hip):
     assert abs(res["segments"][0]["avg_logprob"] - avg) < 1e-3
     _diag("fidelity", {"tokens": len(got), "avg_logprob_diff": abs(res["segments"][0]["avg_logprob"] - avg)})
     model.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases, full-size properties, determinism
+# ---------------------------------------------------------------------------------------------
+def test_logmel_full_size_properties(hip):
+    """BASELINE-scale input: 10 min of noisy audio in one launch -- frame count, agreement with the oracle on a
+    sampled set of frames, global-max clamp floor, and bit-identical repeat."""
+    from whisperjav_amd import engine, synth
+    audio = synth.speech_like(600.0, seed=1234, noisy=True)
+    fe = engine.HipLogMel(128, "fw")
+    n_frames = fe.frames(len(audio))
+    assert n_frames == (len(audio) + 160) // 160 == 60001
+    got = fe([audio], out_frames=n_frames).cpu().numpy()[0]
+    again = fe([audio], out_frames=n_frames).cpu().numpy()[0]
+    assert np.array_equal(got, again)
+    ref = olm.logmel_fw(audio, 128)
+    assert got.shape == ref.shape
+    cols = np.r_[0:50, 29990:30010, 59950:60001, np.arange(100, 60000, 997)]
+    assert np.abs(got[:, cols] - ref[:, cols]).max() < 2e-4
+    assert abs(float(got.min()) - float(ref.min())) < 1e-6            # clamp floor = (global max - 8 + 4) / 4
+    assert abs(float(got.astype(np.float64).sum()) - float(ref.astype(np.float64).sum())) < 1e-4 * abs(float(ref.sum()))
+
+
+def test_logmel_minimum_clip_and_rejects_too_short(hip):
+    from whisperjav_amd import engine, hipbind
+    fe = engine.HipLogMel(80, "fw")
+    rng = np.random.default_rng(0)
+    clip = (rng.standard_normal(201) * 0.1).astype(np.float32)
+    got = fe([clip]).cpu().numpy()[0]
+    ref = olm.window_features(clip, 80, "fw")
+    assert np.abs(got - ref).max() < 2e-4
+    with pytest.raises(hipbind.WjError):
+        fe([clip[:200]])
+
+
+def test_vad_degenerate_streams(hip):
+    from oracle import silero_ref
+    from whisperjav_amd import vad, vad_weights
+    w = vad_weights.synth_weights()
+    scorer = vad.HipSileroScorer(w)
+    rng = np.random.default_rng(1)
+    clips = [np.zeros(0, np.float32), (rng.standard_normal(1) * 0.1).astype(np.float32),
+             (rng.standard_normal(512) * 0.1).astype(np.float32), (rng.standard_normal(513) * 0.1).astype(np.float32)]
+    got = scorer.scores(clips)
+    assert [len(g) for g in got] == [0, 1, 1, 2]
+    oracle = silero_ref.SileroOracle(w)
+    for c, g in zip(clips[1:], got[1:]):
+        assert np.abs(g - oracle.probs(c)).max() < 1e-5
+    assert vad.get_speech_timestamps(np.zeros(0, np.float32), scorer) == []
+    scorer.close()
+
+
+def test_decode_is_deterministic_and_respects_context_limit(hip):
+    from whisperjav_amd import engine, hipbind
+    d, oracle, model = _engine_and_oracle("bfloat16", max_batch=2)
+    mel = torch.from_numpy(helpers.synth_mel(2, d.n_mels, seed=41))
+    model.encode(mel.cuda())
+    prompt = np.tile(np.array(model.sot_prompt("ja"), dtype=np.int32), (2, 1))
+    a = model.decode_greedy(prompt, engine.DecodeOptions(max_new_tokens=445))     # 3 + 445 = n_text_ctx
+    b = model.decode_greedy(prompt, engine.DecodeOptions(max_new_tokens=445))
+    assert np.array_equal(a.tokens, b.tokens) and np.array_equal(a.token_logprob, b.token_logprob)
+    assert a.tokens.shape == (2, 445)
+    with pytest.raises(hipbind.WjError):
+        model.decode_greedy(prompt, engine.DecodeOptions(max_new_tokens=446))
+    with pytest.raises(hipbind.WjError):
+        model.encode(torch.zeros((3, d.n_mels, 3000), device="cuda"))               # more windows than max_batch
+    model.close()

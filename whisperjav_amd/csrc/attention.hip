@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ int aswz(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) << 3); }
 
+template <int VAR>
 __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                             const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
                                                             int T, int Tpad, int H) {
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
   const int nqb = gridDim.x, total = gridDim.x * gridDim.y * gridDim.z;
   const int lin = blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
   const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7;
-  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  const int id = (VAR & 1) ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3) : lin;
   const int qb = id % nqb, h = (id / nqb) % H, b = id / (nqb * H);
   const int q0 = qb * 128 + wave * 32;
   const int64_t bh = (int64_t)b * H + h;
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
     // lane (q = li, lg) now holds, for block kb, keys  kt*64 + 32*(kb>>1) + 8*lg + 4*(kb&1) + r
     bf16x8_t pf[2][2];
     const bool tail = (kt + 1) * 64 > T;     // only the last key tile contains padding keys
-    constexpr float kScaleLog2 = 0.125f * 1.44269504088896340736f;   // 1/sqrt(64) * log2(e): softmax in base 2
+    // VAR & 2: softmax in base 2 on the raw v_exp_f32 (scale folds 1/sqrt(64) * log2 e); else natural exp
+    constexpr float kScaleLog2 = (VAR & 2) ? 0.125f * 1.44269504088896340736f : 0.125f;
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
       float mx = -INFINITY;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[f], mx);
-      const float alpha = exp2f(m_run[f] - m_new);
+      const float alpha = (VAR & 2) ? __builtin_amdgcn_exp2f(m_run[f] - m_new) : __expf(m_run[f] - m_new);
       m_run[f] = m_new;
       float psum = 0.f;
       float p[4][4];
@@ -128,11 +130,11 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p[kb][r] = exp2f(st[f][kb][r] - m_new);
+          p[kb][r] = (VAR & 2) ? __builtin_amdgcn_exp2f(st[f][kb][r] - m_new) : __expf(st[f][kb][r] - m_new);
           psum += p[kb][r];
         }
       l_run[f] = l_run[f] * alpha + psum;
-      if (alpha != 1.0f) {     // wave-divergent at worst; the running max rarely moves after the first tiles
+      if (!(VAR & 4) || alpha != 1.0f) {   // VAR & 4: skip the O rescale when the running max did not move
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -238,6 +240,8 @@ __global__ __launch_bounds__(64) void attn_enc_f32_kernel(const float* __restric
   }
 }
 
+int g_attn_enc_variant = 6;   // wj_tune("attn_enc_variant"): bit0 XCD remap, bit1 base-2 softmax, bit2 lazy rescale
+
 int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt, void* out, int B, int T, int Tpad,
                          int H, hipStream_t s) {
   if (Tpad % 128 || Tpad < T) { set_error("attention_enc: Tpad must be a multiple of 128 and >= T"); return WJ_E_INVALID; }
@@ -247,8 +251,20 @@ int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt
                        (float*)out, T, Tpad, H);
   } else {
     dim3 grid(Tpad / 128, H, B);
-    hipLaunchKernelGGL(attn_enc_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,
-                       (const bf16_t*)Vt, (bf16_t*)out, T, Tpad, H);
+#define WJ_ATTN(V)                                                                                                 \
+  hipLaunchKernelGGL(attn_enc_bf16_kernel<V>, grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,          \
+                     (const bf16_t*)Vt, (bf16_t*)out, T, Tpad, H)
+    switch (g_attn_enc_variant & 7) {
+      case 0: WJ_ATTN(0); break;
+      case 1: WJ_ATTN(1); break;
+      case 2: WJ_ATTN(2); break;
+      case 3: WJ_ATTN(3); break;
+      case 4: WJ_ATTN(4); break;
+      case 5: WJ_ATTN(5); break;
+      case 6: WJ_ATTN(6); break;
+      default: WJ_ATTN(7); break;
+    }
+#undef WJ_ATTN
   }
   WJ_LAUNCH_CHECK();
   return WJ_OK;

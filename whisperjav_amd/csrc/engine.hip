@@ -85,6 +85,8 @@ struct Tunables {
   int dec_ks_fc2 = 8;       // split-K factor of the decode fc2 GEMM (K = 4d)
   int dec_tile_min_m = 128; // rows from which the split-K decode GEMMs use the 128x128 tile kernel (0 = never)
   int decode_chains = 1;    // concurrent row chains in the greedy loop
+  int dec_ks_proj = 0;      // split-K factor of the K = d projections (QKV, cross-q, fc1); 0 = single-pass kernels
+  int dec_proj_min_m = 96;  // rows from which those projections go split-K (tile kernel + reduce kernel)
 };
 static Tunables g_tune;
 
@@ -294,6 +296,21 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     }
     return WJ_OK;
   };
+  // projections with a scatter / activation epilogue: single pass, or (many rows) split-K slabs from the tile
+  // kernel + one reduce kernel that applies the very same epilogue
+  auto proj_gemm = [&](int tag, Epi epi, GemmArgs& g) -> int {
+    const int ks = g_tune.dec_ks_proj;
+    if (dt == WJ_BF16 && ks > 1 && R >= g_tune.dec_proj_min_m && (int64_t)ks * g.N <= (int64_t)kDecKsMax * D &&
+        g.K % (64 * ks) == 0 && !pend_ks) {
+      GemmArgs p = g;
+      p.out = slab; p.ldc = g.N; p.ksplit = ks; p.bias = nullptr;
+      PROF(tag, launch_gemm(dt, EPI_PARTIAL_F32, p, s, 3));
+      PROF(tag, launch_splitk_reduce(dt, epi, g, slab, ks, s));
+    } else {
+      PROF(tag, launch_gemm(dt, epi, g, s));
+    }
+    return WJ_OK;
+  };
   auto norm = [&](const float* w, const float* b) -> int {
     if (pend_ks) {
       const int ks = pend_ks;
@@ -317,7 +334,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       g.M = R; g.N = 3 * D; g.K = D; g.out = dq;
       g.out2 = m->at(sk, row0 * self_row); g.out3 = m->at(sv, row0 * self_row);
       g.D = D; g.H = H; g.pos_ptr = pos; g.cache_len = d.n_text_ctx;
-      PROF(PT_D_QKV, launch_gemm(dt, EPI_QKV_DEC, g, s));
+      WJ_TRY(proj_gemm(PT_D_QKV, EPI_QKV_DEC, g));
     }
     {
       DecAttnArgs a;   // K/V bases stay absolute: the row map holds absolute physical rows
@@ -332,7 +349,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       GemmArgs g;
       g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
       g.M = R; g.N = D; g.K = D; g.out = dq; g.ldc = D;
-      PROF(PT_D_CQ, launch_gemm(dt, EPI_T, g, s));
+      WJ_TRY(proj_gemm(PT_D_CQ, EPI_T, g));
     }
     {
       DecAttnArgs a;
@@ -348,7 +365,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       GemmArgs g;
       g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_FC1_B);
       g.M = R; g.N = 4 * D; g.K = D; g.out = dff; g.ldc = 4 * D;
-      PROF(PT_D_FC1, launch_gemm(dt, EPI_GELU_T, g, s));
+      WJ_TRY(proj_gemm(PT_D_FC1, EPI_GELU_T, g));
     }
     WJ_TRY(resid_gemm(PT_D_FC2, dff, 4 * D, m->W(b0 + WJ_TD_FC2_W), m->F(b0 + WJ_TD_FC2_B), ks_fc2));
   }
@@ -479,6 +496,9 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_ks_fc2")) g_tune.dec_ks_fc2 = value;
   else if (!strcmp(key, "dec_tile_min_m")) g_tune.dec_tile_min_m = value;
   else if (!strcmp(key, "decode_chains")) g_tune.decode_chains = value;
+  else if (!strcmp(key, "attn_enc_variant")) wj::g_attn_enc_variant = value;
+  else if (!strcmp(key, "dec_ks_proj")) g_tune.dec_ks_proj = value;
+  else if (!strcmp(key, "dec_proj_min_m")) g_tune.dec_proj_min_m = value;
   else { set_error("wj_tune: unknown key %s", key); return WJ_E_INVALID; }
   return WJ_OK;
 }
@@ -926,6 +946,34 @@ int wj_k_attention_enc(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, void* o
                        (bf16_t*)(base + one), (bf16_t*)(base + 2 * one), T, Tpad, H);
   WJ_LAUNCH_CHECK();
   return launch_attention_enc(dtype, base, base + one, base + 2 * one, out_dev, B, T, Tpad, H, s);
+}
+
+int wj_k_attention_enc_timed(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, void* out_dev, int B, int T, int H,
+                             int reps, float* ms_per_launch) {
+  WJ_REQUIRE(ctx && qkv_f32_dev && out_dev && ms_per_launch && reps >= 1, "wj_k_attention_enc_timed: bad arguments");
+  int rc = wj_k_attention_enc(ctx, dtype, qkv_f32_dev, out_dev, B, T, H, nullptr);   // builds Q/K/Vt in the scratch + warm-up
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const int Tpad = (T + 127) / 128 * 128;
+  const size_t esz = dtype == WJ_BF16 ? 2 : 4;
+  const size_t one = align_up((size_t)B * H * Tpad * 64 * esz, 256);
+  char* base = reinterpret_cast<char*>(ctx->scratch);
+  hipEvent_t e0, e1;
+  WJ_HIP(hipEventCreate(&e0));
+  WJ_HIP(hipEventCreate(&e1));
+  WJ_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < reps; ++i) {
+    rc = launch_attention_enc(dtype, base, base + one, base + 2 * one, out_dev, B, T, Tpad, H, s);
+    if (rc) return rc;
+  }
+  WJ_HIP(hipEventRecord(e1, s));
+  WJ_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  WJ_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = ms / reps;
+  return WJ_OK;
 }
 
 int wj_k_attention_dec(wj_ctx* ctx, int dtype, const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev,

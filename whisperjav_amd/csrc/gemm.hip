@@ -390,6 +390,44 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 }
 
 // --------------------------------------------------------------------------------------------
+// split-K consumer: out = EPI(sum_s slab[s]) for epilogues that have no natural consumer kernel
+// (QKV + cache append, cross-q, fc1 + GELU).  One thread per 4 consecutive columns of a row.
+// --------------------------------------------------------------------------------------------
+template <int EPI, typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g, const float* __restrict__ slab, int ks) {
+  const int quads = g.N >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)g.M * quads) return;
+  const int m = (int)(idx / quads), n = (int)(idx % quads) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < ks; ++s) {
+    const float4 p = *reinterpret_cast<const float4*>(slab + ((int64_t)s * g.M + m) * g.N + n);
+    v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+  }
+  epi_nm<EPI, T>(g, 0, m, n, v);
+}
+
+template <int EPI>
+static int launch_reduce_epi(int dtype, const GemmArgs& a, const float* slab, int ks, hipStream_t s) {
+  const int64_t total = (int64_t)a.M * (a.N >> 2);
+  dim3 grid((unsigned)ceil_div64(total, 256));
+  if (dtype == WJ_F32) hipLaunchKernelGGL((splitk_reduce_kernel<EPI, float>), grid, dim3(256), 0, s, a, slab, ks);
+  else hipLaunchKernelGGL((splitk_reduce_kernel<EPI, bf16_t>), grid, dim3(256), 0, s, a, slab, ks);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+int launch_splitk_reduce(int dtype, Epi epi, const GemmArgs& a, const float* slab, int ks, hipStream_t s) {
+  if (a.N % 4) { set_error("splitk_reduce: N must be a multiple of 4"); return WJ_E_INVALID; }
+  switch (epi) {
+    case EPI_T: return launch_reduce_epi<EPI_T>(dtype, a, slab, ks, s);
+    case EPI_GELU_T: return launch_reduce_epi<EPI_GELU_T>(dtype, a, slab, ks, s);
+    case EPI_QKV_DEC: return launch_reduce_epi<EPI_QKV_DEC>(dtype, a, slab, ks, s);
+    default: set_error("splitk_reduce: unsupported epilogue %d", (int)epi); return WJ_E_INVALID;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
 // dispatch
 // --------------------------------------------------------------------------------------------
 template <int EPI>

@@ -42,6 +42,10 @@ struct GemmArgs {
 //          3 = tiled kernel with LDS-DMA staging; 4 = tiled kernel with register staging
 int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int variant = 0);
 
+// second half of a split-K GEMM whose epilogue has no consumer kernel to fold the reduction into:
+// out = EPI(bias + sum_s slab[s][M][N]); `a` carries the epilogue operands exactly as for launch_gemm
+int launch_splitk_reduce(int dtype, Epi epi, const GemmArgs& a, const float* slab, int ks, hipStream_t s);
+
 // ---------------- normalisation / elementwise ------------------------------------------------
 int launch_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, int M, int D,
                      hipStream_t s);
@@ -58,6 +62,7 @@ int launch_f32_to_T(int dtype, const float* in, void* out, int64_t n, hipStream_
 
 // ---------------- attention --------------------------------------------------------------------
 // encoder: Q,K [B][H][Tpad][64], Vt [B][H][64][Tpad] (T dtype) -> out T [B][T][H*64]
+extern int g_attn_enc_variant;
 int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt, void* out, int B, int T,
                          int Tpad, int H, hipStream_t s);
 // decode: q T [G*nb][H*64]; K,V laid out [group][H][kv_stride][64]. n_keys from n_keys_ptr (device,
