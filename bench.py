@@ -292,7 +292,9 @@ def main():
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", f"r01_pmc_cross_attn_b{B}.json")
         if dom == "dec_cross_attn" and os.path.exists(pmc_file) and args.dtype == "bfloat16":
-            traffic = json.load(open(pmc_file))["hbm_read_bytes_per_launch"]   # rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction
+            pmc = json.load(open(pmc_file))   # rocprofv3 --pmc FETCH_SIZE pass at this batch, x2 gfx950 wide-read correction
+            if "expected_average_bytes_per_launch" not in pmc:     # single-chain passes only (one launch = all windows)
+                traffic = pmc["hbm_read_bytes_per_launch"]
         if "bound" in stages[dom]:
             e = stages[dom]
             roofline = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"],
