@@ -166,7 +166,9 @@ def run_cfg3(args, info, dims):
         clips = [audio[a:b] for a, b in groups if b - a > 400]
         out, _ = model.transcribe_many(clips, **kw)
         t3 = time.perf_counter()
-        return {"scenes": len(scenes), "groups": len(clips), "segments": sum(len(x) for x in out),
+        from whisperjav_amd import search as _search
+        return {"beam_timing": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in _search.LAST_TIMING.items()},
+                "scenes": len(scenes), "groups": len(clips), "segments": sum(len(x) for x in out),
                 "speech_s": sum(len(c) for c in clips) / 16000.0, "t_scene": t1 - t0, "t_vad": t2 - t1, "t_asr": t3 - t2}
 
     for _ in range(args.warmup):

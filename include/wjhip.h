@@ -138,6 +138,11 @@ typedef struct {
   int32_t max_initial_timestamp_index; /* round(max_initial_timestamp / 0.02); <0 = none */
   int32_t eot, no_timestamps, timestamp_begin, blank, no_speech;
   const uint8_t* suppress_mask_dev;   /* [n_vocab] 1 = always suppressed (may be NULL) */
+  /* device-sampler logits processors (ctranslate2 RepetitionPenalty / NoRepeatNgram, applied before the
+   * suppress / timestamp rules over [last prompt token] + generated); <= 0 or 1.0 / 0 = off.  Honoured by
+   * wj_whisper_decode_greedy / _sample; the step API takes them per call (wj_decode_topk_rules). */
+  float repetition_penalty;
+  int32_t no_repeat_ngram_size;
 } wj_decode_opts;
 
 /* Greedy decode, fully device resident (one host sync at the end; per-step launches are
@@ -151,6 +156,17 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
                              const wj_decode_opts* opts, int32_t* tokens_out, int32_t* n_tokens_out,
                              float* sum_logprob_out, float* no_speech_prob_out,
                              float* token_logprob_out, void* stream);
+
+/* Generalisation used by the temperature-fallback ladder (faster_whisper generate_with_fallback /
+ * whisper decode_with_fallback): `group` rows per window (best_of samples) share the window's cross K/V,
+ * `slots_host` (may be NULL = identity) names the resident window slot of each decoded window so a subset of
+ * an encoded batch can be re-decoded, temperature > 0 draws from softmax(filtered logits / T) with a
+ * counter-based generator (seed, row, step, token) -- reproducible; reported log-probs are unscaled.
+ * prompts_host is [batch][prompt_len]; outputs are per ROW ([batch * group]...). */
+int wj_whisper_decode_sample(wj_whisper* m, int batch, int group, const int32_t* slots_host, const int32_t* prompts_host,
+                             int prompt_len, const wj_decode_opts* opts, float temperature, uint32_t seed,
+                             int32_t* tokens_out, int32_t* n_tokens_out, float* sum_logprob_out,
+                             float* no_speech_prob_out, float* token_logprob_out, void* stream);
 
 /* diagnostics of the last wj_whisper_decode_greedy call: out[0] = 1 if the step was replayed from a
  * hipGraph, out[1] = number of concurrent row chains */

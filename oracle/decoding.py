@@ -102,9 +102,12 @@ class GreedyOut:
 
 
 def greedy_decode(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], max_new_tokens: int,
-                  cfg: Optional[FilterConfig] = None, forced: Optional[Sequence[Sequence[int]]] = None) -> GreedyOut:
+                  cfg: Optional[FilterConfig] = None, forced: Optional[Sequence[Sequence[int]]] = None,
+                  processors: Optional["BeamConfig"] = None) -> GreedyOut:
     """Greedy decode every window of ``xa`` [B, T, D].  ``forced`` (teacher forcing) feeds the given
-    tokens instead of the arg-max while still reporting what the model would have scored them."""
+    tokens instead of the arg-max while still reporting what the model would have scored them.
+    ``processors`` (its repetition_penalty / no_repeat_ngram_size) applies the ctranslate2 logits
+    processors before the Whisper rules, as ``Whisper.generate(beam_size=1, repetition_penalty=...)`` does."""
     cfg = cfg or FilterConfig()
     lay = TokenLayout.for_vocab(model.dims.n_vocab)
     B = xa.shape[0]
@@ -122,6 +125,8 @@ def greedy_decode(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int],
             if p == 0:
                 nsp = torch.softmax(logits.float(), dim=-1)[:, lay.no_speech].numpy().astype(np.float32)
         for i in range(max_new_tokens):
+            if processors is not None:
+                logits = _apply_ct2_processors(logits, [h[P - 1:] for h in hist], processors)
             filt = filter_logits(logits, hist, P, lay, cfg)
             lp = torch.log_softmax(filt, dim=-1)
             nxt = lp.argmax(dim=-1).tolist()

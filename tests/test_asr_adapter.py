@@ -143,6 +143,7 @@ def _model(scripts):
     m.dims, m.model, m.fe = d, FakeEngine(d, scripts), FakeFrontEnd()
     m.tokens, m.tokenizer = m.model.tokens, wm.IdTokenizer()
     m.max_batch, m.max_beam, m.max_length, m._warned, m.compute_type = 8, 1, 448, set(), "float32"
+    m.seed, m._sample_calls = 0, 0
     return m
 
 
@@ -196,6 +197,47 @@ def test_no_speech_gate_skips_window():
     assert list(segs) == []
 
 
+def test_temperature_fallback_ladder_redecodes_only_failing_windows():
+    """generate_with_fallback: a window whose average log-prob is under the threshold is re-decoded at the next
+    temperature (best_of samples, on its resident slot); the others keep their zero-temperature result; when every
+    rung fails faster-whisper keeps the best average log-prob and reports the LAST temperature."""
+    tb = pdims.special_tokens(51865).timestamp_begin
+    m = _model([[tb, 5, tb + 100]])
+    m.max_beam = 2
+    greedy0 = m.model.decode_greedy
+
+    def greedy(prompts, options):
+        res = greedy0(prompts, options)
+        res.sum_logprob[1] = -30.0          # clip 1 fails log_prob_threshold at T = 0
+        res.sum_logprob[2] = -40.0          # clip 2 fails every rung
+        return res
+    calls = []
+
+    def sample(prompts, options, temperature, best_of, slots, seed):
+        calls.append((float(temperature), int(best_of), list(slots), int(seed)))
+        R, n = len(slots) * best_of, options.max_new_tokens
+        toks = np.full((R, n), m.model.tokens.eot, dtype=np.int32)
+        slp = np.zeros(R, np.float32)
+        for w, slot in enumerate(slots):
+            for g in range(best_of):
+                r = w * best_of + g
+                toks[r, :3] = [tb, 40 + g, tb + 200]
+                slp[r] = (-3.0 if g == 1 else -6.0) if slot == 1 else (-35.0 - g - 10 * temperature)
+        return engine.GreedyResult(toks, np.full(R, 3, np.int32), slp, np.full(R, 0.01, np.float32), np.zeros((R, n), np.float32))
+    m.model.decode_greedy, m.model.decode_sample = greedy, sample
+    clips = [np.zeros(16000 * 3, np.float32)] * 3
+    segs, _ = m.transcribe_many(clips, beam_size=1, best_of=2, temperature=(0.0, 0.4, 0.8), condition_on_previous_text=False,
+                                log_prob_threshold=-1.0, compression_ratio_threshold=None)
+    assert [c[:3] for c in calls] == [(0.4, 2, [1, 2]), (0.8, 2, [2])]
+    assert len({c[3] for c in calls}) == 2                                      # a fresh seed per rung
+    assert segs[0][0].temperature == 0.0 and segs[0][0].tokens == [tb, 5, tb + 100]
+    assert segs[1][0].temperature == pytest.approx(0.4) and segs[1][0].tokens == [tb, 41, tb + 200]   # best of the two samples
+    assert segs[1][0].avg_logprob == pytest.approx(-3.0 / 4)
+    # clip 2: rungs gave -40/4 (T=0), -39/4 (T=.4, g=0), -43/4 (T=.8, g=0) -> keeps T=.4's tokens, reports T=.8
+    assert segs[2][0].temperature == pytest.approx(0.8) and segs[2][0].avg_logprob == pytest.approx(-39.0 / 4)
+    assert segs[2][0].tokens == [tb, 40, tb + 200]
+
+
 # ---- fidelity flavour (openai-whisper call contract) ------------------------------------------------
 def _ow_model(scripts):
     d = pdims.custom_dims(80, 128, 2, 2, 51865)
@@ -208,6 +250,7 @@ def _ow_model(scripts):
     m.fe = OwFrontEnd()
     m.tokens, m.tokenizer = m.model.tokens, wm.IdTokenizer()
     m.max_batch, m.max_beam, m.max_length, m._warned, m.compute_type = 8, 1, 448, set(), "float32"
+    m.seed, m._sample_calls = 0, 0
     return m
 
 

@@ -48,4 +48,5 @@ def test_no_cpu_fallback_without_device(hip):
 def test_struct_layouts_match_header():
     from whisperjav_amd import hipbind
     assert ctypes.sizeof(hipbind.WhisperDimsC) == 40
-    assert hipbind.DecodeOptsC.suppress_mask_dev.offset == 40 and ctypes.sizeof(hipbind.DecodeOptsC) == 48
+    assert hipbind.DecodeOptsC.suppress_mask_dev.offset == 40 and ctypes.sizeof(hipbind.DecodeOptsC) == 56
+    assert hipbind.DecodeOptsC.repetition_penalty.offset == 48 and hipbind.DecodeOptsC.no_repeat_ngram_size.offset == 52

@@ -85,11 +85,11 @@ def test_logmel_bit_reproducible(hip):
 SMALL = dict(n_mels=80, d_model=128, heads=2, layers=2, n_vocab=51865)
 
 
-def _engine_and_oracle(dtype, dims_kw=SMALL, seed=21, max_batch=3):
+def _engine_and_oracle(dtype, dims_kw=SMALL, seed=21, max_batch=3, max_beam=1):
     from whisperjav_amd import engine
     d = helpers.small_dims(**dims_kw)
     oracle, w = helpers.make_oracle(d, seed=seed, emulate_bf16=(dtype == "bfloat16"))
-    model = engine.HipWhisper(d, w, dtype=dtype, max_batch=max_batch)
+    model = engine.HipWhisper(d, w, dtype=dtype, max_batch=max_batch, max_beam=max_beam)
     return d, oracle, model
 
 
@@ -383,6 +383,16 @@ def test_whisper_model_shim_end_to_end(hip):
     assert [t for s in many[0] for t in s.tokens] == got
     beam, _ = model.transcribe(audio, **dict(kw, beam_size=2, patience=1.2, repetition_penalty=1.5, no_repeat_ngram_size=3))
     assert len(list(beam)) >= 1
+    # the temperature ladder: an unreachable log-prob bar makes every rung fail -> best average log-prob is kept
+    # (never worse than the zero-temperature one) and the LAST temperature is reported; without bars nothing falls back
+    lad, _ = model.transcribe(audio, **dict(kw, temperature=(0.0, 0.5, 1.0), best_of=2, log_prob_threshold=-1e-3,
+                                             compression_ratio_threshold=None))
+    lad = list(lad)
+    assert lad and all(s.temperature == 1.0 for s in lad)
+    assert lad[0].avg_logprob >= segs[0].avg_logprob - 1e-6
+    calm, _ = model.transcribe(audio, **dict(kw, temperature=(0.0, 0.5, 1.0), best_of=2, log_prob_threshold=None,
+                                              compression_ratio_threshold=None))
+    assert [t for s in calm for t in s.tokens] == got
     model.close()
 
 
@@ -539,4 +549,134 @@ def test_decode_is_deterministic_and_respects_context_limit(hip):
         model.decode_greedy(prompt, engine.DecodeOptions(max_new_tokens=446))
     with pytest.raises(hipbind.WjError):
         model.encode(torch.zeros((3, d.n_mels, 3000), device="cuda"))               # more windows than max_batch
+    model.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# device sampler: logits processors and temperature sampling (the fallback ladder's rungs)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rep,ngram", [(1.5, 0), (1.0, 2), (1.3, 3)])
+def test_greedy_device_processors_match_oracle(hip, rep, ngram):
+    """beam_size=1 with repetition_penalty / no_repeat_ngram_size stays in the device loop: token ids identical,
+    per-token log-probs within 1e-3 (fp32) of the oracle's ctranslate2-style processors + Whisper rules."""
+    from whisperjav_amd import engine
+    d, oracle, model = _engine_and_oracle("float32")
+    mel = torch.from_numpy(helpers.synth_mel(3, d.n_mels, seed=31))
+    suppress = (1, 2, 7, 8, 9, 10, 14, 25, 50256, 50360, 50361)
+    n_new = 28
+    prompt = model.sot_prompt("ja", "transcribe", False)
+    model.encode(mel.cuda())
+    res = model.decode_greedy(np.tile(np.array(prompt, dtype=np.int32), (3, 1)),
+                              engine.DecodeOptions(max_new_tokens=n_new, suppress_tokens=suppress, max_initial_timestamp=1.0,
+                                                   repetition_penalty=rep, no_repeat_ngram_size=ngram))
+    cfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=50)
+    with torch.no_grad():
+        ref = decoding.greedy_decode(oracle, oracle.encode(mel), prompt, n_new, cfg,
+                                     processors=decoding.BeamConfig(repetition_penalty=rep, no_repeat_ngram_size=ngram))
+        plain = decoding.greedy_decode(oracle, oracle.encode(mel), prompt, n_new, cfg)
+    worst = 0.0
+    for r in range(3):
+        got = res.tokens[r, : res.n_tokens[r]].tolist()
+        assert got == ref.tokens[r], (r, got, ref.tokens[r])
+        for j in range(len(got)):
+            worst = max(worst, abs(float(res.token_logprob[r, j]) - ref.token_logprob[r][j]))
+    assert worst < 1e-3, worst
+    assert any(ref.tokens[r] != plain.tokens[r] for r in range(3)), "processors had no effect: test is vacuous"
+    _diag("greedy_processors", {"rep": rep, "ngram": ngram, "max_logprob_diff": worst})
+    model.close()
+
+
+def test_sampling_small_temperature_equals_greedy_and_is_seeded(hip):
+    from whisperjav_amd import engine
+    d, oracle, model = _engine_and_oracle("float32", max_batch=4, max_beam=8)
+    mel = torch.from_numpy(helpers.synth_mel(4, d.n_mels, seed=32))
+    prompt = np.tile(np.array(model.sot_prompt("ja", "transcribe", False), dtype=np.int32), (4, 1))
+    o = engine.DecodeOptions(max_new_tokens=20, max_initial_timestamp=1.0)
+    model.encode(mel.cuda())
+    g = model.decode_greedy(prompt, o)
+    # group = 1, temperature 0 through the general entry == greedy, bit for bit
+    z = model.decode_sample(prompt, o, temperature=0.0, best_of=1)
+    assert np.array_equal(z.tokens, g.tokens) and np.array_equal(z.sum_logprob, g.sum_logprob)
+    # T -> 0+: the Gumbel noise is scaled out (logit gaps / 1e-4 dwarf it)
+    c = model.decode_sample(prompt, o, temperature=1e-4, best_of=1, seed=5)
+    assert np.array_equal(c.tokens, g.tokens)
+    assert np.abs(c.sum_logprob - g.sum_logprob).max() < 1e-4
+    # a subset of the resident windows through the slot map, two samples each: rows are window-major
+    s = model.decode_sample(prompt[[3, 1]], o, temperature=0.0, best_of=2, slots=[3, 1])
+    for row, w in enumerate([3, 3, 1, 1]):
+        assert np.array_equal(s.tokens[row], g.tokens[w]), (row, w)
+        assert abs(float(s.sum_logprob[row]) - float(g.sum_logprob[w])) < 1e-4
+        assert abs(float(s.no_speech_prob[row]) - float(g.no_speech_prob[w])) < 1e-6
+    # seeded: same seed -> same draw, different seed -> a different one; rows of one window differ from each other
+    a = model.decode_sample(prompt, o, temperature=1.0, best_of=4, seed=11)
+    b = model.decode_sample(prompt, o, temperature=1.0, best_of=4, seed=11)
+    c2 = model.decode_sample(prompt, o, temperature=1.0, best_of=4, seed=12)
+    assert np.array_equal(a.tokens, b.tokens) and np.array_equal(a.sum_logprob, b.sum_logprob)
+    assert not np.array_equal(a.tokens, c2.tokens)
+    assert any(not np.array_equal(a.tokens[4 * w], a.tokens[4 * w + 1]) for w in range(4))
+    model.close()
+
+
+def test_sampled_sequences_obey_rules_and_report_unscaled_logprobs(hip):
+    """Every sampled sequence must be possible under the Whisper rules, and its reported per-token log-probs are
+    those of the UNSCALED filtered distribution: the fp32 oracle teacher-forced on the sampled tokens gives the
+    same numbers (1e-3)."""
+    from whisperjav_amd import engine
+    d, oracle, model = _engine_and_oracle("float32", max_batch=4, max_beam=8)
+    mel = torch.from_numpy(helpers.synth_mel(2, d.n_mels, seed=33))
+    suppress = (1, 2, 7, 8, 9, 10, 14, 25, 50256, 50360, 50361)
+    p = model.sot_prompt("ja", "transcribe", False)
+    o = engine.DecodeOptions(max_new_tokens=16, suppress_tokens=suppress, max_initial_timestamp=1.0)
+    model.encode(mel.cuda())
+    G = 5
+    s = model.decode_sample(np.tile(np.array(p, dtype=np.int32), (2, 1)), o, temperature=0.8, best_of=G, seed=77)
+    cfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=50)
+    worst = 0.0
+    with torch.no_grad():
+        xa = oracle.encode(mel)
+        forced = [s.tokens[r, : min(16, s.n_tokens[r] + 1)].tolist() for r in range(2 * G)]
+        ref = decoding.greedy_decode(oracle, xa.repeat_interleave(G, dim=0), p, 16, cfg, forced=forced)
+    for r in range(2 * G):
+        n = len(forced[r])
+        for j in range(n):
+            assert np.isfinite(ref.token_logprob[r][j]), (r, j, forced[r])      # the rules allow the sampled token
+            worst = max(worst, abs(float(s.token_logprob[r, j]) - ref.token_logprob[r][j]))
+        assert abs(float(s.sum_logprob[r]) - float(np.sum(ref.token_logprob[r][:n]))) < 1e-3 * n
+    _diag("sampling_forced", {"max_logprob_diff": worst})
+    assert worst < 1e-3, worst
+    model.close()
+
+
+def test_sampling_first_token_frequencies_follow_softmax(hip):
+    """Statistical check of the Gumbel-max draw: 8 samples/window/call x 96 calls of ONE step; the empirical
+    distribution of the first token matches softmax(filtered logits / T) from the oracle (chi-square style bound)."""
+    from whisperjav_amd import engine
+    d, oracle, model = _engine_and_oracle("float32", max_batch=4, max_beam=8)
+    mel = torch.from_numpy(helpers.synth_mel(1, d.n_mels, seed=34))
+    p = model.sot_prompt("ja", "transcribe", False)
+    T = 2.5   # flatten the synthetic model's first-step distribution over the 51 allowed initial timestamps
+    o = engine.DecodeOptions(max_new_tokens=1, max_initial_timestamp=1.0)
+    model.encode(mel.cuda())
+    counts = {}
+    n_draws = 0
+    for call in range(96):
+        s = model.decode_sample(np.array([p], dtype=np.int32), o, temperature=T, best_of=8, seed=1000 + call)
+        for r in range(8):
+            counts[int(s.tokens[r, 0])] = counts.get(int(s.tokens[r, 0]), 0) + 1
+            n_draws += 1
+    with torch.no_grad():
+        xa = oracle.encode(mel)
+        dec = whisper_ref.CachedDecoder(oracle, xa)
+        for t in p:
+            lg = dec.step(torch.tensor([[t]]))
+        filt = decoding.filter_logits(lg, [list(p)], len(p), decoding.TokenLayout.for_vocab(d.n_vocab),
+                                      decoding.FilterConfig(max_initial_timestamp_index=50))
+        probs = torch.softmax(filt[0].double() / T, dim=-1).numpy()
+    assert all(probs[t] > 0 for t in counts)                       # nothing outside the allowed set was drawn
+    support = np.nonzero(probs > 0)[0]
+    chi2 = sum((counts.get(int(t), 0) - n_draws * probs[t]) ** 2 / (n_draws * probs[t]) for t in support if n_draws * probs[t] >= 5)
+    dof = sum(1 for t in support if n_draws * probs[t] >= 5) - 1
+    _diag("sampling_chi2", {"chi2": float(chi2), "dof": int(dof), "draws": n_draws, "distinct": len(counts)})
+    assert dof >= 3, "distribution too peaked for the test to mean anything"
+    assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)         # > 5 sigma of the chi-square would be a broken sampler
     model.close()

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void attn_enc_f32_kernel(const float* __restric
   }
 }
 
-int g_attn_enc_variant = 6;   // wj_tune("attn_enc_variant"): bit0 XCD remap, bit1 base-2 softmax, bit2 lazy rescale
+int g_attn_enc_variant = 7;   // wj_tune("attn_enc_variant"): bit0 XCD remap, bit1 base-2 softmax, bit2 lazy rescale
 
 int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt, void* out, int B, int T, int Tpad,
                          int H, hipStream_t s) {

@@ -85,7 +85,7 @@ struct Tunables {
   int dec_ks_fc2 = 8;       // split-K factor of the decode fc2 GEMM (K = 4d)
   int dec_tile_min_m = 128; // rows from which the split-K decode GEMMs use the 128x128 tile kernel (0 = never)
   int decode_chains = 1;    // concurrent row chains in the greedy loop
-  int dec_ks_proj = 0;      // split-K factor of the K = d projections (QKV, cross-q, fc1); 0 = single-pass kernels
+  int dec_ks_proj = 4;      // split-K factor of the K = d projections (QKV, cross-q, fc1); 0 = single-pass kernels
   int dec_proj_min_m = 96;  // rows from which those projections go split-K (tile kernel + reduce kernel)
 };
 static Tunables g_tune;
@@ -138,6 +138,8 @@ struct wj_whisper {
   int cur_map = 0;
   int32_t* parent = nullptr;  // [R]
   int32_t* step_tok = nullptr;  // [R] staging for wj_decode_step
+  int32_t* slot_map = nullptr;  // [max_batch] window slot of each decoded window (sub-batch re-decodes)
+  bool use_slots = false;
   int32_t* topk_ids = nullptr;  // [R][16]
   float* topk_lp = nullptr;
   float* topk_lse = nullptr;
@@ -354,8 +356,10 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     {
       DecAttnArgs a;
       a.q = dq;
-      a.K = m->at(m->cross_k, l * m->cross_layer_elems() + win0 * cross_win);
-      a.V = m->at(m->cross_v, l * m->cross_layer_elems() + win0 * cross_win);
+      const int64_t woff = m->use_slots ? 0 : win0 * cross_win;   // with a slot map the K/V base stays absolute
+      a.K = m->at(m->cross_k, l * m->cross_layer_elems() + woff);
+      a.V = m->at(m->cross_v, l * m->cross_layer_elems() + woff);
+      a.group_of = m->use_slots ? m->slot_map + win0 : nullptr;
       a.out = dattn; a.G = n_windows; a.nb = beam; a.H = H; a.n_keys = d.n_audio_ctx; a.kv_stride = d.n_audio_ctx;
       PROF(PT_D_CROSS, launch_attention_dec(dt, a, s));
     }
@@ -590,6 +594,7 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   WJ_ALLOC(row_map[1], R * d.n_text_ctx * sizeof(int32_t), true);
   WJ_ALLOC(parent, R * sizeof(int32_t), true);
   WJ_ALLOC(step_tok, R * sizeof(int32_t), true);
+  WJ_ALLOC(slot_map, B * sizeof(int32_t), true);
   WJ_ALLOC(topk_ids, R * 16 * sizeof(int32_t), true);
   WJ_ALLOC(topk_lp, R * 16 * sizeof(float), true);
   WJ_ALLOC(topk_lse, R * sizeof(float), true);
@@ -617,27 +622,45 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
                              const wj_decode_opts* opts, int32_t* tokens_out, int32_t* n_tokens_out,
                              float* sum_logprob_out, float* no_speech_prob_out, float* token_logprob_out,
                              void* stream) {
-  WJ_REQUIRE(m && prompts_host && opts && tokens_out && n_tokens_out && sum_logprob_out, "wj_whisper_decode_greedy: NULL argument");
-  WJ_REQUIRE(batch >= 1 && batch <= m->max_batch, "decode_greedy: batch %d outside 1..%d", batch, m->max_batch);
+  return wj_whisper_decode_sample(m, batch, 1, nullptr, prompts_host, prompt_len, opts, 0.0f, 0u, tokens_out, n_tokens_out,
+                                  sum_logprob_out, no_speech_prob_out, token_logprob_out, stream);
+}
+
+int wj_whisper_decode_sample(wj_whisper* m, int batch, int group, const int32_t* slots_host, const int32_t* prompts_host,
+                             int prompt_len, const wj_decode_opts* opts, float temperature, uint32_t seed,
+                             int32_t* tokens_out, int32_t* n_tokens_out, float* sum_logprob_out,
+                             float* no_speech_prob_out, float* token_logprob_out, void* stream) {
+  WJ_REQUIRE(m && prompts_host && opts && tokens_out && n_tokens_out && sum_logprob_out, "wj_whisper_decode_sample: NULL argument");
+  WJ_REQUIRE(batch >= 1 && batch <= m->max_batch, "decode: batch %d outside 1..%d", batch, m->max_batch);
+  WJ_REQUIRE(group >= 1 && (group <= 6 || group == 8) && batch * group <= m->max_rows,
+             "decode: %d samples per window x %d windows does not fit (max_rows %d; group 1..6 or 8)", group, batch, m->max_rows);
+  WJ_REQUIRE(temperature >= 0.f, "decode: negative temperature");
+  if (slots_host)
+    for (int i = 0; i < batch; ++i)
+      WJ_REQUIRE(slots_host[i] >= 0 && slots_host[i] < m->max_batch, "decode: window slot %d out of range", slots_host[i]);
   const int max_new = opts->max_new_tokens;
   WJ_REQUIRE(prompt_len >= 1 && max_new >= 1 && prompt_len + max_new <= m->d.n_text_ctx,
              "decode_greedy: prompt_len %d + max_new_tokens %d exceeds n_text_ctx %d", prompt_len, max_new, m->d.n_text_ctx);
   WJ_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->pick(stream);
-  const int R = batch;
+  const int R = batch * group;   // row r belongs to window r / group
   WJ_TRY(reset_decode_state(m, R, s));
+  m->use_slots = slots_host != nullptr;
+  if (slots_host) WJ_HIP(hipMemcpyAsync(m->slot_map, slots_host, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+  struct SlotGuard { wj_whisper* m; ~SlotGuard() { m->use_slots = false; } } slot_guard{m};
   // prompt -> device history (row stride tok_stride)
   {
     std::vector<int32_t> hist((size_t)R * m->tok_stride, opts->eot);
     for (int r = 0; r < R; ++r)
-      for (int j = 0; j < prompt_len; ++j) hist[(size_t)r * m->tok_stride + j] = prompts_host[(size_t)r * prompt_len + j];
+      for (int j = 0; j < prompt_len; ++j)
+        hist[(size_t)r * m->tok_stride + j] = prompts_host[(size_t)(r / group) * prompt_len + j];
     WJ_HIP(hipMemcpyAsync(m->tokens, hist.data(), hist.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
     WJ_HIP(hipStreamSynchronize(s));
   }
   // prompt positions 0 .. prompt_len-2 only fill the KV cache (position 0 also yields no_speech_prob)
   for (int p = 0; p + 1 < prompt_len; ++p) {
     const bool ns = (p == 0) && no_speech_prob_out != nullptr;
-    WJ_TRY(run_decoder_step(m, 0, R, R, 1, ns, s));
+    WJ_TRY(run_decoder_step(m, 0, R, batch, group, ns, s));
     if (ns) WJ_TRY(launch_no_speech_prob(m->logits, m->ldl, R, m->d.n_vocab, opts->no_speech, m->nsp, s));
     WJ_TRY(launch_advance_pos(m->pos, s));
   }
@@ -651,7 +674,7 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
   if (const char* ce = getenv("WJ_DECODE_CHAINS")) chains = atoi(ce);
   if (chains < 1) chains = 1;
   if (chains > 4) chains = 4;
-  if (prof_on(m->ctx)) chains = 1;            // event pairs are recorded on one stream
+  if (prof_on(m->ctx) || group > 1) chains = 1;   // event pairs are recorded on one stream; samples share K/V
   while (chains > 1 && R < 2 * chains) --chains;
   hipStream_t side[4] = {s, nullptr, nullptr, nullptr};
   hipEvent_t ev_start = nullptr;
@@ -667,12 +690,13 @@ int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_ho
     const int r0 = (int)((int64_t)R * c / chains), r1 = (int)((int64_t)R * (c + 1) / chains);
     hipStream_t s = side[c];   // shadows the outer stream: PROF records on the chain's stream
     int* pos = m->pos + c;
-    WJ_TRY(run_decoder_step(m, r0, r1 - r0, r1 - r0, 1, true, s, pos));
+    WJ_TRY(run_decoder_step(m, r0, r1 - r0, (r1 - r0) / group, group, true, s, pos));
     GreedyArgs ga;
     ga.logits = m->logits + (int64_t)r0 * m->ldl; ga.ldl = m->ldl; ga.R = r1 - r0; ga.V = m->d.n_vocab;
     ga.tokens = m->tokens + (int64_t)r0 * m->tok_stride; ga.tok_stride = m->tok_stride; ga.pos_ptr = pos;
     ga.sample_begin = prompt_len; ga.sum_logprob = m->sum_lp + r0; ga.token_logprob = m->tok_lp + (int64_t)r0 * m->tok_stride;
     ga.finished = m->finished + r0; ga.opts = *opts;
+    ga.temperature = temperature; ga.seed = seed; ga.row_offset = r0;
     PROF(PT_D_SAMPLE, launch_greedy_sample(ga, s));
     PROF(PT_D_MISC, launch_advance_pos(pos, s));
     return WJ_OK;

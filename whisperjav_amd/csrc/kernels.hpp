@@ -84,7 +84,7 @@ int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s);
 
 // ---------------- sampling -----------------------------------------------------------------------
 struct GreedyArgs {
-  const float* logits = nullptr;  // [R][ldl]
+  float* logits = nullptr;        // [R][ldl] (processors edit them in place)
   int64_t ldl = 0;
   int R = 0, V = 0;
   int32_t* tokens = nullptr;      // [R][tok_stride] full history (prompt + sampled)
@@ -95,6 +95,9 @@ struct GreedyArgs {
   float* token_logprob = nullptr; // [R][tok_stride] or NULL
   int32_t* finished = nullptr;    // [R]
   wj_decode_opts opts;
+  float temperature = 0.f;        // > 0: sample from softmax(filtered logits / T) (Gumbel-max), log-probs stay unscaled
+  uint32_t seed = 0;
+  int row_offset = 0;             // absolute index of row 0 (keeps the random stream independent of chains)
 };
 int launch_greedy_sample(const GreedyArgs& a, hipStream_t s);
 int launch_no_speech_prob(const float* logits, int64_t ldl, int R, int V, int no_speech_id, float* out,

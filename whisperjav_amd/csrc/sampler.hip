@@ -55,6 +55,16 @@ __device__ __forceinline__ bool token_allowed(int v, const RowRules& rr, const w
   return true;
 }
 
+// counter-based uniform in (0,1) for (seed, row, step, token): stateless, so sampling is reproducible and
+// independent of launch geometry
+__device__ __forceinline__ float uniform01(uint32_t seed, uint32_t row, uint32_t step, uint32_t v) {
+  auto mix = [](uint32_t h) { h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16; return h; };
+  uint32_t h = mix(seed ^ (row * 0x9E3779B1u));
+  h = mix(h + step * 0x85EBCA77u);
+  h = mix(h ^ (v * 0xC2B2AE3Du));
+  return ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
 constexpr int SB = 1024;  // sampler block size (one workgroup per row sweeps the 51.9k-entry vocabulary)
 
 __global__ __launch_bounds__(SB) void greedy_sample_kernel(const GreedyArgs a) {
@@ -71,6 +81,33 @@ __global__ __launch_bounds__(SB) void greedy_sample_kernel(const GreedyArgs a) {
       if (a.token_logprob) a.token_logprob[(int64_t)r * a.tok_stride + len] = 0.f;
     }
     return;
+  }
+  const float rep = o.repetition_penalty;
+  const int ngram = o.no_repeat_ngram_size;
+  if ((rep > 0.f && rep != 1.f) || ngram > 0) {
+    // ctranslate2 RepetitionPenalty then NoRepeatNgram, in place on this row's logits (they are recomputed
+    // every step); the processor sequence is [last prompt token] + generated = tok[s0 .. len)
+    float* xw = a.logits + (int64_t)r * a.ldl;
+    const int s0 = a.sample_begin - 1, L = len - s0;
+    if (rep > 0.f && rep != 1.f) {
+      for (int j = tid; j < L; j += SB) {
+        const int t = tok[s0 + j];
+        bool first = true;
+        for (int i = 0; i < j; ++i)
+          if (tok[s0 + i] == t) { first = false; break; }
+        if (first) { const float v = xw[t]; xw[t] = v < 0.f ? v * rep : v / rep; }
+      }
+      __syncthreads();
+    }
+    if (ngram > 0 && L >= ngram) {
+      for (int i = tid; i <= L - ngram; i += SB) {
+        bool match = true;
+        for (int k = 0; k < ngram - 1; ++k)
+          if (tok[s0 + i + k] != tok[len - (ngram - 1) + k]) { match = false; break; }
+        if (match) xw[tok[s0 + i + ngram - 1]] = -INFINITY;
+      }
+    }
+    __syncthreads();
   }
   if (tid == 0) {
     RowRules rr;
@@ -132,21 +169,46 @@ __global__ __launch_bounds__(SB) void greedy_sample_kernel(const GreedyArgs a) {
   sum_ts = wave_sum(sum_ts);
   if (lane == 0) { s_f[0][wave] = sum_all; s_f[1][wave] = sum_ts; }
   __syncthreads();
+  __shared__ float s_pick[3];   // norm, ts_only, (unused)
   if (tid == 0) {
     sum_all = 0.f; sum_ts = 0.f;
     for (int w = 0; w < SB / 64; ++w) { sum_all += s_f[0][w]; sum_ts += s_f[1][w]; }
     const float lse = best_all.v + logf(sum_all);
-    int token = best_all.i;
-    float lp = best_all.v - lse;
+    float norm = lse, ts_only = 0.f;
     if (rr.ts_rules && sum_ts > 0.f) {
       // "if the probability mass on timestamps exceeds every single text token, emit a timestamp"
       const float ts_lp = best_all.v + logf(sum_ts) - lse;
       const float text_lp = max_text - lse;
-      if (ts_lp > text_lp) {
-        token = best_ts.i;
-        lp = best_ts.v - (best_all.v + logf(sum_ts));   // renormalised over timestamps only
-      }
+      if (ts_lp > text_lp) { ts_only = 1.f; norm = best_all.v + logf(sum_ts); }   // renormalised over timestamps only
     }
+    s_pick[0] = norm;
+    s_pick[1] = ts_only;
+  }
+  __syncthreads();
+  const float norm = s_pick[0];
+  const bool ts_only = s_pick[1] != 0.f;
+  ArgMax pick = ts_only ? best_ts : best_all;      // temperature 0: arg-max of what is left
+  if (a.temperature > 0.f) {
+    // Gumbel-max draw from softmax(filtered logits / T); the reported log-prob is the UNSCALED one
+    // (whisper.decoding.GreedyDecoder.update)
+    const float inv_t = 1.0f / a.temperature;
+    ArgMax best = {-INFINITY, 0x7fffffff};
+    for (int v = tid; v < a.V; v += SB) {
+      if (ts_only && v < o.timestamp_begin) continue;
+      if (!token_allowed(v, rr, o)) continue;
+      const float u = uniform01(a.seed, (uint32_t)(a.row_offset + r), (uint32_t)len, (uint32_t)v);
+      best = amax(best, ArgMax{x[v] * inv_t - logf(-logf(u)), v});
+    }
+    best = wave_amax(best);
+    __syncthreads();
+    if (lane == 0) { s_f[0][wave] = best.v; s_i[0][wave] = best.i; }
+    __syncthreads();
+    pick = ArgMax{s_f[0][0], s_i[0][0]};
+    for (int w = 1; w < SB / 64; ++w) pick = amax(pick, ArgMax{s_f[0][w], s_i[0][w]});
+  }
+  if (tid == 0) {
+    const int token = pick.i;
+    const float lp = x[token] - norm;
     tok[len] = token;
     a.sum_logprob[r] += lp;
     if (a.token_logprob) a.token_logprob[(int64_t)r * a.tok_stride + len] = lp;

@@ -84,6 +84,8 @@ class DecodeOptions:
     without_timestamps: bool = False
     max_initial_timestamp: Optional[float] = 1.0
     suppress_tokens: Sequence[int] = field(default_factory=tuple)
+    repetition_penalty: float = 1.0
+    no_repeat_ngram_size: int = 0
 
 
 @dataclass
@@ -193,7 +195,8 @@ class HipWhisper:
             max_new_tokens=int(o.max_new_tokens), suppress_blank=int(bool(o.suppress_blank)),
             without_timestamps=int(bool(o.without_timestamps)), max_initial_timestamp_index=idx,
             eot=t.eot, no_timestamps=t.no_timestamps, timestamp_begin=t.timestamp_begin, blank=t.blank,
-            no_speech=t.no_speech, suppress_mask_dev=mask.data_ptr() if mask is not None else None)
+            no_speech=t.no_speech, suppress_mask_dev=mask.data_ptr() if mask is not None else None,
+            repetition_penalty=float(o.repetition_penalty), no_repeat_ngram_size=int(o.no_repeat_ngram_size))
 
     def decode_greedy(self, prompts: np.ndarray, options: Optional[DecodeOptions] = None) -> GreedyResult:
         """Greedy decode of the windows currently resident (rows of ``prompts`` = windows)."""
@@ -213,6 +216,33 @@ class HipWhisper:
         as_f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
         check(self._lib.wj_whisper_decode_greedy(self.handle, B, as_i(prompts), P, C.byref(oc), as_i(toks), as_i(ntok),
                                                  as_f(slp), as_f(nsp), as_f(tlp), None), "wj_whisper_decode_greedy")
+        return GreedyResult(toks, ntok, slp, nsp, tlp)
+
+    def decode_sample(self, prompts: np.ndarray, options: Optional[DecodeOptions] = None, *, temperature: float = 0.0,
+                      best_of: int = 1, slots: Optional[Sequence[int]] = None, seed: int = 0) -> GreedyResult:
+        """``best_of`` rows per window (sharing its cross K/V) decoded at ``temperature``; ``slots`` selects which
+        resident windows are decoded (default: 0..len(prompts)-1).  Results are per row, window-major."""
+        o = options or DecodeOptions()
+        prompts = np.ascontiguousarray(prompts, dtype=np.int32)
+        B, P = prompts.shape
+        R, n = B * int(best_of), o.max_new_tokens
+        oc = self._opts(o)
+        toks = np.empty((R, n), dtype=np.int32)
+        ntok = np.empty(R, dtype=np.int32)
+        slp = np.empty(R, dtype=np.float32)
+        nsp = np.empty(R, dtype=np.float32)
+        tlp = np.empty((R, n), dtype=np.float32)
+        as_i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+        as_f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        sl = None
+        if slots is not None:
+            sl_arr = np.ascontiguousarray(slots, dtype=np.int32)
+            if sl_arr.shape != (B,):
+                raise ValueError("slots must name one resident window per prompt row")
+            sl = as_i(sl_arr)
+        check(self._lib.wj_whisper_decode_sample(self.handle, B, int(best_of), sl, as_i(prompts), P, C.byref(oc),
+                                                 float(temperature), int(seed) & 0xFFFFFFFF, as_i(toks), as_i(ntok), as_f(slp),
+                                                 as_f(nsp), as_f(tlp), None), "wj_whisper_decode_sample")
         return GreedyResult(toks, ntok, slp, nsp, tlp)
 
     def last_decode_info(self) -> dict:

@@ -36,7 +36,7 @@ class DecodeOptsC(C.Structure):
         ("max_new_tokens", C.c_int32), ("suppress_blank", C.c_int32), ("without_timestamps", C.c_int32),
         ("max_initial_timestamp_index", C.c_int32), ("eot", C.c_int32), ("no_timestamps", C.c_int32),
         ("timestamp_begin", C.c_int32), ("blank", C.c_int32), ("no_speech", C.c_int32),
-        ("suppress_mask_dev", C.c_void_p),
+        ("suppress_mask_dev", C.c_void_p), ("repetition_penalty", C.c_float), ("no_repeat_ngram_size", C.c_int32),
     ]
 
 
@@ -62,6 +62,9 @@ _SIGNATURES = {
     "wj_whisper_encode": (_I, [_P, _P, _I, _I, _P, _P]),
     "wj_whisper_decode_greedy": (_I, [_P, _I, C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _P]),
+    "wj_whisper_decode_sample": (_I, [_P, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), _F,
+                                      C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F),
+                                      C.POINTER(_F), _P]),
     "wj_whisper_last_decode_info": (_I, [_P, C.POINTER(C.c_int32)]),
     "wj_decode_open": (_I, [_P, _I, _I, _P]),
     "wj_decode_step": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _P]),

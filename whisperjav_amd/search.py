@@ -89,6 +89,9 @@ def ngram_bans(history: Sequence[int], n: int) -> List[int]:
     return sorted(set(out))
 
 
+LAST_TIMING: dict = {}     # wall-clock split of the most recent beam_search call (device step / device scoring / host)
+
+
 @dataclass
 class _Beam:
     tokens: List[int]
@@ -123,8 +126,13 @@ def beam_search(scorer: StepScorer, prompts: Sequence[Sequence[int]], opts: Sear
     feed = np.repeat(np.array(start_tok, dtype=np.int32), K)
     parents: Optional[np.ndarray] = None
 
+    import time as _time
+    t_step = t_score = t_host = 0.0
     for step in range(max_new):
+        _t0 = _time.perf_counter()
         scorer.step(feed, parents, want_logits=True)
+        _t1 = _time.perf_counter()
+        t_step += _t1 - _t0
         if P == 1 and step == 0:
             nsp = scorer.no_speech()[::K].copy()
         rules = np.zeros((R, 4), dtype=np.int32)
@@ -144,7 +152,11 @@ def beam_search(scorer: StepScorer, prompts: Sequence[Sequence[int]], opts: Sear
         for r in range(R):
             bans[r, :len(ban_lists[r])] = ban_lists[r]
             pens[r, :len(pen_lists[r])] = pen_lists[r]
+        _t2 = _time.perf_counter()
         ids, lps = scorer.score(n_cand, rules, bans, pens, float(opts.repetition_penalty))
+        _t3 = _time.perf_counter()
+        t_score += _t3 - _t2
+        t_host += _t2 - _t1
 
         last_step = step == max_new - 1
         new_parents = np.arange(R, dtype=np.int32)
@@ -186,9 +198,11 @@ def beam_search(scorer: StepScorer, prompts: Sequence[Sequence[int]], opts: Sear
             beams[w] = nxt
             if last_step or len(finished[w]) >= max_candidates:
                 done[w] = True
+        t_host += _time.perf_counter() - _t3
         if all(done):
             break
         feed, parents = new_feed, new_parents
+    LAST_TIMING.update(step_s=t_step, score_s=t_score, host_s=t_host, steps=step + 1, rows=R)
 
     results: List[WindowResult] = []
     for w in range(B):

@@ -17,8 +17,7 @@ segments cut at consecutive timestamp pairs.  Beyond the drop-in call, ``transcr
 SAME per-clip procedure for many clips at once (one encoder batch + one batched decode per round),
 which is how the MI355X is kept busy: every VAD group of a scene (or file) becomes one row.
 
-Not implemented (documented in DESIGN.md): sampling temperatures > 0 (the fallback ladder stops at
-its zero-temperature entry), word-level timestamps (``words`` is None).
+Not implemented (documented in DESIGN.md): word-level timestamps (``words`` is None).
 """
 from __future__ import annotations
 
@@ -246,6 +245,8 @@ class HipWhisperModel:
         self.max_batch, self.max_beam = max_batch, max_beam
         self.max_length = dims.n_text_ctx
         self._warned = set()
+        self.seed = 0               # base seed of the device sampler's counter-based generator
+        self._sample_calls = 0
 
     # ---- loading ---------------------------------------------------------------------------
     def _load_checkpoint(self, path: str):
@@ -324,32 +325,75 @@ class HipWhisperModel:
         return prompt
 
     # ---- decoding of one batch of windows ------------------------------------------------------
-    def _decode_windows(self, prompts: List[List[int]], o: TranscribeOptions, suppress: Tuple[int, ...]):
-        """Returns per window (tokens, avg_logprob, no_speech_prob, temperature, compression_ratio)."""
-        from . import engine, search
-        temps = o.temperature if isinstance(o.temperature, (list, tuple)) else [o.temperature]
-        if any(float(x) > 0 for x in temps[1:]) or float(temps[0]) > 0:
-            self._warn_once("temp", "temperature fallback with sampling (temperature > 0) is not implemented on the HIP "
-                                    "path; only the zero-temperature entry is evaluated")
-        P = len(prompts[0])
+    def _max_new(self, o: TranscribeOptions, P: int) -> int:
         if self.FLAVOR == "ow":
             max_new = self.max_length // 2                      # DecodingOptions.sample_len default
             if o.max_new_tokens is not None:
                 max_new = min(max_new, int(o.max_new_tokens))
         else:
             max_new = (self.max_length - P) if o.max_new_tokens is None else int(o.max_new_tokens)
-        max_new = max(1, min(max_new, self.max_length - P))
+        return max(1, min(max_new, self.max_length - P))
+
+    def _rank_score(self, sum_lp: float, n: int, o: TranscribeOptions) -> float:
+        """Hypothesis ranking among ``best_of`` samples: ctranslate2 normalises the cumulative log-prob by
+        ``len ** length_penalty``; whisper's MaximumLikelihoodRanker by the length (or the GNMT penalty)."""
+        n = max(n, 1)
+        lp = o.length_penalty
+        if self.FLAVOR == "ow":
+            return sum_lp / (n if lp is None else ((5 + n) / 6) ** float(lp))
+        return sum_lp / (n ** float(1.0 if lp is None else lp))
+
+    def _decode_once(self, prompts: List[List[int]], slots: List[int], temperature: float, o: TranscribeOptions,
+                     suppress: Tuple[int, ...]) -> List[Tuple[List[int], float, float]]:
+        """One rung of the ladder for the resident windows ``slots``: (tokens, avg_logprob, no_speech_prob) each."""
+        from . import engine, search
+        P = len(prompts[0])
+        max_new = self._max_new(o, P)
         mit = int(round(float(o.max_initial_timestamp) / TIME_PRECISION))
+        n = len(prompts)
+        if temperature > 0:
+            # sampling rung: beam_size -> 1, best_of hypotheses per window drawn on the device
+            best_of = max(1, int(o.best_of or 1))
+            if best_of == 7 or best_of > 8:
+                raise ValueError(f"best_of={best_of}: the device sampler groups 1..6 or 8 samples per window")
+            do = engine.DecodeOptions(max_new_tokens=max_new, suppress_blank=o.suppress_blank,
+                                      without_timestamps=o.without_timestamps, suppress_tokens=suppress,
+                                      max_initial_timestamp=mit * TIME_PRECISION,
+                                      repetition_penalty=float(o.repetition_penalty if self.FLAVOR == "fw" else 1.0),
+                                      no_repeat_ngram_size=int(o.no_repeat_ngram_size if self.FLAVOR == "fw" else 0))
+            cap = max(1, (self.max_batch * self.max_beam) // best_of)
+            out: List[Tuple[List[int], float, float]] = []
+            for c0 in range(0, n, cap):
+                sub = slice(c0, min(n, c0 + cap))
+                self._sample_calls += 1
+                res = self.model.decode_sample(np.array(prompts[sub], dtype=np.int32), do, temperature=temperature,
+                                               best_of=best_of, slots=slots[sub],
+                                               seed=(self.seed + 0x9E3779B1 * self._sample_calls) & 0xFFFFFFFF)
+                for w in range(sub.stop - sub.start):
+                    rows = range(w * best_of, (w + 1) * best_of)
+                    r = max(rows, key=lambda q: self._rank_score(float(res.sum_logprob[q]), int(res.n_tokens[q]), o))
+                    toks = res.tokens[r, : res.n_tokens[r]].tolist()
+                    out.append((toks, float(res.sum_logprob[r]) / (len(toks) + 1), float(res.no_speech_prob[r])))
+            return out
+        if slots != list(range(n)):
+            # a zero-temperature rung after a sampled one (unusual ladder): decode the resident prefix, keep ours
+            hi = max(slots) + 1
+            full = self._decode_once([prompts[slots.index(i)] if i in slots else prompts[0] for i in range(hi)],
+                                     list(range(hi)), temperature, o, suppress)
+            return [full[i] for i in slots]
         beam = int(o.beam_size or 1)
-        greedy = (beam == 1 and float(o.repetition_penalty) == 1.0 and int(o.no_repeat_ngram_size) == 0)
+        device_loop = beam == 1 and (self.FLAVOR == "fw" or (float(o.repetition_penalty) == 1.0
+                                                             and int(o.no_repeat_ngram_size) == 0))
         out = []
-        if greedy:
+        if device_loop:
             res = self.model.decode_greedy(
                 np.array(prompts, dtype=np.int32),
                 engine.DecodeOptions(max_new_tokens=max_new, suppress_blank=o.suppress_blank,
                                      without_timestamps=o.without_timestamps, suppress_tokens=suppress,
-                                     max_initial_timestamp=mit * TIME_PRECISION))
-            for r in range(len(prompts)):
+                                     max_initial_timestamp=mit * TIME_PRECISION,
+                                     repetition_penalty=float(o.repetition_penalty),
+                                     no_repeat_ngram_size=int(o.no_repeat_ngram_size)))
+            for r in range(n):
                 toks = res.tokens[r, : res.n_tokens[r]].tolist()
                 out.append((toks, float(res.sum_logprob[r]) / (len(toks) + 1), float(res.no_speech_prob[r])))
         else:
@@ -365,10 +409,49 @@ class HipWhisperModel:
                          timestamp_begin=self.tokens.timestamp_begin, n_text_ctx=self.max_length)
             for wr in results:
                 out.append((wr.sequences[0], wr.avg_logprob(0), wr.no_speech_prob))
-        final = []
-        for toks, avg_lp, nsp in out:
-            text = self.tokenizer.decode([t for t in toks if t < self.tokens.eot]).strip()
-            final.append((toks, avg_lp, nsp, float(temps[0]), compression_ratio(text)))
+        return out
+
+    def _decode_windows(self, prompts: List[List[int]], o: TranscribeOptions, suppress: Tuple[int, ...]):
+        """Temperature-fallback ladder over the resident windows (faster-whisper ``generate_with_fallback`` /
+        whisper ``decode_with_fallback``): every rung re-decodes only the windows that still need a fallback.
+        Returns per window (tokens, avg_logprob, no_speech_prob, temperature, compression_ratio)."""
+        temps = [float(x) for x in (o.temperature if isinstance(o.temperature, (list, tuple)) else [o.temperature])]
+        n = len(prompts)
+        final: List[Any] = [None] * n
+        tried: List[List[Any]] = [[] for _ in range(n)]        # every rung's result
+        below_cr: List[List[Any]] = [[] for _ in range(n)]     # ... those under the compression-ratio threshold
+        pending = list(range(n))
+        for T in temps:
+            if not pending:
+                break
+            decoded = self._decode_once([prompts[i] for i in pending], pending, T, o, suppress)
+            still = []
+            for i, (toks, avg_lp, nsp) in zip(pending, decoded):
+                text = self.tokenizer.decode([t for t in toks if t < self.tokens.eot]).strip()
+                cr = compression_ratio(text)
+                cand = (toks, avg_lp, nsp, T, cr)
+                tried[i].append(cand)
+                needs_fallback = False
+                if o.compression_ratio_threshold is not None and cr > o.compression_ratio_threshold:
+                    needs_fallback = True                                   # too repetitive
+                else:
+                    below_cr[i].append(cand)
+                if o.log_prob_threshold is not None and avg_lp < o.log_prob_threshold:
+                    needs_fallback = True                                   # average log probability too low
+                if (o.no_speech_threshold is not None and nsp > o.no_speech_threshold
+                        and o.log_prob_threshold is not None and avg_lp < o.log_prob_threshold):
+                    needs_fallback = False                                  # silence
+                if needs_fallback:
+                    still.append(i)
+                else:
+                    final[i] = cand
+            pending = still
+        for i in pending:       # every rung failed
+            if self.FLAVOR == "ow":
+                final[i] = tried[i][-1]                                     # whisper keeps the last rung's result
+            else:
+                best = max(below_cr[i] or tried[i], key=lambda c: c[1])     # faster-whisper: best average log-prob
+                final[i] = (best[0], best[1], best[2], temps[-1], best[4])  # last temperature drives the prompt reset
         return final
 
     # ---- public API ------------------------------------------------------------------------------
