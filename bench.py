@@ -56,7 +56,8 @@ def stage_model(tag, count, ms, dims, B, n_dec, prompt_len, dtype):
         "enc_out_gemm": 2.0 * M * d * d,
         "enc_fc1_gemm": 2.0 * M * 4 * d * d,
         "enc_fc2_gemm": 2.0 * M * 4 * d * d,
-        "cross_kv_gemm": 2.0 * M * 2 * d * d,
+        # bf16: two launches per layer (K head-split, V transposed per head), float32: one fused launch
+        "cross_kv_gemm": 2.0 * M * d * d * (1 if dtype == "bfloat16" else 2),
         "enc_attention": 4.0 * B * H * T * T * 64,
     }
     avg_keys = prompt_len + (n_dec + 1) / 2.0

@@ -238,6 +238,11 @@ int wj_k_attention_enc_timed(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, v
  * k,v float32 [G][H][n_keys][64]; out float32 [G][nb][H*64]. */
 int wj_k_attention_dec(wj_ctx* ctx, int dtype, const float* q_dev, const float* k_dev, const float* v_dev,
                        float* out_dev, int G, int nb, int H, int n_keys, void* stream);
+/* same kernel, `reps` back-to-back launches timed with HIP events; layout 0 = the engine's layout for the dtype
+ * (bf16: V transposed per head, matrix-core kernel), 1 = row-major V with the vector kernel (A/B comparisons) */
+int wj_k_attention_dec_timed(wj_ctx* ctx, int dtype, const float* q_dev, const float* k_dev, const float* v_dev,
+                             float* out_dev, int G, int nb, int H, int n_keys, int layout, int reps,
+                             float* ms_per_launch);
 
 #ifdef __cplusplus
 }

@@ -414,6 +414,143 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
   }
 }
 
+// --------------------------------------------------------------------------------------------
+// decode-step CROSS attention on the matrix cores (bf16).  The VALU kernel above needs ~25 vector
+// instructions per KiB of K/V (bf16->fp32 unpack, FMAs, shuffles, a redundant exp per lane), which
+// at 8 TB/s is as expensive as the HBM stream itself; here a 16-byte load IS an MFMA operand:
+//   pass 1  S[16 keys][beams]   = K tile [16 keys x 64]  . Q^T   (A = K rows as stored, 2 MFMAs / KiB pair)
+//   softmax scores -> LDS (fp32), exact max, P = exp(S - max) -> LDS once per key (bf16) + fp32 row sums
+//   pass 2  O^T[16 d][beams]    = V^T tile [16 d x 32 keys] . P^T (wave w owns output features 16w..16w+15:
+//           it streams 16 contiguous V^T rows and needs no cross-wave reduction)
+// V is therefore kept TRANSPOSED per head ([H][64][vt_stride], zero padded) -- written that way by the
+// cross-K/V GEMM epilogue.  Beams of a window are the MFMA's N columns (up to 16 for free).
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+__device__ __forceinline__ uint32_t scale2_bf16(uint32_t pair, float sc) {
+  const float lo = __uint_as_float(pair << 16) * sc, hi = __uint_as_float(pair & 0xffff0000u) * sc;
+  return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16);
+}
+
+template <int U1, int U2>
+__global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int h = blockIdx.x, gi = blockIdx.y;
+  const int NB = a.nb, n_keys = a.n_keys, kpad = a.vt_stride;
+  float* sc = smem;                                              // [NB][kpad] scores
+  bf16_t* pl = reinterpret_cast<bf16_t*>(sc + NB * kpad);        // [NB][kpad] probabilities
+  float* red_m = reinterpret_cast<float*>(pl + NB * kpad);       // [4][16]
+  float* red_l = red_m + 64;                                     // [4][16]
+  const int D = a.H * 64;
+  const int grp = a.group_of ? a.group_of[gi] : gi;
+  const bf16_t* Kh = reinterpret_cast<const bf16_t*>(a.K) + ((int64_t)grp * a.H + h) * (int64_t)a.kv_stride * 64;
+  const bf16_t* Vh = reinterpret_cast<const bf16_t*>(a.V) + (((int64_t)grp * a.H + h) * 64 + wave * 16 + li) * (int64_t)kpad;
+
+  // B operand of pass 1: Q^T, column = beam (zero beyond NB), pre-scaled by 1/8 (exact in bf16)
+  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+  if (li < NB) {
+    const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)(gi * NB + li) * D + h * 64 + lg * 8;
+    q0 = *reinterpret_cast<const uint4*>(qp);
+    q1 = *reinterpret_cast<const uint4*>(qp + 32);
+    q0.x = scale2_bf16(q0.x, 0.125f); q0.y = scale2_bf16(q0.y, 0.125f); q0.z = scale2_bf16(q0.z, 0.125f); q0.w = scale2_bf16(q0.w, 0.125f);
+    q1.x = scale2_bf16(q1.x, 0.125f); q1.y = scale2_bf16(q1.y, 0.125f); q1.z = scale2_bf16(q1.z, 0.125f); q1.w = scale2_bf16(q1.w, 0.125f);
+  }
+  const bf16x8_t qb0 = as_bf16x8(q0), qb1 = as_bf16x8(q1);
+
+  // ---- pass 1: scores.  Tile t (16 keys) belongs to wave t % 4; U1 tiles are fetched before any is used.
+  const int n_tiles = (n_keys + 15) >> 4;
+  float lmax = -INFINITY;
+  for (int t0 = wave; t0 < n_tiles; t0 += 4 * U1) {
+    uint4 ka[U1][2];
+#pragma unroll
+    for (int u = 0; u < U1; ++u) {
+      const int key = min((t0 + 4 * u) * 16 + li, n_keys - 1);     // clamped, never predicated
+      const bf16_t* kp = Kh + (int64_t)key * 64 + lg * 8;
+      ka[u][0] = *reinterpret_cast<const uint4*>(kp);
+      ka[u][1] = *reinterpret_cast<const uint4*>(kp + 32);
+    }
+#pragma unroll
+    for (int u = 0; u < U1; ++u) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ka[u][0]), qb0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ka[u][1]), qb1, acc, 0, 0, 0);
+      const int kbase = (t0 + 4 * u) * 16 + lg * 4;
+      if (li < NB) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kbase + r < n_keys) {
+            sc[li * kpad + kbase + r] = acc[r];
+            lmax = fmaxf(lmax, acc[r]);
+          }
+      }
+    }
+  }
+  lmax = fmaxf(lmax, __shfl_xor(lmax, 16, 64));
+  lmax = fmaxf(lmax, __shfl_xor(lmax, 32, 64));
+  if (lg == 0) red_m[wave * 16 + li] = lmax;
+  __syncthreads();
+
+  // ---- probabilities, once per (beam, key)
+  for (int b = 0; b < NB; ++b) {
+    const float mx = fmaxf(fmaxf(red_m[b], red_m[16 + b]), fmaxf(red_m[32 + b], red_m[48 + b]));
+    float ls = 0.f;
+    for (int j = tid; j < kpad; j += 256) {
+      const float p = j < n_keys ? __builtin_amdgcn_exp2f((sc[b * kpad + j] - mx) * 1.4426950408889634f) : 0.f;
+      pl[b * kpad + j] = f2bf(p);
+      ls += p;
+    }
+    ls = wave_sum(ls);
+    if (lane == 0) red_l[wave * 16 + b] = ls;
+  }
+  __syncthreads();
+
+  // ---- pass 2: O^T = V^T . P^T, 32 keys per MFMA, U2 chunks in flight
+  const int n_chunks = (n_keys + 31) >> 5;
+  f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+  const bf16_t* prow = pl + li * kpad + lg * 8;
+  for (int c0 = 0; c0 < n_chunks; c0 += U2) {
+    uint4 va[U2];
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+      const int c = min(c0 + u, n_chunks - 1);
+      va[u] = *reinterpret_cast<const uint4*>(Vh + c * 32 + lg * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+      if (c0 + u < n_chunks) {
+        uint4 pb = make_uint4(0, 0, 0, 0);
+        if (li < NB) pb = *reinterpret_cast<const uint4*>(prow + (c0 + u) * 32);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(va[u]), as_bf16x8(pb), o, 0, 0, 0);
+      }
+    }
+  }
+  if (li < NB) {
+    const float l = (red_l[li] + red_l[16 + li]) + (red_l[32 + li] + red_l[48 + li]);
+    const float inv = 1.0f / l;
+    float v[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+    st4(reinterpret_cast<bf16_t*>(a.out) + (int64_t)(gi * NB + li) * D + h * 64 + wave * 16 + lg * 4, v);
+  }
+}
+
+int g_dec_cross_u = 0;   // wj_tune("dec_cross_u"): loads in flight per wave in the MFMA cross-attention kernel
+
+static int launch_cross_mfma(const DecAttnArgs& a, hipStream_t s) {
+  if (a.nb < 1 || a.nb > 16) { set_error("attention_dec: %d query rows per window (1..16)", a.nb); return WJ_E_INVALID; }
+  if (a.vt_stride < a.n_keys || (a.vt_stride & 31)) { set_error("attention_dec: vt_stride %d must be a multiple of 32 >= n_keys %d", a.vt_stride, a.n_keys); return WJ_E_INVALID; }
+  const size_t smem = (size_t)a.nb * a.vt_stride * 6 + 128 * sizeof(float);
+  const dim3 grid(a.H, a.G), block(256);
+  switch (g_dec_cross_u) {
+    case 1: hipLaunchKernelGGL((attn_cross_mfma_kernel<2, 4>), grid, block, smem, s, a); break;
+    case 2: hipLaunchKernelGGL((attn_cross_mfma_kernel<6, 12>), grid, block, smem, s, a); break;
+    case 3: hipLaunchKernelGGL((attn_cross_mfma_kernel<8, 16>), grid, block, smem, s, a); break;
+    default: hipLaunchKernelGGL((attn_cross_mfma_kernel<4, 8>), grid, block, smem, s, a); break;
+  }
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
 template <typename T, int NB, int NW, bool SELF>
 static int launch_dec_inst(const DecAttnArgs& a, int kmax, hipStream_t s) {
   const int kpad = (kmax + 7) & ~7;
@@ -444,6 +581,10 @@ static int launch_dec_T(const DecAttnArgs& a, hipStream_t s) {
 
 int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s) {
   if (a.G <= 0) return WJ_OK;
+  if (a.vt_stride > 0) {
+    if (dtype != WJ_BF16 || a.n_keys_ptr) { set_error("attention_dec: transposed V is the bf16 cross-attention layout"); return WJ_E_INVALID; }
+    return launch_cross_mfma(a, s);
+  }
   return dtype == WJ_F32 ? launch_dec_T<float>(a, s) : launch_dec_T<bf16_t>(a, s);
 }
 

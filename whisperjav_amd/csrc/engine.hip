@@ -87,6 +87,7 @@ struct Tunables {
   int decode_chains = 1;    // concurrent row chains in the greedy loop
   int dec_ks_proj = 4;      // split-K factor of the K = d projections (QKV, cross-q, fc1); 0 = single-pass kernels
   int dec_proj_min_m = 96;  // rows from which those projections go split-K (tile kernel + reduce kernel)
+  int dec_cross_mfma = 1;   // bf16 models: cross V kept transposed, cross attention on the matrix cores (read at create)
 };
 static Tunables g_tune;
 
@@ -115,7 +116,8 @@ struct wj_whisper {
   void* ff = nullptr;         // T   [B*ctx][4d]
   // per-window state kept for decoding
   void* cross_k = nullptr;    // T   [L][max_batch][H][ctx][64]
-  void* cross_v = nullptr;
+  void* cross_v = nullptr;    // same, or (cross_tpad > 0) transposed per head: [L][max_batch][H][64][cross_tpad]
+  int cross_tpad = 0;
   // decoder workspaces
   float* dx = nullptr;        // f32 [R][d]
   void* dh = nullptr;         // T   [R][d]
@@ -152,6 +154,9 @@ struct wj_whisper {
   int enc_base(int l) const { return WJ_T_N_GLOBAL + l * WJ_TE_N; }
   int dec_base(int l) const { return WJ_T_N_GLOBAL + d.n_audio_layer * WJ_TE_N + l * WJ_TD_N; }
   int64_t cross_layer_elems() const { return (int64_t)max_batch * d.n_text_head * d.n_audio_ctx * 64; }
+  int64_t cross_v_layer_elems() const {
+    return (int64_t)max_batch * d.n_text_head * 64 * (cross_tpad > 0 ? cross_tpad : d.n_audio_ctx);
+  }
   int64_t self_layer_elems() const { return (int64_t)max_rows * d.n_text_head * d.n_text_ctx * 64; }
   void* at(void* base, int64_t elems) const { return reinterpret_cast<char*>(base) + elems * (int64_t)esz; }
 };
@@ -251,8 +256,19 @@ static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, flo
     g.W = m->W(b0 + WJ_TD_CKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CKV_B);
     g.M = T; g.N = 2 * D; g.K = D; g.nbatch = B;
     g.out = m->at(m->cross_k, l * m->cross_layer_elems());
-    g.out2 = m->at(m->cross_v, l * m->cross_layer_elems());
+    g.out2 = m->at(m->cross_v, l * m->cross_v_layer_elems());
     g.D = D; g.H = d.n_text_head; g.Tpad = T;
+    if (m->cross_tpad > 0) {   // K head-split as stored; V transposed per head for the MFMA cross attention
+      GemmArgs v = g;
+      g.N = D; g.out2 = nullptr;
+      PROF(PT_E_CKV, launch_gemm(dt, EPI_QK_HEADS, g, s, 1));
+      v.W = reinterpret_cast<const char*>(m->W(b0 + WJ_TD_CKV_W)) + (int64_t)D * D * m->esz;
+      v.bias = m->F(b0 + WJ_TD_CKV_B) + D;
+      v.N = D; v.out = m->at(m->cross_v, l * m->cross_v_layer_elems()); v.out2 = nullptr;
+      v.Tpad = m->cross_tpad;
+      PROF(PT_E_CKV, launch_gemm(dt, EPI_VT, v, s, 1));
+      continue;
+    }
     PROF(PT_E_CKV, launch_gemm(dt, EPI_CKV, g, s, 1));
   }
   return WJ_OK;
@@ -358,7 +374,13 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       a.q = dq;
       const int64_t woff = m->use_slots ? 0 : win0 * cross_win;   // with a slot map the K/V base stays absolute
       a.K = m->at(m->cross_k, l * m->cross_layer_elems() + woff);
-      a.V = m->at(m->cross_v, l * m->cross_layer_elems() + woff);
+      if (m->cross_tpad > 0) {
+        const int64_t vwin = (int64_t)H * 64 * m->cross_tpad;
+        a.V = m->at(m->cross_v, l * m->cross_v_layer_elems() + (m->use_slots ? 0 : win0 * vwin));
+        a.vt_stride = m->cross_tpad;
+      } else {
+        a.V = m->at(m->cross_v, l * m->cross_layer_elems() + woff);
+      }
       a.group_of = m->use_slots ? m->slot_map + win0 : nullptr;
       a.out = dattn; a.G = n_windows; a.nb = beam; a.H = H; a.n_keys = d.n_audio_ctx; a.kv_stride = d.n_audio_ctx;
       PROF(PT_D_CROSS, launch_attention_dec(dt, a, s));
@@ -503,6 +525,8 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "attn_enc_variant")) wj::g_attn_enc_variant = value;
   else if (!strcmp(key, "dec_ks_proj")) g_tune.dec_ks_proj = value;
   else if (!strcmp(key, "dec_proj_min_m")) g_tune.dec_proj_min_m = value;
+  else if (!strcmp(key, "dec_cross_mfma")) g_tune.dec_cross_mfma = value;
+  else if (!strcmp(key, "dec_cross_u")) g_dec_cross_u = value;
   else { set_error("wj_tune: unknown key %s", key); return WJ_E_INVALID; }
   return WJ_OK;
 }
@@ -572,7 +596,8 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   WJ_ALLOC(attn, B * T * D * e, false);
   WJ_ALLOC(ff, B * T * 4 * D * e, false);
   WJ_ALLOC(cross_k, (size_t)d.n_text_layer * m->cross_layer_elems() * e, false);
-  WJ_ALLOC(cross_v, (size_t)d.n_text_layer * m->cross_layer_elems() * e, false);
+  m->cross_tpad = (dtype == WJ_BF16 && g_tune.dec_cross_mfma) ? (d.n_audio_ctx + 31) / 32 * 32 : 0;
+  WJ_ALLOC(cross_v, (size_t)d.n_text_layer * m->cross_v_layer_elems() * e, true);   // pad keys stay zero forever
   WJ_ALLOC(dx, R * D * sizeof(float), false);
   WJ_ALLOC(dh, R * D * e, false);
   WJ_ALLOC(dq, R * D * e, false);
@@ -1000,23 +1025,56 @@ int wj_k_attention_enc_timed(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, v
   return WJ_OK;
 }
 
-int wj_k_attention_dec(wj_ctx* ctx, int dtype, const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev,
-                       int G, int nb, int H, int n_keys, void* stream) {
-  WJ_REQUIRE(ctx && q_dev && k_dev && v_dev && out_dev, "wj_k_attention_dec: NULL argument");
-  WJ_HIP(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->pick(stream);
+// float32 [G][H][n_keys][64] -> bf16 [G][H][64][kp] (pad columns are left as they are: the caller zeroes them)
+__global__ void v_transpose_bf16_kernel(const float* in, bf16_t* out, int64_t n, int n_keys, int kp) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int dd = (int)(i & 63);
+    const int64_t t = i >> 6;
+    const int key = (int)(t % n_keys);
+    const int64_t gh = t / n_keys;
+    out[(gh * 64 + dd) * kp + key] = f2bf(in[i]);
+  }
+}
+
+static int attention_dec_common(wj_ctx* ctx, int dtype, const float* q_dev, const float* k_dev, const float* v_dev,
+                                float* out_dev, int G, int nb, int H, int n_keys, int layout, int reps, float* ms,
+                                hipStream_t s) {
   const size_t esz = dtype == WJ_BF16 ? 2 : 4;
-  const int64_t nq = (int64_t)G * nb * H * 64, nkv = (int64_t)G * H * n_keys * 64;
-  const size_t bq = align_up(nq * esz, 256), bkv = align_up(nkv * esz, 256);
-  WJ_TRY(ctx->ensure_scratch(2 * bq + 2 * bkv));
+  const bool vt = dtype == WJ_BF16 && layout != 1;   // the engine's bf16 layout: V transposed, MFMA kernel
+  const int kp = (n_keys + 31) / 32 * 32;
+  const int64_t nq = (int64_t)G * nb * H * 64, nkv = (int64_t)G * H * n_keys * 64, nvt = (int64_t)G * H * 64 * kp;
+  const size_t bq = align_up(nq * esz, 256), bk = align_up(nkv * esz, 256), bv = align_up((vt ? nvt : nkv) * esz, 256);
+  WJ_TRY(ctx->ensure_scratch(2 * bq + bk + bv));
   char* base = reinterpret_cast<char*>(ctx->scratch);
-  void *tq = base, *tk = base + bq, *tv = base + bq + bkv, *to = base + bq + 2 * bkv;
+  void *tq = base, *tk = base + bq, *tv = base + bq + bk, *to = base + bq + bk + bv;
   WJ_TRY(launch_f32_to_T(dtype, q_dev, tq, nq, s));
   WJ_TRY(launch_f32_to_T(dtype, k_dev, tk, nkv, s));
-  WJ_TRY(launch_f32_to_T(dtype, v_dev, tv, nkv, s));
+  if (vt) {
+    WJ_HIP(hipMemsetAsync(tv, 0, bv, s));
+    hipLaunchKernelGGL(v_transpose_bf16_kernel, dim3((unsigned)min((int64_t)4096, ceil_div64(nkv, 256))), dim3(256), 0, s,
+                       v_dev, reinterpret_cast<bf16_t*>(tv), nkv, n_keys, kp);
+    WJ_LAUNCH_CHECK();
+  } else {
+    WJ_TRY(launch_f32_to_T(dtype, v_dev, tv, nkv, s));
+  }
   DecAttnArgs a;
   a.q = tq; a.K = tk; a.V = tv; a.out = to; a.G = G; a.nb = nb; a.H = H; a.n_keys = n_keys; a.kv_stride = n_keys;
+  a.vt_stride = vt ? kp : 0;
   WJ_TRY(launch_attention_dec(dtype, a, s));
+  if (reps > 0) {
+    hipEvent_t e0, e1;
+    WJ_HIP(hipEventCreate(&e0)); WJ_HIP(hipEventCreate(&e1));
+    WJ_HIP(hipEventRecord(e0, s));
+    int rc = WJ_OK;
+    for (int i = 0; i < reps && rc == WJ_OK; ++i) rc = launch_attention_dec(dtype, a, s);
+    WJ_HIP(hipEventRecord(e1, s));
+    WJ_HIP(hipEventSynchronize(e1));
+    float t = 0.f;
+    WJ_HIP(hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc != WJ_OK) return rc;
+    if (ms) *ms = t / reps;
+  }
   const int blocks = (int)min((int64_t)1024, ceil_div64(nq, 256));
   if (dtype == WJ_F32)
     hipLaunchKernelGGL(T_to_f32_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)to, out_dev, nq);
@@ -1024,6 +1082,21 @@ int wj_k_attention_dec(wj_ctx* ctx, int dtype, const float* q_dev, const float* 
     hipLaunchKernelGGL(T_to_f32_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)to, out_dev, nq);
   WJ_LAUNCH_CHECK();
   return WJ_OK;
+}
+
+int wj_k_attention_dec(wj_ctx* ctx, int dtype, const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev,
+                       int G, int nb, int H, int n_keys, void* stream) {
+  WJ_REQUIRE(ctx && q_dev && k_dev && v_dev && out_dev, "wj_k_attention_dec: NULL argument");
+  WJ_HIP(hipSetDevice(ctx->device));
+  return attention_dec_common(ctx, dtype, q_dev, k_dev, v_dev, out_dev, G, nb, H, n_keys, 0, 0, nullptr, ctx->pick(stream));
+}
+
+int wj_k_attention_dec_timed(wj_ctx* ctx, int dtype, const float* q_dev, const float* k_dev, const float* v_dev,
+                             float* out_dev, int G, int nb, int H, int n_keys, int layout, int reps, float* ms_per_launch) {
+  WJ_REQUIRE(ctx && q_dev && k_dev && v_dev && out_dev && ms_per_launch && reps > 0, "wj_k_attention_dec_timed: bad argument");
+  WJ_HIP(hipSetDevice(ctx->device));
+  return attention_dec_common(ctx, dtype, q_dev, k_dev, v_dev, out_dev, G, nb, H, n_keys, layout, reps, ms_per_launch,
+                              ctx->pick(nullptr));
 }
 
 }  // extern "C"

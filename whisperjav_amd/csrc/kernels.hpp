@@ -79,7 +79,9 @@ struct DecAttnArgs {
   int kv_stride = 0;                 // positions allocated per (group, head)
   const int32_t* row_map = nullptr;  // [G][kv_stride]
   const int32_t* group_of = nullptr; // [G] window slot per group (cross attention), NULL = identity
+  int vt_stride = 0;                 // > 0: bf16 cross attention on the matrix cores; V is [group][H][64][vt_stride]
 };
+extern int g_dec_cross_u;
 int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s);
 
 // ---------------- sampling -----------------------------------------------------------------------

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Union
+from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -374,3 +374,21 @@ def k_attention_dec(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dtype: st
                                  _ptr(v.contiguous()), _ptr(out), G, nb, H, n_keys, None), "wj_k_attention_dec")
     ctx.sync()
     return out
+
+
+def k_attention_dec_timed(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dtype: str, layout: int = 0, reps: int = 20,
+                          device: int = 0) -> Tuple[torch.Tensor, float]:
+    """As ``k_attention_dec`` plus the mean milliseconds per launch over ``reps`` back-to-back launches.
+    ``layout`` 0 = the engine's layout for the dtype, 1 = row-major V with the vector kernel."""
+    ctx = hipbind.context(device)
+    lib = hipbind.lib()
+    G, nb, D = q.shape
+    H, n_keys = k.shape[1], k.shape[2]
+    out = torch.empty((G, nb, D), dtype=torch.float32, device=q.device)
+    ms = C.c_float(0.0)
+    _torch_sync()
+    check(lib.wj_k_attention_dec_timed(ctx.handle, DTYPES[dtype], _ptr(q.contiguous()), _ptr(k.contiguous()),
+                                       _ptr(v.contiguous()), _ptr(out), G, nb, H, n_keys, int(layout), int(reps),
+                                       C.byref(ms)), "wj_k_attention_dec_timed")
+    ctx.sync()
+    return out, float(ms.value)

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "wj_k_attention_enc": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
     "wj_k_attention_enc_timed": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, C.POINTER(_F)]),
     "wj_k_attention_dec": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "wj_k_attention_dec_timed": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
