@@ -202,7 +202,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=128, help="30 s windows per GPU per step")
+    ap.add_argument("--batch", type=int, default=384, help="30 s windows per GPU per step (384: 133 GiB of workspace, cross K/V resident)")
     ap.add_argument("--decode-tokens", type=int, default=224, help="new tokens per window (n_text_ctx // 2)")
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])

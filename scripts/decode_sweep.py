@@ -18,25 +18,24 @@ toks = model.tokens
 suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
 opts = engine.DecodeOptions(max_new_tokens=TOK, suppress_tokens=suppress, max_initial_timestamp=1.0)
 rows = []
-# (batch, ks_attn, ks_fc2, tile_min_m, ks_proj, proj_min_m)
-configs = [(64, 4, 8, 128, 0, 96), (64, 4, 8, 128, 4, 64), (64, 4, 8, 64, 4, 64), (64, 4, 8, 64, 0, 96),
-           (128, 4, 8, 128, 0, 96), (128, 4, 8, 128, 2, 96), (128, 4, 8, 128, 4, 96), (128, 4, 8, 128, 5, 96)]
+# (batch, dec_rows, rows_ks_attn, rows_ks_fc2)
+configs = [(128, 0, 2, 8), (128, 1, 1, 8), (128, 1, 2, 8), (128, 1, 4, 8), (128, 1, 2, 4), (128, 1, 4, 16),
+           (64, 0, 2, 8), (64, 1, 2, 8), (64, 1, 4, 8), (16, 0, 2, 8), (16, 1, 2, 8), (16, 1, 4, 8)]
 ref_tokens = {}
-for B, ka, kf, tm, kp, pm in configs:
-    hipbind.tune("dec_ks_attn", ka); hipbind.tune("dec_ks_fc2", kf); hipbind.tune("dec_tile_min_m", tm)
-    hipbind.tune("dec_ks_proj", kp); hipbind.tune("dec_proj_min_m", pm)
+for B, dr, ka, kf in configs:
+    hipbind.tune("dec_rows", dr); hipbind.tune("dec_rows_ks_attn", ka); hipbind.tune("dec_rows_ks_fc2", kf)
     prompt = np.tile(np.array(model.sot_prompt("ja"), dtype=np.int32), (B, 1))
     model.decode_greedy(prompt, engine.DecodeOptions(max_new_tokens=4, suppress_tokens=suppress))   # warm
     best = 1e9
     for _ in range(2):
         t0 = time.perf_counter(); res = model.decode_greedy(prompt, opts); best = min(best, time.perf_counter() - t0)
-    key = B
     same = None
-    if key in ref_tokens:
-        same = float((res.tokens == ref_tokens[key]).mean())
+    if B in ref_tokens:
+        same = float((res.tokens == ref_tokens[B]).mean())
     else:
-        ref_tokens[key] = res.tokens.copy()
-    rows.append({"B": B, "ks_attn": ka, "ks_fc2": kf, "tile_min_m": tm, "ks_proj": kp, "proj_min_m": pm, "ms_per_step": round(1e3 * best / (TOK + 2), 3),
+        ref_tokens[B] = res.tokens.copy()
+    rows.append({"B": B, "dec_rows": dr, "rows_ks_attn": ka, "rows_ks_fc2": kf, "ms_per_step": round(1e3 * best / (TOK + 2), 3),
                  "token_agreement_vs_first_config": same})
     print(rows[-1], flush=True)
+hipbind.tune("dec_rows", 1); hipbind.tune("dec_rows_ks_attn", 2); hipbind.tune("dec_rows_ks_fc2", 8)
 json.dump(rows, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "decode_sweep.json"), "w"), indent=1)

@@ -87,6 +87,10 @@ struct Tunables {
   int decode_chains = 1;    // concurrent row chains in the greedy loop
   int dec_ks_proj = 4;      // split-K factor of the K = d projections (QKV, cross-q, fc1); 0 = single-pass kernels
   int dec_proj_min_m = 96;  // rows from which those projections go split-K (tile kernel + reduce kernel)
+  int dec_rows = 1;         // decode GEMMs with <= dec_rows_max_m rows use the one-wave-per-row-block kernel
+  int dec_rows_max_m = 32;   // measured: faster than the alternatives up to ~32 rows, slower from 64 (vector-L1 line rate)
+  int dec_rows_ks_attn = 2; // its split-K factors for the residual projections (K = d) and fc2 (K = 4d)
+  int dec_rows_ks_fc2 = 8;
   int dec_cross_mfma = 1;   // bf16 models: cross V kept transposed, cross attention on the matrix cores (read at create)
 };
 static Tunables g_tune;
@@ -296,7 +300,9 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   // Residual-writing GEMMs (attention out-projections, fc2) can run split-K: each K slice writes a raw fp32
   // slab and the LayerNorm that always follows folds  x += bias + sum(slabs)  in a fixed order (deterministic).
   // This keeps the per-workgroup A traffic at M*K/ksplit and multiplies the number of workgroups streaming W.
-  const int ks_attn = g_tune.dec_ks_attn, ks_fc2 = g_tune.dec_ks_fc2, tile_min_m = g_tune.dec_tile_min_m;
+  const bool rows = dt == WJ_BF16 && g_tune.dec_rows && R <= g_tune.dec_rows_max_m;
+  const int ks_attn = rows ? g_tune.dec_rows_ks_attn : g_tune.dec_ks_attn;
+  const int ks_fc2 = rows ? g_tune.dec_rows_ks_fc2 : g_tune.dec_ks_fc2, tile_min_m = g_tune.dec_tile_min_m;
   float* slab = m->partial + (int64_t)row0 * kDecKsMax * D;
   int pend_ks = 0;
   const float* pend_bias = nullptr;
@@ -306,11 +312,11 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     if (dt == WJ_BF16 && ks > 1 && ks <= kDecKsMax && K % (64 * ks) == 0) {
       g.out = slab; g.ksplit = ks;
       pend_ks = ks; pend_bias = bias;
-      const int variant = (tile_min_m > 0 && R >= tile_min_m) ? 3 : 2;
+      const int variant = rows ? 5 : ((tile_min_m > 0 && R >= tile_min_m) ? 3 : 2);
       PROF(tag, launch_gemm(dt, EPI_PARTIAL_F32, g, s, variant));
     } else {
       g.bias = bias; g.out = dx;
-      PROF(tag, launch_gemm(dt, EPI_RESID_F32, g, s));
+      PROF(tag, launch_gemm(dt, EPI_RESID_F32, g, s, rows ? 5 : 0));
     }
     return WJ_OK;
   };
@@ -318,7 +324,9 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   // kernel + one reduce kernel that applies the very same epilogue
   auto proj_gemm = [&](int tag, Epi epi, GemmArgs& g) -> int {
     const int ks = g_tune.dec_ks_proj;
-    if (dt == WJ_BF16 && ks > 1 && R >= g_tune.dec_proj_min_m && (int64_t)ks * g.N <= (int64_t)kDecKsMax * D &&
+    if (rows) {
+      PROF(tag, launch_gemm(dt, epi, g, s, 5));
+    } else if (dt == WJ_BF16 && ks > 1 && R >= g_tune.dec_proj_min_m && (int64_t)ks * g.N <= (int64_t)kDecKsMax * D &&
         g.K % (64 * ks) == 0 && !pend_ks) {
       GemmArgs p = g;
       p.out = slab; p.ldc = g.N; p.ksplit = ks; p.bias = nullptr;
@@ -400,7 +408,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     GemmArgs g;
     g.A = dh; g.lda = D; g.W = m->W(WJ_T_DEC_TOK_EMB); g.ldw = D;
     g.M = R; g.N = d.n_vocab; g.K = D; g.out = m->logits + (int64_t)row0 * m->ldl; g.ldc = m->ldl;
-    PROF(PT_D_LOGITS, launch_gemm(dt, EPI_F32, g, s));
+    PROF(PT_D_LOGITS, launch_gemm(dt, EPI_F32, g, s, rows ? 5 : 0));
   }
   return WJ_OK;
 }
@@ -526,6 +534,10 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_ks_proj")) g_tune.dec_ks_proj = value;
   else if (!strcmp(key, "dec_proj_min_m")) g_tune.dec_proj_min_m = value;
   else if (!strcmp(key, "dec_cross_mfma")) g_tune.dec_cross_mfma = value;
+  else if (!strcmp(key, "dec_rows")) g_tune.dec_rows = value;
+  else if (!strcmp(key, "dec_rows_max_m")) g_tune.dec_rows_max_m = value;
+  else if (!strcmp(key, "dec_rows_ks_attn")) g_tune.dec_rows_ks_attn = value;
+  else if (!strcmp(key, "dec_rows_ks_fc2")) g_tune.dec_rows_ks_fc2 = value;
   else if (!strcmp(key, "dec_cross_u")) g_dec_cross_u = value;
   else { set_error("wj_tune: unknown key %s", key); return WJ_E_INVALID; }
   return WJ_OK;

@@ -328,6 +328,83 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(const GemmArgs g)
 }
 
 // --------------------------------------------------------------------------------------------
+// bf16 MFMA, "rows" (decode) kernel: 16 output columns per workgroup, ONE WAVE PER 16-ROW BLOCK.
+// No LDS, no barrier, no cross-wave reduction: a wave owns a 16x16 output tile, both MFMA operands are
+// 16-byte loads straight from L2/HBM, and UNR k-steps (2 A + 2 W loads each) are requested before the
+// first MFMA -- with K (or the K slice) <= 640 the whole operand stream of a wave is ONE round trip.
+// The waves of a workgroup share the W fragments through the CU's vector L1; every workgroup re-reads A
+// (M x K bf16, L2 resident).  Latency, not bandwidth, bounds a decode-step GEMM (M <= ~200 rows against
+// 3-13 MB of weights): what matters is the number of dependent memory round trips per wave and the
+// number of launches, which is what this kernel minimises.  blockIdx.y = K slice (EPI_PARTIAL_F32),
+// blockIdx.z = group of 8 row blocks.
+// --------------------------------------------------------------------------------------------
+template <int EPI, int UNR>
+__global__ __launch_bounds__(512) void gemm_bf16_rows_kernel(const GemmArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int m0 = (blockIdx.z * 8 + wave) * 16;
+  if (m0 >= g.M) return;
+  const int kz = (EPI == EPI_PARTIAL_F32) ? blockIdx.y : 0;
+  const int kslice = (EPI == EPI_PARTIAL_F32) ? g.K / g.ksplit : g.K;
+  const int kb = kz * kslice, ke = kb + kslice;
+  const bf16_t* __restrict__ Ap = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)min(m0 + li, g.M - 1) * g.lda + lg * 8;
+  const bf16_t* __restrict__ Wp = reinterpret_cast<const bf16_t*>(g.W) + (int64_t)min(n0 + li, g.N - 1) * g.ldw + lg * 8;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = kb; k0 < ke; k0 += 64 * UNR) {
+    uint4 av[UNR][2], wv[UNR][2];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int k = min(k0 + 64 * u, ke - 64);     // clamped (never predicated); surplus steps are skipped below
+      wv[u][0] = *reinterpret_cast<const uint4*>(Wp + k);
+      wv[u][1] = *reinterpret_cast<const uint4*>(Wp + k + 32);
+      av[u][0] = *reinterpret_cast<const uint4*>(Ap + k);
+      av[u][1] = *reinterpret_cast<const uint4*>(Ap + k + 32);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (k0 + 64 * u < ke) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[u][0]),
+                                                      __builtin_bit_cast(bf16x8_t, av[u][0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[u][1]),
+                                                      __builtin_bit_cast(bf16x8_t, av[u][1]), acc, 0, 0, 0);
+      }
+    }
+  }
+  const int m = m0 + li, n = n0 + lg * 4;
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+  if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, kz, m, n, v);
+}
+
+template <int EPI>
+static int launch_rows(const GemmArgs& a, hipStream_t s, int unr) {
+  if constexpr (EPI == EPI_T || EPI == EPI_GELU_T || EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_DEC ||
+                EPI == EPI_PARTIAL_F32) {
+    const int ks = EPI == EPI_PARTIAL_F32 ? a.ksplit : 1;
+    if (a.nbatch != 1 || (a.K % (64 * ks))) {
+      set_error("gemm: the rows kernel needs nbatch == 1 and K %% (64 * ksplit) == 0 (K=%d ksplit=%d)", a.K, ks);
+      return WJ_E_INVALID;
+    }
+    const int steps = a.K / ks / 64;
+    if (unr <= 0) unr = steps % 10 == 0 ? 10 : (steps % 5 == 0 ? 5 : (steps >= 8 ? 8 : 4));
+    const dim3 grid(ceil_div(a.N, 16), ks, ceil_div(a.M, 128));
+    const dim3 block(64 * min(8, ceil_div(a.M, 16)));
+    switch (unr) {
+      case 4: hipLaunchKernelGGL((gemm_bf16_rows_kernel<EPI, 4>), grid, block, 0, s, a); break;
+      case 5: hipLaunchKernelGGL((gemm_bf16_rows_kernel<EPI, 5>), grid, block, 0, s, a); break;
+      case 8: hipLaunchKernelGGL((gemm_bf16_rows_kernel<EPI, 8>), grid, block, 0, s, a); break;
+      case 10: hipLaunchKernelGGL((gemm_bf16_rows_kernel<EPI, 10>), grid, block, 0, s, a); break;
+      default: set_error("gemm: rows kernel unroll %d not instantiated (4, 5, 8, 10)", unr); return WJ_E_INVALID;
+    }
+    WJ_LAUNCH_CHECK();
+    return WJ_OK;
+  } else {
+    set_error("gemm: the rows kernel does not carry epilogue %d", (int)EPI);
+    return WJ_E_INVALID;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
 // fp32 VALU kernel (parity compute type)
 // --------------------------------------------------------------------------------------------
 template <int EPI>
@@ -445,6 +522,7 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
     WJ_LAUNCH_CHECK();
     return WJ_OK;
   }
+  if (variant == 5 || (variant >= 50 && variant < 70)) return launch_rows<EPI>(a, s, variant == 5 ? 0 : variant - 50);
   const bool skinny_ok = (EPI != EPI_VT) && a.nbatch == 1;
   bool skinny = skinny_ok && a.M <= 512;
   if (variant == 1 || variant == 3 || variant == 4) skinny = false;
