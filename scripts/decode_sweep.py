@@ -8,7 +8,7 @@ from whisperjav_amd import dims as pdims, engine, hipbind, weights as pweights
 TOK = int(os.environ.get("SWEEP_TOKENS", "48"))
 dims = pdims.dims_for("large-v3")
 w = pweights.synth_weights(dims, seed=1234)
-BMAX = 128
+BMAX = int(os.environ.get('SWEEP_BMAX', '384'))
 model = engine.HipWhisper(dims, w, dtype="bfloat16", max_batch=BMAX)
 del w
 g = torch.Generator(device="cuda").manual_seed(1)
@@ -18,12 +18,12 @@ toks = model.tokens
 suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
 opts = engine.DecodeOptions(max_new_tokens=TOK, suppress_tokens=suppress, max_initial_timestamp=1.0)
 rows = []
-# (batch, dec_rows, rows_ks_attn, rows_ks_fc2)
-configs = [(128, 0, 2, 8), (128, 1, 1, 8), (128, 1, 2, 8), (128, 1, 4, 8), (128, 1, 2, 4), (128, 1, 4, 16),
-           (64, 0, 2, 8), (64, 1, 2, 8), (64, 1, 4, 8), (16, 0, 2, 8), (16, 1, 2, 8), (16, 1, 4, 8)]
+# (batch, dec_fuse_reduce, ks_proj)
+configs = [(128, 0, 4), (128, 1, 4), (128, 1, 2), (128, 1, 5), (384, 0, 4), (384, 1, 4), (384, 1, 2), (384, 1, 5),
+           (96, 0, 4), (96, 1, 4)]
 ref_tokens = {}
-for B, dr, ka, kf in configs:
-    hipbind.tune("dec_rows", dr); hipbind.tune("dec_rows_ks_attn", ka); hipbind.tune("dec_rows_ks_fc2", kf)
+for B, fr, kp in configs:
+    hipbind.tune("dec_fuse_reduce", fr); hipbind.tune("dec_ks_proj", kp)
     prompt = np.tile(np.array(model.sot_prompt("ja"), dtype=np.int32), (B, 1))
     model.decode_greedy(prompt, engine.DecodeOptions(max_new_tokens=4, suppress_tokens=suppress))   # warm
     best = 1e9
@@ -32,10 +32,11 @@ for B, dr, ka, kf in configs:
     same = None
     if B in ref_tokens:
         same = float((res.tokens == ref_tokens[B]).mean())
+        lp_same = bool(np.array_equal(res.sum_logprob, ref_lp[B]))
     else:
-        ref_tokens[B] = res.tokens.copy()
-    rows.append({"B": B, "dec_rows": dr, "rows_ks_attn": ka, "rows_ks_fc2": kf, "ms_per_step": round(1e3 * best / (TOK + 2), 3),
-                 "token_agreement_vs_first_config": same})
+        ref_tokens[B] = res.tokens.copy(); ref_lp = dict(globals().get("ref_lp", {})); ref_lp[B] = res.sum_logprob.copy(); lp_same = None
+    rows.append({"B": B, "fuse_reduce": fr, "ks_proj": kp, "ms_per_step": round(1e3 * best / (TOK + 2), 3),
+                 "token_agreement_vs_first_config": same, "sum_logprob_bit_identical": lp_same})
     print(rows[-1], flush=True)
-hipbind.tune("dec_rows", 1); hipbind.tune("dec_rows_ks_attn", 2); hipbind.tune("dec_rows_ks_fc2", 8)
+hipbind.tune("dec_fuse_reduce", 1); hipbind.tune("dec_ks_proj", 4)
 json.dump(rows, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "decode_sweep.json"), "w"), indent=1)

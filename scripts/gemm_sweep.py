@@ -6,12 +6,11 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from whisperjav_amd import engine
 
-SHAPES = [("enc_qk", 24000, 2560, 1280), ("enc_out", 24000, 1280, 1280), ("enc_fc1", 24000, 5120, 1280),
-          ("enc_fc2", 24000, 1280, 5120), ("cube4096", 4096, 4096, 4096), ("dec_fc1_m64", 64, 5120, 1280),
-          ("dec_out_m64", 64, 1280, 1280)]
+SHAPES = [("enc_qk", 96000, 2560, 1280), ("enc_out", 96000, 1280, 1280), ("enc_fc1", 96000, 5120, 1280),
+          ("enc_fc2", 96000, 1280, 5120), ("cube4096", 4096, 4096, 4096), ("cube8192", 8192, 8192, 8192)]
 rows = []
 for name, M, N, K in SHAPES:
-    for variant, label in ((4, "reg"), (3, "glds"), (2, "skinny")):
+    for variant, label in ((3, "glds"), (6, "big256")):
         if label == "skinny" and M > 512:
             continue
         if label != "skinny" and M <= 512:

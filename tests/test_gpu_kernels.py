@@ -37,19 +37,22 @@ GEMM_SHAPES = [
     (64, 1280, 1280),    # decode-sized
     (5, 1003, 128),      # N not a multiple of 4 (logits path, f32 out)
     (320, 512, 640),     # beam-sized M
+    (1100, 256, 192),    # 256-tile kernel with an M tail
 ]
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
-@pytest.mark.parametrize("variant", [4, 2, 3, 5, 54])
+@pytest.mark.parametrize("variant", [4, 2, 3, 5, 54, 6, 7, 73, 75])
 def test_gemm(hip, dtype, shape, variant):
     from whisperjav_amd import engine
     M, N, K = shape
     if dtype == "float32" and variant != 4:
         pytest.skip("the fp32 compute type has a single GEMM kernel")
-    if variant in (3, 5, 54) and K % 64:
-        pytest.skip("the LDS-DMA tile kernel and the rows kernel need K % 64 == 0")
+    if variant in (3, 5, 54, 6, 7, 73, 75) and K % 64:
+        pytest.skip("the LDS-DMA tile kernels and the rows kernel need K % 64 == 0")
+    if variant == 6 and (N % 256 or M < 1024):
+        pytest.skip("the 256-tile kernel takes N % 256 == 0, M >= 1024")
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     a = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) * 0.3 + 0.05

@@ -295,12 +295,55 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
   const int32_t* rmap = (SELF && a.row_map) ? a.row_map + (int64_t)gi * a.kv_stride : nullptr;
 
   float qf[NB][8];
+  float knew[8], vnew[8];          // fused mode: the newest position's k / v (this lane's 8-feature chunk)
+  bool fused = false;
+  if constexpr (SELF && NB == 1 && sizeof(T) == 2) fused = a.slab != nullptr;
+  if (fused) {
+    const int64_t col = h * 64 + c * 8;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    ld8(reinterpret_cast<const T*>(a.q) + (int64_t)(gi * NB + b) * D + h * 64 + c * 8, qf[b]);
+    for (int e = 0; e < 8; ++e) { qf[0][e] = 0.f; knew[e] = 0.f; vnew[e] = 0.f; }
+    for (int sl = 0; sl < a.slab_ks; ++sl) {
+      const float* sp = a.slab + ((int64_t)sl * a.slab_rows + gi) * a.slab_ld + col;
+      float t0[8], t1[8], t2[8];
+      ld8(sp, t0);
+      ld8(sp + D, t1);
+      ld8(sp + 2 * D, t2);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qf[b][e] *= 0.125f;
+      for (int e = 0; e < 8; ++e) { qf[0][e] += t0[e]; knew[e] += t1[e]; vnew[e] += t2[e]; }
+    }
+    {   // slices first, bias last: the order of the stand-alone reduce kernel (bit-identical results)
+      float b0[8], b1[8], b2[8];
+      ld8(a.slab_bias + col, b0);
+      ld8(a.slab_bias + D + col, b1);
+      ld8(a.slab_bias + 2 * D + col, b2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qf[0][e] += b0[e]; knew[e] += b1[e]; vnew[e] += b2[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {   // the projection epilogue rounds q, k, v to the cache dtype
+      qf[0][e] = bf2f(f2bf(qf[0][e])) * 0.125f;
+      knew[e] = bf2f(f2bf(knew[e]));
+      vnew[e] = bf2f(f2bf(vnew[e]));
+    }
+    if (kk == 0) {                  // append to the cache for the steps to come
+      const int64_t off = (((int64_t)(a.row_base + gi) * a.H + h) * a.kv_stride + (n_keys - 1)) * 64 + c * 8;
+      float k4[4] = {knew[0], knew[1], knew[2], knew[3]}, k5[4] = {knew[4], knew[5], knew[6], knew[7]};
+      float v4[4] = {vnew[0], vnew[1], vnew[2], vnew[3]}, v5[4] = {vnew[4], vnew[5], vnew[6], vnew[7]};
+      T* kc = const_cast<T*>(Kb) + off;
+      T* vc = const_cast<T*>(Vb) + off;
+      st4(kc, k4); st4(kc + 4, k5);
+      st4(vc, v4); st4(vc + 4, v5);
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      ld8(reinterpret_cast<const T*>(a.q) + (int64_t)(gi * NB + b) * D + h * 64 + c * 8, qf[b]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[b][e] *= 0.125f;
+    }
   }
+  // fused mode reads positions < n_old from the cache and takes the newest one from registers
+  const int n_old = fused ? n_keys - 1 : n_keys;
 
   // Addresses are clamped to the last valid key instead of predicating the loads (a predicated
   // load makes the compiler select between a global and a stack pointer -> flat loads); U key octets
@@ -311,18 +354,18 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
 #pragma unroll
   for (int b = 0; b < NB; ++b) lmax[b] = -INFINITY;
 
-  for (int j0 = wave * 8; j0 < n_keys; j0 += NW * 8 * U) {
+  for (int j0 = wave * 8; j0 < n_old; j0 += NW * 8 * U) {
     float kv[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int j = min(j0 + u * NW * 8 + kk, n_keys - 1);
+      const int j = min(j0 + u * NW * 8 + kk, n_old - 1);
       const int64_t prow = SELF ? (rmap ? rmap[j] : gi) : grp;
       ld8(Kb + ((prow * a.H + h) * a.kv_stride + j) * 64 + c * 8, kv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = j0 + u * NW * 8 + kk;
-      const bool valid = j < n_keys;
+      const bool valid = j < n_old;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         float s = 0.f;
@@ -337,6 +380,15 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
         }
       }
     }
+  }
+  float s_new = 0.f;
+  if (fused) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_new = fmaf(qf[0][e], knew[e], s_new);
+    s_new += __shfl_xor(s_new, 1, 64);
+    s_new += __shfl_xor(s_new, 2, 64);
+    s_new += __shfl_xor(s_new, 4, 64);
+    lmax[0] = fmaxf(lmax[0], s_new);
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -363,19 +415,25 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[b][e] = 0.f;
   }
-  for (int j0 = wave * 8; j0 < n_keys; j0 += NW * 8 * U) {
+  if (fused && kk == 0 && wave == 0) {
+    const float p = expf(s_new - mx[0]);
+    lsum[0] = p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[0][e] = p * vnew[e];
+  }
+  for (int j0 = wave * 8; j0 < n_old; j0 += NW * 8 * U) {
     float vv[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int j = min(j0 + u * NW * 8 + kk, n_keys - 1);
+      const int j = min(j0 + u * NW * 8 + kk, n_old - 1);
       const int64_t prow = SELF ? (rmap ? rmap[j] : gi) : grp;
       ld8(Vb + ((prow * a.H + h) * a.kv_stride + j) * 64 + c * 8, vv[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = j0 + u * NW * 8 + kk;
-      const bool valid = j < n_keys;
-      const int jc = min(j, n_keys - 1);
+      const bool valid = j < n_old;
+      const int jc = min(j, n_old - 1);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const float p = valid ? expf(sc[b * kpad + jc] - mx[b]) : 0.f;
@@ -450,10 +508,34 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
 
   // B operand of pass 1: Q^T, column = beam (zero beyond NB), pre-scaled by 1/8 (exact in bf16)
   uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
-  if (li < NB) {
+  if (li < NB && a.slab) {
+    // q = bf16(bias + sum of the projection's K-slices), same rounding point as the unfused epilogue
+    const int64_t col = h * 64 + lg * 8;
+    float s0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < a.slab_ks; ++sl) {
+      const float* sp = a.slab + ((int64_t)sl * a.slab_rows + (gi * NB + li)) * a.slab_ld + col;
+      float t0[8], t1[8];
+      ld8(sp, t0);
+      ld8(sp + 32, t1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s0[e] += t0[e]; s1[e] += t1[e]; }
+    }
+    {   // slices first, bias last: the order of the stand-alone reduce kernel (bit-identical results)
+      float b0[8], b1[8];
+      ld8(a.slab_bias + col, b0);
+      ld8(a.slab_bias + col + 32, b1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s0[e] += b0[e]; s1[e] += b1[e]; }
+    }
+    auto pack = [](float lo, float hi) { return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16); };
+    q0 = make_uint4(pack(s0[0], s0[1]), pack(s0[2], s0[3]), pack(s0[4], s0[5]), pack(s0[6], s0[7]));
+    q1 = make_uint4(pack(s1[0], s1[1]), pack(s1[2], s1[3]), pack(s1[4], s1[5]), pack(s1[6], s1[7]));
+  } else if (li < NB) {
     const bf16_t* qp = reinterpret_cast<const bf16_t*>(a.q) + (int64_t)(gi * NB + li) * D + h * 64 + lg * 8;
     q0 = *reinterpret_cast<const uint4*>(qp);
     q1 = *reinterpret_cast<const uint4*>(qp + 32);
+  }
+  if (li < NB) {
     q0.x = scale2_bf16(q0.x, 0.125f); q0.y = scale2_bf16(q0.y, 0.125f); q0.z = scale2_bf16(q0.z, 0.125f); q0.w = scale2_bf16(q0.w, 0.125f);
     q1.x = scale2_bf16(q1.x, 0.125f); q1.y = scale2_bf16(q1.y, 0.125f); q1.z = scale2_bf16(q1.z, 0.125f); q1.w = scale2_bf16(q1.w, 0.125f);
   }

@@ -91,6 +91,8 @@ struct Tunables {
   int dec_rows_max_m = 32;   // measured: faster than the alternatives up to ~32 rows, slower from 64 (vector-L1 line rate)
   int dec_rows_ks_attn = 2; // its split-K factors for the residual projections (K = d) and fc2 (K = 4d)
   int dec_rows_ks_fc2 = 8;
+  int dec_ms_stages = 0;    // LDS-DMA stages of the decode tile GEMM (0 = the 2-stage encoder kernel; 3-5 measured equal)
+  int dec_fuse_reduce = 1;  // attention kernels consume the q / qkv split-K slices directly (no reduce launch)
   int dec_cross_mfma = 1;   // bf16 models: cross V kept transposed, cross attention on the matrix cores (read at create)
 };
 static Tunables g_tune;
@@ -303,6 +305,8 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   const bool rows = dt == WJ_BF16 && g_tune.dec_rows && R <= g_tune.dec_rows_max_m;
   const int ks_attn = rows ? g_tune.dec_rows_ks_attn : g_tune.dec_ks_attn;
   const int ks_fc2 = rows ? g_tune.dec_rows_ks_fc2 : g_tune.dec_ks_fc2, tile_min_m = g_tune.dec_tile_min_m;
+  const int ms = g_tune.dec_ms_stages;
+  const int tile_variant = (ms >= 3 && ms <= 5) ? 70 + ms : 3;
   float* slab = m->partial + (int64_t)row0 * kDecKsMax * D;
   int pend_ks = 0;
   const float* pend_bias = nullptr;
@@ -312,7 +316,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     if (dt == WJ_BF16 && ks > 1 && ks <= kDecKsMax && K % (64 * ks) == 0) {
       g.out = slab; g.ksplit = ks;
       pend_ks = ks; pend_bias = bias;
-      const int variant = rows ? 5 : ((tile_min_m > 0 && R >= tile_min_m) ? 3 : 2);
+      const int variant = rows ? 5 : ((tile_min_m > 0 && R >= tile_min_m) ? tile_variant : 2);
       PROF(tag, launch_gemm(dt, EPI_PARTIAL_F32, g, s, variant));
     } else {
       g.bias = bias; g.out = dx;
@@ -322,16 +326,20 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   };
   // projections with a scatter / activation epilogue: single pass, or (many rows) split-K slabs from the tile
   // kernel + one reduce kernel that applies the very same epilogue
-  auto proj_gemm = [&](int tag, Epi epi, GemmArgs& g) -> int {
+  // `deferred` (may be NULL): the caller's next kernel consumes the raw K-slices itself (attention kernels), so the
+  // reduce launch is skipped and *deferred = number of slices left in `slab`
+  auto proj_gemm = [&](int tag, Epi epi, GemmArgs& g, int* deferred = nullptr) -> int {
     const int ks = g_tune.dec_ks_proj;
+    if (deferred) *deferred = 0;
     if (rows) {
       PROF(tag, launch_gemm(dt, epi, g, s, 5));
     } else if (dt == WJ_BF16 && ks > 1 && R >= g_tune.dec_proj_min_m && (int64_t)ks * g.N <= (int64_t)kDecKsMax * D &&
         g.K % (64 * ks) == 0 && !pend_ks) {
       GemmArgs p = g;
       p.out = slab; p.ldc = g.N; p.ksplit = ks; p.bias = nullptr;
-      PROF(tag, launch_gemm(dt, EPI_PARTIAL_F32, p, s, 3));
-      PROF(tag, launch_splitk_reduce(dt, epi, g, slab, ks, s));
+      PROF(tag, launch_gemm(dt, EPI_PARTIAL_F32, p, s, tile_variant));
+      if (deferred && g_tune.dec_fuse_reduce) *deferred = ks;
+      else PROF(tag, launch_splitk_reduce(dt, epi, g, slab, ks, s));
     } else {
       PROF(tag, launch_gemm(dt, epi, g, s));
     }
@@ -351,6 +359,8 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
                                 m->tok_stride, pos, dx, R, D, s));
   for (int l = 0; l < d.n_text_layer; ++l) {
     const int b0 = m->dec_base(l);
+    int qkv_slices = 0, cq_slices = 0;
+    const float *qkv_bias = nullptr, *cq_bias = nullptr;
     void* sk = m->at(m->self_k, l * m->self_layer_elems());
     void* sv = m->at(m->self_v, l * m->self_layer_elems());
     WJ_TRY(norm(m->F(b0 + WJ_TD_LN1_W), m->F(b0 + WJ_TD_LN1_B)));
@@ -360,13 +370,17 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       g.M = R; g.N = 3 * D; g.K = D; g.out = dq;
       g.out2 = m->at(sk, row0 * self_row); g.out3 = m->at(sv, row0 * self_row);
       g.D = D; g.H = H; g.pos_ptr = pos; g.cache_len = d.n_text_ctx;
-      WJ_TRY(proj_gemm(PT_D_QKV, EPI_QKV_DEC, g));
+      WJ_TRY(proj_gemm(PT_D_QKV, EPI_QKV_DEC, g, &qkv_slices));
+      qkv_bias = g.bias;
     }
     {
       DecAttnArgs a;   // K/V bases stay absolute: the row map holds absolute physical rows
       a.q = dq; a.K = sk; a.V = sv; a.out = dattn; a.G = R; a.nb = 1; a.H = H;
       a.n_keys_ptr = pos; a.kv_stride = d.n_text_ctx;
       a.row_map = m->row_map[m->cur_map] + (int64_t)row0 * d.n_text_ctx;
+      if (qkv_slices) {   // the attention kernel sums the K-slices, appends k/v to the cache and attends
+        a.slab = slab; a.slab_bias = qkv_bias; a.slab_ks = qkv_slices; a.slab_rows = R; a.slab_ld = 3 * D; a.row_base = row0;
+      }
       PROF(PT_D_SELF, launch_attention_dec(dt, a, s));
     }
     WJ_TRY(resid_gemm(PT_D_OUT, dattn, D, m->W(b0 + WJ_TD_OUT_W), m->F(b0 + WJ_TD_OUT_B), ks_attn));
@@ -375,11 +389,13 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       GemmArgs g;
       g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
       g.M = R; g.N = D; g.K = D; g.out = dq; g.ldc = D;
-      WJ_TRY(proj_gemm(PT_D_CQ, EPI_T, g));
+      WJ_TRY(proj_gemm(PT_D_CQ, EPI_T, g, m->cross_tpad > 0 ? &cq_slices : nullptr));
+      cq_bias = g.bias;
     }
     {
       DecAttnArgs a;
       a.q = dq;
+      if (cq_slices) { a.slab = slab; a.slab_bias = cq_bias; a.slab_ks = cq_slices; a.slab_rows = R; a.slab_ld = D; }
       const int64_t woff = m->use_slots ? 0 : win0 * cross_win;   // with a slot map the K/V base stays absolute
       a.K = m->at(m->cross_k, l * m->cross_layer_elems() + woff);
       if (m->cross_tpad > 0) {
@@ -408,7 +424,8 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     GemmArgs g;
     g.A = dh; g.lda = D; g.W = m->W(WJ_T_DEC_TOK_EMB); g.ldw = D;
     g.M = R; g.N = d.n_vocab; g.K = D; g.out = m->logits + (int64_t)row0 * m->ldl; g.ldc = m->ldl;
-    PROF(PT_D_LOGITS, launch_gemm(dt, EPI_F32, g, s, rows ? 5 : 0));
+    const bool big_m = dt == WJ_BF16 && tile_min_m > 0 && R >= tile_min_m;
+    PROF(PT_D_LOGITS, launch_gemm(dt, EPI_F32, g, s, rows ? 5 : (big_m ? tile_variant : 0)));
   }
   return WJ_OK;
 }
@@ -534,6 +551,9 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_ks_proj")) g_tune.dec_ks_proj = value;
   else if (!strcmp(key, "dec_proj_min_m")) g_tune.dec_proj_min_m = value;
   else if (!strcmp(key, "dec_cross_mfma")) g_tune.dec_cross_mfma = value;
+  else if (!strcmp(key, "gemm_big")) g_gemm_big = value;
+  else if (!strcmp(key, "dec_ms_stages")) g_tune.dec_ms_stages = value;
+  else if (!strcmp(key, "dec_fuse_reduce")) g_tune.dec_fuse_reduce = value;
   else if (!strcmp(key, "dec_rows")) g_tune.dec_rows = value;
   else if (!strcmp(key, "dec_rows_max_m")) g_tune.dec_rows_max_m = value;
   else if (!strcmp(key, "dec_rows_ks_attn")) g_tune.dec_rows_ks_attn = value;

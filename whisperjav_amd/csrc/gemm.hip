@@ -49,7 +49,7 @@ __device__ __forceinline__ void epi_nm(const GemmArgs& g, int z, int m, int n, f
     if constexpr (EPI == EPI_T || EPI == EPI_GELU_T) {
       if constexpr (EPI == EPI_GELU_T) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_exact(v[j]);
+        for (int j = 0; j < 4; ++j) v[j] = gelu_for<T>(v[j]);
       }
       st4(reinterpret_cast<T*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n, v);
     } else if constexpr (EPI == EPI_RESID_F32) {
@@ -61,8 +61,8 @@ __device__ __forceinline__ void epi_nm(const GemmArgs& g, int z, int m, int n, f
     } else if constexpr (EPI == EPI_GELU_POS_F32) {
       const float4 p = *reinterpret_cast<const float4*>(g.pos + (int64_t)m * g.N + n);
       float4 x;
-      x.x = gelu_exact(v[0]) + p.x; x.y = gelu_exact(v[1]) + p.y;
-      x.z = gelu_exact(v[2]) + p.z; x.w = gelu_exact(v[3]) + p.w;
+      x.x = gelu_for<T>(v[0]) + p.x; x.y = gelu_for<T>(v[1]) + p.y;
+      x.z = gelu_for<T>(v[2]) + p.z; x.w = gelu_for<T>(v[3]) + p.w;
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch +
                                  (int64_t)m * g.ldc + n) = x;
     } else if constexpr (EPI == EPI_QK_HEADS || EPI == EPI_CKV) {
@@ -254,6 +254,289 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
         if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, z, m, n, v);
       }
     }
+}
+
+// --------------------------------------------------------------------------------------------
+// bf16 MFMA, 256x256x64 tile, 8 waves (2 x 4; a wave owns 128 x 64 of C in 128 accumulator registers).
+// Same LDS image and LDS-DMA staging as the 128-tile kernel, but each operand byte read from LDS feeds
+// 1.5x more MFMAs ((8 + 4) fragment reads for 32 MFMAs per k-half instead of (4 + 4) for 16) and the two
+// waves that share a SIMD overlap one wave's ds_reads with the other's MFMAs.  2 x 64 KiB of LDS.
+// Used for the big encoder GEMMs (N % 256 == 0, K % 64 == 0).
+// --------------------------------------------------------------------------------------------
+constexpr int BBM = 256, BBN = 256;
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds_big[];   // [buf][A|W][256][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int z = blockIdx.z;
+  const int nx = gridDim.x, ntiles = gridDim.x * gridDim.y;
+  const int lin = blockIdx.y * nx + blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  constexpr int GM = 8;
+  const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
+  const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
+  const int m0 = (first_m + in_group % gsz) * BBM, n0 = (in_group / gsz) * BBN;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)z * g.a_batch;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / TBK;
+  constexpr int STAGE = 2 * BBM * TBK;   // elements per buffer (A then W)
+#define WJ_BIG_STAGE(buf, k0)                                                                      \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                  \
+    const int r0 = (wave * 4 + q) * 8;                                                             \
+    const int row = r0 + (lane >> 3);                                                              \
+    const int c = (lane & 7) ^ (row & 7);                                                          \
+    const bf16_t* ga = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + (k0) + c * 8;                 \
+    const bf16_t* gw = W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + (k0) + c * 8;                 \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,            \
+        (__attribute__((address_space(3))) void*)(&lds_big[(buf) * STAGE + r0 * TBK]), 16, 0, 0);  \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,            \
+        (__attribute__((address_space(3))) void*)(&lds_big[(buf) * STAGE + BBM * TBK + r0 * TBK]), 16, 0, 0); \
+  }
+
+  WJ_BIG_STAGE(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) { WJ_BIG_STAGE(cur ^ 1, (kt + 1) * TBK) }
+    const bf16_t* la = &lds_big[cur * STAGE];
+    const bf16_t* lb = la + BBM * TBK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[8], wf[4];
+      const int ch = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + (lane & 15);
+        wf[j] = *reinterpret_cast<const bf16x8_t*>(&lb[swz(row, ch)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + i * 16 + (lane & 15);
+        af[i] = *reinterpret_cast<const bf16x8_t*>(&la[swz(row, ch)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (EPI == EPI_VT)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of tile kt+1 has landed
+    __syncthreads();
+  }
+#undef WJ_BIG_STAGE
+
+  if constexpr (EPI == EPI_RESID_F32) {
+    // x += acc + bias: all 16 residual loads of a half-tile are issued before the first add/store (written as
+    // load-add-store per fragment this epilogue is a chain of 32 dependent memory round trips)
+    const int nb = n0 + wn * 64 + (lane >> 4) * 4;
+    float4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bias4[j] = g.bias ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* xo = reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch;
+#pragma unroll
+    for (int ih = 0; ih < 8; ih += 4) {
+      float4 r[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = min(m0 + wm * 128 + (ih + i) * 16 + (lane & 15), g.M - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[i][j] = *reinterpret_cast<const float4*>(xo + (int64_t)m * g.ldc + nb + j * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 128 + (ih + i) * 16 + (lane & 15);
+        if (m < g.M) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4_t a4 = acc[ih + i][j];
+            float4 x = r[i][j];
+            x.x += a4[0] + bias4[j].x; x.y += a4[1] + bias4[j].y; x.z += a4[2] + bias4[j].z; x.w += a4[3] + bias4[j].w;
+            *reinterpret_cast<float4*>(xo + (int64_t)m * g.ldc + nb + j * 16) = x;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if constexpr (EPI == EPI_VT) {
+        const int m = m0 + wm * 128 + i * 16 + (lane >> 4) * 4;
+        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+        if (m < g.M && n < g.N) epi_vt<bf16_t>(g, z, m, n, v);
+      } else {
+        const int m = m0 + wm * 128 + i * 16 + (lane & 15);
+        const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, z, m, n, v);
+      }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// bf16 MFMA, 128x128x64 tile with an NS-stage LDS-DMA pipeline (decode GEMMs, M = a few hundred rows).
+// A decode GEMM gives a workgroup only 5-20 k-steps of 32 MFMAs per wave: with one stage of prefetch every
+// k-step costs a full global->LDS round trip (~1 us), so the kernel is latency- not MFMA-bound.  Here NS-1
+// stages are in flight: stage kt+NS-1 is requested right after the barrier that retires stage kt-1, and the
+// wait before computing stage kt lets the younger stages stay outstanding (s_waitcnt vmcnt(8 * younger)).
+// One barrier per k-step.  NS * 32 KiB of LDS.
+// --------------------------------------------------------------------------------------------
+template <int EPI, int NS>
+__global__ __launch_bounds__(256) void gemm_bf16_tile_ms_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds_ms[];   // [stage][A|W][128][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int z = blockIdx.z;
+  const int nx = gridDim.x, ntiles = gridDim.x * gridDim.y;
+  const int lin = blockIdx.y * nx + blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  constexpr int GM = 8;
+  const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
+  const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
+  const int m0 = (first_m + in_group % gsz) * TBM, n0 = (in_group / gsz) * TBN;
+  const int kslice = (EPI == EPI_PARTIAL_F32) ? g.K / g.ksplit : g.K;
+  const int64_t koff = (EPI == EPI_PARTIAL_F32) ? (int64_t)z * kslice : 0;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + ((EPI == EPI_PARTIAL_F32) ? koff : (int64_t)z * g.a_batch);
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W) + koff;
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = kslice / TBK;
+  constexpr int STAGE = 2 * TBM * TBK;
+#define WJ_MS_STAGE(buf, k0)                                                                       \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                  \
+    const int r0 = (wave * 4 + q) * 8;                                                             \
+    const int row = r0 + (lane >> 3);                                                              \
+    const int c = (lane & 7) ^ (row & 7);                                                          \
+    const bf16_t* ga = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + (k0) + c * 8;                 \
+    const bf16_t* gw = W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + (k0) + c * 8;                 \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,            \
+        (__attribute__((address_space(3))) void*)(&lds_ms[(buf) * STAGE + r0 * TBK]), 16, 0, 0);   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,            \
+        (__attribute__((address_space(3))) void*)(&lds_ms[(buf) * STAGE + TBM * TBK + r0 * TBK]), 16, 0, 0); \
+  }
+
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (st < nk) { WJ_MS_STAGE(st, st * TBK) }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int younger = min(NS - 2, nk - 1 - kt);     // stages requested after stage kt and still allowed in flight
+    if (younger >= 4) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (younger == 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // stage kt visible to all; buffer of stage kt-1 is free
+    if (kt + NS - 1 < nk) { WJ_MS_STAGE((kt + NS - 1) % NS, (kt + NS - 1) * TBK) }
+    const bf16_t* la = &lds_ms[(kt % NS) * STAGE];
+    const bf16_t* lb = la + TBM * TBK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], wf[4];
+      const int ch = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(&la[swz(wm * 64 + i * 16 + (lane & 15), ch)]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(&lb[swz(wn * 64 + j * 16 + (lane & 15), ch)]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  }
+#undef WJ_MS_STAGE
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+      const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, z, m, n, v);
+    }
+}
+
+template <int EPI, int NS>
+static int launch_ms_inst(const GemmArgs& a, hipStream_t s) {
+  constexpr size_t smem = (size_t)NS * 2 * TBM * TBK * sizeof(bf16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_tile_ms_kernel<EPI, NS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%d KiB LDS): %s", (int)(smem >> 10), hipGetErrorString(e)); return WJ_E_HIP; }
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), EPI == EPI_PARTIAL_F32 ? a.ksplit : a.nbatch);
+  hipLaunchKernelGGL((gemm_bf16_tile_ms_kernel<EPI, NS>), grid, dim3(256), smem, s, a);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+template <int EPI>
+static int launch_ms(const GemmArgs& a, hipStream_t s, int ns) {
+  if constexpr (EPI == EPI_T || EPI == EPI_GELU_T || EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_DEC ||
+                EPI == EPI_PARTIAL_F32) {
+    const int ks = EPI == EPI_PARTIAL_F32 ? a.ksplit : 1;
+    if (a.K % (TBK * ks)) { set_error("gemm: the multi-stage tile kernel needs K %% (64 * ksplit) == 0"); return WJ_E_INVALID; }
+    switch (ns) {
+      case 3: return launch_ms_inst<EPI, 3>(a, s);
+      case 5: return launch_ms_inst<EPI, 5>(a, s);
+      default: return launch_ms_inst<EPI, 4>(a, s);
+    }
+  } else {
+    set_error("gemm: the multi-stage tile kernel does not carry epilogue %d", (int)EPI);
+    return WJ_E_INVALID;
+  }
+}
+
+int g_gemm_big = 1;   // wj_tune("gemm_big"): 0 disables the 256-tile kernel (A/B timing)
+
+template <int EPI>
+static int launch_big(const GemmArgs& a, hipStream_t s) {
+  if constexpr (EPI == EPI_PARTIAL_F32) {
+    set_error("gemm: the 256-tile kernel has no split-K mode");
+    return WJ_E_INVALID;
+  } else {
+    constexpr size_t smem = 2 * 2 * BBM * TBK * sizeof(bf16_t);   // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_big_kernel<EPI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) { set_error("hipFuncSetAttribute(128 KiB LDS): %s", hipGetErrorString(e)); return WJ_E_HIP; }
+      attr_set = true;
+    }
+    dim3 grid(ceil_div(a.N, BBN), ceil_div(a.M, BBM), a.nbatch);
+    hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI>), grid, dim3(512), smem, s, a);
+    WJ_LAUNCH_CHECK();
+    return WJ_OK;
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -523,6 +806,7 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
     return WJ_OK;
   }
   if (variant == 5 || (variant >= 50 && variant < 70)) return launch_rows<EPI>(a, s, variant == 5 ? 0 : variant - 50);
+  if (variant == 7 || (variant >= 73 && variant <= 75)) return launch_ms<EPI>(a, s, variant == 7 ? 4 : variant - 70);
   const bool skinny_ok = (EPI != EPI_VT) && a.nbatch == 1;
   bool skinny = skinny_ok && a.M <= 512;
   if (variant == 1 || variant == 3 || variant == 4) skinny = false;
@@ -541,6 +825,10 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
     }
     return WJ_OK;
   }
+  // big encoder GEMMs: 256-tile kernel (variant 6 forces it, 0 = auto when the shape qualifies)
+  const bool big_ok = EPI != EPI_PARTIAL_F32 && (a.N % BBN) == 0 && (a.K % TBK) == 0 && a.M >= 1024;
+  if (variant == 6 && !big_ok) { set_error("gemm: the 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, M >= 1024"); return WJ_E_INVALID; }
+  if (variant == 6 || ((variant == 0 || variant == 1) && g_gemm_big && big_ok)) return launch_big<EPI>(a, s);
   dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), EPI == EPI_PARTIAL_F32 ? a.ksplit : a.nbatch);
   static const int tile_mode = [] {   // WJ_GEMM_TILE=reg|glds overrides the default staging path
     const char* e = getenv("WJ_GEMM_TILE");

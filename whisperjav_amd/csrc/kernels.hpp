@@ -80,8 +80,16 @@ struct DecAttnArgs {
   const int32_t* row_map = nullptr;  // [G][kv_stride]
   const int32_t* group_of = nullptr; // [G] window slot per group (cross attention), NULL = identity
   int vt_stride = 0;                 // > 0: bf16 cross attention on the matrix cores; V is [group][H][64][vt_stride]
+  // Fused split-K consumer (bf16): the projection that feeds this attention left `slab_ks` raw fp32 K-slices
+  // [slab_ks][slab_rows][slab_ld] instead of q (cross: slab_ld = D) or q|k|v (self: slab_ld = 3 D); the kernel
+  // sums them in slice order, adds slab_bias, rounds to bf16 exactly like the projection's own epilogue would,
+  // and (self) appends k, v to the cache at position *n_keys_ptr of physical row row_base + group.
+  const float* slab = nullptr;
+  const float* slab_bias = nullptr;
+  int slab_ks = 0, slab_rows = 0, slab_ld = 0, row_base = 0;
 };
 extern int g_dec_cross_u;
+extern int g_gemm_big;
 int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s);
 
 // ---------------- sampling -----------------------------------------------------------------------
