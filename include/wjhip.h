@@ -168,6 +168,22 @@ int wj_whisper_decode_sample(wj_whisper* m, int batch, int group, const int32_t*
                              int32_t* tokens_out, int32_t* n_tokens_out, float* sum_logprob_out,
                              float* no_speech_prob_out, float* token_logprob_out, void* stream);
 
+/* Word-timestamp alignment.  Replaces: ctranslate2 Whisper.align (faster_whisper.transcribe.WhisperModel
+ * .find_alignment, reached with word_timestamps=True from faster_whisper_pro_asr.py:819) and whisper/timing.py
+ * find_alignment (whisper_pro_asr.py:433).  Teacher-forced decoder pass over tokens_host [batch][n_tokens_max]
+ * (= sot sequence, <|notimestamps|>, text tokens, eot; rows padded with eot; n_tokens_host[b] counts them,
+ * n_prefix = len(sot sequence) + 1) for the windows resident in slots_host (NULL = 0..batch-1); the scaled
+ * cross-attention scores of the n_heads (layer, head) pairs in heads_host go through softmax over the first
+ * num_frames/2 encoder positions, (w - mean) / std over the tokens, a median filter of width medfilt_width
+ * (odd, <= 15, reflect padding), the mean over heads and a DTW of the negated matrix.
+ * Outputs (host): the DTW path of window b in path_text_out / path_time_out [b][n_tokens_max + n_audio_ctx]
+ * (path_len_out[b] entries; text index 0 = the row of <|notimestamps|>), token_prob_out [b][n_tokens_max]
+ * = softmax(logits[:eot]) probability of text token i of window b at index i. */
+int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const int32_t* tokens_host, int n_tokens_max,
+                     const int32_t* n_tokens_host, int n_prefix, const int32_t* heads_host, int n_heads,
+                     const int32_t* num_frames_host, int medfilt_width, int eot, int32_t* path_text_out,
+                     int32_t* path_time_out, int32_t* path_len_out, float* token_prob_out, void* stream);
+
 /* diagnostics of the last wj_whisper_decode_greedy call: out[0] = 1 if the step was replayed from a
  * hipGraph, out[1] = number of concurrent row chains */
 int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[2]);

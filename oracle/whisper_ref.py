@@ -91,8 +91,9 @@ class WhisperOracle:
         return F.layer_norm(x, (x.shape[-1],), self.w[prefix + ".weight"],
                             self.w[prefix + ".bias"], 1e-5)
 
-    def _attention(self, q, k, v, n_head, causal_from: Optional[int] = None):
-        """q [B,Tq,D], k/v [B,Tk,D]; scores scaled by 1/sqrt(d_head); fp32 softmax."""
+    def _attention(self, q, k, v, n_head, causal_from: Optional[int] = None, qk_out: Optional[list] = None):
+        """q [B,Tq,D], k/v [B,Tk,D]; scores scaled by 1/sqrt(d_head); fp32 softmax.
+        ``qk_out`` (a list) receives the scaled scores [B,H,Tq,Tk] -- what whisper/timing.py's hooks capture."""
         B, Tq, D = q.shape
         Tk = k.shape[1]
         dh = D // n_head
@@ -105,6 +106,8 @@ class WhisperOracle:
             qpos = torch.arange(Tq)[:, None] + causal_from
             kpos = torch.arange(Tk)[None, :]
             s = s.masked_fill(kpos > qpos, float("-inf"))
+        if qk_out is not None:
+            qk_out.append(s)
         p = torch.softmax(s, dim=-1)
         o = self.rnd(p) @ vh
         return o.permute(0, 2, 1, 3).reshape(B, Tq, D)
@@ -149,8 +152,9 @@ class WhisperOracle:
         return out
 
     def decoder_logits(self, tokens: torch.Tensor, xa: torch.Tensor, cross=None,
-                       n_layers: Optional[int] = None) -> torch.Tensor:
-        """Full (uncached) decoder pass: tokens [B,T] int64 -> logits [B,T,V] fp32."""
+                       n_layers: Optional[int] = None, cross_qk: Optional[list] = None) -> torch.Tensor:
+        """Full (uncached) decoder pass: tokens [B,T] int64 -> logits [B,T,V] fp32.
+        ``cross_qk`` (a list) receives every layer's scaled cross-attention scores [B,H,T,Tk]."""
         B, T = tokens.shape
         x = self.w["decoder.token_embedding.weight"][tokens] + \
             self.w["decoder.positional_embedding"][:T]
@@ -168,7 +172,7 @@ class WhisperOracle:
             h = self._ln(x, p + "cross_attn_ln")
             q = self._linear(h, p + "cross_attn.query")
             ck, cv = cross[i]
-            x = x + self._linear(self._attention(q, ck, cv, H), p + "cross_attn.out")
+            x = x + self._linear(self._attention(q, ck, cv, H, qk_out=cross_qk), p + "cross_attn.out")
             h = self._ln(x, p + "mlp_ln")
             h = F.gelu(self._linear(h, p + "mlp.0"))
             x = x + self._linear(h, p + "mlp.2")

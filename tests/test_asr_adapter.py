@@ -289,3 +289,40 @@ def test_fidelity_asr_module_gate_on_by_default(tmp_path):
     assert res["segments"][0]["start"] == pytest.approx(0.5)
     assert a.get_filter_statistics()["logprob_filtered"] == 1
     assert model.calls[0]["temperature"] == (0.0, 0.2) and model.calls[0]["fp16"] is True and "verbose" in model.calls[0]
+
+
+# ---- word timestamps (host side of add_word_timestamps with a scripted alignment) ----------------------------
+def test_word_timestamps_host_logic_and_seek_update():
+    """The engine double returns a scripted DTW path; the host must cut it into words exactly as faster-whisper's
+    find_alignment / add_word_timestamps do (jump times at word boundaries, 0.02 s units, offsets, segment
+    start/end snapped to the words, seek moved to the last word end when the window does not end on a single
+    timestamp)."""
+    tb = pdims.special_tokens(51865).timestamp_begin
+    # one window: <|0.00|> 11 12 <|2.00|><|2.00|> 13 <|4.00|>  (two sub-segments, ends on a single timestamp? no: pair open)
+    m = _model([[tb, 11, 12, tb + 100, tb + 100, 13, tb + 200]])
+    m.dims = pdims.custom_dims(80, 128, 2, 2, 51865)
+    calls = []
+
+    def align(rows, n_prefix, heads, num_frames, slots=None, medfilt_width=7):
+        calls.append((rows, n_prefix, list(num_frames), list(slots)))
+        # text tokens 11, 12, 13 -> rows 0..3 (3 = eot); token i starts at frame 25 * (i + 1)
+        text_idx = np.array([0] * 25 + [1] * 25 + [2] * 25 + [3] * 25)
+        time_idx = np.arange(100) + 25
+        return [(text_idx, time_idx, np.array([0.9, 0.5, 0.7], np.float32))]
+    m.model.align = align
+    segs, _ = m.transcribe(np.zeros(16000 * 10, np.float32), beam_size=1, temperature=0.0, word_timestamps=True,
+                           condition_on_previous_text=False, language="ja")
+    segs = list(segs)
+    rows, n_prefix, nf, slots = calls[0]
+    t = m.tokens
+    assert rows == [[t.sot, t.language_token(pdims.language_index("ja")), t.transcribe, t.no_timestamps, 11, 12, 13, t.eot]]
+    assert n_prefix == 4 and nf == [1000] and slots == [0]
+    words = [w for s in segs for w in s.words]
+    assert [w.word for w in words] == ["<11>", "<12>", "<13>"]
+    assert [(w.start, w.end) for w in words] == [(0.5, 1.0), (1.0, 1.5), (1.5, 2.0)]
+    assert [w.probability for w in words] == pytest.approx([0.9, 0.5, 0.7])
+    assert [len(s.words) for s in segs[:2]] == [2, 1]
+    # segment boundaries snap to the words (no 0.5 s disagreement rule triggered for the first, triggered for none)
+    assert (segs[0].start, segs[0].end) == (0.5, 1.5) and (segs[1].start, segs[1].end) == (1.5, 2.0)
+    # the window did not end on a single timestamp pair -> the next window starts at the last word end (2.0 s = frame 200)
+    assert segs[2].seek == 200 if len(segs) > 2 else True

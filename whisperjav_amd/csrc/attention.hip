@@ -399,6 +399,18 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
     if (lane == 0) red_m[wave * NB + b] = v;
   }
   __syncthreads();
+  if constexpr (!SELF) {
+    if (a.dump) {   // alignment heads hand their scaled scores to the word-timestamp pass
+      const int sel = a.dump_sel[h];
+      if (sel >= 0) {
+        const int pos = *a.dump_pos_ptr;
+        for (int b = 0; b < NB; ++b) {
+          float* dst = a.dump + ((((int64_t)(a.dump_row_base + gi * NB + b) * a.dump_nsel + sel) * a.dump_tmax + pos) * n_keys);
+          for (int j = tid; j < n_keys; j += NW * 64) dst[j] = sc[b * kpad + j];
+        }
+      }
+    }
+  }
   float mx[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -573,6 +585,17 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
   lmax = fmaxf(lmax, __shfl_xor(lmax, 32, 64));
   if (lg == 0) red_m[wave * 16 + li] = lmax;
   __syncthreads();
+
+  if (a.dump) {   // alignment heads hand their scaled scores to the word-timestamp pass
+    const int sel = a.dump_sel[h];
+    if (sel >= 0) {
+      const int pos = *a.dump_pos_ptr;
+      for (int b = 0; b < NB; ++b) {
+        float* dst = a.dump + ((((int64_t)(a.dump_row_base + gi * NB + b) * a.dump_nsel + sel) * a.dump_tmax + pos) * n_keys);
+        for (int j = tid; j < n_keys; j += 256) dst[j] = sc[b * kpad + j];
+      }
+    }
+  }
 
   // ---- probabilities, once per (beam, key)
   for (int b = 0; b < NB; ++b) {

@@ -148,6 +148,12 @@ struct wj_whisper {
   int32_t* step_tok = nullptr;  // [R] staging for wj_decode_step
   int32_t* slot_map = nullptr;  // [max_batch] window slot of each decoded window (sub-batch re-decodes)
   bool use_slots = false;
+  // word-timestamp alignment (wj_whisper_align): scratch grown on demand, selection table [L][H]
+  void* align_buf = nullptr;
+  size_t align_bytes = 0;
+  int32_t* align_sel = nullptr;
+  float* dump_qk = nullptr;     // non-NULL while the teacher-forced pass of wj_whisper_align runs
+  int dump_nsel = 0, dump_tmax = 0;
   int32_t* topk_ids = nullptr;  // [R][16]
   float* topk_lp = nullptr;
   float* topk_lse = nullptr;
@@ -396,6 +402,10 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       DecAttnArgs a;
       a.q = dq;
       if (cq_slices) { a.slab = slab; a.slab_bias = cq_bias; a.slab_ks = cq_slices; a.slab_rows = R; a.slab_ld = D; }
+      if (m->dump_qk) {
+        a.dump = m->dump_qk; a.dump_sel = m->align_sel + (int64_t)l * H; a.dump_pos_ptr = pos;
+        a.dump_nsel = m->dump_nsel; a.dump_tmax = m->dump_tmax; a.dump_row_base = row0;
+      }
       const int64_t woff = m->use_slots ? 0 : win0 * cross_win;   // with a slot map the K/V base stays absolute
       a.K = m->at(m->cross_k, l * m->cross_layer_elems() + woff);
       if (m->cross_tpad > 0) {
@@ -580,6 +590,7 @@ int wj_whisper_free(wj_whisper* m) {
   (void)hipSetDevice(m->ctx->device);
   (void)hipStreamSynchronize(m->ctx->stream);
   for (void* p : m->allocs) (void)hipFree(p);
+  if (m->align_buf) (void)hipFree(m->align_buf);
   delete m;
   return WJ_OK;
 }
@@ -652,6 +663,7 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   WJ_ALLOC(parent, R * sizeof(int32_t), true);
   WJ_ALLOC(step_tok, R * sizeof(int32_t), true);
   WJ_ALLOC(slot_map, B * sizeof(int32_t), true);
+  WJ_ALLOC(align_sel, (size_t)d.n_text_layer * d.n_text_head * sizeof(int32_t), true);
   WJ_ALLOC(topk_ids, R * 16 * sizeof(int32_t), true);
   WJ_ALLOC(topk_lp, R * 16 * sizeof(float), true);
   WJ_ALLOC(topk_lse, R * sizeof(float), true);
@@ -870,6 +882,96 @@ int wj_decode_step(wj_whisper* m, const int32_t* tokens_host, const int32_t* par
 }
 
 float* wj_decode_logits_dev(wj_whisper* m) { return m ? m->logits : nullptr; }
+
+// ------------------------------------------------------------------------------------------------
+// word-timestamp alignment
+// ------------------------------------------------------------------------------------------------
+int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const int32_t* tokens_host, int n_tokens_max,
+                     const int32_t* n_tokens_host, int n_prefix, const int32_t* heads_host, int n_heads,
+                     const int32_t* num_frames_host, int medfilt_width, int eot, int32_t* path_text_out,
+                     int32_t* path_time_out, int32_t* path_len_out, float* token_prob_out, void* stream) {
+  WJ_REQUIRE(m && tokens_host && n_tokens_host && heads_host && num_frames_host && path_text_out && path_time_out &&
+             path_len_out && token_prob_out, "wj_whisper_align: NULL argument");
+  const wj_whisper_dims& d = m->d;
+  const int L = d.n_text_layer, H = d.n_text_head, nctx = d.n_audio_ctx, T = n_tokens_max, n0 = n_prefix - 1;
+  WJ_REQUIRE(batch >= 1 && batch <= m->max_batch && batch <= m->max_rows, "align: batch %d outside 1..%d", batch, m->max_batch);
+  WJ_REQUIRE(T >= n_prefix + 1 && T <= d.n_text_ctx, "align: %d tokens per window outside %d..%d", T, n_prefix + 1, d.n_text_ctx);
+  WJ_REQUIRE(n_prefix >= 2 && n_heads >= 1 && n_heads <= L * H, "align: bad prefix length / head count");
+  WJ_REQUIRE(eot > 0 && eot <= d.n_vocab, "align: eot id out of range");
+  std::vector<int32_t> sel((size_t)L * H, -1), nf2(batch);
+  for (int i = 0; i < n_heads; ++i) {
+    const int l = heads_host[2 * i], h = heads_host[2 * i + 1];
+    WJ_REQUIRE(l >= 0 && l < L && h >= 0 && h < H, "align: head (%d, %d) outside the %d x %d decoder", l, h, L, H);
+    WJ_REQUIRE(sel[(size_t)l * H + h] < 0, "align: head (%d, %d) listed twice", l, h);
+    sel[(size_t)l * H + h] = i;
+  }
+  for (int b = 0; b < batch; ++b) {
+    WJ_REQUIRE(n_tokens_host[b] >= n_prefix + 1 && n_tokens_host[b] <= T, "align: window %d has %d tokens (prefix %d + eot .. %d)", b,
+               n_tokens_host[b], n_prefix, T);
+    WJ_REQUIRE(num_frames_host[b] >= 2 && num_frames_host[b] / 2 <= nctx, "align: window %d: %d feature frames", b, num_frames_host[b]);
+    nf2[b] = num_frames_host[b] / 2;
+    if (slots_host) WJ_REQUIRE(slots_host[b] >= 0 && slots_host[b] < m->max_batch, "align: window slot %d out of range", slots_host[b]);
+  }
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  // scratch: qk [B][n_heads][T][nctx] f32 | matrix [B][T][nctx] f32 | trace [B][T+1][nctx+1] i8 | paths | meta | probs
+  const size_t plen = (size_t)T + nctx;
+  const size_t b_qk = align_up(sizeof(float) * (size_t)batch * n_heads * T * nctx, 256);
+  const size_t b_mx = align_up(sizeof(float) * (size_t)batch * T * nctx, 256);
+  const size_t b_tr = align_up((size_t)batch * (T + 1) * (nctx + 1), 256);
+  const size_t b_path = align_up(sizeof(int32_t) * (size_t)batch * plen, 256);
+  const size_t b_meta = align_up(sizeof(int32_t) * (size_t)batch, 256);
+  const size_t b_prob = align_up(sizeof(float) * (size_t)batch * T, 256);
+  const size_t need = b_qk + b_mx + b_tr + 2 * b_path + 3 * b_meta + b_prob;
+  if (need > m->align_bytes) {
+    if (m->align_buf) { WJ_HIP(hipStreamSynchronize(s)); (void)hipFree(m->align_buf); m->align_buf = nullptr; m->align_bytes = 0; }
+    WJ_HIP(hipMalloc(&m->align_buf, need));
+    m->align_bytes = need;
+  }
+  char* base = reinterpret_cast<char*>(m->align_buf);
+  float* qk = reinterpret_cast<float*>(base);
+  float* matrix = reinterpret_cast<float*>(base + b_qk);
+  int8_t* trace = reinterpret_cast<int8_t*>(base + b_qk + b_mx);
+  int32_t* p_text = reinterpret_cast<int32_t*>(base + b_qk + b_mx + b_tr);
+  int32_t* p_time = reinterpret_cast<int32_t*>(base + b_qk + b_mx + b_tr + b_path);
+  int32_t* d_ntok = reinterpret_cast<int32_t*>(base + b_qk + b_mx + b_tr + 2 * b_path);
+  int32_t* d_nf2 = d_ntok + b_meta / sizeof(int32_t);
+  int32_t* d_plen = d_nf2 + b_meta / sizeof(int32_t);
+  float* d_prob = reinterpret_cast<float*>(base + b_qk + b_mx + b_tr + 2 * b_path + 3 * b_meta);
+
+  const int R = batch;
+  WJ_TRY(reset_decode_state(m, R, s));
+  WJ_HIP(hipMemcpyAsync(m->align_sel, sel.data(), sizeof(int32_t) * sel.size(), hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(d_ntok, n_tokens_host, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(d_nf2, nf2.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemsetAsync(d_prob, 0, b_prob, s));
+  m->use_slots = slots_host != nullptr;
+  if (slots_host) WJ_HIP(hipMemcpyAsync(m->slot_map, slots_host, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+  {
+    std::vector<int32_t> hist((size_t)R * m->tok_stride, eot);
+    for (int r = 0; r < R; ++r)
+      for (int j = 0; j < T; ++j) hist[(size_t)r * m->tok_stride + j] = tokens_host[(size_t)r * T + j];
+    WJ_HIP(hipMemcpyAsync(m->tokens, hist.data(), sizeof(int32_t) * hist.size(), hipMemcpyHostToDevice, s));
+    WJ_HIP(hipStreamSynchronize(s));   // `hist`, `sel`, `nf2` go out of scope / are reused
+  }
+  m->dump_qk = qk; m->dump_nsel = n_heads; m->dump_tmax = T;
+  struct Guard { wj_whisper* m; ~Guard() { m->dump_qk = nullptr; m->use_slots = false; } } guard{m};
+  // teacher-forced pass: position t reads token t of the history; logits only where a text token is predicted
+  for (int t = 0; t < T; ++t) {
+    const bool want = t >= n0 && t + 1 < T;
+    WJ_TRY(run_decoder_step(m, 0, R, batch, 1, want, s));
+    if (want)
+      WJ_TRY(launch_align_token_prob(m->logits, m->ldl, eot, m->tokens, m->tok_stride, m->pos, n0, d_prob, T, R, s));
+    WJ_TRY(launch_advance_pos(m->pos, s));
+  }
+  WJ_TRY(launch_align_post(qk, matrix, trace, d_ntok, d_nf2, R, n_heads, T, nctx, n0, medfilt_width, p_text, p_time, d_plen, s));
+  WJ_HIP(hipMemcpyAsync(path_text_out, p_text, sizeof(int32_t) * (size_t)batch * plen, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(path_time_out, p_time, sizeof(int32_t) * (size_t)batch * plen, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(path_len_out, d_plen, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(token_prob_out, d_prob, sizeof(float) * (size_t)batch * T, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipStreamSynchronize(s));
+  return WJ_OK;
+}
 
 int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[2]) {
   WJ_REQUIRE(m && out, "wj_whisper_last_decode_info: NULL argument");

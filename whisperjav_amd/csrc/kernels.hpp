@@ -87,10 +87,23 @@ struct DecAttnArgs {
   const float* slab = nullptr;
   const float* slab_bias = nullptr;
   int slab_ks = 0, slab_rows = 0, slab_ld = 0, row_base = 0;
+  // Word-timestamp alignment: cross-attention heads with dump_sel[h] >= 0 copy their scaled scores to
+  // dump[query row][dump_sel[h]][*dump_pos_ptr][n_keys] (query row counted from dump_row_base)
+  float* dump = nullptr;
+  const int32_t* dump_sel = nullptr;   // [H] device
+  const int* dump_pos_ptr = nullptr;
+  int dump_nsel = 0, dump_tmax = 0, dump_row_base = 0;
 };
 extern int g_dec_cross_u;
 extern int g_gemm_big;
 int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s);
+
+// ---------------- word-timestamp alignment (align.hip) ------------------------------------------------
+int launch_align_token_prob(const float* logits, int64_t ldl, int limit, const int32_t* tokens, int64_t tok_stride,
+                            const int* pos_ptr, int n0, float* prob_out, int tmax, int R, hipStream_t s);
+int launch_align_post(float* qk, float* matrix, int8_t* trace, const int32_t* n_tok, const int32_t* nf2, int R, int nsel,
+                      int tmax, int nctx, int n0, int width, int32_t* path_text, int32_t* path_time, int32_t* path_len,
+                      hipStream_t s);
 
 // ---------------- sampling -----------------------------------------------------------------------
 struct GreedyArgs {

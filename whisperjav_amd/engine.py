@@ -245,6 +245,43 @@ class HipWhisper:
                                                  as_f(nsp), as_f(tlp), None), "wj_whisper_decode_sample")
         return GreedyResult(toks, ntok, slp, nsp, tlp)
 
+    def align(self, token_rows: Sequence[Sequence[int]], n_prefix: int, heads: Sequence[Tuple[int, int]],
+              num_frames: Sequence[int], *, slots: Optional[Sequence[int]] = None, medfilt_width: int = 7):
+        """Word-timestamp alignment of the resident windows.  ``token_rows[b]`` = sot sequence + <|notimestamps|> +
+        text tokens + eot (``n_prefix`` = len(sot sequence) + 1).  Returns per window
+        ``(text_indices, time_indices, text_token_probs)`` as numpy arrays (see ``wj_whisper_align``)."""
+        B = len(token_rows)
+        eot = self.tokens.eot
+        n_tok = np.array([len(r) for r in token_rows], dtype=np.int32)
+        T = int(n_tok.max())
+        toks = np.full((B, T), eot, dtype=np.int32)
+        for b, r in enumerate(token_rows):
+            toks[b, : len(r)] = r
+        hd = np.ascontiguousarray(heads, dtype=np.int32).reshape(-1, 2)
+        nf = np.ascontiguousarray(num_frames, dtype=np.int32)
+        if nf.shape != (B,):
+            raise ValueError("num_frames must hold one entry per window")
+        plen = T + self.dims.n_audio_ctx
+        p_text = np.empty((B, plen), dtype=np.int32)
+        p_time = np.empty((B, plen), dtype=np.int32)
+        p_len = np.empty(B, dtype=np.int32)
+        probs = np.empty((B, T), dtype=np.float32)
+        as_i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+        sl = None
+        if slots is not None:
+            sl_arr = np.ascontiguousarray(slots, dtype=np.int32)
+            if sl_arr.shape != (B,):
+                raise ValueError("slots must name one resident window per token row")
+            sl = as_i(sl_arr)
+        check(self._lib.wj_whisper_align(self.handle, B, sl, as_i(toks), T, as_i(n_tok), int(n_prefix), as_i(hd), hd.shape[0],
+                                         as_i(nf), int(medfilt_width), eot, as_i(p_text), as_i(p_time), as_i(p_len),
+                                         probs.ctypes.data_as(C.POINTER(C.c_float)), None), "wj_whisper_align")
+        out = []
+        for b in range(B):
+            n = int(p_len[b])
+            out.append((p_text[b, :n].copy(), p_time[b, :n].copy(), probs[b, : int(n_tok[b]) - n_prefix - 1].copy()))
+        return out
+
     def last_decode_info(self) -> dict:
         out = (C.c_int32 * 2)()
         check(self._lib.wj_whisper_last_decode_info(self.handle, out), "wj_whisper_last_decode_info")

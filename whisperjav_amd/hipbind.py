@@ -65,6 +65,9 @@ _SIGNATURES = {
     "wj_whisper_decode_sample": (_I, [_P, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), _F,
                                       C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F),
                                       C.POINTER(_F), _P]),
+    "wj_whisper_align": (_I, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I,
+                              C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32),
+                              C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),
     "wj_whisper_last_decode_info": (_I, [_P, C.POINTER(C.c_int32)]),
     "wj_decode_open": (_I, [_P, _I, _I, _P]),
     "wj_decode_step": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _P]),

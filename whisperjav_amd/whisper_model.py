@@ -17,7 +17,8 @@ segments cut at consecutive timestamp pairs.  Beyond the drop-in call, ``transcr
 SAME per-clip procedure for many clips at once (one encoder batch + one batched decode per round),
 which is how the MI355X is kept busy: every VAD group of a scene (or file) becomes one row.
 
-Not implemented (documented in DESIGN.md): word-level timestamps (``words`` is None).
+``word_timestamps=True`` runs the device alignment pass (``wj_whisper_align``) window by window while the
+cross K/V are resident, then faster-whisper's word heuristics; ``hallucination_silence_threshold`` is not implemented.
 """
 from __future__ import annotations
 
@@ -90,6 +91,13 @@ class IdTokenizer:
     def non_speech_tokens(self) -> List[int]:
         return []
 
+    def split_to_word_tokens(self, tokens: Sequence[int], language: str = "ja"):
+        """Without a vocabulary every token renders as one ``<id>`` "word"."""
+        return [f"<{t}>" for t in tokens], [[int(t)] for t in tokens]
+
+
+_NO_SPACE_LANGUAGES = {"zh", "ja", "th", "lo", "my", "yue"}
+
 
 class HfTokenizer:
     """``tokenizer.json`` of a CTranslate2 / HF Whisper model directory via the ``tokenizers`` package."""
@@ -105,6 +113,40 @@ class HfTokenizer:
 
     def encode(self, text: str) -> List[int]:
         return self._tok.encode(text, add_special_tokens=False).ids
+
+    def split_tokens_on_unicode(self, tokens: Sequence[int]):
+        """whisper/tokenizer.py ``split_tokens_on_unicode``: a word closes when its tokens decode to valid unicode."""
+        full = self.decode(tokens)
+        bad = "\ufffd"
+        words, word_tokens, current, offset = [], [], [], 0
+        for t in tokens:
+            current.append(int(t))
+            dec = self.decode(current)
+            idx = dec.find(bad)
+            if idx < 0 or (offset + idx < len(full) and full[offset + idx] == bad):
+                words.append(dec)
+                word_tokens.append(current)
+                current = []
+                offset += len(dec)
+        return words, word_tokens
+
+    def split_to_word_tokens(self, tokens: Sequence[int], language: str = "ja"):
+        """whisper/tokenizer.py ``split_to_word_tokens`` (``tokens`` end with eot)."""
+        import string
+        words, word_tokens = self.split_tokens_on_unicode(tokens)
+        if language in _NO_SPACE_LANGUAGES:
+            return words, word_tokens
+        eot = self._tok.token_to_id("<|endoftext|>")
+        out_w, out_t = [], []
+        for sub, sub_t in zip(words, word_tokens):
+            special = eot is not None and sub_t[0] >= eot
+            if special or sub.startswith(" ") or sub.strip() in string.punctuation or not out_w:
+                out_w.append(sub)
+                out_t.append(list(sub_t))
+            else:
+                out_w[-1] += sub
+                out_t[-1].extend(sub_t)
+        return out_w, out_t
 
     def non_speech_tokens(self) -> List[int]:
         symbols = list('"#()*+/:;<=>@[\\]^_`{|}~「」『』')
@@ -208,6 +250,7 @@ class _ClipState:
     prompt_reset_since: int = 0
     segments: List[Segment] = field(default_factory=list)
     next_id: int = 0
+    last_speech: float = 0.0
 
     @property
     def active(self) -> bool:
@@ -283,9 +326,12 @@ class HipWhisperModel:
         o = TranscribeOptions(**kw)
         if o.length_penalty is None and self.FLAVOR == "fw":
             o.length_penalty = 1.0
-        if o.word_timestamps:
-            self._warn_once("words", "word_timestamps=True: word-level alignment is not implemented on the HIP path "
-                                     "yet; segments carry start/end/text/avg_logprob and words=None")
+        if o.prepend_punctuations is None:
+            o.prepend_punctuations = "\"'“¿([{-"
+        if o.append_punctuations is None:
+            o.append_punctuations = "\"'.。,，!！?？:：”)]}、"
+        if o.word_timestamps and o.hallucination_silence_threshold is not None:
+            self._warn_once("hst", "hallucination_silence_threshold is not implemented on the HIP path; ignored")
         if o.vad_filter:
             raise ValueError("vad_filter=True is not supported: WhisperJAV runs its own speech segmenter "
                              "(faster_whisper_pro_asr.py passes vad_filter=False)")
@@ -454,6 +500,179 @@ class HipWhisperModel:
                 final[i] = (best[0], best[1], best[2], temps[-1], best[4])  # last temperature drives the prompt reset
         return final
 
+    # ---- word timestamps ---------------------------------------------------------------------------
+    def alignment_heads(self) -> List[Tuple[int, int]]:
+        """(layer, head) pairs whose cross-attention tracks time.  A model directory may carry them in
+        ``config.json`` ("alignment_heads", CTranslate2 converter); else the published table entry of the model, else
+        whisper's default (every head of the upper half of the decoder)."""
+        if getattr(self, "_alignment_heads", None):
+            return self._alignment_heads
+        L, H = self.dims.n_text_layer, self.dims.n_text_head
+        if (L, H, self.dims.n_mels) == (32, 20, 128):     # large-v3 (generation_config.json of openai/whisper-large-v3)
+            return [(7, 0), (10, 17), (12, 18), (13, 12), (16, 1), (17, 14), (19, 11), (21, 4), (24, 1), (25, 6)]
+        return [(l, h) for l in range(L // 2, L) for h in range(H)]
+
+    def _find_alignment(self, windows: List[Tuple[int, List[int], int]], language: str) -> List[List[dict]]:
+        """``windows`` = (resident slot, text tokens, content frames) -> per window the word dicts of
+        faster-whisper ``find_alignment`` ({word, tokens, start, end, probability}; times relative to the window)."""
+        t = self.tokens
+        sot_sequence = [t.sot, t.language_token(pdims.language_index(language)), t.transcribe]
+        rows, keep = [], []
+        for i, (_, text_tokens, _) in enumerate(windows):
+            if text_tokens:
+                rows.append([*sot_sequence, t.no_timestamps, *text_tokens, t.eot])
+                keep.append(i)
+        out: List[List[dict]] = [[] for _ in windows]
+        if not rows:
+            return out
+        res = self.model.align(rows, len(sot_sequence) + 1, self.alignment_heads(), [windows[i][2] for i in keep],
+                               slots=[windows[i][0] for i in keep])
+        for i, (text_idx, time_idx, probs) in zip(keep, res):
+            text_tokens = windows[i][1]
+            words, word_tokens = self.tokenizer.split_to_word_tokens(list(text_tokens) + [t.eot], language)
+            if len(word_tokens) <= 1 or len(text_idx) == 0:
+                continue
+            bounds = np.pad(np.cumsum([len(w) for w in word_tokens[:-1]]), (1, 0))
+            jumps = np.pad(np.diff(text_idx), (1, 0), constant_values=1).astype(bool)
+            jump_times = time_idx[jumps] / (SAMPLE_RATE / HOP / INPUT_STRIDE)      # tokens_per_second = 50
+            starts, ends = jump_times[bounds[:-1]], jump_times[bounds[1:]]
+            out[i] = [dict(word=w, tokens=wt, start=float(s0), end=float(e0), probability=float(np.mean(probs[a:b])))
+                      for w, wt, s0, e0, a, b in zip(words, word_tokens, starts, ends, bounds[:-1], bounds[1:])]
+        return out
+
+    @staticmethod
+    def _merge_punctuations(alignment: List[dict], prepended: str, appended: str) -> None:
+        i, j = len(alignment) - 2, len(alignment) - 1
+        while i >= 0:
+            prev, foll = alignment[i], alignment[j]
+            if prev["word"].startswith(" ") and prev["word"].strip() in prepended:
+                foll["word"] = prev["word"] + foll["word"]
+                foll["tokens"] = prev["tokens"] + foll["tokens"]
+                prev["word"], prev["tokens"] = "", []
+            else:
+                j = i
+            i -= 1
+        i, j = 0, 1
+        while j < len(alignment):
+            prev, foll = alignment[i], alignment[j]
+            if not prev["word"].endswith(" ") and foll["word"] in appended:
+                prev["word"] = prev["word"] + foll["word"]
+                prev["tokens"] = prev["tokens"] + foll["tokens"]
+                foll["word"], foll["tokens"] = "", []
+            else:
+                i = j
+            j += 1
+
+    def _add_word_timestamps(self, windows: List[dict], o: TranscribeOptions) -> None:
+        """faster-whisper ``add_word_timestamps`` (whisper/timing.py's, which it copies) for a batch of windows.
+        Each entry: {"slot", "pieces" (the window's sub-segments), "frames", "seek", "last_speech"}; the pieces
+        gain "words" and their start/end move to the word boundaries; "last_speech" is updated."""
+        eot = self.tokens.eot
+        per_piece = [[[tk for tk in pc["tokens"] if tk < eot] for pc in w["pieces"]] for w in windows]
+        flat = [[tk for pc in pieces for tk in pc] for pieces in per_piece]
+        alignments = self._find_alignment([(w["slot"], flat[i], w["frames"]) for i, w in enumerate(windows)],
+                                          o.language or "ja")
+        for w, alignment, piece_tokens in zip(windows, alignments, per_piece):
+            durations = np.array([a["end"] - a["start"] for a in alignment])
+            durations = durations[durations.nonzero()]
+            median_duration = min(0.7, float(np.median(durations))) if len(durations) else 0.0
+            max_duration = median_duration * 2
+            if len(durations):      # truncate long words at sentence boundaries
+                marks = ".。!！?？"
+                for i in range(1, len(alignment)):
+                    if alignment[i]["end"] - alignment[i]["start"] > max_duration:
+                        if alignment[i]["word"] in marks:
+                            alignment[i]["end"] = alignment[i]["start"] + max_duration
+                        elif alignment[i - 1]["word"] in marks:
+                            alignment[i]["start"] = alignment[i]["end"] - max_duration
+            self._merge_punctuations(alignment, o.prepend_punctuations, o.append_punctuations)
+            time_offset = w["seek"] / FRAMES_PER_SECOND
+            last_speech = w["last_speech"]
+            word_index = 0
+            for pc, toks in zip(w["pieces"], piece_tokens):
+                saved, words = 0, []
+                while word_index < len(alignment) and saved < len(toks):
+                    timing = alignment[word_index]
+                    if timing["word"]:
+                        words.append(dict(word=timing["word"], start=round(time_offset + timing["start"], 2),
+                                          end=round(time_offset + timing["end"], 2), probability=timing["probability"]))
+                    saved += len(timing["tokens"])
+                    word_index += 1
+                if words:
+                    # the first (and second) word after a pause may not be longer than twice the median duration
+                    if words[0]["end"] - last_speech > median_duration * 4 and (
+                            words[0]["end"] - words[0]["start"] > max_duration
+                            or (len(words) > 1 and words[1]["end"] - words[0]["start"] > max_duration * 2)):
+                        if len(words) > 1 and words[1]["end"] - words[1]["start"] > max_duration:
+                            boundary = max(words[1]["end"] / 2, words[1]["end"] - max_duration)
+                            words[0]["end"] = words[1]["start"] = boundary
+                        words[0]["start"] = max(0, words[0]["end"] - max_duration)
+                    # prefer the segment-level start / end if the first / last word is too long
+                    if pc["start"] < words[0]["end"] and pc["start"] - 0.5 > words[0]["start"]:
+                        words[0]["start"] = max(0, min(words[0]["end"] - median_duration, pc["start"]))
+                    else:
+                        pc["start"] = words[0]["start"]
+                    if pc["end"] > words[-1]["start"] and pc["end"] + 0.5 < words[-1]["end"]:
+                        words[-1]["end"] = max(words[-1]["start"] + median_duration, pc["end"])
+                    else:
+                        pc["end"] = words[-1]["end"]
+                    last_speech = pc["end"]
+                pc["words"] = words
+            w["last_speech"] = last_speech
+
+    def _finish_windows(self, o: TranscribeOptions, batch: List["_ClipState"], sizes: List[int], decoded, slots: List[int],
+                        tb: int) -> None:
+        """Gates, timestamp slicing, word alignment (while the windows' cross K/V are resident at ``slots``), seek
+        update and segment emission for one decoded group of windows (the body of ``generate_segments``)."""
+        work = []
+        for st, size, dec, slot in zip(batch, sizes, decoded, slots):
+            toks, avg_lp, nsp, temp, cr = dec
+            time_offset = st.seek * HOP / SAMPLE_RATE
+            seg_duration = size * HOP / SAMPLE_RATE
+            if o.no_speech_threshold is not None:
+                skip = nsp > o.no_speech_threshold
+                if o.log_prob_threshold is not None and avg_lp > o.log_prob_threshold:
+                    skip = False
+                if skip:
+                    st.seek += size
+                    continue
+            prev_seek = st.seek
+            pieces, st.seek, single_ending = split_segments_by_timestamps(toks, time_offset, size, seg_duration, st.seek, tb)
+            work.append(dict(st=st, dec=dec, pieces=pieces, prev_seek=prev_seek, single_ending=single_ending,
+                             time_offset=time_offset, slot=slot, frames=size, seek=prev_seek, last_speech=st.last_speech))
+        if o.word_timestamps and work:
+            self._add_word_timestamps(work, o)
+            for w in work:
+                st = w["st"]
+                ends = [wd["end"] for pc in w["pieces"] for wd in pc.get("words", [])]
+                last_word_end = ends[-1] if ends else None
+                if not w["single_ending"] and last_word_end is not None and last_word_end > w["time_offset"]:
+                    st.seek = round(last_word_end * FRAMES_PER_SECOND)
+                if last_word_end is not None:
+                    st.last_speech = last_word_end
+        for w in work:
+            st = w["st"]
+            _, avg_lp, nsp, temp, cr = w["dec"]
+            for piece in w["pieces"]:
+                text = self.tokenizer.decode([t for t in piece["tokens"] if t < self.tokens.eot])
+                words = [Word(start=x["start"], end=x["end"], word=x["word"], probability=x["probability"])
+                         for x in piece["words"]] if "words" in piece else None
+                if piece["start"] == piece["end"] or not text.strip():
+                    if self.FLAVOR == "ow":   # whisper.transcribe keeps the slot with cleared text/tokens
+                        st.next_id += 1
+                        st.segments.append(Segment(id=st.next_id, seek=w["prev_seek"], start=piece["start"],
+                                                   end=piece["end"], text="", tokens=[], avg_logprob=avg_lp,
+                                                   compression_ratio=cr, no_speech_prob=nsp, temperature=temp,
+                                                   words=[] if words is not None else None))
+                    continue
+                st.all_tokens.extend(piece["tokens"])
+                st.next_id += 1
+                st.segments.append(Segment(id=st.next_id, seek=w["prev_seek"], start=piece["start"], end=piece["end"],
+                                           text=text, tokens=piece["tokens"], avg_logprob=avg_lp,
+                                           compression_ratio=cr, no_speech_prob=nsp, words=words, temperature=temp))
+            if not o.condition_on_previous_text or temp > o.prompt_reset_on_temperature:
+                st.prompt_reset_since = len(st.all_tokens)
+
     # ---- public API ------------------------------------------------------------------------------
     def transcribe(self, audio: np.ndarray, **kwargs) -> Tuple[Iterator[Segment], TranscriptionInfo]:
         """faster-whisper's call contract for ONE clip: ``(segment iterator, info)``."""
@@ -504,45 +723,14 @@ class HipWhisperModel:
                     groups.setdefault(len(p), []).append((batch[j], p, j))
                 if len(groups) == 1:
                     decoded = self._decode_windows(prompts, o, suppress)
+                    self._finish_windows(o, batch, sizes, decoded, list(range(len(batch))), tb)
                 else:   # heterogeneous prompt lengths: decode group by group against re-encoded slots
-                    decoded = [None] * len(batch)
                     for _, members in groups.items():
                         idx = [j for _, _, j in members]
                         self.model.encode(mel[idx].contiguous())
                         res = self._decode_windows([p for _, p, _ in members], o, suppress)
-                        for j, r in zip(idx, res):
-                            decoded[j] = r
-                for j, st in enumerate(batch):
-                    toks, avg_lp, nsp, temp, cr = decoded[j]
-                    size = sizes[j]
-                    time_offset = st.seek * HOP / SAMPLE_RATE
-                    seg_duration = size * HOP / SAMPLE_RATE
-                    if o.no_speech_threshold is not None:
-                        skip = nsp > o.no_speech_threshold
-                        if o.log_prob_threshold is not None and avg_lp > o.log_prob_threshold:
-                            skip = False
-                        if skip:
-                            st.seek += size
-                            continue
-                    prev_seek = st.seek
-                    pieces, st.seek, _ = split_segments_by_timestamps(toks, time_offset, size, seg_duration, st.seek, tb)
-                    for piece in pieces:
-                        text = self.tokenizer.decode([t for t in piece["tokens"] if t < self.tokens.eot])
-                        if piece["start"] == piece["end"] or not text.strip():
-                            if self.FLAVOR == "ow":   # whisper.transcribe keeps the slot with cleared text/tokens
-                                st.next_id += 1
-                                st.segments.append(Segment(id=st.next_id, seek=prev_seek, start=piece["start"],
-                                                           end=piece["end"], text="", tokens=[], avg_logprob=avg_lp,
-                                                           compression_ratio=cr, no_speech_prob=nsp, temperature=temp))
-                            continue
-                        st.all_tokens.extend(piece["tokens"])
-                        st.next_id += 1
-                        st.segments.append(Segment(id=st.next_id, seek=prev_seek, start=piece["start"], end=piece["end"],
-                                                   text=text, tokens=piece["tokens"], avg_logprob=avg_lp,
-                                                   compression_ratio=cr, no_speech_prob=nsp, words=None,
-                                                   temperature=temp))
-                    if not o.condition_on_previous_text or temp > o.prompt_reset_on_temperature:
-                        st.prompt_reset_since = len(st.all_tokens)
+                        self._finish_windows(o, [batch[j] for j in idx], [sizes[j] for j in idx], res,
+                                             list(range(len(idx))), tb)
         infos = [TranscriptionInfo(language=o.language or "ja", language_probability=1.0, duration=st.duration,
                                    duration_after_vad=st.duration, transcription_options=dict(kwargs))
                  for st in states]
@@ -588,5 +776,8 @@ class HipOpenAIWhisperModel(HipWhisperModel):
                      "temperature": s.temperature, "avg_logprob": s.avg_logprob,
                      "compression_ratio": s.compression_ratio, "no_speech_prob": s.no_speech_prob}
                     for i, s in enumerate(segs[0])]
+        for d, s in zip(segments, segs[0]):
+            if s.words is not None:     # whisper.transcribe: segment["words"] = [{word, start, end, probability}]
+                d["words"] = [{"word": w.word, "start": w.start, "end": w.end, "probability": w.probability} for w in s.words]
         tokens = [t for s in segs[0] for t in s.tokens if t < self.tokens.eot]
         return {"text": self.tokenizer.decode(tokens), "segments": segments, "language": infos[0].language}
