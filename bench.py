@@ -145,7 +145,7 @@ def run_cfg3(args, info, dims):
     kw = dict(task="transcribe", language="ja", beam_size=5, best_of=2, patience=1.2, temperature=[0.0],
               repetition_penalty=1.5, no_repeat_ngram_size=3, condition_on_previous_text=False, suppress_blank=True,
               max_initial_timestamp=0.0, no_speech_threshold=None, log_prob_threshold=-1.0,
-              max_new_tokens=args.max_new_tokens, word_timestamps=False)
+              max_new_tokens=args.max_new_tokens, word_timestamps=bool(args.word_timestamps))
 
     def once():
         t0 = time.perf_counter()
@@ -168,7 +168,9 @@ def run_cfg3(args, info, dims):
         out, _ = model.transcribe_many(clips, **kw)
         t3 = time.perf_counter()
         from whisperjav_amd import search as _search
-        return {"beam_timing": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in _search.LAST_TIMING.items()},
+        calls = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in c.items()} for c in _search.TIMING_LOG]
+        _search.TIMING_LOG.clear()
+        return {"beam_timing": calls,
                 "scenes": len(scenes), "groups": len(clips), "segments": sum(len(x) for x in out),
                 "speech_s": sum(len(c) for c in clips) / 16000.0, "t_scene": t1 - t0, "t_vad": t2 - t1, "t_asr": t3 - t2}
 
@@ -212,6 +214,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--minutes", type=float, default=10.0, help="cfg3: synthetic audio length")
     ap.add_argument("--max-new-tokens", type=int, default=64, help="cfg3: transcribe(max_new_tokens=...)")
+    ap.add_argument("--word-timestamps", type=int, default=0, help="cfg3: transcribe(word_timestamps=...)")
     args = ap.parse_args()
 
     info = sharding.init_distributed()

@@ -685,12 +685,15 @@ def test_sampling_first_token_frequencies_follow_softmax(hip):
 # ---------------------------------------------------------------------------------------------
 # word-timestamp alignment (wj_whisper_align vs oracle/alignment.py = whisper/timing.py restated)
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prefill", [1, 0])
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
-def test_alignment_matches_oracle(hip, dtype):
+def test_alignment_matches_oracle(hip, dtype, prefill):
     """Teacher-forced pass + softmax / normalise / median filter / head mean / DTW on the device.  float32: the DTW
     path (integer token / frame indices) is identical to the oracle's and the text-token probabilities agree to
     1e-4; bfloat16 (throughput mode): the path may wander by a few 20 ms frames."""
     from oracle import alignment
+    from whisperjav_amd import hipbind
+    hipbind.tune("align_prefill", prefill)      # 1: one full-sequence decoder pass (default), 0: token by token
     d, oracle, model = _engine_and_oracle(dtype, max_batch=3)
     mel = torch.from_numpy(helpers.synth_mel(3, d.n_mels, seed=41))
     model.encode(mel.cuda())
@@ -718,7 +721,8 @@ def test_alignment_matches_oracle(hip, dtype):
         else:   # first frame of every token row, compared in 20 ms units
             first = lambda a, b: np.array([b[np.argmax(a == k)] for k in range(len(texts[w]) + 1)])   # noqa: E731
             worst_t = max(worst_t, int(np.abs(first(g_ti, g_fi) - first(ti, fi)).max()))
-    _diag("alignment", {"dtype": dtype, "max_prob_diff": worst_p, "max_token_start_shift_frames": worst_t})
+    hipbind.tune("align_prefill", 1)
+    _diag("alignment", {"dtype": dtype, "prefill": prefill, "max_prob_diff": worst_p, "max_token_start_shift_frames": worst_t})
     assert worst_p < (1e-4 if dtype == "float32" else 2e-2), worst_p
     assert worst_t <= 25, worst_t
     model.close()

@@ -193,6 +193,43 @@ __global__ __launch_bounds__(256) void align_token_prob_kernel(const float* logi
   }
 }
 
+// full-sequence pass: logits row i of the chunk is global row row0 + i = (window, t); the probability of the token at
+// t + 1 goes to prob_out[window][t - n0] for n0 <= t < n_tok[window] - 2 (the text-token predictions)
+__global__ __launch_bounds__(256) void align_token_prob_seq_kernel(const float* logits, int64_t ldl, int limit,
+                                                                   const int32_t* tokens, int64_t tok_stride, int row0, int Tp,
+                                                                   int n0, const int32_t* n_tok, float* prob_out) {
+  const int r = row0 + blockIdx.x, w = r / Tp, t = r % Tp;
+  if (t < n0 || t >= n_tok[w] - 2) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = logits + (int64_t)blockIdx.x * ldl;
+  __shared__ float red[4];
+  float mx = -INFINITY;
+  for (int v = tid; v < limit; v += 256) mx = fmaxf(mx, x[v]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int v = tid; v < limit; v += 256) sum += expf(x[v] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    const int tok = tokens[(int64_t)w * tok_stride + t + 1];
+    const float total = (red[0] + red[1]) + (red[2] + red[3]);
+    prob_out[(int64_t)w * Tp + (t - n0)] = (tok >= 0 && tok < limit) ? expf(x[tok] - mx) / total : 0.f;
+  }
+}
+
+int launch_align_token_prob_seq(const float* logits, int64_t ldl, int limit, const int32_t* tokens, int64_t tok_stride,
+                                int row0, int rows, int Tp, int n0, const int32_t* n_tok, float* prob_out, hipStream_t s) {
+  hipLaunchKernelGGL(align_token_prob_seq_kernel, dim3(rows), dim3(256), 0, s, logits, ldl, limit, tokens, tok_stride, row0, Tp,
+                     n0, n_tok, prob_out);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
 int launch_align_token_prob(const float* logits, int64_t ldl, int limit, const int32_t* tokens, int64_t tok_stride,
                             const int* pos_ptr, int n0, float* prob_out, int tmax, int R, hipStream_t s) {
   hipLaunchKernelGGL(align_token_prob_kernel, dim3(R), dim3(256), 0, s, logits, ldl, limit, tokens, tok_stride, pos_ptr, n0,

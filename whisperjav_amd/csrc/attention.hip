@@ -282,8 +282,8 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kk = lane >> 3, c = lane & 7;
   const int h = blockIdx.x, gi = blockIdx.y;
-  const int n_keys = a.n_keys_ptr ? (*a.n_keys_ptr + 1) : a.n_keys;
-  const int kpad = (n_keys + 7) & ~7;
+  const int n_keys = (SELF && a.seq_tp > 0) ? gi % a.seq_tp + 1 : (a.n_keys_ptr ? (*a.n_keys_ptr + 1) : a.n_keys);
+  const int kpad = (((SELF && a.seq_tp > 0) ? a.seq_tp : n_keys) + 7) & ~7;
   float* sc = smem;                         // [NB][kpad]
   float* red_m = sc + NB * kpad;            // [NW][NB]
   float* red_l = red_m + NW * NB;           // [NW][NB]
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = min(j0 + u * NW * 8 + kk, n_old - 1);
-      const int64_t prow = SELF ? (rmap ? rmap[j] : gi) : grp;
+      const int64_t prow = SELF ? (a.seq_tp > 0 ? gi / a.seq_tp : (rmap ? rmap[j] : gi)) : grp;
       ld8(Kb + ((prow * a.H + h) * a.kv_stride + j) * 64 + c * 8, kv[u]);
     }
 #pragma unroll
@@ -403,9 +403,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
     if (a.dump) {   // alignment heads hand their scaled scores to the word-timestamp pass
       const int sel = a.dump_sel[h];
       if (sel >= 0) {
-        const int pos = *a.dump_pos_ptr;
         for (int b = 0; b < NB; ++b) {
-          float* dst = a.dump + ((((int64_t)(a.dump_row_base + gi * NB + b) * a.dump_nsel + sel) * a.dump_tmax + pos) * n_keys);
+          const int64_t drow = a.dump_chunks > 0 ? gi / a.dump_chunks : a.dump_row_base + gi * NB + b;
+          const int pos = a.dump_chunks > 0 ? (gi % a.dump_chunks) * NB + b : *a.dump_pos_ptr;
+          float* dst = a.dump + (((drow * a.dump_nsel + sel) * a.dump_tmax + pos) * n_keys);
           for (int j = tid; j < n_keys; j += NW * 64) dst[j] = sc[b * kpad + j];
         }
       }
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int j = min(j0 + u * NW * 8 + kk, n_old - 1);
-      const int64_t prow = SELF ? (rmap ? rmap[j] : gi) : grp;
+      const int64_t prow = SELF ? (a.seq_tp > 0 ? gi / a.seq_tp : (rmap ? rmap[j] : gi)) : grp;
       ld8(Vb + ((prow * a.H + h) * a.kv_stride + j) * 64 + c * 8, vv[u]);
     }
 #pragma unroll
@@ -589,9 +590,10 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
   if (a.dump) {   // alignment heads hand their scaled scores to the word-timestamp pass
     const int sel = a.dump_sel[h];
     if (sel >= 0) {
-      const int pos = *a.dump_pos_ptr;
       for (int b = 0; b < NB; ++b) {
-        float* dst = a.dump + ((((int64_t)(a.dump_row_base + gi * NB + b) * a.dump_nsel + sel) * a.dump_tmax + pos) * n_keys);
+        const int64_t drow = a.dump_chunks > 0 ? gi / a.dump_chunks : a.dump_row_base + gi * NB + b;
+        const int pos = a.dump_chunks > 0 ? (gi % a.dump_chunks) * NB + b : *a.dump_pos_ptr;
+        float* dst = a.dump + (((drow * a.dump_nsel + sel) * a.dump_tmax + pos) * n_keys);
         for (int j = tid; j < n_keys; j += 256) dst[j] = sc[b * kpad + j];
       }
     }
@@ -667,10 +669,10 @@ static int launch_dec_inst(const DecAttnArgs& a, int kmax, hipStream_t s) {
 
 template <typename T>
 static int launch_dec_T(const DecAttnArgs& a, hipStream_t s) {
-  const bool self = a.n_keys_ptr != nullptr;
+  const bool self = a.n_keys_ptr != nullptr || a.seq_tp > 0;
   if (self) {
     if (a.nb != 1) { set_error("attention_dec: self attention expects nb == 1"); return WJ_E_INVALID; }
-    return launch_dec_inst<T, 1, 1, true>(a, a.kv_stride, s);
+    return launch_dec_inst<T, 1, 1, true>(a, a.seq_tp > 0 ? a.seq_tp : a.kv_stride, s);
   }
   switch (a.nb) {
     case 1: return launch_dec_inst<T, 1, 4, false>(a, a.n_keys, s);
@@ -687,7 +689,7 @@ static int launch_dec_T(const DecAttnArgs& a, hipStream_t s) {
 int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s) {
   if (a.G <= 0) return WJ_OK;
   if (a.vt_stride > 0) {
-    if (dtype != WJ_BF16 || a.n_keys_ptr) { set_error("attention_dec: transposed V is the bf16 cross-attention layout"); return WJ_E_INVALID; }
+    if (dtype != WJ_BF16 || a.n_keys_ptr || a.seq_tp) { set_error("attention_dec: transposed V is the bf16 cross-attention layout"); return WJ_E_INVALID; }
     return launch_cross_mfma(a, s);
   }
   return dtype == WJ_F32 ? launch_dec_T<float>(a, s) : launch_dec_T<bf16_t>(a, s);

@@ -93,6 +93,7 @@ struct Tunables {
   int dec_rows_ks_fc2 = 8;
   int dec_ms_stages = 0;    // LDS-DMA stages of the decode tile GEMM (0 = the 2-stage encoder kernel; 3-5 measured equal)
   int dec_fuse_reduce = 1;  // attention kernels consume the q / qkv split-K slices directly (no reduce launch)
+  int align_prefill = 1;    // word-timestamp alignment as one full-sequence decoder pass (0: token by token)
   int dec_cross_mfma = 1;   // bf16 models: cross V kept transposed, cross attention on the matrix cores (read at create)
 };
 static Tunables g_tune;
@@ -440,6 +441,92 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   return WJ_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// decoder: full-sequence teacher-forced pass (word-timestamp alignment).  Rows = windows x Tp positions, run
+// through the layers as ONE batch: the decoder weights are streamed once instead of once per token and a
+// window's cross K/V is read Tp/16 times instead of Tp times.  Activations live in the encoder workspaces
+// (x, h, q, attn, ff: sized for batch x 1500 rows), k/v go to the self-attention cache rows of the windows.
+// ------------------------------------------------------------------------------------------------
+static int run_decoder_seq(wj_whisper* m, int B, int Tp, int n0, const int32_t* d_ntok, float* d_prob, int eot,
+                           const int32_t* d_groups, int nb, hipStream_t s) {
+  const wj_whisper_dims& d = m->d;
+  const int D = d.n_text_state, H = d.n_text_head, dt = m->dtype;
+  const int M = B * Tp;
+  float* x = m->x;
+  void *h = m->h, *q = m->q, *attn = m->attn, *ff = m->ff;
+  WJ_TRY(launch_embed_seq(dt, m->W(WJ_T_DEC_TOK_EMB), m->F(WJ_T_DEC_POS), m->tokens, m->tok_stride, Tp, x, B, D, s));
+  for (int l = 0; l < d.n_text_layer; ++l) {
+    const int b0 = m->dec_base(l);
+    void* sk = m->at(m->self_k, l * m->self_layer_elems());
+    void* sv = m->at(m->self_v, l * m->self_layer_elems());
+    WJ_TRY(launch_layernorm(dt, x, m->F(b0 + WJ_TD_LN1_W), m->F(b0 + WJ_TD_LN1_B), h, M, D, s));
+    {
+      GemmArgs g;
+      g.A = h; g.lda = D; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
+      g.M = M; g.N = 3 * D; g.K = D; g.out = q; g.out2 = sk; g.out3 = sv;
+      g.D = D; g.H = H; g.cache_len = d.n_text_ctx; g.seq_tp = Tp;
+      WJ_TRY(launch_gemm(dt, EPI_QKV_DEC, g, s));
+    }
+    {
+      DecAttnArgs a;
+      a.q = q; a.K = sk; a.V = sv; a.out = attn; a.G = M; a.nb = 1; a.H = H; a.kv_stride = d.n_text_ctx; a.seq_tp = Tp;
+      WJ_TRY(launch_attention_dec(dt, a, s));
+    }
+    {
+      GemmArgs g;
+      g.A = attn; g.lda = D; g.W = m->W(b0 + WJ_TD_OUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_OUT_B);
+      g.M = M; g.N = D; g.K = D; g.out = x; g.ldc = D;
+      WJ_TRY(launch_gemm(dt, EPI_RESID_F32, g, s));
+    }
+    WJ_TRY(launch_layernorm(dt, x, m->F(b0 + WJ_TD_LNX_W), m->F(b0 + WJ_TD_LNX_B), h, M, D, s));
+    {
+      GemmArgs g;
+      g.A = h; g.lda = D; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
+      g.M = M; g.N = D; g.K = D; g.out = q; g.ldc = D;
+      WJ_TRY(launch_gemm(dt, EPI_T, g, s));
+    }
+    {
+      DecAttnArgs a;
+      a.q = q; a.out = attn; a.G = M / nb; a.nb = nb; a.H = H; a.n_keys = d.n_audio_ctx; a.kv_stride = d.n_audio_ctx;
+      a.K = m->at(m->cross_k, l * m->cross_layer_elems());
+      a.V = m->at(m->cross_v, l * m->cross_v_layer_elems());
+      a.vt_stride = m->cross_tpad;
+      a.group_of = d_groups;
+      a.dump = m->dump_qk; a.dump_sel = m->align_sel + (int64_t)l * H; a.dump_nsel = m->dump_nsel; a.dump_tmax = Tp;
+      a.dump_chunks = Tp / nb;
+      WJ_TRY(launch_attention_dec(dt, a, s));
+    }
+    {
+      GemmArgs g;
+      g.A = attn; g.lda = D; g.W = m->W(b0 + WJ_TD_COUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_COUT_B);
+      g.M = M; g.N = D; g.K = D; g.out = x; g.ldc = D;
+      WJ_TRY(launch_gemm(dt, EPI_RESID_F32, g, s));
+    }
+    WJ_TRY(launch_layernorm(dt, x, m->F(b0 + WJ_TD_LN2_W), m->F(b0 + WJ_TD_LN2_B), h, M, D, s));
+    {
+      GemmArgs g;
+      g.A = h; g.lda = D; g.W = m->W(b0 + WJ_TD_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_FC1_B);
+      g.M = M; g.N = 4 * D; g.K = D; g.out = ff; g.ldc = 4 * D;
+      WJ_TRY(launch_gemm(dt, EPI_GELU_T, g, s));
+      GemmArgs g2;
+      g2.A = ff; g2.lda = 4 * D; g2.W = m->W(b0 + WJ_TD_FC2_W); g2.ldw = 4 * D; g2.bias = m->F(b0 + WJ_TD_FC2_B);
+      g2.M = M; g2.N = D; g2.K = 4 * D; g2.out = x; g2.ldc = D;
+      WJ_TRY(launch_gemm(dt, EPI_RESID_F32, g2, s));
+    }
+  }
+  WJ_TRY(launch_layernorm(dt, x, m->F(WJ_T_DEC_LN_W), m->F(WJ_T_DEC_LN_B), h, M, D, s));
+  // text-token probabilities: logits in chunks of max_rows rows (the logits buffer is sized for decode steps)
+  for (int r0 = 0; r0 < M; r0 += m->max_rows) {
+    const int rows = min(m->max_rows, M - r0);
+    GemmArgs g;
+    g.A = m->at(h, (int64_t)r0 * D); g.lda = D; g.W = m->W(WJ_T_DEC_TOK_EMB); g.ldw = D;
+    g.M = rows; g.N = d.n_vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
+    WJ_TRY(launch_gemm(dt, EPI_F32, g, s));
+    WJ_TRY(launch_align_token_prob_seq(m->logits, m->ldl, eot, m->tokens, m->tok_stride, r0, rows, Tp, n0, d_ntok, d_prob, s));
+  }
+  return WJ_OK;
+}
+
 __global__ void init_rows_kernel(int32_t* map0, int32_t* map1, int R, int stride) {
   const int r = blockIdx.x;
   for (int j = threadIdx.x; j < stride; j += 256) {
@@ -564,6 +651,7 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "gemm_big")) g_gemm_big = value;
   else if (!strcmp(key, "dec_ms_stages")) g_tune.dec_ms_stages = value;
   else if (!strcmp(key, "dec_fuse_reduce")) g_tune.dec_fuse_reduce = value;
+  else if (!strcmp(key, "align_prefill")) g_tune.align_prefill = value;
   else if (!strcmp(key, "dec_rows")) g_tune.dec_rows = value;
   else if (!strcmp(key, "dec_rows_max_m")) g_tune.dec_rows_max_m = value;
   else if (!strcmp(key, "dec_rows_ks_attn")) g_tune.dec_rows_ks_attn = value;
@@ -893,9 +981,14 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
   WJ_REQUIRE(m && tokens_host && n_tokens_host && heads_host && num_frames_host && path_text_out && path_time_out &&
              path_len_out && token_prob_out, "wj_whisper_align: NULL argument");
   const wj_whisper_dims& d = m->d;
-  const int L = d.n_text_layer, H = d.n_text_head, nctx = d.n_audio_ctx, T = n_tokens_max, n0 = n_prefix - 1;
+  const int L = d.n_text_layer, H = d.n_text_head, nctx = d.n_audio_ctx, n0 = n_prefix - 1;
   WJ_REQUIRE(batch >= 1 && batch <= m->max_batch && batch <= m->max_rows, "align: batch %d outside 1..%d", batch, m->max_batch);
-  WJ_REQUIRE(T >= n_prefix + 1 && T <= d.n_text_ctx, "align: %d tokens per window outside %d..%d", T, n_prefix + 1, d.n_text_ctx);
+  WJ_REQUIRE(n_tokens_max >= n_prefix + 1 && n_tokens_max <= d.n_text_ctx, "align: %d tokens per window outside %d..%d",
+             n_tokens_max, n_prefix + 1, d.n_text_ctx);
+  // full-sequence pass: positions padded to a multiple of 16 (the cross-attention kernels take 16 / 8 query rows
+  // of a window per workgroup); needs the sequence to fit the encoder workspaces
+  const bool prefill = g_tune.align_prefill && (n_tokens_max + 15) / 16 * 16 <= 512 && (n_tokens_max + 15) / 16 * 16 <= d.n_audio_ctx;
+  const int T = prefill ? (n_tokens_max + 15) / 16 * 16 : n_tokens_max;     // rows of the score / matrix buffers per window
   WJ_REQUIRE(n_prefix >= 2 && n_heads >= 1 && n_heads <= L * H, "align: bad prefix length / head count");
   WJ_REQUIRE(eot > 0 && eot <= d.n_vocab, "align: eot id out of range");
   std::vector<int32_t> sel((size_t)L * H, -1), nf2(batch);
@@ -906,8 +999,8 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
     sel[(size_t)l * H + h] = i;
   }
   for (int b = 0; b < batch; ++b) {
-    WJ_REQUIRE(n_tokens_host[b] >= n_prefix + 1 && n_tokens_host[b] <= T, "align: window %d has %d tokens (prefix %d + eot .. %d)", b,
-               n_tokens_host[b], n_prefix, T);
+    WJ_REQUIRE(n_tokens_host[b] >= n_prefix + 1 && n_tokens_host[b] <= n_tokens_max, "align: window %d has %d tokens (prefix %d + eot .. %d)", b,
+               n_tokens_host[b], n_prefix, n_tokens_max);
     WJ_REQUIRE(num_frames_host[b] >= 2 && num_frames_host[b] / 2 <= nctx, "align: window %d: %d feature frames", b, num_frames_host[b]);
     nf2[b] = num_frames_host[b] / 2;
     if (slots_host) WJ_REQUIRE(slots_host[b] >= 0 && slots_host[b] < m->max_batch, "align: window slot %d out of range", slots_host[b]);
@@ -950,12 +1043,24 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
   {
     std::vector<int32_t> hist((size_t)R * m->tok_stride, eot);
     for (int r = 0; r < R; ++r)
-      for (int j = 0; j < T; ++j) hist[(size_t)r * m->tok_stride + j] = tokens_host[(size_t)r * T + j];
+      for (int j = 0; j < n_tokens_max; ++j) hist[(size_t)r * m->tok_stride + j] = tokens_host[(size_t)r * n_tokens_max + j];
     WJ_HIP(hipMemcpyAsync(m->tokens, hist.data(), sizeof(int32_t) * hist.size(), hipMemcpyHostToDevice, s));
     WJ_HIP(hipStreamSynchronize(s));   // `hist`, `sel`, `nf2` go out of scope / are reused
   }
   m->dump_qk = qk; m->dump_nsel = n_heads; m->dump_tmax = T;
   struct Guard { wj_whisper* m; ~Guard() { m->dump_qk = nullptr; m->use_slots = false; } } guard{m};
+  if (prefill) {
+    const int nb = m->dtype == WJ_BF16 && m->cross_tpad > 0 ? 16 : 8;     // query rows of a window per cross-attention workgroup
+    const int chunks = T / nb;
+    std::vector<int32_t> groups((size_t)batch * chunks);
+    for (int b = 0; b < batch; ++b)
+      for (int c = 0; c < chunks; ++c) groups[(size_t)b * chunks + c] = slots_host ? slots_host[b] : b;
+    int32_t* d_groups = reinterpret_cast<int32_t*>(trace);                // the trace is written after the pass: borrow its head
+    WJ_REQUIRE(sizeof(int32_t) * groups.size() <= b_tr, "align: group table does not fit its scratch");
+    WJ_HIP(hipMemcpyAsync(d_groups, groups.data(), sizeof(int32_t) * groups.size(), hipMemcpyHostToDevice, s));
+    WJ_HIP(hipStreamSynchronize(s));
+    WJ_TRY(run_decoder_seq(m, batch, T, n0, d_ntok, d_prob, eot, d_groups, nb, s));
+  } else
   // teacher-forced pass: position t reads token t of the history; logits only where a text token is predicted
   for (int t = 0; t < T; ++t) {
     const bool want = t >= n0 && t + 1 < T;
@@ -965,10 +1070,15 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
     WJ_TRY(launch_advance_pos(m->pos, s));
   }
   WJ_TRY(launch_align_post(qk, matrix, trace, d_ntok, d_nf2, R, n_heads, T, nctx, n0, medfilt_width, p_text, p_time, d_plen, s));
-  WJ_HIP(hipMemcpyAsync(path_text_out, p_text, sizeof(int32_t) * (size_t)batch * plen, hipMemcpyDeviceToHost, s));
-  WJ_HIP(hipMemcpyAsync(path_time_out, p_time, sizeof(int32_t) * (size_t)batch * plen, hipMemcpyDeviceToHost, s));
+  // device rows are T wide; the ABI's are n_tokens_max wide
+  const size_t plen_out = (size_t)n_tokens_max + nctx;
+  WJ_HIP(hipMemcpy2DAsync(path_text_out, sizeof(int32_t) * plen_out, p_text, sizeof(int32_t) * plen, sizeof(int32_t) * plen_out,
+                          batch, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpy2DAsync(path_time_out, sizeof(int32_t) * plen_out, p_time, sizeof(int32_t) * plen, sizeof(int32_t) * plen_out,
+                          batch, hipMemcpyDeviceToHost, s));
   WJ_HIP(hipMemcpyAsync(path_len_out, d_plen, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
-  WJ_HIP(hipMemcpyAsync(token_prob_out, d_prob, sizeof(float) * (size_t)batch * T, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpy2DAsync(token_prob_out, sizeof(float) * n_tokens_max, d_prob, sizeof(float) * T, sizeof(float) * n_tokens_max,
+                          batch, hipMemcpyDeviceToHost, s));
   WJ_HIP(hipStreamSynchronize(s));
   return WJ_OK;
 }

@@ -78,9 +78,10 @@ __device__ __forceinline__ void epi_nm(const GemmArgs& g, int z, int m, int n, f
         st4(reinterpret_cast<T*>(g.out) + (int64_t)m * g.D + nn, v);
       } else {
         const int h = nn >> 6, dd = nn & 63;
-        const int pos = *g.pos_ptr;
+        const int pos = g.seq_tp ? m % g.seq_tp : *g.pos_ptr;
+        const int64_t crow = g.seq_tp ? m / g.seq_tp : m;
         T* base = reinterpret_cast<T*>(which == 1 ? g.out2 : g.out3);
-        st4(base + (((int64_t)m * g.H + h) * g.cache_len + pos) * 64 + dd, v);
+        st4(base + ((crow * g.H + h) * g.cache_len + pos) * 64 + dd, v);
       }
     }
   }

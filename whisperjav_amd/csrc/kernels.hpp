@@ -36,6 +36,7 @@ struct GemmArgs {
   const int* pos_ptr = nullptr;
   int cache_len = 0;
   int ksplit = 1;               // EPI_PARTIAL_F32: K is cut into ksplit slices (grid.z resp. grid.y)
+  int seq_tp = 0;               // EPI_QKV_DEC, > 0: row m is position m % seq_tp of cache row m / seq_tp (full-sequence pass)
 };
 
 // variant: 0 = auto; 1 = tiled MFMA kernel (default staging); 2 = skinny (decode) kernel;
@@ -56,6 +57,8 @@ int launch_layernorm_resid(int dtype, float* x, const float* partial, int ksplit
 // mel f32 [B][n_mels][frames] -> engine layout T [B][frames+2][n_mels] (row 0 and frames+1 stay zero)
 int launch_mel_to_rows(int dtype, const float* mel, void* out, int B, int n_mels, int frames, hipStream_t s);
 // decoder embedding: x[r][:] = tok_emb[token[r]][:] + pos_emb[*pos][:]
+int launch_embed_seq(int dtype, const void* tok_emb, const float* pos_emb, const int32_t* tokens, int64_t tok_stride,
+                     int Tp, float* x, int B, int D, hipStream_t s);
 int launch_embed(int dtype, const void* tok_emb, const float* pos_emb, const int32_t* tokens, int64_t tok_stride,
                  const int* pos_ptr, float* x, int R, int D, hipStream_t s);
 int launch_f32_to_T(int dtype, const float* in, void* out, int64_t n, hipStream_t s);
@@ -93,6 +96,10 @@ struct DecAttnArgs {
   const int32_t* dump_sel = nullptr;   // [H] device
   const int* dump_pos_ptr = nullptr;
   int dump_nsel = 0, dump_tmax = 0, dump_row_base = 0;
+  // Full-sequence (teacher-forced) pass.  Self attention: seq_tp > 0 -> query row g is position g % seq_tp of cache
+  // row g / seq_tp and sees keys 0..position.  Cross attention dump: dump_chunks > 0 -> group g is chunk
+  // g % dump_chunks of window g / dump_chunks, query b of it is position chunk * nb + b.
+  int seq_tp = 0, dump_chunks = 0;
 };
 extern int g_dec_cross_u;
 extern int g_gemm_big;
@@ -101,6 +108,8 @@ int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s);
 // ---------------- word-timestamp alignment (align.hip) ------------------------------------------------
 int launch_align_token_prob(const float* logits, int64_t ldl, int limit, const int32_t* tokens, int64_t tok_stride,
                             const int* pos_ptr, int n0, float* prob_out, int tmax, int R, hipStream_t s);
+int launch_align_token_prob_seq(const float* logits, int64_t ldl, int limit, const int32_t* tokens, int64_t tok_stride,
+                                int row0, int rows, int Tp, int n0, const int32_t* n_tok, float* prob_out, hipStream_t s);
 int launch_align_post(float* qk, float* matrix, int8_t* trace, const int32_t* n_tok, const int32_t* nf2, int R, int nsel,
                       int tmax, int nctx, int n0, int width, int32_t* path_text, int32_t* path_time, int32_t* path_len,
                       hipStream_t s);

@@ -171,6 +171,30 @@ __global__ __launch_bounds__(256) void embed_kernel(const T* __restrict__ emb, c
   for (int c = threadIdx.x; c < D; c += 256) x[(int64_t)r * D + c] = Elem<T>::ld(e + c) + p[c];
 }
 
+// full-sequence pass: row r = window * Tp + t embeds token t of the window's history at position t
+template <typename T>
+__global__ __launch_bounds__(256) void embed_seq_kernel(const T* __restrict__ emb, const float* __restrict__ pos_emb,
+                                                        const int32_t* __restrict__ tokens, int64_t tok_stride, int Tp,
+                                                        float* __restrict__ x, int D) {
+  const int r = blockIdx.x, w = r / Tp, t = r % Tp;
+  const int tok = tokens[(int64_t)w * tok_stride + t];
+  const T* e = emb + (int64_t)tok * D;
+  const float* p = pos_emb + (int64_t)t * D;
+  for (int c = threadIdx.x; c < D; c += 256) x[(int64_t)r * D + c] = Elem<T>::ld(e + c) + p[c];
+}
+
+int launch_embed_seq(int dtype, const void* tok_emb, const float* pos_emb, const int32_t* tokens, int64_t tok_stride,
+                     int Tp, float* x, int B, int D, hipStream_t s) {
+  if (dtype == WJ_F32)
+    hipLaunchKernelGGL(embed_seq_kernel<float>, dim3(B * Tp), dim3(256), 0, s, (const float*)tok_emb, pos_emb, tokens,
+                       tok_stride, Tp, x, D);
+  else
+    hipLaunchKernelGGL(embed_seq_kernel<bf16_t>, dim3(B * Tp), dim3(256), 0, s, (const bf16_t*)tok_emb, pos_emb, tokens,
+                       tok_stride, Tp, x, D);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
 int launch_embed(int dtype, const void* tok_emb, const float* pos_emb, const int32_t* tokens, int64_t tok_stride,
                  const int* pos_ptr, float* x, int R, int D, hipStream_t s) {
   if (dtype == WJ_F32)

@@ -90,6 +90,7 @@ def ngram_bans(history: Sequence[int], n: int) -> List[int]:
 
 
 LAST_TIMING: dict = {}     # wall-clock split of the most recent beam_search call (device step / device scoring / host)
+TIMING_LOG: list = []      # ... of every call since the list was last cleared (bench.py --workload cfg3 reports it)
 
 
 @dataclass
@@ -203,6 +204,8 @@ def beam_search(scorer: StepScorer, prompts: Sequence[Sequence[int]], opts: Sear
             break
         feed, parents = new_feed, new_parents
     LAST_TIMING.update(step_s=t_step, score_s=t_score, host_s=t_host, steps=step + 1, rows=R)
+    TIMING_LOG.append(dict(LAST_TIMING))
+    del TIMING_LOG[:-64]
 
     results: List[WindowResult] = []
     for w in range(B):
