@@ -192,7 +192,7 @@ def run_cfg3(args, info, dims):
             "config": {"workload": (f"cfg3: mode=balanced on {minutes} min of noisy synthetic audio: energy-gate scenes <= 29 s, "
                                     f"HIP Silero-class VAD, groups <= 6 s, Whisper {args.model} geometry (seeded random "
                                     f"weights), beam 5 / patience 1.2 / repetition penalty 1.5 / no-repeat-3-gram, "
-                                    f"max_new_tokens={args.max_new_tokens}, host-driven beam search"),
+                                    f"max_new_tokens={args.max_new_tokens}, device-resident beam search"),
                        "windows_per_batch": args.batch, "compute_type": args.dtype, **stats},
             "roofline": None, "cpu_baseline": None}
     print(json.dumps(line), flush=True)

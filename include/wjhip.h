@@ -168,6 +168,20 @@ int wj_whisper_decode_sample(wj_whisper* m, int batch, int group, const int32_t*
                              int32_t* tokens_out, int32_t* n_tokens_out, float* sum_logprob_out,
                              float* no_speech_prob_out, float* token_logprob_out, void* stream);
 
+/* Beam search, fully device resident.  Replaces: ctranslate2 Whisper.generate(beam_size = beam, patience,
+ * length_penalty, repetition_penalty, no_repeat_ngram_size [the last two in opts]) as called by
+ * faster_whisper.WhisperModel.generate_with_fallback (faster_whisper_pro_asr.py:819).  Semantics of
+ * CTranslate2's search: per step the best 2*beam of beam x vocabulary, EOT candidates among the first `beam`
+ * retire to the window's finished list and are replaced by the next non-EOT candidates, a window stops once
+ * round(beam * patience) hypotheses are finished or max_new_tokens is reached; the hypothesis with the best
+ * score / len^length_penalty wins.  Outputs per WINDOW: tokens_out [batch][max_new_tokens] (eot padded),
+ * n_tokens_out, score_out (normalised, may be NULL), sum_logprob_out (cumulative log-prob incl. EOT),
+ * no_speech_prob_out (may be NULL). */
+int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* prompts_host, int prompt_len,
+                           const wj_decode_opts* opts, float patience, float length_penalty, int32_t* tokens_out,
+                           int32_t* n_tokens_out, float* score_out, float* sum_logprob_out, float* no_speech_prob_out,
+                           void* stream);
+
 /* Word-timestamp alignment.  Replaces: ctranslate2 Whisper.align (faster_whisper.transcribe.WhisperModel
  * .find_alignment, reached with word_timestamps=True from faster_whisper_pro_asr.py:819) and whisper/timing.py
  * find_alignment (whisper_pro_asr.py:433).  Teacher-forced decoder pass over tokens_host [batch][n_tokens_max]

@@ -143,7 +143,7 @@ def _model(scripts):
     m.dims, m.model, m.fe = d, FakeEngine(d, scripts), FakeFrontEnd()
     m.tokens, m.tokenizer = m.model.tokens, wm.IdTokenizer()
     m.max_batch, m.max_beam, m.max_length, m._warned, m.compute_type = 8, 1, 448, set(), "float32"
-    m.seed, m._sample_calls = 0, 0
+    m.seed, m._sample_calls, m.device_beam = 0, 0, False
     return m
 
 
@@ -250,7 +250,7 @@ def _ow_model(scripts):
     m.fe = OwFrontEnd()
     m.tokens, m.tokenizer = m.model.tokens, wm.IdTokenizer()
     m.max_batch, m.max_beam, m.max_length, m._warned, m.compute_type = 8, 1, 448, set(), "float32"
-    m.seed, m._sample_calls = 0, 0
+    m.seed, m._sample_calls, m.device_beam = 0, 0, False
     return m
 
 

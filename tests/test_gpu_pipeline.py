@@ -757,3 +757,51 @@ def test_word_timestamps_through_the_shim(hip):
     many, _ = model.transcribe_many([audio, audio[: 16000 * 4]], **kw)
     assert [[(w.start, w.end) for w in s.words] for s in many[0]] == [[(w.start, w.end) for w in s.words] for s in segs]
     model.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident beam search (wj_whisper_decode_beam) vs the oracle's CTranslate2 restatement and vs the
+# host-driven search over the step API
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("beam,patience,rep,ngram,n_new", [(2, 1.2, 1.5, 3, 16), (5, 1.2, 1.5, 3, 16), (3, 1.0, 1.0, 0, 16),
+                                                           (5, 2.0, 1.1, 2, 40), (8, 1.0, 1.0, 0, 9)])
+def test_device_beam_search_matches_oracle(hip, dtype, beam, patience, rep, ngram, n_new):
+    from whisperjav_amd import engine, search
+    d = helpers.small_dims()
+    oracle, w = helpers.make_oracle(d, seed=33, emulate_bf16=(dtype == "bfloat16"))
+    model = engine.HipWhisper(d, w, dtype=dtype, max_batch=3, max_beam=beam)
+    mel = torch.from_numpy(helpers.synth_mel(3, d.n_mels, seed=19))
+    toks = model.tokens
+    prompt = model.sot_prompt("ja", "transcribe")
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    model.encode(mel.cuda())
+    res = model.decode_beam(np.tile(np.array(prompt, dtype=np.int32), (3, 1)),
+                            engine.DecodeOptions(max_new_tokens=n_new, suppress_tokens=suppress, max_initial_timestamp=0.0,
+                                                 repetition_penalty=rep, no_repeat_ngram_size=ngram),
+                            beam_size=beam, patience=patience, length_penalty=1.0)
+    assert model.last_decode_info()["hip_graph"]
+    # the host-driven restatement over the step API must agree with the device loop (same engine numerics)
+    opts = search.SearchOptions(beam_size=beam, patience=patience, length_penalty=1.0, repetition_penalty=rep,
+                                no_repeat_ngram_size=ngram, suppress_tokens=suppress, max_initial_timestamp_index=0,
+                                max_new_tokens=n_new)
+    host = search.beam_search(search.HipStepScorer(model, opts), [prompt] * 3, opts, eot=toks.eot,
+                              timestamp_begin=toks.timestamp_begin)
+    fcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=0)
+    bcfg = decoding.BeamConfig(beam, patience, 1.0, rep, ngram, n_new)
+    with torch.no_grad():
+        xa = oracle.encode(mel)
+    worst = 0.0
+    for wdx in range(3):
+        got = res.tokens[wdx, : res.n_tokens[wdx]].tolist()
+        assert got == host[wdx].sequences[0], (wdx, got, host[wdx].sequences[0])
+        assert abs(float(res.sum_logprob[wdx]) - host[wdx].cum_logprobs[0]) < 1e-3
+        ref, nsp = decoding.beam_search(oracle, xa[wdx:wdx + 1], prompt, bcfg, fcfg)
+        if dtype == "float32":
+            assert got == ref[0][0], (wdx, got, ref[0][0])
+            assert abs(float(res.sum_logprob[wdx]) - ref[0][2]) < 1e-3
+            assert abs(float(res.token_logprob[wdx, 0]) - ref[0][1]) < 1e-3       # normalised score
+            assert abs(float(res.no_speech_prob[wdx]) - nsp) < 1e-5
+        worst = max(worst, abs(float(res.sum_logprob[wdx]) - ref[0][2]))
+    _diag("device_beam", {"dtype": dtype, "beam": beam, "patience": patience, "cum_logprob_diff": worst})
+    model.close()

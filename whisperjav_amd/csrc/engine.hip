@@ -78,6 +78,7 @@ int wj_ctx::ensure_scratch(size_t bytes) {
 // model object
 // ------------------------------------------------------------------------------------------------
 static constexpr int kDecKsMax = 16;
+static constexpr int kFinCap = 24;   // finished hypotheses kept per window: round(beam * patience) + beam <= 24
 
 // run-time tunables (wj_tune): defaults chosen from the MI355X sweeps recorded in profiles/
 struct Tunables {
@@ -149,6 +150,14 @@ struct wj_whisper {
   int32_t* step_tok = nullptr;  // [R] staging for wj_decode_step
   int32_t* slot_map = nullptr;  // [max_batch] window slot of each decoded window (sub-batch re-decodes)
   bool use_slots = false;
+  // device-resident beam search (wj_whisper_decode_beam)
+  int32_t* tokens2 = nullptr;     // second history buffer (histories are gathered by parent every step)
+  float* beam_score = nullptr;    // [R]
+  int32_t* beam_done = nullptr;   // [max_batch] + n_done at [max_batch]
+  int32_t* fin_count = nullptr;   // [max_batch]
+  float* fin_score = nullptr;     // [max_batch][kFinCap]
+  int32_t* fin_len = nullptr;
+  int32_t* fin_tokens = nullptr;  // [max_batch][kFinCap][tok_stride]
   // word-timestamp alignment (wj_whisper_align): scratch grown on demand, selection table [L][H]
   void* align_buf = nullptr;
   size_t align_bytes = 0;
@@ -755,6 +764,13 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   WJ_ALLOC(topk_ids, R * 16 * sizeof(int32_t), true);
   WJ_ALLOC(topk_lp, R * 16 * sizeof(float), true);
   WJ_ALLOC(topk_lse, R * sizeof(float), true);
+  WJ_ALLOC(tokens2, R * m->tok_stride * sizeof(int32_t), true);
+  WJ_ALLOC(beam_score, R * sizeof(float), true);
+  WJ_ALLOC(beam_done, (B + 1) * sizeof(int32_t), true);
+  WJ_ALLOC(fin_count, B * sizeof(int32_t), true);
+  WJ_ALLOC(fin_score, B * kFinCap * sizeof(float), true);
+  WJ_ALLOC(fin_len, B * kFinCap * sizeof(int32_t), true);
+  WJ_ALLOC(fin_tokens, B * kFinCap * m->tok_stride * sizeof(int32_t), true);
   hipError_t se = hipStreamSynchronize(ctx->stream);
   if (se != hipSuccess) {
     set_error("wj_whisper_create: %s", hipGetErrorString(se));
@@ -929,6 +945,144 @@ int wj_whisper_decode_sample(wj_whisper* m, int batch, int group, const int32_t*
       if (!done) ++n;
     }
     n_tokens_out[r] = n;
+  }
+  return WJ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// beam search, device resident (CTranslate2 semantics; the host-driven restatement in
+// whisperjav_amd/search.py stays the cross-check).  A step = decoder step + top-2K per row + per-window
+// merge + cache re-binding, captured as two hipGraphs (even / odd steps swap the history and row-map
+// buffers).  The host only polls a done counter every 8 steps and ranks the finished lists at the end.
+// ------------------------------------------------------------------------------------------------
+int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* prompts_host, int prompt_len,
+                           const wj_decode_opts* opts, float patience, float length_penalty, int32_t* tokens_out,
+                           int32_t* n_tokens_out, float* score_out, float* sum_logprob_out, float* no_speech_prob_out,
+                           void* stream) {
+  WJ_REQUIRE(m && prompts_host && opts && tokens_out && n_tokens_out && sum_logprob_out, "wj_whisper_decode_beam: NULL argument");
+  WJ_REQUIRE(batch >= 1 && batch <= m->max_batch && beam >= 1 && (beam <= 6 || beam == 8) && batch * beam <= m->max_rows,
+             "decode_beam: batch %d x beam %d does not fit (max_batch %d, max_rows %d; beam 1..6 or 8)", batch, beam,
+             m->max_batch, m->max_rows);
+  const int max_new = opts->max_new_tokens, K = beam, R = batch * beam, P = prompt_len;
+  WJ_REQUIRE(P >= 1 && max_new >= 1 && P + max_new <= m->d.n_text_ctx, "decode_beam: prompt_len %d + max_new_tokens %d exceeds n_text_ctx %d",
+             P, max_new, m->d.n_text_ctx);
+  WJ_REQUIRE(patience > 0.f, "decode_beam: patience must be positive");
+  const int max_candidates = (int)lroundf(K * patience);
+  WJ_REQUIRE(max_candidates >= 1 && max_candidates + K <= kFinCap, "decode_beam: beam %d x patience %g needs %d finished slots (max %d)",
+             K, (double)patience, max_candidates + K, kFinCap);
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  WJ_TRY(reset_decode_state(m, R, s));
+  int32_t* buf[2] = {m->tokens, m->tokens2};
+  {
+    std::vector<int32_t> hist((size_t)R * m->tok_stride, opts->eot);
+    std::vector<float> sc(R, -INFINITY);
+    for (int r = 0; r < R; ++r) {
+      for (int j = 0; j < P; ++j) hist[(size_t)r * m->tok_stride + j] = prompts_host[(size_t)(r / K) * P + j];
+      if (r % K == 0) sc[r] = 0.f;                 // one live beam per window at the start
+    }
+    WJ_HIP(hipMemcpyAsync(buf[0], hist.data(), sizeof(int32_t) * hist.size(), hipMemcpyHostToDevice, s));
+    WJ_HIP(hipMemcpyAsync(m->beam_score, sc.data(), sizeof(float) * R, hipMemcpyHostToDevice, s));
+    WJ_HIP(hipMemsetAsync(m->beam_done, 0, sizeof(int32_t) * (m->max_batch + 1), s));
+    WJ_HIP(hipMemsetAsync(m->fin_count, 0, sizeof(int32_t) * m->max_batch, s));
+    WJ_HIP(hipStreamSynchronize(s));
+  }
+  // prompt: all but its last token (its logits are not needed, except for the no-speech probability at step 0)
+  for (int p = 0; p + 1 < P; ++p) {
+    const bool ns = p == 0 && opts->no_speech >= 0;
+    WJ_TRY(run_decoder_step(m, 0, R, batch, K, ns, s));
+    if (ns) WJ_TRY(launch_no_speech_prob(m->logits, m->ldl, R, m->d.n_vocab, opts->no_speech, m->nsp, s));
+    WJ_TRY(launch_advance_pos(m->pos, s));
+  }
+  auto iteration = [&](int par, bool first) -> int {
+    int32_t* saved = m->tokens;
+    m->tokens = buf[par];                           // the decoder step embeds the token at *pos of this history
+    m->cur_map = par;
+    int rc = run_decoder_step(m, 0, R, batch, K, true, s);
+    m->tokens = saved;
+    if (rc) return rc;
+    if (first && P == 1 && opts->no_speech >= 0)
+      WJ_TRY(launch_no_speech_prob(m->logits, m->ldl, R, m->d.n_vocab, opts->no_speech, m->nsp, s));
+    BeamArgs a;
+    a.logits = m->logits; a.ldl = m->ldl; a.V = m->d.n_vocab; a.K = K;
+    a.hist_in = buf[par]; a.hist_out = buf[par ^ 1]; a.tok_stride = m->tok_stride; a.pos_ptr = m->pos;
+    a.sample_begin = P; a.max_new = max_new; a.max_candidates = max_candidates; a.opts = *opts;
+    a.cand_ids = m->topk_ids; a.cand_lp = m->topk_lp; a.score = m->beam_score; a.parent = m->parent;
+    a.done = m->beam_done; a.n_done = m->beam_done + m->max_batch;
+    a.fin_count = m->fin_count; a.fin_score = m->fin_score; a.fin_len = m->fin_len; a.fin_tokens = m->fin_tokens;
+    a.fin_cap = kFinCap;
+    WJ_TRY(launch_beam_step(a, R, batch, s));
+    WJ_TRY(launch_advance_pos(m->pos, s));
+    WJ_TRY(launch_rebind_rows(m->row_map[par], m->row_map[par ^ 1], m->parent, m->pos, R, m->d.n_text_ctx, s));
+    return WJ_OK;
+  };
+  // row maps: reset_decode_state initialised both to the identity; parity 0 reads map 0
+  hipGraph_t graph[2] = {nullptr, nullptr};
+  hipGraphExec_t exec[2] = {nullptr, nullptr};
+  const char* env = getenv("WJ_NO_GRAPH");
+  bool use_graph = !(env && env[0] == '1') && !prof_on(m->ctx) && !(P == 1 && opts->no_speech >= 0);
+  for (int par = 0; par < 2 && use_graph; ++par) {
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      int rc = iteration(par, false);
+      e = hipStreamEndCapture(s, &graph[par]);
+      if (rc || e != hipSuccess || graph[par] == nullptr) use_graph = false;
+      else if (hipGraphInstantiate(&exec[par], graph[par], nullptr, nullptr, 0) != hipSuccess) use_graph = false;
+    } else {
+      use_graph = false;
+    }
+  }
+  if (!use_graph) (void)hipGetLastError();
+  m->last_used_graph = use_graph ? 1 : 0;
+  m->last_chains = 1;
+  int rc_loop = WJ_OK;
+  for (int i = 0; i < max_new && rc_loop == WJ_OK; ++i) {
+    const int par = i & 1;
+    if (use_graph) {
+      if (hipGraphLaunch(exec[par], s) != hipSuccess) { set_error("decode_beam: graph launch failed"); rc_loop = WJ_E_HIP; }
+    } else {
+      rc_loop = iteration(par, i == 0);
+    }
+    if ((i & 7) == 7 && i + 1 < max_new && rc_loop == WJ_OK) {
+      int32_t nd = 0;
+      if (hipMemcpyAsync(&nd, m->beam_done + m->max_batch, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess) { set_error("decode_beam: done poll failed"); rc_loop = WJ_E_HIP; }
+      if (nd >= batch) break;
+    }
+  }
+  for (int par = 0; par < 2; ++par) {
+    if (exec[par]) (void)hipGraphExecDestroy(exec[par]);
+    if (graph[par]) (void)hipGraphDestroy(graph[par]);
+  }
+  m->cur_map = 0;
+  if (rc_loop) return rc_loop;
+  // finished lists -> best hypothesis per window (score / len^length_penalty, first one wins ties)
+  std::vector<int32_t> fcount(batch), flen((size_t)batch * kFinCap), ftok((size_t)batch * kFinCap * m->tok_stride);
+  std::vector<float> fscore((size_t)batch * kFinCap), nsp(R);
+  WJ_HIP(hipMemcpyAsync(fcount.data(), m->fin_count, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(flen.data(), m->fin_len, sizeof(int32_t) * flen.size(), hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(fscore.data(), m->fin_score, sizeof(float) * fscore.size(), hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(ftok.data(), m->fin_tokens, sizeof(int32_t) * ftok.size(), hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(nsp.data(), m->nsp, sizeof(float) * R, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipStreamSynchronize(s));
+  for (int w = 0; w < batch; ++w) {
+    const int n = std::min(fcount[w], kFinCap);
+    WJ_REQUIRE(n >= 1, "decode_beam: window %d finished no hypothesis", w);
+    int best = 0;
+    double best_norm = -INFINITY;
+    for (int i = 0; i < n; ++i) {
+      const int len = std::max(flen[(size_t)w * kFinCap + i], 1);
+      const double sc = fscore[(size_t)w * kFinCap + i];
+      const double norm = length_penalty != 0.f ? sc / pow((double)len, (double)length_penalty) : sc;
+      if (norm > best_norm) { best_norm = norm; best = i; }
+    }
+    const int len = flen[(size_t)w * kFinCap + best];
+    for (int j = 0; j < max_new; ++j)
+      tokens_out[(size_t)w * max_new + j] = j < len ? ftok[((size_t)w * kFinCap + best) * m->tok_stride + j] : opts->eot;
+    n_tokens_out[w] = len;
+    sum_logprob_out[w] = fscore[(size_t)w * kFinCap + best];
+    if (score_out) score_out[w] = (float)best_norm;
+    if (no_speech_prob_out) no_speech_prob_out[w] = nsp[(size_t)w * K];
   }
   return WJ_OK;
 }

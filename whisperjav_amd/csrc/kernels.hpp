@@ -137,6 +137,31 @@ int launch_no_speech_prob(const float* logits, int64_t ldl, int R, int V, int no
 // masked log-softmax + top-k (k <= 16) per row
 int launch_topk_logprob(const float* logits, int64_t ldl, int R, int V, int k, const uint8_t* ban,
                         int32_t* ids, float* logprobs, float* lse, hipStream_t s);
+// device-resident beam search step (see sampler.hip)
+struct BeamArgs {
+  float* logits = nullptr;            // [R][ldl], edited in place by the processors
+  int64_t ldl = 0;
+  int V = 0, K = 0;                   // vocabulary, beam size (rows per window)
+  const int32_t* hist_in = nullptr;   // [R][tok_stride] token history read this step (prompt + generated)
+  int32_t* hist_out = nullptr;        // ... written for the next step (gathered by parent + new token)
+  int64_t tok_stride = 0;
+  const int* pos_ptr = nullptr;       // device: index of the token fed this step
+  int sample_begin = 0, max_new = 0, max_candidates = 0;
+  wj_decode_opts opts;
+  int32_t* cand_ids = nullptr;        // [R][16]
+  float* cand_lp = nullptr;           // [R][16]
+  float* score = nullptr;             // [R] cumulative log-prob of the live beams (-inf = dead)
+  int32_t* parent = nullptr;          // [R] absolute parent row of next step's row
+  int32_t* done = nullptr;            // [B]
+  int32_t* n_done = nullptr;          // [1]
+  int32_t* fin_count = nullptr;       // [B]
+  float* fin_score = nullptr;         // [B][fin_cap]
+  int32_t* fin_len = nullptr;         // [B][fin_cap]
+  int32_t* fin_tokens = nullptr;      // [B][fin_cap][tok_stride]
+  int fin_cap = 0;
+};
+int launch_beam_step(const BeamArgs& a, int R, int B, hipStream_t s);
+
 // beam search: logits processors + timestamp rules + masked log-softmax + top-k (see sampler.hip)
 int launch_topk_rules(float* logits, int64_t ldl, int R, int V, int k, const wj_decode_opts& o, const int32_t* row_rules,
                       const int32_t* ban, int maxb, const int32_t* pen, int maxp, float penalty, int32_t* ids,

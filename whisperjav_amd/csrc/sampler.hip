@@ -418,6 +418,257 @@ __global__ __launch_bounds__(SB) void topk_rules_kernel(float* __restrict__ logi
   }
 }
 
+// --------------------------------------------------------------------------------------------
+// Device-resident beam search (CTranslate2 semantics, the host restatement is whisperjav_amd/search.py
+// beam_search; reference entry: WhisperModel.generate(beam_size > 1) behind faster_whisper_pro_asr.py:819).
+// Per step:  beam_topk  (one workgroup per hypothesis row: logits processors + Whisper rules computed from
+// the row's device token history, masked log-softmax, top 2K)  ->  beam_merge  (one workgroup per window:
+// best 2K of beam x vocab by (score desc, beam asc, token asc), EOT / last-step candidates move to the
+// window's finished list and are refilled from the secondary candidates, the K survivors' histories are
+// gathered from their parents).  Nothing goes to the host until the windows are done.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SB) void beam_topk_kernel(const BeamArgs a) {
+  __shared__ float s_f[4][SB / 64];
+  __shared__ int s_i[2][SB / 64];
+  __shared__ int s_sel[16];
+  __shared__ float s_stat[4];
+  __shared__ RowRules s_rr;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const wj_decode_opts& o = a.opts;
+  const int k = 2 * a.K, V = a.V;
+  const int len = *a.pos_ptr + 1;
+  const int32_t* tok = a.hist_in + (int64_t)r * a.tok_stride;
+  float* x = a.logits + (int64_t)r * a.ldl;
+  const float rep = o.repetition_penalty;
+  const int ngram = o.no_repeat_ngram_size;
+  if ((rep > 0.f && rep != 1.f) || ngram > 0) {      // same prepass as greedy_sample_kernel
+    const int s0 = a.sample_begin - 1, L = len - s0;
+    if (rep > 0.f && rep != 1.f) {
+      for (int j = tid; j < L; j += SB) {
+        const int t = tok[s0 + j];
+        bool first = true;
+        for (int i = 0; i < j; ++i)
+          if (tok[s0 + i] == t) { first = false; break; }
+        if (first) { const float v = x[t]; x[t] = v < 0.f ? v * rep : v / rep; }
+      }
+      __syncthreads();
+    }
+    if (ngram > 0 && L >= ngram) {
+      for (int i = tid; i <= L - ngram; i += SB) {
+        bool match = true;
+        for (int q = 0; q < ngram - 1; ++q)
+          if (tok[s0 + i + q] != tok[len - (ngram - 1) + q]) { match = false; break; }
+        if (match) x[tok[s0 + i + ngram - 1]] = -INFINITY;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    RowRules rr;
+    const int ns = len - a.sample_begin;
+    rr.first = ns == 0;
+    rr.ts_rules = !o.without_timestamps;
+    rr.last_ts = ns >= 1 && tok[len - 1] >= o.timestamp_begin;
+    rr.penult_ts = ns < 2 || tok[len - 2] >= o.timestamp_begin;
+    int ts_last = -1;
+    for (int i = a.sample_begin; i < len; ++i)
+      if (tok[i] >= o.timestamp_begin) ts_last = tok[i];
+    rr.ts_floor = -1;
+    if (ts_last >= 0) rr.ts_floor = (rr.last_ts && !rr.penult_ts) ? ts_last : ts_last + 1;
+    s_rr = rr;
+  }
+  __syncthreads();
+  const RowRules rr = s_rr;
+
+  ArgMax best_all = {-INFINITY, 0x7fffffff};
+  float max_text = -INFINITY;
+  for (int v = tid; v < V; v += SB) {
+    if (!token_allowed(v, rr, o)) continue;
+    const float xv = x[v];
+    best_all = amax(best_all, ArgMax{xv, v});
+    if (v < o.timestamp_begin) max_text = fmaxf(max_text, xv);
+  }
+  best_all = wave_amax(best_all);
+  max_text = wave_max(max_text);
+  if (lane == 0) { s_f[0][wave] = best_all.v; s_i[0][wave] = best_all.i; s_f[2][wave] = max_text; }
+  __syncthreads();
+  best_all = ArgMax{s_f[0][0], s_i[0][0]};
+  max_text = s_f[2][0];
+  for (int w = 1; w < SB / 64; ++w) {
+    best_all = amax(best_all, ArgMax{s_f[0][w], s_i[0][w]});
+    max_text = fmaxf(max_text, s_f[2][w]);
+  }
+  __syncthreads();
+  float sum_all = 0.f, sum_ts = 0.f;
+  for (int v = tid; v < V; v += SB) {
+    if (!token_allowed(v, rr, o)) continue;
+    const float e = expf(x[v] - best_all.v);
+    sum_all += e;
+    if (v >= o.timestamp_begin) sum_ts += e;
+  }
+  sum_all = wave_sum(sum_all);
+  sum_ts = wave_sum(sum_ts);
+  if (lane == 0) { s_f[0][wave] = sum_all; s_f[1][wave] = sum_ts; }
+  __syncthreads();
+  if (tid == 0) {
+    sum_all = 0.f; sum_ts = 0.f;
+    for (int w = 0; w < SB / 64; ++w) { sum_all += s_f[0][w]; sum_ts += s_f[1][w]; }
+    const float lse = best_all.v + logf(sum_all);
+    float ts_only = 0.f, norm = lse;
+    if (rr.ts_rules && sum_ts > 0.f) {
+      const float ts_lp = best_all.v + logf(sum_ts) - lse;
+      if (ts_lp > max_text - lse) { ts_only = 1.f; norm = best_all.v + logf(sum_ts); }
+    }
+    s_stat[0] = norm;
+    s_stat[1] = ts_only;
+  }
+  __syncthreads();
+  const float norm = s_stat[0];
+  const bool ts_only = s_stat[1] != 0.f;
+  for (int round = 0; round < k; ++round) {
+    ArgMax best = {-INFINITY, 0x7fffffff};
+    for (int v = tid; v < V; v += SB) {
+      if (ts_only && v < o.timestamp_begin) continue;
+      if (!token_allowed(v, rr, o)) continue;
+      bool taken = false;
+      for (int q = 0; q < round; ++q) taken |= (s_sel[q] == v);
+      if (!taken) best = amax(best, ArgMax{x[v], v});
+    }
+    best = wave_amax(best);
+    if (lane == 0) { s_f[0][wave] = best.v; s_i[0][wave] = best.i; }
+    __syncthreads();
+    if (tid == 0) {
+      ArgMax b = {s_f[0][0], s_i[0][0]};
+      for (int w = 1; w < SB / 64; ++w) b = amax(b, ArgMax{s_f[0][w], s_i[0][w]});
+      s_sel[round] = b.i;
+      const bool none = b.i == 0x7fffffff || b.v == -INFINITY;
+      a.cand_ids[(int64_t)r * 16 + round] = none ? -1 : b.i;
+      a.cand_lp[(int64_t)r * 16 + round] = none ? -INFINITY : b.v - norm;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(128) void beam_merge_kernel(const BeamArgs a) {
+  __shared__ float c_score[128];
+  __shared__ int c_beam[128], c_tok[128];
+  __shared__ float s_score[16];          // sorted best 2K
+  __shared__ int s_beam[16], s_tok[16];
+  __shared__ float old_score[8];
+  __shared__ int n_parent[8], n_feed[8];
+  __shared__ float n_score[8];
+  __shared__ int fin_b[8], fin_tok[8], fin_slot[8];
+  __shared__ float fin_sc[8];
+  __shared__ int s_counts[3];            // candidates, finished this step, sorted length
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const int K = a.K, nc = 2 * K, eot = a.opts.eot;
+  const int pos = *a.pos_ptr, len = pos + 1;
+  const bool last_step = (len - a.sample_begin) == a.max_new - 1;
+  const bool done = a.done[w] != 0;
+  if (tid < K) old_score[tid] = a.score[w * K + tid];
+  __syncthreads();
+  // ---- candidates: beam-major, token order as the top-k kernel emitted them
+  const int total = K * nc;
+  for (int i = tid; i < 128; i += 128) {
+    float sc = -INFINITY; int b = 0, t = -1;
+    if (i < total) {
+      b = i / nc;
+      const int j = i - b * nc;
+      t = a.cand_ids[(int64_t)(w * K + b) * 16 + j];
+      sc = (old_score[b] == -INFINITY || t < 0) ? -INFINITY : old_score[b] + a.cand_lp[(int64_t)(w * K + b) * 16 + j];
+      if (old_score[b] == -INFINITY) t = -1;
+    }
+    c_score[i] = sc; c_beam[i] = b; c_tok[i] = t;
+  }
+  __syncthreads();
+  // ---- rank = number of valid candidates that precede (score desc, beam asc, token asc): a strict total order
+  {
+    const int i = tid;
+    if (i < total && c_tok[i] >= 0) {
+      int rank = 0;
+      for (int j = 0; j < total; ++j) {
+        if (j == i || c_tok[j] < 0) continue;
+        const bool before = c_score[j] > c_score[i] ||
+                            (c_score[j] == c_score[i] && (c_beam[j] < c_beam[i] || (c_beam[j] == c_beam[i] && c_tok[j] < c_tok[i])));
+        rank += before;
+      }
+      if (rank < nc) { s_score[rank] = c_score[i]; s_beam[rank] = c_beam[i]; s_tok[rank] = c_tok[i]; }
+    }
+    if (tid == 0) {
+      int n = 0;
+      for (int j = 0; j < total; ++j) n += c_tok[j] >= 0;
+      s_counts[0] = n;
+      s_counts[2] = n < nc ? n : nc;
+    }
+  }
+  __syncthreads();
+  // ---- selection (sequential, as the reference loop)
+  if (tid == 0) {
+    const int n = s_counts[2];
+    int secondary = K, nfin = 0, nn = 0;
+    int fcount = a.fin_count[w];
+    if (!done) {
+      for (int k = 0; k < (K < n ? K : n); ++k) {
+        float sc = s_score[k]; int b = s_beam[k], t = s_tok[k];
+        float usc = sc; int ub = b, ut = t;
+        if (t == eot || last_step) {
+          fin_b[nfin] = b; fin_tok[nfin] = (t == eot) ? -1 : t; fin_sc[nfin] = sc; fin_slot[nfin] = fcount + nfin;
+          ++nfin;
+          for (int j = secondary; j < n; ++j)
+            if (s_tok[j] != eot) { usc = s_score[j]; ub = s_beam[j]; ut = s_tok[j]; secondary = j + 1; break; }
+        }
+        n_parent[nn] = ub; n_feed[nn] = ut; n_score[nn] = usc;
+        ++nn;
+      }
+    }
+    for (; nn < K; ++nn) {     // dead beams (or a finished window): keep the row, feed EOT
+      n_parent[nn] = done ? nn : nn; n_feed[nn] = eot; n_score[nn] = done ? old_score[nn] : -INFINITY;
+    }
+    s_counts[1] = nfin;
+    if (!done) {
+      a.fin_count[w] = fcount + nfin;
+      if (last_step || fcount + nfin >= a.max_candidates) { a.done[w] = 1; atomicAdd(a.n_done, 1); }
+    }
+  }
+  __syncthreads();
+  // ---- finished hypotheses: score + generated tokens (history of the parent beam [+ the token])
+  const int nfin = s_counts[1];
+  for (int f = 0; f < nfin; ++f) {
+    const int slot = fin_slot[f];
+    if (slot >= a.fin_cap) continue;                                   // cannot happen: cap = max_candidates + K
+    const int32_t* src = a.hist_in + (int64_t)(w * K + fin_b[f]) * a.tok_stride + a.sample_begin;
+    int32_t* dst = a.fin_tokens + ((int64_t)w * a.fin_cap + slot) * a.tok_stride;
+    const int ng = len - a.sample_begin;
+    for (int j = tid; j < ng; j += 128) dst[j] = src[j];
+    if (tid == 0) {
+      int n = ng;
+      if (fin_tok[f] >= 0) dst[n++] = fin_tok[f];
+      a.fin_len[(int64_t)w * a.fin_cap + slot] = n;
+      a.fin_score[(int64_t)w * a.fin_cap + slot] = fin_sc[f];
+    }
+  }
+  // ---- survivors: history gather + new token, scores, parents
+  for (int k = 0; k < K; ++k) {
+    const int32_t* src = a.hist_in + (int64_t)(w * K + n_parent[k]) * a.tok_stride;
+    int32_t* dst = a.hist_out + (int64_t)(w * K + k) * a.tok_stride;
+    for (int j = tid; j < len; j += 128) dst[j] = src[j];
+    if (tid == 0) {
+      dst[len] = n_feed[k];
+      a.score[w * K + k] = n_score[k];
+      a.parent[w * K + k] = w * K + n_parent[k];
+    }
+  }
+}
+
+int launch_beam_step(const BeamArgs& a, int R, int B, hipStream_t s) {
+  if (a.K < 1 || a.K > 8) { set_error("beam search: beam size %d outside 1..8", a.K); return WJ_E_INVALID; }
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(R), dim3(SB), 0, s, a);
+  WJ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(128), 0, s, a);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
 int launch_topk_rules(float* logits, int64_t ldl, int R, int V, int k, const wj_decode_opts& o, const int32_t* row_rules,
                       const int32_t* ban, int maxb, const int32_t* pen, int maxp, float penalty, int32_t* ids,
                       float* logprobs, hipStream_t s) {

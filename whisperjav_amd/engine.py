@@ -245,6 +245,28 @@ class HipWhisper:
                                                  as_f(nsp), as_f(tlp), None), "wj_whisper_decode_sample")
         return GreedyResult(toks, ntok, slp, nsp, tlp)
 
+    def decode_beam(self, prompts: np.ndarray, options: Optional[DecodeOptions] = None, *, beam_size: int = 5,
+                    patience: float = 1.0, length_penalty: float = 1.0) -> GreedyResult:
+        """CTranslate2-style beam search of the resident windows, entirely on the device.  Per window: best
+        hypothesis tokens, count, cumulative log-prob (``sum_logprob``), no-speech probability;
+        ``token_logprob`` carries the normalised score in column 0."""
+        o = options or DecodeOptions()
+        prompts = np.ascontiguousarray(prompts, dtype=np.int32)
+        B, P = prompts.shape
+        n = o.max_new_tokens
+        oc = self._opts(o)
+        toks = np.empty((B, n), dtype=np.int32)
+        ntok = np.empty(B, dtype=np.int32)
+        score = np.empty(B, dtype=np.float32)
+        slp = np.empty(B, dtype=np.float32)
+        nsp = np.empty(B, dtype=np.float32)
+        as_i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+        as_f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+        check(self._lib.wj_whisper_decode_beam(self.handle, B, int(beam_size), as_i(prompts), P, C.byref(oc), float(patience),
+                                               float(length_penalty), as_i(toks), as_i(ntok), as_f(score), as_f(slp), as_f(nsp),
+                                               None), "wj_whisper_decode_beam")
+        return GreedyResult(toks, ntok, slp, nsp, score.reshape(B, 1))
+
     def align(self, token_rows: Sequence[Sequence[int]], n_prefix: int, heads: Sequence[Tuple[int, int]],
               num_frames: Sequence[int], *, slots: Optional[Sequence[int]] = None, medfilt_width: int = 7):
         """Word-timestamp alignment of the resident windows.  ``token_rows[b]`` = sot sequence + <|notimestamps|> +

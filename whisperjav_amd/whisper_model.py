@@ -289,6 +289,7 @@ class HipWhisperModel:
         self.max_length = dims.n_text_ctx
         self._warned = set()
         self.seed = 0               # base seed of the device sampler's counter-based generator
+        self.device_beam = True     # beam search on the device (False: host-driven search.py over the step API)
         self._sample_calls = 0
 
     # ---- loading ---------------------------------------------------------------------------
@@ -431,7 +432,23 @@ class HipWhisperModel:
         device_loop = beam == 1 and (self.FLAVOR == "fw" or (float(o.repetition_penalty) == 1.0
                                                              and int(o.no_repeat_ngram_size) == 0))
         out = []
-        if device_loop:
+        if (not device_loop and self.FLAVOR == "fw" and self.device_beam and beam in (2, 3, 4, 5, 6, 8)
+                and round(beam * float(o.patience or 1.0)) + beam <= 24):
+            # CTranslate2's beam search, device resident (wj_whisper_decode_beam); the host-driven restatement in
+            # search.py stays available (device_beam = False) and is what the GPU tests cross-check it with
+            lp = o.length_penalty
+            res = self.model.decode_beam(
+                np.array(prompts, dtype=np.int32),
+                engine.DecodeOptions(max_new_tokens=max_new, suppress_blank=o.suppress_blank,
+                                     without_timestamps=o.without_timestamps, suppress_tokens=suppress,
+                                     max_initial_timestamp=mit * TIME_PRECISION,
+                                     repetition_penalty=float(o.repetition_penalty),
+                                     no_repeat_ngram_size=int(o.no_repeat_ngram_size)),
+                beam_size=beam, patience=float(o.patience or 1.0), length_penalty=(1.0 if lp is None else float(lp)))
+            for r in range(n):
+                toks = res.tokens[r, : res.n_tokens[r]].tolist()
+                out.append((toks, float(res.sum_logprob[r]) / (len(toks) + 1), float(res.no_speech_prob[r])))
+        elif device_loop:
             res = self.model.decode_greedy(
                 np.array(prompts, dtype=np.int32),
                 engine.DecodeOptions(max_new_tokens=max_new, suppress_blank=o.suppress_blank,
