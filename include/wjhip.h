@@ -81,6 +81,14 @@ int64_t wj_logmel_frames(int64_t n_samples, int mode);
 int wj_logmel_f32(wj_ctx* ctx, const float* pcm_dev, const int64_t* offsets_host, int n_clips,
                   int n_mels, int mode, int out_frames, float* out_dev, void* stream);
 
+/* Scene detection front end.  Replaces the per-frame energy computation inside auditok.split as
+ * driven by AuditokSceneDetector._detect_pass1/_detect_pass2 (scene_detection_backends/auditok_backend.py:385,
+ * 561-567): for every analysis frame (offset, length in samples of the resident float32 clip) the exact integer
+ * sum of squares of the PCM16-quantised samples ((x * 32767) truncated to int16).  The host turns the sums into
+ * auditok's 20 log10(sqrt(mean)) energies and runs its tokenizer (whisperjav_amd/scenes.py). */
+int wj_frame_sumsq(wj_ctx* ctx, const float* pcm_dev, int64_t n_samples, const int64_t* frame_off_host,
+                   const int32_t* frame_len_host, int64_t n_frames, int64_t* sums_out_host, void* stream);
+
 /* ---- Whisper model -------------------------------------------------------------------- */
 typedef struct {
   int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;

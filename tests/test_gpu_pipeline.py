@@ -805,3 +805,39 @@ def test_device_beam_search_matches_oracle(hip, dtype, beam, patience, rep, ngra
         worst = max(worst, abs(float(res.sum_logprob[wdx]) - ref[0][2]))
     _diag("device_beam", {"dtype": dtype, "beam": beam, "patience": patience, "cum_logprob_diff": worst})
     model.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# scene detection: device frame energies + host tokenizer vs the reference driver's fixtures
+# ---------------------------------------------------------------------------------------------
+def test_scene_detection_matches_reference_fixtures(hip, tmp_path):
+    """HipAuditokSceneDetector.split_clip reproduces, bit for bit (float equality of the boundaries), the scenes the
+    REFERENCE's two-pass driver produced for the committed fixtures; detect_scenes writes the PCM16 WAVs."""
+    import wave
+    from whisperjav_amd import scenes, synth
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_scenes.json")))
+    n_scenes = 0
+    for case in gold["cases"]:
+        audio = synth.speech_like(case["seconds"], seed=case["seed"], noisy=case["noisy"])
+        det = scenes.HipAuditokSceneDetector(config=scenes.AuditokSceneConfig(**case["cfg"]))
+        got, story = det.split_clip(audio, 16000)
+        assert [list(x) for x in story] == case["story"], case["seed"]
+        assert [[a, b, p, m.get("split_method")] for a, b, p, m in got] == case["scenes"], case["seed"]
+        n_scenes += len(got)
+    assert n_scenes > 100
+    # file interface: WAVs on disk, legacy tuples, metadata
+    case = gold["cases"][8]
+    audio = synth.speech_like(case["seconds"], seed=case["seed"], noisy=case["noisy"])
+    src = tmp_path / "clip.wav"
+    with wave.open(str(src), "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000)
+        wf.writeframes((np.clip(audio, -1, 1) * 32767).astype("<i2").tobytes())
+    det = scenes.HipAuditokSceneDetector(**{"max_duration_s": 10.0, "pass1_energy_threshold": 55, "pass2_energy_threshold": 60,
+                                            "pass1_max_silence_s": 1.0, "pass2_max_silence_s": 0.4})
+    res = det.detect_scenes(src, tmp_path / "scenes", "clip")
+    assert res.method == "auditok-hip" and res.num_scenes >= 10 and res.audio_duration_sec == pytest.approx(case["seconds"], abs=0.01)
+    for path, s, e, dur in res.to_legacy_tuples():
+        with wave.open(str(path), "rb") as wf:
+            assert wf.getframerate() == 16000 and wf.getnframes() == int(e * 16000) - int(s * 16000)
+        assert 0 <= s < e <= case["seconds"] + 1e-6 and dur <= 10.0 + 1e-9
+    det.cleanup()

@@ -268,3 +268,59 @@ int logmel_run(wj_ctx* ctx, const float* pcm, const int64_t* offsets_host, int n
 }
 
 }  // namespace wj
+
+// --------------------------------------------------------------------------------------------
+// Scene detection front end: sum of squares of the PCM16-quantised samples per analysis frame.
+// The reference quantises with (audio * 32767).astype(int16) (auditok_backend.py:385) and auditok gates on
+// 20 log10(sqrt(mean(x^2))): the integer sums are exact, so the host reproduces auditok's float64 energies bit for
+// bit from them.  One workgroup per frame (frames are 50 ms: 800 samples at 16 kHz).
+// --------------------------------------------------------------------------------------------
+namespace wj {
+
+__global__ __launch_bounds__(256) void frame_sumsq_kernel(const float* __restrict__ pcm, const int64_t* __restrict__ off,
+                                                          const int32_t* __restrict__ len, long long* __restrict__ out) {
+  __shared__ long long red[4];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = pcm + off[f];
+  const int n = len[f];
+  long long acc = 0;
+  for (int i = tid; i < n; i += 256) {
+    const int q = (int)(short)(int)(x[i] * 32767.0f);       // float32 product, truncation toward zero, int16 wrap
+    acc += (long long)q * q;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (tid == 0) out[f] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace wj
+
+extern "C" int wj_frame_sumsq(wj_ctx* ctx, const float* pcm_dev, int64_t n_samples, const int64_t* frame_off_host,
+                              const int32_t* frame_len_host, int64_t n_frames, int64_t* sums_out_host, void* stream) {
+  using namespace wj;
+  WJ_REQUIRE(ctx && pcm_dev && frame_off_host && frame_len_host && sums_out_host, "wj_frame_sumsq: NULL argument");
+  if (n_frames <= 0) return WJ_OK;
+  for (int64_t i = 0; i < n_frames; ++i)
+    WJ_REQUIRE(frame_len_host[i] >= 1 && frame_off_host[i] >= 0 && frame_off_host[i] + frame_len_host[i] <= n_samples,
+               "wj_frame_sumsq: frame %lld outside the clip", (long long)i);
+  WJ_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->pick(stream);
+  const size_t b_off = align_up(sizeof(int64_t) * (size_t)n_frames, 256), b_len = align_up(sizeof(int32_t) * (size_t)n_frames, 256);
+  if (int rc = ctx->ensure_scratch(2 * b_off + b_len)) return rc;
+  char* base = reinterpret_cast<char*>(ctx->scratch);
+  int64_t* d_off = reinterpret_cast<int64_t*>(base);
+  long long* d_out = reinterpret_cast<long long*>(base + b_off);
+  int32_t* d_len = reinterpret_cast<int32_t*>(base + 2 * b_off);
+  WJ_HIP(hipMemcpyAsync(d_off, frame_off_host, sizeof(int64_t) * (size_t)n_frames, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(d_len, frame_len_host, sizeof(int32_t) * (size_t)n_frames, hipMemcpyHostToDevice, s));
+  for (int64_t f0 = 0; f0 < n_frames; f0 += 1 << 30) {
+    const unsigned n = (unsigned)std::min<int64_t>(n_frames - f0, 1 << 30);
+    hipLaunchKernelGGL(frame_sumsq_kernel, dim3(n), dim3(256), 0, s, pcm_dev, d_off + f0, d_len + f0, d_out + f0);
+    WJ_LAUNCH_CHECK();
+  }
+  WJ_HIP(hipMemcpyAsync(sums_out_host, d_out, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipStreamSynchronize(s));
+  return WJ_OK;
+}

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "wj_profile_stop": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I]),
     "wj_logmel_frames": (_I64, [_I64, _I]),
     "wj_logmel_f32": (_I, [_P, _P, C.POINTER(_I64), _I, _I, _I, _I, _P, _P]),
+    "wj_frame_sumsq": (_I, [_P, _P, _I64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _I64, C.POINTER(C.c_int64), _P]),
     "wj_whisper_create": (_I, [_P, C.POINTER(WhisperDimsC), _I, _P, _I64, C.POINTER(_I64), _I, _I, _I, C.POINTER(_P)]),
     "wj_whisper_free": (_I, [_P]),
     "wj_whisper_workspace_bytes": (_I64, [_P]),
