@@ -19,6 +19,9 @@ LIB = CSRC / "libwjhip.so"
 SOURCES = ["engine.hip", "gemm.hip", "attention.hip", "norm.hip", "sampler.hip", "logmel.hip", "vad.hip", "align.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "../../include/wjhip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+# attention.hip: MFMA results feed VALU softmax code every key tile; with accumulators in AGPRs the compiler emits
+# ~190 v_accvgpr_read/write per tile, the VGPR form of the MFMAs removes all of them (gfx950 has a unified file)
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -33,6 +36,7 @@ def _stamp(paths) -> str:
     for p in paths:
         h.update(Path(p).read_bytes())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -50,7 +54,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         stamp = _stamp([src]) + hdr_stamp
         if not force and obj.exists() and stamp_file.exists() and stamp_file.read_text() == stamp:
             return obj
-        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)

@@ -46,6 +46,10 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
       qf[f][ks] = *reinterpret_cast<const bf16x8_t*>(Qp + (int64_t)(q0 + f * 16 + li) * 64 + ks * 32 + lg * 8);
 
   f32x4_t o[2][4];
+  f32x4_t lsum[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};   // VAR & 8: row sums from the MFMA pipe
+  bf16x8_t ones8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones8[e] = (__bf16)1.0f;
   float m_run[2], l_run[2];
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
@@ -101,7 +105,65 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
     }
     // lane (q = li, lg) now holds, for block kb, keys  kt*64 + 32*(kb>>1) + 8*lg + 4*(kb&1) + r
     bf16x8_t pf[2][2];
-    const bool tail = (kt + 1) * 64 > T;     // only the last key tile contains padding keys
+    // only the last key tile contains padding keys: a real (scalar) branch, not 64 selects per tile
+    if (__builtin_amdgcn_readfirstlane((kt + 1) * 64 > T)) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 64 + 32 * (kb >> 1) + 8 * lg + 4 * (kb & 1) + r;
+            if (key >= T) st[f][kb][r] = -INFINITY;
+          }
+    }
+    if constexpr (VAR & 8) {
+      // Lean softmax.  The running maximum is kept on the RAW scores and only moves when it is exceeded by more than
+      // kSlack (in base-2 exponent units after scaling): probabilities may then reach 2^kSlack, which fp32 sums and
+      // bf16 P hold without trouble, and the accumulator rescale (32 multiplies + its register traffic) runs on
+      // a few tiles instead of every tile.  p = exp2(fma(s, c, -m c)): no separate scale pass.  Row sums come
+      // out of the MFMA pipe (ones block appended to V^T) instead of 32 VALU adds per tile.
+      constexpr float c2 = 0.125f * 1.44269504088896340736f;
+      constexpr float kSlack = 8.0f;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mxs = mx * c2;
+        if (mxs > m_run[f] + kSlack || m_run[f] == -INFINITY) {      // rare after the first tiles
+          const float m_new = fmaxf(m_run[f], mxs);
+          const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+          m_run[f] = m_new;
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[f][d][r] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lsum[f][r] *= alpha;
+        }
+        const float nm = -m_run[f];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8_t v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = (__bf16)__builtin_amdgcn_exp2f(fmaf(st[f][2 * s2][r], c2, nm));
+            v[4 + r] = (__bf16)__builtin_amdgcn_exp2f(fmaf(st[f][2 * s2 + 1][r], c2, nm));
+          }
+          pf[f][s2] = v;
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {     // row sums of the bf16 probabilities: ones . P^T
+        lsum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, pf[0][s2], lsum[0], 0, 0, 0);
+        lsum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, pf[1][s2], lsum[1], 0, 0, 0);
+      }
+    } else {
     // VAR & 2: softmax in base 2 on the raw v_exp_f32 (scale folds 1/sqrt(64) * log2 e); else natural exp
     constexpr float kScaleLog2 = (VAR & 2) ? 0.125f * 1.44269504088896340736f : 0.125f;
 #pragma unroll
@@ -111,11 +173,7 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float s = st[f][kb][r] * kScaleLog2;
-          if (tail) {
-            const int key = kt * 64 + 32 * (kb >> 1) + 8 * lg + 4 * (kb & 1) + r;
-            s = key < T ? s : -INFINITY;
-          }
+          const float s = st[f][kb][r] * kScaleLog2;
           st[f][kb][r] = s;
           mx = fmaxf(mx, s);
         }
@@ -151,6 +209,7 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
         pf[f][s2] = v;
       }
     }
+    }
     // ---- O^T += Vt . P^T ----
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -170,9 +229,14 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
 
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    float l = l_run[f];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l;
+    if constexpr (VAR & 8) {
+      l = lsum[f][0];                      // every row of the ones-block result holds the full sum of column li
+    } else {
+      l = l_run[f];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     const float inv = 1.0f / l;
     const int t = q0 + f * 16 + li;
     if (t < T) {
@@ -240,7 +304,7 @@ __global__ __launch_bounds__(64) void attn_enc_f32_kernel(const float* __restric
   }
 }
 
-int g_attn_enc_variant = 7;   // wj_tune("attn_enc_variant"): bit0 XCD remap, bit1 base-2 softmax, bit2 lazy rescale
+int g_attn_enc_variant = 9;   // wj_tune("attn_enc_variant"): bit0 XCD remap, bit1 base-2 softmax, bit2 lazy rescale, bit3 lean softmax
 
 int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt, void* out, int B, int T, int Tpad,
                          int H, hipStream_t s) {
@@ -254,7 +318,7 @@ int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt
 #define WJ_ATTN(V)                                                                                                 \
   hipLaunchKernelGGL(attn_enc_bf16_kernel<V>, grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,          \
                      (const bf16_t*)Vt, (bf16_t*)out, T, Tpad, H)
-    switch (g_attn_enc_variant & 7) {
+    switch (g_attn_enc_variant & 15) {
       case 0: WJ_ATTN(0); break;
       case 1: WJ_ATTN(1); break;
       case 2: WJ_ATTN(2); break;
@@ -262,7 +326,9 @@ int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt
       case 4: WJ_ATTN(4); break;
       case 5: WJ_ATTN(5); break;
       case 6: WJ_ATTN(6); break;
-      default: WJ_ATTN(7); break;
+      case 7: WJ_ATTN(7); break;
+      case 8: WJ_ATTN(8); break;
+      default: WJ_ATTN(9); break;
     }
 #undef WJ_ATTN
   }
