@@ -180,6 +180,17 @@ def run_cfg3(args, info, dims):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     rtfx = 60.0 * minutes * args.steps / elapsed
+    stages = {}
+    if not args.no_profile:     # one more (eager, event-timed) pass: where the ASR time goes per launch class
+        from whisperjav_amd import hipbind
+        ctx = hipbind.context(info.local_rank)
+        ctx.profile_start()
+        once()
+        prof = ctx.profile_stop()
+        total_ms = sum(ms for _, ms in prof.values()) or 1.0
+        for tag, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]:
+            stages[tag] = {"launches": cnt, "ms_total": round(ms, 3), "share": round(ms / total_ms, 4),
+                           "us_per_launch": round(1e3 * ms / max(cnt, 1), 2)}
     line = {"metric": "audio-hours/sec (RTF) end-to-end, Whisper large-v3 ja", "value": round(rtfx, 2),
             "unit": "x real-time (audio-s per wall-s)", "audio_hours_per_sec": round(rtfx / 3600.0, 5), "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
@@ -190,7 +201,7 @@ def run_cfg3(args, info, dims):
                                     f"weights), beam 5 / patience 1.2 / repetition penalty 1.5 / no-repeat-3-gram, "
                                     f"max_new_tokens={args.max_new_tokens}, device-resident beam search"),
                        "windows_per_batch": args.batch, "compute_type": args.dtype, **stats},
-            "roofline": None, "cpu_baseline": None}
+            "roofline": None, "cpu_baseline": None, "stages": stages}
     print(json.dumps(line), flush=True)
     model.close()
 
