@@ -841,3 +841,51 @@ def test_scene_detection_matches_reference_fixtures(hip, tmp_path):
             assert wf.getframerate() == 16000 and wf.getnframes() == int(e * 16000) - int(s * 16000)
         assert 0 <= s < e <= case["seconds"] + 1e-6 and dur <= 10.0 + 1e-9
     det.cleanup()
+
+
+def test_large_v3_geometry_beam_and_alignment_consistency(hip):
+    """BASELINE geometry (large-v3 shape, bf16): properties that need no CPU oracle run at full size --
+    the device-resident beam search equals the host-driven restatement over the step API, a window's result does not
+    depend on its batch neighbours, and the full-sequence alignment pass agrees with the token-by-token one."""
+    from whisperjav_amd import dims as pdims, engine, hipbind, search, synth, weights as pweights
+    dims = pdims.dims_for("large-v3")
+    model = engine.HipWhisper(dims, pweights.synth_weights(dims, seed=1234), dtype="bfloat16", max_batch=3, max_beam=5)
+    fe = engine.HipLogMel(128, "fw")
+    clips = [synth.speech_like(30.0, seed=1234), synth.speech_like(11.0, seed=77), synth.speech_like(30.0, seed=5)]
+    model.encode(fe(clips))
+    toks = model.tokens
+    prompt = model.sot_prompt("ja", "transcribe")
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    o = engine.DecodeOptions(max_new_tokens=14, suppress_tokens=suppress, max_initial_timestamp=0.0, repetition_penalty=1.5,
+                             no_repeat_ngram_size=3)
+    P = np.tile(np.array(prompt, dtype=np.int32), (3, 1))
+    dev = model.decode_beam(P, o, beam_size=5, patience=1.2, length_penalty=1.0)
+    so = search.SearchOptions(beam_size=5, patience=1.2, length_penalty=1.0, repetition_penalty=1.5, no_repeat_ngram_size=3,
+                              suppress_tokens=suppress, max_initial_timestamp_index=0, max_new_tokens=14)
+    host = search.beam_search(search.HipStepScorer(model, so), [prompt] * 3, so, eot=toks.eot, timestamp_begin=toks.timestamp_begin)
+    for w in range(3):
+        assert dev.tokens[w, : dev.n_tokens[w]].tolist() == host[w].sequences[0], w
+        assert abs(float(dev.sum_logprob[w]) - host[w].cum_logprobs[0]) < 2e-2
+    # batch invariance: window 1 alone (slot map) == window 1 inside the batch of three
+    g3 = model.decode_greedy(P, o)
+    g1 = model.decode_sample(P[:1], o, temperature=0.0, best_of=1, slots=[1])
+    assert g1.tokens[0].tolist() == g3.tokens[1].tolist()
+    # alignment: full-sequence pass vs token-by-token pass
+    sot_seq = prompt[:3]
+    rows = [[*sot_seq, toks.no_timestamps, *[int(t) for t in g3.tokens[w, : g3.n_tokens[w]] if t < toks.eot], toks.eot] for w in range(3)]
+    heads = [(7, 0), (10, 17), (12, 18), (13, 12), (16, 1), (17, 14), (19, 11), (21, 4), (24, 1), (25, 6)]
+    frames = [3000, 1100, 3000]
+    a = model.align(rows, 4, heads, frames)
+    hipbind.tune("align_prefill", 0)
+    b = model.align(rows, 4, heads, frames)
+    hipbind.tune("align_prefill", 1)
+    worst = 0
+    for (ti_a, fi_a, p_a), (ti_b, fi_b, p_b), row, nf in zip(a, b, rows, frames):
+        n_text = len(row) - 5
+        assert ti_a[-1] == n_text and fi_a[-1] == nf // 2 - 1 and ti_b[-1] == n_text
+        first = lambda t, f: np.array([f[np.argmax(t == k)] for k in range(n_text + 1)])   # noqa: E731
+        worst = max(worst, int(np.abs(first(ti_a, fi_a) - first(ti_b, fi_b)).max()))
+        assert np.abs(p_a - p_b).max() < 5e-3
+    _diag("large_v3_consistency", {"align_shift_frames_prefill_vs_steps": worst})
+    assert worst <= 3, worst
+    model.close()
