@@ -65,3 +65,35 @@ def test_cached_decoder_equals_full_pass(pair):
     # logits spread is wide enough for stable argmax (design goal of synth_weights)
     top2 = full[0, -1].topk(2).values
     assert full[0, -1].std() > 0.5 and (top2[0] - top2[1]) > 1e-3
+
+
+def test_hf_checkpoint_directory_loads_with_the_right_names(tmp_path):
+    """weights.load_hf_checkpoint on a directory written by transformers' own save_pretrained: the oracle run on
+    the imported tensors reproduces the HF model's logits (pins the name mapping and the dims parsing), and the
+    engine's packer accepts the result."""
+    import json
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    from whisperjav_amd import weights as pweights
+    torch.manual_seed(3)
+    cfg = WhisperConfig(vocab_size=51865, num_mel_bins=80, d_model=128, encoder_layers=2, decoder_layers=2,
+                        encoder_attention_heads=2, decoder_attention_heads=2, encoder_ffn_dim=512, decoder_ffn_dim=512,
+                        max_source_positions=1500, max_target_positions=448)
+    hf = WhisperForConditionalGeneration(cfg).eval()
+    hf.save_pretrained(tmp_path, safe_serialization=True)
+    with open(tmp_path / "generation_config.json") as f:
+        gen = json.load(f)
+    gen["alignment_heads"] = [[1, 0], [1, 1]]
+    with open(tmp_path / "generation_config.json", "w") as f:
+        json.dump(gen, f)
+    dims, sd, extras = pweights.load_hf_checkpoint(str(tmp_path))
+    assert (dims.n_mels, dims.n_audio_state, dims.n_text_layer, dims.n_vocab) == (80, 128, 2, 51865)
+    assert extras["alignment_heads"] == [(1, 0), (1, 1)]
+    oracle = whisper_ref.WhisperOracle(helpers.oracle_dims(dims), sd)
+    mel = torch.from_numpy(helpers.synth_mel(1, 80, seed=2))
+    toks = torch.tensor([[50258, 50266, 50359, 50363, 11, 12]])
+    with torch.no_grad():
+        ref = hf(input_features=mel, decoder_input_ids=toks).logits
+        got = oracle.decoder_logits(toks, oracle.encode(mel))
+    assert float((got - ref).abs().max()) < 5e-4
+    blob, offsets = pweights.pack_blob(dims, sd, "bfloat16")
+    assert len(offsets) == pweights.expected_tensor_count(dims)

@@ -228,3 +228,81 @@ def load_openai_checkpoint(path: str) -> Tuple[WhisperDims, Dict[str, np.ndarray
     dims = WhisperDims(**{k: int(v) for k, v in ckpt["dims"].items()})
     sd = {k: v.float().numpy() for k, v in ckpt["model_state_dict"].items()}
     return dims, sd
+
+
+def load_hf_checkpoint(path: str) -> Tuple[WhisperDims, Dict[str, np.ndarray], Dict[str, object]]:
+    """Import a Hugging Face ``WhisperForConditionalGeneration`` directory (``config.json`` + ``model.safetensors`` or
+    its sharded form, e.g. a local copy of openai/whisper-large-v3).  Returns ``(dims, openai-named state dict,
+    extras)`` where extras may hold ``alignment_heads`` from ``generation_config.json``."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    with open(os.path.join(path, "config.json")) as f:
+        cfg = json.load(f)
+    dims = WhisperDims(n_mels=int(cfg["num_mel_bins"]), n_audio_ctx=int(cfg["max_source_positions"]),
+                       n_audio_state=int(cfg["d_model"]), n_audio_head=int(cfg["encoder_attention_heads"]),
+                       n_audio_layer=int(cfg["encoder_layers"]), n_vocab=int(cfg["vocab_size"]),
+                       n_text_ctx=int(cfg["max_target_positions"]), n_text_state=int(cfg["d_model"]),
+                       n_text_head=int(cfg["decoder_attention_heads"]), n_text_layer=int(cfg["decoder_layers"]))
+    index = os.path.join(path, "model.safetensors.index.json")
+    if os.path.exists(index):
+        with open(index) as f:
+            files = sorted(set(json.load(f)["weight_map"].values()))
+    else:
+        files = ["model.safetensors"]
+    hf: Dict[str, np.ndarray] = {}
+    for name in files:
+        for k, v in load_file(os.path.join(path, name)).items():      # any stored dtype (fp16 / bf16 / fp32)
+            hf[k[6:] if k.startswith("model.") else k] = v.float().numpy()
+    sd: Dict[str, np.ndarray] = {}
+
+    def take(dst: str, src: str, required: bool = True) -> None:
+        if src in hf:
+            sd[dst] = np.ascontiguousarray(hf[src], dtype=np.float32)
+        elif required:
+            raise KeyError(f"{path}: tensor {src!r} missing (not a Whisper checkpoint?)")
+
+    for side in ("encoder", "decoder"):
+        take(f"{side}.positional_embedding", f"{side}.embed_positions.weight")
+    for n in ("conv1", "conv2"):
+        take(f"encoder.{n}.weight", f"encoder.{n}.weight")
+        take(f"encoder.{n}.bias", f"encoder.{n}.bias")
+    take("encoder.ln_post.weight", "encoder.layer_norm.weight")
+    take("encoder.ln_post.bias", "encoder.layer_norm.bias")
+    take("decoder.token_embedding.weight", "decoder.embed_tokens.weight")
+    take("decoder.ln.weight", "decoder.layer_norm.weight")
+    take("decoder.ln.bias", "decoder.layer_norm.bias")
+
+    def attn(dst: str, src: str) -> None:
+        for a, b in (("query", "q_proj"), ("key", "k_proj"), ("value", "v_proj"), ("out", "out_proj")):
+            take(f"{dst}.{a}.weight", f"{src}.{b}.weight")
+            take(f"{dst}.{a}.bias", f"{src}.{b}.bias", required=(a != "key"))
+
+    def pair(dst: str, src: str) -> None:
+        take(dst + ".weight", src + ".weight")
+        take(dst + ".bias", src + ".bias")
+
+    for i in range(dims.n_audio_layer):
+        d, h = f"encoder.blocks.{i}", f"encoder.layers.{i}"
+        attn(d + ".attn", h + ".self_attn")
+        pair(d + ".attn_ln", h + ".self_attn_layer_norm")
+        pair(d + ".mlp_ln", h + ".final_layer_norm")
+        pair(d + ".mlp.0", h + ".fc1")
+        pair(d + ".mlp.2", h + ".fc2")
+    for i in range(dims.n_text_layer):
+        d, h = f"decoder.blocks.{i}", f"decoder.layers.{i}"
+        attn(d + ".attn", h + ".self_attn")
+        attn(d + ".cross_attn", h + ".encoder_attn")
+        pair(d + ".attn_ln", h + ".self_attn_layer_norm")
+        pair(d + ".cross_attn_ln", h + ".encoder_attn_layer_norm")
+        pair(d + ".mlp_ln", h + ".final_layer_norm")
+        pair(d + ".mlp.0", h + ".fc1")
+        pair(d + ".mlp.2", h + ".fc2")
+    extras: Dict[str, object] = {}
+    gen = os.path.join(path, "generation_config.json")
+    if os.path.exists(gen):
+        with open(gen) as f:
+            heads = json.load(f).get("alignment_heads")
+        if heads:
+            extras["alignment_heads"] = [(int(a), int(b)) for a, b in heads]
+    return dims, sd, extras

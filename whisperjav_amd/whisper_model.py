@@ -303,8 +303,15 @@ class HipWhisperModel:
                 cand = os.path.join(path, name)
                 if os.path.exists(cand):
                     return W.load_openai_checkpoint(cand)
-            raise FileNotFoundError(f"{path} holds no openai-format checkpoint (model.pt); convert the CTranslate2 "
-                                    "model with tools described in INTEGRATION.md")
+            if os.path.exists(os.path.join(path, "config.json")) and (
+                    os.path.exists(os.path.join(path, "model.safetensors"))
+                    or os.path.exists(os.path.join(path, "model.safetensors.index.json"))):
+                dims, sd, extras = W.load_hf_checkpoint(path)      # a Hugging Face WhisperForConditionalGeneration directory
+                if extras.get("alignment_heads"):
+                    self._alignment_heads = list(extras["alignment_heads"])
+                return dims, sd
+            raise FileNotFoundError(f"{path} holds neither an openai-format checkpoint (model.pt) nor a Hugging Face "
+                                    "one (config.json + model.safetensors); see INTEGRATION.md")
         if os.path.isfile(path):
             return W.load_openai_checkpoint(path)
         raise FileNotFoundError(
