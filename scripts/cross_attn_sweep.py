@@ -12,7 +12,7 @@ from whisperjav_amd import engine, hipbind  # noqa: E402
 
 out = []
 H, n_keys = 20, 1500
-for G, nb in [(128, 1), (64, 1), (32, 1), (26, 5), (128, 5)]:
+for G, nb in [(384, 1), (128, 1), (128, 5)]:
     g = torch.Generator().manual_seed(1)
     q = torch.randn(G, nb, H * 64, generator=g).cuda()
     k = torch.randn(G, H, n_keys, 64, generator=g).cuda()
@@ -20,13 +20,14 @@ for G, nb in [(128, 1), (64, 1), (32, 1), (26, 5), (128, 5)]:
     bytes_ = 2.0 * G * H * n_keys * 64 * 2
     ref, ms_old = engine.k_attention_dec_timed(q, k, v, "bfloat16", layout=1, reps=30)
     row = {"G": G, "nb": nb, "valu_ms": ms_old, "valu_GBs": bytes_ / ms_old / 1e6}
-    for u in (0, 1, 2, 3):
-        hipbind.tune("dec_cross_u", u)
-        got, ms = engine.k_attention_dec_timed(q, k, v, "bfloat16", layout=0, reps=30)
-        row[f"mfma_u{u}_ms"] = ms
-        row[f"mfma_u{u}_GBs"] = bytes_ / ms / 1e6
-        row[f"mfma_u{u}_maxdiff"] = float((got - ref).abs().max())
-    hipbind.tune("dec_cross_u", 0)
+    for nt in (0, 1):
+        hipbind.tune("dec_cross_nt", nt)
+        for u in (0, 1, 2, 3):
+            hipbind.tune("dec_cross_u", u)
+            got, ms = engine.k_attention_dec_timed(q, k, v, "bfloat16", layout=0, reps=30)
+            row[f"mfma_nt{nt}_u{u}_GBs"] = round(bytes_ / ms / 1e6, 1)
+            row[f"mfma_nt{nt}_u{u}_maxdiff"] = float((got - ref).abs().max())
+    hipbind.tune("dec_cross_u", 0); hipbind.tune("dec_cross_nt", 0)
     print(json.dumps(row), flush=True)
     out.append(row)
     del q, k, v

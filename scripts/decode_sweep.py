@@ -18,12 +18,11 @@ toks = model.tokens
 suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
 opts = engine.DecodeOptions(max_new_tokens=TOK, suppress_tokens=suppress, max_initial_timestamp=1.0)
 rows = []
-# (batch, ks_attn, ks_fc2, ks_proj)
-configs = [(384, 4, 8, 4), (384, 4, 8, 2), (384, 2, 8, 2), (384, 4, 4, 2), (384, 2, 4, 2), (384, 8, 8, 2), (384, 4, 16, 2),
-           (256, 4, 8, 4), (256, 4, 8, 2), (256, 2, 4, 2)]
+# (batch, dec_cross_nt, dec_cross_u)
+configs = [(384, 0, 0), (384, 1, 0), (384, 0, 2), (384, 1, 2), (384, 1, 3), (128, 0, 0), (128, 1, 0), (128, 1, 2)]
 ref_tokens = {}
-for B, ka, kf, kp in configs:
-    hipbind.tune("dec_ks_attn", ka); hipbind.tune("dec_ks_fc2", kf); hipbind.tune("dec_ks_proj", kp)
+for B, nt, u in configs:
+    hipbind.tune("dec_cross_nt", nt); hipbind.tune("dec_cross_u", u)
     prompt = np.tile(np.array(model.sot_prompt("ja"), dtype=np.int32), (B, 1))
     model.decode_greedy(prompt, engine.DecodeOptions(max_new_tokens=4, suppress_tokens=suppress))   # warm
     best = 1e9
@@ -34,8 +33,8 @@ for B, ka, kf, kp in configs:
         same = float((res.tokens == ref_tokens[B]).mean())
     else:
         ref_tokens[B] = res.tokens.copy()
-    rows.append({"B": B, "ks_attn": ka, "ks_fc2": kf, "ks_proj": kp, "ms_per_step": round(1e3 * best / (TOK + 2), 3),
+    rows.append({"B": B, "cross_nt": nt, "cross_u": u, "ms_per_step": round(1e3 * best / (TOK + 2), 3),
                  "token_agreement_vs_first_config": same})
     print(rows[-1], flush=True)
-hipbind.tune("dec_ks_attn", 4); hipbind.tune("dec_ks_fc2", 8); hipbind.tune("dec_ks_proj", 4)
+hipbind.tune("dec_cross_nt", 0); hipbind.tune("dec_cross_u", 0)
 json.dump(rows, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "decode_sweep.json"), "w"), indent=1)

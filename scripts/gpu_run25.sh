@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out && rm -rf gpurun_out/summary.log
+export TMPDIR=/tmp
+timeout 400 python scripts/cross_attn_sweep.py > gpurun_out/cross_attn_sweep.log 2>&1; echo "xsweep rc=$?" >> gpurun_out/summary.log
+timeout 600 python scripts/decode_sweep.py > gpurun_out/decode_sweep.log 2>&1; echo "sweep rc=$?" >> gpurun_out/summary.log
+tail -4 gpurun_out/cross_attn_sweep.log; tail -9 gpurun_out/decode_sweep.log; cat gpurun_out/summary.log

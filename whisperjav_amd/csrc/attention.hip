@@ -569,7 +569,20 @@ __device__ __forceinline__ uint32_t scale2_bf16(uint32_t pair, float sc) {
   return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16);
 }
 
-template <int U1, int U2>
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// K / V are read exactly once per launch and never again before 30 GB of other traffic has passed: NT = non-temporal
+// loads keep them from displacing the step's reusable lines (weights slices, q, partial slabs) in L2 / MALL
+template <bool NT>
+__device__ __forceinline__ uint4 ldg_stream(const bf16_t* p) {
+  if constexpr (NT) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  } else {
+    return *reinterpret_cast<const uint4*>(p);
+  }
+}
+
+template <int U1, int U2, bool NT>
 __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -629,8 +642,8 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
     for (int u = 0; u < U1; ++u) {
       const int key = min((t0 + 4 * u) * 16 + li, n_keys - 1);     // clamped, never predicated
       const bf16_t* kp = Kh + (int64_t)key * 64 + lg * 8;
-      ka[u][0] = *reinterpret_cast<const uint4*>(kp);
-      ka[u][1] = *reinterpret_cast<const uint4*>(kp + 32);
+      ka[u][0] = ldg_stream<NT>(kp);
+      ka[u][1] = ldg_stream<NT>(kp + 32);
     }
 #pragma unroll
     for (int u = 0; u < U1; ++u) {
@@ -688,7 +701,7 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
 #pragma unroll
     for (int u = 0; u < U2; ++u) {
       const int c = min(c0 + u, n_chunks - 1);
-      va[u] = *reinterpret_cast<const uint4*>(Vh + c * 32 + lg * 8);
+      va[u] = ldg_stream<NT>(Vh + c * 32 + lg * 8);
     }
 #pragma unroll
     for (int u = 0; u < U2; ++u) {
@@ -707,6 +720,7 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
   }
 }
 
+int g_dec_cross_nt = 0;  // wj_tune("dec_cross_nt"): non-temporal K/V loads in the MFMA cross-attention kernel
 int g_dec_cross_u = 0;   // wj_tune("dec_cross_u"): loads in flight per wave in the MFMA cross-attention kernel
 
 static int launch_cross_mfma(const DecAttnArgs& a, hipStream_t s) {
@@ -714,11 +728,16 @@ static int launch_cross_mfma(const DecAttnArgs& a, hipStream_t s) {
   if (a.vt_stride < a.n_keys || (a.vt_stride & 31)) { set_error("attention_dec: vt_stride %d must be a multiple of 32 >= n_keys %d", a.vt_stride, a.n_keys); return WJ_E_INVALID; }
   const size_t smem = (size_t)a.nb * a.vt_stride * 6 + 128 * sizeof(float);
   const dim3 grid(a.H, a.G), block(256);
-  switch (g_dec_cross_u) {
-    case 1: hipLaunchKernelGGL((attn_cross_mfma_kernel<2, 4>), grid, block, smem, s, a); break;
-    case 2: hipLaunchKernelGGL((attn_cross_mfma_kernel<6, 12>), grid, block, smem, s, a); break;
-    case 3: hipLaunchKernelGGL((attn_cross_mfma_kernel<8, 16>), grid, block, smem, s, a); break;
-    default: hipLaunchKernelGGL((attn_cross_mfma_kernel<4, 8>), grid, block, smem, s, a); break;
+  const int sel = (g_dec_cross_u & 3) | (g_dec_cross_nt ? 4 : 0);
+  switch (sel) {
+    case 1: hipLaunchKernelGGL((attn_cross_mfma_kernel<2, 4, false>), grid, block, smem, s, a); break;
+    case 2: hipLaunchKernelGGL((attn_cross_mfma_kernel<6, 12, false>), grid, block, smem, s, a); break;
+    case 3: hipLaunchKernelGGL((attn_cross_mfma_kernel<8, 16, false>), grid, block, smem, s, a); break;
+    case 4: hipLaunchKernelGGL((attn_cross_mfma_kernel<4, 8, true>), grid, block, smem, s, a); break;
+    case 5: hipLaunchKernelGGL((attn_cross_mfma_kernel<2, 4, true>), grid, block, smem, s, a); break;
+    case 6: hipLaunchKernelGGL((attn_cross_mfma_kernel<6, 12, true>), grid, block, smem, s, a); break;
+    case 7: hipLaunchKernelGGL((attn_cross_mfma_kernel<8, 16, true>), grid, block, smem, s, a); break;
+    default: hipLaunchKernelGGL((attn_cross_mfma_kernel<4, 8, false>), grid, block, smem, s, a); break;
   }
   WJ_LAUNCH_CHECK();
   return WJ_OK;

@@ -666,6 +666,7 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_rows_ks_attn")) g_tune.dec_rows_ks_attn = value;
   else if (!strcmp(key, "dec_rows_ks_fc2")) g_tune.dec_rows_ks_fc2 = value;
   else if (!strcmp(key, "dec_cross_u")) g_dec_cross_u = value;
+  else if (!strcmp(key, "dec_cross_nt")) g_dec_cross_nt = value;
   else { set_error("wj_tune: unknown key %s", key); return WJ_E_INVALID; }
   return WJ_OK;
 }

@@ -102,6 +102,7 @@ struct DecAttnArgs {
   int seq_tp = 0, dump_chunks = 0;
 };
 extern int g_dec_cross_u;
+extern int g_dec_cross_nt;
 extern int g_gemm_big;
 int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s);
 
