@@ -326,3 +326,37 @@ def test_word_timestamps_host_logic_and_seek_update():
     assert (segs[0].start, segs[0].end) == (0.5, 1.5) and (segs[1].start, segs[1].end) == (1.5, 2.0)
     # the window did not end on a single timestamp pair -> the next window starts at the last word end (2.0 s = frame 200)
     assert segs[2].seek == 200 if len(segs) > 2 else True
+
+
+def test_language_detection_feeds_prompt_and_info():
+    """language=None: the per-clip winner of the language-token distribution goes into the prompt and the info
+    (faster-whisper's detect loop with language_detection_segments windows and the 0.5 threshold)."""
+    tb = pdims.special_tokens(51865).timestamp_begin
+    m = _model([[tb, 5, tb + 100]])
+    seen = []
+    greedy0 = m.model.decode_greedy
+
+    def greedy(prompts, options):
+        seen.append(prompts.copy())
+        return greedy0(prompts, options)
+    calls = {"n": 0}
+
+    def language_probs(n):
+        calls["n"] += 1
+        p = np.full((n, 99), 0.001, dtype=np.float32)
+        if calls["n"] == 1:
+            p[0, pdims.language_index("en")] = 0.9          # clip 0: confident at once
+            p[1, pdims.language_index("ko")] = 0.4          # clip 1: below the threshold -> second window decides
+        else:
+            p[0, pdims.language_index("ja")] = 0.45
+        return p
+    m.model.decode_greedy, m.model.language_probs = greedy, language_probs
+    clips = [np.zeros(16000 * 3, np.float32), np.zeros(16000 * 40, np.float32)]
+    _, infos = m.transcribe_many(clips, beam_size=1, temperature=0.0, language=None, language_detection_segments=2,
+                                 condition_on_previous_text=False)
+    assert [i.language for i in infos] == ["en", "ko"]          # tie in the vote: the first window's language wins
+    assert infos[0].language_probability == pytest.approx(0.9) and infos[0].all_language_probs[0] == ("en", pytest.approx(0.9))
+    t = m.tokens
+    first = seen[0]
+    assert first[0, 1] == t.language_token(pdims.language_index(infos[0].language))
+    assert first[1, 1] == t.language_token(pdims.language_index(infos[1].language))

@@ -889,3 +889,29 @@ def test_large_v3_geometry_beam_and_alignment_consistency(hip):
     _diag("large_v3_consistency", {"align_shift_frames_prefill_vs_steps": worst})
     assert worst <= 3, worst
     model.close()
+
+
+def test_language_detection_matches_oracle(hip):
+    """detect_language: one decoder step on <|sot|>, softmax over the language tokens -- probabilities against the
+    fp32 oracle (1e-5) and the winner through the shim (language=None)."""
+    from whisperjav_amd import dims as pdims, synth, weights as pweights, whisper_model as wm
+    d, oracle, model = _engine_and_oracle("float32", max_batch=3)
+    mel = torch.from_numpy(helpers.synth_mel(3, d.n_mels, seed=51))
+    model.encode(mel.cuda())
+    got = model.language_probs(3)
+    t = model.tokens
+    with torch.no_grad():
+        lg = oracle.decoder_logits(torch.full((3, 1), t.sot), oracle.encode(mel))[:, 0]
+    ref = torch.softmax(lg[:, t.sot + 1: t.sot + 1 + t.num_languages].double(), dim=-1).numpy()
+    assert got.shape == ref.shape == (3, 99) and np.abs(got - ref).max() < 1e-5
+    assert np.array_equal(got.argmax(1), ref.argmax(1))
+    model.close()
+    w = pweights.synth_weights(d, seed=21)
+    shim = wm.HipWhisperModel("tiny", compute_type="float32", weights=w, dims=d, max_batch=2, max_beam=1)
+    audio = synth.speech_like(5.0, seed=8)
+    segs, info = shim.transcribe(audio, language=None, beam_size=1, temperature=0.0, max_new_tokens=8, word_timestamps=False,
+                                 no_speech_threshold=None, language_detection_threshold=0.0)
+    segs = list(segs)
+    assert info.language in pdims.LANGUAGE_CODES and info.all_language_probs[0][0] == info.language
+    assert abs(sum(p for _, p in info.all_language_probs) - 1.0) < 1e-4
+    shim.close()

@@ -341,6 +341,18 @@ class HipWhisper:
         self.ctx.sync()
         return out
 
+    def language_probs(self, n_windows: int) -> np.ndarray:
+        """ctranslate2 ``Whisper.detect_language`` / ``whisper.decoding.detect_language`` for the resident windows:
+        one decoder step on ``<|startoftranscript|>``, softmax over the language tokens only -> float32
+        ``[n_windows, num_languages]`` (order of ``dims.LANGUAGE_CODES``)."""
+        t = self.tokens
+        self.open(int(n_windows), 1)
+        self.step(np.full(int(n_windows), t.sot, dtype=np.int32), want_logits=True)
+        lg = self.logits()[:, t.sot + 1: t.sot + 1 + t.num_languages].cpu().numpy().astype(np.float64)
+        lg -= lg.max(axis=1, keepdims=True)
+        p = np.exp(lg)
+        return (p / p.sum(axis=1, keepdims=True)).astype(np.float32)
+
     def topk(self, k: int, ban: Optional[torch.Tensor] = None):
         rows = self._rows
         ids = np.empty((rows, k), dtype=np.int32)

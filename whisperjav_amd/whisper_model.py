@@ -251,6 +251,9 @@ class _ClipState:
     segments: List[Segment] = field(default_factory=list)
     next_id: int = 0
     last_speech: float = 0.0
+    language: str = "ja"
+    language_probability: float = 1.0
+    all_language_probs: Optional[List[Tuple[str, float]]] = None
 
     @property
     def active(self) -> bool:
@@ -355,7 +358,8 @@ class HipWhisperModel:
             sup.append(t.no_speech)      # whisper/decoding.py _get_suppress_tokens adds <|nospeech|> as well
         return tuple(sorted(set(sup)))
 
-    def _prompt(self, o: TranscribeOptions, previous: Sequence[int], first_window: bool) -> List[int]:
+    def _prompt(self, o: TranscribeOptions, previous: Sequence[int], first_window: bool,
+                language: Optional[str] = None) -> List[int]:
         t = self.tokens
         prompt: List[int] = []
         hot = o.hotwords if (o.hotwords and not o.prefix) else None
@@ -366,7 +370,7 @@ class HipWhisperModel:
                 prompt.extend(ht[: self.max_length // 2 - 1])
             if previous:
                 prompt.extend(list(previous)[-(self.max_length // 2 - 1):])
-        lang = o.language or "ja"
+        lang = language or o.language or "ja"
         prompt.extend([t.sot, t.language_token(pdims.language_index(lang)),
                        t.transcribe if o.task == "transcribe" else t.translate])
         if o.without_timestamps:
@@ -536,24 +540,24 @@ class HipWhisperModel:
             return [(7, 0), (10, 17), (12, 18), (13, 12), (16, 1), (17, 14), (19, 11), (21, 4), (24, 1), (25, 6)]
         return [(l, h) for l in range(L // 2, L) for h in range(H)]
 
-    def _find_alignment(self, windows: List[Tuple[int, List[int], int]], language: str) -> List[List[dict]]:
-        """``windows`` = (resident slot, text tokens, content frames) -> per window the word dicts of
+    def _find_alignment(self, windows: List[Tuple[int, List[int], int, str]], task: str = "transcribe") -> List[List[dict]]:
+        """``windows`` = (resident slot, text tokens, content frames, language) -> per window the word dicts of
         faster-whisper ``find_alignment`` ({word, tokens, start, end, probability}; times relative to the window)."""
         t = self.tokens
-        sot_sequence = [t.sot, t.language_token(pdims.language_index(language)), t.transcribe]
+        task_tok = t.transcribe if task == "transcribe" else t.translate
         rows, keep = [], []
-        for i, (_, text_tokens, _) in enumerate(windows):
+        for i, (_, text_tokens, _, lang) in enumerate(windows):
             if text_tokens:
-                rows.append([*sot_sequence, t.no_timestamps, *text_tokens, t.eot])
+                rows.append([t.sot, t.language_token(pdims.language_index(lang)), task_tok, t.no_timestamps, *text_tokens, t.eot])
                 keep.append(i)
         out: List[List[dict]] = [[] for _ in windows]
         if not rows:
             return out
-        res = self.model.align(rows, len(sot_sequence) + 1, self.alignment_heads(), [windows[i][2] for i in keep],
+        res = self.model.align(rows, 4, self.alignment_heads(), [windows[i][2] for i in keep],
                                slots=[windows[i][0] for i in keep])
         for i, (text_idx, time_idx, probs) in zip(keep, res):
             text_tokens = windows[i][1]
-            words, word_tokens = self.tokenizer.split_to_word_tokens(list(text_tokens) + [t.eot], language)
+            words, word_tokens = self.tokenizer.split_to_word_tokens(list(text_tokens) + [t.eot], windows[i][3])
             if len(word_tokens) <= 1 or len(text_idx) == 0:
                 continue
             bounds = np.pad(np.cumsum([len(w) for w in word_tokens[:-1]]), (1, 0))
@@ -594,8 +598,8 @@ class HipWhisperModel:
         eot = self.tokens.eot
         per_piece = [[[tk for tk in pc["tokens"] if tk < eot] for pc in w["pieces"]] for w in windows]
         flat = [[tk for pc in pieces for tk in pc] for pieces in per_piece]
-        alignments = self._find_alignment([(w["slot"], flat[i], w["frames"]) for i, w in enumerate(windows)],
-                                          o.language or "ja")
+        alignments = self._find_alignment([(w["slot"], flat[i], w["frames"], w["st"].language) for i, w in enumerate(windows)],
+                                          o.task)
         for w, alignment, piece_tokens in zip(windows, alignments, per_piece):
             durations = np.array([a["end"] - a["start"] for a in alignment])
             durations = durations[durations.nonzero()]
@@ -697,6 +701,46 @@ class HipWhisperModel:
             if not o.condition_on_previous_text or temp > o.prompt_reset_on_temperature:
                 st.prompt_reset_since = len(st.all_tokens)
 
+    def _detect_languages(self, states: List["_ClipState"], feats, threshold: float, n_segments: int) -> None:
+        """``language=None``: faster-whisper's detection loop (whisper.transcribe uses the first 30 s only, i.e.
+        ``n_segments`` = 1) -- per clip the language-token distribution of successive 30 s windows until one exceeds
+        ``threshold``, else the majority vote of the per-window winners."""
+        import torch
+        codes = pdims.LANGUAGE_CODES[: self.tokens.num_languages]
+        votes: List[List[Tuple[str, float]]] = [[] for _ in states]
+        todo = list(range(len(states)))
+        for seg in range(n_segments):
+            todo = [i for i in todo if seg * N_FRAMES < states[i].n_frames_content]
+            if not todo:
+                break
+            nxt = []
+            for lo in range(0, len(todo), self.max_batch):
+                part = todo[lo: lo + self.max_batch]
+                mel = torch.zeros((len(part), self.dims.n_mels, N_FRAMES), dtype=torch.float32, device=feats.device)
+                for j, i in enumerate(part):
+                    size = min(N_FRAMES, states[i].n_frames_content - seg * N_FRAMES)
+                    mel[j, :, :size] = feats[states[i].index, :, seg * N_FRAMES: seg * N_FRAMES + size]
+                self.model.encode(mel)
+                probs = self.model.language_probs(len(part))
+                for j, i in enumerate(part):
+                    order = np.argsort(-probs[j], kind="stable")
+                    st = states[i]
+                    st.all_language_probs = [(codes[k], float(probs[j, k])) for k in order]
+                    top, p = st.all_language_probs[0]
+                    votes[i].append((top, p))
+                    if p > threshold:
+                        st.language, st.language_probability = top, p
+                    else:
+                        nxt.append(i)
+            todo = nxt
+        for i in todo:      # no window was confident enough: majority vote over the windows seen
+            seen: Dict[str, List[float]] = {}
+            for name, p in votes[i]:
+                seen.setdefault(name, []).append(p)
+            best = max(seen, key=lambda name: len(seen[name]))          # first language wins ties (insertion order)
+            states[i].language = best
+            states[i].language_probability = max(seen[best])
+
     # ---- public API ------------------------------------------------------------------------------
     def transcribe(self, audio: np.ndarray, **kwargs) -> Tuple[Iterator[Segment], TranscriptionInfo]:
         """faster-whisper's call contract for ONE clip: ``(segment iterator, info)``."""
@@ -724,6 +768,12 @@ class HipWhisperModel:
             for st in states:
                 st.all_tokens.extend(initial)
         tb = self.tokens.timestamp_begin
+        if o.language is None:
+            self._detect_languages(states, feats, float(o.language_detection_threshold or 0.5),
+                                   max(1, int(o.language_detection_segments or 1)))
+        else:
+            for st in states:
+                st.language = o.language
 
         while True:
             active = [st for st in states if st.active]
@@ -742,7 +792,7 @@ class HipWhisperModel:
                     if size < N_FRAMES:
                         mel[j, :, size:] = 0.0
                 self.model.encode(mel)
-                prompts = [self._prompt(o, st.all_tokens[st.prompt_reset_since:], st.seek == 0) for st in batch]
+                prompts = [self._prompt(o, st.all_tokens[st.prompt_reset_since:], st.seek == 0, st.language) for st in batch]
                 for j, p in enumerate(prompts):
                     groups.setdefault(len(p), []).append((batch[j], p, j))
                 if len(groups) == 1:
@@ -755,8 +805,9 @@ class HipWhisperModel:
                         res = self._decode_windows([p for _, p, _ in members], o, suppress)
                         self._finish_windows(o, [batch[j] for j in idx], [sizes[j] for j in idx], res,
                                              list(range(len(idx))), tb)
-        infos = [TranscriptionInfo(language=o.language or "ja", language_probability=1.0, duration=st.duration,
-                                   duration_after_vad=st.duration, transcription_options=dict(kwargs))
+        infos = [TranscriptionInfo(language=st.language, language_probability=st.language_probability, duration=st.duration,
+                                   duration_after_vad=st.duration, all_language_probs=st.all_language_probs,
+                                   transcription_options=dict(kwargs))
                  for st in states]
         return [st.segments for st in states], infos
 
