@@ -18,11 +18,11 @@ toks = model.tokens
 suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
 opts = engine.DecodeOptions(max_new_tokens=TOK, suppress_tokens=suppress, max_initial_timestamp=1.0)
 rows = []
-# (batch, dec_cross_nt, dec_cross_u)
-configs = [(384, 0, 0), (384, 1, 0), (384, 0, 2), (384, 1, 2), (384, 1, 3), (128, 0, 0), (128, 1, 0), (128, 1, 2)]
+# (batch, dec_tile_reg)
+configs = [(384, 0), (384, 1), (128, 0), (128, 1), (256, 0), (256, 1)]
 ref_tokens = {}
-for B, nt, u in configs:
-    hipbind.tune("dec_cross_nt", nt); hipbind.tune("dec_cross_u", u)
+for B, tr in configs:
+    hipbind.tune("dec_tile_reg", tr)
     prompt = np.tile(np.array(model.sot_prompt("ja"), dtype=np.int32), (B, 1))
     model.decode_greedy(prompt, engine.DecodeOptions(max_new_tokens=4, suppress_tokens=suppress))   # warm
     best = 1e9
@@ -33,8 +33,7 @@ for B, nt, u in configs:
         same = float((res.tokens == ref_tokens[B]).mean())
     else:
         ref_tokens[B] = res.tokens.copy()
-    rows.append({"B": B, "cross_nt": nt, "cross_u": u, "ms_per_step": round(1e3 * best / (TOK + 2), 3),
-                 "token_agreement_vs_first_config": same})
+    rows.append({"B": B, "tile_reg": tr, "ms_per_step": round(1e3 * best / (TOK + 2), 3), "token_agreement_vs_first_config": same})
     print(rows[-1], flush=True)
-hipbind.tune("dec_cross_nt", 0); hipbind.tune("dec_cross_u", 0)
+hipbind.tune("dec_tile_reg", 0)
 json.dump(rows, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "decode_sweep.json"), "w"), indent=1)

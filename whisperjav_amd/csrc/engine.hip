@@ -92,6 +92,7 @@ struct Tunables {
   int dec_rows_max_m = 32;   // measured: faster than the alternatives up to ~32 rows, slower from 64 (vector-L1 line rate)
   int dec_rows_ks_attn = 2; // its split-K factors for the residual projections (K = d) and fc2 (K = 4d)
   int dec_rows_ks_fc2 = 8;
+  int dec_tile_reg = 0;     // 1: the decode tile GEMMs stage through registers (global->VGPR->LDS) instead of LDS-DMA
   int dec_ms_stages = 0;    // LDS-DMA stages of the decode tile GEMM (0 = the 2-stage encoder kernel; 3-5 measured equal)
   int dec_fuse_reduce = 1;  // attention kernels consume the q / qkv split-K slices directly (no reduce launch)
   int align_prefill = 1;    // word-timestamp alignment as one full-sequence decoder pass (0: token by token)
@@ -322,7 +323,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   const int ks_attn = rows ? g_tune.dec_rows_ks_attn : g_tune.dec_ks_attn;
   const int ks_fc2 = rows ? g_tune.dec_rows_ks_fc2 : g_tune.dec_ks_fc2, tile_min_m = g_tune.dec_tile_min_m;
   const int ms = g_tune.dec_ms_stages;
-  const int tile_variant = (ms >= 3 && ms <= 5) ? 70 + ms : 3;
+  const int tile_variant = (ms >= 3 && ms <= 5) ? 70 + ms : (g_tune.dec_tile_reg ? 4 : 3);
   float* slab = m->partial + (int64_t)row0 * kDecKsMax * D;
   int pend_ks = 0;
   const float* pend_bias = nullptr;
@@ -659,6 +660,7 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_cross_mfma")) g_tune.dec_cross_mfma = value;
   else if (!strcmp(key, "gemm_big")) g_gemm_big = value;
   else if (!strcmp(key, "dec_ms_stages")) g_tune.dec_ms_stages = value;
+  else if (!strcmp(key, "dec_tile_reg")) g_tune.dec_tile_reg = value;
   else if (!strcmp(key, "dec_fuse_reduce")) g_tune.dec_fuse_reduce = value;
   else if (!strcmp(key, "align_prefill")) g_tune.align_prefill = value;
   else if (!strcmp(key, "dec_rows")) g_tune.dec_rows = value;
