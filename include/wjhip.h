@@ -52,8 +52,13 @@ int wj_sync(wj_ctx* ctx);
 /* device properties for roofline reporting: out[0]=CU count, out[1]=clock kHz, out[2]=HBM bytes (lo32), out[3]=(hi32) */
 int wj_device_info(wj_ctx* ctx, int64_t out[4]);
 
-/* Run-time tunables of the decode step ("dec_ks_attn", "dec_ks_fc2", "dec_tile_min_m", "decode_chains");
- * "attn_enc_variant"); defaults come from the sweeps under profiles/. */
+/* Run-time tunables (A/B switches behind the sweeps under profiles/; the defaults are the measured optimum).
+ * Decode step: "dec_ks_attn", "dec_ks_fc2", "dec_ks_proj", "dec_proj_min_m", "dec_tile_min_m" (split-K factors and the
+ * row counts that select them), "dec_rows", "dec_rows_max_m", "dec_rows_ks_attn", "dec_rows_ks_fc2" (one-wave-per-row-
+ * block GEMM for small batches), "dec_ms_stages", "dec_tile_reg" (decode tile GEMM staging), "dec_fuse_reduce",
+ * "decode_chains", "dec_cross_mfma" (read at wj_whisper_create), "dec_cross_u", "dec_cross_nt".
+ * Encoder: "attn_enc_variant" (bit0 XCD remap, bit1 base-2 softmax, bit2 lazy rescale, bit3 lean softmax),
+ * "gemm_big" (256-tile kernel).  Alignment: "align_prefill".  Unknown keys are an error. */
 int wj_tune(const char* key, int value);
 
 /* ---- profiler --------------------------------------------------------------------------
