@@ -97,3 +97,51 @@ def test_hf_checkpoint_directory_loads_with_the_right_names(tmp_path):
     assert float((got - ref).abs().max()) < 5e-4
     blob, offsets = pweights.pack_blob(dims, sd, "bfloat16")
     assert len(offsets) == pweights.expected_tensor_count(dims)
+
+
+def test_timestamp_rules_match_transformers_logits_processor():
+    """oracle/decoding.filter_logits (ApplyTimestampRules + SuppressTokens + SuppressBlank) against transformers'
+    independent WhisperTimeStampLogitsProcessor / SuppressTokens(AtBegin)LogitsProcessor on random logits and
+    histories covering every rule branch (first step, open pair, closed pair, monotonic floor, max initial
+    timestamp, timestamp-mass rule)."""
+    from types import SimpleNamespace
+    from transformers.generation.logits_process import (SuppressTokensAtBeginLogitsProcessor, SuppressTokensLogitsProcessor,
+                                                        WhisperTimeStampLogitsProcessor)
+    from oracle import decoding
+    V = 51865
+    lay = decoding.TokenLayout.for_vocab(V)
+    tb, P = lay.timestamp_begin, 3
+    gen_cfg = SimpleNamespace(no_timestamps_token_id=lay.no_timestamps, eos_token_id=lay.eot, bos_token_id=lay.eot,
+                              max_initial_timestamp_index=50, _detect_timestamp_from_logprob=True)
+    ts_proc = WhisperTimeStampLogitsProcessor(gen_cfg, begin_index=P)
+    suppress = [1, 2, 7, 8, 50256, lay.sot, lay.no_speech]
+    sup_proc = SuppressTokensLogitsProcessor(suppress)
+    blank_proc = SuppressTokensAtBeginLogitsProcessor([lay.blank, lay.eot], begin_index=P)
+    prompt = [lay.sot, lay.sot + 8, lay.sot + 101]
+    histories = [
+        [],                                   # first step: only initial timestamps <= 1.0 s
+        [tb],                                 # single opening timestamp
+        [tb, 500, 600],                       # inside a segment
+        [tb, 500, tb + 120],                  # pair open: text forbidden
+        [tb, 500, tb + 120, tb + 120],        # pair closed: no third timestamp, floor at tb + 121
+        [tb, 500, tb + 120, tb + 120, 41],    # text after a closed pair
+        [tb + 3, tb + 3, tb + 700],           # odd but reachable
+        [tb + 1499],                          # last timestamp value
+    ]
+    rng = np.random.default_rng(0)
+    cfg = decoding.FilterConfig(suppress_tokens=tuple(suppress), max_initial_timestamp_index=50, suppress_blank=True)
+    checked = 0
+    for trial in range(6):
+        for gen in histories:
+            logits = torch.from_numpy(rng.standard_normal((1, V)).astype(np.float32) * 3.0)
+            if trial % 2:        # push probability mass onto the timestamps: exercises the timestamp-mass rule both ways
+                logits[0, tb:] += 4.0
+            ids = torch.tensor([prompt + gen])
+            ref = blank_proc(ids, sup_proc(ids, logits))
+            ref = ts_proc(ids, ref)
+            got = decoding.filter_logits(logits, [prompt + gen], P, lay, cfg)
+            assert torch.equal(torch.isinf(got), torch.isinf(ref)), (trial, gen)
+            keep = ~torch.isinf(ref)
+            assert torch.equal(got[keep], ref[keep])
+            checked += 1
+    assert checked == 48
