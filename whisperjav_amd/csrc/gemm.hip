@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
 // --------------------------------------------------------------------------------------------
 constexpr int BBM = 256, BBN = 256;
 
-template <int EPI>
+template <int EPI, int SCHED>
 __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds_big[];   // [buf][A|W][256][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -336,6 +336,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
           else
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
+    }
+    if constexpr (SCHED == 1) {
+      // Issue-order hint for the whole k-step (both k-halves are one basic block): the first half's 12 fragment reads,
+      // then the second half's reads trickle in between the first half's MFMAs (1 ds_read per 2 MFMAs) so the LDS
+      // latency of half 2 hides under the matrix pipe, the 8 LDS-DMA requests of the next stage are spread over the
+      // second half's MFMAs.  Scheduling only: the data flow is unchanged.
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // DS read
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read (LDS-DMA)
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of tile kt+1 has landed
     __syncthreads();
@@ -517,7 +535,7 @@ static int launch_ms(const GemmArgs& a, hipStream_t s, int ns) {
   }
 }
 
-int g_gemm_big = 1;   // wj_tune("gemm_big"): 0 disables the 256-tile kernel (A/B timing)
+int g_gemm_big = 1;   // wj_tune("gemm_big"): 0 disables the 256-tile kernel, 2 selects its issue-order-hinted build
 
 template <int EPI>
 static int launch_big(const GemmArgs& a, hipStream_t s) {
@@ -528,13 +546,17 @@ static int launch_big(const GemmArgs& a, hipStream_t s) {
     constexpr size_t smem = 2 * 2 * BBM * TBK * sizeof(bf16_t);   // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_big_kernel<EPI>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_big_kernel<EPI, 0>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_big_kernel<EPI, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(128 KiB LDS): %s", hipGetErrorString(e)); return WJ_E_HIP; }
       attr_set = true;
     }
     dim3 grid(ceil_div(a.N, BBN), ceil_div(a.M, BBM), a.nbatch);
-    hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI>), grid, dim3(512), smem, s, a);
+    if (g_gemm_big == 2) hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 1>), grid, dim3(512), smem, s, a);
+    else hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 0>), grid, dim3(512), smem, s, a);
     WJ_LAUNCH_CHECK();
     return WJ_OK;
   }
