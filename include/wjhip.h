@@ -189,11 +189,12 @@ int wj_whisper_decode_sample(wj_whisper* m, int batch, int group, const int32_t*
  * round(beam * patience) hypotheses are finished or max_new_tokens is reached; the hypothesis with the best
  * score / len^length_penalty wins.  Outputs per WINDOW: tokens_out [batch][max_new_tokens] (eot padded),
  * n_tokens_out, score_out (normalised, may be NULL), sum_logprob_out (cumulative log-prob incl. EOT),
- * no_speech_prob_out (may be NULL). */
-int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* prompts_host, int prompt_len,
-                           const wj_decode_opts* opts, float patience, float length_penalty, int32_t* tokens_out,
-                           int32_t* n_tokens_out, float* score_out, float* sum_logprob_out, float* no_speech_prob_out,
-                           void* stream);
+ * no_speech_prob_out (may be NULL).  slots_host (may be NULL = 0..batch-1) names the resident window of each row
+ * group, as for wj_whisper_decode_sample. */
+int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* slots_host, const int32_t* prompts_host,
+                           int prompt_len, const wj_decode_opts* opts, float patience, float length_penalty,
+                           int32_t* tokens_out, int32_t* n_tokens_out, float* score_out, float* sum_logprob_out,
+                           float* no_speech_prob_out, void* stream);
 
 /* Word-timestamp alignment.  Replaces: ctranslate2 Whisper.align (faster_whisper.transcribe.WhisperModel
  * .find_alignment, reached with word_timestamps=True from faster_whisper_pro_asr.py:819) and whisper/timing.py

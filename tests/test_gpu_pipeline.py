@@ -385,6 +385,14 @@ def test_whisper_model_shim_end_to_end(hip):
     assert len(list(beam)) >= 1
     # the temperature ladder: an unreachable log-prob bar makes every rung fail -> best average log-prob is kept
     # (never worse than the zero-temperature one) and the LAST temperature is reported; without bars nothing falls back
+    # condition_on_previous_text=True makes prompt lengths differ between clips from the second window on: the batched
+    # path then decodes per length against slot-addressed resident windows and must equal the per-clip results
+    long_a, long_b = synth.speech_like(41.0, seed=3), synth.speech_like(35.0, seed=4)
+    ckw = dict(kw, condition_on_previous_text=True, max_new_tokens=12)
+    both, _ = model.transcribe_many([long_a, long_b], **ckw)
+    for clip, got_segs in zip((long_a, long_b), both):
+        alone, _ = model.transcribe(clip, **ckw)
+        assert [(s.seek, s.tokens) for s in alone] == [(s.seek, s.tokens) for s in got_segs]
     lad, _ = model.transcribe(audio, **dict(kw, temperature=(0.0, 0.5, 1.0), best_of=2, log_prob_threshold=-1e-3,
                                              compression_ratio_threshold=None))
     lad = list(lad)
@@ -781,6 +789,14 @@ def test_device_beam_search_matches_oracle(hip, dtype, beam, patience, rep, ngra
                                                  repetition_penalty=rep, no_repeat_ngram_size=ngram),
                             beam_size=beam, patience=patience, length_penalty=1.0)
     assert model.last_decode_info()["hip_graph"]
+    # a subset of the resident windows through the slot map gives the same hypotheses
+    sub = model.decode_beam(np.tile(np.array(prompt, dtype=np.int32), (2, 1)),
+                            engine.DecodeOptions(max_new_tokens=n_new, suppress_tokens=suppress, max_initial_timestamp=0.0,
+                                                 repetition_penalty=rep, no_repeat_ngram_size=ngram),
+                            beam_size=beam, patience=patience, length_penalty=1.0, slots=[2, 0])
+    for row, w in enumerate([2, 0]):
+        assert sub.tokens[row, : sub.n_tokens[row]].tolist() == res.tokens[w, : res.n_tokens[w]].tolist()
+        assert abs(float(sub.sum_logprob[row]) - float(res.sum_logprob[w])) < 1e-4
     # the host-driven restatement over the step API must agree with the device loop (same engine numerics)
     opts = search.SearchOptions(beam_size=beam, patience=patience, length_penalty=1.0, repetition_penalty=rep,
                                 no_repeat_ngram_size=ngram, suppress_tokens=suppress, max_initial_timestamp_index=0,

@@ -958,10 +958,10 @@ int wj_whisper_decode_sample(wj_whisper* m, int batch, int group, const int32_t*
 // merge + cache re-binding, captured as two hipGraphs (even / odd steps swap the history and row-map
 // buffers).  The host only polls a done counter every 8 steps and ranks the finished lists at the end.
 // ------------------------------------------------------------------------------------------------
-int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* prompts_host, int prompt_len,
-                           const wj_decode_opts* opts, float patience, float length_penalty, int32_t* tokens_out,
-                           int32_t* n_tokens_out, float* score_out, float* sum_logprob_out, float* no_speech_prob_out,
-                           void* stream) {
+int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* slots_host, const int32_t* prompts_host,
+                           int prompt_len, const wj_decode_opts* opts, float patience, float length_penalty,
+                           int32_t* tokens_out, int32_t* n_tokens_out, float* score_out, float* sum_logprob_out,
+                           float* no_speech_prob_out, void* stream) {
   WJ_REQUIRE(m && prompts_host && opts && tokens_out && n_tokens_out && sum_logprob_out, "wj_whisper_decode_beam: NULL argument");
   WJ_REQUIRE(batch >= 1 && batch <= m->max_batch && beam >= 1 && (beam <= 6 || beam == 8) && batch * beam <= m->max_rows,
              "decode_beam: batch %d x beam %d does not fit (max_batch %d, max_rows %d; beam 1..6 or 8)", batch, beam,
@@ -973,9 +973,15 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* pr
   const int max_candidates = (int)lroundf(K * patience);
   WJ_REQUIRE(max_candidates >= 1 && max_candidates + K <= kFinCap, "decode_beam: beam %d x patience %g needs %d finished slots (max %d)",
              K, (double)patience, max_candidates + K, kFinCap);
+  if (slots_host)
+    for (int i = 0; i < batch; ++i)
+      WJ_REQUIRE(slots_host[i] >= 0 && slots_host[i] < m->max_batch, "decode_beam: window slot %d out of range", slots_host[i]);
   WJ_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->pick(stream);
   WJ_TRY(reset_decode_state(m, R, s));
+  m->use_slots = slots_host != nullptr;
+  if (slots_host) WJ_HIP(hipMemcpyAsync(m->slot_map, slots_host, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+  struct SlotGuard { wj_whisper* m; ~SlotGuard() { m->use_slots = false; } } slot_guard{m};
   int32_t* buf[2] = {m->tokens, m->tokens2};
   {
     std::vector<int32_t> hist((size_t)R * m->tok_stride, opts->eot);

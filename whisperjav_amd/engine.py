@@ -246,7 +246,7 @@ class HipWhisper:
         return GreedyResult(toks, ntok, slp, nsp, tlp)
 
     def decode_beam(self, prompts: np.ndarray, options: Optional[DecodeOptions] = None, *, beam_size: int = 5,
-                    patience: float = 1.0, length_penalty: float = 1.0) -> GreedyResult:
+                    patience: float = 1.0, length_penalty: float = 1.0, slots: Optional[Sequence[int]] = None) -> GreedyResult:
         """CTranslate2-style beam search of the resident windows, entirely on the device.  Per window: best
         hypothesis tokens, count, cumulative log-prob (``sum_logprob``), no-speech probability;
         ``token_logprob`` carries the normalised score in column 0."""
@@ -262,7 +262,13 @@ class HipWhisper:
         nsp = np.empty(B, dtype=np.float32)
         as_i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
         as_f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
-        check(self._lib.wj_whisper_decode_beam(self.handle, B, int(beam_size), as_i(prompts), P, C.byref(oc), float(patience),
+        sl = None
+        if slots is not None:
+            sl_arr = np.ascontiguousarray(slots, dtype=np.int32)
+            if sl_arr.shape != (B,):
+                raise ValueError("slots must name one resident window per prompt row")
+            sl = as_i(sl_arr)
+        check(self._lib.wj_whisper_decode_beam(self.handle, B, int(beam_size), sl, as_i(prompts), P, C.byref(oc), float(patience),
                                                float(length_penalty), as_i(toks), as_i(ntok), as_f(score), as_f(slp), as_f(nsp),
                                                None), "wj_whisper_decode_beam")
         return GreedyResult(toks, ntok, slp, nsp, score.reshape(B, 1))

@@ -66,7 +66,7 @@ _SIGNATURES = {
     "wj_whisper_decode_sample": (_I, [_P, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), _F,
                                       C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F),
                                       C.POINTER(_F), _P]),
-    "wj_whisper_decode_beam": (_I, [_P, _I, _I, C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), _F, _F, C.POINTER(C.c_int32),
+    "wj_whisper_decode_beam": (_I, [_P, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), _F, _F, C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _P]),
     "wj_whisper_align": (_I, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I,
                               C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32),

@@ -433,18 +433,20 @@ class HipWhisperModel:
                     toks = res.tokens[r, : res.n_tokens[r]].tolist()
                     out.append((toks, float(res.sum_logprob[r]) / (len(toks) + 1), float(res.no_speech_prob[r])))
             return out
-        if slots != list(range(n)):
-            # a zero-temperature rung after a sampled one (unusual ladder): decode the resident prefix, keep ours
+        identity = list(slots) == list(range(n))
+        beam = int(o.beam_size or 1)
+        device_loop = beam == 1 and (self.FLAVOR == "fw" or (float(o.repetition_penalty) == 1.0
+                                                             and int(o.no_repeat_ngram_size) == 0))
+        device_beam = (not device_loop and self.FLAVOR == "fw" and self.device_beam and beam in (2, 3, 4, 5, 6, 8)
+                       and round(beam * float(o.patience or 1.0)) + beam <= 24)
+        if not identity and not (device_loop or device_beam):
+            # host-driven search over the step API addresses windows 0..n-1 only: decode the resident prefix, keep ours
             hi = max(slots) + 1
             full = self._decode_once([prompts[slots.index(i)] if i in slots else prompts[0] for i in range(hi)],
                                      list(range(hi)), temperature, o, suppress)
             return [full[i] for i in slots]
-        beam = int(o.beam_size or 1)
-        device_loop = beam == 1 and (self.FLAVOR == "fw" or (float(o.repetition_penalty) == 1.0
-                                                             and int(o.no_repeat_ngram_size) == 0))
         out = []
-        if (not device_loop and self.FLAVOR == "fw" and self.device_beam and beam in (2, 3, 4, 5, 6, 8)
-                and round(beam * float(o.patience or 1.0)) + beam <= 24):
+        if device_beam:
             # CTranslate2's beam search, device resident (wj_whisper_decode_beam); the host-driven restatement in
             # search.py stays available (device_beam = False) and is what the GPU tests cross-check it with
             lp = o.length_penalty
@@ -455,18 +457,21 @@ class HipWhisperModel:
                                      max_initial_timestamp=mit * TIME_PRECISION,
                                      repetition_penalty=float(o.repetition_penalty),
                                      no_repeat_ngram_size=int(o.no_repeat_ngram_size)),
-                beam_size=beam, patience=float(o.patience or 1.0), length_penalty=(1.0 if lp is None else float(lp)))
+                beam_size=beam, patience=float(o.patience or 1.0), length_penalty=(1.0 if lp is None else float(lp)),
+                slots=None if identity else slots)
             for r in range(n):
                 toks = res.tokens[r, : res.n_tokens[r]].tolist()
                 out.append((toks, float(res.sum_logprob[r]) / (len(toks) + 1), float(res.no_speech_prob[r])))
         elif device_loop:
-            res = self.model.decode_greedy(
-                np.array(prompts, dtype=np.int32),
-                engine.DecodeOptions(max_new_tokens=max_new, suppress_blank=o.suppress_blank,
-                                     without_timestamps=o.without_timestamps, suppress_tokens=suppress,
-                                     max_initial_timestamp=mit * TIME_PRECISION,
-                                     repetition_penalty=float(o.repetition_penalty),
-                                     no_repeat_ngram_size=int(o.no_repeat_ngram_size)))
+            do = engine.DecodeOptions(max_new_tokens=max_new, suppress_blank=o.suppress_blank,
+                                      without_timestamps=o.without_timestamps, suppress_tokens=suppress,
+                                      max_initial_timestamp=mit * TIME_PRECISION,
+                                      repetition_penalty=float(o.repetition_penalty),
+                                      no_repeat_ngram_size=int(o.no_repeat_ngram_size))
+            if identity:
+                res = self.model.decode_greedy(np.array(prompts, dtype=np.int32), do)
+            else:
+                res = self.model.decode_sample(np.array(prompts, dtype=np.int32), do, temperature=0.0, best_of=1, slots=slots)
             for r in range(n):
                 toks = res.tokens[r, : res.n_tokens[r]].tolist()
                 out.append((toks, float(res.sum_logprob[r]) / (len(toks) + 1), float(res.no_speech_prob[r])))
@@ -485,7 +490,8 @@ class HipWhisperModel:
                 out.append((wr.sequences[0], wr.avg_logprob(0), wr.no_speech_prob))
         return out
 
-    def _decode_windows(self, prompts: List[List[int]], o: TranscribeOptions, suppress: Tuple[int, ...]):
+    def _decode_windows(self, prompts: List[List[int]], o: TranscribeOptions, suppress: Tuple[int, ...],
+                        slots: Optional[List[int]] = None):
         """Temperature-fallback ladder over the resident windows (faster-whisper ``generate_with_fallback`` /
         whisper ``decode_with_fallback``): every rung re-decodes only the windows that still need a fallback.
         Returns per window (tokens, avg_logprob, no_speech_prob, temperature, compression_ratio)."""
@@ -495,10 +501,11 @@ class HipWhisperModel:
         tried: List[List[Any]] = [[] for _ in range(n)]        # every rung's result
         below_cr: List[List[Any]] = [[] for _ in range(n)]     # ... those under the compression-ratio threshold
         pending = list(range(n))
+        where = list(range(n)) if slots is None else list(slots)      # resident window of each prompt row
         for T in temps:
             if not pending:
                 break
-            decoded = self._decode_once([prompts[i] for i in pending], pending, T, o, suppress)
+            decoded = self._decode_once([prompts[i] for i in pending], [where[i] for i in pending], T, o, suppress)
             still = []
             for i, (toks, avg_lp, nsp) in zip(pending, decoded):
                 text = self.tokenizer.decode([t for t in toks if t < self.tokens.eot]).strip()
@@ -798,13 +805,11 @@ class HipWhisperModel:
                 if len(groups) == 1:
                     decoded = self._decode_windows(prompts, o, suppress)
                     self._finish_windows(o, batch, sizes, decoded, list(range(len(batch))), tb)
-                else:   # heterogeneous prompt lengths: decode group by group against re-encoded slots
+                else:   # heterogeneous prompt lengths: one decode per length, addressing the resident windows by slot
                     for _, members in groups.items():
                         idx = [j for _, _, j in members]
-                        self.model.encode(mel[idx].contiguous())
-                        res = self._decode_windows([p for _, p, _ in members], o, suppress)
-                        self._finish_windows(o, [batch[j] for j in idx], [sizes[j] for j in idx], res,
-                                             list(range(len(idx))), tb)
+                        res = self._decode_windows([p for _, p, _ in members], o, suppress, slots=idx)
+                        self._finish_windows(o, [batch[j] for j in idx], [sizes[j] for j in idx], res, idx, tb)
         infos = [TranscriptionInfo(language=st.language, language_probability=st.language_probability, duration=st.duration,
                                    duration_after_vad=st.duration, all_language_probs=st.all_language_probs,
                                    transcription_options=dict(kwargs))
