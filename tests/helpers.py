@@ -73,3 +73,24 @@ def synth_mel(batch, n_mels, seed=7, frames=3000):
     """Log-mel-shaped random input in the value range Whisper sees ([-1, 1.5])."""
     rng = np.random.default_rng(seed)
     return (rng.standard_normal((batch, n_mels, frames), dtype=np.float32) * 0.4).clip(-1.0, 1.5)
+
+
+def scripted_segments(n_samples: int):
+    """The "model" of the ASR-adapter fixtures: segments that depend only on the clip length (the reference side
+    in tests/golden/make_asr_adapter_fixtures.py and the product side in tests/test_asr_adapter.py call the same
+    function, so any difference in the results comes from the adapter logic around the model call)."""
+    dur = n_samples / 16000.0
+    k = n_samples % 7
+    segs = [dict(id=1, seek=0, start=round(0.05 * dur, 3), end=round(0.45 * dur, 3), text=f" 台詞{n_samples % 1000} ", tokens=[1, 2],
+                 avg_logprob=-0.2 - 0.1 * k, compression_ratio=1.0, no_speech_prob=0.01, temperature=0.0),
+            dict(id=2, seek=0, start=round(0.5 * dur, 3), end=round(0.6 * dur, 3), text="ご視聴ありがとうございました", tokens=[3],
+                 avg_logprob=-0.1, compression_ratio=1.0, no_speech_prob=0.01, temperature=0.0),
+            dict(id=3, seek=0, start=round(0.62 * dur, 3), end=round(0.7 * dur, 3), text="Thank you", tokens=[4],
+                 avg_logprob=-0.9, compression_ratio=1.0, no_speech_prob=0.01, temperature=0.0),
+            dict(id=4, seek=0, start=round(0.72 * dur, 3), end=round(0.8 * dur, 3), text="あっ…", tokens=[5],
+                 avg_logprob=-0.45, compression_ratio=1.0, no_speech_prob=0.01, temperature=0.0),
+            dict(id=5, seek=0, start=round(0.82 * dur, 3), end=round(0.82 * dur, 3) + 0.0, text="   ", tokens=[6],
+                 avg_logprob=-0.3, compression_ratio=1.0, no_speech_prob=0.01, temperature=0.0),
+            dict(id=6, seek=0, start=round(0.85 * dur, 3), end=round(0.99 * dur, 3), text="低い確率の行", tokens=[7],
+                 avg_logprob=-1.4 + 0.15 * k, compression_ratio=1.0, no_speech_prob=0.01, temperature=0.0)]
+    return segs

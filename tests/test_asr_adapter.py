@@ -360,3 +360,70 @@ def test_language_detection_feeds_prompt_and_info():
     first = seen[0]
     assert first[0, 1] == t.language_token(pdims.language_index(infos[0].language))
     assert first[1, 1] == t.language_token(pdims.language_index(infos[1].language))
+
+
+# ---- the adapter against the REFERENCE's own FasterWhisperProASR (fixtures: tests/golden/make_asr_adapter_fixtures.py) ------
+def _reference_cases():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_asr_adapter.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_adapter_equals_reference_class_on_scripted_model(idx, tmp_path):
+    """Same scripted "model" and segmenter on both sides: the returned segments (shifted timestamps, texts, log-probs),
+    the filter statistics, the VAD segments and the clips / normalised parameters handed to the model must equal what
+    the reference's FasterWhisperProASR produced."""
+    from tests.helpers import scripted_segments
+    case = _reference_cases()[idx]
+    calls = []
+
+    class Model:
+        def transcribe_many(self, clips, **params):
+            calls.append({"n": [int(len(c)) for c in clips], "params": params})
+            return [[wm.Segment(**d) for d in scripted_segments(len(c))] for c in clips], [None] * len(clips)
+
+        def close(self):
+            pass
+    seg = FakeSegmenter([[tuple(x) for x in g] for g in case["groups"]])
+    seg.name = "silero-v6.2"
+    a = asr.HipFasterWhisperProASR({"model_name": "large-v3", "device": "cuda", "compute_type": "float16"}, case["params"],
+                                   "transcribe", whisper_model=Model(), segmenter=seg)
+    path = tmp_path / f"{case['name']}.wav"
+    audio = (np.sin(np.arange(int(16000 * case["seconds"])) * 0.05) * 0.25).astype(np.float32)
+    import wave as _wave
+    with _wave.open(str(path), "wb") as wf:      # float -> PCM16 -> float is not the identity, but only LENGTHS matter to the script
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000)
+        wf.writeframes((audio * 32767).astype("<i2").tobytes())
+    got = a.transcribe(path)
+    ref = case["result"]
+    assert got["language"] == ref["language"] and got["text"] == ref["text"]
+    assert len(got["segments"]) == len(ref["segments"])
+    for g, r in zip(got["segments"], ref["segments"]):
+        assert g["text"] == r["text"]
+        assert g["start"] == pytest.approx(r["start"], abs=1e-9) and g["end"] == pytest.approx(r["end"], abs=1e-9)
+        assert g["avg_logprob"] == pytest.approx(r["avg_logprob"], abs=1e-12)
+    assert a.get_filter_statistics() == case["filter_stats"]
+    assert a.get_last_vad_segments() == case["vad_segments"]
+    assert [n for c in calls for n in c["n"]] == [c["n"] for c in case["calls"]]          # same clips, same order
+    if case["calls"]:
+        want = dict(case["calls"][0]["params"])
+        have = dict(calls[0]["params"])
+        if isinstance(have.get("temperature"), tuple):
+            have["temperature"] = list(have["temperature"])
+        assert have == want
+
+
+def test_standalone_nonverbal_filter_matches_reference_table():
+    """The stand-alone mirror of SegmentFilterHelper._looks_nonverbal (used when whisperjav is not importable) against
+    the reference's verdicts on a list of strings (tests/golden/reference_nonverbal.json)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_nonverbal.json"), encoding="utf-8") as f:
+        cases = json.load(f)
+    helper = asr.SegmentFilterHelper(asr.SegmentFilterConfig(enabled=True, logprob_threshold=None, drop_nonverbal_vocals=True))
+    for text, verdict in cases:
+        drop, reason, _ = helper.should_filter(avg_logprob=0.0, duration=1.0, text=text)
+        assert drop == verdict and (reason == "nonverbal") == verdict, text
+    assert sum(v for _, v in cases) >= 15 and sum(not v for _, v in cases) >= 10

@@ -28,7 +28,7 @@ except Exception:
     from dataclasses import dataclass
 
     @dataclass
-    class SegmentFilterConfig:  # logprob gate only; the nonverbal tables live in the reference
+    class SegmentFilterConfig:  # stand-alone mirror of modules/segment_filters.py:10-34 (same fields, same defaults)
         enabled: bool = True
         logprob_threshold: Optional[float] = None
         logprob_margin: float = 0.0
@@ -41,8 +41,30 @@ except Exception:
             self.threshold = config.logprob_threshold
             self.margin = max(0.0, config.logprob_margin or 0.0)
             self.short_window = max(0.4, float(config.short_segment_window or 1.6))
-            if config.drop_nonverbal_vocals:
-                logger.warning("drop_nonverbal_vocals needs whisperjav.modules.segment_filters; ignored standalone")
+            self.drop_nonverbal = bool(config.drop_nonverbal_vocals)
+
+        # what the reference treats as "not speech" (segment_filters.py:40-72): descriptor words, music notes, and
+        # up-to-six-character strings made only of vocalisation kana / letters once punctuation is removed
+        _WORDS = ("music applause laugh laughs laughter sfx fx noise silence ambient moan moans moaning groan groans sigh "
+                  "sighs breath breathing 喘 喘ぎ 喘ぎ声 うめき うめき声").split()
+        _NOTES = frozenset("♪♫")
+        _VOCAL = frozenset("ahmnou" "ぁあァアんンっッふフぅゥうウおオえエはハほホ")
+        _IGNORED = frozenset("!！?？。、,.・~〜～ー… \u3000")
+
+        @classmethod
+        def _looks_nonverbal(cls, text: str) -> bool:
+            body = (text or "").strip()
+            if not body:
+                return False
+            if all(ch in cls._NOTES or ch in cls._IGNORED for ch in body):
+                return True
+            body = body.lower().strip().lstrip("[](){}<>").rstrip("[](){}<>").strip()
+            if not body:
+                return False
+            if any(w in body for w in cls._WORDS):
+                return True
+            core = "".join(ch for ch in body if ch not in cls._IGNORED)
+            return bool(core) and len(core) <= 6 and all(ch in cls._VOCAL for ch in core)
 
         def should_filter(self, avg_logprob: float, duration: float, text: str):
             if not self.enabled:
@@ -52,6 +74,8 @@ except Exception:
                 thr = thr - self.margin
             if thr is not None and avg_logprob < thr:
                 return True, "logprob", thr
+            if self.drop_nonverbal and self._looks_nonverbal(text):
+                return True, "nonverbal", thr
             return False, None, thr
 
     def should_force_full_transcribe(vad_segments, audio_duration, min_duration_for_fallback=120.0,
@@ -125,6 +149,11 @@ class HipFasterWhisperProASR:
             vad_params = {}
         self.vad_threshold = vad_params.get("threshold", 0.28)
         self.min_speech_duration_ms = vad_params.get("min_speech_duration_ms", 100)
+        # faster-whisper VadOptions dict the reference hands to transcribe() although vad_filter stays False
+        # (faster_whisper_pro_asr.py:319-338, :410-411): carried through for call compatibility
+        keys = ("threshold", "neg_threshold", "min_speech_duration_ms", "max_speech_duration_s", "min_silence_duration_ms",
+                "speech_pad_ms")
+        self._vad_parameters = {k: vad_params[k] for k in keys if vad_params.get(k) is not None} or None
         merged = {**vad_params, **seg_cfg} if backend.startswith("silero") else dict(seg_cfg)
         merged.pop("backend", None)
         if segmenter is not None:
@@ -214,6 +243,8 @@ class HipFasterWhisperProASR:
             p.pop(key, None)
         p.setdefault("log_progress", False)
         p["vad_filter"] = p.get("vad_filter", False)
+        if self._vad_parameters and "vad_parameters" not in p:
+            p["vad_parameters"] = self._vad_parameters
         return {k: v for k, v in p.items() if v is not None}
 
     # ---- transcription ----------------------------------------------------------------------------
