@@ -427,3 +427,54 @@ def test_standalone_nonverbal_filter_matches_reference_table():
         drop, reason, _ = helper.should_filter(avg_logprob=0.0, duration=1.0, text=text)
         assert drop == verdict and (reason == "nonverbal") == verdict, text
     assert sum(v for _, v in cases) >= 15 and sum(not v for _, v in cases) >= 10
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_fidelity_adapter_equals_reference_class_on_scripted_model(idx, tmp_path):
+    """HipWhisperProASR against fixtures produced by the reference's own WhisperProASR (fidelity pipeline) with the same
+    scripted openai-style model and segmenter (tests/golden/make_fidelity_adapter_fixtures.py)."""
+    import json
+    import os
+    import wave as _wave
+    from tests.helpers import scripted_segments
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_fidelity_adapter.json"),
+              encoding="utf-8") as f:
+        case = json.load(f)[idx]
+    calls = []
+
+    class OpenAIStyleModel:          # dict-returning transcribe, like whisper.load_model(...)
+        def transcribe(self, audio, **params):
+            calls.append({"n": int(len(audio)), "params": params})
+            segs = scripted_segments(len(audio))
+            return {"text": "".join(s["text"] for s in segs), "segments": segs, "language": "ja"}
+    seg = FakeSegmenter([[tuple(x) for x in g] for g in case["groups"]])
+    seg.name = "silero-v4.0"
+    a = asr.HipWhisperProASR({"model_name": "large-v2", "device": "cuda"}, case["params"], "transcribe",
+                             whisper_model=OpenAIStyleModel(), segmenter=seg)
+    path = tmp_path / f"{case['name']}.wav"
+    audio = (np.sin(np.arange(int(16000 * case["seconds"])) * 0.05) * 0.25).astype(np.float32)
+    with _wave.open(str(path), "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000)
+        wf.writeframes((audio * 32767).astype("<i2").tobytes())
+    got = a.transcribe(path)
+    ref = case["result"]
+    assert got["language"] == ref["language"] and got["text"] == ref["text"]
+    assert len(got["segments"]) == len(ref["segments"])
+    for g, r in zip(got["segments"], ref["segments"]):
+        assert g["text"] == r["text"]
+        assert g["start"] == pytest.approx(r["start"], abs=1e-9) and g["end"] == pytest.approx(r["end"], abs=1e-9)
+        assert g["avg_logprob"] == pytest.approx(r["avg_logprob"], abs=1e-12)
+    assert a.get_filter_statistics() == case["filter_stats"]
+    assert [c["n"] for c in calls] == [c["n"] for c in case["calls"]]
+    if case["calls"]:
+        want = dict(case["calls"][0]["params"])
+        have = {k: (list(v) if isinstance(v, tuple) else v) for k, v in calls[0]["params"].items()}
+        assert have == want
+
+
+def test_suppress_tokens_string_form_of_openai_whisper():
+    m = _ow_model([[pdims.special_tokens(51865).timestamp_begin, 5]])
+    o = m._options({"suppress_tokens": "-1"})
+    assert m._suppressed(o) == m._suppressed(m._options({"suppress_tokens": [-1]}))
+    o2 = m._options({"suppress_tokens": "11, 12"})
+    assert {11, 12} <= set(m._suppressed(o2))

@@ -346,11 +346,13 @@ class HipWhisperProASR(HipFasterWhisperProASR):
         super().__init__(model_config, params, task, tracer, whisper_model=whisper_model, segmenter=segmenter)
 
     def _prepare_whisper_params(self) -> Dict[str, Any]:
+        # whisper_pro_asr.py:201-218: the tuner's parameters go through as they are (None values included --
+        # whisper.transcribe accepts them), the temperature list becomes a tuple, verbose defaults to None
         p = dict(self.whisper_params)
         if isinstance(p.get("temperature"), list):
             p["temperature"] = tuple(p["temperature"])
         p.setdefault("verbose", None)
-        return {k: v for k, v in p.items() if v is not None or k == "verbose"}
+        return p
 
     def transcribe(self, audio_path, **kwargs):
         # the dict-returning model is adapted to the (segments, info) batch interface of the base class

@@ -350,7 +350,10 @@ class HipWhisperModel:
 
     def _suppressed(self, o: TranscribeOptions) -> Tuple[int, ...]:
         t = self.tokens
-        sup = list(o.suppress_tokens or [])
+        raw = o.suppress_tokens
+        if isinstance(raw, str):          # whisper.DecodingOptions: "-1" or a comma-separated id list
+            raw = [int(x) for x in raw.split(",") if x.strip()]
+        sup = list(raw or [])
         if -1 in sup:
             sup = [x for x in sup if x >= 0] + list(self.tokenizer.non_speech_tokens())
         sup += [t.transcribe, t.translate, t.sot, t.sot_prev, t.sot_lm]
