@@ -478,3 +478,14 @@ def test_suppress_tokens_string_form_of_openai_whisper():
     assert m._suppressed(o) == m._suppressed(m._options({"suppress_tokens": [-1]}))
     o2 = m._options({"suppress_tokens": "11, 12"})
     assert {11, 12} <= set(m._suppressed(o2))
+
+
+def test_srt_fallback_follows_the_srt_package_rules():
+    """compose_srt without the ``srt`` package: floor-millisecond timestamps, sorting, skipping and re-indexing as
+    srt.compose does (reference: transcribe_to_srt, faster_whisper_pro_asr.py:1044-1057)."""
+    segs = [{"start": 5.0006, "end": 6.9999, "text": "b"}, {"start": 1.0, "end": 2.5, "text": "a\n\n\nx"},
+            {"start": 3.0, "end": 3.0, "text": "zero length"}, {"start": 4.0, "end": 4.5, "text": "   "},
+            {"start": 3661.25, "end": 3662.0, "text": "late"}]
+    text = asr.compose_srt(segs)
+    assert text == ("1\n00:00:01,000 --> 00:00:02,500\na\nx\n\n" "2\n00:00:05,000 --> 00:00:06,999\nb\n\n"
+                    "3\n01:01:01,250 --> 01:01:02,000\nlate\n\n")

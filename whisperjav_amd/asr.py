@@ -110,16 +110,18 @@ def read_audio(path: Union[str, Path]):
         return pcm, sr
 
 
-def _srt_time(seconds: float) -> str:
-    td = datetime.timedelta(seconds=max(0.0, seconds))
-    total_ms = int(round(td.total_seconds() * 1000))
-    h, rem = divmod(total_ms, 3600000)
-    m, rem = divmod(rem, 60000)
-    s, ms = divmod(rem, 1000)
-    return f"{h:02d}:{m:02d}:{s:02d},{ms:03d}"
+def _srt_time(td: datetime.timedelta) -> str:
+    """``srt.timedelta_to_srt_timestamp``: milliseconds are the FLOOR of the timedelta's microseconds."""
+    hrs, rem = divmod(td.seconds, 3600)
+    hrs += td.days * 24
+    mins, secs = divmod(rem, 60)
+    return "%02d:%02d:%02d,%03d" % (hrs, mins, secs, td.microseconds // 1000)
 
 
 def compose_srt(segments: List[Dict[str, Any]]) -> str:
+    """``srt.compose`` of the reference's ``transcribe_to_srt`` (faster_whisper_pro_asr.py:1044-1057); without the
+    ``srt`` package the same rules are applied here: sort by (start, end, index), skip subtitles without content, with
+    a negative start or with start >= end, re-index from 1, collapse blank lines inside the content."""
     try:
         import srt
         subs = [srt.Subtitle(index=i, start=datetime.timedelta(seconds=s["start"]),
@@ -127,8 +129,18 @@ def compose_srt(segments: List[Dict[str, Any]]) -> str:
                 for i, s in enumerate(segments, 1)]
         return srt.compose(subs)
     except ImportError:
-        return "".join(f"{i}\n{_srt_time(s['start'])} --> {_srt_time(s['end'])}\n{s['text']}\n\n"
-                       for i, s in enumerate(segments, 1))
+        import re
+        rows = sorted(((datetime.timedelta(seconds=s["start"]), datetime.timedelta(seconds=s["end"]), i, s["text"])
+                       for i, s in enumerate(segments, 1)), key=lambda r: r[:3])
+        out, idx = [], 1
+        for start, end, _, content in rows:
+            if not content.strip() or start < datetime.timedelta(0) or start >= end:
+                continue
+            if content[0] == "\n" or "\n\n" in content:
+                content = re.sub(r"\n\n+", "\n", content.strip("\n"))
+            out.append(f"{idx}\n{_srt_time(start)} --> {_srt_time(end)}\n{content}\n\n")
+            idx += 1
+        return "".join(out)
 
 
 class HipFasterWhisperProASR:
