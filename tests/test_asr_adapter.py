@@ -489,3 +489,21 @@ def test_srt_fallback_follows_the_srt_package_rules():
     text = asr.compose_srt(segs)
     assert text == ("1\n00:00:01,000 --> 00:00:02,500\na\nx\n\n" "2\n00:00:05,000 --> 00:00:06,999\nb\n\n"
                     "3\n01:01:01,250 --> 01:01:02,000\nlate\n\n")
+
+
+def test_optional_decoding_options_of_the_fidelity_config():
+    """openai_whisper.py config fields that may arrive as None / extra keys: max_initial_timestamp=None (no bound on
+    the first timestamp), prompt (overwritten per window by whisper.transcribe), clip_timestamps=None."""
+    tb = pdims.special_tokens(51865).timestamp_begin
+    m = _ow_model([[tb, 5, tb + 100]])
+    seen = []
+    greedy0 = m.model.decode_greedy
+
+    def greedy(prompts, options):
+        seen.append(options)
+        return greedy0(prompts, options)
+    m.model.decode_greedy = greedy
+    res = m.transcribe(np.zeros(16000 * 3, np.float32), beam_size=None, temperature=0.0, max_initial_timestamp=None,
+                       prompt="ignored", clip_timestamps=None, verbose=None, fp16=True, language="ja", suppress_tokens="-1",
+                       logprob_threshold=None, no_speech_threshold=None, condition_on_previous_text=False)
+    assert len(res["segments"]) == 1 and seen[0].max_initial_timestamp is None

@@ -186,7 +186,7 @@ class TranscribeOptions:
     suppress_blank: bool = True
     suppress_tokens: Optional[Sequence[int]] = (-1,)
     without_timestamps: bool = False
-    max_initial_timestamp: float = 1.0
+    max_initial_timestamp: Optional[float] = 1.0
     word_timestamps: bool = False
     max_new_tokens: Optional[int] = None
     hotwords: Optional[str] = None
@@ -410,7 +410,8 @@ class HipWhisperModel:
         from . import engine, search
         P = len(prompts[0])
         max_new = self._max_new(o, P)
-        mit = int(round(float(o.max_initial_timestamp) / TIME_PRECISION))
+        mit = None if o.max_initial_timestamp is None else int(round(float(o.max_initial_timestamp) / TIME_PRECISION))
+        mit_s = None if mit is None else mit * TIME_PRECISION        # None: any first timestamp (whisper's default for the option)
         n = len(prompts)
         if temperature > 0:
             # sampling rung: beam_size -> 1, best_of hypotheses per window drawn on the device
@@ -419,7 +420,7 @@ class HipWhisperModel:
                 raise ValueError(f"best_of={best_of}: the device sampler groups 1..6 or 8 samples per window")
             do = engine.DecodeOptions(max_new_tokens=max_new, suppress_blank=o.suppress_blank,
                                       without_timestamps=o.without_timestamps, suppress_tokens=suppress,
-                                      max_initial_timestamp=mit * TIME_PRECISION,
+                                      max_initial_timestamp=mit_s,
                                       repetition_penalty=float(o.repetition_penalty if self.FLAVOR == "fw" else 1.0),
                                       no_repeat_ngram_size=int(o.no_repeat_ngram_size if self.FLAVOR == "fw" else 0))
             cap = max(1, (self.max_batch * self.max_beam) // best_of)
@@ -457,7 +458,7 @@ class HipWhisperModel:
                 np.array(prompts, dtype=np.int32),
                 engine.DecodeOptions(max_new_tokens=max_new, suppress_blank=o.suppress_blank,
                                      without_timestamps=o.without_timestamps, suppress_tokens=suppress,
-                                     max_initial_timestamp=mit * TIME_PRECISION,
+                                     max_initial_timestamp=mit_s,
                                      repetition_penalty=float(o.repetition_penalty),
                                      no_repeat_ngram_size=int(o.no_repeat_ngram_size)),
                 beam_size=beam, patience=float(o.patience or 1.0), length_penalty=(1.0 if lp is None else float(lp)),
@@ -468,7 +469,7 @@ class HipWhisperModel:
         elif device_loop:
             do = engine.DecodeOptions(max_new_tokens=max_new, suppress_blank=o.suppress_blank,
                                       without_timestamps=o.without_timestamps, suppress_tokens=suppress,
-                                      max_initial_timestamp=mit * TIME_PRECISION,
+                                      max_initial_timestamp=mit_s,
                                       repetition_penalty=float(o.repetition_penalty),
                                       no_repeat_ngram_size=int(o.no_repeat_ngram_size))
             if identity:
@@ -832,7 +833,7 @@ class HipOpenAIWhisperModel(HipWhisperModel):
     FLAVOR = "ow"
 
     _RENAMES = {"logprob_threshold": "log_prob_threshold"}
-    _DROPPED = ("verbose", "fp16", "carry_initial_prompt", "sample_len")
+    _DROPPED = ("verbose", "fp16", "carry_initial_prompt", "sample_len", "prompt")   # prompt: whisper.transcribe overwrites it per window
 
     def _options(self, kw: Dict[str, Any]) -> TranscribeOptions:
         kw = dict(kw)
