@@ -1,0 +1,134 @@
+"""The registration recipe of INTEGRATION.md executed against the REFERENCE's own factories (imported from source).
+Needs /root/reference (present in the build container, absent on the GPU box: the tests skip there) -- it proves the
+plugin seams accept the classes of this package with the parameters the reference's resolver produces."""
+import importlib
+import os
+import sys
+import types
+
+import pytest
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "whisperjav")), reason="reference tree not present")
+
+
+@pytest.fixture()
+def ref_modules(monkeypatch):
+    """Load reference sub-packages by path without running whisperjav/__init__.py's application imports."""
+    saved = {k: v for k, v in sys.modules.items() if k == "whisperjav" or k.startswith("whisperjav.")}
+    for k in saved:
+        del sys.modules[k]
+    for name, path in (("whisperjav", f"{REF}/whisperjav"), ("whisperjav.modules", f"{REF}/whisperjav/modules")):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+    yield
+    for k in [k for k in sys.modules if k == "whisperjav" or k.startswith("whisperjav.")]:
+        del sys.modules[k]
+    sys.modules.update(saved)
+
+
+def test_speech_segmenter_factory_creates_the_hip_backends(ref_modules, monkeypatch):
+    from whisperjav_amd import hipbind, segmenters
+    monkeypatch.setattr(hipbind, "context", lambda device=0: types.SimpleNamespace(handle=None, device=device))
+    factory = importlib.import_module("whisperjav.modules.speech_segmentation.factory")
+    for name, target in segmenters.REGISTRY_ENTRIES.items():
+        factory._BACKEND_REGISTRY[name] = target
+        factory._BACKEND_DEPENDENCIES[name] = {"packages": ["whisperjav_amd"], "install_hint": "build libwjhip.so",
+                                                "always_available": False}
+    factory._PARAM_SCHEMAS["silero-hip"] = factory._PARAM_SCHEMAS["silero-v6.2"]
+    factory._PARAM_SCHEMAS["silero-v6.2-hip"] = factory._PARAM_SCHEMAS["silero-v6.2"]
+    ok, _ = factory.SpeechSegmenterFactory.is_backend_available("silero-hip")
+    assert ok
+    # what FasterWhisperProASR hands over: resolver VAD presets merged with the speech_segmenter section (:104-122);
+    # GUI-style string values must be coerced by the reference's sanitiser, unknown keys stripped
+    cfg = {"threshold": "0.35", "min_speech_duration_ms": 100, "min_silence_duration_ms": 300, "speech_pad_ms": 400,
+           "chunk_threshold_s": 2.5, "max_group_duration_s": 6.0, "backend": "silero-hip", "not_a_parameter": 1}
+    seg = factory.SpeechSegmenterFactory.create("silero-hip", config=cfg)
+    assert type(seg).__name__ == "HipSileroV6SpeechSegmenter"
+    assert seg.threshold == pytest.approx(0.35) and seg.max_group_duration_s == 6.0 and seg.speech_pad_ms == 400
+    assert seg.name.startswith("silero") and 16000 in seg.get_supported_sample_rates()
+    legacy = factory.SpeechSegmenterFactory.create("silero-v4.0-hip", config={"threshold": 0.4})
+    assert type(legacy).__name__ == "HipSileroSpeechSegmenter"
+    seg.cleanup(); legacy.cleanup()
+
+
+def test_scene_detector_factory_creates_the_hip_backend(ref_modules, monkeypatch):
+    from whisperjav_amd import hipbind
+    monkeypatch.setattr(hipbind, "context", lambda device=0: types.SimpleNamespace(handle=None, device=device))
+    monkeypatch.setattr(hipbind, "lib", lambda: None)
+    for stub in ("soundfile", "librosa"):
+        monkeypatch.setitem(sys.modules, stub, types.ModuleType(stub))
+    factory = importlib.import_module("whisperjav.modules.scene_detection_backends.factory")
+    factory._BACKEND_REGISTRY["auditok-hip"] = "whisperjav_amd.scenes.HipAuditokSceneDetector"
+    if hasattr(factory, "_BACKEND_DEPENDENCIES"):
+        factory._BACKEND_DEPENDENCIES["auditok-hip"] = {"packages": ["whisperjav_amd"], "install_hint": "build libwjhip.so",
+                                                        "always_available": False}
+    det = factory.SceneDetectorFactory.create("auditok-hip", max_duration=29.0, min_duration=0.3)
+    assert type(det).__name__ == "HipAuditokSceneDetector" and det.name == "auditok-hip"
+    assert det._config.max_duration == 29.0 and det._config.pass2_max_duration == 28.0
+    legacy = factory.SceneDetectorFactory.create_from_legacy_kwargs(method="auditok-hip", max_duration=20.0, pass1_max_silence_s=2.5)
+    assert legacy._config.max_duration == 20.0 and legacy._config.pass1_max_silence == 2.5
+    det.cleanup()
+
+
+def test_reference_asr_module_drives_the_model_shim_with_its_balanced_preset(ref_modules, monkeypatch, tmp_path):
+    """INTEGRATION.md "smallest possible diff": the reference's FasterWhisperProASR stays, only
+    ``faster_whisper.WhisperModel`` is swapped for ``HipWhisperModel``.  Run here with the reference class imported from
+    source, its ``balanced`` preset values (config/components/asr/faster_whisper.py) and the shim over an engine double:
+    the shim must accept every keyword the reference sends and its segments must flow through the reference's
+    post-processing."""
+    import numpy as np
+    from tests import test_asr_adapter as doubles
+    from whisperjav_amd import dims as pdims, whisper_model as wm
+    tb = pdims.special_tokens(51865).timestamp_begin
+    shim = doubles._model([[tb, 11, 12, tb + 100, tb + 100, 13, tb + 150]])
+    shim.model.align = lambda rows, n_prefix, heads, num_frames, slots=None, medfilt_width=7: [
+        (np.repeat(np.arange(len(r) - 4), 10), np.arange(10 * (len(r) - 4)), np.full(len(r) - 5, 0.8, np.float32)) for r in rows]
+    shim.dims = pdims.custom_dims(80, 128, 2, 2, 51865)
+    seen = []
+    real = shim.transcribe
+
+    class SwappedWhisperModel:
+        def __init__(self, *a, **kw):
+            self.ctor = (a, kw)
+
+        def transcribe(self, audio, **params):
+            seen.append(params)
+            return real(audio, **params)
+    fw = types.ModuleType("faster_whisper"); fw.WhisperModel = SwappedWhisperModel
+    sf = types.ModuleType("soundfile"); sf.SoundFileError = Exception
+    audio = (np.sin(np.arange(16000 * 9) * 0.05) * 0.2).astype(np.float32)
+    sf.read = lambda path, dtype="float32", **kw: (audio.copy(), 16000)
+    for name, mod in (("faster_whisper", fw), ("soundfile", sf), ("srt", types.ModuleType("srt"))):
+        monkeypatch.setitem(sys.modules, name, mod)
+    ref = importlib.import_module("whisperjav.modules.faster_whisper_pro_asr")
+    base = importlib.import_module("whisperjav.modules.speech_segmentation.base")
+
+    class Seg:
+        name = "silero-v6.2"
+
+        def segment(self, a, sample_rate=16000, **kw):
+            s = [base.SpeechSegment(start_sec=1.0, end_sec=4.0, start_sample=16000, end_sample=64000)]
+            return base.SegmentationResult(segments=s, groups=[s], method=self.name, audio_duration_sec=len(a) / sample_rate, parameters={})
+
+        def cleanup(self):
+            pass
+    monkeypatch.setattr(ref.SpeechSegmenterFactory, "create", staticmethod(lambda name, config=None, **kw: Seg()))
+    balanced = dict(task="transcribe", language="ja", beam_size=1, best_of=2, patience=1.2, length_penalty=None, prefix=None,
+                    suppress_tokens=None, suppress_blank=True, without_timestamps=False, max_initial_timestamp=0.0,
+                    temperature=[0.0], compression_ratio_threshold=2.4, logprob_threshold=-1.0, logprob_margin=0.0,
+                    no_speech_threshold=0.65, drop_nonverbal_vocals=False, condition_on_previous_text=False, initial_prompt=None,
+                    word_timestamps=True, prepend_punctuations=None, append_punctuations=None, clip_timestamps=None)
+    engine_opts = dict(chunk_length=None, repetition_penalty=1.5, no_repeat_ngram_size=3, prompt_reset_on_temperature=None,
+                       hotwords=None, multilingual=False, max_new_tokens=None, language_detection_threshold=None,
+                       language_detection_segments=None, log_progress=False, hallucination_silence_threshold=None)
+    params = {"decoder": balanced, "provider": engine_opts, "vad": {"threshold": 0.28, "min_speech_duration_ms": 100},
+              "speech_segmenter": {"backend": "silero-v6.2"}}
+    a = ref.FasterWhisperProASR({"model_name": "large-v3", "device": "cuda", "compute_type": "float16"}, params, "transcribe")
+    out = a.transcribe(tmp_path / "scene_0001.wav")
+    assert len(seen) == 1 and seen[0]["word_timestamps"] is True and seen[0]["vad_filter"] is False
+    assert "hallucination_silence_threshold" not in seen[0] and seen[0]["temperature"] == 0.0
+    # two sub-segments decoded by the shim, shifted by the group start (1.0 s) by the reference's own code
+    assert [s["text"] for s in out["segments"]] == ["<11><12>", "<13>"]
+    assert out["segments"][0]["start"] >= 1.0 and out["segments"][-1]["end"] <= 4.0 + 1e-6
