@@ -132,3 +132,55 @@ def test_reference_asr_module_drives_the_model_shim_with_its_balanced_preset(ref
     # two sub-segments decoded by the shim, shifted by the group start (1.0 s) by the reference's own code
     assert [s["text"] for s in out["segments"]] == ["<11><12>", "<13>"]
     assert out["segments"][0]["start"] >= 1.0 and out["segments"][-1]["end"] <= 4.0 + 1e-6
+
+
+def test_reference_fidelity_module_drives_the_openai_shim_with_its_balanced_preset(ref_modules, monkeypatch, tmp_path):
+    """The fidelity seam: the reference's WhisperProASR (from source) with ``whisper.load_model`` returning
+    ``HipOpenAIWhisperModel`` (over an engine double) and the reference's own ``balanced`` preset
+    (config/components/asr/openai_whisper.py:225-258), None values included."""
+    import numpy as np
+    from tests import test_asr_adapter as doubles
+    from whisperjav_amd import dims as pdims
+    tb = pdims.special_tokens(51865).timestamp_begin
+    shim = doubles._ow_model([[tb, 11, 12, tb + 100, tb + 100, 13, tb + 150]])
+    shim.model.align = lambda rows, n_prefix, heads, num_frames, slots=None, medfilt_width=7: [
+        (np.repeat(np.arange(len(r) - 4), 10), np.arange(10 * (len(r) - 4)), np.full(len(r) - 5, 0.8, np.float32)) for r in rows]
+    shim.dims = pdims.custom_dims(80, 128, 2, 2, 51865)
+    seen = []
+    real = shim.transcribe
+
+    def transcribe(audio, **params):
+        seen.append(params)
+        return real(audio, **params)
+    shim.transcribe = transcribe
+    wh = types.ModuleType("whisper"); wh.load_model = lambda name, device=None, **kw: shim
+    sf = types.ModuleType("soundfile"); sf.SoundFileError = Exception
+    audio = (np.sin(np.arange(16000 * 9) * 0.05) * 0.2).astype(np.float32)
+    sf.read = lambda path, dtype="float32", **kw: (audio.copy(), 16000)
+    for name, mod in (("whisper", wh), ("soundfile", sf), ("srt", types.ModuleType("srt"))):
+        monkeypatch.setitem(sys.modules, name, mod)
+    ref = importlib.import_module("whisperjav.modules.whisper_pro_asr")
+    base = importlib.import_module("whisperjav.modules.speech_segmentation.base")
+
+    class Seg:
+        name = "silero-v4.0"
+
+        def segment(self, a, sample_rate=16000, **kw):
+            s = [base.SpeechSegment(start_sec=1.0, end_sec=4.0, start_sample=16000, end_sample=64000)]
+            return base.SegmentationResult(segments=s, groups=[s], method=self.name, audio_duration_sec=len(a) / sample_rate, parameters={})
+
+        def cleanup(self):
+            pass
+    monkeypatch.setattr(ref.SpeechSegmenterFactory, "create", staticmethod(lambda name, config=None, **kw: Seg()))
+    decoder = dict(task="transcribe", language="ja", beam_size=1, best_of=2, patience=1.2, length_penalty=None, prefix=None,
+                   suppress_tokens=None, suppress_blank=True, without_timestamps=False, max_initial_timestamp=0.0,
+                   temperature=[0.0], compression_ratio_threshold=2.4, logprob_threshold=-1.0, logprob_margin=0.0,
+                   no_speech_threshold=0.71, drop_nonverbal_vocals=False, condition_on_previous_text=False, initial_prompt=None,
+                   word_timestamps=True, prepend_punctuations=None, append_punctuations=None, clip_timestamps=None)
+    provider = dict(verbose=None, carry_initial_prompt=None, prompt=None, fp16=True, hallucination_silence_threshold=None)
+    params = {"decoder": decoder, "provider": provider, "vad": {"threshold": 0.3}, "speech_segmenter": {"backend": "silero-v4.0"}}
+    a = ref.WhisperProASR({"model_name": "large-v2", "device": "cuda"}, params, "transcribe")
+    out = a.transcribe(tmp_path / "scene_0001.wav")
+    assert len(seen) >= 1 and seen[0]["fp16"] is True and seen[0]["word_timestamps"] is True
+    assert [s["text"] for s in out["segments"]] == ["<11><12>", "<13>"]
+    assert out["segments"][0]["start"] >= 1.0 and out["segments"][-1]["end"] <= 4.0 + 1e-6
