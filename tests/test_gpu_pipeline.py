@@ -931,3 +931,31 @@ def test_language_detection_matches_oracle(hip):
     assert info.language in pdims.LANGUAGE_CODES and info.all_language_probs[0][0] == info.language
     assert abs(sum(p for _, p in info.all_language_probs) - 1.0) < 1e-4
     shim.close()
+
+
+def test_sharded_transcribe_cli_single_rank(hip, tmp_path):
+    """The cfg4 driver end to end on one rank: Hugging Face checkpoint directory (written by transformers, random
+    weights) -> blob -> scenes -> VAD groups -> batched beam search with word timestamps -> SRT."""
+    import subprocess
+    import sys
+    import wave
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    from whisperjav_amd import synth
+    torch.manual_seed(5)
+    cfg = WhisperConfig(vocab_size=51865, num_mel_bins=80, d_model=128, encoder_layers=2, decoder_layers=2,
+                        encoder_attention_heads=2, decoder_attention_heads=2, encoder_ffn_dim=512, decoder_ffn_dim=512,
+                        max_source_positions=1500, max_target_positions=448)
+    WhisperForConditionalGeneration(cfg).save_pretrained(tmp_path / "model", safe_serialization=True)
+    audio = synth.speech_like(40.0, seed=12)
+    wav = tmp_path / "rec.wav"
+    with wave.open(str(wav), "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000)
+        wf.writeframes((np.clip(audio, -1, 1) * 32767).astype("<i2").tobytes())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "whisperjav_amd.sharded_transcribe", str(wav), str(tmp_path / "out" / "rec.srt"),
+                          "--model", str(tmp_path / "model"), "--compute-type", "float32", "--batch", "8", "--beam-size", "2",
+                          "--max-new-tokens", "12", "--scene-energy-db", "52"],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    text = (tmp_path / "out" / "rec.srt").read_text(encoding="utf-8")
+    assert text.count("-->") >= 2 and text.startswith("1\n")

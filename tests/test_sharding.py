@@ -77,3 +77,37 @@ def test_single_process_paths_are_noops():
     assert torch.equal(b, blob) and o.tolist() == [0, 32]
     assert sharding.gather_objects({"a": 1}) == [{"a": 1}]
     assert sharding.max_over_ranks(3.5, torch.device("cpu")) == 3.5
+
+
+def _scene_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from whisperjav_amd import sharded_transcribe
+    sharding.init_distributed("gloo")
+    scenes = sharding.broadcast_object([(0.0, 29.0), (30.0, 33.5), (40.0, 52.0), (60.0, 88.5), (90.0, 97.25)] if rank == 0 else None)
+    audio = np.arange(16000 * 100, dtype=np.float32)
+    seen = []
+
+    def transcribe_scene(clip, start_s):
+        seen.append(start_s)
+        assert clip[0] == int(start_s * 16000)          # the right slice of the recording
+        return [{"start": start_s + 1.0, "end": start_s + 2.0, "text": f"rank{rank}@{start_s}", "avg_logprob": -0.1},
+                {"start": start_s + 0.2, "end": start_s + 0.9, "text": "first", "avg_logprob": -0.2}]
+    merged = sharded_transcribe.transcribe_scenes(audio, 16000, scenes, transcribe_scene)
+    torch.save({"merged": merged, "seen": seen}, os.path.join(out_dir, f"scene_rank{rank}.pt"))
+    sharding.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_scene_parallel_driver_two_ranks(tmp_path):
+    """cfg4's control flow on two gloo ranks: scene list broadcast, LPT split, every scene transcribed exactly once,
+    rank 0 holds all segments sorted by absolute start."""
+    port = _free_port()
+    mp.spawn(_scene_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "scene_rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "scene_rank1.pt", weights_only=False)
+    assert r1["merged"] is None and len(r0["merged"]) == 10
+    assert sorted(r0["seen"] + r1["seen"]) == [0.0, 30.0, 40.0, 60.0, 90.0] and r0["seen"] and r1["seen"]
+    starts = [s["start"] for s in r0["merged"]]
+    assert starts == sorted(starts) and starts[0] == pytest.approx(0.2)
+    assert {s["text"].split("@")[0] for s in r0["merged"] if "@" in s["text"]} == {"rank0", "rank1"}

@@ -123,3 +123,27 @@ def max_over_ranks(value: float, device: torch.device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
+
+
+def broadcast_object(obj: Any, src: int = 0) -> Any:
+    """Small Python object (the scene list) from ``src`` to every rank."""
+    info = rank_info()
+    if info.world == 1 or not dist.is_initialized():
+        return obj
+    box = [obj if info.rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def scene_parallel(scenes: Sequence[Tuple[float, float]], work) -> Optional[List[Any]]:
+    """BASELINE cfg4's flow: every rank holds the same scene list ``[(start_s, end_s)]``; scenes are
+    assigned longest-first, rank r calls ``work(scene_index)`` for its own scenes only, rank 0 returns all results in
+    scene order (the order the reference's SRTStitcher restores, srt_stitching.py:35); other ranks return None.
+    No collective touches the data path: one object gather at the end."""
+    info = rank_info()
+    plan = assign_lpt([float(b) - float(a) for a, b in scenes], info.world)
+    mine = {i: work(i) for i in plan[info.rank]}
+    gathered = gather_objects(mine, dst=0)
+    if info.rank != 0:
+        return None
+    return merge_by_index(plan, gathered)
