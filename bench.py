@@ -33,7 +33,7 @@ from whisperjav_amd import sharding, synth  # noqa: E402
 from whisperjav_amd import weights as pweights  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float32": 157.3}   # dense peaks
+MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float16": 2500.0, "float32": 157.3}   # dense peaks
 
 
 def log(*a):
@@ -44,7 +44,7 @@ def stage_model(tag, count, ms, dims, B, n_dec, prompt_len, dtype):
     """Algorithmic work of one launch of a launch class -> (bound, achieved, unit, work_per_launch)."""
     if count == 0 or ms <= 0:
         return None
-    esz = 2 if dtype == "bfloat16" else 4
+    esz = 4 if dtype == "float32" else 2
     d, H, T, V = dims.n_audio_state, dims.n_audio_head, dims.n_audio_ctx, dims.n_vocab
     M = B * T
     per = ms / count * 1e-3
@@ -57,7 +57,7 @@ def stage_model(tag, count, ms, dims, B, n_dec, prompt_len, dtype):
         "enc_fc1_gemm": 2.0 * M * 4 * d * d,
         "enc_fc2_gemm": 2.0 * M * 4 * d * d,
         # bf16: two launches per layer (K head-split, V transposed per head), float32: one fused launch
-        "cross_kv_gemm": 2.0 * M * d * d * (1 if dtype == "bfloat16" else 2),
+        "cross_kv_gemm": 2.0 * M * d * d * (2 if dtype == "float32" else 1),
         "enc_attention": 4.0 * B * H * T * T * 64,
     }
     avg_keys = prompt_len + (n_dec + 1) / 2.0
@@ -195,7 +195,7 @@ def run_cfg3(args, info, dims):
             "unit": "x real-time (audio-s per wall-s)", "audio_hours_per_sec": round(rtfx / 3600.0, 5), "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+            "dtype": {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.dtype], "data": "synthetic",
             "config": {"workload": (f"cfg3: mode=balanced on {minutes} min of noisy synthetic audio: two-pass energy-gate scenes <= 29 s (device frame energies), "
                                     f"HIP Silero-class VAD, groups <= 6 s, Whisper {args.model} geometry (seeded random "
                                     f"weights), beam 5 / patience 1.2 / repetition penalty 1.5 / no-repeat-3-gram, "
@@ -214,7 +214,7 @@ def main():
     ap.add_argument("--batch", type=int, default=384, help="30 s windows per GPU per step (384: 133 GiB of workspace, cross K/V resident)")
     ap.add_argument("--decode-tokens", type=int, default=224, help="new tokens per window (n_text_ctx // 2)")
     ap.add_argument("--model", default="large-v3")
-    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16", "float32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-sample-tokens", type=int, default=32)
@@ -304,7 +304,7 @@ def main():
         dom = next(iter(stages))
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", f"r01_pmc_cross_attn_b{B}.json")
-        if dom == "dec_cross_attn" and os.path.exists(pmc_file) and args.dtype == "bfloat16":
+        if dom == "dec_cross_attn" and os.path.exists(pmc_file) and args.dtype != "float32":
             pmc = json.load(open(pmc_file))   # rocprofv3 --pmc FETCH_SIZE pass at this batch, x2 gfx950 wide-read correction
             if "expected_average_bytes_per_launch" not in pmc:     # single-chain passes only (one launch = all windows)
                 traffic = pmc["hbm_read_bytes_per_launch"]
@@ -313,7 +313,7 @@ def main():
             roofline = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"],
                         "peak": HBM_PEAK_GBS if e["bound"] == "hbm" else MFMA_PEAK_TFLOPS[args.dtype],
                         "unit": e["unit"], "frac": e["frac"], "traffic": traffic,
-                        "algorithmic_bytes_per_launch": B * dims.n_text_head * dims.n_audio_ctx * 64 * 2 * (2 if args.dtype == "bfloat16" else 4) if dom == "dec_cross_attn" else None,
+                        "algorithmic_bytes_per_launch": B * dims.n_text_head * dims.n_audio_ctx * 64 * 2 * (4 if args.dtype == "float32" else 2) if dom == "dec_cross_attn" else None,
                         "share_of_step": e["share"], "us_per_launch": e["us_per_launch"]}
         enc = [k for k in stages if k.startswith("enc_") and stages[k].get("bound") == "mfma"]
         if enc:
@@ -348,7 +348,7 @@ def main():
             "audio_hours_per_sec": round(rtfx / 3600.0, 5),
             "n_gpus": info.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.dtype], "data": "synthetic",
             "config": {"workload": (f"cfg2: Whisper {args.model} geometry (seeded random weights), {B} x 30 s 16 kHz "
                                     f"windows per GPU per step resident in HBM: log-mel + encoder + greedy decode of "
                                     f"{n_dec} tokens/window with timestamp rules, no VAD"),

@@ -34,7 +34,11 @@ enum {
   WJ_E_UNSUPPORTED = -5
 };
 
-enum { WJ_F32 = 0, WJ_BF16 = 1 };          /* compute/storage type of matrices & activations */
+/* compute/storage type of matrices & activations.  WJ_F32: exact fp32 kernels.  WJ_BF16 / WJ_F16: 16-bit matrices and
+ * GEMM / attention operands on the matrix cores with fp32 accumulation and an fp32 residual stream, LayerNorm,
+ * softmax and logits.  WJ_F16 is the arithmetic the reference runs on a GPU (ctranslate2 compute_type="float16",
+ * whisper fp16=True: whisperjav/modules/whisper_pro_asr.py:201-218). */
+enum { WJ_F32 = 0, WJ_BF16 = 1, WJ_F16 = 2 };
 enum { WJ_MEL_FW = 0, WJ_MEL_OW = 1 };     /* faster-whisper vs openai-whisper mel semantics */
 
 typedef struct wj_ctx wj_ctx;
@@ -56,7 +60,8 @@ int wj_device_info(wj_ctx* ctx, int64_t out[4]);
  * Decode step: "dec_ks_attn", "dec_ks_fc2", "dec_ks_proj", "dec_proj_min_m", "dec_tile_min_m" (split-K factors and the
  * row counts that select them), "dec_rows", "dec_rows_max_m", "dec_rows_ks_attn", "dec_rows_ks_fc2" (one-wave-per-row-
  * block GEMM for small batches), "dec_ms_stages", "dec_tile_reg" (decode tile GEMM staging), "dec_fuse_reduce",
- * "decode_chains", "dec_cross_mfma" (read at wj_whisper_create), "dec_cross_u", "dec_cross_nt".
+ * "decode_chains", "dec_cross_mfma" and "dec_split_act" (fp16 models: decode GEMM activations as hi + lo pairs; both read
+ * at wj_whisper_create), "dec_cross_u", "dec_cross_nt".
  * Encoder: "attn_enc_variant" (bit0 XCD remap, bit1 base-2 softmax, bit2 lazy rescale, bit3 lean softmax),
  * "gemm_big" (256-tile kernel).  Alignment: "align_prefill".  Unknown keys are an error. */
 int wj_tune(const char* key, int value);
@@ -270,6 +275,11 @@ int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, cons
 int wj_k_gemm_timed(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev,
                     void* c_dev, int M, int N, int K, int act_gelu, int out_f32, int variant, int reps,
                     float* ms_per_launch);
+/* Split-activation GEMM of the fp16 / bf16 decode step: a_f32_dev float32 [M][K] is stored as [hi | lo] 16-bit rows
+ * (hi = T(a), lo = T(a - hi)) and C = W.hi + W.lo is accumulated in one fp32 accumulator; c_dev float32 [M][N].
+ * variant as for wj_k_gemm (rows / skinny / LDS-DMA tile kernels). */
+int wj_k_gemm_split(wj_ctx* ctx, int dtype, const float* a_f32_dev, const void* w_dev, const float* bias_dev,
+                    float* c_dev, int M, int N, int K, int variant, void* stream);
 int wj_k_layernorm(wj_ctx* ctx, int dtype, const float* x_dev, const float* w_dev, const float* b_dev,
                    void* out_dev, int M, int D, void* stream);
 /* encoder self-attention: qkv in the engine's head-split layouts built from a

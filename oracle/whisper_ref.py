@@ -14,9 +14,9 @@ Weights are a flat ``dict[str, np.ndarray]`` using openai-whisper's state-dict n
 (``encoder.conv1.weight`` ... ``decoder.ln.bias``); see ``whisperjav_amd.weights`` for the
 blob layout the HIP engine consumes (same names).
 
-``act_round`` lets the oracle emulate the HIP engine's bf16 rounding points (every GEMM /
-attention operand is rounded to bf16, accumulation stays fp32) so that the bf16 engine can
-be checked against something tighter than "fp32 +- bf16 noise".
+``act_round`` lets the oracle emulate the HIP engine's 16-bit rounding points (every GEMM /
+attention operand is rounded to bf16 resp. fp16, accumulation stays fp32) so that the 16-bit
+compute types can be checked against something tighter than "fp32 +- rounding noise".
 """
 from __future__ import annotations
 
@@ -68,6 +68,10 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.
 
 def bf16_round(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
+
+
+def f16_round(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.float16).to(torch.float32)
 
 
 class WhisperOracle:

@@ -1,0 +1,48 @@
+#!/bin/bash
+# One parametrised runner for every gpurun call of the round (replaces the per-run scripts of round 1):
+#     gpurun --timeout 1500 -- 'bash scripts/gpu_run.sh <plan> [args...]'
+# Every plan writes its logs under gpurun_out/ (merged back by gpurun) and a one-line verdict per step into
+# gpurun_out/summary.log.  Plans:
+#   tests [pytest args]      the -m gpu suite (default: all of tests/)
+#   smoke                    __graft_entry__.smoke()
+#   bench [bench.py args]    python bench.py ... -> gpurun_out/bench_<tag>.json  (tag = $BENCH_TAG, default "default")
+#   prof  [bench.py args]    rocprofv3 --kernel-trace --stats of bench.py ... -> gpurun_out/prof_<tag>/
+#   pmc <counters> [bench.py args]   rocprofv3 --pmc <counters> (own pass, no tracing domains) -> gpurun_out/pmc_<tag>/
+#   py <file> [args]         python <file> ... -> gpurun_out/<basename>.log
+#   seq "<plan a...>" "<plan b...>"   several plans in one call
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+TAG="${BENCH_TAG:-default}"
+note() { echo "$*" >> gpurun_out/summary.log; }
+plan="$1"; shift
+case "$plan" in
+  tests)
+    args=("$@"); [ ${#args[@]} -eq 0 ] && args=(tests)
+    timeout 2400 python -m pytest "${args[@]}" -m gpu -q --timeout 900 --maxfail=25 > gpurun_out/pytest_gpu.log 2>&1
+    note "pytest ${args[*]} rc=$?"; tail -8 gpurun_out/pytest_gpu.log ;;
+  smoke)
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1
+    note "smoke rc=$?"; tail -3 gpurun_out/smoke.log ;;
+  bench)
+    timeout 1800 python bench.py "$@" > "gpurun_out/bench_${TAG}.json" 2> "gpurun_out/bench_${TAG}.err"
+    note "bench[$TAG] $* rc=$?"; cut -c1-1500 "gpurun_out/bench_${TAG}.json"; tail -3 "gpurun_out/bench_${TAG}.err" ;;
+  prof)
+    rm -rf "gpurun_out/prof_${TAG}"
+    (cd /tmp && timeout 1800 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_${TAG}" -o trace --output-format csv -- \
+        python "$OLDPWD/bench.py" "$@" > "$OLDPWD/gpurun_out/prof_${TAG}.json" 2> "$OLDPWD/gpurun_out/prof_${TAG}.err")
+    note "prof[$TAG] $* rc=$?"; find "gpurun_out/prof_${TAG}" -name '*kernel_stats.csv' | head -1 | xargs -r head -12 ;;
+  pmc)
+    counters="$1"; shift
+    rm -rf "gpurun_out/pmc_${TAG}"
+    (cd /tmp && timeout 1800 rocprofv3 --pmc $counters -d "$OLDPWD/gpurun_out/pmc_${TAG}" -o pmc --output-format csv -- \
+        python "$OLDPWD/bench.py" "$@" > "$OLDPWD/gpurun_out/pmc_${TAG}.json" 2> "$OLDPWD/gpurun_out/pmc_${TAG}.err")
+    note "pmc[$TAG] $counters $* rc=$?" ;;
+  py)
+    f="$1"; shift
+    timeout 1800 python "$f" "$@" > "gpurun_out/$(basename "$f" .py).log" 2>&1
+    note "py $f $* rc=$?"; tail -15 "gpurun_out/$(basename "$f" .py).log" ;;
+  seq)
+    for p in "$@"; do eval "bash scripts/gpu_run.sh $p"; done ;;
+  *) echo "unknown plan $plan"; exit 2 ;;
+esac

@@ -13,6 +13,12 @@ and audio that both sides can regenerate bit-identically:
                           vocab 51866), one 30 s window of synthetic speech: encoder probes and
                           the first greedy tokens with their log-probs (timestamps on)
   * golden_logmel.npz   : log-mel probes of the synthetic clip under both upstream semantics
+  * golden_large_v3_r2_<weights>.npz (--large-r2): large-v3 geometry with weights that are NOT pre-rounded to the
+                          engine's storage type (``none``: raw fp32 draws) resp. rounded to fp16 (``float16``: the
+                          storage type of the published checkpoints): 32 greedy tokens with per-token log-probs AND
+                          the BASELINE cfg3 search (beam 5, patience 1.2, repetition penalty 1.5, no-repeat-3-gram,
+                          32 new tokens) -- every finished hypothesis with its cumulative log-prob.  These carry the
+                          north-star's 1e-3 log-prob bar for the 16-bit compute types (tests/test_gpu_pipeline.py).
 """
 import os
 import sys
@@ -67,9 +73,55 @@ def run(dims: pdims.WhisperDims, seed: int, n_new: int, out_name: str, mel: np.n
     print(f"[{out_name}] tokens {res.tokens[0]} lp {np.round(res.token_logprob[0], 4)}")
 
 
+def run_r2(exact: str, n_new: int, mel: np.ndarray):
+    """Round-2 golden: greedy + cfg3 beam search at the large-v3 geometry on weights of rounding mode ``exact``."""
+    dims = pdims.dims_for("large-v3")
+    t0 = time.time()
+    w = pweights.synth_weights(dims, seed=1234, exact=exact)
+    oracle = whisper_ref.WhisperOracle(helpers.oracle_dims(dims), w)
+    lay = decoding.TokenLayout.for_vocab(dims.n_vocab)
+    toks = pdims.special_tokens(dims.n_vocab)
+    prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
+    suppress = (1, 2, 7, 8, 9, 10, 14, 25, toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev,
+                toks.no_speech)
+    gcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=50)
+    bfil = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=0)
+    bcfg = decoding.BeamConfig(5, 1.2, 1.0, 1.5, 3, n_new)
+    name = f"golden_large_v3_r2_{exact}.npz"
+    with torch.no_grad():
+        enc = oracle.encode(torch.from_numpy(mel))
+        print(f"[{name}] weights + encode {time.time() - t0:.0f}s", flush=True)
+        t0 = time.time()
+        res = decoding.greedy_decode(oracle, enc, prompt, n_new, gcfg)
+        print(f"[{name}] greedy {time.time() - t0:.0f}s", flush=True)
+        t0 = time.time()
+        hyps, nsp = decoding.beam_search(oracle, enc, prompt, bcfg, bfil)
+        print(f"[{name}] beam {time.time() - t0:.0f}s, {len(hyps)} finished hypotheses", flush=True)
+    pv, cols = probes(enc)
+    width = max(len(t) for t, _, _ in hyps)
+    beam_tokens = np.full((len(hyps), width), lay.eot, dtype=np.int64)
+    for i, (t, _, _) in enumerate(hyps):
+        beam_tokens[i, : len(t)] = t
+    np.savez_compressed(
+        os.path.join(HERE, name), seed=1234, exact=exact, dims=np.array(list(dims.as_dict().values())),
+        prompt=np.array(prompt), suppress=np.array(suppress), tokens=np.array(res.tokens[0]),
+        token_logprob=np.array(res.token_logprob[0], dtype=np.float32), sum_logprob=res.sum_logprob,
+        no_speech_prob=res.no_speech_prob, enc_probe=pv.astype(np.float32), probe_t=PROBE_T, probe_d=cols,
+        enc_abs_mean=np.float32(enc.abs().mean()), eot=lay.eot,
+        beam=np.array([5, 1.2, 1.0, 1.5, 3, n_new]), beam_tokens=beam_tokens,
+        beam_len=np.array([len(t) for t, _, _ in hyps]), beam_norm=np.array([n for _, n, _ in hyps], dtype=np.float64),
+        beam_cum=np.array([c for _, _, c in hyps], dtype=np.float64), beam_no_speech=np.float64(nsp))
+    print(f"[{name}] greedy {res.tokens[0][:10]}... beam best {hyps[0][0][:10]}... cum {hyps[0][2]:.4f} "
+          f"(runner-up {hyps[1][2]:.4f})" if len(hyps) > 1 else "")
+
+
 def main():
     audio = synth.speech_like(30.0, seed=1234)
     fw128 = logmel.window_features(audio, 128, "fw")
+    if "--only-r2" in sys.argv:
+        for exact in ("none", "float16"):
+            run_r2(exact, 32, fw128[None])
+        return
     fw80 = logmel.window_features(audio, 80, "fw")
     ow128 = logmel.window_features(audio[: 16000 * 11], 128, "ow")
     cols = np.array([0, 1, 2, 100, 1000, 1099, 1100, 1101, 1500, 2998, 2999])
@@ -80,6 +132,9 @@ def main():
     run(small, 21, 24, "golden_small.npz", fw80[None])
     if "--large" in sys.argv:
         run(pdims.dims_for("large-v3"), 1234, 16, "golden_large_v3.npz", fw128[None])
+    if "--large-r2" in sys.argv:
+        for exact in ("none", "float16"):
+            run_r2(exact, 32, fw128[None])
 
 
 if __name__ == "__main__":

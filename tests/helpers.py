@@ -17,9 +17,14 @@ def small_dims(n_mels=80, d_model=128, heads=2, layers=2, n_vocab=51865) -> pdim
     return pdims.custom_dims(n_mels, d_model, heads, layers, n_vocab)
 
 
-def make_oracle(d: pdims.WhisperDims, seed=1234, emulate_bf16=False):
+def make_oracle(d: pdims.WhisperDims, seed=1234, emulate_bf16=False, emulate: str = ""):
+    """``emulate`` = "bfloat16" / "float16": the oracle rounds every GEMM / attention operand to that type at the
+    engine's rounding points (fp32 accumulation), so a 16-bit engine can be checked against something tighter than
+    "fp32 +- rounding noise"; "" / "float32" = the plain fp32 oracle."""
     w = pweights.synth_weights(d, seed=seed)
-    rnd = whisper_ref.bf16_round if emulate_bf16 else None
+    if emulate_bf16:
+        emulate = "bfloat16"
+    rnd = {"bfloat16": whisper_ref.bf16_round, "float16": whisper_ref.f16_round}.get(emulate)
     return whisper_ref.WhisperOracle(oracle_dims(d), w, act_round=rnd), w
 
 

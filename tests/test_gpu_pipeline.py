@@ -23,6 +23,12 @@ pytestmark = pytest.mark.gpu
 DIAG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
+def _tol(dtype, f32, bf16, f16=None):
+    """Per-compute-type bound: float32 carries the north-star bar, the 16-bit types are compared with the oracle run
+    at their own rounding points (fp16 has 3 more mantissa bits than bf16: 1/8 of its bound unless stated)."""
+    return {"float32": f32, "bfloat16": bf16, "float16": bf16 / 8.0 if f16 is None else f16}[dtype]
+
+
 def _diag(name, payload):
     os.makedirs(DIAG, exist_ok=True)
     with open(os.path.join(DIAG, "diag_pipeline.jsonl"), "a") as f:
@@ -88,17 +94,17 @@ SMALL = dict(n_mels=80, d_model=128, heads=2, layers=2, n_vocab=51865)
 def _engine_and_oracle(dtype, dims_kw=SMALL, seed=21, max_batch=3, max_beam=1):
     from whisperjav_amd import engine
     d = helpers.small_dims(**dims_kw)
-    oracle, w = helpers.make_oracle(d, seed=seed, emulate_bf16=(dtype == "bfloat16"))
+    oracle, w = helpers.make_oracle(d, seed=seed, emulate=dtype)
     model = engine.HipWhisper(d, w, dtype=dtype, max_batch=max_batch, max_beam=max_beam)
     return d, oracle, model
 
 
-@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 def test_encoder_layer_bisection(hip, dtype):
     """Stem only, one block, full stack: localises a kernel bug to a launch group."""
     d, oracle, model = _engine_and_oracle(dtype)
     mel = torch.from_numpy(helpers.synth_mel(2, d.n_mels, seed=4))
-    tol = 2e-3 if dtype == "float32" else 6e-2
+    tol = _tol(dtype, 2e-3, 6e-2, 8e-3)
     for n_layers in (0, 1, -1):
         with torch.no_grad():
             ref = oracle.encode(mel, n_layers=None if n_layers < 0 else n_layers, final_ln=n_layers < 0)
@@ -110,7 +116,7 @@ def test_encoder_layer_bisection(hip, dtype):
     model.close()
 
 
-@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 @pytest.mark.parametrize("without_timestamps", [False, True])
 def test_greedy_decode_matches_oracle(hip, dtype, without_timestamps):
     from whisperjav_amd import engine
@@ -128,7 +134,7 @@ def test_greedy_decode_matches_oracle(hip, dtype, without_timestamps):
     with torch.no_grad():
         xa = oracle.encode(mel)
         ref = decoding.greedy_decode(oracle, xa, prompt, n_new, cfg)
-    lp_tol = 1e-3 if dtype == "float32" else 0.15
+    lp_tol = _tol(dtype, 1e-3, 0.15, 0.02)
     agree = 0
     worst = 0.0
     for r in range(3):
@@ -150,7 +156,7 @@ def test_greedy_decode_matches_oracle(hip, dtype, without_timestamps):
     _diag("greedy", {"dtype": dtype, "without_timestamps": without_timestamps, "common_tokens": agree,
                      "max_logprob_diff": worst, "no_speech_diff": float(np.abs(res.no_speech_prob - ref.no_speech_prob).max())})
     assert worst < lp_tol, worst
-    assert np.abs(res.no_speech_prob - ref.no_speech_prob).max() < (1e-5 if dtype == "float32" else 1e-3)
+    assert np.abs(res.no_speech_prob - ref.no_speech_prob).max() < _tol(dtype, 1e-5, 1e-3, 2e-4)
     if not without_timestamps:  # structural timestamp rules: first token is a timestamp <= 1.0 s
         tb = model.tokens.timestamp_begin
         assert all(tb <= res.tokens[r, 0] <= tb + 50 for r in range(3))
@@ -218,18 +224,18 @@ def test_step_api_equals_greedy_and_beam_rebinding(hip):
     model2.close()
 
 
-@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 def test_whisper_tiny_shape(hip, dtype):
     """The published 'tiny' geometry (384 / 6 heads / 4 layers), BASELINE config #1's model size."""
     from whisperjav_amd import dims as pdims, engine
     d = pdims.dims_for("tiny")
-    oracle, w = helpers.make_oracle(d, seed=2, emulate_bf16=(dtype == "bfloat16"))
+    oracle, w = helpers.make_oracle(d, seed=2, emulate=dtype)
     model = engine.HipWhisper(d, w, dtype=dtype, max_batch=1)
     mel = torch.from_numpy(helpers.synth_mel(1, d.n_mels, seed=1))
     with torch.no_grad():
         ref = oracle.encode(mel)
     got = model.encode(mel.cuda(), want_output=True).cpu()
-    tol = 2e-3 if dtype == "float32" else 8e-2
+    tol = _tol(dtype, 2e-3, 8e-2, 1e-2)
     assert float((got - ref).abs().max()) < tol * max(1.0, float(ref.abs().max()))
     model.close()
 
@@ -258,7 +264,7 @@ def _golden_run(name, dims, dtype, n_mels):
     return g, enc, probe, res
 
 
-@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 def test_golden_small_end_to_end(hip, dtype):
     """audio -> HIP log-mel -> encoder -> greedy decode against the committed fp32 oracle vectors."""
     g, enc, probe, res = _golden_run("golden_small.npz", helpers.small_dims(), dtype, 80)
@@ -275,6 +281,8 @@ def test_golden_small_end_to_end(hip, dtype):
     _diag("golden_small", {"dtype": dtype, "probe_max_abs": d_probe, "common": common, "lp_max_abs": d_lp})
     if dtype == "float32":
         assert d_probe < 2e-3 and got == ref and d_lp < 1e-3
+    elif dtype == "float16":      # weights are bf16-exact here, so only the activations are rounded (2^-11)
+        assert d_probe < 1.5e-2 and common >= 8 and d_lp < 2e-2
     else:
         assert d_probe < 0.1 and common >= 3 and d_lp < 0.15
 
@@ -306,15 +314,72 @@ def test_golden_large_v3_window(hip, dtype):
         assert common >= 3 and d_lp < 0.2
 
 
+# Round-2 goldens: large-v3 geometry, weights NOT pre-rounded to the engine's storage type, 32 greedy tokens + the
+# BASELINE cfg3 search (beam 5, patience 1.2, repetition penalty 1.5, no-repeat-3-gram).  Bars:
+#   * float32: tokens identical, per-token log-probs within 1e-3 (the north-star bar; measured ~1e-5);
+#   * float16 (the reference's GPU arithmetic, split-activation decode GEMMs): tokens and the winning beam identical
+#     (zero flips); per-token log-probs within 1e-3 when the weights are fp16-representable (as the published
+#     checkpoints are) and within 2.5e-3 on the raw fp32 draws, where storing the weights in fp16 alone moves the
+#     oracle's log-probs by 1.05e-3 (profiles/r02_precision_ablation_cpu.json, case only_weights16);
+#   * bfloat16: reported, bounded loosely (8 mantissa bits; not the default compute type any more).
+R2_LP_BAR = {("float32", "none"): 1e-3, ("float32", "float16"): 1e-3, ("float16", "float16"): 1e-3,
+             ("float16", "none"): 2.5e-3, ("bfloat16", "none"): 0.1, ("bfloat16", "float16"): 0.1}
+
+
+@pytest.mark.parametrize("exact", ["float16", "none"])
+@pytest.mark.parametrize("dtype", ["float16", "float32", "bfloat16"])
+def test_golden_large_v3_r2_greedy_and_beam(hip, dtype, exact):
+    from whisperjav_amd import dims as pdims, engine, synth, weights as pweights
+    g = np.load(os.path.join(GOLDEN, f"golden_large_v3_r2_{exact}.npz"))
+    dims = pdims.dims_for("large-v3")
+    audio = synth.speech_like(30.0, seed=1234)
+    mel = engine.HipLogMel(128, "fw")([audio])
+    w = pweights.synth_weights(dims, seed=int(g["seed"]), exact=exact)
+    model = engine.HipWhisper(dims, w, dtype=dtype, max_batch=1, max_beam=5)
+    del w
+    enc = model.encode(mel, want_output=True).cpu()
+    probe = enc[0][g["probe_t"]][:, g["probe_d"]].numpy()
+    d_probe = float(np.abs(probe - g["enc_probe"]).max())
+    sup = tuple(int(t) for t in g["suppress"])
+    prompt = np.array([g["prompt"]], dtype=np.int32)
+    ref_t = g["tokens"].tolist()
+    res = model.decode_greedy(prompt, engine.DecodeOptions(max_new_tokens=len(ref_t), suppress_tokens=sup, max_initial_timestamp=1.0))
+    got = res.tokens[0, : int(res.n_tokens[0])].tolist()
+    common = next((i for i, (a, b) in enumerate(zip(got, ref_t)) if a != b), min(len(got), len(ref_t)))
+    d_lp = float(np.abs(res.token_logprob[0, :common] - g["token_logprob"][:common]).max()) if common else 0.0
+    beam, patience, lpen, rep, ngram, n_new = (float(x) for x in g["beam"])
+    br = model.decode_beam(prompt, engine.DecodeOptions(max_new_tokens=int(n_new), suppress_tokens=sup, max_initial_timestamp=0.0,
+                                                       repetition_penalty=rep, no_repeat_ngram_size=int(ngram)),
+                           beam_size=int(beam), patience=patience, length_penalty=lpen)
+    model.close()
+    b_got = br.tokens[0, : int(br.n_tokens[0])].tolist()
+    b_ref = g["beam_tokens"][0, : int(g["beam_len"][0])].tolist()
+    d_cum = abs(float(br.sum_logprob[0]) - float(g["beam_cum"][0]))
+    margin = float(g["beam_norm"][0] - g["beam_norm"][1]) if len(g["beam_norm"]) > 1 else float("inf")
+    _diag("golden_large_v3_r2", {"dtype": dtype, "weights": exact, "probe_max_abs": d_probe, "greedy_common": common,
+                                 "greedy_n": len(ref_t), "greedy_lp_max_abs": d_lp, "beam_same": b_got == b_ref,
+                                 "beam_cum_abs": d_cum, "beam_len": len(b_ref), "beam_norm_margin_to_runner_up": margin,
+                                 "greedy_sum_abs": abs(float(res.sum_logprob[0]) - float(g["sum_logprob"][0]))})
+    bar = R2_LP_BAR[(dtype, exact)]
+    if dtype == "bfloat16":
+        assert common >= 3 and d_lp < bar
+        return
+    assert got == ref_t, (common, got, ref_t)                      # zero token flips over 32 greedy tokens
+    assert d_lp < bar, d_lp
+    assert b_got == b_ref, (b_got, b_ref)                          # the same winning hypothesis
+    assert d_cum < bar * max(1, len(b_ref)), d_cum                 # cumulative log-prob: the per-token bar x length
+    assert abs(float(br.no_speech_prob[0]) - float(g["beam_no_speech"])) < (1e-5 if dtype == "float32" else 1e-3)
+
+
 # ---------------------------------------------------------------------------------------------
 # beam search through the device scorer (wj_decode_topk_rules) vs the oracle's CTranslate2 restatement
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 @pytest.mark.parametrize("beam,patience,rep,ngram", [(2, 1.2, 1.5, 3), (5, 1.2, 1.5, 3), (3, 1.0, 1.0, 0)])
 def test_beam_search_matches_oracle(hip, dtype, beam, patience, rep, ngram):
     from whisperjav_amd import engine, search
     d = helpers.small_dims()
-    oracle, w = helpers.make_oracle(d, seed=33, emulate_bf16=(dtype == "bfloat16"))
+    oracle, w = helpers.make_oracle(d, seed=33, emulate=dtype)
     model = engine.HipWhisper(d, w, dtype=dtype, max_batch=2, max_beam=beam)
     mel = torch.from_numpy(helpers.synth_mel(2, d.n_mels, seed=19))
     toks = model.tokens
@@ -694,7 +759,7 @@ def test_sampling_first_token_frequencies_follow_softmax(hip):
 # word-timestamp alignment (wj_whisper_align vs oracle/alignment.py = whisper/timing.py restated)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prefill", [1, 0])
-@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 def test_alignment_matches_oracle(hip, dtype, prefill):
     """Teacher-forced pass + softmax / normalise / median filter / head mean / DTW on the device.  float32: the DTW
     path (integer token / frame indices) is identical to the oracle's and the text-token probabilities agree to
@@ -731,7 +796,7 @@ def test_alignment_matches_oracle(hip, dtype, prefill):
             worst_t = max(worst_t, int(np.abs(first(g_ti, g_fi) - first(ti, fi)).max()))
     hipbind.tune("align_prefill", 1)
     _diag("alignment", {"dtype": dtype, "prefill": prefill, "max_prob_diff": worst_p, "max_token_start_shift_frames": worst_t})
-    assert worst_p < (1e-4 if dtype == "float32" else 2e-2), worst_p
+    assert worst_p < _tol(dtype, 1e-4, 2e-2, 4e-3), worst_p
     assert worst_t <= 25, worst_t
     model.close()
 
@@ -771,13 +836,13 @@ def test_word_timestamps_through_the_shim(hip):
 # device-resident beam search (wj_whisper_decode_beam) vs the oracle's CTranslate2 restatement and vs the
 # host-driven search over the step API
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 @pytest.mark.parametrize("beam,patience,rep,ngram,n_new", [(2, 1.2, 1.5, 3, 16), (5, 1.2, 1.5, 3, 16), (3, 1.0, 1.0, 0, 16),
                                                            (5, 2.0, 1.1, 2, 40), (8, 1.0, 1.0, 0, 9)])
 def test_device_beam_search_matches_oracle(hip, dtype, beam, patience, rep, ngram, n_new):
     from whisperjav_amd import engine, search
     d = helpers.small_dims()
-    oracle, w = helpers.make_oracle(d, seed=33, emulate_bf16=(dtype == "bfloat16"))
+    oracle, w = helpers.make_oracle(d, seed=33, emulate=dtype)
     model = engine.HipWhisper(d, w, dtype=dtype, max_batch=3, max_beam=beam)
     mel = torch.from_numpy(helpers.synth_mel(3, d.n_mels, seed=19))
     toks = model.tokens

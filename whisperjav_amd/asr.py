@@ -354,7 +354,7 @@ class HipWhisperProASR(HipFasterWhisperProASR):
         if whisper_model is None:
             from .whisper_model import HipOpenAIWhisperModel
             whisper_model = HipOpenAIWhisperModel(model_config.get("model_name", "large-v2"), device="cuda",
-                                                  compute_type="bfloat16" if decoder.get("fp16", True) else "float32")
+                                                  compute_type="float16" if decoder.get("fp16", True) else "float32")
         super().__init__(model_config, params, task, tracer, whisper_model=whisper_model, segmenter=segmenter)
 
     def _prepare_whisper_params(self) -> Dict[str, Any]:

@@ -12,8 +12,9 @@
 
 namespace wj {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <typename T> struct Lane16;                       // scalar type of an MFMA operand element
+template <> struct Lane16<bf16_t> { typedef __bf16 type; };
+template <> struct Lane16<f16_t> { typedef _Float16 type; };
 
 __device__ __forceinline__ int aswz(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) << 3); }
 // K tile of the encoder attention: key k of the 64-key tile is stored at the LDS row the MFMA A-operand reads it from
@@ -23,10 +24,12 @@ __device__ __forceinline__ int aswz(int row, int chunk) { return row * 64 + ((ch
 __device__ __forceinline__ int kperm(int k) { return 16 * (2 * (k >> 5) + ((k >> 2) & 1)) + 4 * ((k >> 3) & 3) + (k & 3); }
 __device__ __forceinline__ int kswz(int prow, int chunk) { return prow * 64 + ((chunk ^ ((prow ^ (prow >> 4)) & 7)) << 3); }
 
-template <int VAR>
-__global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                            const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
-                                                            int T, int Tpad, int H) {
+template <typename E, int VAR>
+__global__ __launch_bounds__(256) void attn_enc_h_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                         const bf16_t* __restrict__ Vt, E* __restrict__ out,
+                                                         int T, int Tpad, int H) {
+  typedef typename Vec8<E>::type vec8_t;       // the operand vector of this instantiation (bf16 or fp16 lanes)
+  typedef typename Lane16<E>::type lane_t;
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * 64 * 64];  // [buf][K|Vt][64][64] = 32 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -44,18 +47,18 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
   const bf16_t* Kp = K + bh * Tpad * 64;
   const bf16_t* Vp = Vt + bh * 64 * Tpad;
 
-  bf16x8_t qf[2][2];
+  vec8_t qf[2][2];
 #pragma unroll
   for (int f = 0; f < 2; ++f)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
-      qf[f][ks] = *reinterpret_cast<const bf16x8_t*>(Qp + (int64_t)(q0 + f * 16 + li) * 64 + ks * 32 + lg * 8);
+      qf[f][ks] = *reinterpret_cast<const vec8_t*>(Qp + (int64_t)(q0 + f * 16 + li) * 64 + ks * 32 + lg * 8);
 
   f32x4_t o[2][4];
   f32x4_t lsum[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};   // VAR & 8: row sums from the MFMA pipe
-  bf16x8_t ones8;
+  vec8_t ones8;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones8[e] = (__bf16)1.0f;
+  for (int e = 0; e < 8; ++e) ones8[e] = (lane_t)1.0f;
   float m_run[2], l_run[2];
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
@@ -104,13 +107,13 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
       st[1][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&lk[kswz(krow, ks * 4 + lg)]);
-        st[0][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], st[0][kb], 0, 0, 0);
-        st[1][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], st[1][kb], 0, 0, 0);
+        const vec8_t kf = *reinterpret_cast<const vec8_t*>(&lk[kswz(krow, ks * 4 + lg)]);
+        st[0][kb] = mfma16(kf, qf[0][ks], st[0][kb]);
+        st[1][kb] = mfma16(kf, qf[1][ks], st[1][kb]);
       }
     }
     // lane (q = li, lg) now holds, for block kb, keys  kt*64 + 32*(kb>>1) + 8*lg + 4*(kb&1) + r
-    bf16x8_t pf[2][2];
+    vec8_t pf[2][2];
     // only the last key tile contains padding keys: a real (scalar) branch, not 64 selects per tile
     if (__builtin_amdgcn_readfirstlane((kt + 1) * 64 > T)) {
 #pragma unroll
@@ -155,19 +158,19 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
         const float nm = -m_run[f];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          bf16x8_t v;
+          vec8_t v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            v[r] = (__bf16)__builtin_amdgcn_exp2f(fmaf(st[f][2 * s2][r], c2, nm));
-            v[4 + r] = (__bf16)__builtin_amdgcn_exp2f(fmaf(st[f][2 * s2 + 1][r], c2, nm));
+            v[r] = (lane_t)__builtin_amdgcn_exp2f(fmaf(st[f][2 * s2][r], c2, nm));
+            v[4 + r] = (lane_t)__builtin_amdgcn_exp2f(fmaf(st[f][2 * s2 + 1][r], c2, nm));
           }
           pf[f][s2] = v;
         }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {     // row sums of the bf16 probabilities: ones . P^T
-        lsum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, pf[0][s2], lsum[0], 0, 0, 0);
-        lsum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, pf[1][s2], lsum[1], 0, 0, 0);
+        lsum[0] = mfma16(ones8, pf[0][s2], lsum[0]);
+        lsum[1] = mfma16(ones8, pf[1][s2], lsum[1]);
       }
     } else {
     // VAR & 2: softmax in base 2 on the raw v_exp_f32 (scale folds 1/sqrt(64) * log2 e); else natural exp
@@ -206,11 +209,11 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8_t v;
+        vec8_t v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = (__bf16)p[2 * s2][r];
-          v[4 + r] = (__bf16)p[2 * s2 + 1][r];
+          v[r] = (lane_t)p[2 * s2][r];
+          v[4 + r] = (lane_t)p[2 * s2 + 1][r];
         }
         pf[f][s2] = v;
       }
@@ -221,9 +224,9 @@ __global__ __launch_bounds__(256) void attn_enc_bf16_kernel(const bf16_t* __rest
     for (int d = 0; d < 4; ++d)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(&lv[aswz(d * 16 + li, s2 * 4 + lg)]);
-        o[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][s2], o[0][d], 0, 0, 0);
-        o[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][s2], o[1][d], 0, 0, 0);
+        const vec8_t vf = *reinterpret_cast<const vec8_t*>(&lv[aswz(d * 16 + li, s2 * 4 + lg)]);
+        o[0][d] = mfma16(vf, pf[0][s2], o[0][d]);
+        o[1][d] = mfma16(vf, pf[1][s2], o[1][d]);
       }
     if (kt + 1 < nt) { WJ_ASTORE(cur ^ 1) }
     __syncthreads();
@@ -322,8 +325,14 @@ int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt
   } else {
     dim3 grid(Tpad / 128, H, B);
 #define WJ_ATTN(V)                                                                                                 \
-  hipLaunchKernelGGL(attn_enc_bf16_kernel<V>, grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K,          \
-                     (const bf16_t*)Vt, (bf16_t*)out, T, Tpad, H)
+  do {                                                                                                             \
+    if (dtype == WJ_F16)                                                                                           \
+      hipLaunchKernelGGL((attn_enc_h_kernel<f16_t, V>), grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
+                         (const bf16_t*)Vt, (f16_t*)out, T, Tpad, H);                                              \
+    else                                                                                                           \
+      hipLaunchKernelGGL((attn_enc_h_kernel<bf16_t, V>), grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
+                         (const bf16_t*)Vt, (bf16_t*)out, T, Tpad, H);                                             \
+  } while (0)
     switch (g_attn_enc_variant & 15) {
       case 0: WJ_ATTN(0); break;
       case 1: WJ_ATTN(1); break;
@@ -393,9 +402,9 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {   // the projection epilogue rounds q, k, v to the cache dtype
-      qf[0][e] = bf2f(f2bf(qf[0][e])) * 0.125f;
-      knew[e] = bf2f(f2bf(knew[e]));
-      vnew[e] = bf2f(f2bf(vnew[e]));
+      qf[0][e] = round_T<T>(qf[0][e]) * 0.125f;
+      knew[e] = round_T<T>(knew[e]);
+      vnew[e] = round_T<T>(vnew[e]);
     }
     if (kk == 0) {                  // append to the cache for the steps to come
       const int64_t off = (((int64_t)(a.row_base + gi) * a.H + h) * a.kv_stride + (n_keys - 1)) * 64 + c * 8;
@@ -553,7 +562,11 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
       num += red_o[(w * NB + b) * 64 + d];
       den += red_l[w * NB + b];
     }
-    Elem<T>::st(reinterpret_cast<T*>(a.out) + (int64_t)(gi * NB + b) * D + h * 64 + d, num / den);
+    T* op = reinterpret_cast<T*>(a.out) + (int64_t)(gi * NB + b) * D * (a.out_split ? 2 : 1) + h * 64 + d;
+    if constexpr (sizeof(T) == 2) {
+      if (a.out_split) { st_split<T>(op, D, num / den); continue; }     // [hi(D) | lo(D)] rows for a split-activation GEMM
+    }
+    Elem<T>::st(op, num / den);
   }
 }
 
@@ -568,11 +581,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dec_kernel(const DecAttnArgs a) 
 // V is therefore kept TRANSPOSED per head ([H][64][vt_stride], zero padded) -- written that way by the
 // cross-K/V GEMM epilogue.  Beams of a window are the MFMA's N columns (up to 16 for free).
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ bf16x8_t as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
-
-__device__ __forceinline__ uint32_t scale2_bf16(uint32_t pair, float sc) {
-  const float lo = __uint_as_float(pair << 16) * sc, hi = __uint_as_float(pair & 0xffff0000u) * sc;
-  return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16);
+template <typename E> __device__ __forceinline__ uint32_t scale2(uint32_t pair, float sc) {
+  float lo, hi;
+  unpack2<E>(pair, lo, hi);
+  return pack2<E>(lo * sc, hi * sc);
 }
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -588,7 +600,7 @@ __device__ __forceinline__ uint4 ldg_stream(const bf16_t* p) {
   }
 }
 
-template <int U1, int U2, bool NT>
+template <typename E, int U1, int U2, bool NT>
 __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -596,7 +608,7 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
   const int h = blockIdx.x, gi = blockIdx.y;
   const int NB = a.nb, n_keys = a.n_keys, kpad = a.vt_stride;
   float* sc = smem;                                              // [NB][kpad] scores
-  bf16_t* pl = reinterpret_cast<bf16_t*>(sc + NB * kpad);        // [NB][kpad] probabilities
+  E* pl = reinterpret_cast<E*>(sc + NB * kpad);                  // [NB][kpad] probabilities
   float* red_m = reinterpret_cast<float*>(pl + NB * kpad);       // [4][16]
   float* red_l = red_m + 64;                                     // [4][16]
   const int D = a.H * 64;
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s0[e] += b0[e]; s1[e] += b1[e]; }
     }
-    auto pack = [](float lo, float hi) { return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16); };
+    auto pack = [](float lo, float hi) { return pack2<E>(lo, hi); };
     q0 = make_uint4(pack(s0[0], s0[1]), pack(s0[2], s0[3]), pack(s0[4], s0[5]), pack(s0[6], s0[7]));
     q1 = make_uint4(pack(s1[0], s1[1]), pack(s1[2], s1[3]), pack(s1[4], s1[5]), pack(s1[6], s1[7]));
   } else if (li < NB) {
@@ -634,10 +646,10 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
     q1 = *reinterpret_cast<const uint4*>(qp + 32);
   }
   if (li < NB) {
-    q0.x = scale2_bf16(q0.x, 0.125f); q0.y = scale2_bf16(q0.y, 0.125f); q0.z = scale2_bf16(q0.z, 0.125f); q0.w = scale2_bf16(q0.w, 0.125f);
-    q1.x = scale2_bf16(q1.x, 0.125f); q1.y = scale2_bf16(q1.y, 0.125f); q1.z = scale2_bf16(q1.z, 0.125f); q1.w = scale2_bf16(q1.w, 0.125f);
+    q0.x = scale2<E>(q0.x, 0.125f); q0.y = scale2<E>(q0.y, 0.125f); q0.z = scale2<E>(q0.z, 0.125f); q0.w = scale2<E>(q0.w, 0.125f);
+    q1.x = scale2<E>(q1.x, 0.125f); q1.y = scale2<E>(q1.y, 0.125f); q1.z = scale2<E>(q1.z, 0.125f); q1.w = scale2<E>(q1.w, 0.125f);
   }
-  const bf16x8_t qb0 = as_bf16x8(q0), qb1 = as_bf16x8(q1);
+  const typename Vec8<E>::type qb0 = as_vec8<E>(q0), qb1 = as_vec8<E>(q1);
 
   // ---- pass 1: scores.  Tile t (16 keys) belongs to wave t % 4; U1 tiles are fetched before any is used.
   const int n_tiles = (n_keys + 15) >> 4;
@@ -654,8 +666,8 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
 #pragma unroll
     for (int u = 0; u < U1; ++u) {
       f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ka[u][0]), qb0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ka[u][1]), qb1, acc, 0, 0, 0);
+      acc = mfma16(as_vec8<E>(ka[u][0]), qb0, acc);
+      acc = mfma16(as_vec8<E>(ka[u][1]), qb1, acc);
       const int kbase = (t0 + 4 * u) * 16 + lg * 4;
       if (li < NB) {
 #pragma unroll
@@ -690,7 +702,7 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
     float ls = 0.f;
     for (int j = tid; j < kpad; j += 256) {
       const float p = j < n_keys ? __builtin_amdgcn_exp2f((sc[b * kpad + j] - mx) * 1.4426950408889634f) : 0.f;
-      pl[b * kpad + j] = f2bf(p);
+      Elem<E>::st(pl + b * kpad + j, p);
       ls += p;
     }
     ls = wave_sum(ls);
@@ -701,7 +713,7 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
   // ---- pass 2: O^T = V^T . P^T, 32 keys per MFMA, U2 chunks in flight
   const int n_chunks = (n_keys + 31) >> 5;
   f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-  const bf16_t* prow = pl + li * kpad + lg * 8;
+  const E* prow = pl + li * kpad + lg * 8;
   for (int c0 = 0; c0 < n_chunks; c0 += U2) {
     uint4 va[U2];
 #pragma unroll
@@ -714,7 +726,7 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
       if (c0 + u < n_chunks) {
         uint4 pb = make_uint4(0, 0, 0, 0);
         if (li < NB) pb = *reinterpret_cast<const uint4*>(prow + (c0 + u) * 32);
-        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(va[u]), as_bf16x8(pb), o, 0, 0, 0);
+        o = mfma16(as_vec8<E>(va[u]), as_vec8<E>(pb), o);
       }
     }
   }
@@ -722,13 +734,16 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const DecAttnArgs 
     const float l = (red_l[li] + red_l[16 + li]) + (red_l[32 + li] + red_l[48 + li]);
     const float inv = 1.0f / l;
     float v[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
-    st4(reinterpret_cast<bf16_t*>(a.out) + (int64_t)(gi * NB + li) * D + h * 64 + wave * 16 + lg * 4, v);
+    E* op = reinterpret_cast<E*>(a.out) + (int64_t)(gi * NB + li) * D * (a.out_split ? 2 : 1) + h * 64 + wave * 16 + lg * 4;
+    if (a.out_split) st4_split<E>(op, D, v);      // [hi(D) | lo(D)] rows for a split-activation GEMM
+    else st4(op, v);
   }
 }
 
 int g_dec_cross_nt = 0;  // wj_tune("dec_cross_nt"): non-temporal K/V loads in the MFMA cross-attention kernel
 int g_dec_cross_u = 0;   // wj_tune("dec_cross_u"): loads in flight per wave in the MFMA cross-attention kernel
 
+template <typename E>
 static int launch_cross_mfma(const DecAttnArgs& a, hipStream_t s) {
   if (a.nb < 1 || a.nb > 16) { set_error("attention_dec: %d query rows per window (1..16)", a.nb); return WJ_E_INVALID; }
   if (a.vt_stride < a.n_keys || (a.vt_stride & 31)) { set_error("attention_dec: vt_stride %d must be a multiple of 32 >= n_keys %d", a.vt_stride, a.n_keys); return WJ_E_INVALID; }
@@ -736,14 +751,14 @@ static int launch_cross_mfma(const DecAttnArgs& a, hipStream_t s) {
   const dim3 grid(a.H, a.G), block(256);
   const int sel = (g_dec_cross_u & 3) | (g_dec_cross_nt ? 4 : 0);
   switch (sel) {
-    case 1: hipLaunchKernelGGL((attn_cross_mfma_kernel<2, 4, false>), grid, block, smem, s, a); break;
-    case 2: hipLaunchKernelGGL((attn_cross_mfma_kernel<6, 12, false>), grid, block, smem, s, a); break;
-    case 3: hipLaunchKernelGGL((attn_cross_mfma_kernel<8, 16, false>), grid, block, smem, s, a); break;
-    case 4: hipLaunchKernelGGL((attn_cross_mfma_kernel<4, 8, true>), grid, block, smem, s, a); break;
-    case 5: hipLaunchKernelGGL((attn_cross_mfma_kernel<2, 4, true>), grid, block, smem, s, a); break;
-    case 6: hipLaunchKernelGGL((attn_cross_mfma_kernel<6, 12, true>), grid, block, smem, s, a); break;
-    case 7: hipLaunchKernelGGL((attn_cross_mfma_kernel<8, 16, true>), grid, block, smem, s, a); break;
-    default: hipLaunchKernelGGL((attn_cross_mfma_kernel<4, 8, false>), grid, block, smem, s, a); break;
+    case 1: hipLaunchKernelGGL((attn_cross_mfma_kernel<E, 2, 4, false>), grid, block, smem, s, a); break;
+    case 2: hipLaunchKernelGGL((attn_cross_mfma_kernel<E, 6, 12, false>), grid, block, smem, s, a); break;
+    case 3: hipLaunchKernelGGL((attn_cross_mfma_kernel<E, 8, 16, false>), grid, block, smem, s, a); break;
+    case 4: hipLaunchKernelGGL((attn_cross_mfma_kernel<E, 4, 8, true>), grid, block, smem, s, a); break;
+    case 5: hipLaunchKernelGGL((attn_cross_mfma_kernel<E, 2, 4, true>), grid, block, smem, s, a); break;
+    case 6: hipLaunchKernelGGL((attn_cross_mfma_kernel<E, 6, 12, true>), grid, block, smem, s, a); break;
+    case 7: hipLaunchKernelGGL((attn_cross_mfma_kernel<E, 8, 16, true>), grid, block, smem, s, a); break;
+    default: hipLaunchKernelGGL((attn_cross_mfma_kernel<E, 4, 8, false>), grid, block, smem, s, a); break;
   }
   WJ_LAUNCH_CHECK();
   return WJ_OK;
@@ -780,10 +795,11 @@ static int launch_dec_T(const DecAttnArgs& a, hipStream_t s) {
 int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s) {
   if (a.G <= 0) return WJ_OK;
   if (a.vt_stride > 0) {
-    if (dtype != WJ_BF16 || a.n_keys_ptr || a.seq_tp) { set_error("attention_dec: transposed V is the bf16 cross-attention layout"); return WJ_E_INVALID; }
-    return launch_cross_mfma(a, s);
+    if (!is16(dtype) || a.n_keys_ptr || a.seq_tp) { set_error("attention_dec: transposed V is the 16-bit cross-attention layout"); return WJ_E_INVALID; }
+    return dtype == WJ_F16 ? launch_cross_mfma<f16_t>(a, s) : launch_cross_mfma<bf16_t>(a, s);
   }
-  return dtype == WJ_F32 ? launch_dec_T<float>(a, s) : launch_dec_T<bf16_t>(a, s);
+  if (dtype == WJ_F32) return launch_dec_T<float>(a, s);
+  return dtype == WJ_F16 ? launch_dec_T<f16_t>(a, s) : launch_dec_T<bf16_t>(a, s);
 }
 
 }  // namespace wj

@@ -78,6 +78,15 @@ __host__ __device__ inline bf16_t f2bf(float f) {
   return static_cast<bf16_t>(u >> 16);
 }
 
+// ---- fp16 as _Float16 (a distinct 2-byte type, so templates can tell it from bf16_t) -------
+typedef _Float16 f16_t;
+
+__host__ __device__ inline float h2f(f16_t v) { return static_cast<float>(v); }
+__host__ __device__ inline f16_t f2h(float f) { return static_cast<f16_t>(f); }   // RNE (v_cvt_f16_f32)
+
+inline bool is16(int dtype) { return dtype == WJ_BF16 || dtype == WJ_F16; }
+inline size_t dtype_size(int dtype) { return dtype == WJ_F32 ? 4 : 2; }
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int dtype = WJ_F32;
@@ -90,6 +99,42 @@ template <> struct Elem<bf16_t> {
   __device__ static inline void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+template <> struct Elem<f16_t> {
+  static constexpr int dtype = WJ_F16;
+  __device__ static inline float ld(const f16_t* p) { return h2f(*p); }
+  __device__ static inline void st(f16_t* p, float v) { *p = f2h(v); }
+};
+
+// value of x after a round trip through the 16-bit storage type T (what a producing epilogue would have stored)
+template <typename T> __device__ inline float round_T(float x);
+template <> __device__ inline float round_T<bf16_t>(float x) { return bf2f(f2bf(x)); }
+template <> __device__ inline float round_T<f16_t>(float x) { return h2f(f2h(x)); }
+template <> __device__ inline float round_T<float>(float x) { return x; }
+
+// two floats -> one dword holding (lo, hi) in storage type T
+template <typename T> __device__ inline uint32_t pack2(float lo, float hi);
+template <> __device__ inline uint32_t pack2<bf16_t>(float lo, float hi) {
+  return static_cast<uint32_t>(f2bf(lo)) | (static_cast<uint32_t>(f2bf(hi)) << 16);
+}
+template <> __device__ inline uint32_t pack2<f16_t>(float lo, float hi) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  h2_t v;
+  v[0] = f2h(lo);
+  v[1] = f2h(hi);
+  return __builtin_bit_cast(uint32_t, v);
+}
+template <typename T> __device__ inline void unpack2(uint32_t w, float& lo, float& hi);
+template <> __device__ inline void unpack2<bf16_t>(uint32_t w, float& lo, float& hi) {
+  lo = __uint_as_float(w << 16);
+  hi = __uint_as_float(w & 0xFFFF0000u);
+}
+template <> __device__ inline void unpack2<f16_t>(uint32_t w, float& lo, float& hi) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  const h2_t v = __builtin_bit_cast(h2_t, w);
+  lo = h2f(v[0]);
+  hi = h2f(v[1]);
+}
+
 // store 4 consecutive elements (address must be aligned to 4 elements)
 __device__ inline void st4(float* p, const float v[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -100,6 +145,25 @@ __device__ inline void st4(bf16_t* p, const float v[4]) {
   u.y = static_cast<uint32_t>(f2bf(v[2])) | (static_cast<uint32_t>(f2bf(v[3])) << 16);
   *reinterpret_cast<uint2*>(p) = u;
 }
+__device__ inline void st4(f16_t* p, const float v[4]) {
+  uint2 u;
+  u.x = pack2<f16_t>(v[0], v[1]);
+  u.y = pack2<f16_t>(v[2], v[3]);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+// split store: hi = T(v) at p, lo = T(v - hi) at p + lo_off (4 consecutive elements each)
+template <typename T> __device__ inline void st4_split(T* p, int64_t lo_off, const float v[4]) {
+  float r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = v[i] - round_T<T>(v[i]);
+  st4(p, v);
+  st4(p + lo_off, r);
+}
+template <typename T> __device__ inline void st_split(T* p, int64_t lo_off, float v) {
+  Elem<T>::st(p, v);
+  Elem<T>::st(p + lo_off, v - round_T<T>(v));
+}
+
 // load 8 consecutive elements as floats (address aligned to 8 elements)
 __device__ inline void ld8(const float* p, float v[8]) {
   float4 a = *reinterpret_cast<const float4*>(p);
@@ -115,6 +179,32 @@ __device__ inline void ld8(const bf16_t* p, float v[8]) {
     v[2 * i] = __uint_as_float(w[i] << 16);
     v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
   }
+}
+
+__device__ inline void ld8(const f16_t* p, float v[8]) {
+  uint4 u = *reinterpret_cast<const uint4*>(p);
+  uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) unpack2<f16_t>(w[i], v[2 * i], v[2 * i + 1]);
+}
+
+// ---- 16x16x32 MFMA for both 16-bit operand types (fp32 accumulate) -----------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> { typedef bf16x8_t type; };
+template <> struct Vec8<f16_t> { typedef f16x8_t type; };
+
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mfma16(f16x8_t a, f16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type as_vec8(uint4 v) {
+  return __builtin_bit_cast(typename Vec8<T>::type, v);
 }
 
 __device__ inline float gelu_exact(float x) {

@@ -96,7 +96,8 @@ struct Tunables {
   int dec_ms_stages = 0;    // LDS-DMA stages of the decode tile GEMM (0 = the 2-stage encoder kernel; 3-5 measured equal)
   int dec_fuse_reduce = 1;  // attention kernels consume the q / qkv split-K slices directly (no reduce launch)
   int align_prefill = 1;    // word-timestamp alignment as one full-sequence decoder pass (0: token by token)
-  int dec_cross_mfma = 1;   // bf16 models: cross V kept transposed, cross attention on the matrix cores (read at create)
+  int dec_cross_mfma = 1;   // 16-bit models: cross V kept transposed, cross attention on the matrix cores (read at create)
+  int dec_split_act = 1;    // fp16 models: decode-step GEMMs take their activations as hi + lo fp16 pairs (read at create)
 };
 static Tunables g_tune;
 
@@ -127,6 +128,10 @@ struct wj_whisper {
   void* cross_k = nullptr;    // T   [L][max_batch][H][ctx][64]
   void* cross_v = nullptr;    // same, or (cross_tpad > 0) transposed per head: [L][max_batch][H][64][cross_tpad]
   int cross_tpad = 0;
+  // fp16: the decode-step GEMMs read their activations as [hi | lo] rows (x to ~22 bits; profiles/r02_precision_*):
+  // the decode step is HBM / latency bound, the second MFMA per fragment is free, and the per-token log-probs move
+  // from ~2e-3 to ~3e-4 of the fp32 evaluation.  dh / dattn / dff rows are then twice as wide.
+  bool split_act = false;
   // decoder workspaces
   float* dx = nullptr;        // f32 [R][d]
   void* dh = nullptr;         // T   [R][d]
@@ -309,17 +314,18 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   const wj_whisper_dims& d = m->d;
   const int D = d.n_text_state, H = d.n_text_head, dt = m->dtype;
   const int win0 = row0 / beam;
+  const int split = m->split_act ? 1 : 0, sm = split ? 2 : 1;   // activation rows [hi | lo] for the decode GEMMs
   float* dx = m->dx + (int64_t)row0 * D;
-  void* dh = m->at(m->dh, (int64_t)row0 * D);
+  void* dh = m->at(m->dh, (int64_t)row0 * D * sm);
   void* dq = m->at(m->dq, (int64_t)row0 * D);
-  void* dattn = m->at(m->dattn, (int64_t)row0 * D);
-  void* dff = m->at(m->dff, (int64_t)row0 * 4 * D);
+  void* dattn = m->at(m->dattn, (int64_t)row0 * D * sm);
+  void* dff = m->at(m->dff, (int64_t)row0 * 4 * D * sm);
   const int64_t self_row = (int64_t)H * d.n_text_ctx * 64;      // cache elements per row
   const int64_t cross_win = (int64_t)H * d.n_audio_ctx * 64;    // cross K (or V) elements per window
   // Residual-writing GEMMs (attention out-projections, fc2) can run split-K: each K slice writes a raw fp32
   // slab and the LayerNorm that always follows folds  x += bias + sum(slabs)  in a fixed order (deterministic).
   // This keeps the per-workgroup A traffic at M*K/ksplit and multiplies the number of workgroups streaming W.
-  const bool rows = dt == WJ_BF16 && g_tune.dec_rows && R <= g_tune.dec_rows_max_m;
+  const bool rows = is16(dt) && g_tune.dec_rows && R <= g_tune.dec_rows_max_m;
   const int ks_attn = rows ? g_tune.dec_rows_ks_attn : g_tune.dec_ks_attn;
   const int ks_fc2 = rows ? g_tune.dec_rows_ks_fc2 : g_tune.dec_ks_fc2, tile_min_m = g_tune.dec_tile_min_m;
   const int ms = g_tune.dec_ms_stages;
@@ -329,8 +335,8 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   const float* pend_bias = nullptr;
   auto resid_gemm = [&](int tag, const void* A, int K, const void* W, const float* bias, int ks) -> int {
     GemmArgs g;
-    g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = R; g.N = D; g.K = K; g.ldc = D;
-    if (dt == WJ_BF16 && ks > 1 && ks <= kDecKsMax && K % (64 * ks) == 0) {
+    g.A = A; g.lda = (int64_t)K * sm; g.split = split; g.W = W; g.ldw = K; g.M = R; g.N = D; g.K = K; g.ldc = D;
+    if (is16(dt) && ks > 1 && ks <= kDecKsMax && K % (64 * ks) == 0) {
       g.out = slab; g.ksplit = ks;
       pend_ks = ks; pend_bias = bias;
       const int variant = rows ? 5 : ((tile_min_m > 0 && R >= tile_min_m) ? tile_variant : 2);
@@ -350,10 +356,10 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     if (deferred) *deferred = 0;
     if (rows) {
       PROF(tag, launch_gemm(dt, epi, g, s, 5));
-    } else if (dt == WJ_BF16 && ks > 1 && R >= g_tune.dec_proj_min_m && (int64_t)ks * g.N <= (int64_t)kDecKsMax * D &&
+    } else if (is16(dt) && ks > 1 && R >= g_tune.dec_proj_min_m && (int64_t)ks * g.N <= (int64_t)kDecKsMax * D &&
         g.K % (64 * ks) == 0 && !pend_ks) {
       GemmArgs p = g;
-      p.out = slab; p.ldc = g.N; p.ksplit = ks; p.bias = nullptr;
+      p.out = slab; p.ldc = g.N; p.ksplit = ks; p.bias = nullptr; p.split_out = 0;
       PROF(tag, launch_gemm(dt, EPI_PARTIAL_F32, p, s, tile_variant));
       if (deferred && g_tune.dec_fuse_reduce) *deferred = ks;
       else PROF(tag, launch_splitk_reduce(dt, epi, g, slab, ks, s));
@@ -366,9 +372,9 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     if (pend_ks) {
       const int ks = pend_ks;
       pend_ks = 0;
-      PROF(PT_D_LN, launch_layernorm_resid(dt, dx, slab, ks, pend_bias, w, b, dh, R, D, s));
+      PROF(PT_D_LN, launch_layernorm_resid(dt, dx, slab, ks, pend_bias, w, b, dh, R, D, s, split));
     } else {
-      PROF(PT_D_LN, launch_layernorm(dt, dx, w, b, dh, R, D, s));
+      PROF(PT_D_LN, launch_layernorm(dt, dx, w, b, dh, R, D, s, split));
     }
     return WJ_OK;
   };
@@ -383,7 +389,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     WJ_TRY(norm(m->F(b0 + WJ_TD_LN1_W), m->F(b0 + WJ_TD_LN1_B)));
     {
       GemmArgs g;
-      g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
+      g.A = dh; g.lda = (int64_t)D * sm; g.split = split; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
       g.M = R; g.N = 3 * D; g.K = D; g.out = dq;
       g.out2 = m->at(sk, row0 * self_row); g.out3 = m->at(sv, row0 * self_row);
       g.D = D; g.H = H; g.pos_ptr = pos; g.cache_len = d.n_text_ctx;
@@ -392,7 +398,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     }
     {
       DecAttnArgs a;   // K/V bases stay absolute: the row map holds absolute physical rows
-      a.q = dq; a.K = sk; a.V = sv; a.out = dattn; a.G = R; a.nb = 1; a.H = H;
+      a.q = dq; a.K = sk; a.V = sv; a.out = dattn; a.out_split = split; a.G = R; a.nb = 1; a.H = H;
       a.n_keys_ptr = pos; a.kv_stride = d.n_text_ctx;
       a.row_map = m->row_map[m->cur_map] + (int64_t)row0 * d.n_text_ctx;
       if (qkv_slices) {   // the attention kernel sums the K-slices, appends k/v to the cache and attends
@@ -404,7 +410,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     WJ_TRY(norm(m->F(b0 + WJ_TD_LNX_W), m->F(b0 + WJ_TD_LNX_B)));
     {
       GemmArgs g;
-      g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
+      g.A = dh; g.lda = (int64_t)D * sm; g.split = split; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
       g.M = R; g.N = D; g.K = D; g.out = dq; g.ldc = D;
       WJ_TRY(proj_gemm(PT_D_CQ, EPI_T, g, m->cross_tpad > 0 ? &cq_slices : nullptr));
       cq_bias = g.bias;
@@ -427,15 +433,15 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
         a.V = m->at(m->cross_v, l * m->cross_layer_elems() + woff);
       }
       a.group_of = m->use_slots ? m->slot_map + win0 : nullptr;
-      a.out = dattn; a.G = n_windows; a.nb = beam; a.H = H; a.n_keys = d.n_audio_ctx; a.kv_stride = d.n_audio_ctx;
+      a.out = dattn; a.out_split = split; a.G = n_windows; a.nb = beam; a.H = H; a.n_keys = d.n_audio_ctx; a.kv_stride = d.n_audio_ctx;
       PROF(PT_D_CROSS, launch_attention_dec(dt, a, s));
     }
     WJ_TRY(resid_gemm(PT_D_COUT, dattn, D, m->W(b0 + WJ_TD_COUT_W), m->F(b0 + WJ_TD_COUT_B), ks_attn));
     WJ_TRY(norm(m->F(b0 + WJ_TD_LN2_W), m->F(b0 + WJ_TD_LN2_B)));
     {
       GemmArgs g;
-      g.A = dh; g.lda = D; g.W = m->W(b0 + WJ_TD_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_FC1_B);
-      g.M = R; g.N = 4 * D; g.K = D; g.out = dff; g.ldc = 4 * D;
+      g.A = dh; g.lda = (int64_t)D * sm; g.split = split; g.W = m->W(b0 + WJ_TD_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_FC1_B);
+      g.M = R; g.N = 4 * D; g.K = D; g.out = dff; g.ldc = (int64_t)4 * D * sm; g.split_out = split;
       WJ_TRY(proj_gemm(PT_D_FC1, EPI_GELU_T, g));
     }
     WJ_TRY(resid_gemm(PT_D_FC2, dff, 4 * D, m->W(b0 + WJ_TD_FC2_W), m->F(b0 + WJ_TD_FC2_B), ks_fc2));
@@ -443,9 +449,9 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   if (want_logits) {
     WJ_TRY(norm(m->F(WJ_T_DEC_LN_W), m->F(WJ_T_DEC_LN_B)));
     GemmArgs g;
-    g.A = dh; g.lda = D; g.W = m->W(WJ_T_DEC_TOK_EMB); g.ldw = D;
+    g.A = dh; g.lda = (int64_t)D * sm; g.split = split; g.W = m->W(WJ_T_DEC_TOK_EMB); g.ldw = D;
     g.M = R; g.N = d.n_vocab; g.K = D; g.out = m->logits + (int64_t)row0 * m->ldl; g.ldc = m->ldl;
-    const bool big_m = dt == WJ_BF16 && tile_min_m > 0 && R >= tile_min_m;
+    const bool big_m = is16(dt) && tile_min_m > 0 && R >= tile_min_m;
     PROF(PT_D_LOGITS, launch_gemm(dt, EPI_F32, g, s, rows ? 5 : (big_m ? tile_variant : 0)));
   }
   return WJ_OK;
@@ -535,6 +541,15 @@ static int run_decoder_seq(wj_whisper* m, int B, int Tp, int n0, const int32_t* 
     WJ_TRY(launch_align_token_prob_seq(m->logits, m->ldl, eot, m->tokens, m->tok_stride, r0, rows, Tp, n0, d_ntok, d_prob, s));
   }
   return WJ_OK;
+}
+
+template <typename T>
+__global__ void split_rows_kernel(const float* __restrict__ in, T* __restrict__ out, int64_t M, int K) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M * K; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / K;
+    const int k = (int)(i % K);
+    st_split<T>(out + m * 2 * K + k, K, in[i]);
+  }
 }
 
 __global__ void init_rows_kernel(int32_t* map0, int32_t* map1, int R, int stride) {
@@ -658,6 +673,7 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_ks_proj")) g_tune.dec_ks_proj = value;
   else if (!strcmp(key, "dec_proj_min_m")) g_tune.dec_proj_min_m = value;
   else if (!strcmp(key, "dec_cross_mfma")) g_tune.dec_cross_mfma = value;
+  else if (!strcmp(key, "dec_split_act")) g_tune.dec_split_act = value;
   else if (!strcmp(key, "gemm_big")) g_gemm_big = value;
   else if (!strcmp(key, "dec_ms_stages")) g_tune.dec_ms_stages = value;
   else if (!strcmp(key, "dec_tile_reg")) g_tune.dec_tile_reg = value;
@@ -698,7 +714,7 @@ int wj_whisper_free(wj_whisper* m) {
 int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const void* blob_dev, int64_t blob_bytes,
                       const int64_t* offsets_host, int n_offsets, int max_batch, int max_rows, wj_whisper** out) {
   WJ_REQUIRE(ctx && dims && blob_dev && offsets_host && out, "wj_whisper_create: NULL argument");
-  WJ_REQUIRE(dtype == WJ_F32 || dtype == WJ_BF16, "wj_whisper_create: dtype must be WJ_F32 or WJ_BF16");
+  WJ_REQUIRE(dtype == WJ_F32 || dtype == WJ_BF16 || dtype == WJ_F16, "wj_whisper_create: dtype must be WJ_F32, WJ_BF16 or WJ_F16");
   const wj_whisper_dims& d = *dims;
   WJ_REQUIRE(d.n_audio_state == d.n_text_state && d.n_audio_head == d.n_text_head,
              "wj_whisper_create: encoder/decoder width mismatch");
@@ -719,7 +735,7 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   m->ctx = ctx;
   m->d = d;
   m->dtype = dtype;
-  m->esz = dtype == WJ_BF16 ? 2 : 4;
+  m->esz = dtype_size(dtype);
   m->blob = reinterpret_cast<const char*>(blob_dev);
   m->off.assign(offsets_host, offsets_host + n_offsets);
   m->max_batch = max_batch;
@@ -739,13 +755,15 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   WJ_ALLOC(attn, B * T * D * e, false);
   WJ_ALLOC(ff, B * T * 4 * D * e, false);
   WJ_ALLOC(cross_k, (size_t)d.n_text_layer * m->cross_layer_elems() * e, false);
-  m->cross_tpad = (dtype == WJ_BF16 && g_tune.dec_cross_mfma) ? (d.n_audio_ctx + 31) / 32 * 32 : 0;
+  m->cross_tpad = (is16(dtype) && g_tune.dec_cross_mfma) ? (d.n_audio_ctx + 31) / 32 * 32 : 0;
   WJ_ALLOC(cross_v, (size_t)d.n_text_layer * m->cross_v_layer_elems() * e, true);   // pad keys stay zero forever
   WJ_ALLOC(dx, R * D * sizeof(float), false);
-  WJ_ALLOC(dh, R * D * e, false);
+  m->split_act = dtype == WJ_F16 && g_tune.dec_split_act != 0;
+  const size_t sm = m->split_act ? 2 : 1;
+  WJ_ALLOC(dh, R * D * e * sm, false);
   WJ_ALLOC(dq, R * D * e, false);
-  WJ_ALLOC(dattn, R * D * e, false);
-  WJ_ALLOC(dff, R * 4 * D * e, false);
+  WJ_ALLOC(dattn, R * D * e * sm, false);
+  WJ_ALLOC(dff, R * 4 * D * e * sm, false);
   WJ_ALLOC(partial, R * (size_t)kDecKsMax * D * sizeof(float), false);
   m->ldl = (d.n_vocab + 63) / 64 * 64;
   WJ_ALLOC(logits, R * m->ldl * sizeof(float), false);
@@ -1213,7 +1231,7 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
   m->dump_qk = qk; m->dump_nsel = n_heads; m->dump_tmax = T;
   struct Guard { wj_whisper* m; ~Guard() { m->dump_qk = nullptr; m->use_slots = false; } } guard{m};
   if (prefill) {
-    const int nb = m->dtype == WJ_BF16 && m->cross_tpad > 0 ? 16 : 8;     // query rows of a window per cross-attention workgroup
+    const int nb = is16(m->dtype) && m->cross_tpad > 0 ? 16 : 8;     // query rows of a window per cross-attention workgroup
     const int chunks = T / nb;
     std::vector<int32_t> groups((size_t)batch * chunks);
     for (int b = 0; b < batch; ++b)
@@ -1326,6 +1344,25 @@ int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, cons
   return launch_gemm(dtype, e, g, ctx->pick(stream), variant);
 }
 
+int wj_k_gemm_split(wj_ctx* ctx, int dtype, const float* a_f32_dev, const void* w_dev, const float* bias_dev, float* c_dev,
+                    int M, int N, int K, int variant, void* stream) {
+  WJ_REQUIRE(ctx && a_f32_dev && w_dev && c_dev, "wj_k_gemm_split: NULL argument");
+  WJ_REQUIRE(is16(dtype) && M >= 1 && N >= 1 && K >= 64, "wj_k_gemm_split: 16-bit dtypes only");
+  WJ_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->pick(stream);
+  WJ_TRY(ctx->ensure_scratch((size_t)M * 2 * K * 2));
+  const unsigned blocks = (unsigned)std::min<int64_t>(4096, ceil_div64((int64_t)M * K, 256));
+  if (dtype == WJ_F16)
+    hipLaunchKernelGGL(split_rows_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, a_f32_dev, (f16_t*)ctx->scratch, (int64_t)M, K);
+  else
+    hipLaunchKernelGGL(split_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a_f32_dev, (bf16_t*)ctx->scratch, (int64_t)M, K);
+  WJ_LAUNCH_CHECK();
+  GemmArgs g;
+  g.A = ctx->scratch; g.lda = 2 * (int64_t)K; g.split = 1; g.W = w_dev; g.ldw = K; g.bias = bias_dev;
+  g.M = M; g.N = N; g.K = K; g.out = c_dev; g.ldc = N;
+  return launch_gemm(dtype, EPI_F32, g, s, variant);
+}
+
 int wj_k_gemm_timed(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev,
                     int M, int N, int K, int act_gelu, int out_f32, int variant, int reps, float* ms_per_launch) {
   WJ_REQUIRE(ctx && a_dev && w_dev && c_dev && ms_per_launch && reps >= 1, "wj_k_gemm_timed: bad arguments");
@@ -1363,7 +1400,7 @@ int wj_k_layernorm(wj_ctx* ctx, int dtype, const float* x_dev, const float* w_de
 
 }  // extern "C"
 
-// helpers for the attention test entry points --------------------------------------------------------
+// helpers for the test entry points ------------------------------------------------------------------
 template <typename T>
 __global__ void qkv_split_kernel(const float* __restrict__ qkv, T* __restrict__ Q, T* __restrict__ K, T* __restrict__ Vt,
                                  int Tn, int Tpad, int H) {
@@ -1377,6 +1414,18 @@ __global__ void qkv_split_kernel(const float* __restrict__ qkv, T* __restrict__ 
     Elem<T>::st(Vt + (bh * 64 + dd) * Tpad + t, row[2 * D + c]);
   }
 }
+// float32 [G][H][n_keys][64] -> bf16 [G][H][64][kp] (pad columns are left as they are: the caller zeroes them)
+template <typename T>
+__global__ void v_transpose_h_kernel(const float* in, T* out, int64_t n, int n_keys, int kp) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int dd = (int)(i & 63);
+    const int64_t t = i >> 6;
+    const int key = (int)(t % n_keys);
+    const int64_t gh = t / n_keys;
+    Elem<T>::st(out + (gh * 64 + dd) * kp + key, in[i]);
+  }
+}
+
 template <typename T>
 __global__ void T_to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = Elem<T>::ld(in + i);
@@ -1389,7 +1438,7 @@ int wj_k_attention_enc(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, void* o
   WJ_HIP(hipSetDevice(ctx->device));
   hipStream_t s = ctx->pick(stream);
   const int Tpad = (T + 127) / 128 * 128;
-  const size_t esz = dtype == WJ_BF16 ? 2 : 4;
+  const size_t esz = dtype_size(dtype);
   const size_t one = align_up((size_t)B * H * Tpad * 64 * esz, 256);
   WJ_TRY(ctx->ensure_scratch(3 * one));
   char* base = reinterpret_cast<char*>(ctx->scratch);
@@ -1397,6 +1446,9 @@ int wj_k_attention_enc(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, void* o
   if (dtype == WJ_F32)
     hipLaunchKernelGGL(qkv_split_kernel<float>, dim3(T, B), dim3(256), 0, s, qkv_f32_dev, (float*)base, (float*)(base + one),
                        (float*)(base + 2 * one), T, Tpad, H);
+  else if (dtype == WJ_F16)
+    hipLaunchKernelGGL(qkv_split_kernel<f16_t>, dim3(T, B), dim3(256), 0, s, qkv_f32_dev, (f16_t*)base,
+                       (f16_t*)(base + one), (f16_t*)(base + 2 * one), T, Tpad, H);
   else
     hipLaunchKernelGGL(qkv_split_kernel<bf16_t>, dim3(T, B), dim3(256), 0, s, qkv_f32_dev, (bf16_t*)base,
                        (bf16_t*)(base + one), (bf16_t*)(base + 2 * one), T, Tpad, H);
@@ -1411,7 +1463,7 @@ int wj_k_attention_enc_timed(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, v
   if (rc) return rc;
   hipStream_t s = ctx->stream;
   const int Tpad = (T + 127) / 128 * 128;
-  const size_t esz = dtype == WJ_BF16 ? 2 : 4;
+  const size_t esz = dtype_size(dtype);
   const size_t one = align_up((size_t)B * H * Tpad * 64 * esz, 256);
   char* base = reinterpret_cast<char*>(ctx->scratch);
   hipEvent_t e0, e1;
@@ -1432,22 +1484,11 @@ int wj_k_attention_enc_timed(wj_ctx* ctx, int dtype, const float* qkv_f32_dev, v
   return WJ_OK;
 }
 
-// float32 [G][H][n_keys][64] -> bf16 [G][H][64][kp] (pad columns are left as they are: the caller zeroes them)
-__global__ void v_transpose_bf16_kernel(const float* in, bf16_t* out, int64_t n, int n_keys, int kp) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int dd = (int)(i & 63);
-    const int64_t t = i >> 6;
-    const int key = (int)(t % n_keys);
-    const int64_t gh = t / n_keys;
-    out[(gh * 64 + dd) * kp + key] = f2bf(in[i]);
-  }
-}
-
 static int attention_dec_common(wj_ctx* ctx, int dtype, const float* q_dev, const float* k_dev, const float* v_dev,
                                 float* out_dev, int G, int nb, int H, int n_keys, int layout, int reps, float* ms,
                                 hipStream_t s) {
-  const size_t esz = dtype == WJ_BF16 ? 2 : 4;
-  const bool vt = dtype == WJ_BF16 && layout != 1;   // the engine's bf16 layout: V transposed, MFMA kernel
+  const size_t esz = dtype_size(dtype);
+  const bool vt = is16(dtype) && layout != 1;   // the engine's 16-bit layout: V transposed, MFMA kernel
   const int kp = (n_keys + 31) / 32 * 32;
   const int64_t nq = (int64_t)G * nb * H * 64, nkv = (int64_t)G * H * n_keys * 64, nvt = (int64_t)G * H * 64 * kp;
   const size_t bq = align_up(nq * esz, 256), bk = align_up(nkv * esz, 256), bv = align_up((vt ? nvt : nkv) * esz, 256);
@@ -1458,8 +1499,12 @@ static int attention_dec_common(wj_ctx* ctx, int dtype, const float* q_dev, cons
   WJ_TRY(launch_f32_to_T(dtype, k_dev, tk, nkv, s));
   if (vt) {
     WJ_HIP(hipMemsetAsync(tv, 0, bv, s));
-    hipLaunchKernelGGL(v_transpose_bf16_kernel, dim3((unsigned)min((int64_t)4096, ceil_div64(nkv, 256))), dim3(256), 0, s,
-                       v_dev, reinterpret_cast<bf16_t*>(tv), nkv, n_keys, kp);
+    if (dtype == WJ_F16)
+      hipLaunchKernelGGL(v_transpose_h_kernel<f16_t>, dim3((unsigned)min((int64_t)4096, ceil_div64(nkv, 256))), dim3(256), 0, s,
+                         v_dev, reinterpret_cast<f16_t*>(tv), nkv, n_keys, kp);
+    else
+      hipLaunchKernelGGL(v_transpose_h_kernel<bf16_t>, dim3((unsigned)min((int64_t)4096, ceil_div64(nkv, 256))), dim3(256), 0, s,
+                         v_dev, reinterpret_cast<bf16_t*>(tv), nkv, n_keys, kp);
     WJ_LAUNCH_CHECK();
   } else {
     WJ_TRY(launch_f32_to_T(dtype, v_dev, tv, nkv, s));
@@ -1485,6 +1530,8 @@ static int attention_dec_common(wj_ctx* ctx, int dtype, const float* q_dev, cons
   const int blocks = (int)min((int64_t)1024, ceil_div64(nq, 256));
   if (dtype == WJ_F32)
     hipLaunchKernelGGL(T_to_f32_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)to, out_dev, nq);
+  else if (dtype == WJ_F16)
+    hipLaunchKernelGGL(T_to_f32_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, (const f16_t*)to, out_dev, nq);
   else
     hipLaunchKernelGGL(T_to_f32_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)to, out_dev, nq);
   WJ_LAUNCH_CHECK();

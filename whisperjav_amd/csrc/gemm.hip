@@ -22,9 +22,6 @@
 
 namespace wj {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
 // --------------------------------------------------------------------------------------------
 // epilogues
 // --------------------------------------------------------------------------------------------
@@ -51,7 +48,11 @@ __device__ __forceinline__ void epi_nm(const GemmArgs& g, int z, int m, int n, f
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = gelu_for<T>(v[j]);
       }
-      st4(reinterpret_cast<T*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n, v);
+      T* o = reinterpret_cast<T*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n;
+      if constexpr (sizeof(T) == 2) {
+        if (g.split_out) { st4_split<T>(o, g.N, v); return; }
+      }
+      st4(o, v);
     } else if constexpr (EPI == EPI_RESID_F32) {
       float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch +
                                             (int64_t)m * g.ldc + n);
@@ -113,8 +114,8 @@ __device__ __forceinline__ uint4 ldg16_pred(const void* p, bool pred) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * TBK + ((chunk ^ (row & 7)) << 3); }
 
-template <int EPI, bool GLDS>
-__global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
+template <typename T, int EPI, bool GLDS>
+__global__ __launch_bounds__(256) void gemm_h_tile_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * TBM * TBK];  // [buf][A|W][128][64] = 64 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -133,11 +134,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
   const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
   const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
   const int m0 = (first_m + in_group % gsz) * TBM, n0 = (in_group / gsz) * TBN;
-  // split-K (EPI_PARTIAL_F32): blockIdx.z selects a K slice instead of a batch entry
-  const int kslice = (EPI == EPI_PARTIAL_F32) ? g.K / g.ksplit : g.K;
+  // split-K (EPI_PARTIAL_F32): blockIdx.z selects a K slice instead of a batch entry.  Split activations
+  // (g.split, LDS-DMA path only): A rows are [hi | lo], the k loop runs over 2 K and W wraps at K.
+  const int ktot = g.split ? 2 * g.K : g.K;
+  const int kslice = (EPI == EPI_PARTIAL_F32) ? ktot / g.ksplit : ktot;
   const int64_t koff = (EPI == EPI_PARTIAL_F32) ? (int64_t)z * kslice : 0;
   const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + ((EPI == EPI_PARTIAL_F32) ? koff : (int64_t)z * g.a_batch);
-  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W) + koff;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W) + (g.split ? 0 : koff);
+  const int wwrap = g.split ? g.K : 0x7fffffff;      // W column of logical k (split): (koff + k) mod K
+  const int wbase = g.split ? (int)koff : 0;
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -179,8 +184,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
     const int r0 = (wave * 4 + q) * 8;                                                             \
     const int row = r0 + (lane >> 3);                                                              \
     const int c = (lane & 7) ^ (row & 7);                                                          \
+    int wk = wbase + (k0);                                                                         \
+    wk = wk >= wwrap ? wk - wwrap : wk;                                                            \
     const bf16_t* ga = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + (k0) + c * 8;                 \
-    const bf16_t* gw = W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + (k0) + c * 8;                 \
+    const bf16_t* gw = W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + wk + c * 8;                   \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,            \
         (__attribute__((address_space(3))) void*)(&lds[((buf) * 2 + 0) * TBM * TBK + r0 * TBK]), 16, 0, 0); \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,            \
@@ -205,26 +212,26 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
     const bf16_t* lb = &lds[(cur * 2 + 1) * TBM * TBK];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[4], wf[4];
+      typename Vec8<T>::type af[4], wf[4];
       const int ch = ks * 4 + (lane >> 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = wm * 64 + i * 16 + (lane & 15);
-        af[i] = *reinterpret_cast<const bf16x8_t*>(&la[swz(row, ch)]);
+        af[i] = *reinterpret_cast<const typename Vec8<T>::type*>(&la[swz(row, ch)]);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = wn * 64 + j * 16 + (lane & 15);
-        wf[j] = *reinterpret_cast<const bf16x8_t*>(&lb[swz(row, ch)]);
+        wf[j] = *reinterpret_cast<const typename Vec8<T>::type*>(&lb[swz(row, ch)]);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if constexpr (EPI == EPI_VT)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16(af[i], wf[j], acc[i][j]);
           else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
         }
     }
     if constexpr (GLDS) {
@@ -248,11 +255,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
       if constexpr (EPI == EPI_VT) {
         const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
         const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-        if (m < g.M && n < g.N) epi_vt<bf16_t>(g, z, m, n, v);
+        if (m < g.M && n < g.N) epi_vt<T>(g, z, m, n, v);
       } else {
         const int m = m0 + wm * 64 + i * 16 + (lane & 15);
         const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-        if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, z, m, n, v);
+        if (m < g.M && n < g.N) epi_nm<EPI, T>(g, z, m, n, v);
       }
     }
 }
@@ -266,8 +273,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_kernel(const GemmArgs g) {
 // --------------------------------------------------------------------------------------------
 constexpr int BBM = 256, BBN = 256;
 
-template <int EPI, int SCHED>
-__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
+template <typename T, int EPI, int SCHED>
+__global__ __launch_bounds__(512) void gemm_h_big_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds_big[];   // [buf][A|W][256][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
@@ -315,26 +322,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
     const bf16_t* lb = la + BBM * TBK;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[8], wf[4];
+      typename Vec8<T>::type af[8], wf[4];
       const int ch = ks * 4 + (lane >> 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = wn * 64 + j * 16 + (lane & 15);
-        wf[j] = *reinterpret_cast<const bf16x8_t*>(&lb[swz(row, ch)]);
+        wf[j] = *reinterpret_cast<const typename Vec8<T>::type*>(&lb[swz(row, ch)]);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = wm * 128 + i * 16 + (lane & 15);
-        af[i] = *reinterpret_cast<const bf16x8_t*>(&la[swz(row, ch)]);
+        af[i] = *reinterpret_cast<const typename Vec8<T>::type*>(&la[swz(row, ch)]);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if constexpr (EPI == EPI_VT)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16(af[i], wf[j], acc[i][j]);
           else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
         }
     }
     if constexpr (SCHED == 1) {
@@ -402,11 +409,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
       if constexpr (EPI == EPI_VT) {
         const int m = m0 + wm * 128 + i * 16 + (lane >> 4) * 4;
         const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-        if (m < g.M && n < g.N) epi_vt<bf16_t>(g, z, m, n, v);
+        if (m < g.M && n < g.N) epi_vt<T>(g, z, m, n, v);
       } else {
         const int m = m0 + wm * 128 + i * 16 + (lane & 15);
         const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-        if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, z, m, n, v);
+        if (m < g.M && n < g.N) epi_nm<EPI, T>(g, z, m, n, v);
       }
     }
 }
@@ -419,8 +426,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const GemmArgs g) {
 // wait before computing stage kt lets the younger stages stay outstanding (s_waitcnt vmcnt(8 * younger)).
 // One barrier per k-step.  NS * 32 KiB of LDS.
 // --------------------------------------------------------------------------------------------
-template <int EPI, int NS>
-__global__ __launch_bounds__(256) void gemm_bf16_tile_ms_kernel(const GemmArgs g) {
+template <typename T, int EPI, int NS>
+__global__ __launch_bounds__(256) void gemm_h_tile_ms_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds_ms[];   // [stage][A|W][128][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -433,10 +440,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_ms_kernel(const GemmArgs g
   const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
   const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
   const int m0 = (first_m + in_group % gsz) * TBM, n0 = (in_group / gsz) * TBN;
-  const int kslice = (EPI == EPI_PARTIAL_F32) ? g.K / g.ksplit : g.K;
+  const int ktot = g.split ? 2 * g.K : g.K;
+  const int kslice = (EPI == EPI_PARTIAL_F32) ? ktot / g.ksplit : ktot;
   const int64_t koff = (EPI == EPI_PARTIAL_F32) ? (int64_t)z * kslice : 0;
   const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + ((EPI == EPI_PARTIAL_F32) ? koff : (int64_t)z * g.a_batch);
-  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W) + koff;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W) + (g.split ? 0 : koff);
+  const int wwrap = g.split ? g.K : 0x7fffffff;
+  const int wbase = g.split ? (int)koff : 0;
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -451,8 +461,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_ms_kernel(const GemmArgs g
     const int r0 = (wave * 4 + q) * 8;                                                             \
     const int row = r0 + (lane >> 3);                                                              \
     const int c = (lane & 7) ^ (row & 7);                                                          \
+    int wk = wbase + (k0);                                                                         \
+    wk = wk >= wwrap ? wk - wwrap : wk;                                                            \
     const bf16_t* ga = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + (k0) + c * 8;                 \
-    const bf16_t* gw = W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + (k0) + c * 8;                 \
+    const bf16_t* gw = W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + wk + c * 8;                   \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,            \
         (__attribute__((address_space(3))) void*)(&lds_ms[(buf) * STAGE + r0 * TBK]), 16, 0, 0);   \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,            \
@@ -476,17 +488,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_ms_kernel(const GemmArgs g
     const bf16_t* lb = la + TBM * TBK;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[4], wf[4];
+      typename Vec8<T>::type af[4], wf[4];
       const int ch = ks * 4 + (lane >> 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(&la[swz(wm * 64 + i * 16 + (lane & 15), ch)]);
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const typename Vec8<T>::type*>(&la[swz(wm * 64 + i * 16 + (lane & 15), ch)]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(&lb[swz(wn * 64 + j * 16 + (lane & 15), ch)]);
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const typename Vec8<T>::type*>(&lb[swz(wn * 64 + j * 16 + (lane & 15), ch)]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
     }
   }
 #undef WJ_MS_STAGE
@@ -498,36 +510,39 @@ __global__ __launch_bounds__(256) void gemm_bf16_tile_ms_kernel(const GemmArgs g
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       const int m = m0 + wm * 64 + i * 16 + (lane & 15);
       const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-      if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, z, m, n, v);
+      if (m < g.M && n < g.N) epi_nm<EPI, T>(g, z, m, n, v);
     }
 }
 
-template <int EPI, int NS>
+template <typename T, int EPI, int NS>
 static int launch_ms_inst(const GemmArgs& a, hipStream_t s) {
   constexpr size_t smem = (size_t)NS * 2 * TBM * TBK * sizeof(bf16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_tile_ms_kernel<EPI, NS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_tile_ms_kernel<T, EPI, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(%d KiB LDS): %s", (int)(smem >> 10), hipGetErrorString(e)); return WJ_E_HIP; }
     attr_set = true;
   }
   dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), EPI == EPI_PARTIAL_F32 ? a.ksplit : a.nbatch);
-  hipLaunchKernelGGL((gemm_bf16_tile_ms_kernel<EPI, NS>), grid, dim3(256), smem, s, a);
+  hipLaunchKernelGGL((gemm_h_tile_ms_kernel<T, EPI, NS>), grid, dim3(256), smem, s, a);
   WJ_LAUNCH_CHECK();
   return WJ_OK;
 }
 
-template <int EPI>
+template <typename T, int EPI>
 static int launch_ms(const GemmArgs& a, hipStream_t s, int ns) {
   if constexpr (EPI == EPI_T || EPI == EPI_GELU_T || EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_DEC ||
                 EPI == EPI_PARTIAL_F32) {
     const int ks = EPI == EPI_PARTIAL_F32 ? a.ksplit : 1;
-    if (a.K % (TBK * ks)) { set_error("gemm: the multi-stage tile kernel needs K %% (64 * ksplit) == 0"); return WJ_E_INVALID; }
+    if ((a.split ? 2 * a.K : a.K) % (TBK * ks) || (a.split && a.K % TBK)) {
+      set_error("gemm: the multi-stage tile kernel needs K %% (64 * ksplit) == 0");
+      return WJ_E_INVALID;
+    }
     switch (ns) {
-      case 3: return launch_ms_inst<EPI, 3>(a, s);
-      case 5: return launch_ms_inst<EPI, 5>(a, s);
-      default: return launch_ms_inst<EPI, 4>(a, s);
+      case 3: return launch_ms_inst<T, EPI, 3>(a, s);
+      case 5: return launch_ms_inst<T, EPI, 5>(a, s);
+      default: return launch_ms_inst<T, EPI, 4>(a, s);
     }
   } else {
     set_error("gemm: the multi-stage tile kernel does not carry epilogue %d", (int)EPI);
@@ -537,7 +552,7 @@ static int launch_ms(const GemmArgs& a, hipStream_t s, int ns) {
 
 int g_gemm_big = 1;   // wj_tune("gemm_big"): 0 disables the 256-tile kernel, 2 selects its issue-order-hinted build
 
-template <int EPI>
+template <typename T, int EPI>
 static int launch_big(const GemmArgs& a, hipStream_t s) {
   if constexpr (EPI == EPI_PARTIAL_F32) {
     set_error("gemm: the 256-tile kernel has no split-K mode");
@@ -546,17 +561,17 @@ static int launch_big(const GemmArgs& a, hipStream_t s) {
     constexpr size_t smem = 2 * 2 * BBM * TBK * sizeof(bf16_t);   // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_big_kernel<EPI, 0>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_kernel<T, EPI, 0>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_big_kernel<EPI, 1>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_kernel<T, EPI, 1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(128 KiB LDS): %s", hipGetErrorString(e)); return WJ_E_HIP; }
       attr_set = true;
     }
     dim3 grid(ceil_div(a.N, BBN), ceil_div(a.M, BBM), a.nbatch);
-    if (g_gemm_big == 2) hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 1>), grid, dim3(512), smem, s, a);
-    else hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, 0>), grid, dim3(512), smem, s, a);
+    if (g_gemm_big == 2) hipLaunchKernelGGL((gemm_h_big_kernel<T, EPI, 1>), grid, dim3(512), smem, s, a);
+    else hipLaunchKernelGGL((gemm_h_big_kernel<T, EPI, 0>), grid, dim3(512), smem, s, a);
     WJ_LAUNCH_CHECK();
     return WJ_OK;
   }
@@ -565,8 +580,8 @@ static int launch_big(const GemmArgs& a, hipStream_t s) {
 // --------------------------------------------------------------------------------------------
 // bf16 MFMA, skinny (decode) kernel: 16 output columns per workgroup, 8 waves split K
 // --------------------------------------------------------------------------------------------
-template <int EPI, int MT>
-__global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(const GemmArgs g) {
+template <typename T, int EPI, int MT, bool SPLIT>
+__global__ __launch_bounds__(512) void gemm_h_skinny_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float red[8 * MT * 16 * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt0 = blockIdx.x * 16;
@@ -588,9 +603,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(const GemmArgs g)
     for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // UNR k-steps of W and A fragments are requested before the first MFMA of the group so that
     // each wave keeps several 1 KiB loads in flight (the kernel is latency / HBM bound, not MFMA bound)
-    constexpr int UNR = MT <= 2 ? 4 : (MT == 4 ? 3 : 2);
+    constexpr int UNR = SPLIT ? (MT <= 2 ? 2 : 1) : (MT <= 2 ? 4 : (MT == 4 ? 3 : 2));
     for (int ks0 = ks_begin; ks0 < ks_end; ks0 += UNR) {
-      uint4 wv[UNR], av[UNR][MT];
+      uint4 wv[UNR], av[UNR][MT], al[SPLIT ? UNR : 1][SPLIT ? MT : 1];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int k = (ks0 + u) * 32 + kq;
@@ -601,14 +616,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(const GemmArgs g)
         for (int t = 0; t < MT; ++t) {
           const int arow = mc + t * 16 + (lane & 15);
           av[u][t] = ldg16_pred(A + (int64_t)min(arow, g.M - 1) * g.lda + kc, kin && arow < g.M);
+          if constexpr (SPLIT)   // rounding residuals of the same activations: the second half of the row
+            al[u][t] = ldg16_pred(A + (int64_t)min(arow, g.M - 1) * g.lda + g.K + kc, kin && arow < g.M);
         }
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wv[u]);
+        const typename Vec8<T>::type wf = as_vec8<T>(wv[u]);
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, av[u][t]), acc[t], 0, 0, 0);
+        for (int t = 0; t < MT; ++t) {
+          acc[t] = mfma16(wf, as_vec8<T>(av[u][t]), acc[t]);
+          if constexpr (SPLIT) acc[t] = mfma16(wf, as_vec8<T>(al[u][t]), acc[t]);
+        }
       }
     }
     // partials -> LDS: red[wave][m_local][n_local]
@@ -627,7 +646,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(const GemmArgs g)
         v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
       }
       const int m = mc + mm, n = nt0 + q * 4;
-      if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, kz, m, n, v);
+      if (m < g.M && n < g.N) epi_nm<EPI, T>(g, kz, m, n, v);
     }
     __syncthreads();
   }
@@ -644,8 +663,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(const GemmArgs g)
 // number of launches, which is what this kernel minimises.  blockIdx.y = K slice (EPI_PARTIAL_F32),
 // blockIdx.z = group of 8 row blocks.
 // --------------------------------------------------------------------------------------------
-template <int EPI, int UNR>
-__global__ __launch_bounds__(512) void gemm_bf16_rows_kernel(const GemmArgs g) {
+template <typename T, int EPI, int UNR, bool SPLIT>
+__global__ __launch_bounds__(512) void gemm_h_rows_kernel(const GemmArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int n0 = blockIdx.x * 16;
@@ -658,7 +677,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_rows_kernel(const GemmArgs g) {
   const bf16_t* __restrict__ Wp = reinterpret_cast<const bf16_t*>(g.W) + (int64_t)min(n0 + li, g.N - 1) * g.ldw + lg * 8;
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = kb; k0 < ke; k0 += 64 * UNR) {
-    uint4 av[UNR][2], wv[UNR][2];
+    uint4 av[UNR][2], wv[UNR][2], al[SPLIT ? UNR : 1][2];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int k = min(k0 + 64 * u, ke - 64);     // clamped (never predicated); surplus steps are skipped below
@@ -666,23 +685,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_rows_kernel(const GemmArgs g) {
       wv[u][1] = *reinterpret_cast<const uint4*>(Wp + k + 32);
       av[u][0] = *reinterpret_cast<const uint4*>(Ap + k);
       av[u][1] = *reinterpret_cast<const uint4*>(Ap + k + 32);
+      if constexpr (SPLIT) {                       // rounding residuals: second half of the activation row
+        al[u][0] = *reinterpret_cast<const uint4*>(Ap + g.K + k);
+        al[u][1] = *reinterpret_cast<const uint4*>(Ap + g.K + k + 32);
+      }
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       if (k0 + 64 * u < ke) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[u][0]),
-                                                      __builtin_bit_cast(bf16x8_t, av[u][0]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[u][1]),
-                                                      __builtin_bit_cast(bf16x8_t, av[u][1]), acc, 0, 0, 0);
+        acc = mfma16(as_vec8<T>(wv[u][0]), as_vec8<T>(av[u][0]), acc);
+        acc = mfma16(as_vec8<T>(wv[u][1]), as_vec8<T>(av[u][1]), acc);
+        if constexpr (SPLIT) {
+          acc = mfma16(as_vec8<T>(wv[u][0]), as_vec8<T>(al[u][0]), acc);
+          acc = mfma16(as_vec8<T>(wv[u][1]), as_vec8<T>(al[u][1]), acc);
+        }
       }
     }
   }
   const int m = m0 + li, n = n0 + lg * 4;
   float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  if (m < g.M && n < g.N) epi_nm<EPI, bf16_t>(g, kz, m, n, v);
+  if (m < g.M && n < g.N) epi_nm<EPI, T>(g, kz, m, n, v);
 }
 
-template <int EPI>
+template <typename T, int EPI>
 static int launch_rows(const GemmArgs& a, hipStream_t s, int unr) {
   if constexpr (EPI == EPI_T || EPI == EPI_GELU_T || EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_DEC ||
                 EPI == EPI_PARTIAL_F32) {
@@ -693,15 +718,22 @@ static int launch_rows(const GemmArgs& a, hipStream_t s, int unr) {
     }
     const int steps = a.K / ks / 64;
     if (unr <= 0) unr = steps % 10 == 0 ? 10 : (steps % 5 == 0 ? 5 : (steps >= 8 ? 8 : 4));
+    if (a.split) unr = unr == 10 ? 5 : (unr == 8 ? 4 : unr);      // six 16-byte loads per k-step instead of four
     const dim3 grid(ceil_div(a.N, 16), ks, ceil_div(a.M, 128));
     const dim3 block(64 * min(8, ceil_div(a.M, 16)));
+#define WJ_ROWS(U)                                                                                        \
+  do {                                                                                                    \
+    if (a.split) hipLaunchKernelGGL((gemm_h_rows_kernel<T, EPI, U, true>), grid, block, 0, s, a);         \
+    else hipLaunchKernelGGL((gemm_h_rows_kernel<T, EPI, U, false>), grid, block, 0, s, a);                \
+  } while (0)
     switch (unr) {
-      case 4: hipLaunchKernelGGL((gemm_bf16_rows_kernel<EPI, 4>), grid, block, 0, s, a); break;
-      case 5: hipLaunchKernelGGL((gemm_bf16_rows_kernel<EPI, 5>), grid, block, 0, s, a); break;
-      case 8: hipLaunchKernelGGL((gemm_bf16_rows_kernel<EPI, 8>), grid, block, 0, s, a); break;
-      case 10: hipLaunchKernelGGL((gemm_bf16_rows_kernel<EPI, 10>), grid, block, 0, s, a); break;
+      case 4: WJ_ROWS(4); break;
+      case 5: WJ_ROWS(5); break;
+      case 8: WJ_ROWS(8); break;
+      case 10: WJ_ROWS(10); break;
       default: set_error("gemm: rows kernel unroll %d not instantiated (4, 5, 8, 10)", unr); return WJ_E_INVALID;
     }
+#undef WJ_ROWS
     WJ_LAUNCH_CHECK();
     return WJ_OK;
   } else {
@@ -795,6 +827,7 @@ static int launch_reduce_epi(int dtype, const GemmArgs& a, const float* slab, in
   const int64_t total = (int64_t)a.M * (a.N >> 2);
   dim3 grid((unsigned)ceil_div64(total, 256));
   if (dtype == WJ_F32) hipLaunchKernelGGL((splitk_reduce_kernel<EPI, float>), grid, dim3(256), 0, s, a, slab, ks);
+  else if (dtype == WJ_F16) hipLaunchKernelGGL((splitk_reduce_kernel<EPI, f16_t>), grid, dim3(256), 0, s, a, slab, ks);
   else hipLaunchKernelGGL((splitk_reduce_kernel<EPI, bf16_t>), grid, dim3(256), 0, s, a, slab, ks);
   WJ_LAUNCH_CHECK();
   return WJ_OK;
@@ -813,23 +846,10 @@ int launch_splitk_reduce(int dtype, Epi epi, const GemmArgs& a, const float* sla
 // --------------------------------------------------------------------------------------------
 // dispatch
 // --------------------------------------------------------------------------------------------
-template <int EPI>
-static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) {
-  if (EPI == EPI_PARTIAL_F32) {
-    if (dtype != WJ_BF16) { set_error("gemm: split-K partial output is a bf16-path feature"); return WJ_E_INVALID; }
-    if (a.ksplit < 1 || a.nbatch != 1 || (a.K % (32 * a.ksplit))) {
-      set_error("gemm: split-K needs nbatch == 1 and K %% (32 * ksplit) == 0 (K=%d ksplit=%d)", a.K, a.ksplit);
-      return WJ_E_INVALID;
-    }
-  }
-  if (dtype == WJ_F32) {
-    dim3 grid(ceil_div(a.N, 64), ceil_div(a.M, 64), a.nbatch);
-    hipLaunchKernelGGL(gemm_f32_kernel<EPI>, grid, dim3(256), 0, s, a);
-    WJ_LAUNCH_CHECK();
-    return WJ_OK;
-  }
-  if (variant == 5 || (variant >= 50 && variant < 70)) return launch_rows<EPI>(a, s, variant == 5 ? 0 : variant - 50);
-  if (variant == 7 || (variant >= 73 && variant <= 75)) return launch_ms<EPI>(a, s, variant == 7 ? 4 : variant - 70);
+template <typename T, int EPI>
+static int launch_epi16(const GemmArgs& a, hipStream_t s, int variant) {
+  if (variant == 5 || (variant >= 50 && variant < 70)) return launch_rows<T, EPI>(a, s, variant == 5 ? 0 : variant - 50);
+  if (variant == 7 || (variant >= 73 && variant <= 75)) return launch_ms<T, EPI>(a, s, variant == 7 ? 4 : variant - 70);
   const bool skinny_ok = (EPI != EPI_VT) && a.nbatch == 1;
   bool skinny = skinny_ok && a.M <= 512;
   if (variant == 1 || variant == 3 || variant == 4) skinny = false;
@@ -840,18 +860,24 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
   if (skinny) {
     if constexpr (EPI != EPI_VT) {
       dim3 grid(ceil_div(a.N, 16), EPI == EPI_PARTIAL_F32 ? a.ksplit : 1);
-      if (a.M <= 16) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, 1>), grid, dim3(512), 0, s, a);
-      else if (a.M <= 32) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, 2>), grid, dim3(512), 0, s, a);
-      else if (a.M <= 64) hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, 4>), grid, dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((gemm_bf16_skinny_kernel<EPI, 8>), grid, dim3(512), 0, s, a);
+#define WJ_SKINNY(MT)                                                                                     \
+  do {                                                                                                    \
+    if (a.split) hipLaunchKernelGGL((gemm_h_skinny_kernel<T, EPI, MT, true>), grid, dim3(512), 0, s, a);  \
+    else hipLaunchKernelGGL((gemm_h_skinny_kernel<T, EPI, MT, false>), grid, dim3(512), 0, s, a);         \
+  } while (0)
+      if (a.M <= 16) WJ_SKINNY(1);
+      else if (a.M <= 32) WJ_SKINNY(2);
+      else if (a.M <= 64) WJ_SKINNY(4);
+      else WJ_SKINNY(8);
+#undef WJ_SKINNY
       WJ_LAUNCH_CHECK();
     }
     return WJ_OK;
   }
   // big encoder GEMMs: 256-tile kernel (variant 6 forces it, 0 = auto when the shape qualifies)
-  const bool big_ok = EPI != EPI_PARTIAL_F32 && (a.N % BBN) == 0 && (a.K % TBK) == 0 && a.M >= 1024;
+  const bool big_ok = EPI != EPI_PARTIAL_F32 && (a.N % BBN) == 0 && (a.K % TBK) == 0 && a.M >= 1024 && !a.split;
   if (variant == 6 && !big_ok) { set_error("gemm: the 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, M >= 1024"); return WJ_E_INVALID; }
-  if (variant == 6 || ((variant == 0 || variant == 1) && g_gemm_big && big_ok)) return launch_big<EPI>(a, s);
+  if (variant == 6 || ((variant == 0 || variant == 1) && g_gemm_big && big_ok)) return launch_big<T, EPI>(a, s);
   dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), EPI == EPI_PARTIAL_F32 ? a.ksplit : a.nbatch);
   static const int tile_mode = [] {   // WJ_GEMM_TILE=reg|glds overrides the default staging path
     const char* e = getenv("WJ_GEMM_TILE");
@@ -859,17 +885,38 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
     if (e && !strcmp(e, "glds")) return 2;
     return 0;
   }();
-  const int kchunk = EPI == EPI_PARTIAL_F32 ? a.K / a.ksplit : a.K;
-  bool glds = (kchunk % TBK) == 0 && (variant == 3 || (variant != 4 && tile_mode != 1));
+  const int ktot = a.split ? 2 * a.K : a.K;
+  const int kchunk = EPI == EPI_PARTIAL_F32 ? ktot / a.ksplit : ktot;
+  bool glds = (kchunk % TBK) == 0 && (a.K % TBK) == 0 && (variant == 3 || (variant != 4 && tile_mode != 1));
   if (variant == 3 && (a.K % TBK)) { set_error("gemm: the LDS-DMA tile kernel needs K %% 64 == 0"); return WJ_E_INVALID; }
-  if (glds) hipLaunchKernelGGL((gemm_bf16_tile_kernel<EPI, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemm_bf16_tile_kernel<EPI, false>), grid, dim3(256), 0, s, a);
+  if (a.split && !glds) { set_error("gemm: split activations need the LDS-DMA tile kernel (K %% 64 == 0)"); return WJ_E_INVALID; }
+  if (glds) hipLaunchKernelGGL((gemm_h_tile_kernel<T, EPI, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_h_tile_kernel<T, EPI, false>), grid, dim3(256), 0, s, a);
   WJ_LAUNCH_CHECK();
   return WJ_OK;
 }
 
+template <int EPI>
+static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) {
+  if (EPI == EPI_PARTIAL_F32) {
+    if (!is16(dtype)) { set_error("gemm: split-K partial output is a 16-bit-path feature"); return WJ_E_INVALID; }
+    if (a.ksplit < 1 || a.nbatch != 1 || ((a.split ? 2 * a.K : a.K) % (32 * a.ksplit))) {
+      set_error("gemm: split-K needs nbatch == 1 and K %% (32 * ksplit) == 0 (K=%d ksplit=%d)", a.K, a.ksplit);
+      return WJ_E_INVALID;
+    }
+  }
+  if (dtype == WJ_F32) {
+    dim3 grid(ceil_div(a.N, 64), ceil_div(a.M, 64), a.nbatch);
+    hipLaunchKernelGGL(gemm_f32_kernel<EPI>, grid, dim3(256), 0, s, a);
+    WJ_LAUNCH_CHECK();
+    return WJ_OK;
+  }
+  if (dtype == WJ_F16) return launch_epi16<f16_t, EPI>(a, s, variant);
+  return launch_epi16<bf16_t, EPI>(a, s, variant);
+}
+
 int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int variant) {
-  const int kalign = dtype == WJ_BF16 ? 8 : 4;
+  const int kalign = is16(dtype) ? 8 : 4;
   if (a.K % kalign || a.lda % kalign || a.ldw % kalign || a.a_batch % kalign) {
     set_error("gemm: K/lda/ldw/a_batch must be multiples of %d elements (K=%d lda=%lld ldw=%lld)", kalign, a.K,
               (long long)a.lda, (long long)a.ldw);
@@ -877,7 +924,16 @@ int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int varian
   }
   if (epi != EPI_F32 && (a.N % 4)) { set_error("gemm: N must be a multiple of 4 for this epilogue"); return WJ_E_INVALID; }
   if (epi == EPI_VT && (a.M % 4)) { set_error("gemm: M must be a multiple of 4 for EPI_VT"); return WJ_E_INVALID; }
+  if (a.split && (!is16(dtype) || a.lda < 2 * (int64_t)a.K || a.nbatch != 1)) {
+    set_error("gemm: split activations are a 16-bit single-batch feature with lda >= 2 K");
+    return WJ_E_INVALID;
+  }
+  if (a.split_out && (!is16(dtype) || (epi != EPI_T && epi != EPI_GELU_T) || a.ldc < 2 * (int64_t)a.N)) {
+    set_error("gemm: split_out needs a 16-bit EPI_T / EPI_GELU_T output with ldc >= 2 N");
+    return WJ_E_INVALID;
+  }
   if (a.M <= 0 || a.N <= 0) return WJ_OK;
+  if (dtype != WJ_F32 && dtype != WJ_BF16 && dtype != WJ_F16) { set_error("gemm: unknown dtype %d", dtype); return WJ_E_INVALID; }
   switch (epi) {
     case EPI_T: return launch_epi<EPI_T>(dtype, a, s, variant);
     case EPI_GELU_T: return launch_epi<EPI_GELU_T>(dtype, a, s, variant);

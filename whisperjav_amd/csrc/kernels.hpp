@@ -37,6 +37,12 @@ struct GemmArgs {
   int cache_len = 0;
   int ksplit = 1;               // EPI_PARTIAL_F32: K is cut into ksplit slices (grid.z resp. grid.y)
   int seq_tp = 0;               // EPI_QKV_DEC, > 0: row m is position m % seq_tp of cache row m / seq_tp (full-sequence pass)
+  // Split activations (16-bit decode GEMMs, wj_tune "dec_split_act"): row m of A holds [hi(K) | lo(K)] with
+  // hi = T(x), lo = T(x - hi), i.e. x to ~22 bits; C = W.hi + W.lo in the same fp32 accumulator.  lda >= 2 K.
+  int split = 0;
+  // EPI_T / EPI_GELU_T: also store the rounding residual of the output at column offset N of the same row
+  // (the consumer GEMM reads it as a split activation; ldc >= 2 N)
+  int split_out = 0;
 };
 
 // variant: 0 = auto; 1 = tiled MFMA kernel (default staging); 2 = skinny (decode) kernel;
@@ -48,12 +54,13 @@ int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int varian
 int launch_splitk_reduce(int dtype, Epi epi, const GemmArgs& a, const float* slab, int ks, hipStream_t s);
 
 // ---------------- normalisation / elementwise ------------------------------------------------
+// split != 0 (16-bit types): out rows are [hi(D) | lo(D)] (row stride 2 D), see GemmArgs::split
 int launch_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, int M, int D,
-                     hipStream_t s);
+                     hipStream_t s, int split = 0);
 // residual update fused with LayerNorm: x[m][:] += bias + sum_s partial[s][m][:]  (fixed order -> deterministic),
 // then out = LayerNorm(x).  Consumer side of the split-K decode GEMMs.
 int launch_layernorm_resid(int dtype, float* x, const float* partial, int ksplit, const float* bias, const float* w,
-                           const float* b, void* out, int M, int D, hipStream_t s);
+                           const float* b, void* out, int M, int D, hipStream_t s, int split = 0);
 // mel f32 [B][n_mels][frames] -> engine layout T [B][frames+2][n_mels] (row 0 and frames+1 stay zero)
 int launch_mel_to_rows(int dtype, const float* mel, void* out, int B, int n_mels, int frames, hipStream_t s);
 // decoder embedding: x[r][:] = tok_emb[token[r]][:] + pos_emb[*pos][:]
@@ -100,6 +107,8 @@ struct DecAttnArgs {
   // row g / seq_tp and sees keys 0..position.  Cross attention dump: dump_chunks > 0 -> group g is chunk
   // g % dump_chunks of window g / dump_chunks, query b of it is position chunk * nb + b.
   int seq_tp = 0, dump_chunks = 0;
+  // out_split != 0 (16-bit types): output rows are [hi(D) | lo(D)] (row stride 2 D) for a split-activation GEMM
+  int out_split = 0;
 };
 extern int g_dec_cross_u;
 extern int g_dec_cross_nt;

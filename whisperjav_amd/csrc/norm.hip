@@ -11,7 +11,7 @@ namespace wj {
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, T* __restrict__ out, int M,
-                                                        int D) {
+                                                        int D, int split) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -35,25 +35,33 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     q += d * d;
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
-  T* o = out + (int64_t)row * D;
+  T* o = out + (int64_t)row * D * (split ? 2 : 1);     // split: [hi(D) | lo(D)] per row (GemmArgs::split)
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + i * 64;
-    if (c < D) Elem<T>::st(o + c, (v[i] - mean) * rstd * g[i] + be[i]);
+    if (c < D) {
+      const float y = (v[i] - mean) * rstd * g[i] + be[i];
+      if constexpr (sizeof(T) == 2) {
+        if (split) { st_split<T>(o + c, D, y); continue; }
+      }
+      Elem<T>::st(o + c, y);
+    }
   }
 }
 
 int launch_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, int M, int D,
-                     hipStream_t s) {
+                     hipStream_t s, int split) {
   if (D > 64 * 20 || D <= 0) { set_error("layernorm: D=%d unsupported (max 1280)", D); return WJ_E_INVALID; }
   if (M <= 0) return WJ_OK;
   dim3 grid(ceil_div(M, 4));
 #define WJ_LN(NV)                                                                                          \
   do {                                                                                                     \
     if (dtype == WJ_F32)                                                                                   \
-      hipLaunchKernelGGL((layernorm_kernel<float, NV>), grid, dim3(256), 0, s, x, w, b, (float*)out, M, D); \
+      hipLaunchKernelGGL((layernorm_kernel<float, NV>), grid, dim3(256), 0, s, x, w, b, (float*)out, M, D, 0); \
+    else if (dtype == WJ_F16)                                                                              \
+      hipLaunchKernelGGL((layernorm_kernel<f16_t, NV>), grid, dim3(256), 0, s, x, w, b, (f16_t*)out, M, D, split); \
     else                                                                                                   \
-      hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), grid, dim3(256), 0, s, x, w, b, (bf16_t*)out, M, D); \
+      hipLaunchKernelGGL((layernorm_kernel<bf16_t, NV>), grid, dim3(256), 0, s, x, w, b, (bf16_t*)out, M, D, split); \
   } while (0)
   if (D <= 64 * 6) WJ_LN(6);
   else if (D <= 64 * 12) WJ_LN(12);
@@ -67,7 +75,7 @@ template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_resid_kernel(float* __restrict__ x, const float* __restrict__ partial,
                                                               int ksplit, const float* __restrict__ bias,
                                                               const float* __restrict__ w, const float* __restrict__ b,
-                                                              T* __restrict__ out, int M, int D) {
+                                                              T* __restrict__ out, int M, int D, int split) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -100,16 +108,22 @@ __global__ __launch_bounds__(256) void layernorm_resid_kernel(float* __restrict_
     q += d * d;
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
-  T* o = out + (int64_t)row * D;
+  T* o = out + (int64_t)row * D * (split ? 2 : 1);     // split: [hi(D) | lo(D)] per row (GemmArgs::split)
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + i * 64;
-    if (c < D) Elem<T>::st(o + c, (v[i] - mean) * rstd * g[i] + be[i]);
+    if (c < D) {
+      const float y = (v[i] - mean) * rstd * g[i] + be[i];
+      if constexpr (sizeof(T) == 2) {
+        if (split) { st_split<T>(o + c, D, y); continue; }
+      }
+      Elem<T>::st(o + c, y);
+    }
   }
 }
 
 int launch_layernorm_resid(int dtype, float* x, const float* partial, int ksplit, const float* bias, const float* w,
-                           const float* b, void* out, int M, int D, hipStream_t s) {
+                           const float* b, void* out, int M, int D, hipStream_t s, int split) {
   if (D > 64 * 20 || D <= 0) { set_error("layernorm: D=%d unsupported (max 1280)", D); return WJ_E_INVALID; }
   if (M <= 0) return WJ_OK;
   dim3 grid(ceil_div(M, 4));
@@ -117,10 +131,13 @@ int launch_layernorm_resid(int dtype, float* x, const float* partial, int ksplit
   do {                                                                                                          \
     if (dtype == WJ_F32)                                                                                        \
       hipLaunchKernelGGL((layernorm_resid_kernel<float, NV>), grid, dim3(256), 0, s, x, partial, ksplit, bias, w, b, \
-                         (float*)out, M, D);                                                                    \
+                         (float*)out, M, D, 0);                                                                 \
+    else if (dtype == WJ_F16)                                                                                   \
+      hipLaunchKernelGGL((layernorm_resid_kernel<f16_t, NV>), grid, dim3(256), 0, s, x, partial, ksplit, bias, w, b, \
+                         (f16_t*)out, M, D, split);                                                             \
     else                                                                                                        \
       hipLaunchKernelGGL((layernorm_resid_kernel<bf16_t, NV>), grid, dim3(256), 0, s, x, partial, ksplit, bias, w, b, \
-                         (bf16_t*)out, M, D);                                                                   \
+                         (bf16_t*)out, M, D, split);                                                            \
   } while (0)
   if (D <= 64 * 6) WJ_LNR(6);
   else if (D <= 64 * 12) WJ_LNR(12);
@@ -153,6 +170,8 @@ int launch_mel_to_rows(int dtype, const float* mel, void* out, int B, int n_mels
   dim3 grid(ceil_div(frames, 32), ceil_div(n_mels, 32), B);
   if (dtype == WJ_F32)
     hipLaunchKernelGGL(mel_to_rows_kernel<float>, grid, dim3(256), 0, s, mel, (float*)out, n_mels, frames);
+  else if (dtype == WJ_F16)
+    hipLaunchKernelGGL(mel_to_rows_kernel<f16_t>, grid, dim3(256), 0, s, mel, (f16_t*)out, n_mels, frames);
   else
     hipLaunchKernelGGL(mel_to_rows_kernel<bf16_t>, grid, dim3(256), 0, s, mel, (bf16_t*)out, n_mels, frames);
   WJ_LAUNCH_CHECK();
@@ -188,6 +207,9 @@ int launch_embed_seq(int dtype, const void* tok_emb, const float* pos_emb, const
   if (dtype == WJ_F32)
     hipLaunchKernelGGL(embed_seq_kernel<float>, dim3(B * Tp), dim3(256), 0, s, (const float*)tok_emb, pos_emb, tokens,
                        tok_stride, Tp, x, D);
+  else if (dtype == WJ_F16)
+    hipLaunchKernelGGL(embed_seq_kernel<f16_t>, dim3(B * Tp), dim3(256), 0, s, (const f16_t*)tok_emb, pos_emb, tokens,
+                       tok_stride, Tp, x, D);
   else
     hipLaunchKernelGGL(embed_seq_kernel<bf16_t>, dim3(B * Tp), dim3(256), 0, s, (const bf16_t*)tok_emb, pos_emb, tokens,
                        tok_stride, Tp, x, D);
@@ -199,6 +221,9 @@ int launch_embed(int dtype, const void* tok_emb, const float* pos_emb, const int
                  const int* pos_ptr, float* x, int R, int D, hipStream_t s) {
   if (dtype == WJ_F32)
     hipLaunchKernelGGL(embed_kernel<float>, dim3(R), dim3(256), 0, s, (const float*)tok_emb, pos_emb, tokens,
+                       tok_stride, pos_ptr, x, D);
+  else if (dtype == WJ_F16)
+    hipLaunchKernelGGL(embed_kernel<f16_t>, dim3(R), dim3(256), 0, s, (const f16_t*)tok_emb, pos_emb, tokens,
                        tok_stride, pos_ptr, x, D);
   else
     hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(R), dim3(256), 0, s, (const bf16_t*)tok_emb, pos_emb, tokens,
@@ -218,6 +243,8 @@ int launch_f32_to_T(int dtype, const float* in, void* out, int64_t n, hipStream_
   const int blocks = (int)min((int64_t)4096, ceil_div64(n, 256));
   if (dtype == WJ_F32)
     hipLaunchKernelGGL(f32_to_T_kernel<float>, dim3(blocks), dim3(256), 0, s, in, (float*)out, n);
+  else if (dtype == WJ_F16)
+    hipLaunchKernelGGL(f32_to_T_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, in, (f16_t*)out, n);
   else
     hipLaunchKernelGGL(f32_to_T_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, in, (bf16_t*)out, n);
   WJ_LAUNCH_CHECK();

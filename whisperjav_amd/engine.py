@@ -20,6 +20,7 @@ from .hipbind import DTYPES, WJ_MEL_FW, WJ_MEL_OW, check
 
 N_FRAMES = 3000
 MEL_MODES = {"fw": WJ_MEL_FW, "ow": WJ_MEL_OW}
+TORCH_DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}
 
 
 def _require_gpu(device: int) -> torch.device:
@@ -381,7 +382,7 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype
     """C = A @ W^T (+bias); a [M,K], w [N,K] float32 CUDA tensors, converted to ``dtype`` first."""
     ctx = hipbind.context(device)
     lib = hipbind.lib()
-    td = torch.bfloat16 if dtype == "bfloat16" else torch.float32
+    td = TORCH_DTYPES[dtype]
     A, Wt = a.to(td).contiguous(), w.to(td).contiguous()
     M, K = A.shape
     N = Wt.shape[0]
@@ -393,12 +394,29 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype
     return out.float()
 
 
+def k_gemm_split(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: str, variant=0,
+                 device: int = 0) -> torch.Tensor:
+    """C = A @ W^T (+bias) with A (float32 CUDA [M,K]) entering the matrix cores as hi + lo 16-bit pairs and W in
+    ``dtype`` -- the decode-step GEMM of the fp16 compute type (``wj_k_gemm_split``).  float32 [M,N]."""
+    ctx = hipbind.context(device)
+    lib = hipbind.lib()
+    A, Wt = a.float().contiguous(), w.to(TORCH_DTYPES[dtype]).contiguous()
+    M, K = A.shape
+    N = Wt.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _torch_sync()
+    check(lib.wj_k_gemm_split(ctx.handle, DTYPES[dtype], _ptr(A), _ptr(Wt), _ptr(bias) if bias is not None else None,
+                              _ptr(out), M, N, K, int(variant), None), "wj_k_gemm_split")
+    ctx.sync()
+    return out
+
+
 def k_gemm_timed(M: int, N: int, K: int, dtype: str = "bfloat16", variant: int = 0, reps: int = 20,
                  gelu: bool = False, device: int = 0) -> float:
     """Average milliseconds per launch of an [M,K] x [N,K]^T GEMM on uniform random [-1, 1) operands."""
     ctx = hipbind.context(device)
     lib = hipbind.lib()
-    td = torch.bfloat16 if dtype == "bfloat16" else torch.float32
+    td = TORCH_DTYPES[dtype]
     dev = torch.device("cuda", device)
     g = torch.Generator(device=dev).manual_seed(M + N + K)
     A = (torch.rand((M, K), device=dev, generator=g) * 2 - 1).to(td)
@@ -415,7 +433,7 @@ def k_gemm_timed(M: int, N: int, K: int, dtype: str = "bfloat16", variant: int =
 def k_layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, dtype: str, device: int = 0) -> torch.Tensor:
     ctx = hipbind.context(device)
     lib = hipbind.lib()
-    td = torch.bfloat16 if dtype == "bfloat16" else torch.float32
+    td = TORCH_DTYPES[dtype]
     M, D = x.shape
     out = torch.empty((M, D), dtype=td, device=x.device)
     _torch_sync()
@@ -429,7 +447,7 @@ def k_attention_enc(qkv: torch.Tensor, heads: int, dtype: str, device: int = 0) 
     """qkv float32 CUDA [B, T, 3*D] -> attention output float32 [B, T, D]."""
     ctx = hipbind.context(device)
     lib = hipbind.lib()
-    td = torch.bfloat16 if dtype == "bfloat16" else torch.float32
+    td = TORCH_DTYPES[dtype]
     B, T, D3 = qkv.shape
     out = torch.empty((B, T, D3 // 3), dtype=td, device=qkv.device)
     _torch_sync()

@@ -16,9 +16,9 @@ ABI_VERSION = 1
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwjhip.so"
 _lib: Optional[C.CDLL] = None
 
-WJ_F32, WJ_BF16 = 0, 1
+WJ_F32, WJ_BF16, WJ_F16 = 0, 1, 2
 WJ_MEL_FW, WJ_MEL_OW = 0, 1
-DTYPES = {"float32": WJ_F32, "bfloat16": WJ_BF16}
+DTYPES = {"float32": WJ_F32, "bfloat16": WJ_BF16, "float16": WJ_F16}
 
 
 class WjError(RuntimeError):
@@ -84,6 +84,7 @@ _SIGNATURES = {
     "wj_vad_free": (_I, [_P]),
     "wj_vad_scores": (_I, [_P, _P, C.POINTER(_I64), C.POINTER(_I64), _I, _P, _P]),
     "wj_k_gemm": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "wj_k_gemm_split": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "wj_k_gemm_timed": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F)]),
     "wj_k_layernorm": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _P]),
     "wj_k_attention_enc": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),

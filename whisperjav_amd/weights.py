@@ -47,27 +47,42 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.
     return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
 
 
+def round_to_f16(a: np.ndarray) -> np.ndarray:
+    """fp32 array rounded (RNE) to the nearest fp16-representable fp32 value (published Whisper checkpoints are
+    stored in fp16, so this is what real weights look like)."""
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return t.to(torch.float16).to(torch.float32).numpy()
+
+
 def round_to_bf16(a: np.ndarray) -> np.ndarray:
     """fp32 array rounded (RNE) to the nearest bf16-representable fp32 value."""
     t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
     return t.to(torch.bfloat16).to(torch.float32).numpy()
 
 
-def synth_weights(dims: WhisperDims, seed: int = 1234, bf16_exact: bool = True) -> Dict[str, np.ndarray]:
+def synth_weights(dims: WhisperDims, seed: int = 1234, bf16_exact: bool = True,
+                  exact: str = "") -> Dict[str, np.ndarray]:
     """Seeded random weights with trained-like statistics (there are no checkpoints offline).
 
     Variances are chosen so activations stay O(1) through the stack, attention scores have
     unit-ish spread and logits have a std of ~1.8 over the vocabulary (top-2 gap ~0.4), so
     greedy/beam decisions are numerically well separated -- a uniform-logit random model would
     make token parity meaningless.  With ``bf16_exact`` every matrix is pre-rounded to bf16 so
-    the fp32 oracle and the bf16 engine see bit-identical parameters.
+    the fp32 oracle and the bf16 engine see bit-identical parameters.  ``exact`` overrides it:
+    ``"none"`` keeps the raw fp32 draws (a 16-bit engine then also carries weight-rounding error),
+    ``"float16"`` rounds to fp16 (the storage type of the published checkpoints), ``"bfloat16"`` to bf16.
+    The random draws are the same in every mode.
     """
     rng = np.random.default_rng(seed)
     w: Dict[str, np.ndarray] = {}
+    mode = exact or ("bfloat16" if bf16_exact else "none")
+    if mode not in ("none", "float16", "bfloat16"):
+        raise ValueError("exact must be '', 'none', 'float16' or 'bfloat16'")
+    rnd = {"none": (lambda a: a), "float16": round_to_f16, "bfloat16": round_to_bf16}[mode]
 
     def mat(name, shape, fan_in, gain=1.0):
         a = rng.standard_normal(shape, dtype=np.float32) * np.float32(gain / np.sqrt(fan_in))
-        w[name] = round_to_bf16(a) if bf16_exact else a
+        w[name] = rnd(a)
 
     def vec(name, n, scale=0.1, base=0.0):
         w[name] = (base + scale * rng.standard_normal(n, dtype=np.float32)).astype(np.float32)
@@ -108,7 +123,7 @@ def synth_weights(dims: WhisperDims, seed: int = 1234, bf16_exact: bool = True) 
 
     dt = dims.n_text_state
     a = rng.standard_normal((dims.n_vocab, dt), dtype=np.float32) * np.float32(0.05)
-    w["decoder.token_embedding.weight"] = round_to_bf16(a) if bf16_exact else a
+    w["decoder.token_embedding.weight"] = rnd(a)
     w["decoder.positional_embedding"] = (0.05 * rng.standard_normal(
         (dims.n_text_ctx, dt), dtype=np.float32)).astype(np.float32)
     for i in range(dims.n_text_layer):
@@ -198,17 +213,18 @@ def pack_blob(dims: WhisperDims, w: Dict[str, np.ndarray], dtype: str = "bfloat1
               ) -> Tuple[torch.Tensor, np.ndarray]:
     """Pack a state dict into (host uint8 blob, int64 byte offsets) for ``wj_whisper_create``.
 
-    ``dtype``: ``"bfloat16"`` (matrices stored bf16) or ``"float32"``.
+    ``dtype``: ``"bfloat16"`` / ``"float16"`` (matrices stored in that 16-bit type) or ``"float32"``.
     """
-    if dtype not in ("bfloat16", "float32"):
-        raise ValueError("dtype must be 'bfloat16' or 'float32'")
+    if dtype not in ("bfloat16", "float16", "float32"):
+        raise ValueError("dtype must be 'bfloat16', 'float16' or 'float32'")
+    half = {"bfloat16": torch.bfloat16, "float16": torch.float16}.get(dtype)
     tensors = engine_tensors(dims, w)
     assert len(tensors) == expected_tensor_count(dims)
     offsets = np.zeros(len(tensors), dtype=np.int64)
     cursor = 0
     sizes = []
     for idx, (_, arr, is_mat) in enumerate(tensors):
-        item = 2 if (is_mat and dtype == "bfloat16") else 4
+        item = 2 if (is_mat and half is not None) else 4
         nbytes = int(arr.size) * item
         offsets[idx] = cursor
         sizes.append(nbytes)
@@ -216,8 +232,8 @@ def pack_blob(dims: WhisperDims, w: Dict[str, np.ndarray], dtype: str = "bfloat1
     blob = torch.zeros(cursor, dtype=torch.uint8)
     for (label, arr, is_mat), off, nbytes in zip(tensors, offsets, sizes):
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
-        if is_mat and dtype == "bfloat16":
-            t = t.to(torch.bfloat16)
+        if is_mat and half is not None:
+            t = t.to(half)
         blob[off:off + nbytes] = t.reshape(-1).view(torch.uint8)
     return blob, offsets
 

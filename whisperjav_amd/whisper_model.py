@@ -267,14 +267,18 @@ class HipWhisperModel:
     FLAVOR = "fw"
 
     def __init__(self, model_size_or_path: str = "large-v3", device: str = "cuda", device_index: int = 0,
-                 compute_type: str = "bfloat16", cpu_threads: int = 0, num_workers: int = 1,
+                 compute_type: str = "float16", cpu_threads: int = 0, num_workers: int = 1,
                  weights: Optional[Dict[str, np.ndarray]] = None, dims: Optional[pdims.WhisperDims] = None,
                  max_batch: int = 32, max_beam: int = 5, blob=None, offsets=None, **_unused):
         from . import engine, weights as W
         if device not in ("cuda", "auto", "hip"):
             raise ValueError(f"HipWhisperModel runs on the MI355X only (device={device!r}); there is no CPU path")
-        ct = {"auto": "bfloat16", "default": "bfloat16", "bfloat16": "bfloat16", "float16": "bfloat16",
-              "float32": "float32", "int8": "bfloat16", "int8_float16": "bfloat16", "int8_bfloat16": "bfloat16"}
+        # ctranslate2 compute types -> engine arithmetic.  "float16" is the reference's own GPU arithmetic
+        # (faster-whisper float16 / whisper fp16=True) and what "auto" resolves to on a GPU there
+        # (whisperjav/config/resolver_v3.py:163-168); the int8 flavours have no MI355X counterpart here and run
+        # in the 16-bit type they dequantise to.
+        ct = {"auto": "float16", "default": "float16", "bfloat16": "bfloat16", "float16": "float16",
+              "float32": "float32", "int8": "float16", "int8_float16": "float16", "int8_bfloat16": "bfloat16"}
         if compute_type not in ct:
             raise ValueError(f"unsupported compute_type {compute_type!r}")
         self.compute_type = ct[compute_type]
