@@ -481,7 +481,7 @@ def test_asr_adapter_with_hip_vad_writes_srt(hip, tmp_path):
         wf.writeframes((np.clip(audio, -1, 1) * 32767).astype("<i2").tobytes())
     model = wm.HipWhisperModel("tiny", compute_type="bfloat16", weights=pweights.synth_weights(d, seed=21), dims=d,
                                max_batch=8, max_beam=2)
-    seg = segmenters.HipSileroV6SpeechSegmenter(threshold=0.5, speech_pad_ms=100, max_group_duration_s=6.0)
+    seg = segmenters.HipSileroV6SpeechSegmenter(threshold=0.5, speech_pad_ms=100, max_group_duration_s=6.0, weights="synthetic")
     params = {"decoder": {"task": "transcribe", "language": "ja", "beam_size": 2, "patience": 1.2, "suppress_tokens": None,
                           "temperature": [0.0], "max_initial_timestamp": 0.0, "no_speech_threshold": None,
                           "logprob_threshold": -1.0, "condition_on_previous_text": False, "max_new_tokens": 24},
@@ -1019,8 +1019,61 @@ def test_sharded_transcribe_cli_single_rank(hip, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-m", "whisperjav_amd.sharded_transcribe", str(wav), str(tmp_path / "out" / "rec.srt"),
                           "--model", str(tmp_path / "model"), "--compute-type", "float32", "--batch", "8", "--beam-size", "2",
-                          "--max-new-tokens", "12", "--scene-energy-db", "52"],
+                          "--max-new-tokens", "12", "--scene-energy-db", "52", "--vad-weights", "synthetic"],
                          cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     text = (tmp_path / "out" / "rec.srt").read_text(encoding="utf-8")
     assert text.count("-->") >= 2 and text.startswith("1\n")
+
+
+# ---------------------------------------------------------------------------------------------
+# cross-scene pooling behind the seams (round 2): pooled == per scene, and the priming path of the reference's loop
+# ---------------------------------------------------------------------------------------------
+def test_pooled_scenes_equal_per_scene_and_priming_serves_the_loop(hip, tmp_path):
+    """``RecordingTranscriber`` (steps 2-4 of BalancedPipeline.process) with all scenes pooled into ONE segmentation
+    launch + ONE engine call gives exactly the segments of the reference's call pattern (one call per scene); and the
+    reference's loop shape -- ``prime_scenes`` then ``transcribe_to_srt`` scene by scene -- is served from one pooled
+    pass and writes the same per-scene SRT files."""
+    import wave
+    from whisperjav_amd import asr, pipeline, scenes as scn, segmenters, sharded_transcribe, synth, weights as pweights, whisper_model as wm
+    d = helpers.small_dims()
+    audio = synth.speech_like(150.0, seed=9, noisy=True)
+    model = wm.HipWhisperModel("tiny", compute_type="float32", weights=pweights.synth_weights(d, seed=21), dims=d,
+                               max_batch=16, max_beam=2)
+    params = sharded_transcribe.balanced_params("ja", 2, 12, word_timestamps=False)
+    seg = segmenters.HipSileroV6SpeechSegmenter(weights="synthetic", **params["vad"])
+    module = asr.HipFasterWhisperProASR({"model_name": "tiny"}, params, "transcribe", whisper_model=model, segmenter=seg)
+    calls = []
+    real = model.transcribe_many
+    model.transcribe_many = lambda clips, **kw: (calls.append(len(clips)) or real(clips, **kw))
+    det = scn.HipAuditokSceneDetector(pass1_energy_threshold=52, pass2_energy_threshold=56)
+    runner = pipeline.RecordingTranscriber(module, det)
+    pooled = runner.transcribe(audio, 16000, pooled=True)
+    n_pooled_calls = len(calls)
+    single = runner.transcribe(audio, 16000, pooled=False)
+    assert len(pooled["scenes"]) >= 4 and pooled["scenes"] == single["scenes"]
+    assert n_pooled_calls == 1 and len(calls) - 1 >= len([r for r in single["per_scene"] if r["segments"]])
+    key = lambda segs: [(round(x["start"], 3), round(x["end"], 3), x["text"], round(x["avg_logprob"], 4)) for x in segs]   # noqa: E731
+    assert key(pooled["segments"]) == key(single["segments"]) and len(pooled["segments"]) >= 4
+    for a, b in zip(pooled["per_scene"], single["per_scene"]):
+        assert key(a["segments"]) == key(b["segments"])
+    # the reference's loop: scene files on disk, announced once, then one transcribe_to_srt per scene
+    paths = []
+    for i, sc in enumerate(pooled["scenes"]):
+        path = tmp_path / f"rec_scene_{i:04d}.wav"
+        chunk = audio[int(sc[0] * 16000): int(sc[1] * 16000)]
+        with wave.open(str(path), "wb") as wf:
+            wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000)
+            wf.writeframes(np.clip(np.rint(chunk.astype(np.float64) * 32768.0), -32768, 32767).astype("<i2").tobytes())
+        paths.append(path)
+    del calls[:]
+    module.prime_scenes(paths)
+    srt_primed = [module.transcribe_to_srt(p, tmp_path / "primed" / (p.stem + ".srt")).read_text(encoding="utf-8") for p in paths]
+    vad_primed = module.get_last_vad_segments()
+    assert len(calls) == 1 and module.pooled_calls == 1          # one pooled engine call served every scene
+    del calls[:]
+    srt_loop = [module.transcribe_to_srt(p, tmp_path / "loop" / (p.stem + ".srt")).read_text(encoding="utf-8") for p in paths]
+    assert srt_primed == srt_loop and any("-->" in t for t in srt_loop)
+    assert vad_primed == module.get_last_vad_segments()
+    _diag("pooled_scenes", {"scenes": len(paths), "segments": len(pooled["segments"]), "per_scene_engine_calls": len(calls)})
+    module.cleanup()

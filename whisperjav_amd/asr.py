@@ -8,6 +8,14 @@ attribute ``model_name`` (pipelines/balanced_pipeline.py:398-403,483,497,580), a
 semantics -- speech segmentation, per-group transcription, high/low suppress lists, optional
 post-model log-prob gate, timestamps shifted by the group start -- but hands ALL VAD groups of a
 scene to the engine in one batched call instead of a Python loop of batch-1 upstream calls.
+
+Cross-scene pooling (round 2): ``transcribe_scenes([...])`` runs the SAME per-scene procedure for many scenes with
+ONE speech-segmentation launch and ONE pooled ``transcribe_many`` over the groups of all of them -- a scene only
+yields ~5 groups, the MI355X wants hundreds of windows per launch (45x real-time at batch 1, ~1900x at batch 384).
+The reference's pipeline loop calls ``transcribe_to_srt`` scene by scene (pipelines/balanced_pipeline.py:476-486);
+``prime_scenes(paths)`` lets whoever knows the scene list (``whisperjav_amd.pipeline``: a priming wrapper around the
+scene detector) announce it, the first per-scene call then transcribes the whole list pooled and the following calls
+are served from the cache -- same per-scene results, same SRT files, pooled throughput behind the unchanged loop.
 """
 from __future__ import annotations
 
@@ -91,6 +99,15 @@ except Exception:
         return len(flat) <= 2 and audio_duration >= 4 * min_duration_for_fallback
 
 
+class _NullTracer:
+    """utils/parameter_tracer.py NullTracer: every emit_* is a no-op."""
+
+    def __getattr__(self, name):
+        if name.startswith("emit"):
+            return lambda *a, **k: None
+        raise AttributeError(name)
+
+
 def read_audio(path: Union[str, Path]):
     """float32 mono samples + rate; soundfile when present, stdlib ``wave`` for the PCM16 scene files."""
     try:
@@ -124,11 +141,15 @@ def compose_srt(segments: List[Dict[str, Any]]) -> str:
     a negative start or with start >= end, re-index from 1, collapse blank lines inside the content."""
     try:
         import srt
-        subs = [srt.Subtitle(index=i, start=datetime.timedelta(seconds=s["start"]),
-                             end=datetime.timedelta(seconds=s["end"]), content=s["text"])
+        make, compose = srt.Subtitle, srt.compose
+    except (ImportError, AttributeError):
+        make = None
+    if make is not None:
+        subs = [make(index=i, start=datetime.timedelta(seconds=s["start"]),
+                     end=datetime.timedelta(seconds=s["end"]), content=s["text"])
                 for i, s in enumerate(segments, 1)]
-        return srt.compose(subs)
-    except ImportError:
+        return compose(subs)
+    else:
         import re
         rows = sorted(((datetime.timedelta(seconds=s["start"]), datetime.timedelta(seconds=s["end"]), i, s["text"])
                        for i, s in enumerate(segments, 1)), key=lambda r: r[:3])
@@ -148,7 +169,7 @@ class HipFasterWhisperProASR:
 
     def __init__(self, model_config: Dict, params: Dict, task: str, tracer=None, *, whisper_model=None,
                  segmenter=None):
-        self.tracer = tracer
+        self.tracer = tracer if tracer is not None else _NullTracer()
         self.model_name = model_config.get("model_name", "large-v2")
         self.device = model_config.get("device", "cuda")
         self.compute_type = model_config.get("compute_type", "auto")
@@ -196,6 +217,9 @@ class HipFasterWhisperProASR:
         self.suppress_high = ["視聴ありがとうございました", "ご視聴ありがとうございました", "字幕作成者", "提供", "スポンサー"]
         self._reset_runtime_statistics()
         self._last_full_results: List[Dict] = []
+        self._primed: List[str] = []               # scene paths announced by prime_scenes()
+        self._scene_cache: Dict[str, Dict[str, Any]] = {}
+        self.pooled_calls = 0                      # diagnostics: engine calls made for primed scene lists
         if whisper_model is not None:
             self.whisper_model = whisper_model
         else:
@@ -209,16 +233,31 @@ class HipFasterWhisperProASR:
             from whisperjav.modules.speech_segmentation import SpeechSegmenterFactory  # type: ignore
             return SpeechSegmenterFactory.create(backend, config=config)
         except ImportError:
-            cls_path = segmenters.REGISTRY_ENTRIES.get(backend, segmenters.REGISTRY_ENTRIES["silero-v6.2-hip"])
+            # stand-alone (no whisperjav package): the reference's registry names map onto the HIP back ends
+            # (factory.py:17-33); "none" keeps the reference's semantics -- no gating, the whole scene is transcribed
+            # (backends/none.py:51-92) -- and anything unknown is an error, as in SpeechSegmenterFactory.create
+            if backend in ("none", ""):
+                return segmenters.NullSpeechSegmenter()
+            alias = {"silero": "silero-v4.0-hip", "silero-v4.0": "silero-v4.0-hip", "silero-v3.1": "silero-v3.1-hip",
+                     "silero-v6.2": "silero-v6.2-hip", "ten": "ten-hip"}
+            cls_path = segmenters.REGISTRY_ENTRIES.get(alias.get(backend, backend))
+            if cls_path is None:
+                raise ValueError(f"Unknown speech segmenter backend: {backend!r}. Available: "
+                                 f"{sorted(set(segmenters.REGISTRY_ENTRIES) | {'none'})}")
             cls = getattr(segmenters, cls_path.rsplit(".", 1)[1])
             if "v3.1" in backend or "v4.0" in backend:
                 config = dict(config, version="v3.1" if "v3.1" in backend else "v4.0")
+            if not backend.startswith("silero"):        # silero-only keys of the resolver's VAD presets
+                import inspect
+                accepted = set(inspect.signature(cls.__init__).parameters)
+                config = {k: v for k, v in config.items() if k in accepted}
             return cls(**config)
 
     # ---- statistics hooks used by the pipelines -------------------------------------------------
     def _reset_runtime_statistics(self) -> None:
         self._filter_statistics = {"logprob_filtered": 0, "nonverbal_filtered": 0}
         self._last_vad_segments: List[Dict] = []
+        self._vad_segments_per_scene: List[List[Dict]] = []
 
     def reset_statistics(self) -> None:
         self._reset_runtime_statistics()
@@ -261,43 +300,121 @@ class HipFasterWhisperProASR:
 
     # ---- transcription ----------------------------------------------------------------------------
     def transcribe(self, audio_path: Union[str, Path], **kwargs) -> Dict:
+        """One scene file (the reference's call contract, faster_whisper_pro_asr.py:438-557).  A path announced through
+        ``prime_scenes`` is answered from the pooled pass over the whole announced list."""
         self._last_full_results = []
         audio_path = Path(audio_path)
+        self._apply_runtime_task(kwargs)
+        key = str(audio_path)
+        if key not in self._scene_cache and key in self._primed:
+            batch = [p for p in self._primed if p not in self._scene_cache and Path(p).exists()]
+            self._primed = []
+            results = self._transcribe_loaded([read_audio(Path(p)) for p in batch])
+            self.pooled_calls += 1
+            for p, res, vad in zip(batch, results, self._vad_segments_per_scene):
+                self._scene_cache[p] = {"result": res, "vad": vad}
+        hit = self._scene_cache.pop(key, None)
+        if hit is not None:
+            self._last_vad_segments = hit["vad"]
+            return hit["result"]
+        return self._transcribe_loaded([read_audio(audio_path)])[0]
+
+    def prime_scenes(self, scene_paths) -> None:
+        """Announce the scene files the pipeline is about to hand over one by one (see the module docstring)."""
+        self._primed = [str(Path(p)) for p in scene_paths]
+        self._scene_cache = {}
+
+    def transcribe_scenes(self, scenes, **kwargs) -> List[Dict]:
+        """Pooled form: ``scenes`` = scene file paths or ``(audio float32, sample_rate)`` pairs -> the per-scene result
+        dicts ``transcribe`` would return for each, computed with one segmentation launch and one pooled engine call.
+        ``get_vad_segments_per_scene()`` holds every scene's VAD segments afterwards."""
+        self._apply_runtime_task(kwargs)
+        loaded = [s if isinstance(s, tuple) else read_audio(Path(s)) for s in scenes]
+        return self._transcribe_loaded(loaded)
+
+    def get_vad_segments_per_scene(self) -> List[List[Dict]]:
+        return [list(v) for v in self._vad_segments_per_scene]
+
+    def _apply_runtime_task(self, kwargs: Dict[str, Any]) -> None:
         if "task" in kwargs:
             runtime_task = kwargs.pop("task")
             if runtime_task != self.task:
                 self.whisper_params["task"] = runtime_task
                 self.task = runtime_task
-        audio, sr = read_audio(audio_path)
-        result = self._external_segmenter.segment(audio, sample_rate=sr)
-        vad_groups = result.to_legacy_format()
-        duration = len(audio) / sr if sr else 0.0
-        self._last_vad_segments = [{"start_sec": round(s["start_sec"], 3), "end_sec": round(s["end_sec"], 3)}
-                                   for g in vad_groups for s in g]
+
+    def _segment_all(self, loaded):
+        seg = self._external_segmenter
+        if len(loaded) > 1 and hasattr(seg, "segment_many"):
+            return seg.segment_many([a for a, _ in loaded], [sr for _, sr in loaded])
+        return [seg.segment(a, sample_rate=sr) for a, sr in loaded]
+
+    def _transcribe_loaded(self, loaded) -> List[Dict]:
         language = self.whisper_params.get("language", "ja")
-        if not vad_groups:
-            if self._external_segmenter.name == "none" or should_force_full_transcribe(vad_groups, duration):
+        results: List[Optional[Dict]] = [None] * len(loaded)
+        self._vad_segments_per_scene = []
+        clips: List[np.ndarray] = []
+        owner: List[tuple] = []                       # (scene index, group start in seconds)
+        for i, ((audio, sr), seg_result) in enumerate(zip(loaded, self._segment_all(loaded))):
+            vad_groups = seg_result.to_legacy_format()
+            duration = len(audio) / sr if sr else 0.0
+            vad = [{"start_sec": round(s["start_sec"], 3), "end_sec": round(s["end_sec"], 3)} for g in vad_groups for s in g]
+            self._vad_segments_per_scene.append(vad)
+            self._last_vad_segments = vad
+            if not vad_groups:
+                if self._external_segmenter.name == "none" or should_force_full_transcribe(vad_groups, duration):
+                    spans = [(0.0, duration)]
+                else:
+                    results[i] = {"segments": [], "text": "", "language": language}
+                    continue
+            elif should_force_full_transcribe(vad_groups, duration):
                 spans = [(0.0, duration)]
             else:
-                return {"segments": [], "text": "", "language": language}
-        elif should_force_full_transcribe(vad_groups, duration):
-            spans = [(0.0, duration)]
-        else:
-            spans = [(g[0]["start_sec"], g[-1]["end_sec"]) for g in vad_groups if g]
-        clips, kept = [], []
-        for start, end in spans:
-            clip = audio[int(start * sr): int(end * sr)]
-            if len(clip) > 200:
-                clips.append(clip)
-                kept.append(start)
-        if not clips:
-            return {"segments": [], "text": "", "language": language}
+                spans = [(g[0]["start_sec"], g[-1]["end_sec"]) for g in vad_groups if g]
+            n_before = len(clips)
+            for start, end in spans:
+                clip = audio[int(start * sr): int(end * sr)]
+                if len(clip) > 200:
+                    clips.append(clip)
+                    owner.append((i, start))
+                    self.tracer.emit_transcribe_params(
+                        params=self.whisper_params,
+                        audio_info={"duration_sec": end - start, "start_sec": start, "end_sec": end, "sample_rate": sr,
+                                    "shape": str(clip.shape), "dtype": str(clip.dtype)},
+                        context=("full_audio" if len(spans) == 1 and start == 0.0 and end == duration
+                                 else f"vad_group_{start:.2f}s-{end:.2f}s"))
+            if len(clips) == n_before:
+                results[i] = {"segments": [], "text": "", "language": language}
+        per_scene: List[List[Dict]] = [[] for _ in loaded]
+        if clips:
+            for (i, start), segs in zip(owner, self._run_model(clips)):
+                per_scene[i].extend(self._filter_group(segs, start))
+        for i in range(len(loaded)):
+            if results[i] is None:
+                segs = per_scene[i]
+                results[i] = {"segments": segs, "text": " ".join(s["text"] for s in segs), "language": language}
+        return results  # type: ignore[return-value]
+
+    def _run_model(self, clips: List[np.ndarray]):
+        """Every clip through the engine in one call; on an engine error the reference's retry ladder
+        (faster_whisper_pro_asr.py:925-980): the clip alone with minimal parameters, then an empty result."""
         params = self._prepare_whisper_params()
-        per_clip, _ = self.whisper_model.transcribe_many(clips, **params)
-        all_segments: List[Dict] = []
-        for start, segs in zip(kept, per_clip):
-            all_segments.extend(self._filter_group(segs, start))
-        return {"segments": all_segments, "text": " ".join(s["text"] for s in all_segments), "language": language}
+        try:
+            per_clip, _ = self.whisper_model.transcribe_many(clips, **params)
+            return per_clip
+        except Exception as e:
+            logger.error(f"pooled transcription of {len(clips)} clips failed ({type(e).__name__}: {e}); "
+                         "retrying clip by clip with minimal parameters")
+        minimal = {"task": self.whisper_params.get("task", "transcribe"), "language": self.whisper_params.get("language", "ja"),
+                   "temperature": 0.0, "beam_size": 3, "log_progress": False}
+        out = []
+        for clip in clips:
+            try:
+                segs, _ = self.whisper_model.transcribe_many([clip], **minimal)
+                out.append(segs[0])
+            except Exception as e2:
+                logger.error(f"minimal-parameter retry failed too ({type(e2).__name__}: {e2}); clip dropped")
+                out.append([])
+        return out
 
     def _filter_group(self, segs, start_sec: float) -> List[Dict]:
         out = []

@@ -126,13 +126,37 @@ def _resample(audio: np.ndarray, orig_sr: int, target_sr: int) -> np.ndarray:
 
 
 class _HipSileroBase:
+    _weights_path: Optional[str] = None
+
     def _ensure_model(self) -> None:
         if self._model is not None:
             return
         from . import vad
-        self._model = vad.HipSileroScorer(self._weights, device=self._device)
+        # trained Silero parameters by default (weights_path / the silero_vad package); weights="synthetic" is an
+        # explicit opt-in for tests and benchmarks -- see vad.HipSileroScorer
+        self._model = vad.HipSileroScorer(self._weights, device=self._device, weights_path=self._weights_path)
         if self._get_speech_timestamps is None:
             self._get_speech_timestamps = vad.get_speech_timestamps
+
+    def segment_many(self, audios, sample_rates) -> List["SegmentationResult"]:
+        """``segment`` for many clips (scenes) with ONE scorer launch: every clip is a stream of the batched HIP
+        scorer (``wj_vad_scores`` scores them concurrently, state reset per stream), then the per-clip region logic
+        runs exactly as in ``segment``.  Falls back to a loop when the scorer seam has been replaced (the test
+        doubles of the reference's suite) or a clip needs resampling / loading."""
+        from . import vad
+        self._ensure_model()
+        if isinstance(sample_rates, int):
+            sample_rates = [sample_rates] * len(audios)
+        batched = (self._get_speech_timestamps is vad.get_speech_timestamps and hasattr(self._model, "scores")
+                   and all(isinstance(a, np.ndarray) and sr == VAD_SR for a, sr in zip(audios, sample_rates)))
+        if not batched:
+            return [self.segment(a, sample_rate=sr) for a, sr in zip(audios, sample_rates)]
+        try:
+            probs = self._model.scores([np.asarray(a, dtype=np.float32) for a in audios])
+        except Exception as e:      # per-clip calls reproduce each class's own error policy (swallow / propagate)
+            logger.error(f"batched VAD scoring failed ({e}); falling back to per-clip calls")
+            return [self.segment(a, sample_rate=sr) for a, sr in zip(audios, sample_rates)]
+        return [self.segment(a, sample_rate=sr, _probs=p) for a, sr, p in zip(audios, sample_rates, probs)]
 
     def cleanup(self) -> None:
         model, self._model = self._model, None
@@ -150,12 +174,13 @@ class HipSileroV6SpeechSegmenter(_HipSileroBase):
                  max_speech_duration_s: Optional[float] = None, min_silence_duration_ms: int = 100,
                  speech_pad_ms: int = 350, min_silence_at_max_speech: int = 98,
                  use_max_poss_sil_at_max_speech: bool = True, chunk_threshold_s: Optional[float] = 1.0,
-                 max_group_duration_s: Optional[float] = None, weights: Optional[Dict[str, np.ndarray]] = None,
-                 device: int = 0, **kwargs):
+                 max_group_duration_s: Optional[float] = None, weights: Union[Dict[str, np.ndarray], str, None] = None,
+                 device: int = 0, weights_path: Optional[str] = None, **kwargs):
         self.threshold = float(threshold)
         self.min_speech_duration_ms = int(min_speech_duration_ms)
         self.min_silence_duration_ms = int(min_silence_duration_ms)
         self.speech_pad_ms = int(speech_pad_ms)
+        self._weights_path = weights_path
         self.min_silence_at_max_speech = int(min_silence_at_max_speech)
         self.use_max_poss_sil_at_max_speech = bool(use_max_poss_sil_at_max_speech)
         if chunk_threshold_s is not None:
@@ -200,7 +225,8 @@ class HipSileroV6SpeechSegmenter(_HipSileroBase):
                 min_speech_duration_ms=self.min_speech_duration_ms, max_speech_duration_s=self.max_speech_duration_s,
                 min_silence_duration_ms=self.min_silence_duration_ms, speech_pad_ms=self.speech_pad_ms,
                 return_seconds=False, min_silence_at_max_speech=self.min_silence_at_max_speech,
-                use_max_poss_sil_at_max_speech=self.use_max_poss_sil_at_max_speech)
+                use_max_poss_sil_at_max_speech=self.use_max_poss_sil_at_max_speech,
+                **({"probs": kwargs["_probs"]} if kwargs.get("_probs") is not None else {}))
             segments = [SpeechSegment(start_sec=ts["start"] / sr, end_sec=ts["end"] / sr, start_sample=ts["start"],
                                       end_sample=ts["end"], confidence=1.0) for ts in stamps]
         except Exception as e:  # same policy as the reference backend: log, return an empty result
@@ -231,7 +257,9 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
                  speech_pad_ms: Optional[int] = None, chunk_threshold_s: Optional[float] = None,
                  max_group_duration_s: Optional[float] = None, max_speech_duration_s: Optional[float] = None,
                  start_pad_samples: int = 11200, end_pad_samples: int = 20800,
-                 weights: Optional[Dict[str, np.ndarray]] = None, device: int = 0, **kwargs):
+                 weights: Union[Dict[str, np.ndarray], str, None] = None, device: int = 0,
+                 weights_path: Optional[str] = None, **kwargs):
+        self._weights_path = weights_path
         self.version = version if version in self.VERSION_DEFAULTS else "v4.0"
         dflt = self.VERSION_DEFAULTS[self.version]
         self.threshold = float(threshold) if threshold is not None else dflt["threshold"]
@@ -283,7 +311,8 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
         audio16 = np.asarray(_resample(data, sr, VAD_SR), dtype=np.float32)
         stamps = self._get_speech_timestamps(audio16, self._model, sampling_rate=VAD_SR, threshold=threshold,
                                              min_speech_duration_ms=min_speech, min_silence_duration_ms=min_silence,
-                                             speech_pad_ms=pad_ms)
+                                             speech_pad_ms=pad_ms,
+                                             **({"probs": kwargs["_probs"]} if kwargs.get("_probs") is not None else {}))
         if not stamps:
             return SegmentationResult(segments=[], groups=[], method=self.name, audio_duration_sec=duration,
                                       parameters=self._get_parameters(), processing_time_sec=time.time() - t0)
@@ -303,10 +332,137 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
                                   parameters=self._get_parameters(), processing_time_sec=time.time() - t0)
 
 
+class NullSpeechSegmenter:
+    """Stand-alone mirror of the reference's passthrough segmenter (backends/none.py:21-92): the whole clip is one
+    segment / one group, ``name == "none"`` (the ASR modules then transcribe the full scene).  Inside WhisperJAV the
+    reference's own class is created by its factory; this one serves ``--speech-segmenter none`` without it."""
+
+    def __init__(self, **kwargs):
+        pass
+
+    @property
+    def name(self) -> str:
+        return "none"
+
+    @property
+    def display_name(self) -> str:
+        return "No Segmentation"
+
+    def segment(self, audio: Union[np.ndarray, Path, str], sample_rate: int = 16000, **kwargs) -> SegmentationResult:
+        t0 = time.time()
+        data, sr = _load_audio(audio, sample_rate)
+        duration = len(data) / sr
+        seg = SpeechSegment(start_sec=0.0, end_sec=duration, start_sample=0, end_sample=len(data), confidence=1.0,
+                            metadata={"bypass": True})
+        return SegmentationResult(segments=[seg], groups=[[seg]], method=self.name, audio_duration_sec=duration,
+                                  parameters={"mode": "passthrough"}, processing_time_sec=time.time() - t0)
+
+    def cleanup(self) -> None:
+        pass
+
+    def get_supported_sample_rates(self) -> List[int]:
+        return []
+
+
+class BatchFrameScorer:
+    """Adapter that gives a whole-clip scorer the frame API of ``ten_vad.TenVad`` (``process(frame)`` then
+    ``out_flags.value`` / ``out_probability.value``, backends/ten.py:232-239), so the reference's TEN post-ops can
+    run unchanged on top of it.  ``clip_probs(int16 clip, hop) -> float array`` (one probability per hop) is called
+    once per clip -- on the first frame -- and the frames are then served from the result."""
+
+    class _Box:
+        value = 0
+
+    def __init__(self, clip_probs, threshold: float, hop_size: int):
+        self._clip_probs, self.threshold, self.hop_size = clip_probs, float(threshold), int(hop_size)
+        self.out_flags, self.out_probability = self._Box(), self._Box()
+        self._probs: Optional[np.ndarray] = None
+        self._i = 0
+
+    def begin_clip(self, audio_int16: np.ndarray) -> None:
+        self._probs = np.asarray(self._clip_probs(audio_int16, self.hop_size), dtype=np.float64)
+        self._i = 0
+
+    def process(self, frame) -> None:
+        p = float(self._probs[self._i]) if self._probs is not None and self._i < len(self._probs) else 0.0
+        self._i += 1
+        self.out_probability.value = p
+        self.out_flags.value = int(p >= self.threshold)
+
+
+def hip_ten_segmenter_class():
+    """``HipTenSpeechSegmenter``: the reference's ``TenSpeechSegmenter`` (backends/ten.py:75-520) with every post-op
+    -- flags -> segments with the max-speech cut, silence merge, padding, split at probability minima, grouping --
+    inherited UNCHANGED and only the frame scorer pluggable:
+
+      * ``scorer="ten"``    the ``ten_vad`` package's own model (closed native library, CPU) -- the reference's result;
+      * ``scorer="silero"`` the HIP Silero scorer's window probabilities resampled onto the TEN hop grid (one launch
+                            per clip on the MI355X; a different network, so different probabilities -- opt-in);
+      * a callable ``(int16 clip, hop) -> probabilities`` for anything else (tests use this).
+
+    Needs the ``whisperjav`` package for the post-ops (they are the reference's code, not restated here)."""
+    from whisperjav.modules.speech_segmentation.backends.ten import TenSpeechSegmenter  # type: ignore
+
+    class HipTenSpeechSegmenter(TenSpeechSegmenter):
+        def __init__(self, *args, scorer="ten", weights=None, weights_path=None, device: int = 0, **kwargs):
+            super().__init__(*args, **kwargs)
+            self._scorer_kind, self._weights, self._weights_path, self._device = scorer, weights, weights_path, int(device)
+            self._silero = None
+
+        @property
+        def name(self) -> str:
+            return "ten" if self._scorer_kind == "ten" else "ten-hip"
+
+        @property
+        def display_name(self) -> str:
+            return "TEN VAD" if self._scorer_kind == "ten" else "TEN post-processing over a pluggable scorer (MI355X)"
+
+        def _silero_probs(self, audio_int16: np.ndarray, hop: int) -> np.ndarray:
+            from . import vad
+            if self._silero is None:
+                self._silero = vad.HipSileroScorer(self._weights, device=self._device, weights_path=self._weights_path)
+            win = self._silero.scores([audio_int16.astype(np.float32) / 32768.0])[0]
+            n_frames = (len(audio_int16) + hop - 1) // hop
+            idx = np.minimum((np.arange(n_frames) * hop) // vad.WINDOW, max(len(win) - 1, 0))
+            return win[idx] if len(win) else np.zeros(n_frames)
+
+        def _ensure_model(self) -> None:
+            if self._model is not None:
+                return
+            if self._scorer_kind == "ten":
+                return super()._ensure_model()
+            fn = self._silero_probs if self._scorer_kind == "silero" else self._scorer_kind
+            if not callable(fn):
+                raise ValueError("scorer must be 'ten', 'silero' or a callable (int16 clip, hop) -> probabilities")
+            self._model = BatchFrameScorer(fn, self.threshold, self.hop_size)
+
+        def _convert_to_int16(self, audio_data):
+            out = super()._convert_to_int16(audio_data)
+            if isinstance(self._model, BatchFrameScorer):
+                self._model.begin_clip(out)        # the one scorer launch of this clip
+            return out
+
+        def cleanup(self) -> None:
+            if self._silero is not None:
+                self._silero.close()
+                self._silero = None
+            if hasattr(super(), "cleanup"):
+                super().cleanup()
+
+    return HipTenSpeechSegmenter
+
+
+def __getattr__(name):      # ``segmenters.HipTenSpeechSegmenter`` resolves lazily (it needs the whisperjav package)
+    if name == "HipTenSpeechSegmenter":
+        return hip_ten_segmenter_class()
+    raise AttributeError(name)
+
+
 REGISTRY_ENTRIES = {
     # add these to whisperjav/modules/speech_segmentation/factory.py:_BACKEND_REGISTRY (INTEGRATION.md)
     "silero-hip": "whisperjav_amd.segmenters.HipSileroV6SpeechSegmenter",
     "silero-v6.2-hip": "whisperjav_amd.segmenters.HipSileroV6SpeechSegmenter",
     "silero-v4.0-hip": "whisperjav_amd.segmenters.HipSileroSpeechSegmenter",
     "silero-v3.1-hip": "whisperjav_amd.segmenters.HipSileroSpeechSegmenter",
+    "ten-hip": "whisperjav_amd.segmenters.HipTenSpeechSegmenter",
 }

@@ -5,8 +5,9 @@
 
 One process per GPU.  Rank 0 packs the weights once (one RCCL broadcast), every rank loads the clip, detects the scenes
 with the same deterministic device kernel (``scenes.HipAuditokSceneDetector``; nothing to exchange), takes its
-longest-processing-time-first share, runs VAD -> groups -> batched transcription on its scenes and rank 0 writes the
-SRT in scene order.  Mirrors what the reference does serially in ``BalancedPipeline.process`` steps 2-4
+longest-processing-time-first share and transcribes it POOLED (one VAD launch and one batched engine call for all
+of the rank's scenes, with the ASR adapter's per-scene semantics: ``asr.HipFasterWhisperProASR.transcribe_scenes``),
+and rank 0 writes the SRT in scene order.  Mirrors what the reference does serially in ``BalancedPipeline.process`` steps 2-4
 (/root/reference/whisperjav/pipelines/balanced_pipeline.py:281-514) + ``SRTStitcher.stitch``
 (modules/srt_stitching.py:18-84), minus the files on disk between the steps.
 """
@@ -36,34 +37,52 @@ def transcribe_scenes(audio: np.ndarray, sr: int, scenes: Sequence[Tuple[float, 
     return merged
 
 
+def balanced_params(language: str = "ja", beam_size: int = 2, max_new_tokens: Optional[int] = None,
+                    word_timestamps: bool = True, vad_threshold: float = 0.28) -> Dict[str, Any]:
+    """The ``params`` dict the reference's resolver hands ``FasterWhisperProASR`` in balanced mode
+    (config/components/asr/faster_whisper.py:223-315 decoder + provider defaults, config/components/vad/silero.py:105-114)."""
+    decoder = dict(task="transcribe", language=language, beam_size=beam_size, best_of=2, patience=1.2, length_penalty=None,
+                   suppress_blank=True, without_timestamps=False, max_initial_timestamp=0.0, temperature=[0.0],
+                   compression_ratio_threshold=2.4, logprob_threshold=-1.0, no_speech_threshold=0.65,
+                   condition_on_previous_text=False, word_timestamps=word_timestamps)
+    provider = dict(repetition_penalty=1.5, no_repeat_ngram_size=3, max_new_tokens=max_new_tokens, log_progress=False)
+    vad = dict(threshold=vad_threshold, min_speech_duration_ms=100, min_silence_duration_ms=300, speech_pad_ms=400,
+               chunk_threshold_s=2.5, max_group_duration_s=6.0)
+    return {"decoder": decoder, "provider": provider, "vad": vad, "speech_segmenter": {"backend": "silero-v6.2-hip"}}
+
+
 def main(argv: Optional[Sequence[str]] = None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("audio")
     ap.add_argument("srt")
     ap.add_argument("--model", required=True, help="directory with model.pt or config.json + model.safetensors (+ tokenizer.json)")
-    ap.add_argument("--compute-type", default="bfloat16")
+    ap.add_argument("--compute-type", default="float16")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--beam-size", type=int, default=2)
     ap.add_argument("--language", default="ja")
     ap.add_argument("--max-new-tokens", type=int, default=None)
     ap.add_argument("--scene-energy-db", type=int, default=32, help="auditok pass-1 energy threshold (pass 2 = +6 dB)")
+    ap.add_argument("--vad-weights", default=None, help="trained Silero VAD parameters (silero_vad.jit / .npz / .safetensors); "
+                    "default: the silero_vad package's bundled model; 'synthetic' = seeded random parameters (tests only)")
+    ap.add_argument("--per-scene", action="store_true", help="the reference's call pattern (one engine call per scene) instead of pooling")
     args = ap.parse_args(argv)
     import torch
-    from . import asr, scenes as scn, segmenters, weights as W, whisper_model as wm
+    from . import asr, pipeline, scenes as scn, segmenters, weights as W, whisper_model as wm
     info = sharding.init_distributed()
     torch.cuda.set_device(info.local_rank)
     dev = torch.device("cuda", info.local_rank)
     blob = offsets = meta = None
+    ct = {"auto": "float16", "default": "float16"}.get(args.compute_type, args.compute_type)
     if info.rank == 0:
         loader = wm.HipWhisperModel.__new__(wm.HipWhisperModel)
         loader.tokenizer = wm.IdTokenizer()
         dims, sd = loader._load_checkpoint(args.model)
-        blob, offsets = W.pack_blob(dims, sd, "bfloat16" if args.compute_type != "float32" else "float32")
+        blob, offsets = W.pack_blob(dims, sd, ct)
         meta = {"dims": dims, "alignment_heads": getattr(loader, "_alignment_heads", None)}
     meta = sharding.broadcast_object(meta)
     dims = meta["dims"]
     dev_blob, offsets = sharding.broadcast_blob(blob, offsets, dev)
-    model = wm.HipWhisperModel(args.model, compute_type=args.compute_type, dims=dims, blob=dev_blob, offsets=offsets,
+    model = wm.HipWhisperModel(args.model, compute_type=ct, dims=dims, blob=dev_blob, offsets=offsets,
                                device_index=info.local_rank, max_batch=args.batch, max_beam=max(2, args.beam_size))
     if meta["alignment_heads"]:
         model._alignment_heads = list(meta["alignment_heads"])
@@ -71,30 +90,28 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     if tok.exists():
         model.tokenizer = wm.HfTokenizer(str(tok))
     audio, sr = asr.read_audio(Path(args.audio))
+    audio = pipeline.to_16k(audio, sr)          # every sample index below is a 16 kHz index
     detector = scn.HipAuditokSceneDetector(device=info.local_rank, pass1_energy_threshold=args.scene_energy_db,
                                            pass2_energy_threshold=args.scene_energy_db + 6)
-    found, _ = detector.split_clip(audio, sr)
-    scene_list = [(a, b) for a, b, _, _ in found]
-    segmenter = segmenters.HipSileroV6SpeechSegmenter(device=info.local_rank)
-    kw = dict(language=args.language, beam_size=args.beam_size, patience=1.2, temperature=[0.0], repetition_penalty=1.5,
-              no_repeat_ngram_size=3, condition_on_previous_text=False, max_initial_timestamp=0.0, word_timestamps=True,
-              max_new_tokens=args.max_new_tokens)
-
-    def transcribe_scene(clip: np.ndarray, start_s: float) -> List[Dict[str, Any]]:
-        res = segmenter.segment(clip, sample_rate=sr)
-        spans = [(g[0].start_sample, g[-1].end_sample) for g in res.groups if g]
-        clips = [clip[a:b] for a, b in spans if b - a > 400]
-        out: List[Dict[str, Any]] = []
-        if not clips:
-            return out
-        segs, _ = model.transcribe_many(clips, **kw)
-        for (a, _), group in zip([s for s in spans if s[1] - s[0] > 400], segs):
-            for s in group:
-                out.append({"start": start_s + a / sr + s.start, "end": start_s + a / sr + s.end, "text": s.text.strip(),
-                            "avg_logprob": s.avg_logprob})
-        return out
-    merged = transcribe_scenes(audio, sr, scene_list, transcribe_scene)
-    if merged is not None:
+    params = balanced_params(args.language, args.beam_size, args.max_new_tokens)
+    vad_kw = dict(params["vad"])
+    if args.vad_weights == "synthetic":
+        vad_kw["weights"] = "synthetic"
+    elif args.vad_weights:
+        vad_kw["weights_path"] = args.vad_weights
+    segmenter = segmenters.HipSileroV6SpeechSegmenter(device=info.local_rank, **vad_kw)
+    # the per-scene semantics (VAD fail-over, suppress lists, post-model gate, timestamp shifts) are the ASR adapter's
+    module = asr.HipFasterWhisperProASR({"model_name": args.model, "device": "cuda", "compute_type": ct}, params, "transcribe",
+                                        whisper_model=model, segmenter=segmenter)
+    runner = pipeline.RecordingTranscriber(module, detector)
+    scene_list = runner.detect(audio, pipeline.SR)          # deterministic: every rank computes the same list
+    plan = sharding.assign_lpt([b - a for a, b in scene_list], info.world)
+    mine = plan[info.rank]
+    results = runner.transcribe_scenes(audio, pipeline.SR, [scene_list[i] for i in mine], pooled=not args.per_scene) if mine else []
+    gathered = sharding.gather_objects(dict(zip(mine, results)), dst=0)
+    if info.rank == 0:
+        per_scene = sharding.merge_by_index(plan, gathered)
+        merged = runner.stitch(scene_list, per_scene)
         Path(args.srt).parent.mkdir(parents=True, exist_ok=True)
         Path(args.srt).write_text(asr.compose_srt(merged), encoding="utf-8")
     sharding.barrier()

@@ -10,7 +10,7 @@ samples) so the reference's segmenter backends can keep calling "get_speech_time
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Union
 
 import numpy as np
 import torch
@@ -26,14 +26,20 @@ class HipSileroScorer:
     """``wj_vad_*``: every stream (scene) is scored concurrently, one workgroup per stream, state reset
     per stream like upstream's ``reset_states()`` per call."""
 
-    def __init__(self, weights: Optional[Dict[str, np.ndarray]] = None, device: int = 0):
+    def __init__(self, weights: Union[Dict[str, np.ndarray], str, None] = None, device: int = 0,
+                 weights_path: Optional[str] = None):
+        """``weights``: a parameter dict (``vad_weights`` names), ``"synthetic"`` (seeded random parameters -- an
+        explicit opt-in for tests and benchmarks, never a default) or None = the trained Silero parameters:
+        ``weights_path`` (.npz / .safetensors / TorchScript .jit|.pt) when given, else the ``silero_vad`` package's
+        bundled model (``silero_vad.load_silero_vad()``, the call the reference makes at
+        backends/silero_v6.py:143).  There is no silent fallback: without trained parameters this raises."""
         if not torch.cuda.is_available():
             raise hipbind.WjError("no ROCm device visible: the HIP VAD scorer has no CPU fallback")
         self.device = int(device)
         self.dev = torch.device("cuda", device)
         self.ctx = hipbind.context(device)
         self._lib = hipbind.lib()
-        blob = vad_weights.pack(weights if weights is not None else vad_weights.synth_weights())
+        blob = vad_weights.pack(vad_weights.resolve(weights, weights_path))
         handle = C.c_void_p()
         check(self._lib.wj_vad_create(self.ctx.handle, blob.ctypes.data_as(C.POINTER(C.c_float)), blob.shape[0],
                                       C.byref(handle)), "wj_vad_create")
@@ -172,7 +178,8 @@ def get_speech_timestamps(audio, model: HipSileroScorer, threshold: float = 0.5,
                           min_speech_duration_ms: int = 250, max_speech_duration_s: float = float("inf"),
                           min_silence_duration_ms: int = 100, speech_pad_ms: int = 30, return_seconds: bool = False,
                           neg_threshold: Optional[float] = None, min_silence_at_max_speech: int = 98,
-                          use_max_poss_sil_at_max_speech: bool = True, **_ignored) -> List[Dict]:
+                          use_max_poss_sil_at_max_speech: bool = True, probs: Optional[np.ndarray] = None,
+                          **_ignored) -> List[Dict]:
     """Drop-in for ``silero_vad.get_speech_timestamps(audio, model, **kw)`` with the HIP scorer as the
     ``model`` (same keyword names; ``audio`` may be a NumPy array or a torch tensor)."""
     if sampling_rate != SR:
@@ -182,7 +189,8 @@ def get_speech_timestamps(audio, model: HipSileroScorer, threshold: float = 0.5,
     audio = np.asarray(audio, dtype=np.float32).reshape(-1)
     if audio.shape[0] == 0:
         return []
-    probs = model.scores([audio])[0]
+    if probs is None:       # ``probs``: this clip's window probabilities from a batched scorer call (segment_many)
+        probs = model.scores([audio])[0]
     segs = regions_from_probs(probs, audio.shape[0], threshold=threshold, sampling_rate=sampling_rate,
                               min_speech_duration_ms=min_speech_duration_ms,
                               max_speech_duration_s=max_speech_duration_s,

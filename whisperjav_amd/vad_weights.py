@@ -57,6 +57,46 @@ def from_jit_state_dict(sd) -> Dict[str, np.ndarray]:
     return out
 
 
+def load_file(path: str) -> Dict[str, np.ndarray]:
+    """Trained parameters from a file: ``.npz`` / ``.safetensors`` holding either this module's names or the
+    TorchScript names, or the TorchScript archive itself (``silero_vad.jit``)."""
+    low = path.lower()
+    if low.endswith(".npz"):
+        sd = dict(np.load(path))
+    elif low.endswith(".safetensors"):
+        from safetensors.numpy import load_file as _load
+        sd = _load(path)
+    else:
+        import torch
+        sd = torch.jit.load(path, map_location="cpu").state_dict()
+    if "stft.forward_basis_buffer" in sd:
+        return {k: np.asarray(v, dtype=np.float32) for k, v in sd.items()}
+    return from_jit_state_dict(sd)
+
+
+def resolve(weights, weights_path=None) -> Dict[str, np.ndarray]:
+    """The scorer's parameter source (see ``vad.HipSileroScorer``): dict | "synthetic" | None (trained weights from
+    ``weights_path`` or the ``silero_vad`` package).  Raises when trained parameters were asked for and cannot be had."""
+    if isinstance(weights, dict):
+        return weights
+    if isinstance(weights, str):
+        if weights == "synthetic":
+            return synth_weights()
+        return load_file(weights)
+    if weights is not None:
+        raise TypeError("weights must be a dict, 'synthetic', a file path or None")
+    if weights_path:
+        return load_file(weights_path)
+    try:
+        import silero_vad  # type: ignore
+    except ImportError as e:
+        raise FileNotFoundError(
+            "HipSileroScorer needs trained Silero VAD parameters: pass weights_path=<silero_vad.jit | .npz | "
+            ".safetensors> (vad_weights.load_file) or install the silero-vad package; seeded random parameters are "
+            "only used when asked for explicitly (weights='synthetic')") from e
+    return from_jit_state_dict(silero_vad.load_silero_vad().state_dict())
+
+
 def pack(w: Dict[str, np.ndarray]) -> np.ndarray:
     """Flatten to the blob layout consumed by ``wj_vad_create``."""
     parts = [np.ascontiguousarray(w["stft.forward_basis_buffer"][:, 0, :].T)]           # [256][258]
