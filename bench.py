@@ -1,24 +1,35 @@
 #!/usr/bin/env python
-"""bench.py -- BASELINE.json's metric on the MI355X hot path.
+"""bench.py -- BASELINE.json's metric (real-time factor, end to end) on the MI355X hot path.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--strong] [--workload cfg3|cfg2] [--minutes 120]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of synthetic input per GPU: B windows of 30 s,
-16 kHz synthetic Japanese-speech-shaped audio already resident in HBM ->
-HIP log-mel -> Whisper large-v3 encoder (+ cross K/V) -> device-resident greedy decode of
-`decode_tokens` tokens per window (BASELINE cfg2: "Whisper large-v3 ja, 30 s chunk, mel + encoder +
-greedy decode, no VAD").  Weights are seeded random tensors of the large-v3 geometry (no checkpoints
-offline), packed once on rank 0 and broadcast to every rank over RCCL; after that there is no
-collective in the timed region (weak scaling: every GPU gets its own B windows).
+``--gpus N`` without a torchrun environment re-launches itself under ``torch.distributed.run`` with N ranks (one per
+GPU, RCCL); it fails loudly when fewer than N GPUs are visible.
 
-value = whole-job audio seconds processed per wall second (RTFx; /3600 = audio-hours per second).
-Prints ONE JSON line on rank 0 (plus human-readable notes on stderr).
+Default workload = BASELINE cfg3 at the length the target is quoted on: ``mode=balanced`` end to end on a 120-minute
+synthetic 16 kHz recording per GPU.  One "step" = one pass over one recording through the SAME code as the drop-in
+seams (``pipeline.RecordingTranscriber`` = steps 2-4 of ``BalancedPipeline.process`` over
+``asr.HipFasterWhisperProASR``): two-pass energy-gate scene detection (device frame energies) -> Silero-class VAD of all
+scenes in one launch -> groups <= 6 s -> log-mel -> Whisper large-v3 encoder -> device-resident beam search (beam 5,
+patience 1.2, repetition penalty 1.5, no-repeat-3-gram) -> segments stitched in scene order.  Weights are seeded random
+tensors of the large-v3 geometry (no checkpoints offline): rank 0 packs them, ONE RCCL broadcast, then no collective in
+the timed region.  ``--gpus N``: weak scaling (every GPU transcribes its own recording); ``--strong``: ONE recording
+whose scenes are LPT-sharded over the ranks (BASELINE cfg4).
+
+value = whole-job audio seconds per wall second (RTFx; / 3600 = audio-hours per second).  ONE JSON line on rank 0
+(human-readable notes on stderr), carrying ``roofline`` (dominant kernel, measured live with HIP events on the engine's
+stream), ``cpu_baseline`` (the oracle on a bounded sample), ``stages``, and the secondary figures: ``fp32_mode``
+(the exact-fp32 compute type on a bounded sample), ``word_timestamps`` (the reference's default, alignment pass on),
+``cfg2_batched`` / ``single_window`` (BASELINE cfg2 batched resp. read literally).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -34,223 +45,428 @@ from whisperjav_amd import weights as pweights  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = {"bfloat16": 2500.0, "float16": 2500.0, "float32": 157.3}   # dense peaks
+DT_LABEL = {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}
+METRIC = "audio-hours/sec (RTF) end-to-end, Whisper large-v3 ja"
+UNIT = "x real-time (audio-s per wall-s)"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def stage_model(tag, count, ms, dims, B, n_dec, prompt_len, dtype):
-    """Algorithmic work of one launch of a launch class -> (bound, achieved, unit, work_per_launch)."""
+# ---------------------------------------------------------------------------------------------------------------
+# algorithmic work per launch class
+# ---------------------------------------------------------------------------------------------------------------
+def stage_model(tag, count, ms, units, dims, dtype, beam, avg_keys):
+    """One launch class -> roofline entry.  ``units`` = windows summed over the class's launches, so the per-launch
+    batch is units / count (it varies: the last batch of a recording is smaller)."""
     if count == 0 or ms <= 0:
         return None
     esz = 4 if dtype == "float32" else 2
     d, H, T, V = dims.n_audio_state, dims.n_audio_head, dims.n_audio_ctx, dims.n_vocab
-    M = B * T
-    per = ms / count * 1e-3
+    sec = ms * 1e-3
+    w = float(units)                       # windows over all launches of the class
     flops = {
-        "conv1_gemm": 2.0 * B * 2 * T * d * 3 * dims.n_mels,
-        "conv2_gemm": 2.0 * M * d * 3 * d,
-        "enc_qk_gemm": 2.0 * M * 2 * d * d,
-        "enc_v_gemm": 2.0 * M * d * d,
-        "enc_out_gemm": 2.0 * M * d * d,
-        "enc_fc1_gemm": 2.0 * M * 4 * d * d,
-        "enc_fc2_gemm": 2.0 * M * 4 * d * d,
-        # bf16: two launches per layer (K head-split, V transposed per head), float32: one fused launch
-        "cross_kv_gemm": 2.0 * M * d * d * (2 if dtype == "float32" else 1),
-        "enc_attention": 4.0 * B * H * T * T * 64,
+        "conv1_gemm": 2.0 * w * 2 * T * d * 3 * dims.n_mels,
+        "conv2_gemm": 2.0 * w * T * d * 3 * d,
+        "enc_qk_gemm": 2.0 * w * T * 2 * d * d,
+        "enc_v_gemm": 2.0 * w * T * d * d,
+        "enc_out_gemm": 2.0 * w * T * d * d,
+        "enc_fc1_gemm": 2.0 * w * T * 4 * d * d,
+        "enc_fc2_gemm": 2.0 * w * T * 4 * d * d,
+        # 16-bit types: two launches per layer (K head-split, V transposed per head); float32: one fused launch
+        "cross_kv_gemm": 2.0 * w * T * d * d * (2 if dtype == "float32" else 1),
+        "enc_attention": 4.0 * w * H * T * T * 64,
     }
-    avg_keys = prompt_len + (n_dec + 1) / 2.0
+    rows = w * beam
     byts = {
-        "dec_cross_attn": B * H * T * 64 * 2.0 * esz,          # K and V of every resident window
-        "dec_self_attn": B * H * avg_keys * 64 * 2.0 * esz,
-        "dec_qkv_gemm": 3.0 * d * d * esz,
-        "dec_out_gemm": 1.0 * d * d * esz,
-        "dec_cq_gemm": 1.0 * d * d * esz,
-        "dec_cout_gemm": 1.0 * d * d * esz,
-        "dec_fc1_gemm": 4.0 * d * d * esz,
-        "dec_fc2_gemm": 4.0 * d * d * esz,
-        "dec_logits_gemm": 1.0 * V * d * esz + B * V * 4.0,
-        "dec_sample": B * V * 4.0 * 2,
-        "enc_layernorm": M * d * (4.0 + esz),
-        "dec_layernorm": B * d * (4.0 + esz),
-        "mel_to_rows": B * dims.n_mels * 2 * T * (4.0 + esz),
+        "dec_cross_attn": w * H * T * 64 * 2.0 * esz,          # K and V of every window in the launch, read once
+        "dec_self_attn": rows * H * avg_keys * 64 * 2.0 * esz,
+        "dec_qkv_gemm": count * 3.0 * d * d * esz,
+        "dec_out_gemm": count * 1.0 * d * d * esz,
+        "dec_cq_gemm": count * 1.0 * d * d * esz,
+        "dec_cout_gemm": count * 1.0 * d * d * esz,
+        "dec_fc1_gemm": count * 4.0 * d * d * esz,
+        "dec_fc2_gemm": count * 4.0 * d * d * esz,
+        "dec_logits_gemm": count * 1.0 * V * d * esz + rows * V * 4.0,
+        "dec_sample": rows * V * 4.0 * 2,
+        "enc_layernorm": w * T * d * (4.0 + esz),
+        "dec_layernorm": rows * d * (4.0 + esz),
+        "mel_to_rows": w * dims.n_mels * 2 * T * (4.0 + esz),
     }
     if tag in flops:
-        return {"bound": "mfma", "achieved": flops[tag] / per / 1e12, "unit": "TFLOP/s",
-                "peak": MFMA_PEAK_TFLOPS[dtype], "work": flops[tag]}
+        return {"bound": "mfma", "achieved": flops[tag] / sec / 1e12, "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS[dtype],
+                "work_per_launch": flops[tag] / count}
     if tag in byts:
-        return {"bound": "hbm", "achieved": byts[tag] / per / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                "work": byts[tag]}
+        return {"bound": "hbm", "achieved": byts[tag] / sec / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "work_per_launch": byts[tag] / count}
     return None
 
 
-def cpu_baseline(dims, w, audio, n_mels, decode_tokens, sample_tokens):
-    """The oracle (a CPU port of the reference's upstream math) timed on this host's cores for ONE
-    30 s window: full log-mel + full encoder + `sample_tokens` cached decode steps, the decode time
-    scaled linearly to `decode_tokens`."""
+def stages_from_profile(prof, dims, dtype, beam, avg_keys):
+    stages = {}
+    total_ms = sum(ms for _, ms, _ in prof.values()) or 1.0
+    for tag, (cnt, ms, units) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        entry = {"launches": cnt, "ms_total": round(ms, 3), "share": round(ms / total_ms, 4),
+                 "us_per_launch": round(1e3 * ms / cnt, 2), "windows_per_launch": round(units / cnt, 1)}
+        sm = stage_model(tag, cnt, ms, units, dims, dtype, beam, avg_keys)
+        if sm:
+            entry.update({"bound": sm["bound"], "achieved": round(sm["achieved"], 2), "unit": sm["unit"],
+                          "frac": round(sm["achieved"] / sm["peak"], 4), "work_per_launch": sm["work_per_launch"]})
+        stages[tag] = entry
+    enc = [k for k in stages if stages[k].get("bound") == "mfma"]
+    if enc:
+        fl = sum(stages[k]["achieved"] * stages[k]["ms_total"] for k in enc)
+        ms = sum(stages[k]["ms_total"] for k in enc)
+        stages["_encoder_mfma_aggregate"] = {"achieved": round(fl / ms, 2), "unit": "TFLOP/s",
+                                             "frac": round(fl / ms / MFMA_PEAK_TFLOPS[dtype], 4), "ms_total": round(ms, 3)}
+    return stages
+
+
+def roofline_from_stages(stages, dtype, tag_hint=None):
+    dom = tag_hint or next((k for k in stages if not k.startswith("_") and "bound" in stages[k]), None)
+    if dom is None or "bound" not in stages.get(dom, {}):
+        return None
+    e = stages[dom]
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_cross_attn_cfg3.json")
+    if dom == "dec_cross_attn" and dtype != "float32" and os.path.exists(pmc_file):
+        # rocprofv3 --pmc FETCH_SIZE pass of the same command (own pass, x2 gfx950 wide-read correction, MI355X_MICROARCH.md
+        # "HBM"); stored per window so that it scales to this run's windows per launch
+        pmc = json.load(open(pmc_file))
+        traffic = pmc["hbm_read_bytes_per_window"] * e["windows_per_launch"]
+    return {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"],
+            "peak": HBM_PEAK_GBS if e["bound"] == "hbm" else MFMA_PEAK_TFLOPS[dtype], "unit": e["unit"], "frac": e["frac"],
+            "traffic": traffic, "algorithmic_work_per_launch": e["work_per_launch"], "windows_per_launch": e["windows_per_launch"],
+            "us_per_launch": e["us_per_launch"], "share_of_profiled_kernel_time": e["share"]}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (port of the reference's upstream math) on a bounded sample
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline_cfg3(dims, w, clip, n_groups, audio_s, max_new, sample_tokens, beam):
+    """One VAD group of the recording on this host's cores: log-mel + full encoder + `sample_tokens` steps of the cfg3
+    beam search, decode scaled linearly to `max_new` steps; the recording costs `n_groups` such groups."""
     from oracle import decoding, logmel, whisper_ref
     threads = torch.get_num_threads()
     oracle = whisper_ref.WhisperOracle(whisper_ref.WhisperDims(**dims.as_dict()), w)
     toks = pdims.special_tokens(dims.n_vocab)
     prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
     t0 = time.perf_counter()
-    mel = logmel.window_features(audio, n_mels, "fw")
+    mel = logmel.window_features(clip, dims.n_mels, "fw")
     t_mel = time.perf_counter() - t0
     with torch.no_grad():
         t0 = time.perf_counter()
         enc = oracle.encode(torch.from_numpy(mel[None]))
         t_enc = time.perf_counter() - t0
         t0 = time.perf_counter()
-        decoding.greedy_decode(oracle, enc, prompt, sample_tokens, decoding.FilterConfig(max_initial_timestamp_index=50))
+        decoding.beam_search(oracle, enc, prompt, decoding.BeamConfig(beam, 1.2, 1.0, 1.5, 3, sample_tokens),
+                             decoding.FilterConfig(max_initial_timestamp_index=0))
         t_dec = time.perf_counter() - t0
-    total = t_mel + t_enc + t_dec * (decode_tokens + len(prompt) - 1) / (sample_tokens + len(prompt) - 1)
-    return {"value": 30.0 / total, "unit": "x real-time (audio-s per wall-s)", "cores": threads, "kind": "port",
-            "sample": (f"1 window of 30 s: log-mel + full large-v3-shaped encoder + {sample_tokens} of {decode_tokens} "
-                       f"cached greedy decode steps (decode scaled linearly), PyTorch-CPU fp32 oracle, "
-                       f"{threads} threads; mel {t_mel:.2f}s enc {t_enc:.2f}s dec({sample_tokens}) {t_dec:.2f}s")}
+    per_group = t_mel + t_enc + t_dec * (max_new + len(prompt) - 1) / (sample_tokens + len(prompt) - 1)
+    return {"value": audio_s / (per_group * n_groups), "unit": UNIT, "cores": threads, "kind": "port",
+            "sample": (f"1 of the recording's {n_groups} VAD groups ({len(clip) / 16000:.1f} s of audio -> one 30 s window): log-mel + "
+                       f"full large-v3-shaped encoder + {sample_tokens} of {max_new} beam-{beam} steps (decode scaled linearly), "
+                       f"PyTorch-CPU fp32 oracle, {threads} threads: mel {t_mel:.2f}s enc {t_enc:.2f}s dec({sample_tokens}) {t_dec:.2f}s; "
+                       f"value = recording seconds / (groups x per-group time); the reference's own CPU pipeline "
+                       f"(faster-whisper int8, 4 CT2 threads) cannot run offline -- wheels absent")}
 
 
-def split_scenes(detector, audio, sr=16000):
-    """Scenes <= 29 s from the reference's two-pass energy gate with the frame energies computed on the device
-    (whisperjav_amd/scenes.py mirrors scene_detection_backends/auditok_backend.py:229-567)."""
-    found, _ = detector.split_clip(audio, sr)
-    return [(int(a * sr), int(b * sr)) for a, b, _, _ in found if int(b * sr) - int(a * sr) > 400]
+# ---------------------------------------------------------------------------------------------------------------
+# the cfg3 stack: scene detector + VAD segmenter + model + ASR adapter + recording runner (the seam's own classes)
+# ---------------------------------------------------------------------------------------------------------------
+def transcribe_kwargs(args, words):
+    return dict(task="transcribe", language="ja", beam_size=args.beam, best_of=2, patience=1.2, temperature=[0.0],
+                repetition_penalty=1.5, no_repeat_ngram_size=3, condition_on_previous_text=False, suppress_blank=True,
+                max_initial_timestamp=0.0, no_speech_threshold=None, logprob_threshold=-1.0,
+                max_new_tokens=args.max_new_tokens, word_timestamps=bool(words))
 
 
-def run_cfg3(args, info, dims):
-    """BASELINE cfg3: mode=balanced -- scenes <= 29 s -> Silero-class VAD on the GPU -> groups <= 6 s ->
-    batched beam-5 transcription (patience 1.2, repetition penalty 1.5, no-repeat-3-gram,
-    condition_on_previous_text=False), 10 min of noisy synthetic audio on one GPU."""
-    from whisperjav_amd import segmenters, vad
+def build_stack(args, info, dims, dtype, batch, blob=None, offsets=None, weights=None, words=False):
+    from whisperjav_amd import asr, pipeline, scenes, segmenters
     from whisperjav_amd.whisper_model import HipWhisperModel
+    model = HipWhisperModel(args.model, compute_type=dtype, weights=weights, dims=dims, blob=blob, offsets=offsets,
+                            max_batch=batch, max_beam=args.beam, device_index=info.local_rank)
+    kw = transcribe_kwargs(args, words)
+    params = {"decoder": {k: v for k, v in kw.items() if k not in ("repetition_penalty", "no_repeat_ngram_size", "max_new_tokens")},
+              "provider": {"repetition_penalty": kw["repetition_penalty"], "no_repeat_ngram_size": kw["no_repeat_ngram_size"],
+                           "max_new_tokens": kw["max_new_tokens"]},
+              # BASELINE.md section 3: the balanced preset's Silero parameters (config/components/vad/silero.py:105-114)
+              "vad": dict(threshold=args.vad_threshold, min_speech_duration_ms=100, min_silence_duration_ms=300, speech_pad_ms=400,
+                          chunk_threshold_s=2.5, max_group_duration_s=6.0),
+              "speech_segmenter": {"backend": "silero-v6.2-hip"}}
+    # the Silero network's trained parameters are not available offline: seeded random ones, asked for explicitly
+    seg = segmenters.HipSileroV6SpeechSegmenter(weights="synthetic", device=info.local_rank, **params["vad"])
+    module = asr.HipFasterWhisperProASR({"model_name": args.model, "device": "cuda", "compute_type": dtype}, params, "transcribe",
+                                        whisper_model=model, segmenter=seg)
+    # gates above the synthetic clip's noise floor (the reference's 32 / 38 dB defaults sit below it and would only ever
+    # cut at max_duration)
+    det = scenes.HipAuditokSceneDetector(pass1_energy_threshold=52, pass2_energy_threshold=56, device=info.local_rank)
+    return model, module, pipeline.RecordingTranscriber(module, det)
+
+
+def run_recording(runner, audio, scene_subset=None):
+    """One step: scenes -> pooled VAD -> groups -> pooled beam-search transcription -> stitched segments."""
+    from whisperjav_amd import pipeline
+    t0 = time.perf_counter()
+    scenes = runner.detect(audio, pipeline.SR)
+    if scene_subset is not None:
+        scenes = [scenes[i] for i in scene_subset(scenes)]
+    t1 = time.perf_counter()
+    per_scene = runner.transcribe_scenes(audio, pipeline.SR, scenes)
+    t2 = time.perf_counter()
+    merged = runner.stitch(scenes, per_scene)
+    vad = runner.asr.get_vad_segments_per_scene()
+    return {"scenes": len(scenes), "segments": len(merged), "vad_segments": sum(len(v) for v in vad),
+            "scene_audio_s": round(sum(b - a for a, b in scenes), 1), "t_scene": round(t1 - t0, 4), "t_asr_incl_vad": round(t2 - t1, 4)}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` outside torchrun: become the launcher of N ranks."""
+    if not args.simulate:
+        n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n} GPU(s) visible on this node (one rank per GPU is required; "
+                             "use --simulate for the CPU/gloo dry run of the launcher)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def simulate(args, info):
+    """CPU dry run of the distributed shape of the bench (gloo): weight-blob broadcast, deterministic LPT plan, barrier +
+    max-over-ranks timing, object gather, ONE JSON line with n_gpus = world.  No GPU, no kernels -- it exercises the
+    launcher and the collectives' call pattern only (tests/test_sharding.py drives it with world size 2)."""
+    dev = torch.device("cpu")
+    blob = offsets = None
+    if info.rank == 0:
+        blob = torch.arange(4096, dtype=torch.uint8)
+        offsets = np.arange(0, 4096, 256, dtype=np.int64)
+    dev_blob, offsets = sharding.broadcast_blob(blob, offsets, dev)
+    assert int(dev_blob.sum()) == int(torch.arange(4096, dtype=torch.uint8).sum()) and len(offsets) == 16
+    rng = np.random.default_rng(7)
+    scenes = [(float(a), float(a + d)) for a, d in zip(np.arange(40) * 30.0, rng.uniform(2, 29, 40))]
+    plan = sharding.assign_lpt([b - a for a, b in scenes], info.world)
+    mine = plan[info.rank] if args.strong else list(range(len(scenes)))
+    sharding.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        done = {i: scenes[i][1] - scenes[i][0] for i in mine}
+    sharding.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev) + 1e-9
+    gathered = sharding.gather_objects(done, dst=0)
+    if info.rank == 0:
+        total = sum(sum(g.values()) for g in gathered)
+        if args.strong:
+            assert sorted(i for g in gathered for i in g) == list(range(len(scenes)))
+        print(json.dumps({"metric": METRIC, "value": round(total * args.steps / elapsed, 2), "unit": UNIT, "n_gpus": info.world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                          "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "simulated",
+                          "config": {"workload": "launcher dry run on CPU (gloo): no kernels, collectives and plan only",
+                                     "backend": "gloo", "scenes_per_rank": [len(p) for p in plan]},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cfg3 (default)
+# ---------------------------------------------------------------------------------------------------------------
+def run_cfg3(args, info, dims):
+    dev = torch.device("cuda", info.local_rank)
+    dtype = args.dtype
     minutes = args.minutes
-    audio = synth.speech_like(60.0 * minutes, seed=1234, noisy=True)
-    w = pweights.synth_weights(dims, seed=1234)
-    model = HipWhisperModel(args.model, compute_type=args.dtype, weights=w, dims=dims, max_batch=args.batch,
-                            max_beam=5, device_index=info.local_rank)
-    del w
-    seg = segmenters.HipSileroV6SpeechSegmenter(threshold=0.5, min_speech_duration_ms=100, min_silence_duration_ms=300,
-                                               speech_pad_ms=400, chunk_threshold_s=2.5, max_group_duration_s=6.0,
-                                               device=info.local_rank)
-    kw = dict(task="transcribe", language="ja", beam_size=5, best_of=2, patience=1.2, temperature=[0.0],
-              repetition_penalty=1.5, no_repeat_ngram_size=3, condition_on_previous_text=False, suppress_blank=True,
-              max_initial_timestamp=0.0, no_speech_threshold=None, log_prob_threshold=-1.0,
-              max_new_tokens=args.max_new_tokens, word_timestamps=bool(args.word_timestamps))
+    t_start = time.perf_counter()
+    # ---- weights (rank 0) and audio (every rank) are prepared concurrently ---------------------------------------
+    box = {}
 
-    from whisperjav_amd import scenes as _scenes
-    # gates above the synthetic clip's -45 dBFS noise floor (the reference's 32 / 38 dB defaults sit below it and would
-    # only ever cut at max_duration)
-    scene_detector = _scenes.HipAuditokSceneDetector(pass1_energy_threshold=52, pass2_energy_threshold=56, device=info.local_rank)
+    def make_weights():
+        w = pweights.synth_weights(dims, seed=1234, exact="float16")      # fp16-representable, like the published checkpoints
+        box["w"] = w
+        box["blob"], box["offsets"] = pweights.pack_blob(dims, w, dtype)
+    th = None
+    if info.rank == 0:
+        th = threading.Thread(target=make_weights)
+        th.start()
+    seed = 1234 if args.strong else 1234 + 100003 * info.rank          # weak scaling: every GPU has its own recording
+    audio = synth.speech_like_long(60.0 * minutes, seed=seed, noisy=True)
+    t_audio = time.perf_counter() - t_start
+    if th is not None:
+        th.join()
+    dev_blob, offsets = sharding.broadcast_blob(box.get("blob"), box.get("offsets"), dev)     # the ONE collective
+    box.pop("blob", None)
+    model, module, runner = build_stack(args, info, dims, dtype, args.batch, blob=dev_blob, offsets=offsets)
+    log(f"[bench] rank {info.rank}: audio {t_audio:.1f}s, weights + broadcast + model ready after {time.perf_counter() - t_start:.1f}s; "
+        f"workspace {model.model.workspace_bytes / 2**30:.1f} GiB, blob {dev_blob.numel() / 2**30:.2f} GiB")
 
-    def once():
-        t0 = time.perf_counter()
-        scenes = split_scenes(scene_detector, audio)
-        t1 = time.perf_counter()
-        seg._ensure_model()
-        probs = seg._model.scores([audio[a:b] for a, b in scenes])          # every scene scored concurrently
-        groups = []
-        for (a, b), p in zip(scenes, probs):
-            regions = vad.regions_from_probs(p, b - a, threshold=seg.threshold,
-                                             min_speech_duration_ms=seg.min_speech_duration_ms,
-                                             max_speech_duration_s=seg.max_speech_duration_s,
-                                             min_silence_duration_ms=seg.min_silence_duration_ms,
-                                             speech_pad_ms=seg.speech_pad_ms)
-            segs = [segmenters.SpeechSegment(r["start"] / 16000, r["end"] / 16000, r["start"], r["end"]) for r in regions]
-            for g in segmenters.group_segments(segs, seg.max_group_duration_s, seg.chunk_threshold_s):
-                groups.append((a + g[0].start_sample, a + g[-1].end_sample))
-        t2 = time.perf_counter()
-        clips = [audio[a:b] for a, b in groups if b - a > 400]
-        out, _ = model.transcribe_many(clips, **kw)
-        t3 = time.perf_counter()
-        from whisperjav_amd import search as _search
-        calls = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in c.items()} for c in _search.TIMING_LOG]
-        _search.TIMING_LOG.clear()
-        return {"beam_timing": calls,
-                "scenes": len(scenes), "groups": len(clips), "segments": sum(len(x) for x in out),
-                "speech_s": sum(len(c) for c in clips) / 16000.0, "t_scene": t1 - t0, "t_vad": t2 - t1, "t_asr": t3 - t2}
+    subset = None
+    if args.strong and info.world > 1:
+        def subset(scenes):           # deterministic on every rank: no exchange needed
+            return sharding.assign_lpt([b - a for a, b in scenes], info.world)[info.rank]
 
+    stats = None
     for _ in range(args.warmup):
-        once()
+        stats = run_recording(runner, audio, subset)
+    sharding.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    stats = None
     for _ in range(args.steps):
-        stats = once()
+        stats = run_recording(runner, audio, subset)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    rtfx = 60.0 * minutes * args.steps / elapsed
-    stages = {}
-    if not args.no_profile:     # one more (eager, event-timed) pass: where the ASR time goes per launch class
+    sharding.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    audio_s = 60.0 * minutes * args.steps * (1 if args.strong else info.world)
+    rtfx = audio_s / elapsed
+    per_rank = sharding.gather_objects(stats, dst=0)
+
+    line = None
+    if info.rank == 0:
+        line = {"metric": METRIC, "value": round(rtfx, 2), "unit": UNIT, "audio_hours_per_sec": round(rtfx / 3600.0, 5),
+                "n_gpus": info.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+                "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+                "dtype": DT_LABEL[dtype], "data": "synthetic",
+                "config": {"workload": (f"cfg3-{minutes:g}min: mode=balanced end to end on {minutes:g} min of noisy synthetic 16 kHz audio per "
+                                        f"{'job' if args.strong else 'GPU'}: two-pass energy-gate scenes <= 29 s (device frame energies), "
+                                        f"Silero-class HIP VAD (threshold {args.vad_threshold}, seeded random parameters), groups <= 6 s, "
+                                        f"Whisper {args.model} geometry (seeded random fp16-representable weights), beam {args.beam} / patience 1.2 / "
+                                        f"repetition penalty 1.5 / no-repeat-3-gram, max_new_tokens={args.max_new_tokens} (random weights "
+                                        f"never emit EOT: every window decodes exactly this many tokens), word_timestamps=False, "
+                                        f"through pipeline.RecordingTranscriber over asr.HipFasterWhisperProASR (the drop-in seam's classes)"),
+                           "windows_per_batch": args.batch, "compute_type": dtype, "max_new_tokens": args.max_new_tokens,
+                           "parallelism": (f"scene-parallel x{info.world} ({'one recording LPT-sharded' if args.strong else 'one recording per GPU'}), "
+                                           f"one RCCL weight broadcast, no data-path collective"),
+                           "per_rank_last_step": per_rank},
+                "roofline": None, "cpu_baseline": None, "stages": {}}
+
+    # ---- extras on rank 0 of a single-GPU run: live stage profile, CPU baseline, secondary figures ---------------
+    if info.rank == 0 and info.world == 1 and not args.no_profile:
         from whisperjav_amd import hipbind
         ctx = hipbind.context(info.local_rank)
-        ctx.profile_start()
-        once()
-        prof = ctx.profile_stop()
-        total_ms = sum(ms for _, ms in prof.values()) or 1.0
-        for tag, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]:
-            stages[tag] = {"launches": cnt, "ms_total": round(ms, 3), "share": round(ms / total_ms, 4),
-                           "us_per_launch": round(1e3 * ms / max(cnt, 1), 2)}
-    line = {"metric": "audio-hours/sec (RTF) end-to-end, Whisper large-v3 ja", "value": round(rtfx, 2),
-            "unit": "x real-time (audio-s per wall-s)", "audio_hours_per_sec": round(rtfx / 3600.0, 5), "n_gpus": 1,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.dtype], "data": "synthetic",
-            "config": {"workload": (f"cfg3: mode=balanced on {minutes} min of noisy synthetic audio: two-pass energy-gate scenes <= 29 s (device frame energies), "
-                                    f"HIP Silero-class VAD, groups <= 6 s, Whisper {args.model} geometry (seeded random "
-                                    f"weights), beam 5 / patience 1.2 / repetition penalty 1.5 / no-repeat-3-gram, "
-                                    f"max_new_tokens={args.max_new_tokens}, device-resident beam search"),
-                       "windows_per_batch": args.batch, "compute_type": args.dtype, **stats},
-            "roofline": None, "cpu_baseline": None, "stages": stages}
-    print(json.dumps(line), flush=True)
-    model.close()
+        ctx.profile_start()          # eager replay of one step with a HIP event pair around every launch
+        run_recording(runner, audio, subset)
+        prof = ctx.profile_stop_units()
+        avg_keys = 3 + (args.max_new_tokens + 1) / 2.0
+        line["stages"] = stages_from_profile(prof, dims, dtype, args.beam, avg_keys)
+        line["roofline"] = roofline_from_stages(line["stages"], dtype)
+        n_windows = prof.get("conv1_gemm", (0, 0, 0))[2]
+        line["config"]["windows_per_step"] = n_windows
+    if info.rank == 0 and info.world == 1 and not args.no_extras:
+        # word_timestamps=True (the reference's default, config/components/asr/faster_whisper.py:298): every window also runs
+        # the alignment pass; the word-driven re-seek is switched off (random weights align noise, see whisper_model.word_reseek)
+        module.whisper_params["word_timestamps"] = True
+        model.word_reseek = False
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_recording(runner, audio, subset)
+        torch.cuda.synchronize()
+        tw = time.perf_counter() - t1
+        module.whisper_params["word_timestamps"] = False
+        model.word_reseek = True
+        line["word_timestamps"] = {"rtfx": round(60.0 * minutes / tw, 2), "ms": round(1e3 * tw, 1),
+                                   "what": "the same step with word_timestamps=True (alignment pass + DTW per window); word-driven re-seek off"}
+        # BASELINE cfg2 on the same model: 384 x 30 s windows, log-mel + encoder + greedy decode of 224 tokens (no VAD)
+        from whisperjav_amd import engine
+        B = args.batch
+        clips = [synth.speech_like(30.0, seed=1234 + i) for i in range(4)]
+        pcm = torch.from_numpy(np.concatenate([clips[i % 4] for i in range(B)])).to(dev)
+        offs = [i * 480000 for i in range(B + 1)]
+        fe = engine.HipLogMel(dims.n_mels, "fw", device=info.local_rank)
+        eng = model.model
+        prompt = np.tile(np.array(eng.sot_prompt("ja", "transcribe"), dtype=np.int32), (B, 1))
+        t = eng.tokens
+        opts = engine.DecodeOptions(max_new_tokens=224, max_initial_timestamp=1.0,
+                                    suppress_tokens=(t.sot, t.translate, t.transcribe, t.sot_lm, t.sot_prev, t.no_speech))
+
+        def cfg2(n, pr, of):
+            eng.encode(fe.from_device(pcm[: of[-1]], of))
+            eng.decode_greedy(pr, opts)
+        cfg2(B, prompt, offs)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        cfg2(B, prompt, offs)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter() - t1
+        line["cfg2_batched"] = {"rtfx": round(30.0 * B / t2, 2), "ms": round(1e3 * t2, 1),
+                                "what": f"BASELINE cfg2 batched: {B} x 30 s windows resident in HBM, log-mel + encoder + greedy 224 tokens, no VAD"}
+        best = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cfg2(1, prompt[:1], offs[:2])
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t1)
+        line["single_window"] = {"rtfx": round(30.0 / best, 2), "ms": round(1e3 * best, 2),
+                                 "what": "BASELINE cfg2 read literally: ONE 30 s window, batch 1 (the reference's call pattern): a latency figure"}
+        del pcm
+    # the groups of the recording, for the CPU baseline's scaling (before the model goes away)
+    n_groups = None
+    first_clip = None
+    if info.rank == 0 and info.world == 1 and (not args.no_cpu_baseline or not args.no_extras):
+        scenes = runner.detect(audio, 16000)
+        sc = runner.scene_audio(audio, 16000, scenes[0])
+        res = module._external_segmenter.segment(sc, sample_rate=16000)
+        g = res.groups[0] if res.groups else None
+        first_clip = sc[g[0].start_sample: g[-1].end_sample] if g else sc[: 16000 * 5]
+        n_groups = line["config"].get("windows_per_step") or max(1, int(60 * minutes / 4.5))
+    module.cleanup()
+    del model, module, runner, dev_blob
+    torch.cuda.empty_cache()
+
+    if info.rank == 0 and info.world == 1 and not args.no_extras:
+        # the exact-fp32 compute type (north-star parity type, 1e-5 of the oracle) on a bounded sample of the same recording
+        fp32_audio = audio[: int(16000 * 60 * args.fp32_minutes)]
+        m32, mod32, run32 = build_stack(args, info, dims, "float32", 64, weights=box["w"])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        s32 = run_recording(run32, fp32_audio)
+        torch.cuda.synchronize()
+        t32 = time.perf_counter() - t1
+        mod32.cleanup()
+        line["fp32_mode"] = {"rtfx": round(60.0 * args.fp32_minutes / t32, 2), "ms": round(1e3 * t32, 1),
+                             "what": (f"compute_type float32 (exact-fp32 kernels, the 1e-5 parity type) on the first {args.fp32_minutes:g} min "
+                                      f"of the same recording, same pipeline, 64 windows per batch, one cold pass"), **s32}
+        del m32, mod32, run32
+        torch.cuda.empty_cache()
+    if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_cfg3(dims, box["w"], first_clip, n_groups, 60.0 * minutes, args.max_new_tokens,
+                                                 args.cpu_sample_tokens, args.beam)
+    if info.rank == 0:
+        print(json.dumps(line), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    return 0
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=384, help="30 s windows per GPU per step (384: 133 GiB of workspace, cross K/V resident)")
-    ap.add_argument("--decode-tokens", type=int, default=224, help="new tokens per window (n_text_ctx // 2)")
-    ap.add_argument("--model", default="large-v3")
-    ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16", "float32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--cpu-sample-tokens", type=int, default=32)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
-    ap.add_argument("--minutes", type=float, default=10.0, help="cfg3: synthetic audio length")
-    ap.add_argument("--max-new-tokens", type=int, default=64, help="cfg3: transcribe(max_new_tokens=...)")
-    ap.add_argument("--word-timestamps", type=int, default=0, help="cfg3: transcribe(word_timestamps=...)")
-    args = ap.parse_args()
-
-    info = sharding.init_distributed()
-    if args.gpus != info.world:
-        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={info.world}; using WORLD_SIZE")
+# ---------------------------------------------------------------------------------------------------------------
+# cfg2 (secondary workload: batched 30 s windows, mel + encoder + greedy decode, no VAD)
+# ---------------------------------------------------------------------------------------------------------------
+def run_cfg2(args, info, dims):
     from whisperjav_amd import engine, hipbind
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(info.local_rank)
     dev = torch.device("cuda", info.local_rank)
-    dims = pdims.dims_for(args.model)
-    if args.workload == "cfg3":
-        return run_cfg3(args, info, dims)
-    B, n_dec = args.batch, args.decode_tokens
-
-    # ---- weights: packed once on rank 0, ONE RCCL broadcast, then no collectives -------------
+    B, n_dec, dtype = args.batch, args.decode_tokens, args.dtype
     t0 = time.perf_counter()
     w = blob = offsets = None
     if info.rank == 0:
-        w = pweights.synth_weights(dims, seed=1234)
-        blob, offsets = pweights.pack_blob(dims, w, args.dtype)
+        w = pweights.synth_weights(dims, seed=1234, exact="float16")
+        blob, offsets = pweights.pack_blob(dims, w, dtype)
     dev_blob, offsets = sharding.broadcast_blob(blob, offsets, dev)
     del blob
-    model = engine.HipWhisper(dims, blob=dev_blob, offsets=offsets, dtype=args.dtype, device=info.local_rank,
-                              max_batch=B, max_beam=1)
+    model = engine.HipWhisper(dims, blob=dev_blob, offsets=offsets, dtype=dtype, device=info.local_rank, max_batch=B, max_beam=1)
     log(f"[bench] rank {info.rank}: weights ready in {time.perf_counter() - t0:.1f}s, workspace "
         f"{model.workspace_bytes / 2**30:.1f} GiB, blob {dev_blob.numel() / 2**30:.2f} GiB")
-
-    # ---- synthetic audio resident in HBM ---------------------------------------------------------
     distinct = [synth.speech_like(30.0, seed=1234 + 17 * info.rank + i) for i in range(min(B, 4))]
     clips = [distinct[i % len(distinct)] for i in range(B)]
     pcm = torch.from_numpy(np.concatenate(clips)).to(dev)
@@ -260,13 +476,10 @@ def main():
     toks = model.tokens
     suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
     opts = engine.DecodeOptions(max_new_tokens=n_dec, suppress_tokens=suppress, max_initial_timestamp=1.0)
-    decoded = {"n": None}
 
     def step():
-        mel = fe.from_device(pcm, offs)
-        model.encode(mel)
-        res = model.decode_greedy(prompt, opts)
-        decoded["n"] = res.n_tokens
+        model.encode(fe.from_device(pcm, offs))
+        model.decode_greedy(prompt, opts)
 
     for _ in range(args.warmup):
         step()
@@ -278,89 +491,71 @@ def main():
     torch.cuda.synchronize()
     sharding.barrier()
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
-    audio_s = 30.0 * B * info.world * args.steps
-    rtfx = audio_s / elapsed
-
-    # ---- live per-launch-class timing with HIP events (eager replay of one step) ---------------
+    rtfx = 30.0 * B * info.world * args.steps / elapsed
     stages, roofline = {}, None
     if not args.no_profile and info.rank == 0:
         ctx = hipbind.context(info.local_rank)
         n_prof = min(n_dec, 48)   # the per-launch averages do not need all 224 eager steps
         popts = engine.DecodeOptions(max_new_tokens=n_prof, suppress_tokens=suppress, max_initial_timestamp=1.0)
         ctx.profile_start()
-        mel = fe.from_device(pcm, offs)
-        model.encode(mel)
+        model.encode(fe.from_device(pcm, offs))
         model.decode_greedy(prompt, popts)
-        prof = ctx.profile_stop()
-        total_ms = sum(ms for _, ms in prof.values())
-        for tag, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
-            entry = {"launches": cnt, "ms_total": round(ms, 3), "share": round(ms / total_ms, 4),
-                     "us_per_launch": round(1e3 * ms / cnt, 2)}
-            sm = stage_model(tag, cnt, ms, dims, B, n_prof, prompt.shape[1], args.dtype)
-            if sm:
-                entry.update({"bound": sm["bound"], "achieved": round(sm["achieved"], 2), "unit": sm["unit"],
-                              "frac": round(sm["achieved"] / sm["peak"], 4)})
-            stages[tag] = entry
-        dom = next(iter(stages))
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", f"r01_pmc_cross_attn_b{B}.json")
-        if dom == "dec_cross_attn" and os.path.exists(pmc_file) and args.dtype != "float32":
-            pmc = json.load(open(pmc_file))   # rocprofv3 --pmc FETCH_SIZE pass at this batch, x2 gfx950 wide-read correction
-            if "expected_average_bytes_per_launch" not in pmc:     # single-chain passes only (one launch = all windows)
-                traffic = pmc["hbm_read_bytes_per_launch"]
-        if "bound" in stages[dom]:
-            e = stages[dom]
-            roofline = {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"],
-                        "peak": HBM_PEAK_GBS if e["bound"] == "hbm" else MFMA_PEAK_TFLOPS[args.dtype],
-                        "unit": e["unit"], "frac": e["frac"], "traffic": traffic,
-                        "algorithmic_bytes_per_launch": B * dims.n_text_head * dims.n_audio_ctx * 64 * 2 * (4 if args.dtype == "float32" else 2) if dom == "dec_cross_attn" else None,
-                        "share_of_step": e["share"], "us_per_launch": e["us_per_launch"]}
-        enc = [k for k in stages if k.startswith("enc_") and stages[k].get("bound") == "mfma"]
-        if enc:
-            fl = sum(stages[k]["achieved"] * stages[k]["ms_total"] for k in enc)
-            ms = sum(stages[k]["ms_total"] for k in enc)
-            stages["_encoder_mfma_aggregate"] = {"achieved": round(fl / ms, 2), "unit": "TFLOP/s",
-                                                 "frac": round(fl / ms / MFMA_PEAK_TFLOPS[args.dtype], 4)}
-
-    cpu = None
-    if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(dims, w, clips[0], dims.n_mels, n_dec, args.cpu_sample_tokens)
-
+        stages = stages_from_profile(ctx.profile_stop_units(), dims, dtype, 1, prompt.shape[1] + (n_prof + 1) / 2.0)
+        roofline = roofline_from_stages(stages, dtype)
+        if roofline:
+            roofline["note"] = f"profiled pass decodes {n_prof} tokens: shares are of that pass, not of the {n_dec}-token step"
     if info.rank == 0:
-        # BASELINE configs[1] read literally -- ONE 30 s chunk at a time (batch 1, the reference's own call pattern):
-        # a latency figure reported beside the throughput `value`, never instead of it
-        single = None
-        if not args.no_profile:
-            offs1, prompt1 = offs[:2], prompt[:1]
-            best = float("inf")
-            for _ in range(3):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                model.encode(fe.from_device(pcm[: 480000], offs1))
-                model.decode_greedy(prompt1, opts)
-                torch.cuda.synchronize()
-                best = min(best, time.perf_counter() - t1)
-            single = {"rtfx": round(30.0 / best, 2), "ms": round(1e3 * best, 2),
-                      "what": f"one 30 s window alone: log-mel + encoder + {n_dec} greedy tokens, batch 1"}
-        line = {
-            "metric": "audio-hours/sec (RTF) end-to-end, Whisper large-v3 ja",
-            "value": round(rtfx, 2), "unit": "x real-time (audio-s per wall-s)",
-            "audio_hours_per_sec": round(rtfx / 3600.0, 5),
-            "n_gpus": info.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[args.dtype], "data": "synthetic",
-            "config": {"workload": (f"cfg2: Whisper {args.model} geometry (seeded random weights), {B} x 30 s 16 kHz "
-                                    f"windows per GPU per step resident in HBM: log-mel + encoder + greedy decode of "
-                                    f"{n_dec} tokens/window with timestamp rules, no VAD"),
-                       "windows_per_gpu": B, "decode_tokens": n_dec, "compute_type": args.dtype,
+        print(json.dumps({
+            "metric": METRIC, "value": round(rtfx, 2), "unit": UNIT, "audio_hours_per_sec": round(rtfx / 3600.0, 5),
+            "n_gpus": info.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DT_LABEL[dtype], "data": "synthetic",
+            "config": {"workload": (f"cfg2: Whisper {args.model} geometry (seeded random weights), {B} x 30 s 16 kHz windows per GPU per step "
+                                    f"resident in HBM: log-mel + encoder + greedy decode of {n_dec} tokens/window with timestamp rules, no VAD"),
+                       "windows_per_gpu": B, "decode_tokens": n_dec, "compute_type": dtype,
                        "parallelism": f"scene-parallel x{info.world}, one RCCL weight broadcast, no data-path collective"},
-            "roofline": roofline, "cpu_baseline": cpu, "single_window": single, "stages": stages,
-        }
-        print(json.dumps(line), flush=True)
+            "roofline": roofline, "cpu_baseline": None, "stages": stages}), flush=True)
     model.close()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--minutes", type=float, default=120.0, help="cfg3: length of the synthetic recording")
+    ap.add_argument("--strong", action="store_true", help="cfg3 with --gpus N: ONE recording, scenes LPT-sharded over the ranks (cfg4)")
+    ap.add_argument("--batch", type=int, default=384, help="30 s windows resident per GPU (384: cross K/V of a batch = 94 GB)")
+    ap.add_argument("--beam", type=int, default=5)
+    ap.add_argument("--max-new-tokens", type=int, default=64, help="cfg3: transcribe(max_new_tokens=...); swept 32/64/224 in profiles/")
+    ap.add_argument("--vad-threshold", type=float, default=0.28, help="BASELINE.md section 3 (balanced preset)")
+    ap.add_argument("--decode-tokens", type=int, default=224, help="cfg2: new tokens per window (n_text_ctx // 2)")
+    ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16", "float32"])
+    ap.add_argument("--fp32-minutes", type=float, default=3.0, help="cfg3: audio minutes of the fp32-mode figure")
+    ap.add_argument("--cpu-sample-tokens", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (fp32 mode, word timestamps, cfg2, single window)")
+    ap.add_argument("--simulate", action="store_true", help="CPU/gloo dry run of the launcher and the collectives (no GPU, no kernels)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    info = sharding.init_distributed("gloo" if args.simulate else None)
+    if args.gpus != info.world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {info.world} rank(s)")
+    if args.simulate:
+        return simulate(args, info)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(info.local_rank)
+    dims = pdims.dims_for(args.model)
+    return run_cfg3(args, info, dims) if args.workload == "cfg3" else run_cfg2(args, info, dims)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -74,6 +74,9 @@ int wj_profile_start(wj_ctx* ctx);
 int wj_profile_tags(void);
 const char* wj_profile_tag_name(int tag);
 int wj_profile_stop(wj_ctx* ctx, double* total_ms, int64_t* counts, int n_tags);
+/* as wj_profile_stop, plus units[tag] = sum over the class's launches of the windows in the launch's batch (the
+ * algorithmic bytes of a decode cross-attention launch are windows x 2 x H x 1500 x 64 x element size) */
+int wj_profile_stop_ex(wj_ctx* ctx, double* total_ms, int64_t* counts, int64_t* units, int n_tags);
 
 /* ---- log-mel ---------------------------------------------------------------------------
  * Replaces: faster_whisper.feature_extractor.FeatureExtractor.__call__ (entered from

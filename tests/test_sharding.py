@@ -111,3 +111,26 @@ def test_scene_parallel_driver_two_ranks(tmp_path):
     starts = [s["start"] for s in r0["merged"]]
     assert starts == sorted(starts) and starts[0] == pytest.approx(0.2)
     assert {s["text"].split("@")[0] for s in r0["merged"] if "@" in s["text"]} == {"rank0", "rank1"}
+
+
+def test_bench_launcher_spawns_its_own_ranks_gloo_dry_run():
+    """``python bench.py --gpus 2`` outside torchrun becomes the launcher of two ranks; the CPU dry run (``--simulate``,
+    gloo) exercises the launcher, the weight-blob broadcast, the deterministic LPT plan of ``--strong``, the barrier +
+    max-over-ranks timing and the gather, and prints ONE JSON line with n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--simulate", "--strong", "--steps", "3",
+                          "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong" and line["config"]["backend"] == "gloo"
+    assert sum(line["config"]["scenes_per_rank"]) == 40
+    # asking for more GPUs than the node has is an error, not a silent single-rank run
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                         text=True, timeout=120, env=env, cwd=root)
+    assert res.returncode != 0 and "GPU(s) visible" in (res.stderr + res.stdout)

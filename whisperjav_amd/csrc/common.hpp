@@ -58,6 +58,7 @@ struct wj_ctx {
   // event-pair profiler (wj_profile_start/stop): per-tag kernel time measured with HIP events on the
   // stream the kernels are launched on
   struct wj_profiler* prof = nullptr;
+  int64_t prof_units = 1;   // work units of the launches being profiled (windows of the batch), set by the callers
 };
 
 namespace wj {

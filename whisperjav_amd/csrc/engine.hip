@@ -22,7 +22,7 @@ const char* get_error() { return g_err; }
 using namespace wj;
 
 struct wj_profiler {
-  struct Pair { int tag; hipEvent_t a, b; };
+  struct Pair { int tag; hipEvent_t a, b; int64_t units; };
   std::vector<Pair> pairs;
   int open_tag = -1;
   hipEvent_t open_a = nullptr;
@@ -48,7 +48,7 @@ void prof_end(wj_ctx* ctx, hipStream_t s) {
   hipEvent_t b = nullptr;
   if (hipEventCreate(&b) != hipSuccess) return;
   (void)hipEventRecord(b, s);
-  p->pairs.push_back({p->open_tag, p->open_a, b});
+  p->pairs.push_back({p->open_tag, p->open_a, b, ctx->prof_units});
   p->open_tag = -1;
 }
 }  // namespace wj
@@ -215,6 +215,7 @@ static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, flo
   const wj_whisper_dims& d = m->d;
   const int D = d.n_audio_state, H = d.n_audio_head, C = d.n_mels, T = d.n_audio_ctx, F = m->frames;
   const int dt = m->dtype;
+  m->ctx->prof_units = B;
   PROF(PT_MEL_ROWS, launch_mel_to_rows(dt, mel, m->mel_rows, B, C, F, s));
   {  // conv1 (k=3, pad 1) as a GEMM over the overlapping [t-1, t, t+1] row window + GELU
     GemmArgs g;
@@ -313,6 +314,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   if (!pos) pos = m->pos;
   const wj_whisper_dims& d = m->d;
   const int D = d.n_text_state, H = d.n_text_head, dt = m->dtype;
+  m->ctx->prof_units = n_windows;
   const int win0 = row0 / beam;
   const int split = m->split_act ? 1 : 0, sm = split ? 2 : 1;   // activation rows [hi | lo] for the decode GEMMs
   float* dx = m->dx + (int64_t)row0 * D;
@@ -644,16 +646,21 @@ int wj_profile_tags(void) { return PT_COUNT; }
 const char* wj_profile_tag_name(int tag) { return (tag >= 0 && tag < PT_COUNT) ? kProfNames[tag] : ""; }
 
 int wj_profile_stop(wj_ctx* ctx, double* total_ms, int64_t* counts, int n_tags) {
+  return wj_profile_stop_ex(ctx, total_ms, counts, nullptr, n_tags);
+}
+
+int wj_profile_stop_ex(wj_ctx* ctx, double* total_ms, int64_t* counts, int64_t* units, int n_tags) {
   WJ_REQUIRE(ctx && total_ms && counts && n_tags >= PT_COUNT, "wj_profile_stop: bad arguments");
   wj_profiler* p = ctx->prof;
   WJ_REQUIRE(p != nullptr, "wj_profile_stop: profiler not started");
   WJ_HIP(hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i < n_tags; ++i) { total_ms[i] = 0.0; counts[i] = 0; }
+  for (int i = 0; i < n_tags; ++i) { total_ms[i] = 0.0; counts[i] = 0; if (units) units[i] = 0; }
   for (auto& pr : p->pairs) {
     float ms = 0.f;
     if (hipEventSynchronize(pr.b) == hipSuccess && hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
       total_ms[pr.tag] += ms;
       counts[pr.tag] += 1;
+      if (units) units[pr.tag] += pr.units;
     }
     (void)hipEventDestroy(pr.a);
     (void)hipEventDestroy(pr.b);

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "wj_profile_tags": (_I, []),
     "wj_profile_tag_name": (C.c_char_p, [_I]),
     "wj_profile_stop": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I64), _I]),
+    "wj_profile_stop_ex": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I64), _I]),
     "wj_logmel_frames": (_I64, [_I64, _I]),
     "wj_logmel_f32": (_I, [_P, _P, C.POINTER(_I64), _I, _I, _I, _I, _P, _P]),
     "wj_frame_sumsq": (_I, [_P, _P, _I64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _I64, C.POINTER(C.c_int64), _P]),
@@ -158,6 +159,16 @@ class Context:
         cnt = (_I64 * n)()
         check(self._lib.wj_profile_stop(self.handle, ms, cnt, n), "wj_profile_stop")
         return {self._lib.wj_profile_tag_name(i).decode(): (int(cnt[i]), float(ms[i]))
+                for i in range(n) if cnt[i]}
+
+    def profile_stop_units(self) -> dict:
+        """{launch class: (count, total_ms, units)}; units = windows summed over the class's launches."""
+        n = self._lib.wj_profile_tags()
+        ms = (C.c_double * n)()
+        cnt = (_I64 * n)()
+        units = (_I64 * n)()
+        check(self._lib.wj_profile_stop_ex(self.handle, ms, cnt, units, n), "wj_profile_stop_ex")
+        return {self._lib.wj_profile_tag_name(i).decode(): (int(cnt[i]), float(ms[i]), int(units[i]))
                 for i in range(n) if cnt[i]}
 
     def close(self) -> None:

@@ -32,8 +32,12 @@ SR = 16000
 def pcm16_roundtrip(chunk: np.ndarray) -> np.ndarray:
     """What writing a scene as PCM_16 (``save_scene_wav``: soundfile scales by 32768 and rounds) and reading it back as
     float32 (``sf.read``: int16 / 32768) does to the samples."""
-    q = np.clip(np.rint(np.asarray(chunk, dtype=np.float64) * 32768.0), -32768, 32767)
-    return (q / 32768.0).astype(np.float32)
+    x = np.asarray(chunk)
+    if x.dtype != np.float32:
+        x = x.astype(np.float64)
+    # float32 input: x * 2^15, rint, clip and / 2^15 are all exact in float32, so the result equals the float64 route
+    q = np.clip(np.rint(x * x.dtype.type(32768.0)), -32768, 32767)
+    return (q / x.dtype.type(32768.0)).astype(np.float32)
 
 
 def to_16k(audio: np.ndarray, sr: int) -> np.ndarray:

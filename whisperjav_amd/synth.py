@@ -71,3 +71,28 @@ def speech_like(duration_s: float, seed: int = 1234, noisy: bool = False) -> np.
         noise *= speech_rms * 10 ** (-10 / 20) / (np.sqrt(np.mean(noise ** 2)) + 1e-12)
         out += noise
     return np.clip(out, -1.0, 1.0).astype(np.float32)
+
+
+def _chunk(job):
+    dur, seed, noisy = job
+    return speech_like(dur, seed=seed, noisy=noisy)
+
+
+def speech_like_long(duration_s: float, seed: int = 1234, noisy: bool = False, chunk_s: float = 600.0,
+                     workers: int = 0) -> np.ndarray:
+    """Long recordings (the 120-minute benchmark file) as independent ``chunk_s`` pieces with seeds ``seed + 7919 i``,
+    generated in parallel worker processes (a single 115 M-sample FFT for the pink floor takes minutes); the result
+    depends only on (duration_s, seed, noisy, chunk_s).  Same per-chunk statistics as ``speech_like``."""
+    n_chunks = max(1, int(np.ceil(duration_s / chunk_s)))
+    jobs = [(min(chunk_s, duration_s - i * chunk_s), seed + 7919 * i, noisy) for i in range(n_chunks)]
+    if n_chunks == 1:
+        return speech_like(duration_s, seed=seed, noisy=noisy)
+    import multiprocessing as mp
+    import os
+    workers = workers or min(n_chunks, max(1, (os.cpu_count() or 2) - 1), 16)
+    if workers <= 1:
+        parts = [_chunk(j) for j in jobs]
+    else:
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_chunk, jobs)
+    return np.concatenate(parts)

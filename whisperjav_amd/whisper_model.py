@@ -297,6 +297,10 @@ class HipWhisperModel:
         self._warned = set()
         self.seed = 0               # base seed of the device sampler's counter-based generator
         self.device_beam = True     # beam search on the device (False: host-driven search.py over the step API)
+        # faster-whisper moves ``seek`` to the end of the last aligned word (transcribe.py generate_segments).  On
+        # random weights the alignment is noise and that re-seek multiplies the windows, so bench.py switches it off
+        # for its word-timestamp figure (and says so); everything else keeps upstream's behaviour
+        self.word_reseek = True
         self._sample_calls = 0
 
     # ---- loading ---------------------------------------------------------------------------
@@ -689,7 +693,7 @@ class HipWhisperModel:
                 st = w["st"]
                 ends = [wd["end"] for pc in w["pieces"] for wd in pc.get("words", [])]
                 last_word_end = ends[-1] if ends else None
-                if not w["single_ending"] and last_word_end is not None and last_word_end > w["time_offset"]:
+                if self.word_reseek and not w["single_ending"] and last_word_end is not None and last_word_end > w["time_offset"]:
                     st.seek = round(last_word_end * FRAMES_PER_SECOND)
                 if last_word_end is not None:
                     st.last_speech = last_word_end
