@@ -285,6 +285,16 @@ def simulate(args, info):
 # ---------------------------------------------------------------------------------------------------------------
 # cfg3 (default)
 # ---------------------------------------------------------------------------------------------------------------
+def make_audio(args):
+    """The recording of this rank (weak scaling: every GPU has its own; --strong: one for the job).  Runs BEFORE the
+    process touches the GPU: the chunk workers are separate processes."""
+    rank = int(os.environ.get("RANK", "0"))
+    seed = 1234 if args.strong else 1234 + 100003 * rank
+    t0 = time.perf_counter()
+    audio = synth.speech_like_long(60.0 * args.minutes, seed=seed, noisy=True)
+    return audio, time.perf_counter() - t0
+
+
 def run_cfg3(args, info, dims):
     dev = torch.device("cuda", info.local_rank)
     dtype = args.dtype
@@ -301,9 +311,7 @@ def run_cfg3(args, info, dims):
     if info.rank == 0:
         th = threading.Thread(target=make_weights)
         th.start()
-    seed = 1234 if args.strong else 1234 + 100003 * info.rank          # weak scaling: every GPU has its own recording
-    audio = synth.speech_like_long(60.0 * minutes, seed=seed, noisy=True)
-    t_audio = time.perf_counter() - t_start
+    audio, t_audio = args._audio, args._t_audio          # generated in main() before any GPU initialisation
     if th is not None:
         th.join()
     dev_blob, offsets = sharding.broadcast_blob(box.get("blob"), box.get("offsets"), dev)     # the ONE collective
@@ -346,6 +354,7 @@ def run_cfg3(args, info, dims):
                                         f"never emit EOT: every window decodes exactly this many tokens), word_timestamps=False, "
                                         f"through pipeline.RecordingTranscriber over asr.HipFasterWhisperProASR (the drop-in seam's classes)"),
                            "windows_per_batch": args.batch, "compute_type": dtype, "max_new_tokens": args.max_new_tokens,
+                           "tune": args.tune,
                            "parallelism": (f"scene-parallel x{info.world} ({'one recording LPT-sharded' if args.strong else 'one recording per GPU'}), "
                                            f"one RCCL weight broadcast, no data-path collective"),
                            "per_rank_last_step": per_rank},
@@ -540,11 +549,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (fp32 mode, word timestamps, cfg2, single window)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="wj_tune switches for A/B runs (e.g. dec_split_act=0)")
     ap.add_argument("--simulate", action="store_true", help="CPU/gloo dry run of the launcher and the collectives (no GPU, no kernels)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    if args.workload == "cfg3" and not args.simulate:
+        args._audio, args._t_audio = make_audio(args)
     info = sharding.init_distributed("gloo" if args.simulate else None)
     if args.gpus != info.world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {info.world} rank(s)")
@@ -553,6 +565,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(info.local_rank)
+    if args.tune:
+        from whisperjav_amd import hipbind
+        for kv in args.tune:
+            k, v = kv.split("=")
+            hipbind.tune(k, int(v))
     dims = pdims.dims_for(args.model)
     return run_cfg3(args, info, dims) if args.workload == "cfg3" else run_cfg2(args, info, dims)
 

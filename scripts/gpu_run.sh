@@ -25,7 +25,7 @@ case "$plan" in
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1
     note "smoke rc=$?"; tail -3 gpurun_out/smoke.log ;;
   bench)
-    timeout 1800 python bench.py "$@" > "gpurun_out/bench_${TAG}.json" 2> "gpurun_out/bench_${TAG}.err"
+    timeout ${BENCH_TIMEOUT:-600} python bench.py "$@" > "gpurun_out/bench_${TAG}.json" 2> "gpurun_out/bench_${TAG}.err"
     note "bench[$TAG] $* rc=$?"; cut -c1-1500 "gpurun_out/bench_${TAG}.json"; tail -3 "gpurun_out/bench_${TAG}.err" ;;
   prof)
     rm -rf "gpurun_out/prof_${TAG}"

@@ -97,7 +97,10 @@ struct Tunables {
   int dec_fuse_reduce = 1;  // attention kernels consume the q / qkv split-K slices directly (no reduce launch)
   int align_prefill = 1;    // word-timestamp alignment as one full-sequence decoder pass (0: token by token)
   int dec_cross_mfma = 1;   // 16-bit models: cross V kept transposed, cross attention on the matrix cores (read at create)
-  int dec_split_act = 1;    // fp16 models: decode-step GEMMs take their activations as hi + lo fp16 pairs (read at create)
+  int dec_split_act = 1;    // fp16 models: decode-step GEMMs take their activations as hi + lo fp16 pairs (read at create):
+                            // 1 = the residual-writing GEMMs (attention out-projections, fc2) and the logits GEMM,
+                            // 2 = every decode GEMM, 0 = none
+  int dec_adapt_ks = 1;     // halve the split-K factors while the row tiles alone keep >= 256 workgroups busy
 };
 static Tunables g_tune;
 
@@ -132,6 +135,7 @@ struct wj_whisper {
   // the decode step is HBM / latency bound, the second MFMA per fragment is free, and the per-token log-probs move
   // from ~2e-3 to ~3e-4 of the fp32 evaluation.  dh / dattn / dff rows are then twice as wide.
   bool split_act = false;
+  bool split_all = false;     // also the q/k/v, cross-q and fc1 projections (wj_tune dec_split_act = 2)
   // decoder workspaces
   float* dx = nullptr;        // f32 [R][d]
   void* dh = nullptr;         // T   [R][d]
@@ -316,7 +320,12 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   const int D = d.n_text_state, H = d.n_text_head, dt = m->dtype;
   m->ctx->prof_units = n_windows;
   const int win0 = row0 / beam;
-  const int split = m->split_act ? 1 : 0, sm = split ? 2 : 1;   // activation rows [hi | lo] for the decode GEMMs
+  // activation rows [hi | lo]: `split` for the GEMMs that write the residual stream and the logits (fed by the attention
+  // outputs, the GELU output and the final LayerNorm), `psplit` for the projections fed by the per-layer LayerNorms.
+  // Measured on the oracle (profiles/r02_precision_ablation_cpu.json + DESIGN.md): splitting only the former leaves
+  // 4.4e-4 of per-token log-prob error against 3.5e-4 for all of them, at 43 % instead of 100 % more MFMA work.
+  const int split = m->split_act ? 1 : 0, sm = split ? 2 : 1;
+  const int psplit = m->split_all ? 1 : 0, psm = psplit ? 2 : 1;
   float* dx = m->dx + (int64_t)row0 * D;
   void* dh = m->at(m->dh, (int64_t)row0 * D * sm);
   void* dq = m->at(m->dq, (int64_t)row0 * D);
@@ -335,9 +344,26 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   float* slab = m->partial + (int64_t)row0 * kDecKsMax * D;
   int pend_ks = 0;
   const float* pend_bias = nullptr;
+  // Split-K exists to put enough workgroups on the chip when there are few rows; every K slice costs an fp32 slab
+  // round trip (and, for the projections, a reduce launch).  With many rows (beam search over a full batch: 1920
+  // rows) the row tiles fill the CUs on their own, so the factor is halved while >= 256 workgroups remain -- down to
+  // 1, where the GEMM applies its epilogue directly (no slab, no reduce launch).
+  const bool tiled = !rows && is16(dt) && tile_min_m > 0 && R >= tile_min_m;
+  auto adapt_ks = [&](int ks, int N) -> int {
+    if (!tiled || !g_tune.dec_adapt_ks) return ks;
+    const int tiles = ceil_div(R, 128) * ceil_div(N, 128);
+    while (ks > 1 && tiles * (ks / 2) >= 256) ks /= 2;
+    return ks;
+  };
   auto resid_gemm = [&](int tag, const void* A, int K, const void* W, const float* bias, int ks) -> int {
     GemmArgs g;
     g.A = A; g.lda = (int64_t)K * sm; g.split = split; g.W = W; g.ldw = K; g.M = R; g.N = D; g.K = K; g.ldc = D;
+    ks = adapt_ks(ks, D);
+    if (tiled && ks == 1) {      // enough row tiles: x += acc + bias straight from the tile kernel
+      g.bias = bias; g.out = dx;
+      PROF(tag, launch_gemm(dt, EPI_RESID_F32, g, s, tile_variant));
+      return WJ_OK;
+    }
     if (is16(dt) && ks > 1 && ks <= kDecKsMax && K % (64 * ks) == 0) {
       g.out = slab; g.ksplit = ks;
       pend_ks = ks; pend_bias = bias;
@@ -354,10 +380,12 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   // `deferred` (may be NULL): the caller's next kernel consumes the raw K-slices itself (attention kernels), so the
   // reduce launch is skipped and *deferred = number of slices left in `slab`
   auto proj_gemm = [&](int tag, Epi epi, GemmArgs& g, int* deferred = nullptr) -> int {
-    const int ks = g_tune.dec_ks_proj;
+    const int ks = adapt_ks(g_tune.dec_ks_proj, g.N);
     if (deferred) *deferred = 0;
     if (rows) {
       PROF(tag, launch_gemm(dt, epi, g, s, 5));
+    } else if (tiled && ks == 1 && R >= g_tune.dec_proj_min_m) {
+      PROF(tag, launch_gemm(dt, epi, g, s, tile_variant));       // single pass with the projection's own epilogue
     } else if (is16(dt) && ks > 1 && R >= g_tune.dec_proj_min_m && (int64_t)ks * g.N <= (int64_t)kDecKsMax * D &&
         g.K % (64 * ks) == 0 && !pend_ks) {
       GemmArgs p = g;
@@ -370,13 +398,13 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     }
     return WJ_OK;
   };
-  auto norm = [&](const float* w, const float* b) -> int {
+  auto norm = [&](const float* w, const float* b, int out_split) -> int {
     if (pend_ks) {
       const int ks = pend_ks;
       pend_ks = 0;
-      PROF(PT_D_LN, launch_layernorm_resid(dt, dx, slab, ks, pend_bias, w, b, dh, R, D, s, split));
+      PROF(PT_D_LN, launch_layernorm_resid(dt, dx, slab, ks, pend_bias, w, b, dh, R, D, s, out_split));
     } else {
-      PROF(PT_D_LN, launch_layernorm(dt, dx, w, b, dh, R, D, s, split));
+      PROF(PT_D_LN, launch_layernorm(dt, dx, w, b, dh, R, D, s, out_split));
     }
     return WJ_OK;
   };
@@ -388,10 +416,10 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     const float *qkv_bias = nullptr, *cq_bias = nullptr;
     void* sk = m->at(m->self_k, l * m->self_layer_elems());
     void* sv = m->at(m->self_v, l * m->self_layer_elems());
-    WJ_TRY(norm(m->F(b0 + WJ_TD_LN1_W), m->F(b0 + WJ_TD_LN1_B)));
+    WJ_TRY(norm(m->F(b0 + WJ_TD_LN1_W), m->F(b0 + WJ_TD_LN1_B), psplit));
     {
       GemmArgs g;
-      g.A = dh; g.lda = (int64_t)D * sm; g.split = split; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
+      g.A = dh; g.lda = (int64_t)D * psm; g.split = psplit; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
       g.M = R; g.N = 3 * D; g.K = D; g.out = dq;
       g.out2 = m->at(sk, row0 * self_row); g.out3 = m->at(sv, row0 * self_row);
       g.D = D; g.H = H; g.pos_ptr = pos; g.cache_len = d.n_text_ctx;
@@ -409,10 +437,10 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       PROF(PT_D_SELF, launch_attention_dec(dt, a, s));
     }
     WJ_TRY(resid_gemm(PT_D_OUT, dattn, D, m->W(b0 + WJ_TD_OUT_W), m->F(b0 + WJ_TD_OUT_B), ks_attn));
-    WJ_TRY(norm(m->F(b0 + WJ_TD_LNX_W), m->F(b0 + WJ_TD_LNX_B)));
+    WJ_TRY(norm(m->F(b0 + WJ_TD_LNX_W), m->F(b0 + WJ_TD_LNX_B), psplit));
     {
       GemmArgs g;
-      g.A = dh; g.lda = (int64_t)D * sm; g.split = split; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
+      g.A = dh; g.lda = (int64_t)D * psm; g.split = psplit; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
       g.M = R; g.N = D; g.K = D; g.out = dq; g.ldc = D;
       WJ_TRY(proj_gemm(PT_D_CQ, EPI_T, g, m->cross_tpad > 0 ? &cq_slices : nullptr));
       cq_bias = g.bias;
@@ -439,17 +467,17 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       PROF(PT_D_CROSS, launch_attention_dec(dt, a, s));
     }
     WJ_TRY(resid_gemm(PT_D_COUT, dattn, D, m->W(b0 + WJ_TD_COUT_W), m->F(b0 + WJ_TD_COUT_B), ks_attn));
-    WJ_TRY(norm(m->F(b0 + WJ_TD_LN2_W), m->F(b0 + WJ_TD_LN2_B)));
+    WJ_TRY(norm(m->F(b0 + WJ_TD_LN2_W), m->F(b0 + WJ_TD_LN2_B), psplit));
     {
       GemmArgs g;
-      g.A = dh; g.lda = (int64_t)D * sm; g.split = split; g.W = m->W(b0 + WJ_TD_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_FC1_B);
+      g.A = dh; g.lda = (int64_t)D * psm; g.split = psplit; g.W = m->W(b0 + WJ_TD_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_FC1_B);
       g.M = R; g.N = 4 * D; g.K = D; g.out = dff; g.ldc = (int64_t)4 * D * sm; g.split_out = split;
       WJ_TRY(proj_gemm(PT_D_FC1, EPI_GELU_T, g));
     }
     WJ_TRY(resid_gemm(PT_D_FC2, dff, 4 * D, m->W(b0 + WJ_TD_FC2_W), m->F(b0 + WJ_TD_FC2_B), ks_fc2));
   }
   if (want_logits) {
-    WJ_TRY(norm(m->F(WJ_T_DEC_LN_W), m->F(WJ_T_DEC_LN_B)));
+    WJ_TRY(norm(m->F(WJ_T_DEC_LN_W), m->F(WJ_T_DEC_LN_B), split));
     GemmArgs g;
     g.A = dh; g.lda = (int64_t)D * sm; g.split = split; g.W = m->W(WJ_T_DEC_TOK_EMB); g.ldw = D;
     g.M = R; g.N = d.n_vocab; g.K = D; g.out = m->logits + (int64_t)row0 * m->ldl; g.ldc = m->ldl;
@@ -681,6 +709,7 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_proj_min_m")) g_tune.dec_proj_min_m = value;
   else if (!strcmp(key, "dec_cross_mfma")) g_tune.dec_cross_mfma = value;
   else if (!strcmp(key, "dec_split_act")) g_tune.dec_split_act = value;
+  else if (!strcmp(key, "dec_adapt_ks")) g_tune.dec_adapt_ks = value;
   else if (!strcmp(key, "gemm_big")) g_gemm_big = value;
   else if (!strcmp(key, "dec_ms_stages")) g_tune.dec_ms_stages = value;
   else if (!strcmp(key, "dec_tile_reg")) g_tune.dec_tile_reg = value;
@@ -766,6 +795,7 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   WJ_ALLOC(cross_v, (size_t)d.n_text_layer * m->cross_v_layer_elems() * e, true);   // pad keys stay zero forever
   WJ_ALLOC(dx, R * D * sizeof(float), false);
   m->split_act = dtype == WJ_F16 && g_tune.dec_split_act != 0;
+  m->split_all = m->split_act && g_tune.dec_split_act >= 2;
   const size_t sm = m->split_act ? 2 : 1;
   WJ_ALLOC(dh, R * D * e * sm, false);
   WJ_ALLOC(dq, R * D * e, false);

@@ -73,26 +73,47 @@ def speech_like(duration_s: float, seed: int = 1234, noisy: bool = False) -> np.
     return np.clip(out, -1.0, 1.0).astype(np.float32)
 
 
-def _chunk(job):
-    dur, seed, noisy = job
-    return speech_like(dur, seed=seed, noisy=noisy)
-
-
 def speech_like_long(duration_s: float, seed: int = 1234, noisy: bool = False, chunk_s: float = 600.0,
                      workers: int = 0) -> np.ndarray:
     """Long recordings (the 120-minute benchmark file) as independent ``chunk_s`` pieces with seeds ``seed + 7919 i``,
-    generated in parallel worker processes (a single 115 M-sample FFT for the pink floor takes minutes); the result
-    depends only on (duration_s, seed, noisy, chunk_s).  Same per-chunk statistics as ``speech_like``."""
+    generated in parallel (a single 115 M-sample FFT for the pink floor takes minutes); the result depends only on
+    (duration_s, seed, noisy, chunk_s).  Same per-chunk statistics as ``speech_like``.
+
+    The workers are plain ``python -m whisperjav_amd.synth`` SUBPROCESSES writing .npy files -- not ``multiprocessing``:
+    a forked child of a process that has initialised the HIP runtime (or merely loaded libwjhip.so) can hang at exit
+    (measured: a 22-minute stall of bench.py on the GPU box), and spawn pools re-import ``__main__``."""
     n_chunks = max(1, int(np.ceil(duration_s / chunk_s)))
-    jobs = [(min(chunk_s, duration_s - i * chunk_s), seed + 7919 * i, noisy) for i in range(n_chunks)]
+    jobs = [(min(chunk_s, duration_s - i * chunk_s), seed + 7919 * i) for i in range(n_chunks)]
     if n_chunks == 1:
         return speech_like(duration_s, seed=seed, noisy=noisy)
-    import multiprocessing as mp
     import os
+    import subprocess
+    import sys
+    import tempfile
     workers = workers or min(n_chunks, max(1, (os.cpu_count() or 2) - 1), 16)
-    if workers <= 1:
-        parts = [_chunk(j) for j in jobs]
-    else:
-        with mp.get_context("fork").Pool(workers) as pool:
-            parts = pool.map(_chunk, jobs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+    parts = [None] * n_chunks
+    with tempfile.TemporaryDirectory(prefix="wj_synth_") as tmp:
+        pending = list(range(n_chunks))
+        running = {}
+        while pending or running:
+            while pending and len(running) < workers:
+                i = pending.pop(0)
+                out = os.path.join(tmp, f"{i}.npy")
+                cmd = [sys.executable, "-m", "whisperjav_amd.synth", out, repr(jobs[i][0]), str(jobs[i][1]), str(int(noisy))]
+                running[i] = (subprocess.Popen(cmd, env=env, cwd=root), out)
+            for i, (proc, out) in list(running.items()):
+                rc = proc.wait() if len(running) >= workers or not pending else proc.poll()
+                if rc is None:
+                    continue
+                if rc != 0:
+                    raise RuntimeError(f"synthetic audio worker {i} failed (exit code {rc})")
+                parts[i] = np.load(out)
+                del running[i]
     return np.concatenate(parts)
+
+
+if __name__ == "__main__":      # worker: python -m whisperjav_amd.synth OUT.npy DURATION SEED NOISY
+    import sys
+    np.save(sys.argv[1], speech_like(float(sys.argv[2]), seed=int(sys.argv[3]), noisy=bool(int(sys.argv[4]))))

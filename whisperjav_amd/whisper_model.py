@@ -265,6 +265,10 @@ class HipWhisperModel:
 
     MEL_MODE = "fw"      # faster-whisper feature semantics
     FLAVOR = "fw"
+    # faster-whisper moves ``seek`` to the end of the last aligned word (transcribe.py generate_segments).  On random
+    # weights the alignment is noise and that re-seek multiplies the windows, so bench.py switches it off for its
+    # word-timestamp figure (and says so); everything else keeps upstream's behaviour
+    word_reseek = True
 
     def __init__(self, model_size_or_path: str = "large-v3", device: str = "cuda", device_index: int = 0,
                  compute_type: str = "float16", cpu_threads: int = 0, num_workers: int = 1,
@@ -297,10 +301,6 @@ class HipWhisperModel:
         self._warned = set()
         self.seed = 0               # base seed of the device sampler's counter-based generator
         self.device_beam = True     # beam search on the device (False: host-driven search.py over the step API)
-        # faster-whisper moves ``seek`` to the end of the last aligned word (transcribe.py generate_segments).  On
-        # random weights the alignment is noise and that re-seek multiplies the windows, so bench.py switches it off
-        # for its word-timestamp figure (and says so); everything else keeps upstream's behaviour
-        self.word_reseek = True
         self._sample_calls = 0
 
     # ---- loading ---------------------------------------------------------------------------
