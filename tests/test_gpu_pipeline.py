@@ -1057,6 +1057,9 @@ def test_pooled_scenes_equal_per_scene_and_priming_serves_the_loop(hip, tmp_path
     assert key(pooled["segments"]) == key(single["segments"]) and len(pooled["segments"]) >= 4
     for a, b in zip(pooled["per_scene"], single["per_scene"]):
         assert key(a["segments"]) == key(b["segments"])
+    # clips as views of the recording resident in HBM (default) == numpy clips on the host (the reference's contract)
+    host = pipeline.RecordingTranscriber(module, det, device_resident=False).transcribe(audio, 16000, pooled=True)
+    assert key(host["segments"]) == key(pooled["segments"]) and host["vad_segments"] == pooled["vad_segments"]
     # the reference's loop: scene files on disk, announced once, then one transcribe_to_srt per scene
     paths = []
     for i, sc in enumerate(pooled["scenes"]):

@@ -69,6 +69,12 @@ class HipLogMel:
         return out
 
     def __call__(self, clips: Sequence[np.ndarray], out_frames: int = N_FRAMES) -> torch.Tensor:
+        if len(clips) and all(isinstance(c, torch.Tensor) and c.is_cuda for c in clips):
+            # clips already resident in HBM (views of one uploaded recording): gather on the device
+            offsets = np.concatenate([[0], np.cumsum([int(c.numel()) for c in clips])]).astype(np.int64)
+            pcm = torch.cat([c.reshape(-1).to(torch.float32) for c in clips])
+            return self.from_device(pcm, offsets.tolist(), out_frames)
+        clips = [c.detach().cpu().numpy() if isinstance(c, torch.Tensor) else c for c in clips]
         arrs = [np.ascontiguousarray(c, dtype=np.float32).reshape(-1) for c in clips]
         offsets = np.concatenate([[0], np.cumsum([a.shape[0] for a in arrs])]).astype(np.int64)
         pcm = torch.from_numpy(np.concatenate(arrs)).to(self.dev)

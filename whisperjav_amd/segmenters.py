@@ -105,9 +105,15 @@ def group_segments(segments: List[SpeechSegment], max_group_duration_s: float = 
     return groups
 
 
+def _on_device(audio) -> bool:
+    return hasattr(audio, "is_cuda") and bool(audio.is_cuda)
+
+
 def _load_audio(audio: Union[np.ndarray, Path, str], sample_rate: int) -> Tuple[np.ndarray, int]:
-    if isinstance(audio, np.ndarray):
+    if isinstance(audio, np.ndarray) or _on_device(audio):      # device tensors: clips of a recording resident in HBM
         return audio, sample_rate
+    if hasattr(audio, "detach"):
+        return audio.detach().cpu().numpy(), sample_rate
     try:
         import soundfile as sf
     except ImportError:
@@ -148,11 +154,11 @@ class _HipSileroBase:
         if isinstance(sample_rates, int):
             sample_rates = [sample_rates] * len(audios)
         batched = (self._get_speech_timestamps is vad.get_speech_timestamps and hasattr(self._model, "scores")
-                   and all(isinstance(a, np.ndarray) and sr == VAD_SR for a, sr in zip(audios, sample_rates)))
+                   and all((isinstance(a, np.ndarray) or _on_device(a)) and sr == VAD_SR for a, sr in zip(audios, sample_rates)))
         if not batched:
             return [self.segment(a, sample_rate=sr) for a, sr in zip(audios, sample_rates)]
         try:
-            probs = self._model.scores([np.asarray(a, dtype=np.float32) for a in audios])
+            probs = self._model.scores(list(audios))
         except Exception as e:      # per-clip calls reproduce each class's own error policy (swallow / propagate)
             logger.error(f"batched VAD scoring failed ({e}); falling back to per-clip calls")
             return [self.segment(a, sample_rate=sr) for a, sr in zip(audios, sample_rates)]
@@ -215,9 +221,11 @@ class HipSileroV6SpeechSegmenter(_HipSileroBase):
         self._ensure_model()
         data, sr = _load_audio(audio, sample_rate)
         duration = len(data) / sr
+        if _on_device(data) and sr != VAD_SR:
+            data = data.detach().cpu().numpy()
         if sr != VAD_SR:
             data, sr = _resample(data, sr, VAD_SR), VAD_SR
-        if data.dtype != np.float32:
+        if isinstance(data, np.ndarray) and data.dtype != np.float32:
             data = data.astype(np.float32)
         try:
             stamps = self._get_speech_timestamps(
@@ -308,7 +316,9 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
         min_speech = kwargs.get("min_speech_duration_ms", self.min_speech_duration_ms)
         min_silence = kwargs.get("min_silence_duration_ms", self.min_silence_duration_ms)
         pad_ms = kwargs.get("speech_pad_ms", self.speech_pad_ms)
-        audio16 = np.asarray(_resample(data, sr, VAD_SR), dtype=np.float32)
+        if _on_device(data) and sr != VAD_SR:
+            data = data.detach().cpu().numpy()
+        audio16 = data if _on_device(data) else np.asarray(_resample(data, sr, VAD_SR), dtype=np.float32)
         stamps = self._get_speech_timestamps(audio16, self._model, sampling_rate=VAD_SR, threshold=threshold,
                                              min_speech_duration_ms=min_speech, min_silence_duration_ms=min_silence,
                                              speech_pad_ms=pad_ms,

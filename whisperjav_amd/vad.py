@@ -69,6 +69,14 @@ class HipSileroScorer:
         return [host[poff[i]:poff[i + 1]].copy() for i in range(n)]
 
     def scores(self, clips: Sequence[np.ndarray]) -> List[np.ndarray]:
+        if len(clips) and all(isinstance(c, torch.Tensor) and c.is_cuda for c in clips):
+            # clips already resident in HBM (views of one uploaded recording): gather on the device, no host copy
+            offsets = np.concatenate([[0], np.cumsum([int(c.numel()) for c in clips])]).astype(np.int64)
+            if offsets[-1] == 0:
+                return [np.zeros(0, dtype=np.float32) for _ in clips]
+            pcm = torch.cat([c.reshape(-1).to(torch.float32) for c in clips])
+            return self.scores_device(pcm, offsets.tolist())
+        clips = [c.detach().cpu().numpy() if isinstance(c, torch.Tensor) else c for c in clips]
         arrs = [np.ascontiguousarray(c, dtype=np.float32).reshape(-1) for c in clips]
         offsets = np.concatenate([[0], np.cumsum([a.shape[0] for a in arrs])]).astype(np.int64)
         flat = np.concatenate(arrs) if arrs else np.zeros(1, dtype=np.float32)
@@ -184,14 +192,16 @@ def get_speech_timestamps(audio, model: HipSileroScorer, threshold: float = 0.5,
     ``model`` (same keyword names; ``audio`` may be a NumPy array or a torch tensor)."""
     if sampling_rate != SR:
         raise ValueError("the HIP scorer implements the 16 kHz model")
-    if hasattr(audio, "detach"):
-        audio = audio.detach().cpu().numpy()
-    audio = np.asarray(audio, dtype=np.float32).reshape(-1)
-    if audio.shape[0] == 0:
+    n_samples = int(audio.numel()) if hasattr(audio, "numel") else int(np.asarray(audio).size)
+    if n_samples == 0:
         return []
     if probs is None:       # ``probs``: this clip's window probabilities from a batched scorer call (segment_many)
+        if not (hasattr(audio, "is_cuda") and audio.is_cuda):
+            if hasattr(audio, "detach"):
+                audio = audio.detach().cpu().numpy()
+            audio = np.asarray(audio, dtype=np.float32).reshape(-1)
         probs = model.scores([audio])[0]
-    segs = regions_from_probs(probs, audio.shape[0], threshold=threshold, sampling_rate=sampling_rate,
+    segs = regions_from_probs(probs, n_samples, threshold=threshold, sampling_rate=sampling_rate,
                               min_speech_duration_ms=min_speech_duration_ms,
                               max_speech_duration_s=max_speech_duration_s,
                               min_silence_duration_ms=min_silence_duration_ms, speech_pad_ms=speech_pad_ms,

@@ -771,7 +771,9 @@ class HipWhisperModel:
         import torch
         o = self._options(dict(kwargs))
         suppress = self._suppressed(o)
-        clips = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1) for a in audios]
+        # numpy clips (the reference's call contract) or CUDA tensors (clips of a recording already resident in HBM)
+        clips = [a.reshape(-1) if (hasattr(a, "is_cuda") and a.is_cuda) else np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+                 for a in audios]
         if any(len(c) <= 200 for c in clips):
             raise ValueError("every clip must be longer than 200 samples (12.5 ms)")
         # features of every clip in ONE launch; frame axis padded so any 3000-frame window can be sliced
