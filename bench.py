@@ -29,7 +29,6 @@ import os
 import socket
 import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
@@ -303,17 +302,11 @@ def run_cfg3(args, info, dims):
     # ---- weights (rank 0) and audio (every rank) are prepared concurrently ---------------------------------------
     box = {}
 
-    def make_weights():
-        w = pweights.synth_weights(dims, seed=1234, exact="float16")      # fp16-representable, like the published checkpoints
-        box["w"] = w
-        box["blob"], box["offsets"] = pweights.pack_blob(dims, w, dtype)
-    th = None
-    if info.rank == 0:
-        th = threading.Thread(target=make_weights)
-        th.start()
     audio, t_audio = args._audio, args._t_audio          # generated in main() before any GPU initialisation
-    if th is not None:
-        th.join()
+    if info.rank == 0:
+        # fp16-representable values, like the published checkpoints; rounded and laid out into the blob ON the GPU
+        box["w"] = pweights.synth_weights(dims, seed=1234, exact="float16")
+        box["blob"], box["offsets"] = pweights.pack_blob_device(dims, box["w"], dtype, dev)
     dev_blob, offsets = sharding.broadcast_blob(box.get("blob"), box.get("offsets"), dev)     # the ONE collective
     box.pop("blob", None)
     model, module, runner = build_stack(args, info, dims, dtype, args.batch, blob=dev_blob, offsets=offsets)
