@@ -216,7 +216,9 @@ def run_recording(runner, audio, scene_subset=None):
     t2 = time.perf_counter()
     merged = runner.stitch(scenes, per_scene)
     vad = runner.asr.get_vad_segments_per_scene()
-    return {"scenes": len(scenes), "segments": len(merged), "vad_segments": sum(len(v) for v in vad),
+    import zlib
+    crc = zlib.crc32("|".join(f"{s['start']:.2f},{s['end']:.2f},{s['text']}" for s in merged).encode())    # A/B runs must agree
+    return {"scenes": len(scenes), "segments": len(merged), "vad_segments": sum(len(v) for v in vad), "transcript_crc32": crc,
             "scene_audio_s": round(sum(b - a for a, b in scenes), 1), "t_scene": round(t1 - t0, 4), "t_asr_incl_vad": round(t2 - t1, 4)}
 
 
@@ -365,6 +367,10 @@ def run_cfg3(args, info, dims):
         line["roofline"] = roofline_from_stages(line["stages"], dtype)
         n_windows = prof.get("conv1_gemm", (0, 0, 0))[2]
         line["config"]["windows_per_step"] = n_windows
+    if info.rank == 0 and time.perf_counter() - t_start > args.extras_budget_s and not args.no_extras:
+        log(f"[bench] {time.perf_counter() - t_start:.0f}s used: secondary figures skipped (--extras-budget-s {args.extras_budget_s})")
+        line["config"]["extras_skipped"] = "time budget"
+        args.no_extras = True
     if info.rank == 0 and info.world == 1 and not args.no_extras:
         # word_timestamps=True (the reference's default, config/components/asr/faster_whisper.py:298): every window also runs
         # the alignment pass; the word-driven re-seek is switched off (random weights align noise, see whisper_model.word_reseek)
@@ -541,6 +547,7 @@ def main():
     ap.add_argument("--cpu-sample-tokens", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--extras-budget-s", type=float, default=480.0, help="skip the secondary figures when the run has already taken this long")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (fp32 mode, word timestamps, cfg2, single window)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="wj_tune switches for A/B runs (e.g. dec_split_act=0)")
     ap.add_argument("--simulate", action="store_true", help="CPU/gloo dry run of the launcher and the collectives (no GPU, no kernels)")

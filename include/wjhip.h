@@ -58,7 +58,8 @@ int wj_device_info(wj_ctx* ctx, int64_t out[4]);
 
 /* Run-time tunables (A/B switches behind the sweeps under profiles/; the defaults are the measured optimum).
  * Decode step: "dec_ks_attn", "dec_ks_fc2", "dec_ks_proj", "dec_proj_min_m", "dec_tile_min_m" (split-K factors and the
- * row counts that select them), "dec_adapt_ks" (halve them while the row tiles alone fill the chip), "dec_rows", "dec_rows_max_m", "dec_rows_ks_attn", "dec_rows_ks_fc2" (one-wave-per-row-
+ * row counts that select them), "dec_adapt_ks" (halve them while the row tiles alone fill the chip), "dec_big_min_m" (rows from which wide projections use
+ * the 256-tile kernel), "dec_rows", "dec_rows_max_m", "dec_rows_ks_attn", "dec_rows_ks_fc2" (one-wave-per-row-
  * block GEMM for small batches), "dec_ms_stages", "dec_tile_reg" (decode tile GEMM staging), "dec_fuse_reduce",
  * "decode_chains", "dec_cross_mfma" and "dec_split_act" (fp16 models: decode GEMM activations as hi + lo pairs; both read
  * at wj_whisper_create), "dec_cross_u", "dec_cross_nt".

@@ -101,6 +101,7 @@ struct Tunables {
                             // 1 = the residual-writing GEMMs (attention out-projections, fc2) and the logits GEMM,
                             // 2 = every decode GEMM, 0 = none
   int dec_adapt_ks = 1;     // halve the split-K factors while the row tiles alone keep >= 256 workgroups busy
+  int dec_big_min_m = 0;    // rows from which the wide decode projections (qkv, fc1) use the 256x256 kernel; measured at 1920 rows: 14.00 s vs 13.89 s for the 128-tile kernel (160 workgroups do not fill 256 CUs), so off
 };
 static Tunables g_tune;
 
@@ -385,7 +386,12 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     if (rows) {
       PROF(tag, launch_gemm(dt, epi, g, s, 5));
     } else if (tiled && ks == 1 && R >= g_tune.dec_proj_min_m) {
-      PROF(tag, launch_gemm(dt, epi, g, s, tile_variant));       // single pass with the projection's own epilogue
+      // single pass with the projection's own epilogue.  Wide projections of a big batch (beam search over hundreds of
+      // windows: 1920 rows x 3840 / 5120 columns) go to the 256x256 encoder kernel: the 128-tile kernel gives a
+      // workgroup only 32 MFMAs per wave per k-step to hide the LDS-DMA round trip behind (measured 440 TFLOP/s on fc1)
+      const bool wide = g_tune.dec_big_min_m > 0 && R >= g_tune.dec_big_min_m && !g.split && (g.N % 256) == 0 &&
+                        ceil_div(R, 256) * (g.N / 256) >= 96;
+      PROF(tag, launch_gemm(dt, epi, g, s, wide ? 6 : tile_variant));
     } else if (is16(dt) && ks > 1 && R >= g_tune.dec_proj_min_m && (int64_t)ks * g.N <= (int64_t)kDecKsMax * D &&
         g.K % (64 * ks) == 0 && !pend_ks) {
       GemmArgs p = g;
@@ -710,6 +716,7 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_cross_mfma")) g_tune.dec_cross_mfma = value;
   else if (!strcmp(key, "dec_split_act")) g_tune.dec_split_act = value;
   else if (!strcmp(key, "dec_adapt_ks")) g_tune.dec_adapt_ks = value;
+  else if (!strcmp(key, "dec_big_min_m")) g_tune.dec_big_min_m = value;
   else if (!strcmp(key, "gemm_big")) g_gemm_big = value;
   else if (!strcmp(key, "dec_ms_stages")) g_tune.dec_ms_stages = value;
   else if (!strcmp(key, "dec_tile_reg")) g_tune.dec_tile_reg = value;
