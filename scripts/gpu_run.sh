@@ -7,7 +7,7 @@
 #   smoke                    __graft_entry__.smoke()
 #   bench [bench.py args]    python bench.py ... -> gpurun_out/bench_<tag>.json  (tag = $BENCH_TAG, default "default")
 #   prof  [bench.py args]    rocprofv3 --kernel-trace --stats of bench.py ... -> gpurun_out/prof_<tag>/
-#   pmc <counters> [bench.py args]   rocprofv3 --pmc <counters> (own pass, no tracing domains) -> gpurun_out/pmc_<tag>/
+#   pmc <counters> <kernel> <windows/launch> [bench.py args]   rocprofv3 --pmc (own pass) -> gpurun_out/pmc_<tag>_summary.json
 #   py <file> [args]         python <file> ... -> gpurun_out/<basename>.log
 #   seq "<plan a...>" "<plan b...>"   several plans in one call
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
@@ -28,16 +28,23 @@ case "$plan" in
     timeout ${BENCH_TIMEOUT:-600} python bench.py "$@" > "gpurun_out/bench_${TAG}.json" 2> "gpurun_out/bench_${TAG}.err"
     note "bench[$TAG] $* rc=$?"; cut -c1-1500 "gpurun_out/bench_${TAG}.json"; tail -3 "gpurun_out/bench_${TAG}.err" ;;
   prof)
+    # rocprofv3 --kernel-trace --stats of bench.py; the raw trace (hundreds of MB for a 120-min step) is summarised on the
+    # box into gpurun_out/prof_<tag>_kernel_stats.csv and removed (gpurun merges at most 64 MiB back)
     rm -rf "gpurun_out/prof_${TAG}"
-    (cd /tmp && timeout 1800 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_${TAG}" -o trace --output-format csv -- \
+    (cd /tmp && timeout ${BENCH_TIMEOUT:-900} rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_${TAG}" -o trace --output-format csv -- \
         python "$OLDPWD/bench.py" "$@" > "$OLDPWD/gpurun_out/prof_${TAG}.json" 2> "$OLDPWD/gpurun_out/prof_${TAG}.err")
-    note "prof[$TAG] $* rc=$?"; find "gpurun_out/prof_${TAG}" -name '*kernel_stats.csv' | head -1 | xargs -r head -12 ;;
+    note "prof[$TAG] $* rc=$?"
+    python scripts/rocprof_summarise.py stats "gpurun_out/prof_${TAG}" "gpurun_out/prof_${TAG}_kernel_stats.csv"; note "prof summary rc=$?"
+    rm -rf "gpurun_out/prof_${TAG}"; cut -c1-400 "gpurun_out/prof_${TAG}.json" ;;
   pmc)
-    counters="$1"; shift
+    # rocprofv3 --pmc <counters> in its OWN pass (no tracing domains): pmc <counters> <kernel substring> <windows/launch> [bench args]
+    counters="$1"; kern="$2"; wpl="$3"; shift 3
     rm -rf "gpurun_out/pmc_${TAG}"
-    (cd /tmp && timeout 1800 rocprofv3 --pmc $counters -d "$OLDPWD/gpurun_out/pmc_${TAG}" -o pmc --output-format csv -- \
+    (cd /tmp && timeout ${BENCH_TIMEOUT:-900} rocprofv3 --pmc $counters -d "$OLDPWD/gpurun_out/pmc_${TAG}" -o pmc --output-format csv -- \
         python "$OLDPWD/bench.py" "$@" > "$OLDPWD/gpurun_out/pmc_${TAG}.json" 2> "$OLDPWD/gpurun_out/pmc_${TAG}.err")
-    note "pmc[$TAG] $counters $* rc=$?" ;;
+    note "pmc[$TAG] $counters $* rc=$?"
+    python scripts/rocprof_summarise.py pmc "gpurun_out/pmc_${TAG}" "gpurun_out/pmc_${TAG}_summary.json" "$kern" "$wpl" python bench.py "$@"; note "pmc summary rc=$?"
+    rm -rf "gpurun_out/pmc_${TAG}" ;;
   py)
     f="$1"; shift
     timeout 1800 python "$f" "$@" > "gpurun_out/$(basename "$f" .py).log" 2>&1

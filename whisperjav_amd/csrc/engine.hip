@@ -717,6 +717,7 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_split_act")) g_tune.dec_split_act = value;
   else if (!strcmp(key, "dec_adapt_ks")) g_tune.dec_adapt_ks = value;
   else if (!strcmp(key, "dec_big_min_m")) g_tune.dec_big_min_m = value;
+  else if (!strcmp(key, "beam_topk_reg")) g_beam_topk_reg = value;
   else if (!strcmp(key, "gemm_big")) g_gemm_big = value;
   else if (!strcmp(key, "dec_ms_stages")) g_tune.dec_ms_stages = value;
   else if (!strcmp(key, "dec_tile_reg")) g_tune.dec_tile_reg = value;

@@ -170,6 +170,7 @@ struct BeamArgs {
   int32_t* fin_tokens = nullptr;      // [B][fin_cap][tok_stride]
   int fin_cap = 0;
 };
+extern int g_beam_topk_reg;
 int launch_beam_step(const BeamArgs& a, int R, int B, hipStream_t s);
 
 // beam search: logits processors + timestamp rules + masked log-softmax + top-k (see sampler.hip)

@@ -549,6 +549,148 @@ __global__ __launch_bounds__(SB) void beam_topk_kernel(const BeamArgs a) {
   }
 }
 
+// Register-resident form of beam_topk_kernel (the default): the row's filtered logits are read ONCE -- NV values per
+// thread, all loads issued up front -- and the max / log-sum-exp / top-2K rounds run on registers.  The sweep above makes
+// 2 + 2K dependent passes over the 51.9 k logits (rocprofv3, 120-min balanced step: 3.3 ms per launch at 1920 rows =
+// 7.8 % of the step); this one is a single coalesced read.  Same summation order, same tie-breaking: identical results.
+template <int NV>
+__global__ __launch_bounds__(SB) void beam_topk_reg_kernel(const BeamArgs a) {
+  __shared__ float s_f[4][SB / 64];
+  __shared__ int s_i[2][SB / 64];
+  __shared__ int s_win;
+  __shared__ float s_stat[4];
+  __shared__ RowRules s_rr;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const wj_decode_opts& o = a.opts;
+  const int k = 2 * a.K, V = a.V;
+  const int len = *a.pos_ptr + 1;
+  const int32_t* tok = a.hist_in + (int64_t)r * a.tok_stride;
+  float* x = a.logits + (int64_t)r * a.ldl;
+  const float rep = o.repetition_penalty;
+  const int ngram = o.no_repeat_ngram_size;
+  if ((rep > 0.f && rep != 1.f) || ngram > 0) {      // same prepass as beam_topk_kernel / greedy_sample_kernel
+    const int s0 = a.sample_begin - 1, L = len - s0;
+    if (rep > 0.f && rep != 1.f) {
+      for (int j = tid; j < L; j += SB) {
+        const int t = tok[s0 + j];
+        bool first = true;
+        for (int i = 0; i < j; ++i)
+          if (tok[s0 + i] == t) { first = false; break; }
+        if (first) { const float v = x[t]; x[t] = v < 0.f ? v * rep : v / rep; }
+      }
+      __syncthreads();
+    }
+    if (ngram > 0 && L >= ngram) {
+      for (int i = tid; i <= L - ngram; i += SB) {
+        bool match = true;
+        for (int q = 0; q < ngram - 1; ++q)
+          if (tok[s0 + i + q] != tok[len - (ngram - 1) + q]) { match = false; break; }
+        if (match) x[tok[s0 + i + ngram - 1]] = -INFINITY;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    RowRules rr;
+    const int ns = len - a.sample_begin;
+    rr.first = ns == 0;
+    rr.ts_rules = !o.without_timestamps;
+    rr.last_ts = ns >= 1 && tok[len - 1] >= o.timestamp_begin;
+    rr.penult_ts = ns < 2 || tok[len - 2] >= o.timestamp_begin;
+    int ts_last = -1;
+    for (int i = a.sample_begin; i < len; ++i)
+      if (tok[i] >= o.timestamp_begin) ts_last = tok[i];
+    rr.ts_floor = -1;
+    if (ts_last >= 0) rr.ts_floor = (rr.last_ts && !rr.penult_ts) ? ts_last : ts_last + 1;
+    s_rr = rr;
+  }
+  __syncthreads();
+  const RowRules rr = s_rr;
+
+  // the one read of the row: value j of this thread is token j * SB + tid
+  float val[NV];
+  uint64_t live = 0;                      // bit j: token allowed by the rules (candidates come from these only)
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int v = j * SB + tid, vc = min(v, V - 1);
+    val[j] = x[vc];
+    if (v < V && token_allowed(vc, rr, o)) live |= 1ull << j;
+  }
+  ArgMax best_all = {-INFINITY, 0x7fffffff};
+  float max_text = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if ((live >> j) & 1) {
+      const int v = j * SB + tid;
+      best_all = amax(best_all, ArgMax{val[j], v});
+      if (v < o.timestamp_begin) max_text = fmaxf(max_text, val[j]);
+    }
+  }
+  best_all = wave_amax(best_all);
+  max_text = wave_max(max_text);
+  if (lane == 0) { s_f[0][wave] = best_all.v; s_i[0][wave] = best_all.i; s_f[2][wave] = max_text; }
+  __syncthreads();
+  best_all = ArgMax{s_f[0][0], s_i[0][0]};
+  max_text = s_f[2][0];
+  for (int w = 1; w < SB / 64; ++w) {
+    best_all = amax(best_all, ArgMax{s_f[0][w], s_i[0][w]});
+    max_text = fmaxf(max_text, s_f[2][w]);
+  }
+  __syncthreads();
+  float sum_all = 0.f, sum_ts = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if ((live >> j) & 1) {
+      const float e = expf(val[j] - best_all.v);
+      sum_all += e;
+      if (j * SB + tid >= o.timestamp_begin) sum_ts += e;
+    }
+  }
+  sum_all = wave_sum(sum_all);
+  sum_ts = wave_sum(sum_ts);
+  if (lane == 0) { s_f[0][wave] = sum_all; s_f[1][wave] = sum_ts; }
+  __syncthreads();
+  if (tid == 0) {
+    sum_all = 0.f; sum_ts = 0.f;
+    for (int w = 0; w < SB / 64; ++w) { sum_all += s_f[0][w]; sum_ts += s_f[1][w]; }
+    const float lse = best_all.v + logf(sum_all);
+    float ts_only = 0.f, norm = lse;
+    if (rr.ts_rules && sum_ts > 0.f) {
+      const float ts_lp = best_all.v + logf(sum_ts) - lse;
+      if (ts_lp > max_text - lse) { ts_only = 1.f; norm = best_all.v + logf(sum_ts); }
+    }
+    s_stat[0] = norm;
+    s_stat[1] = ts_only;
+  }
+  __syncthreads();
+  const float norm = s_stat[0];
+  if (s_stat[1] != 0.f) {                 // timestamps only: the text tokens leave the candidate set
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if (j * SB + tid < o.timestamp_begin) live &= ~(1ull << j);
+  }
+  for (int round = 0; round < k; ++round) {
+    ArgMax best = {-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if ((live >> j) & 1) best = amax(best, ArgMax{val[j], j * SB + tid});
+    best = wave_amax(best);
+    if (lane == 0) { s_f[0][wave] = best.v; s_i[0][wave] = best.i; }
+    __syncthreads();
+    if (tid == 0) {
+      ArgMax b = {s_f[0][0], s_i[0][0]};
+      for (int w = 1; w < SB / 64; ++w) b = amax(b, ArgMax{s_f[0][w], s_i[0][w]});
+      s_win = b.i;
+      const bool none = b.i == 0x7fffffff || b.v == -INFINITY;
+      a.cand_ids[(int64_t)r * 16 + round] = none ? -1 : b.i;
+      a.cand_lp[(int64_t)r * 16 + round] = none ? -INFINITY : b.v - norm;
+    }
+    __syncthreads();
+    const int win = s_win;
+    if (win != 0x7fffffff && (win & (SB - 1)) == tid) live &= ~(1ull << (win / SB));     // taken
+  }
+}
+
 __global__ __launch_bounds__(128) void beam_merge_kernel(const BeamArgs a) {
   __shared__ float c_score[128];
   __shared__ int c_beam[128], c_tok[128];
@@ -660,9 +802,14 @@ __global__ __launch_bounds__(128) void beam_merge_kernel(const BeamArgs a) {
   }
 }
 
+int g_beam_topk_reg = 1;   // wj_tune("beam_topk_reg"): 0 = the multi-pass sweep (A/B, cross-check)
+
 int launch_beam_step(const BeamArgs& a, int R, int B, hipStream_t s) {
   if (a.K < 1 || a.K > 8) { set_error("beam search: beam size %d outside 1..8", a.K); return WJ_E_INVALID; }
-  hipLaunchKernelGGL(beam_topk_kernel, dim3(R), dim3(SB), 0, s, a);
+  // register-resident top-2K (one read of the logits) for vocabularies up to 64 values per thread; the sweep otherwise
+  if (g_beam_topk_reg && a.V <= 51 * SB) hipLaunchKernelGGL(beam_topk_reg_kernel<51>, dim3(R), dim3(SB), 0, s, a);
+  else if (g_beam_topk_reg && a.V <= 64 * SB) hipLaunchKernelGGL(beam_topk_reg_kernel<64>, dim3(R), dim3(SB), 0, s, a);
+  else hipLaunchKernelGGL(beam_topk_kernel, dim3(R), dim3(SB), 0, s, a);
   WJ_LAUNCH_CHECK();
   hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(128), 0, s, a);
   WJ_LAUNCH_CHECK();
