@@ -272,6 +272,19 @@ int wj_vad_free(wj_vad* v);
 int wj_vad_scores(wj_vad* v, const float* pcm_dev, const int64_t* offsets_host,
                   const int64_t* prob_offsets_host, int n_streams, float* probs_dev, void* stream);
 
+/* ---- multi-GPU: the one collective of the path ---------------------------------------------
+ * Scenes shard over the GPUs of a node with no exchange step; the only traffic is ONE broadcast of the
+ * packed weight blob at start-up, over RCCL (xGMI).  One process per GPU: rank `root` calls wj_comm_unique_id and hands
+ * the 128 bytes to the other ranks out of band (environment, file, MPI, torch.distributed ...), every rank calls
+ * wj_comm_init and wj_bcast_weights on its own device copy of the blob (same size everywhere), then wj_comm_destroy.
+ * RCCL is resolved at run time (dlopen): a single-GPU process never loads it; WJ_E_UNSUPPORTED when it is absent.
+ * (whisperjav_amd/sharding.py does the same broadcast through torch.distributed, whose "nccl" backend IS RCCL.) */
+typedef struct wj_comm wj_comm;
+int wj_comm_unique_id(char out[128]);
+int wj_comm_init(wj_ctx* ctx, int nranks, int rank, const char id[128], wj_comm** out);
+int wj_bcast_weights(wj_comm* comm, void* blob_dev, int64_t bytes, int root, void* stream);
+int wj_comm_destroy(wj_comm* comm);
+
 /* ---- kernel-level entry points (parity tests and micro-benchmarks only) ----------------- */
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, plain row-major output in `dtype` (out_f32=0) or float32. */
 int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev,

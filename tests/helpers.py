@@ -28,6 +28,17 @@ def make_oracle(d: pdims.WhisperDims, seed=1234, emulate_bf16=False, emulate: st
     return whisper_ref.WhisperOracle(oracle_dims(d), w, act_round=rnd), w
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=4)
+def cached_weights(dims: pdims.WhisperDims, seed: int, exact: str = ""):
+    """Seeded synthetic weights, generated once per (geometry, seed, rounding mode) and test session: a large-v3 set
+    is 1.5 G normal draws (~30 s of single-threaded NumPy) and nine GPU tests want one of three of them.  Callers
+    must not modify the arrays."""
+    return pweights.synth_weights(dims, seed=seed, exact=exact)
+
+
 def hf_state_dict(d: pdims.WhisperDims, w):
     """Map openai-style names onto transformers' WhisperForConditionalGeneration names."""
     sd = {}

@@ -251,7 +251,7 @@ def _golden_run(name, dims, dtype, n_mels):
     g = np.load(os.path.join(GOLDEN, name))
     audio = synth.speech_like(30.0, seed=1234)
     mel = engine.HipLogMel(n_mels, "fw")([audio])
-    w = pweights.synth_weights(dims, seed=int(g["seed"]))
+    w = helpers.cached_weights(dims, int(g["seed"]))
     model = engine.HipWhisper(dims, w, dtype=dtype, max_batch=1)
     del w
     enc = model.encode(mel, want_output=True).cpu()
@@ -334,7 +334,7 @@ def test_golden_large_v3_r2_greedy_and_beam(hip, dtype, exact):
     dims = pdims.dims_for("large-v3")
     audio = synth.speech_like(30.0, seed=1234)
     mel = engine.HipLogMel(128, "fw")([audio])
-    w = pweights.synth_weights(dims, seed=int(g["seed"]), exact=exact)
+    w = helpers.cached_weights(dims, int(g["seed"]), exact)
     model = engine.HipWhisper(dims, w, dtype=dtype, max_batch=1, max_beam=5)
     del w
     enc = model.encode(mel, want_output=True).cpu()
@@ -930,7 +930,7 @@ def test_large_v3_geometry_beam_and_alignment_consistency(hip):
     depend on its batch neighbours, and the full-sequence alignment pass agrees with the token-by-token one."""
     from whisperjav_amd import dims as pdims, engine, hipbind, search, synth, weights as pweights
     dims = pdims.dims_for("large-v3")
-    model = engine.HipWhisper(dims, pweights.synth_weights(dims, seed=1234), dtype="bfloat16", max_batch=3, max_beam=5)
+    model = engine.HipWhisper(dims, helpers.cached_weights(dims, 1234), dtype="bfloat16", max_batch=3, max_beam=5)
     fe = engine.HipLogMel(128, "fw")
     clips = [synth.speech_like(30.0, seed=1234), synth.speech_like(11.0, seed=77), synth.speech_like(30.0, seed=5)]
     model.encode(fe(clips))
@@ -1080,3 +1080,19 @@ def test_pooled_scenes_equal_per_scene_and_priming_serves_the_loop(hip, tmp_path
     assert vad_primed == module.get_last_vad_segments()
     _diag("pooled_scenes", {"scenes": len(paths), "segments": len(pooled["segments"]), "per_scene_engine_calls": len(calls)})
     module.cleanup()
+
+
+def test_cabi_weight_broadcast_single_rank(hip):
+    """``wj_comm_*`` / ``wj_bcast_weights`` (RCCL resolved at run time) with a one-rank communicator: the blob comes back
+    unchanged.  More ranks need more GPUs than this environment leases; the call sequence is the same."""
+    import ctypes as C
+    from whisperjav_amd import hipbind, sharding
+    blob = torch.arange(1 << 20, dtype=torch.int32).view(torch.uint8)
+    offsets = np.arange(0, blob.numel(), 256, dtype=np.int64)
+    out, offs = sharding.broadcast_blob_cabi(blob, offsets, torch.device("cuda", 0))
+    assert out.is_cuda and torch.equal(out.cpu(), blob) and np.array_equal(offs, offsets)
+    uid = C.create_string_buffer(128)
+    hipbind.check(hip.wj_comm_unique_id(uid), "wj_comm_unique_id")
+    assert any(b != 0 for b in uid.raw)
+    comm = C.c_void_p()
+    assert hip.wj_comm_init(hipbind.context(0).handle, 2, 5, uid.raw, C.byref(comm)) != 0          # rank outside the communicator

@@ -16,7 +16,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libwjhip.so"
-SOURCES = ["engine.hip", "gemm.hip", "attention.hip", "norm.hip", "sampler.hip", "logmel.hip", "vad.hip", "align.hip"]
+SOURCES = ["engine.hip", "gemm.hip", "attention.hip", "norm.hip", "sampler.hip", "logmel.hip", "vad.hip", "align.hip", "comm.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "../../include/wjhip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 # attention.hip: MFMA results feed VALU softmax code every key tile; with accumulators in AGPRs the compiler emits
@@ -67,7 +67,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         objs = list(ex.map(compile_one, srcs))
     newest = max(o.stat().st_mtime for o in objs)
     if force or not LIB.exists() or LIB.stat().st_mtime < newest:
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs), "-ldl"]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)

@@ -59,6 +59,8 @@ def broadcast_blob(blob: Optional[torch.Tensor], offsets: Optional[np.ndarray], 
     if info.world == 1 or not dist.is_initialized():
         assert blob is not None and offsets is not None
         return blob.to(device), np.asarray(offsets, dtype=np.int64)
+    if os.environ.get("WJ_BCAST_CABI") == "1" and device.type == "cuda":
+        return broadcast_blob_cabi(blob, offsets, device, src)
     meta = torch.zeros(2, dtype=torch.int64, device=device)
     if info.rank == src:
         assert blob is not None and offsets is not None
@@ -74,6 +76,37 @@ def broadcast_blob(blob: Optional[torch.Tensor], offsets: Optional[np.ndarray], 
     dist.broadcast(off_t, src=src)
     dist.broadcast(dev_blob, src=src)
     return dev_blob, off_t.cpu().numpy()
+
+
+def broadcast_blob_cabi(blob: Optional[torch.Tensor], offsets: Optional[np.ndarray], device: torch.device,
+                        src: int = 0) -> Tuple[torch.Tensor, np.ndarray]:
+    """``broadcast_blob`` with the payload moved by libwjhip's own RCCL entry points (``wj_comm_unique_id`` /
+    ``wj_comm_init`` / ``wj_bcast_weights``, include/wjhip.h) -- what a host without PyTorch would call.  The 128-byte
+    communicator id and the sizes travel through the existing process group (any backend) as Python objects.
+    Selected by ``WJ_BCAST_CABI=1``; the torch.distributed path stays the default (it is the one the multi-GPU bench of
+    the driver exercises)."""
+    import ctypes as C
+    from . import hipbind
+    info = rank_info()
+    lib = hipbind.lib()
+    ctx = hipbind.context(device.index or 0)
+    meta = None
+    if info.rank == src:
+        assert blob is not None and offsets is not None
+        uid = C.create_string_buffer(128)
+        hipbind.check(lib.wj_comm_unique_id(uid), "wj_comm_unique_id")
+        meta = (uid.raw, int(blob.numel()), np.asarray(offsets, dtype=np.int64))
+    meta = broadcast_object(meta, src=src)
+    uid_raw, nbytes, offs = meta
+    dev_blob = blob.to(device) if info.rank == src else torch.empty(nbytes, dtype=torch.uint8, device=device)
+    comm = C.c_void_p()
+    hipbind.check(lib.wj_comm_init(ctx.handle, info.world, info.rank, uid_raw, C.byref(comm)), "wj_comm_init")
+    torch.cuda.current_stream().synchronize()
+    try:
+        hipbind.check(lib.wj_bcast_weights(comm, C.c_void_p(dev_blob.data_ptr()), nbytes, src, None), "wj_bcast_weights")
+    finally:
+        lib.wj_comm_destroy(comm)
+    return dev_blob, offs
 
 
 def assign_lpt(costs: Sequence[float], world: int) -> List[List[int]]:
