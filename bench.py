@@ -113,6 +113,12 @@ def stages_from_profile(prof, dims, dtype, beam, avg_keys):
             entry.update({"bound": sm["bound"], "achieved": round(sm["achieved"], 2), "unit": sm["unit"],
                           "frac": round(sm["achieved"] / sm["peak"], 4), "work_per_launch": sm["work_per_launch"]})
         stages[tag] = entry
+    dec = [k for k in stages if k.startswith("dec_") and stages[k].get("bound") == "hbm"]
+    if dec:     # the decode step as a whole against the HBM roof (weights once per launch + K/V of every row)
+        byts = sum(stages[k]["work_per_launch"] * stages[k]["launches"] for k in dec)
+        ms = sum(stages[k]["ms_total"] for k in dec)
+        stages["_decode_hbm_aggregate"] = {"achieved": round(byts / (ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                                           "frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_total": round(ms, 3)}
     enc = [k for k in stages if stages[k].get("bound") == "mfma"]
     if enc:
         fl = sum(stages[k]["achieved"] * stages[k]["ms_total"] for k in enc)
