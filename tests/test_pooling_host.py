@@ -245,16 +245,14 @@ def test_ten_segmenter_reuses_the_reference_post_ops_with_a_pluggable_scorer(ref
     assert got.to_legacy_format() == want.to_legacy_format()
 
 
-@needs_ref
-def test_hip_balanced_pipeline_pools_inside_the_reference_process_loop(ref_modules, monkeypatch, tmp_path):
-    """The pipeline-level seam: ``HipBalancedPipeline`` IS the reference's ``BalancedPipeline`` (imported from source;
-    ffmpeg extraction, stitching and post-processing replaced by file-level doubles) -- its inherited ``process`` loop
-    calls ``transcribe_to_srt`` per scene, and the engine is entered ONCE with the groups of all scenes; the per-scene
-    SRT files equal those of the unpooled module."""
+def _reference_pipeline_with_doubles(monkeypatch, tmp_path, module_name):
+    """Import ``whisperjav.pipelines.<module_name>`` from source (third-party wheels stubbed) and replace what lies
+    outside the seam -- ffmpeg extraction, scene detection, stitching, post-processing -- by file-level doubles."""
     stubs = {}
-    for name in ("faster_whisper", "soundfile", "srt", "pysrt", "jsonschema", "tqdm", "ffmpeg", "librosa", "auditok"):
+    for name in ("faster_whisper", "whisper", "soundfile", "srt", "pysrt", "jsonschema", "tqdm", "ffmpeg", "librosa", "auditok"):
         stubs[name] = types.ModuleType(name)
     stubs["faster_whisper"].WhisperModel = object
+    stubs["whisper"].load_model = lambda *a, **k: None
     stubs["soundfile"].SoundFileError = Exception
     stubs["soundfile"].read = lambda path, dtype="float32", **kw: _wave_read(path)
     for attr in ("SubRipItem", "SubRipFile", "SubRipTime"):
@@ -265,7 +263,7 @@ def test_hip_balanced_pipeline_pools_inside_the_reference_process_loop(ref_modul
     missing = []
     for _ in range(40):             # anything else the application imports at module level and the container lacks
         try:
-            bp = importlib.import_module("whisperjav.pipelines.balanced_pipeline")
+            bp = importlib.import_module(f"whisperjav.pipelines.{module_name}")
             break
         except ModuleNotFoundError as e:
             if e.name.startswith("whisperjav"):
@@ -275,7 +273,6 @@ def test_hip_balanced_pipeline_pools_inside_the_reference_process_loop(ref_modul
     else:
         pytest.skip(f"reference pipeline not importable here (stubbed {missing})")
     scenes = [(0.0, 6.0), (8.0, 17.0), (20.0, 24.0)]
-    scene_dir = tmp_path / "temp" / "scenes"
 
     class Detector:
         name = "auditok-hip"
@@ -313,6 +310,34 @@ def test_hip_balanced_pipeline_pools_inside_the_reference_process_loop(ref_modul
             return out_path, {"total_subtitles": 0, "empty_removed": 0, "removed_hallucinations": 0, "removed_repetitions": 0,
                               "duration_adjustments": 0, "cps_filtered": 0, "logprob_filtered": 0, "nonverbal_filtered": 0}
     monkeypatch.setattr(bp, "StandardPostProcessor", Post)
+    return bp, stitched
+
+
+def _run_pipeline(cls, resolved, tmp_path, stitched):
+    pipe = cls(output_dir=str(tmp_path / "out"), temp_dir=str(tmp_path / "temp"), keep_temp_files=True, subs_language="native",
+               resolved_config=resolved)
+    media = tmp_path / "movie.wav"
+    _scene_wav(media, 25.0)
+    try:
+        pipe.process({"path": str(media), "basename": "movie", "type": "audio", "duration": 25.0})
+    except Exception:            # anything past the ASR phase that the doubles do not model is outside this seam
+        if not stitched:
+            raise
+
+
+RESOLVED = {"model": {"model_name": "large-v3", "device": "cuda", "compute_type": "float16"},
+            "params": {"decoder": dict(CONFIG["decoder"]), "provider": dict(CONFIG["provider"]), "vad": {"threshold": 0.28},
+                       "speech_segmenter": {"backend": "silero-v6.2-hip"}},
+            "features": {"scene_detection": {"method": "auditok-hip"}, "post_processing": {}}, "task": "transcribe"}
+
+
+@needs_ref
+def test_hip_balanced_pipeline_pools_inside_the_reference_process_loop(ref_modules, monkeypatch, tmp_path):
+    """The pipeline-level seam: ``HipBalancedPipeline`` IS the reference's ``BalancedPipeline`` (imported from source;
+    ffmpeg extraction, stitching and post-processing replaced by file-level doubles) -- its inherited ``process`` loop
+    calls ``transcribe_to_srt`` per scene, and the engine is entered ONCE with the groups of all scenes; the per-scene
+    SRT files equal those of the unpooled module."""
+    bp, stitched = _reference_pipeline_with_doubles(monkeypatch, tmp_path, "balanced_pipeline")
     fake = FakeWhisper(_script)
     real_asr = asr.HipFasterWhisperProASR
 
@@ -321,29 +346,47 @@ def test_hip_balanced_pipeline_pools_inside_the_reference_process_loop(ref_modul
     monkeypatch.setattr(asr, "HipFasterWhisperProASR", make_asr)
     cls = pipeline.hip_balanced_pipeline_class()
     assert issubclass(cls, bp.BalancedPipeline) and issubclass(cls, importlib.import_module("whisperjav.pipelines.base_pipeline").BasePipeline)
-    resolved = {"model": {"model_name": "large-v3", "device": "cuda", "compute_type": "float16"},
-                "params": {"decoder": dict(CONFIG["decoder"]), "provider": dict(CONFIG["provider"]), "vad": {"threshold": 0.28},
-                           "speech_segmenter": {"backend": "silero-v6.2-hip"}},
-                "features": {"scene_detection": {"method": "auditok-hip"}, "post_processing": {}}, "task": "transcribe"}
-    pipe = cls(output_dir=str(tmp_path / "out"), temp_dir=str(tmp_path / "temp"), keep_temp_files=True, subs_language="native",
-               resolved_config=resolved)
-    media = tmp_path / "movie.wav"
-    _scene_wav(media, 25.0)
-    try:
-        meta = pipe.process({"path": str(media), "basename": "movie", "type": "audio", "duration": 25.0})
-    except Exception as e:       # anything past the ASR phase that the doubles do not model is outside this seam
-        if not stitched:
-            raise
-        meta = None
+    _run_pipeline(cls, RESOLVED, tmp_path, stitched)
     assert len(fake.calls) == 1 and fake.calls[0][0] == 6, fake.calls           # ONE engine call: 3 scenes x 2 groups
-    srt_dir = tmp_path / "temp" / "scene_srts"
     assert [s for _, s in stitched["info"]] == [0.0, 8.0, 20.0]                  # one SRT per scene reached the stitcher
     # the same scenes through the unpooled module give byte-identical per-scene SRTs
-    loop = real_asr(resolved["model"], resolved["params"], "transcribe", whisper_model=FakeWhisper(_script), segmenter=LengthSegmenter())
+    loop = real_asr(RESOLVED["model"], RESOLVED["params"], "transcribe", whisper_model=FakeWhisper(_script), segmenter=LengthSegmenter())
     for i in range(3):
-        wavp = scene_dir / f"movie_scene_{i:04d}.wav"
+        wavp = tmp_path / "temp" / "scenes" / f"movie_scene_{i:04d}.wav"
         want = loop.transcribe_to_srt(wavp, tmp_path / "loop" / f"{i}.srt").read_text(encoding="utf-8")
-        assert (srt_dir / f"movie_scene_{i:04d}.srt").read_text(encoding="utf-8") == want
+        assert (tmp_path / "temp" / "scene_srts" / f"movie_scene_{i:04d}.srt").read_text(encoding="utf-8") == want
+
+
+@needs_ref
+def test_hip_fidelity_pipeline_pools_inside_the_reference_process_loop(ref_modules, monkeypatch, tmp_path):
+    """The same for fidelity mode: ``HipFidelityPipeline`` IS the reference's ``FidelityPipeline``; the ASR module its
+    ``process()`` creates as a local (``WhisperProASR(**self._asr_config)``, fidelity_pipeline.py:270) becomes
+    ``HipWhisperProASR``, primed with the scene list, and the model is entered once for all scenes."""
+    fp, stitched = _reference_pipeline_with_doubles(monkeypatch, tmp_path, "fidelity_pipeline")
+    calls = []
+
+    class DictModel:             # whisper.load_model(...) object: transcribe(audio, **kw) -> dict
+        def transcribe_many(self, clips, **params):
+            calls.append(len(clips))
+            return [_script(i, c) for i, c in enumerate(clips)], [None] * len(clips)
+
+        def close(self):
+            pass
+    real_asr = asr.HipWhisperProASR
+    made = []
+
+    def make_asr(model_config, params, task, tracer=None):
+        made.append(real_asr(model_config, params, task, tracer, whisper_model=DictModel(), segmenter=LengthSegmenter()))
+        return made[-1]
+    monkeypatch.setattr(asr, "HipWhisperProASR", make_asr)
+    cls = pipeline.hip_fidelity_pipeline_class()
+    assert issubclass(cls, fp.FidelityPipeline)
+    saved = fp.WhisperProASR
+    _run_pipeline(cls, RESOLVED, tmp_path, stitched)
+    assert fp.WhisperProASR is saved                                             # the module-level name is restored
+    assert calls == [6] and len(made) == 1 and made[0].pooled_calls == 1
+    assert [s for _, s in stitched["info"]] == [0.0, 8.0, 20.0]
+    assert made[0].post_model_filter_enabled is True                            # fidelity's post-model gate default (whisper_pro_asr.py:123-127)
 
 
 def _wave_read(path):

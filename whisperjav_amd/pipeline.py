@@ -13,6 +13,7 @@ Two forms of the same procedure live here:
   scene list is announced to the ASR module (``prime_scenes``) the moment it exists; the inherited loop then still
   calls ``transcribe_to_srt`` per scene and still finds one SRT per scene, but the first call transcribes the whole
   list in one pooled pass.  Registration: INTEGRATION.md section 2d (``main.py`` dispatch + ``PIPELINE_CLASSES``).
+* ``hip_fidelity_pipeline_class()`` -> ``HipFidelityPipeline``: the same for ``FidelityPipeline`` / ``WhisperProASR``.
 * ``RecordingTranscriber``: the same steps 2-4 + stitch for one in-memory recording without the ``whisperjav``
   package (bench.py, ``sharded_transcribe``, the GPU tests): scenes -> PCM16 round trip (the reference writes the
   scenes as PCM_16 WAVs, utils.py:107-150, and reads them back; that quantisation is part of its numerics) -> pooled
@@ -176,7 +177,49 @@ def hip_balanced_pipeline_class():
     return HipBalancedPipeline
 
 
+def hip_fidelity_pipeline_class():
+    """``HipFidelityPipeline``: the reference's ``FidelityPipeline`` (pipelines/fidelity_pipeline.py:32-490) with the ASR
+    module swapped for ``asr.HipWhisperProASR`` (openai-whisper semantics) and the scenes pooled the same way.  Fidelity
+    mode creates its ASR module as a LOCAL of ``process()`` (``asr = WhisperProASR(**self._asr_config)``, :270), so the
+    subclass binds that module-level name to a factory for the duration of the call -- the one-line alternative for a
+    maintainer is the import swap of INTEGRATION.md section 2b."""
+    from whisperjav.pipelines import fidelity_pipeline as ref  # type: ignore
+
+    from . import asr as hip_asr
+
+    class HipFidelityPipeline(ref.FidelityPipeline):
+        def __init__(self, *args, **kwargs):
+            super().__init__(*args, **kwargs)
+            self._pending_scene_paths = None
+            self.scene_detector = PrimingSceneDetector(self.scene_detector, self._announce_scenes)
+
+        def _announce_scenes(self, scene_paths) -> None:
+            self._pending_scene_paths = list(scene_paths)
+
+        def _make_asr(self, **config):
+            module = hip_asr.HipWhisperProASR(**config)
+            if self._pending_scene_paths is not None:
+                module.prime_scenes(self._pending_scene_paths)
+                self._pending_scene_paths = None
+            return module
+
+        def process(self, media_info):
+            saved = ref.WhisperProASR
+            ref.WhisperProASR = self._make_asr
+            try:
+                return super().process(media_info)
+            finally:
+                ref.WhisperProASR = saved
+
+        def get_mode_name(self) -> str:
+            return "fidelity"
+
+    return HipFidelityPipeline
+
+
 def __getattr__(name):
     if name == "HipBalancedPipeline":
         return hip_balanced_pipeline_class()
+    if name == "HipFidelityPipeline":
+        return hip_fidelity_pipeline_class()
     raise AttributeError(name)
