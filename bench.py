@@ -210,7 +210,7 @@ def build_stack(args, info, dims, dtype, batch, blob=None, offsets=None, weights
     return model, module, pipeline.RecordingTranscriber(module, det)
 
 
-def run_recording(runner, audio, scene_subset=None):
+def run_recording(runner, audio, scene_subset=None, pooled=True):
     """One step: scenes -> pooled VAD -> groups -> pooled beam-search transcription -> stitched segments."""
     from whisperjav_amd import pipeline
     t0 = time.perf_counter()
@@ -218,7 +218,7 @@ def run_recording(runner, audio, scene_subset=None):
     if scene_subset is not None:
         scenes = [scenes[i] for i in scene_subset(scenes)]
     t1 = time.perf_counter()
-    per_scene = runner.transcribe_scenes(audio, pipeline.SR, scenes)
+    per_scene = runner.transcribe_scenes(audio, pipeline.SR, scenes, pooled=pooled)
     t2 = time.perf_counter()
     merged = runner.stitch(scenes, per_scene)
     vad = runner.asr.get_vad_segments_per_scene()
@@ -327,13 +327,14 @@ def run_cfg3(args, info, dims):
             return sharding.assign_lpt([b - a for a, b in scenes], info.world)[info.rank]
 
     stats = None
+    pooled = not args.per_scene
     for _ in range(args.warmup):
-        stats = run_recording(runner, audio, subset)
+        stats = run_recording(runner, audio, subset, pooled)
     sharding.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        stats = run_recording(runner, audio, subset)
+        stats = run_recording(runner, audio, subset, pooled)
     torch.cuda.synchronize()
     sharding.barrier()
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
@@ -355,7 +356,7 @@ def run_cfg3(args, info, dims):
                                         f"never emit EOT: every window decodes exactly this many tokens), word_timestamps=False, "
                                         f"through pipeline.RecordingTranscriber over asr.HipFasterWhisperProASR (the drop-in seam's classes)"),
                            "windows_per_batch": args.batch, "compute_type": dtype, "max_new_tokens": args.max_new_tokens,
-                           "tune": args.tune,
+                           "tune": args.tune, "scene_loop": "pooled" if pooled else "one engine call per scene (the reference's call pattern)",
                            "parallelism": (f"scene-parallel x{info.world} ({'one recording LPT-sharded' if args.strong else 'one recording per GPU'}), "
                                            f"one RCCL weight broadcast, no data-path collective"),
                            "per_rank_last_step": per_rank},
@@ -555,6 +556,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--extras-budget-s", type=float, default=480.0, help="skip the secondary figures when the run has already taken this long")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (fp32 mode, word timestamps, cfg2, single window)")
+    ap.add_argument("--per-scene", action="store_true", help="A/B: one engine call per scene (the reference's loop) instead of pooling all scenes")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="wj_tune switches for A/B runs (e.g. dec_split_act=0)")
     ap.add_argument("--simulate", action="store_true", help="CPU/gloo dry run of the launcher and the collectives (no GPU, no kernels)")
     args = ap.parse_args()
