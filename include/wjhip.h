@@ -64,7 +64,9 @@ int wj_device_info(wj_ctx* ctx, int64_t out[4]);
  * "decode_chains", "dec_cross_mfma" and "dec_split_act" (fp16 models: decode GEMM activations as hi + lo pairs; both read
  * at wj_whisper_create), "dec_cross_u", "dec_cross_nt".
  * Encoder: "attn_enc_variant" (bit0 XCD remap, bit1 base-2 softmax, bit2 lazy rescale, bit3 lean softmax),
- * "gemm_big" (256-tile kernel).  Alignment: "align_prefill".  Search: "beam_topk_reg" (register-resident top-2K of the
+ * "gemm_big" (256-tile GEMM kernel: 1 lockstep, 3-5 ping-pong with that many 32-wide ring stages, 6 ping-pong over
+ * 64-wide pairs = default), "epi_wide" (16-byte epilogue stores of the MFMA tile kernels), "dec_ms_resid" (ring stages of
+ * the residual-writing decode tile GEMMs).  Alignment: "align_prefill".  Search: "beam_topk_reg" (register-resident top-2K of the
  * device beam search; 0 = the multi-pass sweep).  Unknown keys are an error. */
 int wj_tune(const char* key, int value);
 

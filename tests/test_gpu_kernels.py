@@ -56,16 +56,16 @@ GEMM_SHAPES = [
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
-@pytest.mark.parametrize("variant", [4, 2, 3, 5, 54, 6, 7, 73, 75])
+@pytest.mark.parametrize("variant", [4, 2, 3, 5, 54, 6, 7, 73, 75, 83, 84, 85, 86])
 def test_gemm(hip, dtype, shape, variant):
     from whisperjav_amd import engine
     M, N, K = shape
     if dtype == "float32" and variant != 4:
         pytest.skip("the fp32 compute type has a single GEMM kernel")
-    if variant in (3, 5, 54, 6, 7, 73, 75) and K % 64:
+    if variant in (3, 5, 54, 6, 7, 73, 75, 83, 84, 85, 86) and K % 64:
         pytest.skip("the LDS-DMA tile kernels and the rows kernel need K % 64 == 0")
-    if variant == 6 and (N % 256 or M < 1024):
-        pytest.skip("the 256-tile kernel takes N % 256 == 0, M >= 1024")
+    if variant in (6, 83, 84, 85, 86) and (N % 256 or M < 1024):
+        pytest.skip("the 256-tile kernels take N % 256 == 0, M >= 1024")
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     a = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) * 0.3 + 0.05
@@ -106,6 +106,35 @@ def test_gemm_split_activations(hip, dtype, shape, variant):
     tol = 2e-5 if dtype == "float16" else 3e-4      # hi + lo carries 22 (fp16) / 16 (bf16) significant bits
     assert st["max_abs"] < tol * scale, st
     assert st["max_abs"] < 0.1 * st["plain16_max_abs"], st
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_kernel_families_and_store_widths_are_bit_identical(hip, dtype, gelu):
+    """Every 16-bit MFMA tile kernel accumulates k in ascending blocks of 32 into fp32 and shares one epilogue: the
+    128-tile kernels (3 LDS-DMA, 4 register staging, 73 three-stage ring), the lockstep 256-tile kernel (6) and its
+    ping-pong successors (83-85: 32-wide ring stages, 86: 64-wide pairs, the default) must agree to the bit, with the
+    16-byte permlane-swapped epilogue stores (wj_tune epi_wide=1, default) and with the 8-byte ones."""
+    from whisperjav_amd import engine, hipbind
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 2300, 768, 448          # M tail of the 256-row tiles, 14 ring stages / 7 pairs
+    a = _rnd(torch.randn(M, K, generator=g), dtype).cuda()
+    w = _rnd(torch.randn(N, K, generator=g) * 0.2, dtype).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    outs = {}
+    try:
+        for wide in (1, 0):
+            hipbind.tune("epi_wide", wide)
+            for variant in (3, 4, 73, 6, 83, 84, 85, 86):
+                outs[(wide, variant)] = engine.k_gemm(a, w, bias, dtype, gelu=gelu, variant=variant).cpu()
+    finally:
+        hipbind.tune("epi_wide", 1)
+    ref = outs[(0, 3)]
+    want = a.float().cpu() @ w.float().cpu().T + bias.cpu()
+    want = torch.nn.functional.gelu(want) if gelu else want
+    assert torch.allclose(ref.float(), want, **TOL16[dtype]), _stats(ref.float(), want)
+    for key, got in outs.items():
+        assert torch.equal(got, ref), key        # the 16-bit outputs widened to float32: equal values <=> equal bits
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])

@@ -93,7 +93,10 @@ struct Tunables {
   int dec_rows_ks_attn = 2; // its split-K factors for the residual projections (K = d) and fc2 (K = 4d)
   int dec_rows_ks_fc2 = 8;
   int dec_tile_reg = 0;     // 1: the decode tile GEMMs stage through registers (global->VGPR->LDS) instead of LDS-DMA
-  int dec_ms_stages = 0;    // LDS-DMA stages of the decode tile GEMM (0 = the 2-stage encoder kernel; 3-5 measured equal)
+  int dec_ms_stages = 0;    // LDS-DMA stages of ALL decode tile GEMMs (0 = the 2-stage kernel, 2 workgroups per CU: faster for
+                            // the wide projections, 746 vs 593 TFLOP/s on 1920 x 3840 x 1280)
+  int dec_ms_resid = 3;     // ... of the residual-writing ones (N = 1280: 150 row x column tiles, one workgroup per CU anyway;
+                            // 3 stages in flight: 204 vs 191 TFLOP/s on 1920 x 1280 x 1280, 368 vs 334 with K = 5120); 0 = off
   int dec_fuse_reduce = 1;  // attention kernels consume the q / qkv split-K slices directly (no reduce launch)
   int align_prefill = 1;    // word-timestamp alignment as one full-sequence decoder pass (0: token by token)
   int dec_cross_mfma = 1;   // 16-bit models: cross V kept transposed, cross attention on the matrix cores (read at create)
@@ -342,6 +345,8 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   const int ks_fc2 = rows ? g_tune.dec_rows_ks_fc2 : g_tune.dec_ks_fc2, tile_min_m = g_tune.dec_tile_min_m;
   const int ms = g_tune.dec_ms_stages;
   const int tile_variant = (ms >= 3 && ms <= 5) ? 70 + ms : (g_tune.dec_tile_reg ? 4 : 3);
+  const int msr = g_tune.dec_ms_resid;
+  const int resid_variant = (msr >= 3 && msr <= 5) ? 70 + msr : tile_variant;
   float* slab = m->partial + (int64_t)row0 * kDecKsMax * D;
   int pend_ks = 0;
   const float* pend_bias = nullptr;
@@ -362,13 +367,13 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     ks = adapt_ks(ks, D);
     if (tiled && ks == 1) {      // enough row tiles: x += acc + bias straight from the tile kernel
       g.bias = bias; g.out = dx;
-      PROF(tag, launch_gemm(dt, EPI_RESID_F32, g, s, tile_variant));
+      PROF(tag, launch_gemm(dt, EPI_RESID_F32, g, s, resid_variant));
       return WJ_OK;
     }
     if (is16(dt) && ks > 1 && ks <= kDecKsMax && K % (64 * ks) == 0) {
       g.out = slab; g.ksplit = ks;
       pend_ks = ks; pend_bias = bias;
-      const int variant = rows ? 5 : ((tile_min_m > 0 && R >= tile_min_m) ? tile_variant : 2);
+      const int variant = rows ? 5 : ((tile_min_m > 0 && R >= tile_min_m) ? resid_variant : 2);
       PROF(tag, launch_gemm(dt, EPI_PARTIAL_F32, g, s, variant));
     } else {
       g.bias = bias; g.out = dx;
@@ -719,7 +724,9 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_big_min_m")) g_tune.dec_big_min_m = value;
   else if (!strcmp(key, "beam_topk_reg")) g_beam_topk_reg = value;
   else if (!strcmp(key, "gemm_big")) g_gemm_big = value;
+  else if (!strcmp(key, "epi_wide")) g_epi_wide = value;
   else if (!strcmp(key, "dec_ms_stages")) g_tune.dec_ms_stages = value;
+  else if (!strcmp(key, "dec_ms_resid")) g_tune.dec_ms_resid = value;
   else if (!strcmp(key, "dec_tile_reg")) g_tune.dec_tile_reg = value;
   else if (!strcmp(key, "dec_fuse_reduce")) g_tune.dec_fuse_reduce = value;
   else if (!strcmp(key, "align_prefill")) g_tune.align_prefill = value;

@@ -25,77 +25,256 @@ namespace wj {
 // --------------------------------------------------------------------------------------------
 // epilogues
 // --------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void epi_vt_store(const GemmArgs& g, int z, int m, int n, float v[4]) {
+  // v[i] belongs to (row m + i, column n), bias already added; m % 4 == 0; m < M (M % 4 == 0), n < N.
+  const int h = n >> 6, dd = n & 63;
+  st4(reinterpret_cast<T*>(g.out) + (((int64_t)z * g.H + h) * 64 + dd) * g.Tpad + m, v);
+}
+
+template <typename T>
+__device__ __forceinline__ void epi_vt(const GemmArgs& g, int z, int m, int n, float v[4]) {
+  const float b = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] += b;
+  epi_vt_store<T>(g, z, m, n, v);
+}
+
+// epi_nm_store: v already carries the bias.  (EPI_F32 here is the float4 store: callers guarantee n + 3 < N.)
+template <int EPI, typename T>
+__device__ __forceinline__ void epi_nm_store(const GemmArgs& g, int z, int m, int n, float v[4]) {
+  if constexpr (EPI == EPI_F32) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n) =
+        make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (EPI == EPI_T || EPI == EPI_GELU_T) {
+    if constexpr (EPI == EPI_GELU_T) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = gelu_for<T>(v[j]);
+    }
+    T* o = reinterpret_cast<T*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n;
+    if constexpr (sizeof(T) == 2) {
+      if (g.split_out) { st4_split<T>(o, g.N, v); return; }
+    }
+    st4(o, v);
+  } else if constexpr (EPI == EPI_RESID_F32) {
+    float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch +
+                                          (int64_t)m * g.ldc + n);
+    float4 x = *o;
+    x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
+    *o = x;
+  } else if constexpr (EPI == EPI_GELU_POS_F32) {
+    const float4 p = *reinterpret_cast<const float4*>(g.pos + (int64_t)m * g.N + n);
+    float4 x;
+    x.x = gelu_for<T>(v[0]) + p.x; x.y = gelu_for<T>(v[1]) + p.y;
+    x.z = gelu_for<T>(v[2]) + p.z; x.w = gelu_for<T>(v[3]) + p.w;
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch +
+                               (int64_t)m * g.ldc + n) = x;
+  } else if constexpr (EPI == EPI_QK_HEADS || EPI == EPI_CKV) {
+    const int which = n >= g.D;
+    const int nn = n - which * g.D;
+    const int h = nn >> 6, dd = nn & 63;
+    T* base = reinterpret_cast<T*>(which ? g.out2 : g.out);
+    st4(base + (((int64_t)z * g.H + h) * g.Tpad + m) * 64 + dd, v);
+  } else if constexpr (EPI == EPI_QKV_DEC) {
+    const int which = n / g.D;
+    const int nn = n - which * g.D;
+    if (which == 0) {
+      st4(reinterpret_cast<T*>(g.out) + (int64_t)m * g.D + nn, v);
+    } else {
+      const int h = nn >> 6, dd = nn & 63;
+      const int pos = g.seq_tp ? m % g.seq_tp : *g.pos_ptr;
+      const int64_t crow = g.seq_tp ? m / g.seq_tp : m;
+      T* base = reinterpret_cast<T*>(which == 1 ? g.out2 : g.out3);
+      st4(base + ((crow * g.H + h) * g.cache_len + pos) * 64 + dd, v);
+    }
+  }
+}
+
 template <int EPI, typename T>
 __device__ __forceinline__ void epi_nm(const GemmArgs& g, int z, int m, int n, float v[4]) {
   // v[j] belongs to (row m, column n + j); n % 4 == 0; caller guarantees m < M and n < N.
   if constexpr (EPI == EPI_PARTIAL_F32) {   // z = K-slice index
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + ((int64_t)z * g.M + m) * g.ldc + n) =
         make_float4(v[0], v[1], v[2], v[3]);
-    return;
-  } else if constexpr (EPI == EPI_F32) {
+  } else if constexpr (EPI == EPI_F32) {    // N tail safe
     float* o = reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (n + j < g.N) o[j] = v[j] + (g.bias ? g.bias[n + j] : 0.0f);
-    return;
   } else {
     if (g.bias) {
       const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
       v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
-    if constexpr (EPI == EPI_T || EPI == EPI_GELU_T) {
-      if constexpr (EPI == EPI_GELU_T) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_for<T>(v[j]);
-      }
-      T* o = reinterpret_cast<T*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n;
-      if constexpr (sizeof(T) == 2) {
-        if (g.split_out) { st4_split<T>(o, g.N, v); return; }
-      }
-      st4(o, v);
-    } else if constexpr (EPI == EPI_RESID_F32) {
-      float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch +
-                                            (int64_t)m * g.ldc + n);
-      float4 x = *o;
-      x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3];
-      *o = x;
-    } else if constexpr (EPI == EPI_GELU_POS_F32) {
-      const float4 p = *reinterpret_cast<const float4*>(g.pos + (int64_t)m * g.N + n);
-      float4 x;
-      x.x = gelu_for<T>(v[0]) + p.x; x.y = gelu_for<T>(v[1]) + p.y;
-      x.z = gelu_for<T>(v[2]) + p.z; x.w = gelu_for<T>(v[3]) + p.w;
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch +
-                                 (int64_t)m * g.ldc + n) = x;
-    } else if constexpr (EPI == EPI_QK_HEADS || EPI == EPI_CKV) {
-      const int which = n >= g.D;
-      const int nn = n - which * g.D;
-      const int h = nn >> 6, dd = nn & 63;
-      T* base = reinterpret_cast<T*>(which ? g.out2 : g.out);
-      st4(base + (((int64_t)z * g.H + h) * g.Tpad + m) * 64 + dd, v);
-    } else if constexpr (EPI == EPI_QKV_DEC) {
-      const int which = n / g.D;
-      const int nn = n - which * g.D;
-      if (which == 0) {
-        st4(reinterpret_cast<T*>(g.out) + (int64_t)m * g.D + nn, v);
-      } else {
-        const int h = nn >> 6, dd = nn & 63;
-        const int pos = g.seq_tp ? m % g.seq_tp : *g.pos_ptr;
-        const int64_t crow = g.seq_tp ? m / g.seq_tp : m;
-        T* base = reinterpret_cast<T*>(which == 1 ? g.out2 : g.out3);
-        st4(base + ((crow * g.H + h) * g.cache_len + pos) * 64 + dd, v);
-      }
-    }
+    epi_nm_store<EPI, T>(g, z, m, n, v);
   }
 }
 
-template <typename T>
-__device__ __forceinline__ void epi_vt(const GemmArgs& g, int z, int m, int n, float v[4]) {
-  // v[i] belongs to (row m + i, column n); m % 4 == 0; m < M (M % 4 == 0), n < N.
-  const float b = g.bias ? g.bias[n] : 0.0f;
+// address of the 8 consecutive output elements (m, n8 .. n8 + 7), n8 % 8 == 0, of the 2-byte row-major / head-split epilogues
+template <int EPI, typename T>
+__device__ __forceinline__ T* epi_addr8(const GemmArgs& g, int z, int m, int n, int posv) {
+  if constexpr (EPI == EPI_T || EPI == EPI_GELU_T) {
+    return reinterpret_cast<T*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n;
+  } else if constexpr (EPI == EPI_QK_HEADS || EPI == EPI_CKV) {
+    const int which = n >= g.D;
+    const int nn = n - which * g.D;
+    const int h = nn >> 6, dd = nn & 63;
+    return reinterpret_cast<T*>(which ? g.out2 : g.out) + (((int64_t)z * g.H + h) * g.Tpad + m) * 64 + dd;
+  } else {   // EPI_QKV_DEC
+    const int which = n / g.D;
+    const int nn = n - which * g.D;
+    if (which == 0) return reinterpret_cast<T*>(g.out) + (int64_t)m * g.D + nn;
+    const int h = nn >> 6, dd = nn & 63;
+    const int pos = g.seq_tp ? m % g.seq_tp : posv;
+    const int64_t crow = g.seq_tp ? m / g.seq_tp : m;
+    return reinterpret_cast<T*>(which == 1 ? g.out2 : g.out3) + ((crow * g.H + h) * g.cache_len + pos) * 64 + dd;
+  }
+}
+
+// v_permlane16_swap: lanes 16-31 / 48-63 of a <-> lanes 0-15 / 32-47 of b
+__device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+
+__device__ __forceinline__ bool g_epi_wide_dev(const GemmArgs& g) { return g.epi_wide != 0; }
+
+// Epilogue of an MFMA tile (RI x 4 fragments of 16 x 16 per wave, wave origin (mw, nw)).  The bias of the wave's four column
+// groups is fetched ONCE, before the fragment loop: written as one load inside every fragment's bounds check, hipcc emits a
+// branch + global_load + s_waitcnt vmcnt(0) per fragment -- 16 to 32 serialised L2 round trips at the end of every tile.
+template <int EPI, typename T, int RI>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& g, int z, int mw, int nw, int lane, f32x4_t (&acc)[RI][4]) {
+  if constexpr (EPI == EPI_PARTIAL_F32 || EPI == EPI_F32) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] += b;
-  const int h = n >> 6, dd = n & 63;
-  st4(reinterpret_cast<T*>(g.out) + (((int64_t)z * g.H + h) * 64 + dd) * g.Tpad + m, v);
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        const int m = mw + i * 16 + (lane & 15), n = nw + j * 16 + (lane >> 4) * 4;
+        if (m < g.M && n < g.N) epi_nm<EPI, T>(g, z, m, n, v);
+      }
+  } else if constexpr (EPI == EPI_RESID_F32) {
+    // x += acc + bias: the 16 residual loads of four fragment rows are issued before the first add / store (written as
+    // load-add-store per fragment this epilogue is a chain of dependent memory round trips)
+    const int nb = nw + (lane >> 4) * 4;
+    float4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = min(nb + j * 16, g.N - 4);
+      bias4[j] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float* xo = reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch;
+#pragma unroll
+    for (int ih = 0; ih < RI; ih += 4) {
+      float4 r[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = min(mw + (ih + i) * 16 + (lane & 15), g.M - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          r[i][j] = *reinterpret_cast<const float4*>(xo + (int64_t)m * g.ldc + min(nb + j * 16, g.N - 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mw + (ih + i) * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = nb + j * 16;
+          if (m < g.M && n < g.N) {
+            const f32x4_t a4 = acc[ih + i][j];
+            float4 x = r[i][j];
+            x.x += a4[0] + bias4[j].x; x.y += a4[1] + bias4[j].y; x.z += a4[2] + bias4[j].z; x.w += a4[3] + bias4[j].w;
+            *reinterpret_cast<float4*>(xo + (int64_t)m * g.ldc + n) = x;
+          }
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_VT) {
+    float b1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = min(nw + j * 16 + (lane & 15), g.N - 1);
+      b1[j] = g.bias ? g.bias[n] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4] = {acc[i][j][0] + b1[j], acc[i][j][1] + b1[j], acc[i][j][2] + b1[j], acc[i][j][3] + b1[j]};
+        const int m = mw + i * 16 + (lane >> 4) * 4, n = nw + j * 16 + (lane & 15);
+        if (m < g.M && n < g.N) epi_vt_store<T>(g, z, m, n, v);
+      }
+  } else {
+    float4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = min(nw + j * 16 + (lane >> 4) * 4, g.N - 4);     // N % 4 == 0 for these epilogues
+      b4[j] = g.bias ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // the bias goes onto every accumulator in straight-line code: inside the bounds-checked fragment blocks each use
+    // costs an `s_waitcnt vmcnt(0)`, which on gfx9 also waits for the previous fragment's STORES to reach L2
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j][0] += b4[j].x; acc[i][j][1] += b4[j].y; acc[i][j][2] += b4[j].z; acc[i][j][3] += b4[j].w;
+      }
+    constexpr bool WIDE = sizeof(T) == 2 && (EPI == EPI_T || EPI == EPI_GELU_T || EPI == EPI_QK_HEADS || EPI == EPI_CKV ||
+                                             EPI == EPI_QKV_DEC);
+    if constexpr (WIDE) {
+      // 16-byte stores.  A lane holds 4 consecutive columns of one row (8 bytes); the lanes 16 apart hold the next 4.
+      // v_permlane16_swap on the packed words of two neighbouring fragments (odd 16-lane rows of the first operand <->
+      // even rows of the second) leaves every lane with 8 consecutive columns: lane group q = lane >> 4 owns columns
+      // (q >> 1) * 8 .. + 7 of fragment j + (q & 1).  The epilogue of a 256 x 256 tile is bound by the NUMBER of store
+      // instructions (32 per wave as 8-byte stores), not by their bytes.
+      if ((g.N & 7) == 0 && (g.ldc & 7) == 0 && g_epi_wide_dev(g)) {
+        int posv = 0;
+        if constexpr (EPI == EPI_QKV_DEC) posv = g.seq_tp ? 0 : *g.pos_ptr;
+        const int q = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+          const int m = mw + i * 16 + (lane & 15);
+#pragma unroll
+          for (int jp = 0; jp < 4; jp += 2) {
+            float va[4] = {acc[i][jp][0], acc[i][jp][1], acc[i][jp][2], acc[i][jp][3]};
+            float vb[4] = {acc[i][jp + 1][0], acc[i][jp + 1][1], acc[i][jp + 1][2], acc[i][jp + 1][3]};
+            if constexpr (EPI == EPI_GELU_T) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { va[e] = gelu_for<T>(va[e]); vb[e] = gelu_for<T>(vb[e]); }
+            }
+            const int n8 = nw + (jp + (q & 1)) * 16 + (q >> 1) * 8;
+            const bool in = m < g.M && n8 < g.N;
+            T* o = epi_addr8<EPI, T>(g, z, min(m, g.M - 1), min(n8, g.N - 8), posv);
+            uint32_t a0 = pack2<T>(va[0], va[1]), a1 = pack2<T>(va[2], va[3]);
+            uint32_t c0 = pack2<T>(vb[0], vb[1]), c1 = pack2<T>(vb[2], vb[3]);
+            swap16(a0, c0); swap16(a1, c1);
+            bool split_out = false;
+            if constexpr (EPI == EPI_T || EPI == EPI_GELU_T) split_out = g.split_out != 0;
+            if (split_out) {   // [hi | lo] rows: lo = T(v - hi), N elements further on
+              float ra[4], rb[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { ra[e] = va[e] - round_T<T>(va[e]); rb[e] = vb[e] - round_T<T>(vb[e]); }
+              uint32_t l0 = pack2<T>(ra[0], ra[1]), l1 = pack2<T>(ra[2], ra[3]);
+              uint32_t d0 = pack2<T>(rb[0], rb[1]), d1 = pack2<T>(rb[2], rb[3]);
+              swap16(l0, d0); swap16(l1, d1);
+              if (in) *reinterpret_cast<uint4*>(o + g.N) = make_uint4(l0, l1, d0, d1);
+            }
+            if (in) *reinterpret_cast<uint4*>(o) = make_uint4(a0, a1, c0, c1);
+          }
+        }
+        return;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        const int m = mw + i * 16 + (lane & 15), n = nw + j * 16 + (lane >> 4) * 4;
+        if (m < g.M && n < g.N) epi_nm_store<EPI, T>(g, z, m, n, v);
+      }
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -113,6 +292,33 @@ __device__ __forceinline__ uint4 ldg16_pred(const void* p, bool pred) {
 }
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * TBK + ((chunk ^ (row & 7)) << 3); }
+
+// Workgroup barrier WITHOUT the fence of __syncthreads().  With LDS-DMA (global_load_lds) requests in flight hipcc turns
+// the fence into `s_waitcnt vmcnt(0)` in front of the s_barrier, i.e. every barrier drains the whole prefetch queue
+// (seen in the device assembly of the multi-stage kernels: the counted wait right before it was dead code).  The kernels
+// that use this barrier order their LDS traffic themselves: a counted s_waitcnt vmcnt(N) by the waves that issued the
+// DMA, then this barrier, then the ds_reads (MI355X: nothing else orders a ds_read behind a pending LDS-DMA), and an
+// s_waitcnt lgkmcnt(0) by the readers before the barrier that hands a buffer back to the DMA.
+__device__ __forceinline__ void wg_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 32 && N % 4 == 0, "unsupported count");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if constexpr (N == 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+}
 
 template <typename T, int EPI, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_h_tile_kernel(const GemmArgs g) {
@@ -247,21 +453,7 @@ __global__ __launch_bounds__(256) void gemm_h_tile_kernel(const GemmArgs g) {
 #undef WJ_GLOAD1
 #undef WJ_SSTORE1
 
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if constexpr (EPI == EPI_VT) {
-        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
-        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-        if (m < g.M && n < g.N) epi_vt<T>(g, z, m, n, v);
-      } else {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-        const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-        if (m < g.M && n < g.N) epi_nm<EPI, T>(g, z, m, n, v);
-      }
-    }
+  tile_epilogue<EPI, T, 4>(g, z, m0 + wm * 64, n0 + wn * 64, lane, acc);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -367,55 +559,299 @@ __global__ __launch_bounds__(512) void gemm_h_big_kernel(const GemmArgs g) {
   }
 #undef WJ_BIG_STAGE
 
-  if constexpr (EPI == EPI_RESID_F32) {
-    // x += acc + bias: all 16 residual loads of a half-tile are issued before the first add/store (written as
-    // load-add-store per fragment this epilogue is a chain of 32 dependent memory round trips)
-    const int nb = n0 + wn * 64 + (lane >> 4) * 4;
-    float4 bias4[4];
+  tile_epilogue<EPI, T, 8>(g, z, m0 + wm * 128, n0 + wn * 64, lane, acc);
+}
+
+// --------------------------------------------------------------------------------------------
+// 16-bit MFMA, 256x256 tile, k-stages of 32, NS-deep LDS-DMA ring, two wave groups in ping-pong.
+//
+// Why: the kernel above keeps all eight waves in lockstep -- after the per-k-step barrier every wave first issues its 8
+// LDS-DMA requests and 24 ds_reads, so the matrix pipe idles for that whole issue phase, and the `vmcnt(0)` in front
+// of the barrier allows one k-step (64 KiB) in flight per CU: measured 0.82-1.0 PFLOP/s, the waves 40-50 % parked at
+// the barrier.  Here
+//   * a stage is 256 x 32 of A and of W (32 KiB, one MFMA k-block), the ring holds NS of them and NS-1 are in flight:
+//     the wait in front of a barrier is `s_waitcnt vmcnt(4 (NS-2))`, never 0 inside the main loop;
+//   * the waves with wm = 0 and wm = 1 (the two waves that share each SIMD) run one barrier apart: while one group
+//     issues its ds_reads + LDS-DMA (MEM phase) the other one runs its 32 MFMAs on fragments already in registers.
+//
+// Barrier sequence B0, B1, ... after the prologue barrier P (every wave takes part in every barrier):
+//   group 0:          MEM(0) B0 MFMA(0) B1 MEM(1) B2 MFMA(1) B3 ...            MEM(kt) ends at B(2kt)
+//   group 1:   -      B0 MEM(0) B1 MFMA(0) B2 MEM(1) B3 MFMA(1) B4 ...         MEM(kt) ends at B(2kt+1)
+//   MEM(kt):  ds_read the fragments of stage kt; request stage kt+NS-1 into the buffer of stage kt-1;
+//             s_waitcnt vmcnt -> own requests of stage kt+1 have landed; s_waitcnt lgkmcnt(0) -> own reads retired.
+// RAW: both groups have waited for their requests of stage kt+1 by B(2kt+1); the first reads of that stage come after
+//      B(2kt+1) (group 0) and B(2kt+2) (group 1).  Stage 0: waited for before P.
+// WAR: the buffer of stage kt-1 is read last in group 1's MEM(kt-1), retired before B(2kt-1); it is requested again in
+//      MEM(kt): after B(2kt-1) (group 0) and after B(2kt) (group 1).
+// 64-byte LDS rows; the 16-byte chunk c of row r sits in slot c ^ f((r >> 2) & 3), f = {0, 2, 3, 1}: conflict-free for
+// the four 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32).  The accumulation order over k is
+// the one of the kernels above (ascending blocks of 32), so the results are bit-identical to theirs.
+// --------------------------------------------------------------------------------------------
+constexpr int PBK = 32;
+constexpr int PSTAGE = 2 * BBM * PBK;   // elements per stage: A[256][32] then W[256][32]
+
+__device__ __forceinline__ int pp_f(int row) {
+  const int q = (row >> 2) & 3;
+  return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
+}
+
+// ABL (timing experiments only, results are wrong): bit 0 no LDS-DMA in the main loop, bit 1 no ds_reads in the main loop,
+// bit 2 no MFMAs, bit 3 no barriers in the main loop
+// PLACE: where a wave issues its 4 LDS-DMA requests of a stage: 0 = in its MEM phase after the ds_reads, 1 = in its MEM
+// phase before them, 2 = between the MFMAs of its MFMA phase (one request per 8 MFMAs; the stage then lands one phase
+// later, so the wait in MEM(kt) leaves NS-3 stages in flight instead of NS-2)
+template <typename T, int EPI, int NS, int ABL = 0, int PLACE = 0>
+__global__ __launch_bounds__(512) void gemm_h_big_pp_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds_pp[];   // [stage][A|W][256][32]
+  constexpr int D = NS - 1;                                          // stages in flight
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int z = blockIdx.z;
+  const int nx = gridDim.x, ntiles = gridDim.x * gridDim.y;
+  const int lin = blockIdx.y * nx + blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  constexpr int GM = 8;
+  const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
+  const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
+  const int m0 = (first_m + in_group % gsz) * BBM, n0 = (in_group / gsz) * BBN;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)z * g.a_batch;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+
+  // staging: a wave request deposits 64 x 16 B = 16 rows of 64 B, lane-linear; the swizzle goes into the SOURCE address
+  // (slot s = lane & 3 of row r fetches chunk s ^ f(r)).  Two A pieces and two W pieces per wave and stage.
+  const bf16_t* ga[2];
+  const bf16_t* gw[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      bias4[j] = g.bias ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float* xo = reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch;
-#pragma unroll
-    for (int ih = 0; ih < 8; ih += 4) {
-      float4 r[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = min(m0 + wm * 128 + (ih + i) * 16 + (lane & 15), g.M - 1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r[i][j] = *reinterpret_cast<const float4*>(xo + (int64_t)m * g.ldc + nb + j * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 128 + (ih + i) * 16 + (lane & 15);
-        if (m < g.M) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const f32x4_t a4 = acc[ih + i][j];
-            float4 x = r[i][j];
-            x.x += a4[0] + bias4[j].x; x.y += a4[1] + bias4[j].y; x.z += a4[2] + bias4[j].z; x.w += a4[3] + bias4[j].w;
-            *reinterpret_cast<float4*>(xo + (int64_t)m * g.ldc + nb + j * 16) = x;
-          }
-        }
-      }
-    }
-    return;
+  for (int p = 0; p < 2; ++p) {
+    const int row = (wave * 2 + p) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ pp_f(row);
+    ga[p] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
+    gw[p] = W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
   }
+#define WJ_PP_ISSUE(buf)                                                                                      \
+  _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga[p],                    \
+        (__attribute__((address_space(3))) void*)(&lds_pp[(buf) * PSTAGE + (wave * 2 + p) * 16 * PBK]), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw[p],                    \
+        (__attribute__((address_space(3))) void*)(&lds_pp[(buf) * PSTAGE + BBM * PBK + (wave * 2 + p) * 16 * PBK]), 16, 0, 0); \
+    ga[p] += PBK;                                                                                             \
+    gw[p] += PBK;                                                                                             \
+  }
+
+  f32x4_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if constexpr (EPI == EPI_VT) {
-        const int m = m0 + wm * 128 + i * 16 + (lane >> 4) * 4;
-        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-        if (m < g.M && n < g.N) epi_vt<T>(g, z, m, n, v);
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: row (lane & 15) of a 16-row block, chunk lane >> 4, swizzled (f depends on the lane only)
+  const int frag = (lane & 15) * PBK + (((lane >> 4) ^ pp_f(lane & 15)) << 3);
+  const int a_frag = wm * 128 * PBK + frag;
+  const int w_frag = BBM * PBK + wn * 64 * PBK + frag;
+
+  const int nk = g.K / PBK;      // launch guarantees nk >= NS
+#pragma unroll
+  for (int st = 0; st < D; ++st) { WJ_PP_ISSUE(st) }
+  wait_vmcnt<4 * (D - 1)>();     // own requests of stage 0 have landed
+  wg_barrier();                  // P: stage 0 visible to every wave
+  if (wm == 1) wg_barrier();     // B0: group 1 runs one barrier behind group 0
+
+  int cbuf = 0, ibuf = D;        // buffer of stage kt / of stage kt + D
+  typename Vec8<T>::type af[8], wf[4];
+  if constexpr ((ABL & 2) != 0) {
+    const bf16_t* ls = &lds_pp[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const typename Vec8<T>::type*>(&ls[w_frag + j * 16 * PBK]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const typename Vec8<T>::type*>(&ls[a_frag + i * 16 * PBK]);
+  }
+#define WJ_PP_MFMA(i, j)                                                   \
+  if constexpr (EPI == EPI_VT) acc[i][j] = mfma16(af[i], wf[j], acc[i][j]); \
+  else acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+#define WJ_PP_ONE(X, p, region)                                                                                  \
+  {                                                                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X[p] + back),               \
+        (__attribute__((address_space(3))) void*)(&lds_pp[ibuf * PSTAGE + (region) + (wave * 2 + p) * 16 * PBK]), 16, 0, 0); \
+    X[p] += step;                                                                                                \
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- MEM(kt)
+    const bool more = kt + D < nk;
+    if constexpr (PLACE == 1 && (ABL & 1) == 0) {
+      if (more) { WJ_PP_ISSUE(ibuf) }
+    }
+    if constexpr ((ABL & 2) == 0) {
+      const bf16_t* ls = &lds_pp[cbuf * PSTAGE];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const typename Vec8<T>::type*>(&ls[w_frag + j * 16 * PBK]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const typename Vec8<T>::type*>(&ls[a_frag + i * 16 * PBK]);
+    }
+    if constexpr (PLACE == 2) {
+      wait_vmcnt<4 * (D - 2)>();   // stage kt+1 landed; the requests of MFMA(kt-D+2) .. MFMA(kt-1) stay in flight
+    } else {
+      if (more) {
+        if constexpr (PLACE == 0 && (ABL & 1) == 0) { WJ_PP_ISSUE(ibuf) }
+        wait_vmcnt<4 * (D - 1)>();   // stage kt+1 landed; stages kt+2 .. kt+D stay in flight
       } else {
-        const int m = m0 + wm * 128 + i * 16 + (lane & 15);
-        const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-        if (m < g.M && n < g.N) epi_nm<EPI, T>(g, z, m, n, v);
+        wait_vmcnt<0>();
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr ((ABL & 8) == 0) wg_barrier(); else __builtin_amdgcn_sched_barrier(0);
+    // ---- MFMA(kt)
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr ((ABL & 4) == 0) {
+      if constexpr (PLACE == 2) {
+        // no branch around the requests (two copies of the MFMA block make hipcc spill the accumulators): past the last
+        // stage the wave re-requests its last block into a buffer nobody reads any more
+        const int back = more ? 0 : -PBK, step = more ? PBK : 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { WJ_PP_MFMA(i, j) }
+          if (i == 1) WJ_PP_ONE(ga, 0, 0)
+          if (i == 3) WJ_PP_ONE(gw, 0, BBM * PBK)
+          if (i == 5) WJ_PP_ONE(ga, 1, 0)
+          if (i == 7) WJ_PP_ONE(gw, 1, BBM * PBK)
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { WJ_PP_MFMA(i, j) }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(wf[j]));
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr ((ABL & 8) == 0) wg_barrier(); else __builtin_amdgcn_sched_barrier(0);
+    cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
+    ibuf = ibuf + 1 == NS ? 0 : ibuf + 1;
+  }
+#undef WJ_PP_MFMA
+#undef WJ_PP_ONE
+  if constexpr (PLACE == 2) wait_vmcnt<0>();   // the dummy requests of the tail must not outlive the workgroup's LDS
+  if (wm == 0) wg_barrier();     // every wave has taken part in the same number of barriers
+#undef WJ_PP_ISSUE
+
+  tile_epilogue<EPI, T, 8>(g, z, m0 + wm * 128, n0 + wn * 64, lane, acc);
+}
+
+// --------------------------------------------------------------------------------------------
+// Ping-pong over 64-wide k "pairs": the schedule of gemm_h_big_pp_kernel, but the LDS-DMA fetches 128-byte row segments
+// (8 rows x 128 B per wave request) into two 64 KiB buffers laid out like gemm_h_big_kernel's.  Measured on MI355X with the
+// DMA stream of this tile sweep alone (scripts/gemm_probe.hip `dma`): 64-byte segments top out at 11-14 TB/s whatever the
+// ring depth or request order, 128-byte segments reach 14-19 TB/s -- the L2 serves a 64-byte request at the cost of a
+// 128-byte one, and the 32-wide stages of the kernel above are bound by exactly that request rate.
+//   stage kt = 2 p + h reads k-half h of pair p (buffer p & 1);  MEM(2p) also requests pair p+1 into the other buffer,
+//   MEM(2p+1) ends with s_waitcnt vmcnt(0).
+// WAR: the other buffer held pair p-1, read last in group 1's MEM(2p-1) (retired before B(4p-1)); MEM(2p) starts after
+//      B(4p-1) (group 0) / B(4p) (group 1).   RAW: both groups have waited for pair p+1 by B(4p+3); it is first read in
+//      MEM(2p+2), after B(4p+3) (group 0) / B(4p+4) (group 1).
+// --------------------------------------------------------------------------------------------
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_h_big_pp64_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds_p6[];   // [buf][A|W][256][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int z = blockIdx.z;
+  const int nx = gridDim.x, ntiles = gridDim.x * gridDim.y;
+  const int lin = blockIdx.y * nx + blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  constexpr int GM = 8;
+  const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
+  const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
+  const int m0 = (first_m + in_group % gsz) * BBM, n0 = (in_group / gsz) * BBN;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)z * g.a_batch;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+  constexpr int STAGE = 2 * BBM * TBK;   // elements per pair buffer (A then W)
+
+  const bf16_t* ga[4];
+  const bf16_t* gw[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = (wave * 4 + q) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (row & 7);
+    ga[q] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
+    gw[q] = W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
+  }
+#define WJ_P6_ISSUE(buf)                                                                                       \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga[q],                     \
+        (__attribute__((address_space(3))) void*)(&lds_p6[(buf) * STAGE + (wave * 4 + q) * 8 * TBK]), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw[q],                     \
+        (__attribute__((address_space(3))) void*)(&lds_p6[(buf) * STAGE + BBM * TBK + (wave * 4 + q) * 8 * TBK]), 16, 0, 0); \
+    ga[q] += TBK;                                                                                              \
+    gw[q] += TBK;                                                                                              \
+  }
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment offsets: row (lane & 15) of a 16-row block, chunk h * 4 + (lane >> 4), XOR-swizzled with row & 7 = lane & 7
+  const int rowoff = (lane & 15) * TBK;
+  const int off_h0 = rowoff + ((((lane >> 4)) ^ (lane & 7)) << 3);
+  const int off_h1 = rowoff + (((4 + (lane >> 4)) ^ (lane & 7)) << 3);
+  const int a_base = wm * 128 * TBK, w_base = BBM * TBK + wn * 64 * TBK;
+
+  const int np = g.K / TBK;
+  WJ_P6_ISSUE(0)
+  wait_vmcnt<0>();
+  wg_barrier();                  // P: pair 0 visible to every wave
+  if (wm == 1) wg_barrier();     // B0: group 1 runs one barrier behind group 0
+
+  typename Vec8<T>::type af[8], wf[4];
+#define WJ_P6_READ(buf, off)                                                                                          \
+  {                                                                                                                    \
+    const bf16_t* ls = &lds_p6[(buf) * STAGE];                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                      \
+      wf[j] = *reinterpret_cast<const typename Vec8<T>::type*>(&ls[w_base + j * 16 * TBK + (off)]);                    \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                      \
+      af[i] = *reinterpret_cast<const typename Vec8<T>::type*>(&ls[a_base + i * 16 * TBK + (off)]);                    \
+  }
+#define WJ_P6_MFMA()                                                         \
+  __builtin_amdgcn_s_setprio(1);                                             \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i)                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                          \
+      if constexpr (EPI == EPI_VT) acc[i][j] = mfma16(af[i], wf[j], acc[i][j]); \
+      else acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);                      \
+    }                                                                        \
+  __builtin_amdgcn_s_setprio(0);
+
+  for (int p = 0; p < np; ++p) {
+    const int b = p & 1;
+    // ---- MEM(2p): k-half 0 of pair p; request pair p+1
+    WJ_P6_READ(b, off_h0)
+    if (p + 1 < np) { WJ_P6_ISSUE(b ^ 1) }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wg_barrier();
+    WJ_P6_MFMA()
+    wg_barrier();
+    // ---- MEM(2p+1): k-half 1 of pair p; pair p+1 has landed
+    WJ_P6_READ(b, off_h1)
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wg_barrier();
+    WJ_P6_MFMA()
+    wg_barrier();
+  }
+  if (wm == 0) wg_barrier();     // every wave has taken part in the same number of barriers
+#undef WJ_P6_ISSUE
+#undef WJ_P6_READ
+#undef WJ_P6_MFMA
+
+  tile_epilogue<EPI, T, 8>(g, z, m0 + wm * 128, n0 + wn * 64, lane, acc);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -482,7 +918,9 @@ __global__ __launch_bounds__(256) void gemm_h_tile_ms_kernel(const GemmArgs g) {
     else if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                  // stage kt visible to all; buffer of stage kt-1 is free
+    // stage kt visible to all; buffer of stage kt-1 is free (its ds_reads were consumed by the MFMAs of step kt-1).
+    // NOT __syncthreads(): its fence drains vmcnt to 0 and with it the stages this loop keeps in flight.
+    wg_barrier();
     if (kt + NS - 1 < nk) { WJ_MS_STAGE((kt + NS - 1) % NS, (kt + NS - 1) * TBK) }
     const bf16_t* la = &lds_ms[(kt % NS) * STAGE];
     const bf16_t* lb = la + TBM * TBK;
@@ -503,15 +941,7 @@ __global__ __launch_bounds__(256) void gemm_h_tile_ms_kernel(const GemmArgs g) {
   }
 #undef WJ_MS_STAGE
 
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-      const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-      if (m < g.M && n < g.N) epi_nm<EPI, T>(g, z, m, n, v);
-    }
+  tile_epilogue<EPI, T, 4>(g, z, m0 + wm * 64, n0 + wn * 64, lane, acc);
 }
 
 template <typename T, int EPI, int NS>
@@ -550,7 +980,12 @@ static int launch_ms(const GemmArgs& a, hipStream_t s, int ns) {
   }
 }
 
-int g_gemm_big = 1;   // wj_tune("gemm_big"): 0 disables the 256-tile kernel, 2 selects its issue-order-hinted build
+// wj_tune("gemm_big"): 0 disables the 256-tile kernels, 1 = lockstep 256-tile kernel, 2 = its issue-order-hinted build,
+// 3 / 4 / 5 = the ping-pong kernel with that many 32-wide ring stages, 6 = the ping-pong kernel over 64-wide pairs (default:
+// 987 / 1136 / 1068 / 973 TFLOP/s on the encoder's fc1 / fc2 / qk / out shapes against 933 / 1084 / 1016 / 947 for 1 and
+// 954 / 1122 / 1043 / 969 for 3; all of them bit-identical, profiles/r02_gemm_probe.json)
+int g_gemm_big = 6;
+int g_epi_wide = 1;   // wj_tune("epi_wide"): 16-byte epilogue stores (GemmArgs::epi_wide)
 
 template <typename T, int EPI>
 static int launch_big(const GemmArgs& a, hipStream_t s) {
@@ -574,6 +1009,69 @@ static int launch_big(const GemmArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_h_big_kernel<T, EPI, 0>), grid, dim3(512), smem, s, a);
     WJ_LAUNCH_CHECK();
     return WJ_OK;
+  }
+}
+
+template <typename T, int EPI, int NS>
+static int launch_big_pp_inst(const GemmArgs& a, hipStream_t s) {
+  constexpr size_t smem = (size_t)NS * PSTAGE * sizeof(bf16_t);   // NS x 32 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_pp_kernel<T, EPI, NS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { set_error("hipFuncSetAttribute(%d KiB LDS): %s", (int)(smem >> 10), hipGetErrorString(e)); return WJ_E_HIP; }
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(a.N, BBN), ceil_div(a.M, BBM), a.nbatch);
+  hipLaunchKernelGGL((gemm_h_big_pp_kernel<T, EPI, NS>), grid, dim3(512), smem, s, a);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+template <typename T, int EPI>
+static int launch_big_pp64(const GemmArgs& a, hipStream_t s) {
+  if constexpr (EPI == EPI_PARTIAL_F32) {
+    set_error("gemm: the 256-tile kernels have no split-K mode");
+    return WJ_E_INVALID;
+  } else {
+    constexpr size_t smem = 2 * 2 * BBM * TBK * sizeof(bf16_t);   // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_pp64_kernel<T, EPI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) { set_error("hipFuncSetAttribute(128 KiB LDS): %s", hipGetErrorString(e)); return WJ_E_HIP; }
+      attr_set = true;
+    }
+    dim3 grid(ceil_div(a.N, BBN), ceil_div(a.M, BBM), a.nbatch);
+    hipLaunchKernelGGL((gemm_h_big_pp64_kernel<T, EPI>), grid, dim3(512), smem, s, a);
+    WJ_LAUNCH_CHECK();
+    return WJ_OK;
+  }
+}
+
+template <typename T, int EPI, int NS, int ABL, int PLACE = 0>
+static int launch_big_pp_abl(const GemmArgs& a, hipStream_t s) {
+  constexpr size_t smem = (size_t)NS * PSTAGE * sizeof(bf16_t);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_pp_kernel<T, EPI, NS, ABL, PLACE>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return WJ_E_HIP; }
+  dim3 grid(ceil_div(a.N, BBN), ceil_div(a.M, BBM), a.nbatch);
+  hipLaunchKernelGGL((gemm_h_big_pp_kernel<T, EPI, NS, ABL, PLACE>), grid, dim3(512), smem, s, a);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
+template <typename T, int EPI>
+static int launch_big_pp(const GemmArgs& a, hipStream_t s, int ns) {
+  if constexpr (EPI == EPI_PARTIAL_F32) {
+    set_error("gemm: the 256-tile kernels have no split-K mode");
+    return WJ_E_INVALID;
+  } else {
+    switch (ns) {
+      case 3: return launch_big_pp_inst<T, EPI, 3>(a, s);
+      case 5: return launch_big_pp_inst<T, EPI, 5>(a, s);
+      default: return launch_big_pp_inst<T, EPI, 4>(a, s);
+    }
   }
 }
 
@@ -877,6 +1375,36 @@ static int launch_epi16(const GemmArgs& a, hipStream_t s, int variant) {
   // big encoder GEMMs: 256-tile kernel (variant 6 forces it, 0 = auto when the shape qualifies)
   const bool big_ok = EPI != EPI_PARTIAL_F32 && (a.N % BBN) == 0 && (a.K % TBK) == 0 && a.M >= 1024 && !a.split;
   if (variant == 6 && !big_ok) { set_error("gemm: the 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, M >= 1024"); return WJ_E_INVALID; }
+  // 83 / 84 / 85 force the ping-pong kernel with a 3 / 4 / 5 stage ring; wj_tune("gemm_big", 3 / 4 / 5) makes it the default
+  const bool pp_ok = big_ok && (a.K % PBK) == 0 && a.K / PBK >= 5;
+  if ((variant >= 100 && variant < 270) || variant == 93 || variant == 94) {   // timing ablations of the ping-pong kernel (wrong results by design): 100 + 10 ABL + NS
+    if constexpr (EPI == EPI_T && Elem<T>::dtype == WJ_F16) {
+      if (!pp_ok) { set_error("gemm: shape not supported by the ping-pong kernel"); return WJ_E_INVALID; }
+      switch (variant) {
+#define WJ_ABL(A_) case 100 + 10 * A_ + 3: return launch_big_pp_abl<T, EPI, 3, A_>(a, s);
+        WJ_ABL(1) WJ_ABL(2) WJ_ABL(3) WJ_ABL(4) WJ_ABL(5) WJ_ABL(6) WJ_ABL(8) WJ_ABL(9) WJ_ABL(10) WJ_ABL(12) WJ_ABL(15)
+#undef WJ_ABL
+        case 93: return launch_big_pp_abl<T, EPI, 3, 0, 1>(a, s);    // experiments with the placement of the LDS-DMA requests
+        case 94: return launch_big_pp_abl<T, EPI, 4, 0, 1>(a, s);    // (correct results)
+        case 263: return launch_big_pp_abl<T, EPI, 3, 0, 2>(a, s);
+        case 264: return launch_big_pp_abl<T, EPI, 4, 0, 2>(a, s);
+        case 265: return launch_big_pp_abl<T, EPI, 5, 0, 2>(a, s);
+        default: break;
+      }
+    }
+    set_error("gemm: unknown ablation variant %d (float16 EPI_T only)", variant);
+    return WJ_E_INVALID;
+  }
+  if (variant >= 83 && variant <= 85) {
+    if (!pp_ok) { set_error("gemm: the ping-pong 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, K >= 160, M >= 1024"); return WJ_E_INVALID; }
+    return launch_big_pp<T, EPI>(a, s, variant - 80);
+  }
+  if (variant == 86) {   // ping-pong over 64-wide pairs (128-byte DMA segments); wj_tune("gemm_big", 6)
+    if (!big_ok) { set_error("gemm: the 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, M >= 1024"); return WJ_E_INVALID; }
+    return launch_big_pp64<T, EPI>(a, s);
+  }
+  if ((variant == 0 || variant == 1) && g_gemm_big == 6 && big_ok) return launch_big_pp64<T, EPI>(a, s);
+  if ((variant == 0 || variant == 1) && g_gemm_big >= 3 && g_gemm_big <= 5 && pp_ok) return launch_big_pp<T, EPI>(a, s, g_gemm_big);
   if (variant == 6 || ((variant == 0 || variant == 1) && g_gemm_big && big_ok)) return launch_big<T, EPI>(a, s);
   dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), EPI == EPI_PARTIAL_F32 ? a.ksplit : a.nbatch);
   static const int tile_mode = [] {   // WJ_GEMM_TILE=reg|glds overrides the default staging path
@@ -915,7 +1443,9 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
   return launch_epi16<bf16_t, EPI>(a, s, variant);
 }
 
-int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int variant) {
+int launch_gemm(int dtype, Epi epi, const GemmArgs& a_in, hipStream_t s, int variant) {
+  GemmArgs a = a_in;
+  a.epi_wide = g_epi_wide;
   const int kalign = is16(dtype) ? 8 : 4;
   if (a.K % kalign || a.lda % kalign || a.ldw % kalign || a.a_batch % kalign) {
     set_error("gemm: K/lda/ldw/a_batch must be multiples of %d elements (K=%d lda=%lld ldw=%lld)", kalign, a.K,

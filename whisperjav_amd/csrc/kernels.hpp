@@ -43,6 +43,9 @@ struct GemmArgs {
   // EPI_T / EPI_GELU_T: also store the rounding residual of the output at column offset N of the same row
   // (the consumer GEMM reads it as a split activation; ldc >= 2 N)
   int split_out = 0;
+  // 2-byte row-major / head-split epilogues of the MFMA tile kernels: 16-byte stores after a v_permlane16_swap of
+  // neighbouring fragments (set by launch_gemm from wj_tune "epi_wide"; 0 = the 8-byte stores, for A/B and cross-checks)
+  int epi_wide = 1;
 };
 
 // variant: 0 = auto; 1 = tiled MFMA kernel (default staging); 2 = skinny (decode) kernel;
@@ -113,6 +116,7 @@ struct DecAttnArgs {
 extern int g_dec_cross_u;
 extern int g_dec_cross_nt;
 extern int g_gemm_big;
+extern int g_epi_wide;
 int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s);
 
 // ---------------- word-timestamp alignment (align.hip) ------------------------------------------------
