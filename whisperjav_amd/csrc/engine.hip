@@ -95,8 +95,10 @@ struct Tunables {
   int dec_tile_reg = 0;     // 1: the decode tile GEMMs stage through registers (global->VGPR->LDS) instead of LDS-DMA
   int dec_ms_stages = 0;    // LDS-DMA stages of ALL decode tile GEMMs (0 = the 2-stage kernel, 2 workgroups per CU: faster for
                             // the wide projections, 746 vs 593 TFLOP/s on 1920 x 3840 x 1280)
-  int dec_ms_resid = 3;     // ... of the residual-writing ones (N = 1280: 150 row x column tiles, one workgroup per CU anyway;
-                            // 3 stages in flight: 204 vs 191 TFLOP/s on 1920 x 1280 x 1280, 368 vs 334 with K = 5120); 0 = off
+  int dec_ms_resid = 0;     // ... of the residual-writing ones only.  Stand-alone (one 150-tile launch, 1920 x 1280 x 1280 / 5120)
+                            // 3 stages are 6-10 % faster; in the step these GEMMs run as 2 K-slices = 300 workgroups, which
+                            // fit the 256 CUs at once with the 64 KiB kernel (2 per CU) and need a second round with 96 KiB:
+                            // measured +18-28 % on the out / cross-out / fc2 GEMMs of the 120-min run.  0 = off
   int dec_fuse_reduce = 1;  // attention kernels consume the q / qkv split-K slices directly (no reduce launch)
   int align_prefill = 1;    // word-timestamp alignment as one full-sequence decoder pass (0: token by token)
   int dec_cross_mfma = 1;   // 16-bit models: cross V kept transposed, cross attention on the matrix cores (read at create)
