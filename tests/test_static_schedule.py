@@ -1,0 +1,126 @@
+"""Static checks of the device code hipcc emitted for the pipelined GEMM kernels (no GPU needed: the gfx950 code object is
+cut out of the built ``gemm.o`` and disassembled).
+
+What they guard: the property the round-2 probe found missing in round 1's multi-stage kernels -- LDS-DMA requests must
+stay in flight ACROSS the workgroup barrier.  ``__syncthreads()`` carries a fence that hipcc lowers to
+``s_waitcnt vmcnt(0) ...`` in front of ``s_barrier`` whenever ``global_load_lds`` is outstanding, which silently turns a
+counted-``vmcnt`` ring into a drain-every-step loop (same results, no pipelining).  The kernels use a raw ``s_barrier``
+and their own counted waits instead; these tests fail if a rebuild brings the drain back, if the main loops lose their
+shape, or if a kernel starts spilling.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+OBJDUMP, READELF = os.path.join(LLVM, "llvm-objdump"), os.path.join(LLVM, "llvm-readelf")
+pytestmark = pytest.mark.skipif(not (os.path.exists(OBJDUMP) and os.path.exists(READELF)), reason="ROCm LLVM tools not present")
+
+GEMM_ARGS = "EEvNS_8GemmArgsE"
+PP64 = "_ZN2wj22gemm_h_big_pp64_kernelIDF16_Li%dE" + GEMM_ARGS            # <f16, EPI>
+PP = "_ZN2wj20gemm_h_big_pp_kernelIDF16_Li0ELi%dELi0ELi0E" + GEMM_ARGS    # <f16, EPI_T, NS, ABL 0, PLACE 0>
+MS = "_ZN2wj21gemm_h_tile_ms_kernelIDF16_Li0ELi%dE" + GEMM_ARGS           # <f16, EPI_T, NS>
+BIG = "_ZN2wj17gemm_h_big_kernelIDF16_Li0ELi0E" + GEMM_ARGS               # lockstep kernel (drains by design)
+
+
+@pytest.fixture(scope="module")
+def code_object(tmp_path_factory):
+    from whisperjav_amd import build
+    build.build(verbose=False)
+    obj = build.CSRC / "build" / "gemm.o"
+    assert obj.exists()
+    tmp = tmp_path_factory.mktemp("co")
+    local = tmp / "gemm.o"
+    shutil.copy(obj, local)
+    subprocess.run([OBJDUMP, "--offloading", str(local)], check=True, capture_output=True)
+    cos = [p for p in tmp.iterdir() if "gfx950" in p.name]
+    assert len(cos) == 1, list(tmp.iterdir())
+    return cos[0]
+
+
+def _disasm(co, symbol):
+    out = subprocess.run([OBJDUMP, "-d", f"--disassemble-symbols={symbol}", str(co)], check=True, capture_output=True, text=True).stdout
+    ins = [l.split("//")[0].strip() for l in out.splitlines() if l.startswith("\t")]
+    assert ins, f"{symbol} not found in the code object"
+    return ins
+
+
+def _before_barriers(ins, window=2):
+    return [ins[max(0, k - window):k] for k, l in enumerate(ins) if l.startswith("s_barrier")]
+
+
+def _is_fence(l):
+    # the lowered fence of __syncthreads(): one s_waitcnt that zeroes vmcnt AND lgkmcnt
+    return l.startswith("s_waitcnt") and "vmcnt(0)" in l and "lgkmcnt(0)" in l
+
+
+def test_pairs_kernel_main_loop(code_object):
+    ins = _disasm(code_object, PP64 % 0)
+    assert sum(l.startswith("v_mfma") for l in ins) == 64          # two MFMA phases of 32, unrolled once
+    assert sum(l.startswith("ds_read_b128") for l in ins) == 24
+    assert sum("global_load_lds_dwordx4" in l for l in ins) == 16    # prologue + one pair per loop trip
+    pre = _before_barriers(ins)
+    assert len(pre) == 7       # P, the stagger barrier, 4 in the loop, the balancing one after it
+    assert not any(_is_fence(l) for w in pre for l in w), pre
+    # the only drains in front of a barrier: the prologue's and the one that ends MEM(2p+1)
+    assert sum(any(l == "s_waitcnt vmcnt(0)" for l in w) for w in pre) == 2, pre
+    # the MFMA phases are uninterrupted: 32 MFMAs between s_setprio 1 and s_setprio 0, nothing else
+    k = ins.index("s_setprio 1")
+    body = [l for l in ins[k + 1:ins.index("s_setprio 0", k)] if l != "s_waitcnt lgkmcnt(0)"]   # hipcc's own (already satisfied) wait
+    assert len(body) == 32 and all(l.startswith("v_mfma") for l in body), body[:40]
+
+
+@pytest.mark.parametrize("ns", [3, 4, 5])
+def test_ring_kernel_keeps_requests_in_flight_across_barriers(code_object, ns):
+    ins = _disasm(code_object, PP % ns)
+    pre = _before_barriers(ins, window=3)
+    assert len(pre) == 5
+    assert not any(_is_fence(l) for w in pre for l in w), pre
+    counted = f"s_waitcnt vmcnt({4 * (ns - 2)})"
+    assert sum(l == counted for l in ins) == 2, (counted, [l for l in ins if l.startswith("s_waitcnt vmcnt")])
+    assert sum(l.startswith("v_mfma") for l in ins) == 32
+
+
+@pytest.mark.parametrize("ns", [3, 4, 5])
+def test_decode_ring_kernel_has_no_fence(code_object, ns):
+    ins = _disasm(code_object, MS % ns)
+    pre = _before_barriers(ins)
+    assert len(pre) == 1 and not any(_is_fence(l) for l in pre[0]), pre
+    assert f"s_waitcnt vmcnt({8 * (ns - 2)})" in ins
+
+
+def test_lockstep_kernel_is_the_one_that_drains(code_object):
+    # the control: __syncthreads() with LDS-DMA in flight does produce the fence this file looks for
+    pre = _before_barriers(_disasm(code_object, BIG))
+    assert any(_is_fence(l) for w in pre for l in w), pre
+
+
+@pytest.mark.parametrize("epi,name", [(0, "bias"), (1, "gelu"), (5, "q/k heads"), (8, "cross k/v")])
+def test_epilogue_store_width_and_no_per_fragment_waits(code_object, epi, name):
+    ins = _disasm(code_object, PP64 % epi)
+    # 16-byte stores exist (permlane-swapped fragment pairs) ...
+    assert sum(l.startswith("v_permlane16_swap") for l in ins) >= 32
+    assert sum(l.startswith("global_store_dwordx4") for l in ins) >= 16
+    # ... and the epilogue is not a chain of "wait for everything, then store" blocks any more (round 1: one per fragment)
+    tail = ins[max(k for k, l in enumerate(ins) if l.startswith("s_barrier")):]
+    assert sum(l.startswith("s_waitcnt vmcnt(0)") for l in tail) <= 2, name
+
+
+def test_no_spills_in_the_256_tile_kernels(code_object):
+    notes = subprocess.run([READELF, "--notes", str(code_object)], check=True, capture_output=True, text=True).stdout
+    blocks = re.split(r"\n\s*- \.agpr_count:", notes)
+    seen = 0
+    for b in blocks:
+        m = re.search(r"\.name:\s+(\S+)", b)
+        if not m or "gemm_h_big" not in m.group(1):
+            continue
+        if re.search(r"Li\d+ELi\d+ELi[1-9]\d*ELi\dE", m.group(1)):   # timing-ablation instantiations
+            continue
+        seen += 1
+        size = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", b).group(1))
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", b).group(1))
+        assert size == 0 and vgpr <= 256, (m.group(1), size, vgpr)
+    assert seen >= 40, seen
