@@ -265,7 +265,7 @@ int main(int argc, char** argv) {
     std::vector<Shape> enc = {
         {"enc_fc1", M, 5120, 1280, 1, 0}, {"enc_fc2", M, 1280, 5120, 0, 0}, {"enc_qk", M, 2560, 1280, 0, 0},
         {"enc_out", M, 1280, 1280, 0, 0}, {"enc_out_f32", M, 1280, 1280, 0, 1}};
-    run_set(enc, 6, {83, 86}, {});
+    run_set(enc, 6, {86, 87}, {});
   }
   if (what == "dma") {
     for (auto sh : {Shape{"fc2", 144128, 1280, 5120, 0, 0}, Shape{"qk", 144128, 2560, 1280, 0, 0}, Shape{"fc1", 144128, 5120, 1280, 0, 0}}) {

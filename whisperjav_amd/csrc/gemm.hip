@@ -18,6 +18,8 @@
 // kernel's P.V operand).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace wj {
@@ -855,6 +857,132 @@ __global__ __launch_bounds__(512) void gemm_h_big_pp64_kernel(const GemmArgs g) 
 }
 
 // --------------------------------------------------------------------------------------------
+// Persistent form of gemm_h_big_pp64_kernel (EXPERIMENT, opt-in: variant 87 / wj_tune("gemm_big", 7)): one workgroup per
+// CU walks tiles L, L + G, L + 2G, ... and treats their k-pairs as ONE stream -- the last MEM(h0) phase of a tile already
+// requests pair 0 of the next tile, so no tile but the first pays the LDS-DMA round trip of a prologue, and the epilogue
+// stores of tile t drain while the first pair of tile t+1 is in flight.  Barrier sequence, RAW and WAR arguments are those
+// of the kernel above with the pair index running across tiles (the epilogue sits at the start of a MEM phase and touches
+// no LDS).  Same accumulation order => bit-identical results.
+// --------------------------------------------------------------------------------------------
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm_h_big_pp64p_kernel(const GemmArgs g, int nx, int ny, int total) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds_p7[];   // [buf][A|W][256][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int G = gridDim.x, ntiles = nx * ny;
+  constexpr int STAGE = 2 * BBM * TBK;
+  const bf16_t* __restrict__ Abase = reinterpret_cast<const bf16_t*>(g.A);
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W);
+
+  // tile L of the launch -> batch entry z and tile origin (same XCD-aware order as the non-persistent kernels, per z)
+  auto origin = [&](int L, int& z, int& m0, int& n0) {
+    z = L / ntiles;
+    const int lin = L - z * ntiles;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+    constexpr int GM = 8;
+    const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
+    const int gsz = min(GM, ny - first_m), in_group = tile - group * per_group;
+    m0 = (first_m + in_group % gsz) * BBM;
+    n0 = (in_group / gsz) * BBN;
+  };
+  const bf16_t* ga[4];
+  const bf16_t* gw[4];
+  auto set_ptrs = [&](int z, int m0, int n0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = (wave * 4 + q) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (row & 7);
+      ga[q] = Abase + (int64_t)z * g.a_batch + (int64_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
+      gw[q] = W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
+    }
+  };
+#define WJ_P7_ISSUE(buf)                                                                                       \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga[q],                     \
+        (__attribute__((address_space(3))) void*)(&lds_p7[(buf) * STAGE + (wave * 4 + q) * 8 * TBK]), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw[q],                     \
+        (__attribute__((address_space(3))) void*)(&lds_p7[(buf) * STAGE + BBM * TBK + (wave * 4 + q) * 8 * TBK]), 16, 0, 0); \
+    ga[q] += TBK;                                                                                              \
+    gw[q] += TBK;                                                                                              \
+  }
+  const int rowoff = (lane & 15) * TBK;
+  const int off_h0 = rowoff + ((((lane >> 4)) ^ (lane & 7)) << 3);
+  const int off_h1 = rowoff + (((4 + (lane >> 4)) ^ (lane & 7)) << 3);
+  const int a_base = wm * 128 * TBK, w_base = BBM * TBK + wn * 64 * TBK;
+  const int np = g.K / TBK;
+
+  int L = blockIdx.x, z, m0, n0;
+  origin(L, z, m0, n0);
+  set_ptrs(z, m0, n0);
+  WJ_P7_ISSUE(0)
+  wait_vmcnt<0>();
+  wg_barrier();                  // P
+  if (wm == 1) wg_barrier();     // B0
+
+  typename Vec8<T>::type af[8], wf[4];
+  f32x4_t acc[8][4];
+#define WJ_P7_READ(buf, off)                                                                                          \
+  {                                                                                                                    \
+    const bf16_t* ls = &lds_p7[(buf) * STAGE];                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                      \
+      wf[j] = *reinterpret_cast<const typename Vec8<T>::type*>(&ls[w_base + j * 16 * TBK + (off)]);                    \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                      \
+      af[i] = *reinterpret_cast<const typename Vec8<T>::type*>(&ls[a_base + i * 16 * TBK + (off)]);                    \
+  }
+#define WJ_P7_MFMA()                                                         \
+  __builtin_amdgcn_s_setprio(1);                                             \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i)                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                          \
+      if constexpr (EPI == EPI_VT) acc[i][j] = mfma16(af[i], wf[j], acc[i][j]); \
+      else acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);                      \
+    }                                                                        \
+  __builtin_amdgcn_s_setprio(0);
+
+  int b = 0;
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int Ln = L + G;
+    const bool has_next = Ln < total;
+    int zn = 0, m0n = 0, n0n = 0;
+    if (has_next) origin(Ln, zn, m0n, n0n);
+    for (int p = 0; p < np; ++p) {
+      // ---- MEM(h0): request the next pair of the stream (of this tile, or pair 0 of the next one)
+      WJ_P7_READ(b, off_h0)
+      if (p + 1 < np) {
+        WJ_P7_ISSUE(b ^ 1)
+      } else if (has_next) {
+        set_ptrs(zn, m0n, n0n);
+        WJ_P7_ISSUE(b ^ 1)
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wg_barrier();
+      WJ_P7_MFMA()
+      wg_barrier();
+      // ---- MEM(h1)
+      WJ_P7_READ(b, off_h1)
+      wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wg_barrier();
+      WJ_P7_MFMA()
+      wg_barrier();
+      b ^= 1;
+    }
+    tile_epilogue<EPI, T, 8>(g, z, m0 + wm * 128, n0 + wn * 64, lane, acc);
+    if (!has_next) break;
+    L = Ln; z = zn; m0 = m0n; n0 = n0n;
+  }
+  if (wm == 0) wg_barrier();
+#undef WJ_P7_ISSUE
+#undef WJ_P7_READ
+#undef WJ_P7_MFMA
+}
+
+// --------------------------------------------------------------------------------------------
 // bf16 MFMA, 128x128x64 tile with an NS-stage LDS-DMA pipeline (decode GEMMs, M = a few hundred rows).
 // A decode GEMM gives a workgroup only 5-20 k-steps of 32 MFMAs per wave: with one stage of prefetch every
 // k-step costs a full global->LDS round trip (~1 us), so the kernel is latency- not MFMA-bound.  Here NS-1
@@ -1044,6 +1172,31 @@ static int launch_big_pp64(const GemmArgs& a, hipStream_t s) {
     }
     dim3 grid(ceil_div(a.N, BBN), ceil_div(a.M, BBM), a.nbatch);
     hipLaunchKernelGGL((gemm_h_big_pp64_kernel<T, EPI>), grid, dim3(512), smem, s, a);
+    WJ_LAUNCH_CHECK();
+    return WJ_OK;
+  }
+}
+
+template <typename T, int EPI>
+static int launch_big_pp64p(const GemmArgs& a, hipStream_t s) {
+  if constexpr (EPI == EPI_PARTIAL_F32) {
+    set_error("gemm: the 256-tile kernels have no split-K mode");
+    return WJ_E_INVALID;
+  } else {
+    constexpr size_t smem = 2 * 2 * BBM * TBK * sizeof(bf16_t);   // 128 KiB
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_pp64p_kernel<T, EPI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      int dev = 0;
+      if (e == hipSuccess) e = hipGetDevice(&dev);
+      if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+      if (e != hipSuccess || n_cu <= 0) { set_error("persistent GEMM setup: %s", hipGetErrorString(e)); return WJ_E_HIP; }
+      attr_set = true;
+    }
+    const int nx = a.N / BBN, ny = ceil_div(a.M, BBM), total = nx * ny * a.nbatch;
+    hipLaunchKernelGGL((gemm_h_big_pp64p_kernel<T, EPI>), dim3(std::min(total, n_cu)), dim3(512), smem, s, a, nx, ny, total);
     WJ_LAUNCH_CHECK();
     return WJ_OK;
   }
@@ -1399,6 +1552,11 @@ static int launch_epi16(const GemmArgs& a, hipStream_t s, int variant) {
     if (!pp_ok) { set_error("gemm: the ping-pong 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, K >= 160, M >= 1024"); return WJ_E_INVALID; }
     return launch_big_pp<T, EPI>(a, s, variant - 80);
   }
+  if (variant == 87) {   // persistent form of 86 (experiment)
+    if (!big_ok) { set_error("gemm: the 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, M >= 1024"); return WJ_E_INVALID; }
+    return launch_big_pp64p<T, EPI>(a, s);
+  }
+  if ((variant == 0 || variant == 1) && g_gemm_big == 7 && big_ok) return launch_big_pp64p<T, EPI>(a, s);
   if (variant == 86) {   // ping-pong over 64-wide pairs (128-byte DMA segments); wj_tune("gemm_big", 6)
     if (!big_ok) { set_error("gemm: the 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, M >= 1024"); return WJ_E_INVALID; }
     return launch_big_pp64<T, EPI>(a, s);
