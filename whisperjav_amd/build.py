@@ -76,6 +76,25 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
+PROBE_SRC = CSRC.parent.parent / "scripts" / "gemm_probe.hip"
+PROBE = CSRC / "gemm_probe"
+
+
+def build_probe(verbose: bool = True) -> Path:
+    """The stand-alone GEMM probe (scripts/gemm_probe.hip): a C-ABI client of libwjhip.so (dlopen), no Python at run time.
+    A development tool -- micro-benchmarks and bit-for-bit variant comparisons in a few seconds of GPU time."""
+    if PROBE.exists() and PROBE.stat().st_mtime >= PROBE_SRC.stat().st_mtime:
+        return PROBE
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", str(PROBE_SRC), "-o", str(PROBE), "-I", str(CSRC.parent.parent / "include"), "-ldl"]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed for the probe:\n{res.stdout}\n{res.stderr}")
+    return PROBE
+
+
 if __name__ == "__main__":
     path = build(force="--force" in sys.argv)
+    build_probe()
     print(path)
