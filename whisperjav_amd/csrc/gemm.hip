@@ -857,7 +857,7 @@ __global__ __launch_bounds__(512) void gemm_h_big_pp64_kernel(const GemmArgs g) 
 }
 
 // --------------------------------------------------------------------------------------------
-// Persistent form of gemm_h_big_pp64_kernel (EXPERIMENT, opt-in: variant 87 / wj_tune("gemm_big", 7)): one workgroup per
+// Persistent form of gemm_h_big_pp64_kernel (EXPERIMENT, variant 87 of wj_k_gemm; measured 2-5 % slower): one workgroup per
 // CU walks tiles L, L + G, L + 2G, ... and treats their k-pairs as ONE stream -- the last MEM(h0) phase of a tile already
 // requests pair 0 of the next tile, so no tile but the first pays the LDS-DMA round trip of a prologue, and the epilogue
 // stores of tile t drain while the first pair of tile t+1 is in flight.  Barrier sequence, RAW and WAR arguments are those
@@ -1552,11 +1552,15 @@ static int launch_epi16(const GemmArgs& a, hipStream_t s, int variant) {
     if (!pp_ok) { set_error("gemm: the ping-pong 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, K >= 160, M >= 1024"); return WJ_E_INVALID; }
     return launch_big_pp<T, EPI>(a, s, variant - 80);
   }
-  if (variant == 87) {   // persistent form of 86 (experiment)
-    if (!big_ok) { set_error("gemm: the 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, M >= 1024"); return WJ_E_INVALID; }
-    return launch_big_pp64p<T, EPI>(a, s);
+  if (variant == 87) {   // persistent form of 86: a measured, rejected experiment, reachable from wj_k_gemm only
+    if constexpr (EPI == EPI_T || EPI == EPI_GELU_T || EPI == EPI_F32) {
+      if (!big_ok) { set_error("gemm: the 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, M >= 1024"); return WJ_E_INVALID; }
+      return launch_big_pp64p<T, EPI>(a, s);
+    } else {
+      set_error("gemm: variant 87 carries the plain epilogues only");
+      return WJ_E_INVALID;
+    }
   }
-  if ((variant == 0 || variant == 1) && g_gemm_big == 7 && big_ok) return launch_big_pp64p<T, EPI>(a, s);
   if (variant == 86) {   // ping-pong over 64-wide pairs (128-byte DMA segments); wj_tune("gemm_big", 6)
     if (!big_ok) { set_error("gemm: the 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, M >= 1024"); return WJ_E_INVALID; }
     return launch_big_pp64<T, EPI>(a, s);
