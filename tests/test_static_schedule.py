@@ -124,3 +124,30 @@ def test_no_spills_in_the_256_tile_kernels(code_object):
         vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", b).group(1))
         assert size == 0 and vgpr <= 256, (m.group(1), size, vgpr)
     assert seen >= 40, seen
+
+
+def test_no_kernel_of_the_library_spills_except_the_known_two(tmp_path):
+    """Scratch (private segment) use of EVERY kernel in every translation unit.  Allowed: the register-resident beam top-2K
+    kernels, which sit at their 128-VGPR cap (1024 threads per workgroup) and spill 24 / 68 bytes per lane by design."""
+    from whisperjav_amd import build
+    build.build(verbose=False)
+    allowed = {"beam_topk_reg_kernelILi51E": 24, "beam_topk_reg_kernelILi64E": 68}
+    total = 0
+    for src in build.SOURCES:
+        obj = build.CSRC / "build" / (src.replace(".hip", ".o"))
+        local = tmp_path / obj.name
+        shutil.copy(obj, local)
+        subprocess.run([OBJDUMP, "--offloading", str(local)], check=True, capture_output=True)
+        cos = [p for p in tmp_path.iterdir() if p.name.startswith(obj.name + ".") and "gfx950" in p.name]
+        if not cos:          # comm.hip is host code only
+            continue
+        notes = subprocess.run([READELF, "--notes", str(cos[0])], check=True, capture_output=True, text=True).stdout
+        for b in re.split(r"\n\s*- \.agpr_count:", notes):
+            m = re.search(r"\.name:\s+(\S+)", b)
+            if not m:
+                continue
+            total += 1
+            size = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", b).group(1))
+            limit = max([v for k, v in allowed.items() if k in m.group(1)] or [0])
+            assert size <= limit, (m.group(1), size)
+    assert total > 500, total
