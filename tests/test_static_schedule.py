@@ -151,3 +151,27 @@ def test_no_kernel_of_the_library_spills_except_the_known_two(tmp_path):
             limit = max([v for k, v in allowed.items() if k in m.group(1)] or [0])
             assert size <= limit, (m.group(1), size)
     assert total > 500, total
+
+
+def test_encoder_attention_masks_padding_keys_on_the_last_tile_only(tmp_path):
+    """attn_enc_h_kernel: the padding-key mask (64 v_cmp / v_cndmask per 64-key tile) must live in a peeled copy of the tile
+    body, not in the main loop -- as a branch inside one loop body hipcc if-converts it onto every tile."""
+    from whisperjav_amd import build
+    build.build(verbose=False)
+    local = tmp_path / "attention.o"
+    shutil.copy(build.CSRC / "build" / "attention.o", local)
+    subprocess.run([OBJDUMP, "--offloading", str(local)], check=True, capture_output=True)
+    co = [p for p in tmp_path.iterdir() if "gfx950" in p.name][0]
+    ins = _disasm(co, "_ZN2wj17attn_enc_h_kernelIDF16_Li9EEEvPKtS2_S2_PT_iii")       # <f16, default variant>
+    blocks, cur = [], []
+    for l in ins:                       # straight-line runs between branches
+        cur.append(l)
+        if l.startswith(("s_cbranch", "s_branch")):
+            blocks.append(cur)
+            cur = []
+    blocks.append(cur)
+    count = lambda b, k: sum(l.startswith(k) for l in b)
+    clean = [b for b in blocks if count(b, "v_mfma") >= 16 and count(b, "v_cndmask") == 0]
+    masked = [b for b in blocks if count(b, "v_mfma") >= 16 and count(b, "v_cndmask") >= 16]
+    assert clean and masked, [(count(b, "v_mfma"), count(b, "v_cndmask")) for b in blocks if count(b, "v_mfma")]
+    assert sum(count(b, "v_mfma") for b in blocks) == 72      # two copies of (16 S + 16 PV + 4 row-sum) MFMAs

@@ -8,6 +8,8 @@
 //   so that after the MFMA a lane already holds, for ITS query column, 8 *consecutive* keys per
 //   32-key step -- exactly the B operand of  O^T += Vt . P^T  with no cross-lane movement, and
 //   the online-softmax statistics (m, l, alpha) are lane-local per query.
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace wj {
@@ -91,7 +93,12 @@ __global__ __launch_bounds__(256) void attn_enc_h_kernel(const bf16_t* __restric
   WJ_ASTORE(0)
   __syncthreads();
 
-  for (int kt = 0; kt < nt; ++kt) {
+  // One key tile.  MASKED = the tile may contain padding keys (with Tpad = round_up(T, 64) only the LAST tile can).  The
+  // two instantiations are called from a loop over the full tiles and a loop over the rest: written as a branch on
+  // `(kt + 1) * 64 > T` inside one loop body, hipcc if-converts the masking into 64 v_cmp / v_cndmask per tile on EVERY
+  // tile (a quarter of the loop's VALU work, seen in the device assembly).
+  auto key_tile = [&](const int kt, auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const int cur = kt & 1;
     if (kt + 1 < nt) { WJ_ALOAD(kt + 1) }
     const bf16_t* lk = &lds[(cur * 2 + 0) * 4096];
@@ -114,8 +121,7 @@ __global__ __launch_bounds__(256) void attn_enc_h_kernel(const bf16_t* __restric
     }
     // lane (q = li, lg) now holds, for block kb, keys  kt*64 + 32*(kb>>1) + 8*lg + 4*(kb&1) + r
     vec8_t pf[2][2];
-    // only the last key tile contains padding keys: a real (scalar) branch, not 64 selects per tile
-    if (__builtin_amdgcn_readfirstlane((kt + 1) * 64 > T)) {
+    if constexpr (MASKED) {
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -230,7 +236,10 @@ __global__ __launch_bounds__(256) void attn_enc_h_kernel(const bf16_t* __restric
       }
     if (kt + 1 < nt) { WJ_ASTORE(cur ^ 1) }
     __syncthreads();
-  }
+  };
+  const int nfull = min(nt, T / 64);          // tiles made of real keys only
+  for (int kt = 0; kt < nfull; ++kt) key_tile(kt, std::false_type{});
+  for (int kt = nfull; kt < nt; ++kt) key_tile(kt, std::true_type{});
 #undef WJ_ALOAD
 #undef WJ_ASTORE
 #undef WJ_ALOAD1
