@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 1
+#define WJ_ABI_VERSION 2
 
 enum {
   WJ_OK = 0,
@@ -224,9 +224,11 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
                      const int32_t* num_frames_host, int medfilt_width, int eot, int32_t* path_text_out,
                      int32_t* path_time_out, int32_t* path_len_out, float* token_prob_out, void* stream);
 
-/* diagnostics of the last wj_whisper_decode_greedy call: out[0] = 1 if the step was replayed from a
- * hipGraph, out[1] = number of concurrent row chains */
-int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[2]);
+/* diagnostics of the last wj_whisper_decode_{greedy,sample,beam} call: out[0] = 1 if the step was replayed from a
+ * hipGraph, out[1] = number of concurrent row chains, out[2] = decode iterations actually run (the loops leave early
+ * once every row has emitted EOT resp. every window has round(beam * patience) finished hypotheses), out[3] = the
+ * iterations it was allowed (max_new_tokens) */
+int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[4]);
 
 /* Step-wise decoder for host-driven search (beam search with CTranslate2's patience /
  * repetition-penalty / no-repeat-ngram processors lives in whisperjav_amd/search.py).

@@ -183,8 +183,11 @@ def _apply_ct2_processors(logits: torch.Tensor, seqs: Sequence[Sequence[int]], c
 
 
 def beam_search(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], bcfg: BeamConfig,
-                fcfg: Optional[FilterConfig] = None):
-    """One window (xa [1, T, D]).  Returns (hypotheses best-first [(tokens, score, cum_logprob)], no_speech_prob)."""
+                fcfg: Optional[FilterConfig] = None, trace: Optional[dict] = None):
+    """One window (xa [1, T, D]).  Returns (hypotheses best-first [(tokens, score, cum_logprob)], no_speech_prob).
+    ``trace`` (a dict) receives which branches of the search ran: ``refills`` (finished slots re-filled from the
+    candidates ``beam .. 2*beam``), ``eot_skipped`` (EOT candidates passed over while refilling), ``finish_steps``
+    (step index of every finished hypothesis, in registration order), ``stop`` ("patience" | "length"), ``steps``."""
     fcfg = fcfg or FilterConfig()
     lay = TokenLayout.for_vocab(model.dims.n_vocab)
     K, V = bcfg.beam_size, model.dims.n_vocab
@@ -203,7 +206,9 @@ def beam_search(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], b
         scores[0] = 0.0
         feed = torch.full((K, 1), prompt[-1])
         finished: List = []
+        tr = dict(refills=0, eot_skipped=0, finish_steps=[], stop="length", steps=0)
         for step in range(max_new):
+            tr["steps"] = step + 1
             logits = dec.step(feed)
             if P == 1 and step == 0:
                 nsp = float(torch.softmax(logits[0].float(), -1)[lay.no_speech])
@@ -221,12 +226,16 @@ def beam_search(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], b
                 use = cand[k]
                 if t == lay.eot or last:
                     finished.append((s, seqs[b] + ([] if t == lay.eot else [t])))
+                    tr["finish_steps"].append(step)
                     for j in range(secondary, len(cand)):
                         if cand[j][2] != lay.eot:
                             use, secondary = cand[j], j + 1
+                            tr["refills"] += 0 if last else 1
                             break
+                        tr["eot_skipped"] += 1
                 nxt.append(use)
             if last or len(finished) >= max_candidates:
+                tr["stop"] = "length" if last else "patience"
                 break
             parents = [b for _, b, _ in nxt] + [0] * (K - len(nxt))
             new_scores = [s for s, _, _ in nxt] + [NEG_INF] * (K - len(nxt))
@@ -236,6 +245,8 @@ def beam_search(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], b
             feed = torch.tensor([[t] for _, _, t in nxt] + [[lay.eot]] * (K - len(nxt)))
     lpn = bcfg.length_penalty
     ranked = sorted(((s / (max(len(t), 1) ** lpn) if lpn != 0 else s, s, t) for s, t in finished), key=lambda x: -x[0])
+    if trace is not None:
+        trace.update(tr)
     return [(t, n, s) for n, s, t in ranked], nsp
 
 

@@ -19,6 +19,11 @@ and audio that both sides can regenerate bit-identically:
                           the BASELINE cfg3 search (beam 5, patience 1.2, repetition penalty 1.5, no-repeat-3-gram,
                           32 new tokens) -- every finished hypothesis with its cumulative log-prob.  These carry the
                           north-star's 1e-3 log-prob bar for the 16-bit compute types (tests/test_gpu_pipeline.py).
+  * golden_large_v3_r3_eot.npz (--large-r3): large-v3 geometry, fp16-representable weights WITH the end-of-text ramp,
+                          duration cue and peaked cross-attention (``synth_weights(**weights.SPEECHLIKE)``), two windows
+                          (a 6 s and a 2.5 s clip of synthetic speech): greedy decode until EOT and the BASELINE cfg3 beam
+                          search until ``round(beam * patience)`` hypotheses have finished -- every finished hypothesis,
+                          different lengths, with the oracle's trace of refills / stop reason (tests/test_gpu_search_eot.py).
 """
 import os
 import sys
@@ -115,7 +120,59 @@ def run_r2(exact: str, n_new: int, mel: np.ndarray):
           f"(runner-up {hyps[1][2]:.4f})" if len(hyps) > 1 else "")
 
 
+def run_r3(max_new: int = 64):
+    """Round-3 golden: searches that END (greedy + cfg3 beam) at the large-v3 geometry, two windows."""
+    dims = pdims.dims_for("large-v3")
+    t0 = time.time()
+    w = pweights.synth_weights(dims, seed=1234, exact="float16", **pweights.SPEECHLIKE)
+    oracle = whisper_ref.WhisperOracle(helpers.oracle_dims(dims), w)
+    lay = decoding.TokenLayout.for_vocab(dims.n_vocab)
+    toks = pdims.special_tokens(dims.n_vocab)
+    prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
+    suppress = (1, 2, 7, 8, 9, 10, 14, 25, toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev,
+                toks.no_speech)
+    gcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=50)
+    bfil = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=0)
+    bcfg = decoding.BeamConfig(5, 1.2, 1.0, 1.5, 3, max_new)
+    clips = ((6.0, 1234), (2.5, 99))
+    mel = np.stack([logmel.window_features(synth.speech_like(s, seed=k), 128, "fw") for s, k in clips])
+    name = "golden_large_v3_r3_eot.npz"
+    out = dict(seed=1234, exact="float16", weights="SPEECHLIKE", dims=np.array(list(dims.as_dict().values())), prompt=np.array(prompt),
+               suppress=np.array(suppress), eot=lay.eot, beam=np.array([5, 1.2, 1.0, 1.5, 3, max_new]),
+               clip_seconds=np.array([s for s, _ in clips]), clip_seeds=np.array([k for _, k in clips]))
+    with torch.no_grad():
+        enc = oracle.encode(torch.from_numpy(mel))
+        print(f"[{name}] weights + encode {time.time() - t0:.0f}s", flush=True)
+        t0 = time.time()
+        res = decoding.greedy_decode(oracle, enc, prompt, max_new, gcfg)
+        print(f"[{name}] greedy {time.time() - t0:.0f}s lens {[len(t) for t in res.tokens]}", flush=True)
+        for b in range(2):
+            tr = {}
+            t0 = time.time()
+            hyps, nsp = decoding.beam_search(oracle, enc[b:b + 1], prompt, bcfg, bfil, trace=tr)
+            print(f"[{name}] beam w{b} {time.time() - t0:.0f}s lens {[len(t) for t, _, _ in hyps]} trace {tr}", flush=True)
+            width = max(len(t) for t, _, _ in hyps)
+            bt = np.full((len(hyps), width), lay.eot, dtype=np.int64)
+            for i, (t, _, _) in enumerate(hyps):
+                bt[i, : len(t)] = t
+            out.update({f"beam{b}_tokens": bt, f"beam{b}_len": np.array([len(t) for t, _, _ in hyps]),
+                        f"beam{b}_norm": np.array([n for _, n, _ in hyps], dtype=np.float64),
+                        f"beam{b}_cum": np.array([c for _, _, c in hyps], dtype=np.float64), f"beam{b}_no_speech": np.float64(nsp),
+                        f"beam{b}_refills": tr["refills"], f"beam{b}_steps": tr["steps"], f"beam{b}_stop": tr["stop"],
+                        f"beam{b}_finish_steps": np.array(tr["finish_steps"])})
+            gl = len(res.tokens[b])
+            out.update({f"greedy{b}_tokens": np.array(res.tokens[b]), f"greedy{b}_logprob": np.array(res.token_logprob[b], dtype=np.float32)})
+            assert len(res.token_logprob[b]) == gl + 1 or gl == max_new
+    pv, cols = probes(enc)
+    out.update(greedy_sum=res.sum_logprob, greedy_no_speech=res.no_speech_prob, enc_probe=pv.astype(np.float32), probe_t=PROBE_T,
+               probe_d=cols, enc_abs_mean=np.float32(enc.abs().mean()))
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
 def main():
+    if "--only-r3" in sys.argv:
+        run_r3()
+        return
     audio = synth.speech_like(30.0, seed=1234)
     fw128 = logmel.window_features(audio, 128, "fw")
     if "--only-r2" in sys.argv:
@@ -135,6 +192,8 @@ def main():
     if "--large-r2" in sys.argv:
         for exact in ("none", "float16"):
             run_r2(exact, 32, fw128[None])
+    if "--large-r3" in sys.argv:
+        run_r3()
 
 
 if __name__ == "__main__":

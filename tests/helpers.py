@@ -17,11 +17,13 @@ def small_dims(n_mels=80, d_model=128, heads=2, layers=2, n_vocab=51865) -> pdim
     return pdims.custom_dims(n_mels, d_model, heads, layers, n_vocab)
 
 
-def make_oracle(d: pdims.WhisperDims, seed=1234, emulate_bf16=False, emulate: str = ""):
+def make_oracle(d: pdims.WhisperDims, seed=1234, emulate_bf16=False, emulate: str = "", eot=None, cross_gain: float = 1.0,
+                exact: str = "", logit_std: float = 0.0):
     """``emulate`` = "bfloat16" / "float16": the oracle rounds every GEMM / attention operand to that type at the
     engine's rounding points (fp32 accumulation), so a 16-bit engine can be checked against something tighter than
-    "fp32 +- rounding noise"; "" / "float32" = the plain fp32 oracle."""
-    w = pweights.synth_weights(d, seed=seed)
+    "fp32 +- rounding noise"; "" / "float32" = the plain fp32 oracle.  ``eot`` / ``cross_gain``: the end-of-text ramp and
+    the peaked cross-attention of ``weights.synth_weights`` (hypotheses then END, at window-dependent lengths)."""
+    w = pweights.synth_weights(d, seed=seed, eot=eot, cross_gain=cross_gain, exact=exact, logit_std=logit_std)
     if emulate_bf16:
         emulate = "bfloat16"
     rnd = {"bfloat16": whisper_ref.bf16_round, "float16": whisper_ref.f16_round}.get(emulate)
@@ -32,11 +34,11 @@ import functools
 
 
 @functools.lru_cache(maxsize=4)
-def cached_weights(dims: pdims.WhisperDims, seed: int, exact: str = ""):
+def cached_weights(dims: pdims.WhisperDims, seed: int, exact: str = "", eot=None, cross_gain: float = 1.0, logit_std: float = 0.0):
     """Seeded synthetic weights, generated once per (geometry, seed, rounding mode) and test session: a large-v3 set
     is 1.5 G normal draws (~30 s of single-threaded NumPy) and nine GPU tests want one of three of them.  Callers
     must not modify the arrays."""
-    return pweights.synth_weights(dims, seed=seed, exact=exact)
+    return pweights.synth_weights(dims, seed=seed, exact=exact, eot=eot, cross_gain=cross_gain, logit_std=logit_std)
 
 
 def hf_state_dict(d: pdims.WhisperDims, w):

@@ -1067,7 +1067,7 @@ def test_pooled_scenes_equal_per_scene_and_priming_serves_the_loop(hip, tmp_path
         chunk = audio[int(sc[0] * 16000): int(sc[1] * 16000)]
         with wave.open(str(path), "wb") as wf:
             wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000)
-            wf.writeframes(np.clip(np.rint(chunk.astype(np.float64) * 32768.0), -32768, 32767).astype("<i2").tobytes())
+            wf.writeframes(pipeline.pcm16_encode(chunk).astype("<i2").tobytes())
         paths.append(path)
     del calls[:]
     module.prime_scenes(paths)

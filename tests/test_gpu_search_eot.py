@@ -1,0 +1,258 @@
+"""Searches that END, on a real MI355X through the C ABI.
+
+The plain synthetic weights never emit the end-of-text token, so in tests/test_gpu_pipeline.py every hypothesis runs to
+``max_new_tokens``.  Here the weights are ``weights.SPEECHLIKE`` (end-of-text ramp, duration cue, peaked cross-attention)
+and the windows are clips of 0.8 .. 6 s of synthetic speech (log-mel by the HIP extractor): windows -- and the beams of
+one window -- finish at different steps, after a number of tokens that grows with the clip.  Against the oracle (``oracle/decoding.py``: ``greedy_decode``, the literal
+CTranslate2 ``beam_search`` with its branch trace) and against the host-driven search over the step API:
+
+  (a) hypotheses of different lengths, ranked by ``cum / len ** length_penalty``;
+  (b) windows stopping on ``len(finished) >= round(beam * patience)`` before the length limit;
+  (c) finished slots re-filled from the candidates ``beam .. 2 * beam``;
+  (d) a 16-window batch with ragged finish == per-window decodes;
+  (e) the greedy loop's early exit (``csrc/engine.hip`` polls the finished flags every 16 steps) and the beam loop's
+      (done counter polled every 8 steps).
+
+Every test asserts that these branches actually ran (oracle trace / realised lengths / ``last_decode_info()["steps"]``).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoding
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+DIAG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SMALL = dict(n_mels=80, d_model=128, heads=2, layers=2, n_vocab=51865)
+
+
+def _diag(name, payload):
+    os.makedirs(DIAG, exist_ok=True)
+    with open(os.path.join(DIAG, "diag_search_eot.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **payload}) + "\n")
+
+
+CLIP_SECONDS = (0.8, 6.0, 2.5, 4.0, 1.5, 5.0, 3.0, 3.5)
+
+
+def _setup(dtype, n_windows, max_beam, seed=33, clip_seed=19):
+    from whisperjav_amd import engine, synth, weights as pweights
+    d = helpers.small_dims(**SMALL)
+    oracle, w = helpers.make_oracle(d, seed=seed, emulate=dtype, **pweights.SPEECHLIKE)
+    model = engine.HipWhisper(d, w, dtype=dtype, max_batch=n_windows, max_beam=max_beam)
+    clips = [synth.speech_like(CLIP_SECONDS[i % len(CLIP_SECONDS)] + 0.1 * (i // len(CLIP_SECONDS)), seed=clip_seed + i)
+             for i in range(n_windows)]
+    mel = engine.HipLogMel(d.n_mels, "fw")(clips)          # the product's own features feed both sides
+    model.encode(mel)
+    with torch.no_grad():
+        xa = oracle.encode(mel.cpu())
+    return d, oracle, model, xa
+
+
+def _common(a, b):
+    return next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float16", "bfloat16"])
+def test_device_greedy_ends_with_eot(hip, dtype):
+    """(e) + ragged rows: every row stops at its own EOT, the cumulative log-prob includes the EOT token, rows that are
+    done are padded with EOT and not advanced, the loop leaves before ``max_new_tokens``."""
+    from whisperjav_amd import engine
+    B, max_new = 6, 64
+    d, oracle, model, xa = _setup(dtype, B, 1)
+    prompt = model.sot_prompt("ja", "transcribe")
+    suppress = (1, 2, 7, 8, 9, 10, 14, 25, 50256, 50360, 50361)
+    res = model.decode_greedy(np.tile(np.array(prompt, dtype=np.int32), (B, 1)),
+                              engine.DecodeOptions(max_new_tokens=max_new, suppress_tokens=suppress, max_initial_timestamp=1.0))
+    info = model.last_decode_info()
+    cfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=50)
+    ref = decoding.greedy_decode(oracle, xa, prompt, max_new, cfg)
+    ref_len = [len(t) for t in ref.tokens]
+    assert max(ref_len) < max_new - 16 and len(set(ref_len)) > 1, ref_len         # the oracle's rows end, raggedly
+    worst, same = 0.0, 0
+    for r in range(B):
+        n = int(res.n_tokens[r])
+        got = res.tokens[r, :n].tolist()
+        assert model.tokens.eot not in got
+        assert (res.tokens[r, n:] == model.tokens.eot).all()                        # padded, not advanced
+        c = _common(got, ref.tokens[r])
+        same += got == ref.tokens[r]
+        lp_n = min(c + 1, len(ref.token_logprob[r])) if got == ref.tokens[r] else c  # + the EOT token's own log-prob
+        worst = max(worst, float(np.abs(res.token_logprob[r, :lp_n] - np.array(ref.token_logprob[r][:lp_n])).max()) if lp_n else 0.0)
+        if dtype == "float32":
+            assert got == ref.tokens[r], (r, got, ref.tokens[r])
+            assert abs(float(res.sum_logprob[r]) - float(ref.sum_logprob[r])) < 1e-3 * (n + 1)
+            assert abs(float(res.sum_logprob[r]) - float(res.token_logprob[r, : n + 1].sum())) < 1e-4   # EOT included
+        else:
+            assert c >= min(4, ref_len[r]), (r, got, ref.tokens[r])
+    _diag("greedy_eot", {"dtype": dtype, "ref_len": ref_len, "got_len": res.n_tokens.tolist(), "rows_identical": same,
+                         "max_logprob_diff": worst, "steps": info["steps"]})
+    assert worst < {"float32": 1e-3, "float16": 0.02, "bfloat16": 0.15}[dtype], worst
+    assert info["steps"] < max_new and info["steps"] >= int(res.n_tokens.max()) + 1, info        # (e) early exit
+    assert len(set(res.n_tokens.tolist())) > 1
+    model.close()
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float16", "bfloat16"])
+@pytest.mark.parametrize("beam,patience,lpen,rep,ngram,max_new", [
+    (2, 1.2, 1.0, 1.5, 3, 64),     # the reference's "balanced" defaults
+    (5, 1.2, 1.0, 1.5, 3, 64),     # BASELINE cfg3
+    (3, 1.0, 0.0, 1.0, 0, 64),     # allow-early-exit shape of CTranslate2 (patience 1, no length penalty)
+    (4, 2.0, 1.0, 1.3, 2, 64),
+    (5, 1.2, 1.0, 1.5, 3, 14),     # some windows stop on patience, others at the length limit
+    (8, 1.0, 1.0, 1.0, 0, 40),
+])
+def test_device_beam_search_ends_with_eot(hip, dtype, beam, patience, lpen, rep, ngram, max_new):
+    """(a) (b) (c) + ragged windows, device loop == host-driven search (same engine numerics, every compute type) ==
+    the oracle (float32: exact hypotheses; 16-bit: winner's cumulative log-prob within the type's bound)."""
+    from whisperjav_amd import engine, search
+    B = 6
+    d, oracle, model, xa = _setup(dtype, B, beam)
+    toks = model.tokens
+    prompt = model.sot_prompt("ja", "transcribe")
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    dopt = engine.DecodeOptions(max_new_tokens=max_new, suppress_tokens=suppress, max_initial_timestamp=0.0,
+                                repetition_penalty=rep, no_repeat_ngram_size=ngram)
+    res = model.decode_beam(np.tile(np.array(prompt, dtype=np.int32), (B, 1)), dopt, beam_size=beam, patience=patience,
+                            length_penalty=lpen)
+    info = model.last_decode_info()
+    assert info["hip_graph"]
+    opts = search.SearchOptions(beam_size=beam, patience=patience, length_penalty=lpen, repetition_penalty=rep,
+                                no_repeat_ngram_size=ngram, suppress_tokens=suppress, max_initial_timestamp_index=0,
+                                max_new_tokens=max_new)
+    host = search.beam_search(search.HipStepScorer(model, opts), [prompt] * B, opts, eot=toks.eot,
+                              timestamp_begin=toks.timestamp_begin)
+    fcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=0)
+    bcfg = decoding.BeamConfig(beam, patience, lpen, rep, ngram, max_new)
+    stops, steps, refills, lens, worst, same = set(), [], 0, set(), 0.0, 0
+    for w in range(B):
+        got = res.tokens[w, : res.n_tokens[w]].tolist()
+        assert toks.eot not in got and (res.tokens[w, res.n_tokens[w]:] == toks.eot).all()
+        assert got == host[w].sequences[0], (w, got, host[w].sequences[0])
+        assert abs(float(res.sum_logprob[w]) - host[w].cum_logprobs[0]) < 1e-3
+        tr = {}
+        ref, nsp = decoding.beam_search(oracle, xa[w:w + 1], prompt, bcfg, fcfg, trace=tr)
+        stops.add(tr["stop"]); steps.append(tr["steps"]); refills += tr["refills"]
+        lens.update(len(t) for t, _, _ in ref)
+        same += got == ref[0][0]
+        if dtype == "float32":
+            assert got == ref[0][0], (w, got, ref[0][0])
+            assert abs(float(res.sum_logprob[w]) - ref[0][2]) < 1e-3
+            assert abs(float(res.token_logprob[w, 0]) - ref[0][1]) < 1e-3           # normalised score
+            assert abs(float(res.no_speech_prob[w]) - nsp) < 1e-5
+        if got == ref[0][0]:
+            worst = max(worst, abs(float(res.sum_logprob[w]) - ref[0][2]))
+    _diag("device_beam_eot", {"dtype": dtype, "beam": beam, "patience": patience, "max_new": max_new, "stops": sorted(stops),
+                              "oracle_steps": steps, "refills": refills, "lens": sorted(lens), "winners_identical": same,
+                              "cum_logprob_diff": worst, "device_steps": info["steps"]})
+    # the oracle ran the branches this test is about (so the equalities above cover them)
+    assert min(lens) < max_new and len(lens) > 1, lens                              # (a)
+    assert "patience" in stops and refills > 0, (stops, refills)                    # (b) (c)
+    if max_new == 14:
+        assert stops == {"patience", "length"}, stops
+    else:
+        assert len(set(steps)) > 1, steps                                           # ragged finish inside the batch
+        assert info["steps"] < max_new, info                                        # (e) the done counter ended the loop
+    assert info["steps"] >= max(steps)
+    if dtype != "float32":
+        assert same >= B - 2 and worst < {"float16": 0.05, "bfloat16": 0.3}[dtype], (same, worst)    # cumulative, up to 25 tokens
+    model.close()
+
+
+def test_ragged_16_window_batch_equals_per_window_decodes(hip):
+    """(d): 16 windows decoded as ONE batch (windows finish at different steps, the rest keep running) give the same
+    hypotheses as 16 single-window calls through the slot map, and as the oracle window by window."""
+    from whisperjav_amd import engine
+    B, beam, max_new = 16, 5, 64
+    d, oracle, model, xa = _setup("float32", B, beam, seed=7, clip_seed=3)
+    toks = model.tokens
+    prompt = model.sot_prompt("ja", "transcribe")
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    dopt = engine.DecodeOptions(max_new_tokens=max_new, suppress_tokens=suppress, max_initial_timestamp=0.0,
+                                repetition_penalty=1.5, no_repeat_ngram_size=3)
+    P = np.array(prompt, dtype=np.int32)
+    res = model.decode_beam(np.tile(P, (B, 1)), dopt, beam_size=beam, patience=1.2, length_penalty=1.0)
+    batch_steps = model.last_decode_info()["steps"]
+    gres = model.decode_greedy(np.tile(P, (B, 1)), dopt)
+    fcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=0)
+    bcfg = decoding.BeamConfig(beam, 1.2, 1.0, 1.5, 3, max_new)
+    gref = decoding.greedy_decode(oracle, xa, prompt, max_new, fcfg, processors=bcfg)
+    steps = []
+    for w in range(B):
+        one = model.decode_beam(P[None], dopt, beam_size=beam, patience=1.2, length_penalty=1.0, slots=[w])
+        steps.append(model.last_decode_info()["steps"])
+        got = res.tokens[w, : res.n_tokens[w]].tolist()
+        assert got == one.tokens[0, : one.n_tokens[0]].tolist(), w
+        assert abs(float(res.sum_logprob[w]) - float(one.sum_logprob[0])) < 1e-4
+        ref, _ = decoding.beam_search(oracle, xa[w:w + 1], prompt, bcfg, fcfg)
+        assert got == ref[0][0], (w, got, ref[0][0])
+        assert abs(float(res.sum_logprob[w]) - ref[0][2]) < 1e-3
+        assert gres.tokens[w, : gres.n_tokens[w]].tolist() == gref.tokens[w], w
+    lens = res.n_tokens.tolist()
+    _diag("ragged16", {"beam_len": lens, "greedy_len": gres.n_tokens.tolist(), "batch_steps": batch_steps, "single_steps": steps})
+    assert len(set(lens)) >= 3 and max(lens) < max_new, lens
+    assert len(set(steps)) >= 2 and batch_steps == max(steps), (batch_steps, steps)     # both polled every 8 steps
+    model.close()
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
+def test_golden_large_v3_r3_searches_that_end(hip, dtype):
+    """Large-v3 geometry, fp16-representable ``SPEECHLIKE`` weights, two windows (a 6 s and a 2.5 s clip): greedy until
+    EOT and the cfg3 beam search until patience stops it, against the committed oracle vectors
+    (tests/golden/make_golden.py --large-r3).  Bars: tokens / winning hypothesis identical, per-token log-probs within
+    1e-3 (the north-star bar) in both compute types."""
+    from whisperjav_amd import dims as pdims, engine, synth, weights as pweights
+    g = np.load(os.path.join(GOLDEN, "golden_large_v3_r3_eot.npz"))
+    dims = pdims.dims_for("large-v3")
+    clips = [synth.speech_like(float(s), seed=int(k)) for s, k in zip(g["clip_seconds"], g["clip_seeds"])]
+    mel = engine.HipLogMel(128, "fw")(clips)
+    assert str(g["weights"]) == "SPEECHLIKE"
+    w = helpers.cached_weights(dims, int(g["seed"]), str(g["exact"]), pweights.SPEECHLIKE["eot"], pweights.SPEECHLIKE["cross_gain"],
+                               pweights.SPEECHLIKE["logit_std"])
+    model = engine.HipWhisper(dims, w, dtype=dtype, max_batch=2, max_beam=5)
+    del w
+    enc = model.encode(mel, want_output=True).cpu()
+    d_probe = float(np.abs(enc[0][g["probe_t"]][:, g["probe_d"]].numpy() - g["enc_probe"]).max())
+    sup = tuple(int(t) for t in g["suppress"])
+    prompts = np.tile(np.array(g["prompt"], dtype=np.int32), (2, 1))
+    beam, patience, lpen, rep, ngram, max_new = (float(x) for x in g["beam"])
+    max_new = int(max_new)
+    res = model.decode_greedy(prompts, engine.DecodeOptions(max_new_tokens=max_new, suppress_tokens=sup, max_initial_timestamp=1.0))
+    g_steps = model.last_decode_info()["steps"]
+    br = model.decode_beam(prompts, engine.DecodeOptions(max_new_tokens=max_new, suppress_tokens=sup, max_initial_timestamp=0.0,
+                                                        repetition_penalty=rep, no_repeat_ngram_size=int(ngram)),
+                           beam_size=int(beam), patience=patience, length_penalty=lpen)
+    b_steps = model.last_decode_info()["steps"]
+    model.close()
+    bar = 1e-3
+    out = {"dtype": dtype, "probe_max_abs": d_probe, "greedy_steps": g_steps, "beam_steps": b_steps}
+    ok = True
+    for b in range(2):
+        ref_t = g[f"greedy{b}_tokens"].tolist()
+        ref_lp = g[f"greedy{b}_logprob"]
+        n = int(res.n_tokens[b])
+        got = res.tokens[b, :n].tolist()
+        c = _common(got, ref_t)
+        lp_n = min(c + 1, len(ref_lp)) if got == ref_t else c
+        d_lp = float(np.abs(res.token_logprob[b, :lp_n] - ref_lp[:lp_n]).max()) if lp_n else 0.0
+        b_got = br.tokens[b, : int(br.n_tokens[b])].tolist()
+        b_ref = g[f"beam{b}_tokens"][0, : int(g[f"beam{b}_len"][0])].tolist()
+        d_cum = abs(float(br.sum_logprob[b]) - float(g[f"beam{b}_cum"][0]))
+        norm = g[f"beam{b}_norm"]
+        out.update({f"w{b}_greedy_len": len(ref_t), f"w{b}_greedy_common": c, f"w{b}_greedy_lp_max_abs": d_lp,
+                    f"w{b}_beam_same": b_got == b_ref, f"w{b}_beam_len": len(b_ref), f"w{b}_beam_cum_abs": d_cum,
+                    f"w{b}_beam_lens": g[f"beam{b}_len"].tolist(), f"w{b}_beam_margin": float(norm[0] - norm[1]),
+                    f"w{b}_oracle_stop": str(g[f"beam{b}_stop"]), f"w{b}_oracle_refills": int(g[f"beam{b}_refills"])})
+        ok = ok and got == ref_t and d_lp < bar and b_got == b_ref and d_cum < bar * max(1, len(b_ref))
+        assert len(ref_t) < max_new and str(g[f"beam{b}_stop"]) == "patience" and int(g[f"beam{b}_refills"]) > 0
+        assert len(set(g[f"beam{b}_len"].tolist())) > 1
+    _diag("golden_large_v3_r3", out)
+    assert d_probe < (5e-3 if dtype == "float32" else 0.05), d_probe
+    assert ok, out
+    assert g_steps < max_new and b_steps < max_new, (g_steps, b_steps)

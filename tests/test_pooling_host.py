@@ -166,13 +166,31 @@ def test_real_silero_state_dict_loads_when_the_package_is_present():
 
 
 def test_pcm16_round_trip_and_resampling():
-    x = np.array([0.0, 0.5, -1.0, 0.999999, 1.0 / 32768 * 0.4], dtype=np.float32)
+    # libsndfile: write = lrint(x * 0x7FFF) stored into a short (no clipping), read = int16 / 0x8000
+    x = np.array([0.0, 0.5, -1.0, 0.999999, 1.0 / 32768 * 0.4, 1.0, 1.0001, 3.0 / 32767 * 0.5], dtype=np.float32)
+    assert pipeline.pcm16_encode(x).tolist() == [0, 16384, -32767, 32767, 0, 32767, -32766, 2]      # half to even; wrap
     q = pipeline.pcm16_roundtrip(x)
-    assert q.tolist() == [0.0, 0.5, -1.0, 32767 / 32768, 0.0]
+    assert q.dtype == np.float32 and q.tolist()[:6] == [0.0, 0.5, -32767 / 32768, 32767 / 32768, 0.0, 32767 / 32768]
+    assert pipeline.pcm16_encode(x.astype(np.float64)).tolist()[:6] == [0, 16384, -32767, 32767, 0, 32767]
     t = np.arange(48000) / 48000.0
     y = pipeline.to_16k(np.sin(2 * np.pi * 440 * t).astype(np.float32), 48000)
     assert y.shape == (16000,) and y.dtype == np.float32
     assert abs(np.abs(np.fft.rfft(y)).argmax() - 440) <= 1
+
+
+def test_pcm16_round_trip_matches_soundfile(tmp_path):
+    """Lights up when ``soundfile`` (libsndfile) is installed: the scene round trip of the reference --
+    ``sf.write(path, x, sr, subtype="PCM_16")`` (scene_detection_backends/utils.py:140) then ``sf.read(path,
+    dtype="float32")`` (faster_whisper_pro_asr.py:477) -- must equal ``pcm16_roundtrip`` bit for bit."""
+    sf = pytest.importorskip("soundfile", reason="soundfile / libsndfile wheel absent offline (parity unpinned, PARITY.md)")
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(-1.0, 1.0, 50000), (np.arange(-40, 41) + 0.5) / 32767.0, [1.0, -1.0, 0.0]]).astype(np.float32)
+    path = tmp_path / "rt.wav"
+    sf.write(str(path), x, 16000, subtype="PCM_16")
+    back, sr = sf.read(str(path), dtype="float32")
+    assert sr == 16000 and np.array_equal(back, pipeline.pcm16_roundtrip(x))
+    raw, _ = sf.read(str(path), dtype="int16")
+    assert np.array_equal(raw, pipeline.pcm16_encode(x))
 
 
 def test_recording_transcriber_stitches_in_scene_order():

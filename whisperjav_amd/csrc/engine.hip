@@ -185,7 +185,8 @@ struct wj_whisper {
   float* topk_lse = nullptr;
   // step-wise decode state
   int open_batch = 0, open_beam = 0, open_rows = 0, host_pos = 0;
-  int last_used_graph = 0, last_chains = 1;   // diagnostics of the last greedy decode
+  int last_used_graph = 0, last_chains = 1;   // diagnostics of the last decode call
+  int last_steps = 0, last_max_new = 0;       // decode iterations it ran / was allowed to run
 
   const void* W(int idx) const { return blob + off[idx]; }
   const float* F(int idx) const { return reinterpret_cast<const float*>(blob + off[idx]); }
@@ -977,7 +978,9 @@ int wj_whisper_decode_sample(wj_whisper* m, int batch, int group, const int32_t*
   m->last_used_graph = use_graph ? 1 : 0;
   m->last_chains = chains;
   std::vector<int32_t> fin(R);
+  m->last_steps = 0; m->last_max_new = max_new;
   for (int i = 0; i < max_new; ++i) {
+    m->last_steps = i + 1;
     for (int c = 0; c < chains; ++c) {
       if (use_graph) {
         WJ_HIP(hipGraphLaunch(exec[c], side[c]));
@@ -1117,8 +1120,10 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
   m->last_used_graph = use_graph ? 1 : 0;
   m->last_chains = 1;
   int rc_loop = WJ_OK;
+  m->last_steps = 0; m->last_max_new = max_new;
   for (int i = 0; i < max_new && rc_loop == WJ_OK; ++i) {
     const int par = i & 1;
+    m->last_steps = i + 1;
     if (use_graph) {
       if (hipGraphLaunch(exec[par], s) != hipSuccess) { set_error("decode_beam: graph launch failed"); rc_loop = WJ_E_HIP; }
     } else {
@@ -1318,10 +1323,12 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
   return WJ_OK;
 }
 
-int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[2]) {
+int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[4]) {
   WJ_REQUIRE(m && out, "wj_whisper_last_decode_info: NULL argument");
   out[0] = m->last_used_graph;
   out[1] = m->last_chains;
+  out[2] = m->last_steps;
+  out[3] = m->last_max_new;
   return WJ_OK;
 }
 

@@ -12,7 +12,7 @@ import os
 from pathlib import Path
 from typing import Optional
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwjhip.so"
 _lib: Optional[C.CDLL] = None
 

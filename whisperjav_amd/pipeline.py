@@ -30,15 +30,29 @@ import numpy as np
 SR = 16000
 
 
-def pcm16_roundtrip(chunk: np.ndarray) -> np.ndarray:
-    """What writing a scene as PCM_16 (``save_scene_wav``: soundfile scales by 32768 and rounds) and reading it back as
-    float32 (``sf.read``: int16 / 32768) does to the samples."""
+def pcm16_encode(chunk: np.ndarray) -> np.ndarray:
+    """The int16 samples ``soundfile.write(path, chunk, sr, subtype="PCM_16")`` stores (``save_scene_wav``,
+    /root/reference/whisperjav/modules/scene_detection_backends/utils.py:140).
+
+    libsndfile (un-vendored; the routine is ``src/pcm.c``: ``f2s_array`` for float32 input, ``d2s_array`` for float64,
+    reached through ``sf_writef_float`` / ``sf_writef_double``) converts with ``normfact = 1.0 * 0x7FFF`` -- NOT 0x8000 --
+    and ``dest[i] = lrintf(src[i] * normfact)``: the product is formed in the INPUT's precision, ``lrint`` rounds half
+    to even (default FP environment), and without ``SFC_SET_CLIPPING`` (python-soundfile never sets it) the ``int`` is
+    stored into a ``short``, i.e. samples beyond +-1.0 wrap.  Parity unpinned against the library itself (absent offline):
+    ``tests/test_pooling_host.py::test_pcm16_round_trip_matches_soundfile`` lights up when ``soundfile`` is installed."""
     x = np.asarray(chunk)
     if x.dtype != np.float32:
         x = x.astype(np.float64)
-    # float32 input: x * 2^15, rint, clip and / 2^15 are all exact in float32, so the result equals the float64 route
-    q = np.clip(np.rint(x * x.dtype.type(32768.0)), -32768, 32767)
-    return (q / x.dtype.type(32768.0)).astype(np.float32)
+    q = np.rint(x * x.dtype.type(32767.0)).astype(np.int64)            # float32 product for float32 input, as f2s_array
+    return ((q + 32768) % 65536 - 32768).astype(np.int16)              # int -> short
+
+
+def pcm16_roundtrip(chunk: np.ndarray) -> np.ndarray:
+    """Scene audio as the reference's ASR module sees it: written as PCM_16 (``pcm16_encode``) and read back with
+    ``sf.read(..., dtype="float32")`` (faster_whisper_pro_asr.py:477), where libsndfile's ``s2f_array`` multiplies by
+    ``1.0 / 0x8000``: ``lrint(x * 32767) / 32768`` -- the write and read scales differ, so full scale comes back as
+    0.99997, and the quantisation is part of the reference's numerics."""
+    return pcm16_encode(chunk).astype(np.float32) / np.float32(32768.0)
 
 
 def to_16k(audio: np.ndarray, sr: int) -> np.ndarray:
@@ -61,7 +75,7 @@ class RecordingTranscriber:
     def __init__(self, asr, scene_detector, pcm16_scenes: bool = True, device_resident: bool = True):
         """``device_resident``: upload the recording to HBM once and hand the ASR module scene clips that are views of
         it (the segmenter, the feature extractor and the engine gather them on the device); off = numpy clips on the
-        host, the reference's call contract.  Both give the same numbers (the PCM16 round trip is exact either way)."""
+        host, the reference's call contract.  Both give the same numbers (the PCM16 round trip is the same IEEE arithmetic either way)."""
         self.asr, self.scene_detector, self.pcm16_scenes = asr, scene_detector, bool(pcm16_scenes)
         self.device_resident = bool(device_resident)
         self.timing: Dict[str, float] = {}
@@ -100,8 +114,9 @@ class RecordingTranscriber:
             return None
         dev = torch.device("cuda", int(getattr(self.scene_detector, "_device", 0)))
         rec = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32)).to(dev)
-        if self.pcm16_scenes:       # the same exact arithmetic as pcm16_roundtrip (x 2^15, round half to even, clamp, / 2^15)
-            rec = rec.mul_(32768.0).round_().clamp_(-32768.0, 32767.0).div_(32768.0)
+        if self.pcm16_scenes:       # pcm16_roundtrip on the device: float32 product with 0x7FFF, round half to even, int -> short
+            q = rec.mul_(32767.0).round_().to(torch.int32)       # wrap, / 0x8000 (every step exact or IEEE-identical to NumPy's)
+            rec = (((q + 32768) & 0xFFFF) - 32768).to(torch.float32).div_(32768.0)
         return [(rec[int(a * sr): int(b * sr)], sr) for a, b in scenes]
 
     @staticmethod

@@ -26,6 +26,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import hipbind
+from .pipeline import pcm16_encode
 
 ANALYSIS_WINDOW = 0.05          # auditok DEFAULT_ANALYSIS_WINDOW
 _EPS = 1e-10
@@ -334,7 +335,7 @@ class HipAuditokSceneDetector:
                 wf.setnchannels(1)
                 wf.setsampwidth(2)
                 wf.setframerate(sr)
-                wf.writeframes(np.clip(np.rint(chunk.astype(np.float64) * 32768.0), -32768, 32767).astype("<i2").tobytes())
+                wf.writeframes(pcm16_encode(chunk).astype("<i2").tobytes())       # libsndfile's float -> PCM_16 conversion
             scenes.append(SceneInfo(start_sec=s, end_sec=e, scene_path=path, detection_pass=p, metadata=dict(meta)))
         self._last_result = SceneDetectionResult(scenes=scenes, method=self.name, audio_duration_sec=total,
                                                  parameters=dict(self._config.__dict__), processing_time_sec=time.time() - t0,

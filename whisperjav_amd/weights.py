@@ -14,6 +14,7 @@ assembled here.
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -61,7 +62,8 @@ def round_to_bf16(a: np.ndarray) -> np.ndarray:
 
 
 def synth_weights(dims: WhisperDims, seed: int = 1234, bf16_exact: bool = True,
-                  exact: str = "") -> Dict[str, np.ndarray]:
+                  exact: str = "", eot: "EotRamp | bool | None" = None, cross_gain: float = 1.0,
+                  logit_std: float = 0.0) -> Dict[str, np.ndarray]:
     """Seeded random weights with trained-like statistics (there are no checkpoints offline).
 
     Variances are chosen so activations stay O(1) through the stack, attention scores have
@@ -72,6 +74,18 @@ def synth_weights(dims: WhisperDims, seed: int = 1234, bf16_exact: bool = True,
     ``"none"`` keeps the raw fp32 draws (a 16-bit engine then also carries weight-rounding error),
     ``"float16"`` rounds to fp16 (the storage type of the published checkpoints), ``"bfloat16"`` to bf16.
     The random draws are the same in every mode.
+
+    ``eot`` (``True`` = ``EotRamp()``): a random-weight model never emits the end-of-text token, so every search runs to
+    ``max_new_tokens`` and the termination half of greedy / beam search is never exercised.  ``apply_eot_ramp`` plants
+    a position-driven EOT logit so that hypotheses finish after a spread of lengths (see there).  Off by default: the
+    round-1/2 golden vectors were produced without it.
+
+    ``cross_gain`` scales the decoder's cross-attention query projections: at 1.0 the scores over the 1500 audio
+    frames have unit spread, the softmax averages hundreds of frames and what is decoded barely depends on the audio;
+    at ~4 the attention is peaked on a handful of frames, as in a trained model, and every window decodes its own text.
+    ``logit_std`` (0 = the historical 0.05 * sqrt(d)) sets the spread of the logits over the vocabulary through the gain
+    of the final LayerNorm: 1.8 is what the default gives at d = 1280, so a small test model sees the same competition
+    between the best text token, the timestamp mass and EOT as the large geometry (``SPEECHLIKE`` bundles the three).
     """
     rng = np.random.default_rng(seed)
     w: Dict[str, np.ndarray] = {}
@@ -99,7 +113,7 @@ def synth_weights(dims: WhisperDims, seed: int = 1234, bf16_exact: bool = True,
         vec(prefix + "attn_ln.bias", dm)
         names = ["attn"] + (["cross_attn"] if cross else [])
         for a in names:
-            mat(f"{prefix}{a}.query.weight", (dm, dm), dm)
+            mat(f"{prefix}{a}.query.weight", (dm, dm), dm, cross_gain if a == "cross_attn" else 1.0)
             vec(f"{prefix}{a}.query.bias", dm)
             mat(f"{prefix}{a}.key.weight", (dm, dm), dm)
             mat(f"{prefix}{a}.value.weight", (dm, dm), dm)
@@ -130,7 +144,144 @@ def synth_weights(dims: WhisperDims, seed: int = 1234, bf16_exact: bool = True,
         block(f"decoder.blocks.{i}.", dt, True)
     vec("decoder.ln.weight", dt, 0.1, 1.0)
     vec("decoder.ln.bias", dt)
+    s_logit = 0.05 * np.sqrt(dt)
+    if logit_std > 0:       # through the final LayerNorm's gain, not the embedding: a larger embedding would also enlarge the
+        f = np.float32(logit_std / s_logit)       # bonus a token's own input embedding gives its logit (repetition loops)
+        w["decoder.ln.weight"] *= f
+        w["decoder.ln.bias"] *= f
+        s_logit = logit_std
+    if eot:
+        apply_eot_ramp(dims, w, EotRamp() if eot is True else eot, seed, rnd, s_logit)
     return w
+
+
+
+
+@dataclass(frozen=True)
+class EotRamp:
+    """Shape of the planted end-of-text logit, in logit units relative to the level ``T`` at which EOT wins a step:
+    ``T = max(4.3 s, log(1501) + s^2 / 2)`` -- the best of ~50 k text tokens whose logits have std ``s``
+    (= 0.05 * sqrt(d) for ``synth_weights``), resp. the probability mass of the 1501 timestamp tokens, which
+    ``ApplyTimestampRules`` lets mask every text token including EOT.  For the n-th sampled token after a 3-token prompt:
+    ``logit[eot](n) ~ T + slope * (n - mid) + noise * N(0, 1)``.  ``noise`` is content driven (audio window, token
+    history) and redrawn every step, so windows -- and the beams of one window -- end about ``noise / slope`` tokens
+    apart around ``mid``."""
+    mid: float = 24.0
+    slope: float = 0.25
+    noise: float = 2.0
+    cap: float = 12.0           # the ramp saturates at T + cap (EOT is certain long before n_text_ctx)
+    gain: float = 8.0           # |tok_emb[eot]| / sigma_final: larger = smaller ramp in the positional table
+    rate: float = 0.0           # > 0: ``mid`` grows by ~rate tokens per second of audio CONTENT in the window (``plant_duration_cue``)
+
+
+# synthetic weights whose searches behave like a trained model's: hypotheses END, after a number of tokens that grows
+# with the amount of audio in the window (a few tokens per second of content; feed it mel of real clips, not random
+# mel), the cross-attention is peaked, the logit spread is the large geometry's -- ``synth_weights(dims, seed, **SPEECHLIKE)``
+SPEECHLIKE = dict(eot=EotRamp(mid=4.0, rate=5.0), cross_gain=4.0, logit_std=1.8)
+
+
+def apply_eot_ramp(dims: WhisperDims, w: Dict[str, np.ndarray], ramp: EotRamp, seed: int, rnd, s_logit: float) -> None:
+    """Make the synthetic decoder end its hypotheses (in place).
+
+    One direction ``u`` of the decoder's residual stream (unit norm, zero mean, seeded) is reserved as an "end of
+    text" counter: the positional table writes ``a(t) * u`` into it, every block output (self / cross attention
+    ``out``, ``mlp.2``) is damped along ``u`` to a fraction ``g`` of what the random draw gave -- so the stream's
+    ``u`` component at the final LayerNorm is the ramp plus ``g`` x content noise -- and the EOT row of the tied token
+    embedding reads it back: ``tok_emb[eot] = beta * u / ln_w`` makes ``logit[eot] = beta * (x . u) / sigma(x) +
+    const`` exactly (the LayerNorm's mean drops out because ``u`` has zero mean).  ``sigma(x)``, the per-element std of
+    the final residual stream, grows like 0.66 * sqrt(layers) for these weights (measured on the oracle)."""
+    from .dims import special_tokens
+    rng = np.random.default_rng([seed, 0xE07])
+    dt, L = dims.n_text_state, dims.n_text_layer
+    u = rng.standard_normal(dt)
+    u -= u.mean()
+    u /= np.linalg.norm(u)
+    sigma = 0.66 * np.sqrt(L)
+    beta = ramp.gain * sigma
+    g = min(1.0, ramp.noise / beta)
+    level = max(4.3 * s_logit, np.log(1501.0) + 0.5 * s_logit ** 2)
+    for i in range(L):
+        for name in ("attn.out", "cross_attn.out", "mlp.2"):
+            k = f"decoder.blocks.{i}.{name}"
+            wt = w[k + ".weight"].astype(np.float64)
+            w[k + ".weight"] = rnd((wt - (1.0 - g) * np.outer(u, u @ wt)).astype(np.float32))
+            b = w[k + ".bias"].astype(np.float64)
+            w[k + ".bias"] = (b - (1.0 - g) * u * (u @ b)).astype(np.float32)
+    eot = special_tokens(dims.n_vocab).eot
+    emb = w["decoder.token_embedding.weight"]
+    row = rnd((beta * u / w["decoder.ln.weight"].astype(np.float64)).astype(np.float32))
+    emb[eot] = row
+    const = float(w["decoder.ln.bias"].astype(np.float64) @ row.astype(np.float64))
+    n = np.arange(dims.n_text_ctx, dtype=np.float64) - 3.0
+    target = level + np.minimum(ramp.slope * (n - ramp.mid), ramp.cap) - const       # logit units
+    pos = w["decoder.positional_embedding"].astype(np.float64)
+    pos -= np.outer(pos @ u, u)                                                        # the table's own u component
+    pos += np.outer(target * sigma / beta, u)
+    w["decoder.positional_embedding"] = pos.astype(np.float32)
+    if ramp.rate > 0:
+        plant_duration_cue(dims, w, rnd, seed, u, -ramp.slope * ramp.rate * sigma / beta)
+
+
+def plant_duration_cue(dims: WhisperDims, w: Dict[str, np.ndarray], rnd, seed: int, u: np.ndarray, per_second: float) -> None:
+    """Let the synthetic model sense how much audio a window holds: adds ``per_second`` x (seconds of audio content in the
+    window) to the ``u`` component of the decoder's residual stream (so with ``EotRamp.rate`` a 6 s clip ends ~``rate`` x 5
+    tokens later than a 1 s clip, as transcripts of real speech do; a random-weight model has no such coupling).
+
+    The chain, every link deterministic: (1) two conv1 channels compute +-8 x (mean of the lowest third of the mel bins -
+    mean of the highest third) of the centre frame: exactly 0 on padding (all bins equal, in faster-whisper's zero-feature
+    pad as in openai-whisper's zero-audio pad) and on frames clamped to the floor, ~3 on speech / noise frames (spectral
+    tilt; 0.37 +- 0.17 on ``synth.speech_like``), so GELU(+c) + GELU(-c) ~ |c| marks content frames; (2) conv2 writes it into
+    a reserved direction ``v`` of the ENCODER's residual stream (centre tap; the GELU passes half of it), every encoder
+    block output and the positional table are projected off ``v`` so it arrives at ``ln_post`` unchanged; (3) head 0 of
+    the first decoder layer's cross-attention gets a zero query (uniform attention over the 1500 frames) and a value
+    row that reads ``v`` back through ``ln_post``: its output is the window's MEAN content flag; (4) that layer's
+    ``cross_attn.out`` writes it along ``u``.  Scale constants are nominal (sigma of the encoder stream ~ 0.56 *
+    sqrt(layers); content flag ~ 3): the realised tokens-per-second is reported by the users, not assumed."""
+    rng = np.random.default_rng([seed, 0xD07A])
+    d, La = dims.n_audio_state, dims.n_audio_layer
+    v = rng.standard_normal(d)
+    v -= v.mean()
+    v /= np.linalg.norm(v)
+    nm = dims.n_mels
+    third = nm // 3
+    contrast = np.zeros(nm)
+    contrast[:third] = 1.0 / third
+    contrast[nm - third:] = -1.0 / third
+    a1, a2, kappa = 8.0, 4.0, 4.0
+    c1 = w["encoder.conv1.weight"].astype(np.float64)                  # [d, n_mels, 3]
+    c1[0] = 0.0; c1[1] = 0.0
+    c1[0, :, 1] = a1 * contrast
+    c1[1, :, 1] = -a1 * contrast
+    w["encoder.conv1.weight"] = rnd(c1.astype(np.float32))
+    w["encoder.conv1.bias"][:2] = 0.0
+    c2 = w["encoder.conv2.weight"].astype(np.float64)                  # [d, d, 3]
+    c2[:, 0, 1] += a2 * v
+    c2[:, 1, 1] += a2 * v
+    w["encoder.conv2.weight"] = rnd(c2.astype(np.float32))
+    for i in range(La):
+        for name in ("attn.out", "mlp.2"):
+            k = f"encoder.blocks.{i}.{name}"
+            wt = w[k + ".weight"].astype(np.float64)
+            w[k + ".weight"] = rnd((wt - np.outer(v, v @ wt)).astype(np.float32))
+            b = w[k + ".bias"].astype(np.float64)
+            w[k + ".bias"] = (b - v * (v @ b)).astype(np.float32)
+    pos = w["encoder.positional_embedding"].astype(np.float64)
+    w["encoder.positional_embedding"] = (pos - np.outer(pos @ v, v)).astype(np.float32)
+    sigma_enc = 0.56 * np.sqrt(La)
+    flag = 0.5 * a2 * 3.0 / sigma_enc                                  # (x . v) / sigma(x) on a content frame, nominal
+    p = "decoder.blocks.0.cross_attn."
+    q = w[p + "query.weight"]; q[:64] = 0.0
+    w[p + "query.bias"][:64] = 0.0
+    lw = w["encoder.ln_post.weight"].astype(np.float64)
+    row = rnd((kappa * v / lw).astype(np.float32))
+    w[p + "value.weight"][0] = row
+    w[p + "value.bias"][0] = np.float32(-(w["encoder.ln_post.bias"].astype(np.float64) @ row.astype(np.float64)))
+    # mean over 1500 frames of kappa * flag on content frames = kappa * flag * seconds / 30
+    lam = per_second * 30.0 / (kappa * flag)
+    o = w[p + "out.weight"].astype(np.float64)
+    o[:, 0] -= u * (u @ o[:, 0])
+    o[:, 0] += lam * u
+    w[p + "out.weight"] = rnd(o.astype(np.float32))
 
 
 # ---- blob packing ---------------------------------------------------------------------------
