@@ -103,6 +103,54 @@ def test_engine_failure_falls_back_to_minimal_parameters_then_drops_the_clip(tmp
     assert fake.calls[0][2]["beam_size"] == 3 and len(res["segments"]) >= 1          # the long group survived, the short one was dropped
 
 
+def test_one_bad_clip_does_not_demote_the_whole_pooled_call(tmp_path):
+    """a pooled engine error is bisected with the FULL parameters; only the clip that still fails alone goes
+    down the reference's per-group ladder (minimal parameters, then dropped)."""
+    paths = [_scene_wav(tmp_path / f"m_scene_{i:04d}.wav", s) for i, s in enumerate((6.0, 9.0, 4.0))]
+    clean = asr.HipFasterWhisperProASR({"model_name": "large-v3"}, CONFIG, "transcribe", whisper_model=FakeWhisper(_script),
+                                       segmenter=LengthSegmenter())
+    good = clean.transcribe_scenes(paths)
+    # poison only clips of exactly the 4 s scene's second group length
+    second = int((4.0 - 0.5) * 16000) - int((2.0 + 0.25) * 16000)
+
+    class Poisoned(FakeWhisper):
+        def transcribe_many(self, clips, **params):
+            if "patience" in params and second in [len(c) for c in clips]:
+                raise RuntimeError("device fault on one clip")
+            return super().transcribe_many(clips, **params)
+    fake2 = Poisoned(_script)
+    b = asr.HipFasterWhisperProASR({"model_name": "large-v3"}, CONFIG, "transcribe", whisper_model=fake2, segmenter=LengthSegmenter())
+    got = b.transcribe_scenes(paths)
+    full = [c for c in fake2.calls if "patience" in c[2]]
+    minimal = [c for c in fake2.calls if "patience" not in c[2]]
+    assert sum(c[0] for c in full) == 5 and len(minimal) == 1 and minimal[0][0] == 1      # 5 clips kept the full parameters
+    assert got[0] == good[0] and got[1] == good[1]                                       # untouched scenes: identical transcripts
+
+
+def test_unreadable_announced_scene_fails_on_its_own_call(tmp_path):
+    """the pooled pass over a primed scene list skips files it cannot read (they fail when the loop reaches
+    them) and a failing pooled pass falls through to the per-scene path."""
+    paths = [_scene_wav(tmp_path / f"m_scene_{i:04d}.wav", s) for i, s in enumerate((6.0, 9.0))]
+    broken = tmp_path / "m_scene_0002.wav"
+    broken.write_bytes(b"not a wav file")
+    a = asr.HipFasterWhisperProASR({"model_name": "large-v3"}, CONFIG, "transcribe", whisper_model=FakeWhisper(_script),
+                                   segmenter=LengthSegmenter())
+    a.prime_scenes(paths + [broken])
+    first = a.transcribe(paths[0])                               # must not raise because of scene 2
+    assert first["segments"] and a.pooled_calls == 1
+    assert a.transcribe(paths[1])["segments"]
+    with pytest.raises(Exception):
+        a.transcribe(broken)
+
+    class BoomSegmenter(LengthSegmenter):
+        def segment_many(self, audios, sample_rates):
+            raise RuntimeError("segmenter fault in the pooled pass")
+    b = asr.HipFasterWhisperProASR({"model_name": "large-v3"}, CONFIG, "transcribe", whisper_model=FakeWhisper(_script),
+                                   segmenter=BoomSegmenter())
+    b.prime_scenes(paths)
+    assert b.transcribe(paths[0]) == first and b.pooled_calls == 0          # served by the per-scene path
+
+
 def test_tracer_receives_one_record_per_group(tmp_path):
     seen = []
 

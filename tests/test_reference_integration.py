@@ -184,3 +184,26 @@ def test_reference_fidelity_module_drives_the_openai_shim_with_its_balanced_pres
     assert len(seen) >= 1 and seen[0]["fp16"] is True and seen[0]["word_timestamps"] is True
     assert [s["text"] for s in out["segments"]] == ["<11><12>", "<13>"]
     assert out["segments"][0]["start"] >= 1.0 and out["segments"][-1]["end"] <= 4.0 + 1e-6
+
+
+def test_device_gate(ref_modules, monkeypatch):
+    """``whisperjav_amd.device.install()`` swaps the AMD-aware ``get_best_device`` into the
+    reference's ``utils/device_detector`` (which answers "cpu" on ROCm, :146-157).  No GPU here: the HIP branch is
+    exercised with a doubled probe, the fall-through must be the reference's own answer."""
+    import torch
+    from whisperjav_amd import device
+    sys.modules["whisperjav.utils"] = types.ModuleType("whisperjav.utils")
+    sys.modules["whisperjav.utils"].__path__ = [f"{REF}/whisperjav/utils"]
+    dd = importlib.import_module("whisperjav.utils.device_detector")
+    ref_answer = dd.get_best_device()
+    assert device.install() and dd.get_best_device is device.get_best_device
+    assert device.install()                                              # idempotent
+    assert dd._reference_get_best_device() == ref_answer
+    assert dd.get_best_device(prefer_cpu=True) == "cpu"
+    if not torch.cuda.is_available():
+        assert dd.get_best_device() == ref_answer == "cpu"               # nothing to enable without a device
+    monkeypatch.setattr(device, "hip_path_available", lambda: (True, "AMD Instinct MI355X"))
+    assert dd.get_best_device() == "cuda"
+    monkeypatch.setattr(device, "hip_path_available", lambda: (False, "AMD Instinct MI355X"))
+    if not torch.cuda.is_available():
+        assert dd.get_best_device() == "cpu"                             # device seen, library unusable: the reference's answer

@@ -89,3 +89,50 @@ def test_failover_and_logprob_gate_match_reference():
         drop, reason, thr = helper.should_filter(avg_logprob=case["avg_logprob"], duration=case["duration"], text="こんにちは")
         assert (drop, reason) == (case["drop"], case["reason"])
         assert thr == case["threshold"] or thr == pytest.approx(case["threshold"])
+
+
+def test_silero_v31_v40_never_substitutes_the_network():
+    """The reference's default back end (silero-v3.1 / v4.0: 1536-sample windows, torch.hub archives,
+    backends/silero.py:68-72,199-206) has no HIP kernel: the drop-in refuses to score instead of running the v5/v6 network
+    under that name; ``network="v6"`` is the explicit, named opt-in."""
+    from whisperjav_amd import hipbind, vad_weights
+    for version in ("v3.1", "v4.0"):
+        seg = segmenters.HipSileroSpeechSegmenter(version=version, weights="synthetic")
+        assert seg.name == f"silero-{version}-hip" and "refuses" in seg.display_name
+        with pytest.raises(hipbind.WjError, match="no HIP kernel"):
+            seg.segment(np.zeros(16000, dtype=np.float32), sample_rate=16000)
+        with pytest.raises(hipbind.WjError, match="no HIP kernel"):
+            seg.segment_many([np.zeros(16000, dtype=np.float32)], 16000)
+        opt = segmenters.HipSileroSpeechSegmenter(version=version, weights="synthetic", network="v6")
+        assert opt.name == f"silero-{version}-hip+v6net" and "v6 network" in opt.display_name
+    with pytest.raises(ValueError):
+        segmenters.HipSileroSpeechSegmenter(network="v4")
+    # archive identification from the parameter names alone
+    v6 = {k: np.zeros(1) for k in vad_weights.V6_KEYS}
+    assert vad_weights.classify_state_dict(v6) == "v5/v6"
+    assert vad_weights.classify_state_dict(vad_weights.synth_weights()) == "v5/v6"
+    legacy = {"_model.first_layer.forward_basis_buffer": np.zeros(1), "_model.encoder.0.dw_conv.0.weight": np.zeros(1),
+              "_model.decoder.lstm.weight_ih_l0": np.zeros(1)}
+    assert vad_weights.classify_state_dict(legacy) == "v3.1/v4.0"
+    with pytest.raises(ValueError):
+        vad_weights.classify_state_dict({"foo.weight": np.zeros(1)})
+
+
+def test_silero_torchscript_archives_light_up_when_present(tmp_path):
+    """Skipped offline.  With the ``silero_vad`` wheel: its bundled archive classifies as v5/v6 and feeds the HIP blob
+    packer; with a torch.hub cache of snakers4/silero-vad v3.1 / v4.0: the archive classifies as the legacy generation and
+    ``load_file`` refuses it."""
+    silero_vad = pytest.importorskip("silero_vad", reason="silero-vad wheel absent offline (parity unpinned, PARITY.md)")
+    import os
+    from whisperjav_amd import hipbind, vad_weights
+    sd = silero_vad.load_silero_vad().state_dict()
+    assert vad_weights.classify_state_dict(sd) == "v5/v6"
+    assert vad_weights.pack(vad_weights.from_jit_state_dict(sd)).shape[0] == vad_weights.BLOB_FLOATS
+    hub = os.path.expanduser("~/.cache/torch/hub")
+    for root, _, files in os.walk(hub) if os.path.isdir(hub) else []:
+        for f in files:
+            if f.endswith(".jit") and "silero" in root.lower() and ("v3.1" in root or "v4.0" in root):
+                gen, _ = vad_weights.from_torchscript(os.path.join(root, f))
+                assert gen == "v3.1/v4.0"
+                with pytest.raises(hipbind.WjError):
+                    vad_weights.load_file(os.path.join(root, f))

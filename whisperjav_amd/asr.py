@@ -307,12 +307,27 @@ class HipFasterWhisperProASR:
         self._apply_runtime_task(kwargs)
         key = str(audio_path)
         if key not in self._scene_cache and key in self._primed:
-            batch = [p for p in self._primed if p not in self._scene_cache and Path(p).exists()]
+            # an unreadable announced scene must fail on ITS OWN call, not on the first scene's: skip it here
+            batch, loaded = [], []
+            for p in self._primed:
+                if p in self._scene_cache or not Path(p).exists():
+                    continue
+                try:
+                    loaded.append(read_audio(Path(p)))
+                    batch.append(p)
+                except Exception as e:
+                    logger.error(f"announced scene {p} is unreadable ({type(e).__name__}: {e}); left to its own call")
             self._primed = []
-            results = self._transcribe_loaded([read_audio(Path(p)) for p in batch])
-            self.pooled_calls += 1
-            for p, res, vad in zip(batch, results, self._vad_segments_per_scene):
-                self._scene_cache[p] = {"result": res, "vad": vad}
+            try:
+                results = self._transcribe_loaded(loaded) if key in batch else None
+            except Exception as e:      # e.g. the segmenter failing on another scene: fall through to the per-scene path
+                logger.error(f"pooled pass over {len(batch)} announced scenes failed ({type(e).__name__}: {e}); "
+                             "continuing scene by scene")
+                results = None
+            if results is not None:
+                self.pooled_calls += 1
+                for p, res, vad in zip(batch, results, self._vad_segments_per_scene):
+                    self._scene_cache[p] = {"result": res, "vad": vad}
         hit = self._scene_cache.pop(key, None)
         if hit is not None:
             self._last_vad_segments = hit["vad"]
@@ -395,25 +410,38 @@ class HipFasterWhisperProASR:
         return results  # type: ignore[return-value]
 
     def _run_model(self, clips: List[np.ndarray]):
-        """Every clip through the engine in one call; on an engine error the reference's retry ladder
-        (faster_whisper_pro_asr.py:925-980): the clip alone with minimal parameters, then an empty result."""
+        """Every clip through the engine in one call.  On an engine error the pooled list is BISECTED with the full
+        parameters (one bad clip or a transient out-of-memory must not change the transcript of the whole recording);
+        only a clip that still fails alone goes down the reference's retry ladder, which is per VAD group
+        (faster_whisper_pro_asr.py:925-980): that clip with minimal parameters, then an empty result."""
         params = self._prepare_whisper_params()
-        try:
-            per_clip, _ = self.whisper_model.transcribe_many(clips, **params)
-            return per_clip
-        except Exception as e:
-            logger.error(f"pooled transcription of {len(clips)} clips failed ({type(e).__name__}: {e}); "
-                         "retrying clip by clip with minimal parameters")
-        minimal = {"task": self.whisper_params.get("task", "transcribe"), "language": self.whisper_params.get("language", "ja"),
-                   "temperature": 0.0, "beam_size": 3, "log_progress": False}
-        out = []
-        for clip in clips:
+        out: List[Any] = [None] * len(clips)
+
+        def run(lo: int, hi: int) -> None:
             try:
-                segs, _ = self.whisper_model.transcribe_many([clip], **minimal)
-                out.append(segs[0])
+                per_clip, _ = self.whisper_model.transcribe_many(clips[lo:hi], **params)
+                out[lo:hi] = list(per_clip)
+                return
+            except Exception as e:
+                if hi - lo > 1:
+                    logger.error(f"pooled transcription of {hi - lo} clips failed ({type(e).__name__}: {e}); "
+                                 "retrying the two halves with the same parameters")
+                    mid = (lo + hi) // 2
+                    run(lo, mid)
+                    run(mid, hi)
+                    return
+                logger.error(f"transcription of one clip failed ({type(e).__name__}: {e}); retrying it with minimal parameters")
+            minimal = {"task": self.whisper_params.get("task", "transcribe"),
+                       "language": self.whisper_params.get("language", "ja"), "temperature": 0.0, "beam_size": 3,
+                       "log_progress": False}
+            try:
+                segs, _ = self.whisper_model.transcribe_many(clips[lo:hi], **minimal)
+                out[lo] = segs[0]
             except Exception as e2:
                 logger.error(f"minimal-parameter retry failed too ({type(e2).__name__}: {e2}); clip dropped")
-                out.append([])
+                out[lo] = []
+
+        run(0, len(clips))
         return out
 
     def _filter_group(self, segs, start_sec: float) -> List[Dict]:

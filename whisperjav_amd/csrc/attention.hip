@@ -807,7 +807,10 @@ int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s) {
     if (!is16(dtype) || a.n_keys_ptr || a.seq_tp) { set_error("attention_dec: transposed V is the 16-bit cross-attention layout"); return WJ_E_INVALID; }
     return dtype == WJ_F16 ? launch_cross_mfma<f16_t>(a, s) : launch_cross_mfma<bf16_t>(a, s);
   }
-  if (dtype == WJ_F32) return launch_dec_T<float>(a, s);
+  if (dtype == WJ_F32) {
+    if (a.out_split) { set_error("attention_dec: split (hi | lo) output rows exist for the 16-bit compute types only"); return WJ_E_INVALID; }
+    return launch_dec_T<float>(a, s);
+  }
   return dtype == WJ_F16 ? launch_dec_T<f16_t>(a, s) : launch_dec_T<bf16_t>(a, s);
 }
 

@@ -34,7 +34,13 @@ int load_rccl() {
   if (g_rccl.lib) return WJ_OK;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
+  // an RCCL the process already carries under ANY soname (PyTorch bundles its own copy) is reused before anything is
+  // opened: two RCCL runtimes in one process would each bootstrap their own communicators
+  if (dlsym(RTLD_DEFAULT, "ncclGetUniqueId") && dlsym(RTLD_DEFAULT, "ncclCommInitRank") && dlsym(RTLD_DEFAULT, "ncclBroadcast") &&
+      dlsym(RTLD_DEFAULT, "ncclCommDestroy"))
+    h = dlopen(nullptr, RTLD_NOW);                  // handle of the global scope: dlsym below resolves the loaded copy
   for (const char* n : names) {
+    if (h) break;
     h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);          // the copy the process already has, if any
     if (h) break;
   }

@@ -245,4 +245,17 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// hipFuncSetAttribute applies to the CURRENT device: a "done once" flag per kernel has to remember which devices it was
+// done on, or a process that opens contexts on two devices launches on the second one without the attribute.
+struct AttrOnce {
+  uint64_t mask = 0, cur = 0;
+  bool need() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    cur = 1ull << (dev & 63);
+    return !(mask & cur);
+  }
+  void done() { mask |= cur; }
+};
+
 }  // namespace wj

@@ -1075,12 +1075,12 @@ __global__ __launch_bounds__(256) void gemm_h_tile_ms_kernel(const GemmArgs g) {
 template <typename T, int EPI, int NS>
 static int launch_ms_inst(const GemmArgs& a, hipStream_t s) {
   constexpr size_t smem = (size_t)NS * 2 * TBM * TBK * sizeof(bf16_t);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_tile_ms_kernel<T, EPI, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(%d KiB LDS): %s", (int)(smem >> 10), hipGetErrorString(e)); return WJ_E_HIP; }
-    attr_set = true;
+    attr_set.done();
   }
   dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), EPI == EPI_PARTIAL_F32 ? a.ksplit : a.nbatch);
   hipLaunchKernelGGL((gemm_h_tile_ms_kernel<T, EPI, NS>), grid, dim3(256), smem, s, a);
@@ -1122,15 +1122,15 @@ static int launch_big(const GemmArgs& a, hipStream_t s) {
     return WJ_E_INVALID;
   } else {
     constexpr size_t smem = 2 * 2 * BBM * TBK * sizeof(bf16_t);   // 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AttrOnce attr_set;
+    if (attr_set.need()) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_kernel<T, EPI, 0>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_kernel<T, EPI, 1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(128 KiB LDS): %s", hipGetErrorString(e)); return WJ_E_HIP; }
-      attr_set = true;
+      attr_set.done();
     }
     dim3 grid(ceil_div(a.N, BBN), ceil_div(a.M, BBM), a.nbatch);
     if (g_gemm_big == 2) hipLaunchKernelGGL((gemm_h_big_kernel<T, EPI, 1>), grid, dim3(512), smem, s, a);
@@ -1143,12 +1143,12 @@ static int launch_big(const GemmArgs& a, hipStream_t s) {
 template <typename T, int EPI, int NS>
 static int launch_big_pp_inst(const GemmArgs& a, hipStream_t s) {
   constexpr size_t smem = (size_t)NS * PSTAGE * sizeof(bf16_t);   // NS x 32 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AttrOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_pp_kernel<T, EPI, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { set_error("hipFuncSetAttribute(%d KiB LDS): %s", (int)(smem >> 10), hipGetErrorString(e)); return WJ_E_HIP; }
-    attr_set = true;
+    attr_set.done();
   }
   dim3 grid(ceil_div(a.N, BBN), ceil_div(a.M, BBM), a.nbatch);
   hipLaunchKernelGGL((gemm_h_big_pp_kernel<T, EPI, NS>), grid, dim3(512), smem, s, a);
@@ -1163,12 +1163,12 @@ static int launch_big_pp64(const GemmArgs& a, hipStream_t s) {
     return WJ_E_INVALID;
   } else {
     constexpr size_t smem = 2 * 2 * BBM * TBK * sizeof(bf16_t);   // 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AttrOnce attr_set;
+    if (attr_set.need()) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_pp64_kernel<T, EPI>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       if (e != hipSuccess) { set_error("hipFuncSetAttribute(128 KiB LDS): %s", hipGetErrorString(e)); return WJ_E_HIP; }
-      attr_set = true;
+      attr_set.done();
     }
     dim3 grid(ceil_div(a.N, BBN), ceil_div(a.M, BBM), a.nbatch);
     hipLaunchKernelGGL((gemm_h_big_pp64_kernel<T, EPI>), grid, dim3(512), smem, s, a);
@@ -1184,16 +1184,16 @@ static int launch_big_pp64p(const GemmArgs& a, hipStream_t s) {
     return WJ_E_INVALID;
   } else {
     constexpr size_t smem = 2 * 2 * BBM * TBK * sizeof(bf16_t);   // 128 KiB
-    static bool attr_set = false;
+    static AttrOnce attr_set;
     static int n_cu = 0;
-    if (!attr_set) {
+    if (attr_set.need()) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_pp64p_kernel<T, EPI>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       int dev = 0;
       if (e == hipSuccess) e = hipGetDevice(&dev);
       if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
       if (e != hipSuccess || n_cu <= 0) { set_error("persistent GEMM setup: %s", hipGetErrorString(e)); return WJ_E_HIP; }
-      attr_set = true;
+      attr_set.done();
     }
     const int nx = a.N / BBN, ny = ceil_div(a.M, BBM), total = nx * ny * a.nbatch;
     hipLaunchKernelGGL((gemm_h_big_pp64p_kernel<T, EPI>), dim3(std::min(total, n_cu)), dim3(512), smem, s, a, nx, ny, total);

@@ -247,11 +247,16 @@ class HipSileroV6SpeechSegmenter(_HipSileroBase):
 
 
 class HipSileroSpeechSegmenter(_HipSileroBase):
-    """Drop-in for ``SileroSpeechSegmenter`` (torch.hub v3.1 / v4.0 API flavour).
+    """``SileroSpeechSegmenter``'s call contract (torch.hub v3.1 / v4.0 flavour, backends/silero.py:214-323: no
+    ``max_speech_duration_s`` forwarded, WhisperJAV-side sample padding and overlap fix, 4 s chunk threshold).
 
-    NOTE: the v3.1 / v4.0 network weights and architecture are not obtainable offline; this class runs
-    the v5/v6-architecture HIP scorer behind the v3.1/v4.0 *call contract* (no ``max_speech_duration_s``
-    forwarded, WhisperJAV-side sample padding).  See DESIGN.md "open items"."""
+    The v3.1 / v4.0 NETWORK (the reference's balanced default, main.py:1867-1876; 1536-sample windows, TorchScript
+    archives from ``torch.hub``, backends/silero.py:68-72,199-206) has no HIP kernel: neither the archives nor their source
+    are reachable offline and the graph cannot be reconstructed from parameter names.  This class therefore REFUSES
+    to score (``WjError`` from ``segment``) unless the caller asks for the substitution by name: ``network="v6"`` runs
+    the v5/v6 HIP scorer behind this contract -- a different network, different probabilities, NOT the reference's VAD
+    frames -- and says so in ``name`` / ``display_name``.  A scorer seam injected by a test double (``_model`` /
+    ``_get_speech_timestamps``) bypasses the check, as in the reference's own suite."""
 
     VERSION_DEFAULTS = {
         "v4.0": {"threshold": 0.25, "min_speech_duration_ms": 150, "min_silence_duration_ms": 300,
@@ -266,8 +271,11 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
                  max_group_duration_s: Optional[float] = None, max_speech_duration_s: Optional[float] = None,
                  start_pad_samples: int = 11200, end_pad_samples: int = 20800,
                  weights: Union[Dict[str, np.ndarray], str, None] = None, device: int = 0,
-                 weights_path: Optional[str] = None, **kwargs):
+                 weights_path: Optional[str] = None, network: Optional[str] = None, **kwargs):
         self._weights_path = weights_path
+        if network not in (None, "v6", "v5/v6"):
+            raise ValueError("network must be None (the version's own network: no HIP kernel, refuses) or 'v6'")
+        self.network = "v6" if network else None
         self.version = version if version in self.VERSION_DEFAULTS else "v4.0"
         dflt = self.VERSION_DEFAULTS[self.version]
         self.threshold = float(threshold) if threshold is not None else dflt["threshold"]
@@ -295,11 +303,23 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
 
     @property
     def name(self) -> str:
-        return f"silero-{self.version}-hip"
+        return f"silero-{self.version}-hip" + ("+v6net" if self.network else "")
 
     @property
     def display_name(self) -> str:
-        return f"Silero VAD {self.version} (MI355X HIP)"
+        if self.network:
+            return f"Silero VAD {self.version} call contract over the v6 network (MI355X HIP)"
+        return f"Silero VAD {self.version} (MI355X HIP; no kernel for this network: refuses to score)"
+
+    def _ensure_model(self) -> None:
+        if self._model is None and self.network is None:
+            from .hipbind import WjError
+            raise WjError(
+                f"silero-{self.version}-hip: the Silero {self.version} network (1536-sample windows, torch.hub "
+                "snakers4/silero-vad) has no HIP kernel and is never replaced silently.  Use 'silero-v6.2-hip' (the "
+                "v5/v6 network, its own thresholds), or pass network='v6' to run the v6 scorer behind the "
+                f"{self.version} call contract knowingly; vad_weights.from_torchscript(path) identifies an archive.")
+        super()._ensure_model()
 
     def _get_parameters(self) -> Dict[str, Any]:
         return {k: getattr(self, k) for k in (

@@ -57,6 +57,34 @@ def from_jit_state_dict(sd) -> Dict[str, np.ndarray]:
     return out
 
 
+V6_KEYS = ("_model.stft.forward_basis_buffer", "_model.encoder.0.reparam_conv.weight", "_model.decoder.rnn.weight_ih",
+           "_model.decoder.decoder.2.weight")
+
+
+def classify_state_dict(sd) -> str:
+    """Which Silero generation a TorchScript state dict belongs to: ``"v5/v6"`` (512-sample windows, conv-STFT + 4
+    reparametrised conv blocks + one LSTM cell: the network ``csrc/vad.hip`` implements; ``silero_vad`` >= 5,
+    reference: backends/silero_v6.py:143) or ``"v3.1/v4.0"`` (the ``torch.hub`` ``snakers4/silero-vad:v3.1`` /
+    ``:v4.0`` archives the reference's default back end loads, backends/silero.py:68-72,199-206: 1536-sample windows,
+    a different graph).  Decided from the parameter names and shapes alone; raises on anything else."""
+    keys = set(sd.keys())
+    if all(k in keys for k in V6_KEYS) or "stft.forward_basis_buffer" in keys:
+        return "v5/v6"
+    names = " ".join(sorted(keys))
+    legacy_marks = ("first_layer", "adaptive_normalization", "_model.encoder.0.dw_conv", "_model_8k", "lstm", "transformer")
+    if any(m in names for m in legacy_marks) and any("forward_basis_buffer" in k for k in keys):
+        return "v3.1/v4.0"
+    raise ValueError(f"not a Silero VAD state dict (neither the v5/v6 nor the v3.1/v4.0 parameter names): {sorted(keys)[:8]} ...")
+
+
+def from_torchscript(path: str):
+    """``(generation, state_dict)`` of a Silero TorchScript archive (``silero_vad.jit``, or the ``model.jit`` that
+    ``torch.hub.load("snakers4/silero-vad:v3.1", "silero_vad")`` caches under ``~/.cache/torch/hub``)."""
+    import torch
+    sd = torch.jit.load(path, map_location="cpu").state_dict()
+    return classify_state_dict(sd), sd
+
+
 def load_file(path: str) -> Dict[str, np.ndarray]:
     """Trained parameters from a file: ``.npz`` / ``.safetensors`` holding either this module's names or the
     TorchScript names, or the TorchScript archive itself (``silero_vad.jit``)."""
@@ -67,8 +95,11 @@ def load_file(path: str) -> Dict[str, np.ndarray]:
         from safetensors.numpy import load_file as _load
         sd = _load(path)
     else:
-        import torch
-        sd = torch.jit.load(path, map_location="cpu").state_dict()
+        gen, sd = from_torchscript(path)
+        if gen != "v5/v6":
+            from .hipbind import WjError
+            raise WjError(f"{path}: a Silero {gen} archive (1536-sample windows); the HIP scorer implements the v5/v6 "
+                          "network only and will not run a different network under that name")
     if "stft.forward_basis_buffer" in sd:
         return {k: np.asarray(v, dtype=np.float32) for k, v in sd.items()}
     return from_jit_state_dict(sd)
