@@ -78,6 +78,16 @@ def stage_model(tag, count, ms, units, dims, dtype, beam, avg_keys):
         "enc_attention": 4.0 * w * H * T * T * 64,
     }
     rows = w * beam
+    # decode-step GEMMs: weights are streamed once per launch (HBM roof) and rows x N x K MACs are issued (MFMA roof; the
+    # out / cross-out / fc2 / logits GEMMs of the 16-bit types run hi + lo split activations = 2x the MACs).  Which roof
+    # binds depends on the rows per launch: 2 * rows / esz FLOP per weight byte against the 310 FLOP/B ridge.
+    split = 2.0 if dtype != "float32" else 1.0
+    dec_flops = {
+        "dec_qkv_gemm": 2.0 * rows * 3 * d * d, "dec_out_gemm": 2.0 * rows * d * d * split,
+        "dec_cq_gemm": 2.0 * rows * d * d, "dec_cout_gemm": 2.0 * rows * d * d * split,
+        "dec_fc1_gemm": 2.0 * rows * 4 * d * d, "dec_fc2_gemm": 2.0 * rows * 4 * d * d * split,
+        "dec_logits_gemm": 2.0 * rows * V * d * split,
+    }
     byts = {
         "dec_cross_attn": w * H * T * 64 * 2.0 * esz,          # K and V of every window in the launch, read once
         "dec_self_attn": rows * H * avg_keys * 64 * 2.0 * esz,
@@ -96,6 +106,14 @@ def stage_model(tag, count, ms, units, dims, dtype, beam, avg_keys):
     if tag in flops:
         return {"bound": "mfma", "achieved": flops[tag] / sec / 1e12, "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS[dtype],
                 "work_per_launch": flops[tag] / count}
+    if tag in dec_flops:
+        hbm = byts[tag] / sec / 1e9 / HBM_PEAK_GBS
+        mfma = dec_flops[tag] / sec / 1e12 / MFMA_PEAK_TFLOPS[dtype]
+        if mfma >= hbm:     # above the ridge: the matrix pipe is the binding roof
+            return {"bound": "mfma", "achieved": dec_flops[tag] / sec / 1e12, "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS[dtype],
+                    "work_per_launch": dec_flops[tag] / count, "other_roof": {"bound": "hbm", "frac": round(hbm, 4)}, "class": "decode_gemm"}
+        return {"bound": "hbm", "achieved": byts[tag] / sec / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "work_per_launch": byts[tag] / count, "other_roof": {"bound": "mfma", "frac": round(mfma, 4)}, "class": "decode_gemm"}
     if tag in byts:
         return {"bound": "hbm", "achieved": byts[tag] / sec / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
                 "work_per_launch": byts[tag] / count}
@@ -112,14 +130,23 @@ def stages_from_profile(prof, dims, dtype, beam, avg_keys):
         if sm:
             entry.update({"bound": sm["bound"], "achieved": round(sm["achieved"], 2), "unit": sm["unit"],
                           "frac": round(sm["achieved"] / sm["peak"], 4), "work_per_launch": sm["work_per_launch"]})
+            for k in ("other_roof", "class"):
+                if k in sm:
+                    entry[k] = sm[k]
         stages[tag] = entry
-    dec = [k for k in stages if k.startswith("dec_") and stages[k].get("bound") == "hbm"]
+    dec = [k for k in stages if k.startswith("dec_") and stages[k].get("bound") == "hbm" and stages[k].get("class") != "decode_gemm"]
     if dec:     # the decode step as a whole against the HBM roof (weights once per launch + K/V of every row)
         byts = sum(stages[k]["work_per_launch"] * stages[k]["launches"] for k in dec)
         ms = sum(stages[k]["ms_total"] for k in dec)
         stages["_decode_hbm_aggregate"] = {"achieved": round(byts / (ms * 1e-3) / 1e9, 2), "unit": "GB/s",
                                            "frac": round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_total": round(ms, 3)}
-    enc = [k for k in stages if stages[k].get("bound") == "mfma"]
+    dg = [k for k in stages if stages[k].get("class") == "decode_gemm" and stages[k].get("bound") == "mfma"]
+    if dg:      # the decode-step GEMM class against the MFMA roof
+        fl = sum(stages[k]["achieved"] * stages[k]["ms_total"] for k in dg)
+        ms = sum(stages[k]["ms_total"] for k in dg)
+        stages["_decode_gemm_mfma_aggregate"] = {"achieved": round(fl / ms, 2), "unit": "TFLOP/s",
+                                                 "frac": round(fl / ms / MFMA_PEAK_TFLOPS[dtype], 4), "ms_total": round(ms, 3)}
+    enc = [k for k in stages if stages[k].get("bound") == "mfma" and stages[k].get("class") != "decode_gemm"]
     if enc:
         fl = sum(stages[k]["achieved"] * stages[k]["ms_total"] for k in enc)
         ms = sum(stages[k]["ms_total"] for k in enc)
@@ -133,48 +160,59 @@ def roofline_from_stages(stages, dtype, tag_hint=None):
     if dom is None or "bound" not in stages.get(dom, {}):
         return None
     e = stages[dom]
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_cross_attn_cfg3.json")
-    if dom == "dec_cross_attn" and dtype != "float32" and os.path.exists(pmc_file):
-        # rocprofv3 --pmc FETCH_SIZE pass of the same command (own pass, x2 gfx950 wide-read correction, MI355X_MICROARCH.md
-        # "HBM"); stored per window so that it scales to this run's windows per launch
+    traffic = traffic_source = None
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_cross_attn_cfg3.json", "r02_pmc_cross_attn_cfg3.json"))
+                     if os.path.exists(f)), None)
+    if dom == "dec_cross_attn" and dtype != "float32" and pmc_file:
+        # NOT measured in this run: a stored rocprofv3 --pmc FETCH_SIZE pass of the same command (own pass, x2 gfx950
+        # wide-read correction, MI355X_MICROARCH.md "HBM"), kept per window and scaled to this run's windows per launch
         pmc = json.load(open(pmc_file))
         traffic = pmc["hbm_read_bytes_per_window"] * e["windows_per_launch"]
+        traffic_source = f"stored PMC pass ({os.path.basename(pmc_file)}: {pmc.get('command', 'bench.py')}), scaled per window; not collected in this run"
     return {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"],
             "peak": HBM_PEAK_GBS if e["bound"] == "hbm" else MFMA_PEAK_TFLOPS[dtype], "unit": e["unit"], "frac": e["frac"],
-            "traffic": traffic, "algorithmic_work_per_launch": e["work_per_launch"], "windows_per_launch": e["windows_per_launch"],
+            "traffic": traffic, "traffic_source": traffic_source,
+            "algorithmic_work_per_launch": e["work_per_launch"], "windows_per_launch": e["windows_per_launch"],
             "us_per_launch": e["us_per_launch"], "share_of_profiled_kernel_time": e["share"]}
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (port of the reference's upstream math) on a bounded sample
 # ---------------------------------------------------------------------------------------------------------------
-def cpu_baseline_cfg3(dims, w, clip, n_groups, audio_s, max_new, sample_tokens, beam):
-    """One VAD group of the recording on this host's cores: log-mel + full encoder + `sample_tokens` steps of the cfg3
-    beam search, decode scaled linearly to `max_new` steps; the recording costs `n_groups` such groups."""
+def cpu_baseline_cfg3(dims, w, clips, n_groups, audio_s, max_new, beam, threads):
+    """A bounded sample of the recording's VAD groups on this host's cores: log-mel + the full encoder (the sample's
+    windows as one batch) + the cfg3 beam search of every sampled group run to its END (EOT-bearing weights: the search
+    stops on patience like the GPU's), timed whole; the recording costs ``n_groups / len(clips)`` such samples."""
     from oracle import decoding, logmel, whisper_ref
-    threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
     oracle = whisper_ref.WhisperOracle(whisper_ref.WhisperDims(**dims.as_dict()), w)
     toks = pdims.special_tokens(dims.n_vocab)
     prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
     t0 = time.perf_counter()
-    mel = logmel.window_features(clip, dims.n_mels, "fw")
+    mel = np.stack([logmel.window_features(c, dims.n_mels, "fw") for c in clips])
     t_mel = time.perf_counter() - t0
+    steps, lens = [], []
     with torch.no_grad():
         t0 = time.perf_counter()
-        enc = oracle.encode(torch.from_numpy(mel[None]))
+        enc = oracle.encode(torch.from_numpy(mel))
         t_enc = time.perf_counter() - t0
         t0 = time.perf_counter()
-        decoding.beam_search(oracle, enc, prompt, decoding.BeamConfig(beam, 1.2, 1.0, 1.5, 3, sample_tokens),
-                             decoding.FilterConfig(max_initial_timestamp_index=0))
+        for g in range(len(clips)):
+            tr = {}
+            hyps, _ = decoding.beam_search(oracle, enc[g:g + 1], prompt, decoding.BeamConfig(beam, 1.2, 1.0, 1.5, 3, max_new),
+                                           decoding.FilterConfig(max_initial_timestamp_index=0), trace=tr)
+            steps.append(tr["steps"]); lens.append(len(hyps[0][0]))
         t_dec = time.perf_counter() - t0
-    per_group = t_mel + t_enc + t_dec * (max_new + len(prompt) - 1) / (sample_tokens + len(prompt) - 1)
-    return {"value": audio_s / (per_group * n_groups), "unit": UNIT, "cores": threads, "kind": "port",
-            "sample": (f"1 of the recording's {n_groups} VAD groups ({len(clip) / 16000:.1f} s of audio -> one 30 s window): log-mel + "
-                       f"full large-v3-shaped encoder + {sample_tokens} of {max_new} beam-{beam} steps (decode scaled linearly), "
-                       f"PyTorch-CPU fp32 oracle, {threads} threads: mel {t_mel:.2f}s enc {t_enc:.2f}s dec({sample_tokens}) {t_dec:.2f}s; "
-                       f"value = recording seconds / (groups x per-group time); the reference's own CPU pipeline "
-                       f"(faster-whisper int8, 4 CT2 threads) cannot run offline -- wheels absent")}
+    sample_audio = sum(len(c) for c in clips) / 16000.0
+    total = t_mel + t_enc + t_dec
+    return {"value": audio_s / (total * n_groups / len(clips)), "unit": UNIT, "cores": threads, "kind": "port",
+            "sample_groups": len(clips), "sample_audio_s": round(sample_audio, 2), "sample_seconds": round(total, 2),
+            "beam_steps_run": steps, "tokens_of_the_winner": lens, "t_mel_s": round(t_mel, 3), "t_encoder_s": round(t_enc, 2),
+            "t_beam_search_s": round(t_dec, 2), "arithmetic": "fp32 (PyTorch-CPU); no int8: the reference's CPU path is CTranslate2 int8 on 4 threads",
+            "sample": (f"{len(clips)} of the recording's {n_groups} VAD groups ({sample_audio:.1f} s of audio -> {len(clips)} x 30 s windows): "
+                       f"log-mel + full large-v3-shaped encoder (one batch) + beam-{beam} / patience 1.2 search of every group to its end "
+                       f"({steps} steps), PyTorch-CPU fp32 oracle on {threads} threads; value = recording seconds / (groups x per-group "
+                       f"time); the reference's own CPU pipeline (faster-whisper int8, 4 CT2 threads) cannot run offline -- wheels absent")}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -213,6 +251,9 @@ def build_stack(args, info, dims, dtype, batch, blob=None, offsets=None, weights
 def run_recording(runner, audio, scene_subset=None, pooled=True):
     """One step: scenes -> pooled VAD -> groups -> pooled beam-search transcription -> stitched segments."""
     from whisperjav_amd import pipeline
+    wm = getattr(runner.asr, "whisper_model", None)
+    if hasattr(wm, "reset_decode_stats"):
+        wm.reset_decode_stats()
     t0 = time.perf_counter()
     scenes = runner.detect(audio, pipeline.SR)
     if scene_subset is not None:
@@ -224,8 +265,15 @@ def run_recording(runner, audio, scene_subset=None, pooled=True):
     vad = runner.asr.get_vad_segments_per_scene()
     import zlib
     crc = zlib.crc32("|".join(f"{s['start']:.2f},{s['end']:.2f},{s['text']}" for s in merged).encode())    # A/B runs must agree
-    return {"scenes": len(scenes), "segments": len(merged), "vad_segments": sum(len(v) for v in vad), "transcript_crc32": crc,
-            "scene_audio_s": round(sum(b - a for a, b in scenes), 1), "t_scene": round(t1 - t0, 4), "t_asr_incl_vad": round(t2 - t1, 4)}
+    out = {"scenes": len(scenes), "segments": len(merged), "vad_segments": sum(len(v) for v in vad), "transcript_crc32": crc,
+           "scene_audio_s": round(sum(b - a for a, b in scenes), 1), "t_scene": round(t1 - t0, 4), "t_asr_incl_vad": round(t2 - t1, 4)}
+    st = getattr(wm, "decode_stats", None)
+    if st and st["windows"]:
+        out["decode"] = {"windows": st["windows"], "engine_calls": st["calls"], "tokens_per_window_mean": round(st["tokens"] / st["windows"], 2),
+                         "tokens_per_window_max": st["max_tokens"], "windows_at_length_limit": st["at_length_limit"],
+                         "decode_steps_run": st["steps_run"], "decode_steps_allowed": st["steps_allowed"],
+                         "window_steps_run": st["window_steps_run"], "batch_compactions": st.get("compactions", 0)}
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -292,6 +340,17 @@ def simulate(args, info):
 # ---------------------------------------------------------------------------------------------------------------
 # cfg3 (default)
 # ---------------------------------------------------------------------------------------------------------------
+def make_weights(args, dims):
+    """Seeded synthetic large-v3-shaped weights.  ``speechlike`` (default): hypotheses END -- EOT ramp whose crossing moves
+    with the amount of audio in the window (``--eot-rate`` nominal tokens per second of content), peaked cross-attention
+    (weights.SPEECHLIKE).  ``plain``: the round-1/2 weights (never emit EOT: every window decodes max_new_tokens)."""
+    if args.weights == "plain":
+        return pweights.synth_weights(dims, seed=1234, exact="float16")
+    kw = dict(pweights.SPEECHLIKE)
+    kw["eot"] = pweights.EotRamp(mid=4.0, rate=args.eot_rate)
+    return pweights.synth_weights(dims, seed=1234, exact="float16", **kw)
+
+
 def make_audio(args):
     """The recording of this rank (weak scaling: every GPU has its own; --strong: one for the job).  Runs BEFORE the
     process touches the GPU: the chunk workers are separate processes."""
@@ -313,7 +372,7 @@ def run_cfg3(args, info, dims):
     audio, t_audio = args._audio, args._t_audio          # generated in main() before any GPU initialisation
     if info.rank == 0:
         # fp16-representable values, like the published checkpoints; rounded and laid out into the blob ON the GPU
-        box["w"] = pweights.synth_weights(dims, seed=1234, exact="float16")
+        box["w"] = make_weights(args, dims)
         box["blob"], box["offsets"] = pweights.pack_blob_device(dims, box["w"], dtype, dev)
     dev_blob, offsets = sharding.broadcast_blob(box.get("blob"), box.get("offsets"), dev)     # the ONE collective
     box.pop("blob", None)
@@ -352,14 +411,26 @@ def run_cfg3(args, info, dims):
                                         f"{'job' if args.strong else 'GPU'}: two-pass energy-gate scenes <= 29 s (device frame energies), "
                                         f"Silero-class HIP VAD (threshold {args.vad_threshold}, seeded random parameters), groups <= 6 s, "
                                         f"Whisper {args.model} geometry (seeded random fp16-representable weights), beam {args.beam} / patience 1.2 / "
-                                        f"repetition penalty 1.5 / no-repeat-3-gram, max_new_tokens={args.max_new_tokens} (random weights "
-                                        f"never emit EOT: every window decodes exactly this many tokens), word_timestamps=False, "
+                                        f"repetition penalty 1.5 / no-repeat-3-gram, max_new_tokens={args.max_new_tokens} ("
+                                        + ("EOT-bearing synthetic weights: every search ends on its own, see workload_facts" if args.weights == "speechlike"
+                                           else "plain random weights never emit EOT: every window decodes exactly this many tokens")
+                                        + "), word_timestamps=False, "
                                         f"through pipeline.RecordingTranscriber over asr.HipFasterWhisperProASR (the drop-in seam's classes)"),
                            "windows_per_batch": args.batch, "compute_type": dtype, "max_new_tokens": args.max_new_tokens,
                            "tune": args.tune, "scene_loop": "pooled" if pooled else "one engine call per scene (the reference's call pattern)",
                            "parallelism": (f"scene-parallel x{info.world} ({'one recording LPT-sharded' if args.strong else 'one recording per GPU'}), "
                                            f"one RCCL weight broadcast, no data-path collective"),
                            "per_rank_last_step": per_rank},
+                # what the headline number depends on, as data
+                "workload_facts": {
+                    "whisper_weights": ("synthetic, seeded, fp16-representable; weights.SPEECHLIKE with EotRamp(mid=4, rate=%g): hypotheses end, "
+                                        "later for windows holding more audio" % args.eot_rate) if args.weights == "speechlike"
+                                       else "synthetic, seeded, fp16-representable, plain (no EOT ever)",
+                    "vad_weights": "synthetic (seeded random Silero-v5/v6-shaped parameters; trained ones are not available offline)",
+                    "vad_threshold": args.vad_threshold, "scene_gate_db": {"pass1": 52, "pass2": 56, "reference_defaults": [32, 38]},
+                    "max_new_tokens": args.max_new_tokens, "beam": args.beam, "patience": 1.2,
+                    "decode_last_step": (stats or {}).get("decode"), "scenes": (stats or {}).get("scenes"),
+                    "vad_segments": (stats or {}).get("vad_segments")},
                 "roofline": None, "cpu_baseline": None, "stages": {}}
 
     # ---- extras on rank 0 of a single-GPU run: live stage profile, CPU baseline, secondary figures ---------------
@@ -369,7 +440,9 @@ def run_cfg3(args, info, dims):
         ctx.profile_start()          # eager replay of one step with a HIP event pair around every launch
         run_recording(runner, audio, subset)
         prof = ctx.profile_stop_units()
-        avg_keys = 3 + (args.max_new_tokens + 1) / 2.0
+        dstat = (stats or {}).get("decode")
+        avg_steps = dstat["decode_steps_run"] / max(1, dstat["engine_calls"]) if dstat else args.max_new_tokens
+        avg_keys = 3 + (avg_steps + 1) / 2.0
         line["stages"] = stages_from_profile(prof, dims, dtype, args.beam, avg_keys)
         line["roofline"] = roofline_from_stages(line["stages"], dtype)
         n_windows = prof.get("conv1_gemm", (0, 0, 0))[2]
@@ -428,13 +501,18 @@ def run_cfg3(args, info, dims):
         del pcm
     # the groups of the recording, for the CPU baseline's scaling (before the model goes away)
     n_groups = None
-    first_clip = None
+    sample_clips = []
     if info.rank == 0 and info.world == 1 and (not args.no_cpu_baseline or not args.no_extras):
         scenes = runner.detect(audio, 16000)
-        sc = runner.scene_audio(audio, 16000, scenes[0])
-        res = module._external_segmenter.segment(sc, sample_rate=16000)
-        g = res.groups[0] if res.groups else None
-        first_clip = sc[g[0].start_sample: g[-1].end_sample] if g else sc[: 16000 * 5]
+        for scn in scenes[: 4 * args.cpu_sample_groups]:        # the first groups of the recording, in order
+            sc = runner.scene_audio(audio, 16000, scn)
+            res = module._external_segmenter.segment(sc, sample_rate=16000)
+            for g in res.groups:
+                clip = sc[g[0].start_sample: g[-1].end_sample]
+                if len(clip) > 1600 and len(sample_clips) < args.cpu_sample_groups:
+                    sample_clips.append(np.ascontiguousarray(clip))
+        if not sample_clips:
+            sample_clips = [audio[: 16000 * 5]]
         n_groups = line["config"].get("windows_per_step") or max(1, int(60 * minutes / 4.5))
     module.cleanup()
     del model, module, runner, dev_blob
@@ -456,8 +534,8 @@ def run_cfg3(args, info, dims):
         del m32, mod32, run32
         torch.cuda.empty_cache()
     if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_cfg3(dims, box["w"], first_clip, n_groups, 60.0 * minutes, args.max_new_tokens,
-                                                 args.cpu_sample_tokens, args.beam)
+        line["cpu_baseline"] = cpu_baseline_cfg3(dims, box["w"], sample_clips, n_groups, 60.0 * minutes, args.max_new_tokens,
+                                                 args.beam, args.cpu_threads or min(32, os.cpu_count() or 1))
     if info.rank == 0:
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
@@ -475,7 +553,7 @@ def run_cfg2(args, info, dims):
     t0 = time.perf_counter()
     w = blob = offsets = None
     if info.rank == 0:
-        w = pweights.synth_weights(dims, seed=1234, exact="float16")
+        w = make_weights(args, dims)
         blob, offsets = pweights.pack_blob(dims, w, dtype)
     dev_blob, offsets = sharding.broadcast_blob(blob, offsets, dev)
     del blob
@@ -551,7 +629,11 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16", "float32"])
     ap.add_argument("--fp32-minutes", type=float, default=3.0, help="cfg3: audio minutes of the fp32-mode figure")
-    ap.add_argument("--cpu-sample-tokens", type=int, default=2)
+    ap.add_argument("--cpu-sample-groups", type=int, default=4, help="cpu_baseline: VAD groups of the recording run on the host")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="cpu_baseline: PyTorch threads (0 = min(32, cores): more threads slow the small decode GEMMs)")
+    ap.add_argument("--weights", default="speechlike", choices=["speechlike", "plain"],
+                    help="speechlike: EOT-bearing synthetic weights (searches end, token count grows with the audio in the window); plain: never EOT")
+    ap.add_argument("--eot-rate", type=float, default=12.0, help="speechlike: nominal tokens per second of audio content (realised: see workload_facts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--extras-budget-s", type=float, default=480.0, help="skip the secondary figures when the run has already taken this long")

@@ -67,7 +67,9 @@ int wj_device_info(wj_ctx* ctx, int64_t out[4]);
  * "gemm_big" (256-tile GEMM kernel: 1 lockstep, 3-5 ping-pong with that many 32-wide ring stages, 6 ping-pong over
  * 64-wide pairs = default), "epi_wide" (16-byte epilogue stores of the MFMA tile kernels), "dec_ms_resid" (ring stages of
  * the residual-writing decode tile GEMMs).  Alignment: "align_prefill".  Search: "beam_topk_reg" (register-resident top-2K of the
- * device beam search; 0 = the multi-pass sweep).  Unknown keys are an error. */
+ * device beam search; 0 = the multi-pass sweep), "beam_compact" (1 = windows whose search has ended leave the batch),
+ * "beam_poll" (iterations between polls of the done flags), "beam_compact_pct" / "beam_compact_min" (share / number of
+ * finished windows that triggers a re-pack).  Unknown keys are an error. */
 int wj_tune(const char* key, int value);
 
 /* ---- profiler --------------------------------------------------------------------------
@@ -227,8 +229,9 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
 /* diagnostics of the last wj_whisper_decode_{greedy,sample,beam} call: out[0] = 1 if the step was replayed from a
  * hipGraph, out[1] = number of concurrent row chains, out[2] = decode iterations actually run (the loops leave early
  * once every row has emitted EOT resp. every window has round(beam * patience) finished hypotheses), out[3] = the
- * iterations it was allowed (max_new_tokens) */
-int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[4]);
+ * iterations it was allowed (max_new_tokens), out[4] = times the beam search re-packed its batch (windows whose search
+ * has ended leave it), out[5] = sum over the iterations of the live windows (window-steps of work actually done) */
+int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[6]);
 
 /* Step-wise decoder for host-driven search (beam search with CTranslate2's patience /
  * repetition-penalty / no-repeat-ngram processors lives in whisperjav_amd/search.py).

@@ -202,6 +202,55 @@ def test_ragged_16_window_batch_equals_per_window_decodes(hip):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float16"])
+def test_batch_compaction_is_transparent(hip, dtype):
+    """The device beam search re-packs its batch when windows finish (``wj_tune beam_compact``): forced here on every
+    poll (``beam_poll=1, beam_compact_min=1, beam_compact_pct=1``), with a slot map, against the un-compacted loop and the
+    oracle.  KV-cache rows and finished lists never move, so the hypotheses must be the same ones."""
+    from whisperjav_amd import engine, hipbind
+    B, beam, max_new = 8, 5, 64
+    d, oracle, model, xa = _setup(dtype, B, beam, seed=11, clip_seed=5)
+    toks = model.tokens
+    prompt = model.sot_prompt("ja", "transcribe")
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    dopt = engine.DecodeOptions(max_new_tokens=max_new, suppress_tokens=suppress, max_initial_timestamp=0.0,
+                                repetition_penalty=1.5, no_repeat_ngram_size=3)
+    P = np.tile(np.array(prompt, dtype=np.int32), (B, 1))
+    order = [5, 0, 7, 2, 1, 6, 3, 4]                                     # windows addressed through the slot map too
+    try:
+        hipbind.tune("beam_compact", 0)
+        plain = model.decode_beam(P, dopt, beam_size=beam, patience=1.2, length_penalty=1.0)
+        assert model.last_decode_info()["compactions"] == 0
+        for k, v in (("beam_compact", 1), ("beam_poll", 1), ("beam_compact_min", 1), ("beam_compact_pct", 1)):
+            hipbind.tune(k, v)
+        packed = model.decode_beam(P, dopt, beam_size=beam, patience=1.2, length_penalty=1.0)
+        info = model.last_decode_info()
+        shuffled = model.decode_beam(P, dopt, beam_size=beam, patience=1.2, length_penalty=1.0, slots=order)
+    finally:
+        for k, v in (("beam_compact", 1), ("beam_poll", 4), ("beam_compact_min", 8), ("beam_compact_pct", 12)):
+            hipbind.tune(k, v)
+    assert info["compactions"] >= 3 and info["hip_graph"], info
+    assert info["window_steps"] < info["steps"] * B                      # less work than the un-compacted loop
+    fcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=0)
+    bcfg = decoding.BeamConfig(beam, 1.2, 1.0, 1.5, 3, max_new)
+    tol = 1e-4 if dtype == "float32" else 2e-2      # smaller batches pick other GEMM kernels: summation order differs
+    for w in range(B):
+        a = plain.tokens[w, : plain.n_tokens[w]].tolist()
+        b = packed.tokens[w, : packed.n_tokens[w]].tolist()
+        c = shuffled.tokens[order.index(w), : shuffled.n_tokens[order.index(w)]].tolist()
+        if dtype == "float32":
+            ref, nsp = decoding.beam_search(oracle, xa[w:w + 1], prompt, bcfg, fcfg)
+            assert a == b == c == ref[0][0], (w, a, b, c, ref[0][0])
+            assert abs(float(packed.sum_logprob[w]) - ref[0][2]) < 1e-3
+            assert abs(float(packed.no_speech_prob[w]) - nsp) < 1e-5
+        else:
+            assert a == b == c, (w, a, b, c)
+        assert abs(float(plain.sum_logprob[w]) - float(packed.sum_logprob[w])) < tol
+        assert abs(float(shuffled.sum_logprob[order.index(w)]) - float(packed.sum_logprob[w])) < tol
+    _diag("compaction", {"dtype": dtype, "lens": packed.n_tokens.tolist(), **info})
+    model.close()
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
 def test_golden_large_v3_r3_searches_that_end(hip, dtype):
     """Large-v3 geometry, fp16-representable ``SPEECHLIKE`` weights, two windows (a 6 s and a 2.5 s clip): greedy until
     EOT and the cfg3 beam search until patience stops it, against the committed oracle vectors

@@ -106,6 +106,11 @@ struct Tunables {
                             // 1 = the residual-writing GEMMs (attention out-projections, fc2) and the logits GEMM,
                             // 2 = every decode GEMM, 0 = none
   int dec_adapt_ks = 1;     // halve the split-K factors while the row tiles alone keep >= 256 workgroups busy
+  int beam_compact = 1;     // device beam search: windows whose search has ended leave the batch at the next poll (the step's cost
+                            // is proportional to the live windows: cross attention reads their K/V, the GEMMs their rows)
+  int beam_poll = 4;        // decode iterations between two polls of the per-window done flags
+  int beam_compact_pct = 12;  // compact when at least this share of the batch's windows ...
+  int beam_compact_min = 8;   // ... and at least this many of them have finished
   int dec_big_min_m = 0;    // rows from which the wide decode projections (qkv, fc1) use the 256x256 kernel; measured at 1920 rows: 14.00 s vs 13.89 s for the 128-tile kernel (160 workgroups do not fill 256 CUs), so off
 };
 static Tunables g_tune;
@@ -170,6 +175,8 @@ struct wj_whisper {
   int32_t* tokens2 = nullptr;     // second history buffer (histories are gathered by parent every step)
   float* beam_score = nullptr;    // [R]
   int32_t* beam_done = nullptr;   // [max_batch] + n_done at [max_batch]
+  int32_t* win_ids = nullptr;     // [max_batch] result-array index of each logical window (compaction of finished windows)
+  int32_t* src_rows = nullptr;    // [max_rows] staging of a compaction's row gather
   int32_t* fin_count = nullptr;   // [max_batch]
   float* fin_score = nullptr;     // [max_batch][kFinCap]
   int32_t* fin_len = nullptr;
@@ -187,6 +194,8 @@ struct wj_whisper {
   int open_batch = 0, open_beam = 0, open_rows = 0, host_pos = 0;
   int last_used_graph = 0, last_chains = 1;   // diagnostics of the last decode call
   int last_steps = 0, last_max_new = 0;       // decode iterations it ran / was allowed to run
+  int last_compactions = 0;                   // beam search: times the batch was re-packed
+  int64_t last_window_steps = 0;              // ... sum over iterations of the live windows (the work actually done)
 
   const void* W(int idx) const { return blob + off[idx]; }
   const float* F(int idx) const { return reinterpret_cast<const float*>(blob + off[idx]); }
@@ -725,6 +734,10 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_split_act")) g_tune.dec_split_act = value;
   else if (!strcmp(key, "dec_adapt_ks")) g_tune.dec_adapt_ks = value;
   else if (!strcmp(key, "dec_big_min_m")) g_tune.dec_big_min_m = value;
+  else if (!strcmp(key, "beam_compact")) g_tune.beam_compact = value;
+  else if (!strcmp(key, "beam_poll")) g_tune.beam_poll = value;
+  else if (!strcmp(key, "beam_compact_pct")) g_tune.beam_compact_pct = value;
+  else if (!strcmp(key, "beam_compact_min")) g_tune.beam_compact_min = value;
   else if (!strcmp(key, "beam_topk_reg")) g_beam_topk_reg = value;
   else if (!strcmp(key, "gemm_big")) g_gemm_big = value;
   else if (!strcmp(key, "epi_wide")) g_epi_wide = value;
@@ -843,6 +856,8 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   WJ_ALLOC(tokens2, R * m->tok_stride * sizeof(int32_t), true);
   WJ_ALLOC(beam_score, R * sizeof(float), true);
   WJ_ALLOC(beam_done, (B + 1) * sizeof(int32_t), true);
+  WJ_ALLOC(win_ids, B * sizeof(int32_t), true);
+  WJ_ALLOC(src_rows, R * sizeof(int32_t), true);
   WJ_ALLOC(fin_count, B * sizeof(int32_t), true);
   WJ_ALLOC(fin_score, B * kFinCap * sizeof(float), true);
   WJ_ALLOC(fin_len, B * kFinCap * sizeof(int32_t), true);
@@ -979,8 +994,10 @@ int wj_whisper_decode_sample(wj_whisper* m, int batch, int group, const int32_t*
   m->last_chains = chains;
   std::vector<int32_t> fin(R);
   m->last_steps = 0; m->last_max_new = max_new;
+  m->last_compactions = 0; m->last_window_steps = 0;
   for (int i = 0; i < max_new; ++i) {
     m->last_steps = i + 1;
+    m->last_window_steps += batch;
     for (int c = 0; c < chains; ++c) {
       if (use_graph) {
         WJ_HIP(hipGraphLaunch(exec[c], side[c]));
@@ -1078,26 +1095,42 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
     if (ns) WJ_TRY(launch_no_speech_prob(m->logits, m->ldl, R, m->d.n_vocab, opts->no_speech, m->nsp, s));
     WJ_TRY(launch_advance_pos(m->pos, s));
   }
+  // Windows whose search has ended (round(beam * patience) hypotheses finished) leave the batch: every `beam_poll`
+  // iterations the host reads the per-window done flags and, when enough of them are set, re-packs the live windows into
+  // the first rows (history, score, row map gathered on the device; KV-cache rows and finished lists do not move: the
+  // row map keeps addressing the former, `win_ids` the latter) and re-captures the two step graphs for the smaller batch.
+  int n_act = batch;                                  // live logical windows; logical window w = rows [w K, (w + 1) K)
+  std::vector<int32_t> act_win(batch), act_slot(batch);
+  for (int w = 0; w < batch; ++w) { act_win[w] = w; act_slot[w] = slots_host ? slots_host[w] : w; }
+  const bool compact_ok = g_tune.beam_compact != 0;
+  if (compact_ok) {   // the window -> cross K/V slot and window -> result index maps become explicit
+    m->use_slots = true;
+    WJ_HIP(hipMemcpyAsync(m->slot_map, act_slot.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+    WJ_HIP(hipMemcpyAsync(m->win_ids, act_win.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+    WJ_HIP(hipStreamSynchronize(s));
+  }
   auto iteration = [&](int par, bool first) -> int {
+    const int Ra = n_act * K;
     int32_t* saved = m->tokens;
     m->tokens = buf[par];                           // the decoder step embeds the token at *pos of this history
     m->cur_map = par;
-    int rc = run_decoder_step(m, 0, R, batch, K, true, s);
+    int rc = run_decoder_step(m, 0, Ra, n_act, K, true, s);
     m->tokens = saved;
     if (rc) return rc;
     if (first && P == 1 && opts->no_speech >= 0)
-      WJ_TRY(launch_no_speech_prob(m->logits, m->ldl, R, m->d.n_vocab, opts->no_speech, m->nsp, s));
+      WJ_TRY(launch_no_speech_prob(m->logits, m->ldl, Ra, m->d.n_vocab, opts->no_speech, m->nsp, s));
     BeamArgs a;
     a.logits = m->logits; a.ldl = m->ldl; a.V = m->d.n_vocab; a.K = K;
     a.hist_in = buf[par]; a.hist_out = buf[par ^ 1]; a.tok_stride = m->tok_stride; a.pos_ptr = m->pos;
     a.sample_begin = P; a.max_new = max_new; a.max_candidates = max_candidates; a.opts = *opts;
     a.cand_ids = m->topk_ids; a.cand_lp = m->topk_lp; a.score = m->beam_score; a.parent = m->parent;
+    a.win_ids = compact_ok ? m->win_ids : nullptr;
     a.done = m->beam_done; a.n_done = m->beam_done + m->max_batch;
     a.fin_count = m->fin_count; a.fin_score = m->fin_score; a.fin_len = m->fin_len; a.fin_tokens = m->fin_tokens;
     a.fin_cap = kFinCap;
-    WJ_TRY(launch_beam_step(a, R, batch, s));
+    WJ_TRY(launch_beam_step(a, Ra, n_act, s));
     WJ_TRY(launch_advance_pos(m->pos, s));
-    WJ_TRY(launch_rebind_rows(m->row_map[par], m->row_map[par ^ 1], m->parent, m->pos, R, m->d.n_text_ctx, s));
+    WJ_TRY(launch_rebind_rows(m->row_map[par], m->row_map[par ^ 1], m->parent, m->pos, Ra, m->d.n_text_ctx, s));
     return WJ_OK;
   };
   // row maps: reset_decode_state initialised both to the identity; parity 0 reads map 0
@@ -1105,41 +1138,84 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
   hipGraphExec_t exec[2] = {nullptr, nullptr};
   const char* env = getenv("WJ_NO_GRAPH");
   bool use_graph = !(env && env[0] == '1') && !prof_on(m->ctx) && !(P == 1 && opts->no_speech >= 0);
-  for (int par = 0; par < 2 && use_graph; ++par) {
-    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess) {
-      int rc = iteration(par, false);
-      e = hipStreamEndCapture(s, &graph[par]);
-      if (rc || e != hipSuccess || graph[par] == nullptr) use_graph = false;
-      else if (hipGraphInstantiate(&exec[par], graph[par], nullptr, nullptr, 0) != hipSuccess) use_graph = false;
-    } else {
-      use_graph = false;
+  auto drop_graphs = [&]() {
+    for (int par = 0; par < 2; ++par) {
+      if (exec[par]) { (void)hipGraphExecDestroy(exec[par]); exec[par] = nullptr; }
+      if (graph[par]) { (void)hipGraphDestroy(graph[par]); graph[par] = nullptr; }
     }
-  }
-  if (!use_graph) (void)hipGetLastError();
+  };
+  auto capture_graphs = [&]() {
+    drop_graphs();
+    for (int par = 0; par < 2 && use_graph; ++par) {
+      hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        int rc = iteration(par, false);
+        e = hipStreamEndCapture(s, &graph[par]);
+        if (rc || e != hipSuccess || graph[par] == nullptr) use_graph = false;
+        else if (hipGraphInstantiate(&exec[par], graph[par], nullptr, nullptr, 0) != hipSuccess) use_graph = false;
+      } else {
+        use_graph = false;
+      }
+    }
+    if (!use_graph) { (void)hipGetLastError(); drop_graphs(); }
+  };
+  capture_graphs();
   m->last_used_graph = use_graph ? 1 : 0;
   m->last_chains = 1;
   int rc_loop = WJ_OK;
   m->last_steps = 0; m->last_max_new = max_new;
+  m->last_compactions = 0; m->last_window_steps = 0;
+  const int poll = std::max(1, g_tune.beam_poll);
+  std::vector<int32_t> done_host(m->max_batch + 1);
+  int par = 0;
   for (int i = 0; i < max_new && rc_loop == WJ_OK; ++i) {
-    const int par = i & 1;
     m->last_steps = i + 1;
+    m->last_window_steps += n_act;
     if (use_graph) {
       if (hipGraphLaunch(exec[par], s) != hipSuccess) { set_error("decode_beam: graph launch failed"); rc_loop = WJ_E_HIP; }
     } else {
       rc_loop = iteration(par, i == 0);
     }
-    if ((i & 7) == 7 && i + 1 < max_new && rc_loop == WJ_OK) {
-      int32_t nd = 0;
-      if (hipMemcpyAsync(&nd, m->beam_done + m->max_batch, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
-          hipStreamSynchronize(s) != hipSuccess) { set_error("decode_beam: done poll failed"); rc_loop = WJ_E_HIP; }
-      if (nd >= batch) break;
+    par ^= 1;                                       // the next iteration reads what this one wrote
+    if ((i % poll) == poll - 1 && i + 1 < max_new && rc_loop == WJ_OK) {
+      if (hipMemcpyAsync(done_host.data(), m->beam_done, sizeof(int32_t) * (m->max_batch + 1), hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess) { set_error("decode_beam: done poll failed"); rc_loop = WJ_E_HIP; break; }
+      if (done_host[m->max_batch] >= batch) break;
+      if (!compact_ok) continue;
+      int live = 0;
+      for (int w = 0; w < n_act; ++w) live += done_host[act_win[w]] == 0;
+      const int gone = n_act - live;
+      if (live == 0 || gone < std::max(1, g_tune.beam_compact_min) || gone * 100 < n_act * g_tune.beam_compact_pct) continue;
+      // ---- re-pack the live windows into logical windows 0 .. live-1 ------------------------------------------
+      std::vector<int32_t> src((size_t)live * K);
+      int nw = 0;
+      for (int w = 0; w < n_act; ++w) {
+        if (done_host[act_win[w]]) continue;
+        for (int b = 0; b < K; ++b) src[(size_t)nw * K + b] = w * K + b;
+        act_win[nw] = act_win[w]; act_slot[nw] = act_slot[w];
+        ++nw;
+      }
+      n_act = live;
+      // the current state sits in buf[par] / row_map[par] (what the next iteration reads): gather it into the other
+      // buffers and read from those instead
+      hipError_t e = hipMemcpyAsync(m->src_rows, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(m->slot_map, act_slot.data(), sizeof(int32_t) * n_act, hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(m->win_ids, act_win.data(), sizeof(int32_t) * n_act, hipMemcpyHostToDevice, s);
+      if (e != hipSuccess) { set_error("decode_beam: compaction upload failed: %s", hipGetErrorString(e)); rc_loop = WJ_E_HIP; break; }
+      rc_loop = launch_compact_rows(m->src_rows, n_act * K, m->row_map[par], m->row_map[par ^ 1], m->d.n_text_ctx, m->pos, buf[par],
+                                    buf[par ^ 1], m->tok_stride, m->beam_score, m->sum_lp, s);
+      if (rc_loop) break;
+      if (hipMemcpyAsync(m->beam_score, m->sum_lp, sizeof(float) * n_act * K, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess) { set_error("decode_beam: compaction failed"); rc_loop = WJ_E_HIP; break; }
+      par ^= 1;
+      ++m->last_compactions;
+      if (use_graph) {
+        capture_graphs();
+        if (!use_graph) m->last_used_graph = 0;
+      }
     }
   }
-  for (int par = 0; par < 2; ++par) {
-    if (exec[par]) (void)hipGraphExecDestroy(exec[par]);
-    if (graph[par]) (void)hipGraphDestroy(graph[par]);
-  }
+  drop_graphs();
   m->cur_map = 0;
   if (rc_loop) return rc_loop;
   // finished lists -> best hypothesis per window (score / len^length_penalty, first one wins ties)
@@ -1323,12 +1399,14 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
   return WJ_OK;
 }
 
-int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[4]) {
+int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[6]) {
   WJ_REQUIRE(m && out, "wj_whisper_last_decode_info: NULL argument");
   out[0] = m->last_used_graph;
   out[1] = m->last_chains;
   out[2] = m->last_steps;
   out[3] = m->last_max_new;
+  out[4] = m->last_compactions;
+  out[5] = (int32_t)std::min<int64_t>(m->last_window_steps, INT32_MAX);
   return WJ_OK;
 }
 

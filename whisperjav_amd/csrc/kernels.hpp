@@ -166,6 +166,8 @@ struct BeamArgs {
   float* cand_lp = nullptr;           // [R][16]
   float* score = nullptr;             // [R] cumulative log-prob of the live beams (-inf = dead)
   int32_t* parent = nullptr;          // [R] absolute parent row of next step's row
+  const int32_t* win_ids = nullptr;   // [B] or NULL: window id of logical window w in the per-window arrays below (the
+                                      // search compacts finished windows out of the batch; their lists stay where they were)
   int32_t* done = nullptr;            // [B]
   int32_t* n_done = nullptr;          // [1]
   int32_t* fin_count = nullptr;       // [B]
@@ -183,6 +185,10 @@ int launch_topk_rules(float* logits, int64_t ldl, int R, int V, int k, const wj_
                       float* logprobs, hipStream_t s);
 int launch_advance_pos(int* pos_ptr, hipStream_t s);
 // row_map update for beam search: new_map[r][0..pos-1] = old_map[parent[r]][..]; new_map[r][pos] = r
+// beam-search compaction: logical row r of the shrunk batch continues old logical row src_rows[r] (history, score, row map)
+int launch_compact_rows(const int32_t* src_rows, int R_new, const int32_t* old_map, int32_t* new_map, int map_stride,
+                        const int* pos_ptr, const int32_t* old_hist, int32_t* new_hist, int64_t tok_stride,
+                        const float* old_score, float* new_score, hipStream_t s);
 int launch_rebind_rows(const int32_t* old_map, int32_t* new_map, const int32_t* parent, const int* pos_ptr,
                        int R, int stride, hipStream_t s);
 

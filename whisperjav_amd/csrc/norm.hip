@@ -275,6 +275,31 @@ __global__ __launch_bounds__(256) void rebind_rows_kernel(const int32_t* __restr
   }
 }
 
+// Compaction of a beam-search batch (finished windows leave it): new logical row r takes over old logical row src[r].
+// Physical KV-cache rows never move -- the row map keeps pointing at them; from the current position on row r writes its
+// own physical row r, which no live history references at those positions (a cell (row, position) is written once).
+__global__ __launch_bounds__(256) void compact_rows_kernel(const int32_t* __restrict__ src_rows, const int32_t* __restrict__ old_map,
+                                                           int32_t* __restrict__ new_map, int map_stride,
+                                                           const int* __restrict__ pos_ptr, const int32_t* __restrict__ old_hist,
+                                                           int32_t* __restrict__ new_hist, int64_t tok_stride,
+                                                           const float* __restrict__ old_score, float* __restrict__ new_score) {
+  const int r = blockIdx.x, src = src_rows[r];
+  const int pos = *pos_ptr;
+  for (int j = threadIdx.x; j < map_stride; j += 256)
+    new_map[(int64_t)r * map_stride + j] = j < pos ? old_map[(int64_t)src * map_stride + j] : r;
+  for (int64_t j = threadIdx.x; j < tok_stride; j += 256) new_hist[(int64_t)r * tok_stride + j] = old_hist[(int64_t)src * tok_stride + j];
+  if (threadIdx.x == 0) new_score[r] = old_score[src];
+}
+
+int launch_compact_rows(const int32_t* src_rows, int R_new, const int32_t* old_map, int32_t* new_map, int map_stride,
+                        const int* pos_ptr, const int32_t* old_hist, int32_t* new_hist, int64_t tok_stride,
+                        const float* old_score, float* new_score, hipStream_t s) {
+  hipLaunchKernelGGL(compact_rows_kernel, dim3(R_new), dim3(256), 0, s, src_rows, old_map, new_map, map_stride, pos_ptr, old_hist,
+                     new_hist, tok_stride, old_score, new_score);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
 int launch_rebind_rows(const int32_t* old_map, int32_t* new_map, const int32_t* parent, const int* pos_ptr, int R,
                        int stride, hipStream_t s) {
   hipLaunchKernelGGL(rebind_rows_kernel, dim3(R), dim3(256), 0, s, old_map, new_map, parent, pos_ptr, stride);

@@ -703,10 +703,11 @@ __global__ __launch_bounds__(128) void beam_merge_kernel(const BeamArgs a) {
   __shared__ float fin_sc[8];
   __shared__ int s_counts[3];            // candidates, finished this step, sorted length
   const int w = blockIdx.x, tid = threadIdx.x;
+  const int ow = a.win_ids ? a.win_ids[w] : w;      // index into the per-window result arrays (done, finished lists)
   const int K = a.K, nc = 2 * K, eot = a.opts.eot;
   const int pos = *a.pos_ptr, len = pos + 1;
   const bool last_step = (len - a.sample_begin) == a.max_new - 1;
-  const bool done = a.done[w] != 0;
+  const bool done = a.done[ow] != 0;
   if (tid < K) old_score[tid] = a.score[w * K + tid];
   __syncthreads();
   // ---- candidates: beam-major, token order as the top-k kernel emitted them
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(128) void beam_merge_kernel(const BeamArgs a) {
   if (tid == 0) {
     const int n = s_counts[2];
     int secondary = K, nfin = 0, nn = 0;
-    int fcount = a.fin_count[w];
+    int fcount = a.fin_count[ow];
     if (!done) {
       for (int k = 0; k < (K < n ? K : n); ++k) {
         float sc = s_score[k]; int b = s_beam[k], t = s_tok[k];
@@ -768,8 +769,8 @@ __global__ __launch_bounds__(128) void beam_merge_kernel(const BeamArgs a) {
     }
     s_counts[1] = nfin;
     if (!done) {
-      a.fin_count[w] = fcount + nfin;
-      if (last_step || fcount + nfin >= a.max_candidates) { a.done[w] = 1; atomicAdd(a.n_done, 1); }
+      a.fin_count[ow] = fcount + nfin;
+      if (last_step || fcount + nfin >= a.max_candidates) { a.done[ow] = 1; atomicAdd(a.n_done, 1); }
     }
   }
   __syncthreads();
@@ -779,14 +780,14 @@ __global__ __launch_bounds__(128) void beam_merge_kernel(const BeamArgs a) {
     const int slot = fin_slot[f];
     if (slot >= a.fin_cap) continue;                                   // cannot happen: cap = max_candidates + K
     const int32_t* src = a.hist_in + (int64_t)(w * K + fin_b[f]) * a.tok_stride + a.sample_begin;
-    int32_t* dst = a.fin_tokens + ((int64_t)w * a.fin_cap + slot) * a.tok_stride;
+    int32_t* dst = a.fin_tokens + ((int64_t)ow * a.fin_cap + slot) * a.tok_stride;
     const int ng = len - a.sample_begin;
     for (int j = tid; j < ng; j += 128) dst[j] = src[j];
     if (tid == 0) {
       int n = ng;
       if (fin_tok[f] >= 0) dst[n++] = fin_tok[f];
-      a.fin_len[(int64_t)w * a.fin_cap + slot] = n;
-      a.fin_score[(int64_t)w * a.fin_cap + slot] = fin_sc[f];
+      a.fin_len[(int64_t)ow * a.fin_cap + slot] = n;
+      a.fin_score[(int64_t)ow * a.fin_cap + slot] = fin_sc[f];
     }
   }
   // ---- survivors: history gather + new token, scores, parents

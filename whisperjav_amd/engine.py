@@ -318,9 +318,10 @@ class HipWhisper:
         return out
 
     def last_decode_info(self) -> dict:
-        out = (C.c_int32 * 4)()
+        out = (C.c_int32 * 6)()
         check(self._lib.wj_whisper_last_decode_info(self.handle, out), "wj_whisper_last_decode_info")
-        return {"hip_graph": bool(out[0]), "chains": int(out[1]), "steps": int(out[2]), "max_new_tokens": int(out[3])}
+        return {"hip_graph": bool(out[0]), "chains": int(out[1]), "steps": int(out[2]), "max_new_tokens": int(out[3]),
+                "compactions": int(out[4]), "window_steps": int(out[5])}
 
     def sot_prompt(self, language: str = "ja", task: str = "transcribe", without_timestamps: bool = False) -> List[int]:
         from .dims import language_index

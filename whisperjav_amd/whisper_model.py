@@ -302,6 +302,7 @@ class HipWhisperModel:
         self.seed = 0               # base seed of the device sampler's counter-based generator
         self.device_beam = True     # beam search on the device (False: host-driven search.py over the step API)
         self._sample_calls = 0
+        self.bucket_by_length = True     # transcribe_many: batches are formed from windows of similar content length
 
     # ---- loading ---------------------------------------------------------------------------
     def _load_checkpoint(self, path: str):
@@ -412,9 +413,40 @@ class HipWhisperModel:
             return sum_lp / (n if lp is None else ((5 + n) / 6) ** float(lp))
         return sum_lp / (n ** float(1.0 if lp is None else lp))
 
+    def reset_decode_stats(self) -> None:
+        """Counters over the decode calls since the last reset (bench.py reports them: realised tokens per window,
+        decode iterations actually run -- searches end at EOT -- against the iterations allowed)."""
+        self.decode_stats = {"calls": 0, "windows": 0, "tokens": 0, "max_tokens": 0, "steps_run": 0, "steps_allowed": 0,
+                             "window_steps_run": 0, "at_length_limit": 0}
+
+    def _count_decode(self, decoded, max_new: int) -> None:
+        st = getattr(self, "decode_stats", None)
+        if st is None:
+            return
+        lens = [len(t) for t, _, _ in decoded]
+        st["calls"] += 1
+        st["windows"] += len(lens)
+        st["tokens"] += int(sum(lens))
+        st["max_tokens"] = max(st["max_tokens"], max(lens) if lens else 0)
+        st["at_length_limit"] += sum(1 for n in lens if n >= max_new)
+        try:
+            info = self.model.last_decode_info()
+            st["steps_run"] += info["steps"]
+            st["steps_allowed"] += info["max_new_tokens"]
+            st["window_steps_run"] += info["window_steps"]
+            st["compactions"] = st.get("compactions", 0) + info["compactions"]
+        except Exception:
+            pass
+
     def _decode_once(self, prompts: List[List[int]], slots: List[int], temperature: float, o: TranscribeOptions,
                      suppress: Tuple[int, ...]) -> List[Tuple[List[int], float, float]]:
         """One rung of the ladder for the resident windows ``slots``: (tokens, avg_logprob, no_speech_prob) each."""
+        out = self._decode_once_impl(prompts, slots, temperature, o, suppress)
+        self._count_decode(out, self._max_new(o, len(prompts[0])))
+        return out
+
+    def _decode_once_impl(self, prompts: List[List[int]], slots: List[int], temperature: float, o: TranscribeOptions,
+                          suppress: Tuple[int, ...]) -> List[Tuple[List[int], float, float]]:
         from . import engine, search
         P = len(prompts[0])
         max_new = self._max_new(o, P)
@@ -454,8 +486,8 @@ class HipWhisperModel:
         if not identity and not (device_loop or device_beam):
             # host-driven search over the step API addresses windows 0..n-1 only: decode the resident prefix, keep ours
             hi = max(slots) + 1
-            full = self._decode_once([prompts[slots.index(i)] if i in slots else prompts[0] for i in range(hi)],
-                                     list(range(hi)), temperature, o, suppress)
+            full = self._decode_once_impl([prompts[slots.index(i)] if i in slots else prompts[0] for i in range(hi)],
+                                          list(range(hi)), temperature, o, suppress)
             return [full[i] for i in slots]
         out = []
         if device_beam:
@@ -800,6 +832,12 @@ class HipWhisperModel:
             active = [st for st in states if st.active]
             if not active:
                 break
+            if self.bucket_by_length and len(active) > self.max_batch:
+                # length bucketing: windows holding similar amounts of audio decode together.  A search ends when its
+                # window's text does, the number of tokens grows with the audio in the window, and a batch runs until its
+                # slowest window is done -- so batches of similar windows end together instead of idling behind a few long
+                # ones (results are stored per clip: the order of the work does not show in the output)
+                active.sort(key=lambda st: -min(N_FRAMES, st.n_frames_content - st.seek))
             # full batches + a tail.  Even batches were measured and are slower (120-min recording, 1544 windows: 5 x 309
             # = 13.47 s against 4 x 384 + 8 = 13.03 s): 384 windows x 5 beams = 1920 rows fill the 128-row GEMM tiles
             # exactly, and the per-step fixed costs are paid on fewer full-size steps
