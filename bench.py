@@ -228,8 +228,11 @@ def transcribe_kwargs(args, words):
 def build_stack(args, info, dims, dtype, batch, blob=None, offsets=None, weights=None, words=False):
     from whisperjav_amd import asr, pipeline, scenes, segmenters
     from whisperjav_amd.whisper_model import HipWhisperModel
+    # KV cache sized for what this run decodes (sot sequence + max_new_tokens; no conditioning on previous text), the
+    # encoder in slices of --enc-batch windows: HBM goes to resident cross K/V, i.e. to windows per engine call
     model = HipWhisperModel(args.model, compute_type=dtype, weights=weights, dims=dims, blob=blob, offsets=offsets,
-                            max_batch=batch, max_beam=args.beam, device_index=info.local_rank)
+                            max_batch=batch, max_beam=args.beam, device_index=info.local_rank,
+                            kv_len=(4 + args.max_new_tokens + 4) if args.kv_fit else None, enc_batch=min(batch, args.enc_batch))
     kw = transcribe_kwargs(args, words)
     params = {"decoder": {k: v for k, v in kw.items() if k not in ("repetition_penalty", "no_repeat_ngram_size", "max_new_tokens")},
               "provider": {"repetition_penalty": kw["repetition_penalty"], "no_repeat_ngram_size": kw["no_repeat_ngram_size"],
@@ -621,7 +624,11 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
     ap.add_argument("--minutes", type=float, default=120.0, help="cfg3: length of the synthetic recording")
     ap.add_argument("--strong", action="store_true", help="cfg3 with --gpus N: ONE recording, scenes LPT-sharded over the ranks (cfg4)")
-    ap.add_argument("--batch", type=int, default=384, help="30 s windows resident per GPU (384: cross K/V of a batch = 94 GB)")
+    ap.add_argument("--batch", type=int, default=768, help="30 s windows resident per GPU per engine call (768: cross K/V = 189 GB, "
+                    "self-attention KV cache sized for max_new_tokens = 46 GB, encoder slices of --enc-batch windows; 238 GiB in all)")
+    ap.add_argument("--enc-batch", type=int, default=384, help="windows per encoder slice (bounds the encoder workspaces)")
+    ap.add_argument("--no-kv-fit", dest="kv_fit", action="store_false",
+                    help="size the self-attention KV cache for n_text_ctx positions instead of prompt + max_new_tokens")
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--max-new-tokens", type=int, default=64, help="cfg3: transcribe(max_new_tokens=...); swept 32/64/224 in profiles/")
     ap.add_argument("--vad-threshold", type=float, default=0.28, help="BASELINE.md section 3 (balanced preset)")
@@ -660,6 +667,9 @@ def main():
         for kv in args.tune:
             k, v = kv.split("=")
             hipbind.tune(k, int(v))
+    if not args.kv_fit and args.batch > 384:
+        log("[bench] --no-kv-fit: a 448-position KV cache leaves room for 384 windows per call")
+        args.batch = 384
     dims = pdims.dims_for(args.model)
     return run_cfg3(args, info, dims) if args.workload == "cfg3" else run_cfg2(args, info, dims)
 

@@ -250,6 +250,37 @@ def test_batch_compaction_is_transparent(hip, dtype):
     model.close()
 
 
+def test_short_kv_cache_and_encoder_slices_change_nothing(hip):
+    """``HipWhisper(kv_len=..., enc_batch=...)``: a KV cache sized for prompt + max_new_tokens and an encoder run in slices
+    give bit-identical encoder outputs and the same hypotheses as the full-size engine; a decode that does not fit the
+    cache is refused."""
+    from whisperjav_amd import engine, hipbind, synth, weights as pweights
+    d = helpers.small_dims(**SMALL)
+    w = pweights.synth_weights(d, seed=33, **pweights.SPEECHLIKE)
+    clips = [synth.speech_like(CLIP_SECONDS[i], seed=19 + i) for i in range(7)]
+    mel = engine.HipLogMel(d.n_mels, "fw")(clips)
+    full = engine.HipWhisper(d, w, dtype="float16", max_batch=7, max_beam=5)
+    small = engine.HipWhisper(d, w, dtype="float16", max_batch=7, max_beam=5, kv_len=3 + 40, enc_batch=3)
+    assert small.kv_len == 48 and small.enc_batch == 3 and small.workspace_bytes < full.workspace_bytes
+    e1 = full.encode(mel, want_output=True)
+    e2 = small.encode(mel, want_output=True)                    # slices of 3 + 3 + 1 windows
+    assert torch.equal(e1, e2)
+    toks = full.tokens
+    prompt = np.tile(np.array(full.sot_prompt("ja", "transcribe"), dtype=np.int32), (7, 1))
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    dopt = engine.DecodeOptions(max_new_tokens=40, suppress_tokens=suppress, max_initial_timestamp=0.0, repetition_penalty=1.5,
+                                no_repeat_ngram_size=3)
+    a = full.decode_beam(prompt, dopt, beam_size=5, patience=1.2)
+    b = small.decode_beam(prompt, dopt, beam_size=5, patience=1.2)
+    assert np.array_equal(a.tokens, b.tokens) and np.array_equal(a.n_tokens, b.n_tokens)
+    assert np.array_equal(a.sum_logprob, b.sum_logprob)
+    ga, gb = full.decode_greedy(prompt, dopt), small.decode_greedy(prompt, dopt)
+    assert np.array_equal(ga.tokens, gb.tokens) and np.array_equal(ga.token_logprob, gb.token_logprob)
+    with pytest.raises(hipbind.WjError, match="KV cache"):
+        small.decode_beam(prompt, engine.DecodeOptions(max_new_tokens=60), beam_size=5)
+    full.close(); small.close()
+
+
 @pytest.mark.parametrize("dtype", ["float32", "float16"])
 def test_golden_large_v3_r3_searches_that_end(hip, dtype):
     """Large-v3 geometry, fp16-representable ``SPEECHLIKE`` weights, two windows (a 6 s and a 2.5 s clip): greedy until

@@ -106,6 +106,10 @@ struct Tunables {
                             // 1 = the residual-writing GEMMs (attention out-projections, fc2) and the logits GEMM,
                             // 2 = every decode GEMM, 0 = none
   int dec_adapt_ks = 1;     // halve the split-K factors while the row tiles alone keep >= 256 workgroups busy
+  int self_kv_len = 0;      // positions of the self-attention KV cache per row (read at create; 0 = n_text_ctx).  The cache is
+                            // [L][rows][H][positions][64] x 2: 141 GB at 1920 rows x 448 positions, 22 GB at 70 -- a caller that
+                            // knows its prompt + max_new_tokens buys batch size with it
+  int enc_batch = 0;        // windows per encoder slice (read at create; 0 = max_batch): bounds the encoder workspaces
   int beam_compact = 1;     // device beam search: windows whose search has ended leave the batch at the next poll (the step's cost
                             // is proportional to the live windows: cross attention reads their K/V, the GEMMs their rows)
   int beam_poll = 4;        // decode iterations between two polls of the per-window done flags
@@ -123,6 +127,8 @@ struct wj_whisper {
   const char* blob = nullptr;
   std::vector<int64_t> off;
   int max_batch = 0, max_rows = 0;
+  int enc_batch = 0; // windows the encoder workspaces hold: wj_whisper_encode runs larger batches in slices of this size
+  int kv_len = 0;    // positions of the self-attention KV cache per row (<= n_text_ctx; wj_tune "self_kv_len" at create)
   int Tpad = 0;      // encoder positions padded to a multiple of 128
   int frames = 0;    // 2 * n_audio_ctx
   std::vector<void*> allocs;
@@ -156,7 +162,7 @@ struct wj_whisper {
   float* partial = nullptr;   // f32 [R][KS_MAX][d] split-K slabs of the decode GEMMs (per row slice)
   float* logits = nullptr;    // f32 [R][ldl]
   int64_t ldl = 0;
-  void* self_k = nullptr;     // T   [L][max_rows][H][n_text_ctx][64]
+  void* self_k = nullptr;     // T   [L][max_rows][H][kv_len][64]
   void* self_v = nullptr;
   int32_t* tokens = nullptr;  // [max_rows][tok_stride]
   int64_t tok_stride = 0;
@@ -165,7 +171,7 @@ struct wj_whisper {
   float* tok_lp = nullptr;    // [R][tok_stride]
   int32_t* finished = nullptr;
   float* nsp = nullptr;       // [R] no-speech probability
-  int32_t* row_map[2] = {nullptr, nullptr};  // [max_rows][n_text_ctx]
+  int32_t* row_map[2] = {nullptr, nullptr};  // [max_rows][kv_len]
   int cur_map = 0;
   int32_t* parent = nullptr;  // [R]
   int32_t* step_tok = nullptr;  // [R] staging for wj_decode_step
@@ -205,7 +211,7 @@ struct wj_whisper {
   int64_t cross_v_layer_elems() const {
     return (int64_t)max_batch * d.n_text_head * 64 * (cross_tpad > 0 ? cross_tpad : d.n_audio_ctx);
   }
-  int64_t self_layer_elems() const { return (int64_t)max_rows * d.n_text_head * d.n_text_ctx * 64; }
+  int64_t self_layer_elems() const { return (int64_t)max_rows * d.n_text_head * kv_len * 64; }
   void* at(void* base, int64_t elems) const { return reinterpret_cast<char*>(base) + elems * (int64_t)esz; }
 };
 
@@ -231,7 +237,7 @@ static int dev_alloc(wj_whisper* m, void** p, size_t bytes, bool zero) {
 // ------------------------------------------------------------------------------------------------
 // encoder
 // ------------------------------------------------------------------------------------------------
-static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, float* enc_out, hipStream_t s) {
+static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, float* enc_out, hipStream_t s, int win0 = 0) {
   const wj_whisper_dims& d = m->d;
   const int D = d.n_audio_state, H = d.n_audio_head, C = d.n_mels, T = d.n_audio_ctx, F = m->frames;
   const int dt = m->dtype;
@@ -304,8 +310,10 @@ static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, flo
     g.A = m->h; g.lda = D; g.a_batch = (int64_t)T * D;
     g.W = m->W(b0 + WJ_TD_CKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CKV_B);
     g.M = T; g.N = 2 * D; g.K = D; g.nbatch = B;
-    g.out = m->at(m->cross_k, l * m->cross_layer_elems());
-    g.out2 = m->at(m->cross_v, l * m->cross_v_layer_elems());
+    // the slice's windows land at window slots win0 .. win0 + B - 1 of the resident cross K/V
+    const int64_t kwin = (int64_t)d.n_text_head * T * 64, vwin = (int64_t)d.n_text_head * 64 * (m->cross_tpad > 0 ? m->cross_tpad : T);
+    g.out = m->at(m->cross_k, l * m->cross_layer_elems() + win0 * kwin);
+    g.out2 = m->at(m->cross_v, l * m->cross_v_layer_elems() + win0 * vwin);
     g.D = D; g.H = d.n_text_head; g.Tpad = T;
     if (m->cross_tpad > 0) {   // K head-split as stored; V transposed per head for the MFMA cross attention
       GemmArgs v = g;
@@ -313,7 +321,7 @@ static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, flo
       PROF(PT_E_CKV, launch_gemm(dt, EPI_QK_HEADS, g, s, 1));
       v.W = reinterpret_cast<const char*>(m->W(b0 + WJ_TD_CKV_W)) + (int64_t)D * D * m->esz;
       v.bias = m->F(b0 + WJ_TD_CKV_B) + D;
-      v.N = D; v.out = m->at(m->cross_v, l * m->cross_v_layer_elems()); v.out2 = nullptr;
+      v.N = D; v.out = m->at(m->cross_v, l * m->cross_v_layer_elems() + win0 * vwin); v.out2 = nullptr;
       v.Tpad = m->cross_tpad;
       PROF(PT_E_CKV, launch_gemm(dt, EPI_VT, v, s, 1));
       continue;
@@ -347,7 +355,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   void* dq = m->at(m->dq, (int64_t)row0 * D);
   void* dattn = m->at(m->dattn, (int64_t)row0 * D * sm);
   void* dff = m->at(m->dff, (int64_t)row0 * 4 * D * sm);
-  const int64_t self_row = (int64_t)H * d.n_text_ctx * 64;      // cache elements per row
+  const int64_t self_row = (int64_t)H * m->kv_len * 64;         // cache elements per row
   const int64_t cross_win = (int64_t)H * d.n_audio_ctx * 64;    // cross K (or V) elements per window
   // Residual-writing GEMMs (attention out-projections, fc2) can run split-K: each K slice writes a raw fp32
   // slab and the LayerNorm that always follows folds  x += bias + sum(slabs)  in a fixed order (deterministic).
@@ -445,15 +453,15 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       g.A = dh; g.lda = (int64_t)D * psm; g.split = psplit; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
       g.M = R; g.N = 3 * D; g.K = D; g.out = dq;
       g.out2 = m->at(sk, row0 * self_row); g.out3 = m->at(sv, row0 * self_row);
-      g.D = D; g.H = H; g.pos_ptr = pos; g.cache_len = d.n_text_ctx;
+      g.D = D; g.H = H; g.pos_ptr = pos; g.cache_len = m->kv_len;
       WJ_TRY(proj_gemm(PT_D_QKV, EPI_QKV_DEC, g, &qkv_slices));
       qkv_bias = g.bias;
     }
     {
       DecAttnArgs a;   // K/V bases stay absolute: the row map holds absolute physical rows
       a.q = dq; a.K = sk; a.V = sv; a.out = dattn; a.out_split = split; a.G = R; a.nb = 1; a.H = H;
-      a.n_keys_ptr = pos; a.kv_stride = d.n_text_ctx;
-      a.row_map = m->row_map[m->cur_map] + (int64_t)row0 * d.n_text_ctx;
+      a.n_keys_ptr = pos; a.kv_stride = m->kv_len;
+      a.row_map = m->row_map[m->cur_map] + (int64_t)row0 * m->kv_len;      // the map's row stride IS the cache's (kernel contract)
       if (qkv_slices) {   // the attention kernel sums the K-slices, appends k/v to the cache and attends
         a.slab = slab; a.slab_bias = qkv_bias; a.slab_ks = qkv_slices; a.slab_rows = R; a.slab_ld = 3 * D; a.row_base = row0;
       }
@@ -533,12 +541,12 @@ static int run_decoder_seq(wj_whisper* m, int B, int Tp, int n0, const int32_t* 
       GemmArgs g;
       g.A = h; g.lda = D; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
       g.M = M; g.N = 3 * D; g.K = D; g.out = q; g.out2 = sk; g.out3 = sv;
-      g.D = D; g.H = H; g.cache_len = d.n_text_ctx; g.seq_tp = Tp;
+      g.D = D; g.H = H; g.cache_len = m->kv_len; g.seq_tp = Tp;
       WJ_TRY(launch_gemm(dt, EPI_QKV_DEC, g, s));
     }
     {
       DecAttnArgs a;
-      a.q = q; a.K = sk; a.V = sv; a.out = attn; a.G = M; a.nb = 1; a.H = H; a.kv_stride = d.n_text_ctx; a.seq_tp = Tp;
+      a.q = q; a.K = sk; a.V = sv; a.out = attn; a.G = M; a.nb = 1; a.H = H; a.kv_stride = m->kv_len; a.seq_tp = Tp;
       WJ_TRY(launch_attention_dec(dt, a, s));
     }
     {
@@ -622,7 +630,7 @@ static int reset_decode_state(wj_whisper* m, int R, hipStream_t s) {
   WJ_HIP(hipMemsetAsync(m->sum_lp, 0, sizeof(float) * R, s));
   WJ_HIP(hipMemsetAsync(m->finished, 0, sizeof(int32_t) * R, s));
   WJ_HIP(hipMemsetAsync(m->tok_lp, 0, sizeof(float) * (size_t)R * m->tok_stride, s));
-  hipLaunchKernelGGL(init_rows_kernel, dim3(R), dim3(256), 0, s, m->row_map[0], m->row_map[1], R, m->d.n_text_ctx);
+  hipLaunchKernelGGL(init_rows_kernel, dim3(R), dim3(256), 0, s, m->row_map[0], m->row_map[1], R, m->kv_len);
   WJ_LAUNCH_CHECK();
   m->cur_map = 0;
   return WJ_OK;
@@ -734,6 +742,8 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_split_act")) g_tune.dec_split_act = value;
   else if (!strcmp(key, "dec_adapt_ks")) g_tune.dec_adapt_ks = value;
   else if (!strcmp(key, "dec_big_min_m")) g_tune.dec_big_min_m = value;
+  else if (!strcmp(key, "self_kv_len")) g_tune.self_kv_len = value;
+  else if (!strcmp(key, "enc_batch")) g_tune.enc_batch = value;
   else if (!strcmp(key, "beam_compact")) g_tune.beam_compact = value;
   else if (!strcmp(key, "beam_poll")) g_tune.beam_poll = value;
   else if (!strcmp(key, "beam_compact_pct")) g_tune.beam_compact_pct = value;
@@ -809,18 +819,21 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   m->max_rows = max_rows;
   m->Tpad = (d.n_audio_ctx + 127) / 128 * 128;
   m->frames = 2 * d.n_audio_ctx;
+  m->kv_len = (g_tune.self_kv_len > 0 && g_tune.self_kv_len < d.n_text_ctx) ? (g_tune.self_kv_len + 7) / 8 * 8 : d.n_text_ctx;
+  if (m->kv_len > d.n_text_ctx) m->kv_len = d.n_text_ctx;
+  m->enc_batch = (g_tune.enc_batch > 0 && g_tune.enc_batch < max_batch) ? g_tune.enc_batch : max_batch;
   const size_t e = m->esz;
   const int D = d.n_audio_state, H = d.n_audio_head, T = d.n_audio_ctx, F = m->frames;
-  const size_t B = max_batch, R = max_rows;
-  WJ_ALLOC(mel_rows, B * (F + 2) * d.n_mels * e, true);
-  WJ_ALLOC(conv1_out, B * (F + 2) * D * e, true);
-  WJ_ALLOC(x, B * T * D * sizeof(float), false);
-  WJ_ALLOC(h, B * T * D * e, false);
-  WJ_ALLOC(q, B * H * m->Tpad * 64 * e, true);
-  WJ_ALLOC(k, B * H * m->Tpad * 64 * e, true);
-  WJ_ALLOC(vt, B * H * 64 * m->Tpad * e, true);
-  WJ_ALLOC(attn, B * T * D * e, false);
-  WJ_ALLOC(ff, B * T * 4 * D * e, false);
+  const size_t B = max_batch, R = max_rows, EB = m->enc_batch;
+  WJ_ALLOC(mel_rows, EB * (F + 2) * d.n_mels * e, true);
+  WJ_ALLOC(conv1_out, EB * (F + 2) * D * e, true);
+  WJ_ALLOC(x, EB * T * D * sizeof(float), false);
+  WJ_ALLOC(h, EB * T * D * e, false);
+  WJ_ALLOC(q, EB * H * m->Tpad * 64 * e, true);
+  WJ_ALLOC(k, EB * H * m->Tpad * 64 * e, true);
+  WJ_ALLOC(vt, EB * H * 64 * m->Tpad * e, true);
+  WJ_ALLOC(attn, EB * T * D * e, false);
+  WJ_ALLOC(ff, EB * T * 4 * D * e, false);
   WJ_ALLOC(cross_k, (size_t)d.n_text_layer * m->cross_layer_elems() * e, false);
   m->cross_tpad = (is16(dtype) && g_tune.dec_cross_mfma) ? (d.n_audio_ctx + 31) / 32 * 32 : 0;
   WJ_ALLOC(cross_v, (size_t)d.n_text_layer * m->cross_v_layer_elems() * e, true);   // pad keys stay zero forever
@@ -844,8 +857,8 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   WJ_ALLOC(tok_lp, R * m->tok_stride * sizeof(float), true);
   WJ_ALLOC(finished, R * sizeof(int32_t), true);
   WJ_ALLOC(nsp, R * sizeof(float), true);
-  WJ_ALLOC(row_map[0], R * d.n_text_ctx * sizeof(int32_t), true);
-  WJ_ALLOC(row_map[1], R * d.n_text_ctx * sizeof(int32_t), true);
+  WJ_ALLOC(row_map[0], R * m->kv_len * sizeof(int32_t), true);
+  WJ_ALLOC(row_map[1], R * m->kv_len * sizeof(int32_t), true);
   WJ_ALLOC(parent, R * sizeof(int32_t), true);
   WJ_ALLOC(step_tok, R * sizeof(int32_t), true);
   WJ_ALLOC(slot_map, B * sizeof(int32_t), true);
@@ -879,7 +892,13 @@ int wj_whisper_encode(wj_whisper* m, const float* mel_dev, int batch, int n_laye
   WJ_REQUIRE(batch >= 1 && batch <= m->max_batch, "wj_whisper_encode: batch %d outside 1..%d", batch, m->max_batch);
   WJ_REQUIRE(n_layers <= m->d.n_audio_layer, "wj_whisper_encode: n_layers too large");
   WJ_HIP(hipSetDevice(m->ctx->device));
-  return run_encoder(m, mel_dev, batch, n_layers, enc_out_dev, m->ctx->pick(stream));
+  hipStream_t s = m->ctx->pick(stream);
+  const int64_t mel_win = (int64_t)m->d.n_mels * m->frames, out_win = (int64_t)m->d.n_audio_ctx * m->d.n_audio_state;
+  for (int w0 = 0; w0 < batch; w0 += m->enc_batch) {      // slices of the encoder workspaces; cross K/V of all windows stays resident
+    const int bc = std::min(m->enc_batch, batch - w0);
+    WJ_TRY(run_encoder(m, mel_dev + w0 * mel_win, bc, n_layers, enc_out_dev ? enc_out_dev + w0 * out_win : nullptr, s, w0));
+  }
+  return WJ_OK;
 }
 
 int wj_whisper_decode_greedy(wj_whisper* m, int batch, const int32_t* prompts_host, int prompt_len,
@@ -903,8 +922,9 @@ int wj_whisper_decode_sample(wj_whisper* m, int batch, int group, const int32_t*
     for (int i = 0; i < batch; ++i)
       WJ_REQUIRE(slots_host[i] >= 0 && slots_host[i] < m->max_batch, "decode: window slot %d out of range", slots_host[i]);
   const int max_new = opts->max_new_tokens;
-  WJ_REQUIRE(prompt_len >= 1 && max_new >= 1 && prompt_len + max_new <= m->d.n_text_ctx,
-             "decode_greedy: prompt_len %d + max_new_tokens %d exceeds n_text_ctx %d", prompt_len, max_new, m->d.n_text_ctx);
+  WJ_REQUIRE(prompt_len >= 1 && max_new >= 1 && prompt_len + max_new <= m->kv_len,
+             "decode_greedy: prompt_len %d + max_new_tokens %d exceeds the %d positions of the KV cache (n_text_ctx %d, self_kv_len at create)",
+             prompt_len, max_new, m->kv_len, m->d.n_text_ctx);
   WJ_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->pick(stream);
   const int R = batch * group;   // row r belongs to window r / group
@@ -1059,8 +1079,9 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
              "decode_beam: batch %d x beam %d does not fit (max_batch %d, max_rows %d; beam 1..6 or 8)", batch, beam,
              m->max_batch, m->max_rows);
   const int max_new = opts->max_new_tokens, K = beam, R = batch * beam, P = prompt_len;
-  WJ_REQUIRE(P >= 1 && max_new >= 1 && P + max_new <= m->d.n_text_ctx, "decode_beam: prompt_len %d + max_new_tokens %d exceeds n_text_ctx %d",
-             P, max_new, m->d.n_text_ctx);
+  WJ_REQUIRE(P >= 1 && max_new >= 1 && P + max_new <= m->kv_len,
+             "decode_beam: prompt_len %d + max_new_tokens %d exceeds the %d positions of the KV cache (n_text_ctx %d, self_kv_len at create)",
+             P, max_new, m->kv_len, m->d.n_text_ctx);
   WJ_REQUIRE(patience > 0.f, "decode_beam: patience must be positive");
   const int max_candidates = (int)lroundf(K * patience);
   WJ_REQUIRE(max_candidates >= 1 && max_candidates + K <= kFinCap, "decode_beam: beam %d x patience %g needs %d finished slots (max %d)",
@@ -1130,7 +1151,7 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
     a.fin_cap = kFinCap;
     WJ_TRY(launch_beam_step(a, Ra, n_act, s));
     WJ_TRY(launch_advance_pos(m->pos, s));
-    WJ_TRY(launch_rebind_rows(m->row_map[par], m->row_map[par ^ 1], m->parent, m->pos, Ra, m->d.n_text_ctx, s));
+    WJ_TRY(launch_rebind_rows(m->row_map[par], m->row_map[par ^ 1], m->parent, m->pos, Ra, m->kv_len, s));
     return WJ_OK;
   };
   // row maps: reset_decode_state initialised both to the identity; parity 0 reads map 0
@@ -1202,7 +1223,7 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
       if (e == hipSuccess) e = hipMemcpyAsync(m->slot_map, act_slot.data(), sizeof(int32_t) * n_act, hipMemcpyHostToDevice, s);
       if (e == hipSuccess) e = hipMemcpyAsync(m->win_ids, act_win.data(), sizeof(int32_t) * n_act, hipMemcpyHostToDevice, s);
       if (e != hipSuccess) { set_error("decode_beam: compaction upload failed: %s", hipGetErrorString(e)); rc_loop = WJ_E_HIP; break; }
-      rc_loop = launch_compact_rows(m->src_rows, n_act * K, m->row_map[par], m->row_map[par ^ 1], m->d.n_text_ctx, m->pos, buf[par],
+      rc_loop = launch_compact_rows(m->src_rows, n_act * K, m->row_map[par], m->row_map[par ^ 1], m->kv_len, m->pos, buf[par],
                                     buf[par ^ 1], m->tok_stride, m->beam_score, m->sum_lp, s);
       if (rc_loop) break;
       if (hipMemcpyAsync(m->beam_score, m->sum_lp, sizeof(float) * n_act * K, hipMemcpyDeviceToDevice, s) != hipSuccess ||
@@ -1266,14 +1287,14 @@ int wj_decode_open(wj_whisper* m, int batch, int beam, void* stream) {
 int wj_decode_step(wj_whisper* m, const int32_t* tokens_host, const int32_t* parent_host, int want_logits, void* stream) {
   WJ_REQUIRE(m && tokens_host, "wj_decode_step: NULL argument");
   WJ_REQUIRE(m->open_rows > 0, "wj_decode_step: call wj_decode_open first");
-  WJ_REQUIRE(m->host_pos < m->d.n_text_ctx, "wj_decode_step: context of %d tokens exhausted", m->d.n_text_ctx);
+  WJ_REQUIRE(m->host_pos < m->kv_len, "wj_decode_step: context of %d tokens exhausted", m->kv_len);
   WJ_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->pick(stream);
   const int R = m->open_rows;
   WJ_HIP(hipMemcpyAsync(m->step_tok, tokens_host, sizeof(int32_t) * R, hipMemcpyHostToDevice, s));
   if (parent_host) {
     WJ_HIP(hipMemcpyAsync(m->parent, parent_host, sizeof(int32_t) * R, hipMemcpyHostToDevice, s));
-    WJ_TRY(launch_rebind_rows(m->row_map[m->cur_map], m->row_map[m->cur_map ^ 1], m->parent, m->pos, R, m->d.n_text_ctx, s));
+    WJ_TRY(launch_rebind_rows(m->row_map[m->cur_map], m->row_map[m->cur_map ^ 1], m->parent, m->pos, R, m->kv_len, s));
     m->cur_map ^= 1;
   }
   hipLaunchKernelGGL(put_tokens_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, s, m->tokens, m->tok_stride, m->pos, m->step_tok, R);
@@ -1299,11 +1320,12 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
   const wj_whisper_dims& d = m->d;
   const int L = d.n_text_layer, H = d.n_text_head, nctx = d.n_audio_ctx, n0 = n_prefix - 1;
   WJ_REQUIRE(batch >= 1 && batch <= m->max_batch && batch <= m->max_rows, "align: batch %d outside 1..%d", batch, m->max_batch);
-  WJ_REQUIRE(n_tokens_max >= n_prefix + 1 && n_tokens_max <= d.n_text_ctx, "align: %d tokens per window outside %d..%d",
-             n_tokens_max, n_prefix + 1, d.n_text_ctx);
+  WJ_REQUIRE(n_tokens_max >= n_prefix + 1 && n_tokens_max <= m->kv_len, "align: %d tokens per window outside %d..%d",
+             n_tokens_max, n_prefix + 1, m->kv_len);
   // full-sequence pass: positions padded to a multiple of 16 (the cross-attention kernels take 16 / 8 query rows
   // of a window per workgroup); needs the sequence to fit the encoder workspaces
-  const bool prefill = g_tune.align_prefill && (n_tokens_max + 15) / 16 * 16 <= 512 && (n_tokens_max + 15) / 16 * 16 <= d.n_audio_ctx;
+  const bool prefill = g_tune.align_prefill && (n_tokens_max + 15) / 16 * 16 <= 512 && (n_tokens_max + 15) / 16 * 16 <= d.n_audio_ctx &&
+                       (int64_t)batch * ((n_tokens_max + 15) / 16 * 16) <= (int64_t)m->enc_batch * d.n_audio_ctx;
   const int T = prefill ? (n_tokens_max + 15) / 16 * 16 : n_tokens_max;     // rows of the score / matrix buffers per window
   WJ_REQUIRE(n_prefix >= 2 && n_heads >= 1 && n_heads <= L * H, "align: bad prefix length / head count");
   WJ_REQUIRE(eot > 0 && eot <= d.n_vocab, "align: eot id out of range");

@@ -113,7 +113,12 @@ class HipWhisper:
 
     def __init__(self, dims: WhisperDims, weights: Union[Dict[str, np.ndarray], None] = None, *,
                  blob: Optional[torch.Tensor] = None, offsets: Optional[np.ndarray] = None,
-                 dtype: str = "bfloat16", device: int = 0, max_batch: int = 8, max_beam: int = 1):
+                 dtype: str = "bfloat16", device: int = 0, max_batch: int = 8, max_beam: int = 1,
+                 kv_len: Optional[int] = None, enc_batch: Optional[int] = None):
+        """``kv_len``: positions of the self-attention KV cache per row (default ``n_text_ctx``): prompt + max_new_tokens of
+        every later decode call must fit.  The cache is [layers][rows][heads][positions][64] x 2 -- 141 GB for 1920 rows at
+        448 positions, 22 GB at 72 -- so a caller that knows its token budget can hold twice the windows.  ``enc_batch``:
+        windows per encoder slice (default ``max_batch``): bounds the encoder workspaces (~50 MB per window)."""
         from . import weights as W
         if dtype not in DTYPES:
             raise ValueError(f"dtype must be one of {sorted(DTYPES)}")
@@ -138,9 +143,15 @@ class HipWhisper:
         handle = C.c_void_p()
         off = (C.c_int64 * len(self.offsets))(*self.offsets.tolist())
         _torch_sync()
+        self.kv_len = dims.n_text_ctx if not kv_len else min(dims.n_text_ctx, (int(kv_len) + 7) // 8 * 8)
+        self.enc_batch = self.max_batch if not enc_batch else min(self.max_batch, int(enc_batch))
+        hipbind.tune("self_kv_len", 0 if self.kv_len >= dims.n_text_ctx else self.kv_len)      # read by wj_whisper_create
+        hipbind.tune("enc_batch", 0 if self.enc_batch >= self.max_batch else self.enc_batch)
         check(self._lib.wj_whisper_create(self.ctx.handle, C.byref(cd), DTYPES[dtype], _ptr(blob), blob.numel(), off,
                                           len(self.offsets), self.max_batch, self.max_batch * self.max_beam,
                                           C.byref(handle)), "wj_whisper_create")
+        hipbind.tune("self_kv_len", 0)
+        hipbind.tune("enc_batch", 0)
         self.handle = handle
         self._suppress_mask: Optional[torch.Tensor] = None
         self._suppress_key = None

@@ -273,7 +273,8 @@ class HipWhisperModel:
     def __init__(self, model_size_or_path: str = "large-v3", device: str = "cuda", device_index: int = 0,
                  compute_type: str = "float16", cpu_threads: int = 0, num_workers: int = 1,
                  weights: Optional[Dict[str, np.ndarray]] = None, dims: Optional[pdims.WhisperDims] = None,
-                 max_batch: int = 32, max_beam: int = 5, blob=None, offsets=None, **_unused):
+                 max_batch: int = 32, max_beam: int = 5, blob=None, offsets=None, kv_len: Optional[int] = None,
+                 enc_batch: Optional[int] = None, **_unused):
         from . import engine, weights as W
         if device not in ("cuda", "auto", "hip"):
             raise ValueError(f"HipWhisperModel runs on the MI355X only (device={device!r}); there is no CPU path")
@@ -293,11 +294,15 @@ class HipWhisperModel:
             dims = pdims.dims_for(model_size_or_path)
         self.dims = dims
         self.model = engine.HipWhisper(dims, weights, blob=blob, offsets=offsets, dtype=self.compute_type,
-                                       device=device_index, max_batch=max_batch, max_beam=max_beam)
+                                       device=device_index, max_batch=max_batch, max_beam=max_beam, kv_len=kv_len,
+                                       enc_batch=enc_batch)
         self.fe = engine.HipLogMel(dims.n_mels, self.MEL_MODE, device=device_index)
         self.tokens = self.model.tokens
         self.max_batch, self.max_beam = max_batch, max_beam
-        self.max_length = dims.n_text_ctx
+        # decoder positions a window may use: n_text_ctx, or the KV cache the engine was sized for (kv_len: a deployment
+        # that caps max_new_tokens trades cache positions for resident windows, see engine.HipWhisper)
+        self.max_length = self.model.kv_len
+        self.n_text_ctx = dims.n_text_ctx
         self._warned = set()
         self.seed = 0               # base seed of the device sampler's counter-based generator
         self.device_beam = True     # beam search on the device (False: host-driven search.py over the step API)
@@ -379,9 +384,9 @@ class HipWhisperModel:
             prompt.append(t.sot_prev)
             if hot:
                 ht = self.tokenizer.encode(" " + hot.strip())
-                prompt.extend(ht[: self.max_length // 2 - 1])
+                prompt.extend(ht[: self.n_text_ctx // 2 - 1])
             if previous:
-                prompt.extend(list(previous)[-(self.max_length // 2 - 1):])
+                prompt.extend(list(previous)[-(self.n_text_ctx // 2 - 1):])
         lang = language or o.language or "ja"
         prompt.extend([t.sot, t.language_token(pdims.language_index(lang)),
                        t.transcribe if o.task == "transcribe" else t.translate])
@@ -391,13 +396,13 @@ class HipWhisperModel:
             pt = self.tokenizer.encode(" " + o.prefix.strip())
             if not o.without_timestamps:
                 prompt.append(t.timestamp_begin)
-            prompt.extend(pt[: self.max_length // 2 - 1])
+            prompt.extend(pt[: self.n_text_ctx // 2 - 1])
         return prompt
 
     # ---- decoding of one batch of windows ------------------------------------------------------
     def _max_new(self, o: TranscribeOptions, P: int) -> int:
         if self.FLAVOR == "ow":
-            max_new = self.max_length // 2                      # DecodingOptions.sample_len default
+            max_new = self.n_text_ctx // 2                      # DecodingOptions.sample_len default
             if o.max_new_tokens is not None:
                 max_new = min(max_new, int(o.max_new_tokens))
         else:
