@@ -218,33 +218,49 @@ def cpu_baseline_cfg3(dims, w, clips, n_groups, audio_s, max_new, beam, threads)
 # ---------------------------------------------------------------------------------------------------------------
 # the cfg3 stack: scene detector + VAD segmenter + model + ASR adapter + recording runner (the seam's own classes)
 # ---------------------------------------------------------------------------------------------------------------
-def transcribe_kwargs(args, words):
+def transcribe_kwargs(args, words, mode="balanced"):
+    if mode == "fidelity":
+        # the reference's fidelity defaults (config/components/asr/openai_whisper.py:229-255, "balanced" sensitivity):
+        # openai-whisper's own search (beam 2, patience 1.2, sum / length ranking), no CTranslate2 processors
+        return dict(task="transcribe", language="ja", beam_size=2, best_of=2, patience=1.2, length_penalty=None, temperature=[0.0],
+                    suppress_blank=True, without_timestamps=False, max_initial_timestamp=0.0, compression_ratio_threshold=2.4,
+                    logprob_threshold=-1.0, no_speech_threshold=None, condition_on_previous_text=False, fp16=True, verbose=None,
+                    sample_len=args.max_new_tokens, word_timestamps=bool(words))
     return dict(task="transcribe", language="ja", beam_size=args.beam, best_of=2, patience=1.2, temperature=[0.0],
                 repetition_penalty=1.5, no_repeat_ngram_size=3, condition_on_previous_text=False, suppress_blank=True,
                 max_initial_timestamp=0.0, no_speech_threshold=None, logprob_threshold=-1.0,
                 max_new_tokens=args.max_new_tokens, word_timestamps=bool(words))
 
 
-def build_stack(args, info, dims, dtype, batch, blob=None, offsets=None, weights=None, words=False):
+def build_stack(args, info, dims, dtype, batch, blob=None, offsets=None, weights=None, words=False, mode="balanced"):
+    """The seam's own classes: balanced = HipWhisperModel (faster-whisper contract, CTranslate2 search) under
+    asr.HipFasterWhisperProASR; fidelity = HipOpenAIWhisperModel (openai-whisper mel padding and search) under
+    asr.HipWhisperProASR (post-model log-prob gate on), as FidelityPipeline wires them."""
     from whisperjav_amd import asr, pipeline, scenes, segmenters
-    from whisperjav_amd.whisper_model import HipWhisperModel
+    from whisperjav_amd.whisper_model import HipOpenAIWhisperModel, HipWhisperModel
+    kw = transcribe_kwargs(args, words, mode)
+    beam = int(kw["beam_size"])
     # KV cache sized for what this run decodes (sot sequence + max_new_tokens; no conditioning on previous text), the
     # encoder in slices of --enc-batch windows: HBM goes to resident cross K/V, i.e. to windows per engine call
-    model = HipWhisperModel(args.model, compute_type=dtype, weights=weights, dims=dims, blob=blob, offsets=offsets,
-                            max_batch=batch, max_beam=args.beam, device_index=info.local_rank,
-                            kv_len=(4 + args.max_new_tokens + 4) if args.kv_fit else None, enc_batch=min(batch, args.enc_batch))
-    kw = transcribe_kwargs(args, words)
-    params = {"decoder": {k: v for k, v in kw.items() if k not in ("repetition_penalty", "no_repeat_ngram_size", "max_new_tokens")},
-              "provider": {"repetition_penalty": kw["repetition_penalty"], "no_repeat_ngram_size": kw["no_repeat_ngram_size"],
-                           "max_new_tokens": kw["max_new_tokens"]},
-              # the balanced preset's Silero parameters (config/components/vad/silero.py:105-114)
-              "vad": dict(threshold=args.vad_threshold, min_speech_duration_ms=100, min_silence_duration_ms=300, speech_pad_ms=400,
-                          chunk_threshold_s=2.5, max_group_duration_s=6.0),
-              "speech_segmenter": {"backend": "silero-v6.2-hip"}}
+    cls = HipOpenAIWhisperModel if mode == "fidelity" else HipWhisperModel
+    model = cls(args.model, compute_type=dtype, weights=weights, dims=dims, blob=blob, offsets=offsets,
+                max_batch=batch, max_beam=beam, device_index=info.local_rank,
+                kv_len=(4 + args.max_new_tokens + 4) if args.kv_fit else None, enc_batch=min(batch, args.enc_batch))
+    # BASELINE.md section 3: the balanced preset's Silero parameters (config/components/vad/silero.py:105-114)
+    vad = dict(threshold=args.vad_threshold, min_speech_duration_ms=100, min_silence_duration_ms=300, speech_pad_ms=400,
+               chunk_threshold_s=2.5, max_group_duration_s=6.0)
+    if mode == "fidelity":
+        params = {"decoder": kw, "provider": {}, "vad": vad, "speech_segmenter": {"backend": "silero-v6.2-hip"}}
+    else:
+        params = {"decoder": {k: v for k, v in kw.items() if k not in ("repetition_penalty", "no_repeat_ngram_size", "max_new_tokens")},
+                  "provider": {"repetition_penalty": kw["repetition_penalty"], "no_repeat_ngram_size": kw["no_repeat_ngram_size"],
+                               "max_new_tokens": kw["max_new_tokens"]},
+                  "vad": vad, "speech_segmenter": {"backend": "silero-v6.2-hip"}}
     # the Silero network's trained parameters are not available offline: seeded random ones, asked for explicitly
-    seg = segmenters.HipSileroV6SpeechSegmenter(weights="synthetic", device=info.local_rank, **params["vad"])
-    module = asr.HipFasterWhisperProASR({"model_name": args.model, "device": "cuda", "compute_type": dtype}, params, "transcribe",
-                                        whisper_model=model, segmenter=seg)
+    seg = segmenters.HipSileroV6SpeechSegmenter(weights="synthetic", device=info.local_rank, **vad)
+    acls = asr.HipWhisperProASR if mode == "fidelity" else asr.HipFasterWhisperProASR
+    module = acls({"model_name": args.model, "device": "cuda", "compute_type": dtype}, params, "transcribe",
+                  whisper_model=model, segmenter=seg)
     # gates above the synthetic clip's noise floor (the reference's 32 / 38 dB defaults sit below it and would only ever
     # cut at max_duration)
     det = scenes.HipAuditokSceneDetector(pass1_energy_threshold=52, pass2_energy_threshold=56, device=info.local_rank)
@@ -379,7 +395,7 @@ def run_cfg3(args, info, dims):
         box["blob"], box["offsets"] = pweights.pack_blob_device(dims, box["w"], dtype, dev)
     dev_blob, offsets = sharding.broadcast_blob(box.get("blob"), box.get("offsets"), dev)     # the ONE collective
     box.pop("blob", None)
-    model, module, runner = build_stack(args, info, dims, dtype, args.batch, blob=dev_blob, offsets=offsets)
+    model, module, runner = build_stack(args, info, dims, dtype, args.batch, blob=dev_blob, offsets=offsets, mode=args.mode)
     log(f"[bench] rank {info.rank}: audio {t_audio:.1f}s, weights + broadcast + model ready after {time.perf_counter() - t_start:.1f}s; "
         f"workspace {model.model.workspace_bytes / 2**30:.1f} GiB, blob {dev_blob.numel() / 2**30:.2f} GiB")
 
@@ -410,15 +426,18 @@ def run_cfg3(args, info, dims):
                 "n_gpus": info.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
                 "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
                 "dtype": DT_LABEL[dtype], "data": "synthetic",
-                "config": {"workload": (f"cfg3-{minutes:g}min: mode=balanced end to end on {minutes:g} min of noisy synthetic 16 kHz audio per "
+                "config": {"workload": (f"{'cfg4' if args.mode == 'fidelity' else 'cfg3'}-{minutes:g}min: mode={args.mode} end to end on {minutes:g} min of noisy synthetic 16 kHz audio per "
                                         f"{'job' if args.strong else 'GPU'}: two-pass energy-gate scenes <= 29 s (device frame energies), "
                                         f"Silero-class HIP VAD (threshold {args.vad_threshold}, seeded random parameters), groups <= 6 s, "
-                                        f"Whisper {args.model} geometry (seeded random fp16-representable weights), beam {args.beam} / patience 1.2 / "
-                                        f"repetition penalty 1.5 / no-repeat-3-gram, max_new_tokens={args.max_new_tokens} ("
+                                        f"Whisper {args.model} geometry (seeded random fp16-representable weights), "
+                                        + (f"beam {args.beam} / patience 1.2 / repetition penalty 1.5 / no-repeat-3-gram (CTranslate2's search)" if args.mode == "balanced"
+                                           else "openai-whisper log-mel padding and search (beam 2 / patience 1.2 / best_of 2, sum / length ranking), post-model gate on")
+                                        + f", max_new_tokens={args.max_new_tokens} ("
                                         + ("EOT-bearing synthetic weights: every search ends on its own, see workload_facts" if args.weights == "speechlike"
                                            else "plain random weights never emit EOT: every window decodes exactly this many tokens")
                                         + "), word_timestamps=False, "
-                                        f"through pipeline.RecordingTranscriber over asr.HipFasterWhisperProASR (the drop-in seam's classes)"),
+                                        f"through pipeline.RecordingTranscriber over asr.{'HipWhisperProASR' if args.mode == 'fidelity' else 'HipFasterWhisperProASR'} (the drop-in seam's classes)"),
+                           "mode": args.mode,
                            "windows_per_batch": args.batch, "compute_type": dtype, "max_new_tokens": args.max_new_tokens,
                            "tune": args.tune, "scene_loop": "pooled" if pooled else "one engine call per scene (the reference's call pattern)",
                            "parallelism": (f"scene-parallel x{info.world} ({'one recording LPT-sharded' if args.strong else 'one recording per GPU'}), "
@@ -521,6 +540,25 @@ def run_cfg3(args, info, dims):
     del model, module, runner, dev_blob
     torch.cuda.empty_cache()
 
+    if info.rank == 0 and info.world == 1 and not args.no_extras and args.mode == "balanced":
+        # BASELINE cfg4's mode on one GPU: the fidelity pipeline's classes (openai-whisper mel padding, device-resident
+        # BeamSearchDecoder search with beam 2 / patience 1.2, post-model gate) on the same recording, second of two passes
+        saved_beam, args.beam = args.beam, 2
+        mf, modf, runf = build_stack(args, info, dims, dtype, args.batch, weights=box["w"], mode="fidelity")
+        run_recording(runf, audio)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sf_ = run_recording(runf, audio)
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - t1
+        modf.cleanup()
+        args.beam = saved_beam
+        line["fidelity"] = {"rtfx": round(60.0 * minutes / tf, 2), "ms": round(1e3 * tf, 1),
+                            "what": ("mode=fidelity on the same recording and GPU: HipFidelity classes (asr.HipWhisperProASR over HipOpenAIWhisperModel), "
+                                     "openai-whisper search on the device (beam 2, patience 1.2, best_of 2), post-model gate on; second of two passes"),
+                            **sf_}
+        del mf, modf, runf
+        torch.cuda.empty_cache()
     if info.rank == 0 and info.world == 1 and not args.no_extras:
         # the exact-fp32 compute type (north-star parity type, 1e-5 of the oracle) on a bounded sample of the same recording
         fp32_audio = audio[: int(16000 * 60 * args.fp32_minutes)]
@@ -623,6 +661,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
     ap.add_argument("--minutes", type=float, default=120.0, help="cfg3: length of the synthetic recording")
+    ap.add_argument("--mode", default="balanced", choices=["balanced", "fidelity"],
+                    help="cfg3 = balanced (faster-whisper contract); fidelity = the openai-whisper contract of FidelityPipeline (BASELINE cfg4 with --strong)")
     ap.add_argument("--strong", action="store_true", help="cfg3 with --gpus N: ONE recording, scenes LPT-sharded over the ranks (cfg4)")
     ap.add_argument("--batch", type=int, default=768, help="30 s windows resident per GPU per engine call (768: cross K/V = 189 GB, "
                     "self-attention KV cache sized for max_new_tokens = 46 GB, encoder slices of --enc-batch windows; 238 GiB in all)")
@@ -667,6 +707,8 @@ def main():
         for kv in args.tune:
             k, v = kv.split("=")
             hipbind.tune(k, int(v))
+    if args.mode == "fidelity":
+        args.beam = 2           # the reference's fidelity default (beam_size=2, patience=1.2)
     if not args.kv_fit and args.batch > 384:
         log("[bench] --no-kv-fit: a 448-position KV cache leaves room for 384 windows per call")
         args.batch = 384

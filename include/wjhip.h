@@ -210,6 +210,22 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
                            int32_t* tokens_out, int32_t* n_tokens_out, float* score_out, float* sum_logprob_out,
                            float* no_speech_prob_out, void* stream);
 
+/* The same loop with openai-whisper's search rules.  Replaces: whisper.decoding.DecodingTask with beam_size set
+ * (BeamSearchDecoder.update / finalize + MaximumLikelihoodRanker), reached through whisper.transcribe from
+ * whisperjav/modules/whisper_pro_asr.py:433 -- the fidelity pipeline's search (defaults beam_size = 2, patience = 1.2:
+ * whisperjav/config/components/asr/openai_whisper.py:229-255).  Per step every beam proposes its top (beam + 1) tokens,
+ * candidates with equal token sequences count once, the best `beam` non-EOT ones continue (all beams stay alive, they
+ * start as `beam` copies), EOT-terminated ones are admitted best first while the window holds fewer than
+ * round(beam * patience) finished sequences, which is also when it stops; at the length limit a window holding fewer
+ * than `beam` sequences is topped up with its live beams; the winner maximises sum_logprob / length (length_penalty < 0,
+ * upstream's None) or sum_logprob / ((5 + length) / 6) ** length_penalty.  opts->repetition_penalty and
+ * no_repeat_ngram_size must be neutral (1.0 / 0: upstream has no such processors).  round(beam * patience) >= beam is
+ * required.  Arguments and outputs as wj_whisper_decode_beam. */
+int wj_whisper_decode_beam_openai(wj_whisper* m, int batch, int beam, const int32_t* slots_host, const int32_t* prompts_host,
+                                  int prompt_len, const wj_decode_opts* opts, float patience, float length_penalty,
+                                  int32_t* tokens_out, int32_t* n_tokens_out, float* score_out, float* sum_logprob_out,
+                                  float* no_speech_prob_out, void* stream);
+
 /* Word-timestamp alignment.  Replaces: ctranslate2 Whisper.align (faster_whisper.transcribe.WhisperModel
  * .find_alignment, reached with word_timestamps=True from faster_whisper_pro_asr.py:819) and whisper/timing.py
  * find_alignment (whisper_pro_asr.py:433).  Teacher-forced decoder pass over tokens_host [batch][n_tokens_max]

@@ -193,7 +193,7 @@ def beam_search(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], b
     K, V = bcfg.beam_size, model.dims.n_vocab
     P = len(prompt)
     max_new = min(bcfg.max_new_tokens, model.dims.n_text_ctx - P)
-    max_candidates = int(round(K * bcfg.patience))
+    max_candidates = int(np.floor(np.float32(K) * np.float32(bcfg.patience) + np.float32(0.5)))      # C++ std::round on floats: half away from zero
     with torch.no_grad():
         dec = CachedDecoder(model, xa.expand(K, -1, -1).contiguous())
         nsp = 0.0

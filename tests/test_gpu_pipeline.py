@@ -998,9 +998,12 @@ def test_language_detection_matches_oracle(hip):
     shim.close()
 
 
-def test_sharded_transcribe_cli_single_rank(hip, tmp_path):
+@pytest.mark.parametrize("mode", ["balanced", "fidelity"])
+def test_sharded_transcribe_cli_single_rank(hip, tmp_path, mode):
     """The cfg4 driver end to end on one rank: Hugging Face checkpoint directory (written by transformers, random
-    weights) -> blob -> scenes -> VAD groups -> batched beam search with word timestamps -> SRT."""
+    weights) -> blob -> scenes -> VAD groups -> batched beam search with word timestamps -> SRT.  ``--mode fidelity`` is
+    BASELINE cfg4 as written: the openai-whisper contract (HipWhisperProASR over HipOpenAIWhisperModel, device-resident
+    BeamSearchDecoder search)."""
     import subprocess
     import sys
     import wave
@@ -1019,7 +1022,8 @@ def test_sharded_transcribe_cli_single_rank(hip, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-m", "whisperjav_amd.sharded_transcribe", str(wav), str(tmp_path / "out" / "rec.srt"),
                           "--model", str(tmp_path / "model"), "--compute-type", "float32", "--batch", "8", "--beam-size", "2",
-                          "--max-new-tokens", "12", "--scene-energy-db", "52", "--vad-weights", "synthetic"],
+                          "--max-new-tokens", "12", "--scene-energy-db", "52", "--vad-weights", "synthetic", "--mode", mode,
+                          "--logprob-threshold", "-30"],      # random weights: the fidelity post-model gate (-1.0) would drop every segment
                          cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     text = (tmp_path / "out" / "rec.srt").read_text(encoding="utf-8")

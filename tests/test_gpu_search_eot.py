@@ -165,6 +165,63 @@ def test_device_beam_search_ends_with_eot(hip, dtype, beam, patience, lpen, rep,
     model.close()
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
+@pytest.mark.parametrize("beam,patience,lpen,max_new", [
+    (2, 1.2, None, 64),      # the reference's fidelity defaults (config/components/asr/openai_whisper.py:229-255)
+    (5, 2.0, None, 64),
+    (3, 1.0, 1.0, 64),       # GNMT length penalty
+    (5, 1.0, None, 15),      # length limit: windows holding fewer than `beam` finished sequences are topped up with live beams
+    (8, 1.0, None, 40),
+])
+def test_device_openai_beam_search_ends_with_eot(hip, dtype, beam, patience, lpen, max_new):
+    """Fidelity mode's search on the device (``wj_whisper_decode_beam_openai``: whisper's ``BeamSearchDecoder`` +
+    ``MaximumLikelihoodRanker``) == the host-driven restatement over the step API (same engine numerics, every compute
+    type) == ``oracle.decoding.beam_search_openai`` (float32: exact), on searches that end at different lengths."""
+    from whisperjav_amd import engine, search
+    B = 6
+    d, oracle, model, xa = _setup(dtype, B, beam)
+    toks = model.tokens
+    prompt = model.sot_prompt("ja", "transcribe")
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    dopt = engine.DecodeOptions(max_new_tokens=max_new, suppress_tokens=suppress, max_initial_timestamp=1.0)
+    P = np.tile(np.array(prompt, dtype=np.int32), (B, 1))
+    res = model.decode_beam(P, dopt, beam_size=beam, patience=patience, length_penalty=lpen, flavor="openai")
+    info = model.last_decode_info()
+    assert info["hip_graph"]
+    sub = model.decode_beam(P[:2], dopt, beam_size=beam, patience=patience, length_penalty=lpen, flavor="openai", slots=[4, 1])
+    for row, w in enumerate([4, 1]):
+        assert sub.tokens[row, : sub.n_tokens[row]].tolist() == res.tokens[w, : res.n_tokens[w]].tolist()
+    opts = search.SearchOptions(beam_size=beam, patience=patience, length_penalty=-1 if lpen is None else lpen,
+                                suppress_tokens=suppress, max_initial_timestamp_index=50, max_new_tokens=max_new)
+    host = search.beam_search_openai(search.HipStepScorer(model, opts), [prompt] * B, opts, eot=toks.eot,
+                                     timestamp_begin=toks.timestamp_begin)
+    fcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=50)
+    lens, same, worst = set(), 0, 0.0
+    for w in range(B):
+        got = res.tokens[w, : res.n_tokens[w]].tolist()
+        assert toks.eot not in got
+        assert got == host[w].sequences[0], (w, got, host[w].sequences[0])
+        assert abs(float(res.sum_logprob[w]) - host[w].cum_logprobs[0]) < 1e-3
+        seq, total, avg, nsp = decoding.beam_search_openai(oracle, xa[w:w + 1], prompt, beam, patience, lpen, max_new, fcfg)
+        lens.add(len(seq))
+        same += got == seq
+        if dtype == "float32":
+            assert got == seq, (w, got, seq)
+            assert abs(float(res.sum_logprob[w]) - total) < 1e-3
+            assert abs(float(res.sum_logprob[w]) / (len(got) + 1) - avg) < 1e-4
+            assert abs(float(res.no_speech_prob[w]) - nsp) < 1e-5
+        if got == seq:
+            worst = max(worst, abs(float(res.sum_logprob[w]) - total))
+    _diag("device_beam_openai", {"dtype": dtype, "beam": beam, "patience": patience, "max_new": max_new, "lens": sorted(lens),
+                                 "winners_identical": same, "cum_logprob_diff": worst, "device_steps": info["steps"]})
+    assert len(lens) > 1, lens
+    if max_new >= 40:
+        assert max(lens) < max_new and info["steps"] < max_new, (lens, info)
+    if dtype != "float32":
+        assert same >= B - 2 and worst < 0.05, (same, worst)
+    model.close()
+
+
 def test_ragged_16_window_batch_equals_per_window_decodes(hip):
     """(d): 16 windows decoded as ONE batch (windows finish at different steps, the rest keep running) give the same
     hypotheses as 16 single-window calls through the slot map, and as the oracle window by window."""

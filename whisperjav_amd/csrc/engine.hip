@@ -1070,10 +1070,13 @@ int wj_whisper_decode_sample(wj_whisper* m, int batch, int group, const int32_t*
 // merge + cache re-binding, captured as two hipGraphs (even / odd steps swap the history and row-map
 // buffers).  The host only polls a done counter every 8 steps and ranks the finished lists at the end.
 // ------------------------------------------------------------------------------------------------
-int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* slots_host, const int32_t* prompts_host,
-                           int prompt_len, const wj_decode_opts* opts, float patience, float length_penalty,
-                           int32_t* tokens_out, int32_t* n_tokens_out, float* score_out, float* sum_logprob_out,
-                           float* no_speech_prob_out, void* stream) {
+}  // extern "C"
+
+// flavor 0: CTranslate2's search (faster-whisper); flavor 1: openai-whisper's BeamSearchDecoder + MaximumLikelihoodRanker
+static int decode_beam_impl(int flavor, wj_whisper* m, int batch, int beam, const int32_t* slots_host, const int32_t* prompts_host,
+                            int prompt_len, const wj_decode_opts* opts, float patience, float length_penalty,
+                            int32_t* tokens_out, int32_t* n_tokens_out, float* score_out, float* sum_logprob_out,
+                            float* no_speech_prob_out, void* stream) {
   WJ_REQUIRE(m && prompts_host && opts && tokens_out && n_tokens_out && sum_logprob_out, "wj_whisper_decode_beam: NULL argument");
   WJ_REQUIRE(batch >= 1 && batch <= m->max_batch && beam >= 1 && (beam <= 6 || beam == 8) && batch * beam <= m->max_rows,
              "decode_beam: batch %d x beam %d does not fit (max_batch %d, max_rows %d; beam 1..6 or 8)", batch, beam,
@@ -1083,9 +1086,14 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
              "decode_beam: prompt_len %d + max_new_tokens %d exceeds the %d positions of the KV cache (n_text_ctx %d, self_kv_len at create)",
              P, max_new, m->kv_len, m->d.n_text_ctx);
   WJ_REQUIRE(patience > 0.f, "decode_beam: patience must be positive");
-  const int max_candidates = (int)lroundf(K * patience);
+  // CTranslate2: std::round (half away from zero); openai-whisper: Python's round() (half to even)
+  const int max_candidates = flavor == 1 ? (int)nearbyintf(K * patience) : (int)lroundf(K * patience);
   WJ_REQUIRE(max_candidates >= 1 && max_candidates + K <= kFinCap, "decode_beam: beam %d x patience %g needs %d finished slots (max %d)",
              K, (double)patience, max_candidates + K, kFinCap);
+  // openai-whisper tops a window up to `beam` sequences with the beams alive when the WHOLE batch stops; with
+  // round(beam * patience) < beam that depends on the other windows of the batch -- not reproduced on the device
+  WJ_REQUIRE(flavor == 0 || max_candidates >= K, "decode_beam (openai flavour): round(beam * patience) = %d < beam %d is not supported",
+             max_candidates, K);
   if (slots_host)
     for (int i = 0; i < batch; ++i)
       WJ_REQUIRE(slots_host[i] >= 0 && slots_host[i] < m->max_batch, "decode_beam: window slot %d out of range", slots_host[i]);
@@ -1101,7 +1109,7 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
     std::vector<float> sc(R, -INFINITY);
     for (int r = 0; r < R; ++r) {
       for (int j = 0; j < P; ++j) hist[(size_t)r * m->tok_stride + j] = prompts_host[(size_t)(r / K) * P + j];
-      if (r % K == 0) sc[r] = 0.f;                 // one live beam per window at the start
+      if (r % K == 0 || flavor == 1) sc[r] = 0.f;  // CTranslate2: one live beam per window at the start; whisper: K copies
     }
     WJ_HIP(hipMemcpyAsync(buf[0], hist.data(), sizeof(int32_t) * hist.size(), hipMemcpyHostToDevice, s));
     WJ_HIP(hipMemcpyAsync(m->beam_score, sc.data(), sizeof(float) * R, hipMemcpyHostToDevice, s));
@@ -1148,7 +1156,7 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
     a.win_ids = compact_ok ? m->win_ids : nullptr;
     a.done = m->beam_done; a.n_done = m->beam_done + m->max_batch;
     a.fin_count = m->fin_count; a.fin_score = m->fin_score; a.fin_len = m->fin_len; a.fin_tokens = m->fin_tokens;
-    a.fin_cap = kFinCap;
+    a.fin_cap = kFinCap; a.flavor = flavor;
     WJ_TRY(launch_beam_step(a, Ra, n_act, s));
     WJ_TRY(launch_advance_pos(m->pos, s));
     WJ_TRY(launch_rebind_rows(m->row_map[par], m->row_map[par ^ 1], m->parent, m->pos, Ra, m->kv_len, s));
@@ -1239,7 +1247,7 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
   drop_graphs();
   m->cur_map = 0;
   if (rc_loop) return rc_loop;
-  // finished lists -> best hypothesis per window (score / len^length_penalty, first one wins ties)
+  // finished lists -> best hypothesis per window
   std::vector<int32_t> fcount(batch), flen((size_t)batch * kFinCap), ftok((size_t)batch * kFinCap * m->tok_stride);
   std::vector<float> fscore((size_t)batch * kFinCap), nsp(R);
   WJ_HIP(hipMemcpyAsync(fcount.data(), m->fin_count, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, s));
@@ -1247,27 +1255,85 @@ int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* sl
   WJ_HIP(hipMemcpyAsync(fscore.data(), m->fin_score, sizeof(float) * fscore.size(), hipMemcpyDeviceToHost, s));
   WJ_HIP(hipMemcpyAsync(ftok.data(), m->fin_tokens, sizeof(int32_t) * ftok.size(), hipMemcpyDeviceToHost, s));
   WJ_HIP(hipMemcpyAsync(nsp.data(), m->nsp, sizeof(float) * R, hipMemcpyDeviceToHost, s));
+  // openai flavour: a window that holds fewer than `beam` finished sequences when the loop ends is topped up with its
+  // live beams (BeamSearchDecoder.finalize): their histories and cumulative log-probs, in the buffers the next
+  // iteration would have read
+  std::vector<int32_t> live_hist;
+  std::vector<float> live_score;
+  std::vector<int> where(batch, -1);              // logical window of each window still in the batch
+  if (flavor == 1) {
+    live_hist.resize((size_t)n_act * K * m->tok_stride);
+    live_score.resize((size_t)n_act * K);
+    WJ_HIP(hipMemcpyAsync(live_hist.data(), buf[par], sizeof(int32_t) * live_hist.size(), hipMemcpyDeviceToHost, s));
+    WJ_HIP(hipMemcpyAsync(live_score.data(), m->beam_score, sizeof(float) * live_score.size(), hipMemcpyDeviceToHost, s));
+    for (int w = 0; w < n_act; ++w) where[act_win[w]] = w;
+  }
   WJ_HIP(hipStreamSynchronize(s));
+  const int n_gen = m->last_steps;                 // tokens every live beam has generated
   for (int w = 0; w < batch; ++w) {
     const int n = std::min(fcount[w], kFinCap);
-    WJ_REQUIRE(n >= 1, "decode_beam: window %d finished no hypothesis", w);
+    struct Hyp { double score; int len; const int32_t* tok; };
+    std::vector<Hyp> hyps;
+    for (int i = 0; i < n; ++i)
+      hyps.push_back({(double)fscore[(size_t)w * kFinCap + i], flen[(size_t)w * kFinCap + i],
+                      &ftok[((size_t)w * kFinCap + i) * m->tok_stride]});
+    if (flavor == 1 && n < K) {
+      WJ_REQUIRE(where[w] >= 0, "decode_beam: window %d left the batch with %d < %d finished sequences", w, n, K);
+      std::vector<int> order(K);
+      for (int b = 0; b < K; ++b) order[b] = b;
+      const float* sc = &live_score[(size_t)where[w] * K];
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sc[x] > sc[y]; });
+      for (int b : order) {
+        if ((int)hyps.size() >= K) break;
+        const int32_t* t = &live_hist[((size_t)where[w] * K + b) * m->tok_stride + P];
+        int len = 0;                                // tokens before the first EOT (whisper slices at the first EOT)
+        while (len < n_gen && t[len] != opts->eot) ++len;
+        bool dup = false;                           // sequences are dict keys upstream: an equal one only overwrites
+        for (const Hyp& h : hyps)
+          if (h.len == len && std::equal(t, t + len, h.tok)) { dup = true; break; }
+        if (!dup) hyps.push_back({(double)sc[b], len, t});
+      }
+    }
+    WJ_REQUIRE(!hyps.empty(), "decode_beam: window %d finished no hypothesis", w);
     int best = 0;
     double best_norm = -INFINITY;
-    for (int i = 0; i < n; ++i) {
-      const int len = std::max(flen[(size_t)w * kFinCap + i], 1);
-      const double sc = fscore[(size_t)w * kFinCap + i];
-      const double norm = length_penalty != 0.f ? sc / pow((double)len, (double)length_penalty) : sc;
-      if (norm > best_norm) { best_norm = norm; best = i; }
+    for (int i = 0; i < (int)hyps.size(); ++i) {
+      const int len = hyps[i].len;
+      double norm;
+      if (flavor == 1) {      // MaximumLikelihoodRanker: sum / length, or the GNMT penalty ((5 + length) / 6) ** alpha
+        const double pen = length_penalty < 0.f ? (double)len : pow((5.0 + len) / 6.0, (double)length_penalty);
+        norm = pen != 0.0 ? hyps[i].score / pen : -INFINITY;
+      } else {                // CTranslate2: score / len ** length_penalty, first one wins ties
+        norm = length_penalty != 0.f ? hyps[i].score / pow((double)std::max(len, 1), (double)length_penalty) : hyps[i].score;
+      }
+      if (norm > best_norm || i == 0) { best_norm = norm; best = i; }
     }
-    const int len = flen[(size_t)w * kFinCap + best];
-    for (int j = 0; j < max_new; ++j)
-      tokens_out[(size_t)w * max_new + j] = j < len ? ftok[((size_t)w * kFinCap + best) * m->tok_stride + j] : opts->eot;
+    const int len = hyps[best].len;
+    for (int j = 0; j < max_new; ++j) tokens_out[(size_t)w * max_new + j] = j < len ? hyps[best].tok[j] : opts->eot;
     n_tokens_out[w] = len;
-    sum_logprob_out[w] = fscore[(size_t)w * kFinCap + best];
+    sum_logprob_out[w] = (float)hyps[best].score;
     if (score_out) score_out[w] = (float)best_norm;
     if (no_speech_prob_out) no_speech_prob_out[w] = nsp[(size_t)w * K];
   }
   return WJ_OK;
+}
+
+extern "C" {
+
+int wj_whisper_decode_beam(wj_whisper* m, int batch, int beam, const int32_t* slots_host, const int32_t* prompts_host,
+                           int prompt_len, const wj_decode_opts* opts, float patience, float length_penalty,
+                           int32_t* tokens_out, int32_t* n_tokens_out, float* score_out, float* sum_logprob_out,
+                           float* no_speech_prob_out, void* stream) {
+  return decode_beam_impl(0, m, batch, beam, slots_host, prompts_host, prompt_len, opts, patience, length_penalty, tokens_out,
+                          n_tokens_out, score_out, sum_logprob_out, no_speech_prob_out, stream);
+}
+
+int wj_whisper_decode_beam_openai(wj_whisper* m, int batch, int beam, const int32_t* slots_host, const int32_t* prompts_host,
+                                  int prompt_len, const wj_decode_opts* opts, float patience, float length_penalty,
+                                  int32_t* tokens_out, int32_t* n_tokens_out, float* score_out, float* sum_logprob_out,
+                                  float* no_speech_prob_out, void* stream) {
+  return decode_beam_impl(1, m, batch, beam, slots_host, prompts_host, prompt_len, opts, patience, length_penalty, tokens_out,
+                          n_tokens_out, score_out, sum_logprob_out, no_speech_prob_out, stream);
 }
 
 int wj_decode_open(wj_whisper* m, int batch, int beam, void* stream) {

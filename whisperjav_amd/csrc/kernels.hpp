@@ -175,6 +175,7 @@ struct BeamArgs {
   int32_t* fin_len = nullptr;         // [B][fin_cap]
   int32_t* fin_tokens = nullptr;      // [B][fin_cap][tok_stride]
   int fin_cap = 0;
+  int flavor = 0;                     // 0 = CTranslate2 (faster-whisper), 1 = openai-whisper BeamSearchDecoder
 };
 extern int g_beam_topk_reg;
 int launch_beam_step(const BeamArgs& a, int R, int B, hipStream_t s);

@@ -803,6 +803,127 @@ __global__ __launch_bounds__(128) void beam_merge_kernel(const BeamArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// openai-whisper's BeamSearchDecoder.update (whisper/decoding.py; fidelity mode, reached from
+// whisperjav/modules/whisper_pro_asr.py:433), one workgroup per window:
+//   every beam proposes its top (K + 1) tokens; candidates are keyed by their token SEQUENCE (beams holding the same
+//   history -- all of them at the first step, copies made when fewer than K candidates survive -- count once); in
+//   order of decreasing cumulative log-prob a candidate ending in EOT joins this step's finished set, any other one
+//   becomes a beam, until K beams exist; this step's finished sequences are then admitted best first while the window
+//   holds fewer than round(K * patience) of them.  All K beams stay alive (no -inf beams, no refill from a second
+//   candidate list: that is CTranslate2's rule, beam_merge_kernel above).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void beam_merge_ow_kernel(const BeamArgs a) {
+  __shared__ float c_score[80];
+  __shared__ int c_beam[80], c_tok[80], c_order[80];
+  __shared__ float old_score[8];
+  __shared__ int cls[8];
+  __shared__ int n_parent[8], n_feed[8];
+  __shared__ float n_score[8];
+  __shared__ int fin_b[16], fin_slot[16];
+  __shared__ float fin_sc[16];
+  __shared__ int s_counts[2];            // candidates, finished this step
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const int ow = a.win_ids ? a.win_ids[w] : w;
+  const int K = a.K, nk = K + 1, eot = a.opts.eot;
+  const int pos = *a.pos_ptr, len = pos + 1;
+  const bool done = a.done[ow] != 0;
+  if (tid < K) old_score[tid] = a.score[w * K + tid];
+  // ---- beams that hold the same token sequence form one class (its first member stands for it)
+  if (tid < K) {
+    int c = tid;
+    const int32_t* mine = a.hist_in + (int64_t)(w * K + tid) * a.tok_stride;
+    for (int b = 0; b < tid; ++b) {
+      const int32_t* other = a.hist_in + (int64_t)(w * K + b) * a.tok_stride;
+      bool same = true;
+      for (int j = len - 1; j >= a.sample_begin; --j)        // histories differ near their end, if at all
+        if (mine[j] != other[j]) { same = false; break; }
+      if (same) { c = b; break; }
+    }
+    cls[tid] = c;
+  }
+  __syncthreads();
+  const int total = K * nk;
+  if (tid < 80) {
+    float sc = -INFINITY; int b = 0, t = -1;
+    if (tid < total) {
+      b = tid / nk;
+      const int j = tid - b * nk;
+      t = a.cand_ids[(int64_t)(w * K + b) * 16 + j];
+      const float lp = a.cand_lp[(int64_t)(w * K + b) * 16 + j];
+      if (cls[b] != b || t < 0 || lp == -INFINITY) t = -1;
+      else sc = old_score[b] + lp;
+    }
+    c_score[tid] = sc; c_beam[tid] = b; c_tok[tid] = t;
+  }
+  __syncthreads();
+  // ---- total order: score descending, then first insertion (beam, rank within the beam's top-k)
+  if (tid < total && c_tok[tid] >= 0) {
+    int rank = 0;
+    for (int j = 0; j < total; ++j) {
+      if (j == tid || c_tok[j] < 0) continue;
+      rank += (c_score[j] > c_score[tid] || (c_score[j] == c_score[tid] && j < tid)) ? 1 : 0;
+    }
+    c_order[rank] = tid;
+  }
+  if (tid == 0) {
+    int n = 0;
+    for (int j = 0; j < total; ++j) n += c_tok[j] >= 0;
+    s_counts[0] = n;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int n = s_counts[0];
+    int nn = 0, nfin = 0;
+    int fcount = a.fin_count[ow];
+    if (!done) {
+      for (int i = 0; i < n && nn < K; ++i) {
+        const int c = c_order[i];
+        if (c_tok[c] == eot) {
+          if (fcount + nfin < a.max_candidates && nfin < 16) {      // admitted best first while there is room
+            fin_b[nfin] = c_beam[c]; fin_sc[nfin] = c_score[c]; fin_slot[nfin] = fcount + nfin;
+            ++nfin;
+          }
+        } else {
+          n_parent[nn] = c_beam[c]; n_feed[nn] = c_tok[c]; n_score[nn] = c_score[c];
+          ++nn;
+        }
+      }
+      if (nn == 0) { n_parent[0] = 0; n_feed[0] = eot; n_score[0] = -INFINITY; nn = 1; }   // everything masked: keep a row
+      for (; nn < K; ++nn) { n_parent[nn] = n_parent[nn - 1]; n_feed[nn] = n_feed[nn - 1]; n_score[nn] = n_score[nn - 1]; }
+      a.fin_count[ow] = fcount + nfin;
+      if (fcount + nfin >= a.max_candidates) { a.done[ow] = 1; atomicAdd(a.n_done, 1); }
+    } else {
+      for (; nn < K; ++nn) { n_parent[nn] = nn; n_feed[nn] = eot; n_score[nn] = old_score[nn]; }
+    }
+    s_counts[1] = nfin;
+  }
+  __syncthreads();
+  const int nfin = s_counts[1];
+  for (int f = 0; f < nfin; ++f) {         // finished: the parent's generated tokens (EOT itself is not stored)
+    const int slot = fin_slot[f];
+    if (slot >= a.fin_cap) continue;
+    const int32_t* src = a.hist_in + (int64_t)(w * K + fin_b[f]) * a.tok_stride + a.sample_begin;
+    int32_t* dst = a.fin_tokens + ((int64_t)ow * a.fin_cap + slot) * a.tok_stride;
+    const int ng = len - a.sample_begin;
+    for (int j = tid; j < ng; j += 128) dst[j] = src[j];
+    if (tid == 0) {
+      a.fin_len[(int64_t)ow * a.fin_cap + slot] = ng;
+      a.fin_score[(int64_t)ow * a.fin_cap + slot] = fin_sc[f];
+    }
+  }
+  for (int k = 0; k < K; ++k) {
+    const int32_t* src = a.hist_in + (int64_t)(w * K + n_parent[k]) * a.tok_stride;
+    int32_t* dst = a.hist_out + (int64_t)(w * K + k) * a.tok_stride;
+    for (int j = tid; j < len; j += 128) dst[j] = src[j];
+    if (tid == 0) {
+      dst[len] = n_feed[k];
+      a.score[w * K + k] = n_score[k];
+      a.parent[w * K + k] = w * K + n_parent[k];
+    }
+  }
+}
+
 int g_beam_topk_reg = 1;   // wj_tune("beam_topk_reg"): 0 = the multi-pass sweep (A/B, cross-check)
 
 int launch_beam_step(const BeamArgs& a, int R, int B, hipStream_t s) {
@@ -812,7 +933,8 @@ int launch_beam_step(const BeamArgs& a, int R, int B, hipStream_t s) {
   else if (g_beam_topk_reg && a.V <= 64 * SB) hipLaunchKernelGGL(beam_topk_reg_kernel<64>, dim3(R), dim3(SB), 0, s, a);
   else hipLaunchKernelGGL(beam_topk_kernel, dim3(R), dim3(SB), 0, s, a);
   WJ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(128), 0, s, a);
+  if (a.flavor == 1) hipLaunchKernelGGL(beam_merge_ow_kernel, dim3(B), dim3(128), 0, s, a);
+  else hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(128), 0, s, a);
   WJ_LAUNCH_CHECK();
   return WJ_OK;
 }

@@ -264,10 +264,19 @@ class HipWhisper:
         return GreedyResult(toks, ntok, slp, nsp, tlp)
 
     def decode_beam(self, prompts: np.ndarray, options: Optional[DecodeOptions] = None, *, beam_size: int = 5,
-                    patience: float = 1.0, length_penalty: float = 1.0, slots: Optional[Sequence[int]] = None) -> GreedyResult:
-        """CTranslate2-style beam search of the resident windows, entirely on the device.  Per window: best
-        hypothesis tokens, count, cumulative log-prob (``sum_logprob``), no-speech probability;
-        ``token_logprob`` carries the normalised score in column 0."""
+                    patience: float = 1.0, length_penalty: Optional[float] = 1.0, slots: Optional[Sequence[int]] = None,
+                    flavor: str = "ct2") -> GreedyResult:
+        """Beam search of the resident windows, entirely on the device: ``flavor="ct2"`` CTranslate2's rules
+        (faster-whisper), ``"openai"`` openai-whisper's ``BeamSearchDecoder`` + ``MaximumLikelihoodRanker`` (fidelity
+        mode; ``length_penalty=None`` = rank by ``sum_logprob / length``).  Per window: best hypothesis tokens, count,
+        cumulative log-prob (``sum_logprob``), no-speech probability; ``token_logprob`` carries the normalised score in
+        column 0."""
+        if flavor not in ("ct2", "openai"):
+            raise ValueError("flavor must be 'ct2' or 'openai'")
+        if length_penalty is None:
+            if flavor == "ct2":
+                raise ValueError("length_penalty=None is openai-whisper's default; CTranslate2 takes a number")
+            length_penalty = -1.0
         o = options or DecodeOptions()
         prompts = np.ascontiguousarray(prompts, dtype=np.int32)
         B, P = prompts.shape
@@ -286,9 +295,9 @@ class HipWhisper:
             if sl_arr.shape != (B,):
                 raise ValueError("slots must name one resident window per prompt row")
             sl = as_i(sl_arr)
-        check(self._lib.wj_whisper_decode_beam(self.handle, B, int(beam_size), sl, as_i(prompts), P, C.byref(oc), float(patience),
-                                               float(length_penalty), as_i(toks), as_i(ntok), as_f(score), as_f(slp), as_f(nsp),
-                                               None), "wj_whisper_decode_beam")
+        fn = self._lib.wj_whisper_decode_beam if flavor == "ct2" else self._lib.wj_whisper_decode_beam_openai
+        check(fn(self.handle, B, int(beam_size), sl, as_i(prompts), P, C.byref(oc), float(patience), float(length_penalty),
+                 as_i(toks), as_i(ntok), as_f(score), as_f(slp), as_f(nsp), None), "wj_whisper_decode_beam")
         return GreedyResult(toks, ntok, slp, nsp, score.reshape(B, 1))
 
     def align(self, token_rows: Sequence[Sequence[int]], n_prefix: int, heads: Sequence[Tuple[int, int]],

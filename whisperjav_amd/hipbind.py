@@ -69,6 +69,8 @@ _SIGNATURES = {
                                       C.POINTER(_F), _P]),
     "wj_whisper_decode_beam": (_I, [_P, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), _F, _F, C.POINTER(C.c_int32),
                                     C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _P]),
+    "wj_whisper_decode_beam_openai": (_I, [_P, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), _F, _F,
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _P]),
     "wj_whisper_align": (_I, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I,
                               C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32),
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),

@@ -110,7 +110,7 @@ def beam_search(scorer: StepScorer, prompts: Sequence[Sequence[int]], opts: Sear
     max_new = min(int(opts.max_new_tokens), n_text_ctx - P)
     if max_new < 1:
         raise ValueError("prompt leaves no room for new tokens")
-    max_candidates = int(round(K * float(opts.patience)))
+    max_candidates = int(np.floor(np.float32(K) * np.float32(opts.patience) + np.float32(0.5)))   # C++ std::round, not Python's half-to-even
     n_cand = 2 * K
     R = B * K
     scorer.open(B, K)

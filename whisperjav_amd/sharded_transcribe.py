@@ -51,11 +51,30 @@ def balanced_params(language: str = "ja", beam_size: int = 2, max_new_tokens: Op
     return {"decoder": decoder, "provider": provider, "vad": vad, "speech_segmenter": {"backend": "silero-v6.2-hip"}}
 
 
+def fidelity_params(language: str = "ja", beam_size: int = 2, sample_len: Optional[int] = None,
+                    word_timestamps: bool = True, vad_threshold: float = 0.28) -> Dict[str, Any]:
+    """The ``params`` dict the reference's resolver hands ``WhisperProASR`` in fidelity mode
+    (config/components/asr/openai_whisper.py:229-255, "balanced" sensitivity; BASELINE cfg4)."""
+    decoder = dict(task="transcribe", language=language, beam_size=beam_size, best_of=2, patience=1.2, length_penalty=None,
+                   prefix=None, suppress_tokens=None, suppress_blank=True, without_timestamps=False, max_initial_timestamp=0.0,
+                   temperature=[0.0], compression_ratio_threshold=2.4, logprob_threshold=-1.0, logprob_margin=0.0,
+                   no_speech_threshold=0.71, drop_nonverbal_vocals=False, condition_on_previous_text=False, initial_prompt=None,
+                   word_timestamps=word_timestamps, verbose=None, fp16=True)
+    if sample_len is not None:
+        decoder["sample_len"] = sample_len
+    vad = dict(threshold=vad_threshold, min_speech_duration_ms=100, min_silence_duration_ms=300, speech_pad_ms=400,
+               chunk_threshold_s=2.5, max_group_duration_s=6.0)
+    return {"decoder": decoder, "provider": {}, "vad": vad, "speech_segmenter": {"backend": "silero-v6.2-hip"}}
+
+
 def main(argv: Optional[Sequence[str]] = None) -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("audio")
     ap.add_argument("srt")
     ap.add_argument("--model", required=True, help="directory with model.pt or config.json + model.safetensors (+ tokenizer.json)")
+    ap.add_argument("--mode", default="balanced", choices=["balanced", "fidelity"],
+                    help="balanced: faster-whisper contract (FasterWhisperProASR, CTranslate2 search); fidelity: openai-whisper "
+                         "contract (WhisperProASR: its mel padding, its beam search, post-model gate) -- BASELINE cfg4")
     ap.add_argument("--compute-type", default="float16")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--beam-size", type=int, default=2)
@@ -64,6 +83,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("--scene-energy-db", type=int, default=32, help="auditok pass-1 energy threshold (pass 2 = +6 dB)")
     ap.add_argument("--vad-weights", default=None, help="trained Silero VAD parameters (silero_vad.jit / .npz / .safetensors); "
                     "default: the silero_vad package's bundled model; 'synthetic' = seeded random parameters (tests only)")
+    ap.add_argument("--logprob-threshold", type=float, default=None,
+                    help="override the preset's logprob_threshold (-1.0): the fallback trigger and, in fidelity mode, the post-model gate")
     ap.add_argument("--per-scene", action="store_true", help="the reference's call pattern (one engine call per scene) instead of pooling")
     args = ap.parse_args(argv)
     import torch
@@ -82,8 +103,9 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     meta = sharding.broadcast_object(meta)
     dims = meta["dims"]
     dev_blob, offsets = sharding.broadcast_blob(blob, offsets, dev)
-    model = wm.HipWhisperModel(args.model, compute_type=ct, dims=dims, blob=dev_blob, offsets=offsets,
-                               device_index=info.local_rank, max_batch=args.batch, max_beam=max(2, args.beam_size))
+    model_cls = wm.HipOpenAIWhisperModel if args.mode == "fidelity" else wm.HipWhisperModel
+    model = model_cls(args.model, compute_type=ct, dims=dims, blob=dev_blob, offsets=offsets,
+                      device_index=info.local_rank, max_batch=args.batch, max_beam=max(2, args.beam_size))
     if meta["alignment_heads"]:
         model._alignment_heads = list(meta["alignment_heads"])
     tok = Path(args.model) / "tokenizer.json"
@@ -93,7 +115,10 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     audio = pipeline.to_16k(audio, sr)          # every sample index below is a 16 kHz index
     detector = scn.HipAuditokSceneDetector(device=info.local_rank, pass1_energy_threshold=args.scene_energy_db,
                                            pass2_energy_threshold=args.scene_energy_db + 6)
-    params = balanced_params(args.language, args.beam_size, args.max_new_tokens)
+    params = (fidelity_params(args.language, args.beam_size, args.max_new_tokens) if args.mode == "fidelity"
+              else balanced_params(args.language, args.beam_size, args.max_new_tokens))
+    if args.logprob_threshold is not None:
+        params["decoder"]["logprob_threshold"] = args.logprob_threshold
     vad_kw = dict(params["vad"])
     if args.vad_weights == "synthetic":
         vad_kw["weights"] = "synthetic"
@@ -101,8 +126,9 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         vad_kw["weights_path"] = args.vad_weights
     segmenter = segmenters.HipSileroV6SpeechSegmenter(device=info.local_rank, **vad_kw)
     # the per-scene semantics (VAD fail-over, suppress lists, post-model gate, timestamp shifts) are the ASR adapter's
-    module = asr.HipFasterWhisperProASR({"model_name": args.model, "device": "cuda", "compute_type": ct}, params, "transcribe",
-                                        whisper_model=model, segmenter=segmenter)
+    asr_cls = asr.HipWhisperProASR if args.mode == "fidelity" else asr.HipFasterWhisperProASR
+    module = asr_cls({"model_name": args.model, "device": "cuda", "compute_type": ct}, params, "transcribe",
+                     whisper_model=model, segmenter=segmenter)
     runner = pipeline.RecordingTranscriber(module, detector)
     scene_list = runner.detect(audio, pipeline.SR)          # deterministic: every rank computes the same list
     plan = sharding.assign_lpt([b - a for a, b in scene_list], info.world)

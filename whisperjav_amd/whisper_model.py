@@ -486,8 +486,9 @@ class HipWhisperModel:
         beam = int(o.beam_size or 1)
         device_loop = beam == 1 and (self.FLAVOR == "fw" or (float(o.repetition_penalty) == 1.0
                                                              and int(o.no_repeat_ngram_size) == 0))
-        device_beam = (not device_loop and self.FLAVOR == "fw" and self.device_beam and beam in (2, 3, 4, 5, 6, 8)
-                       and round(beam * float(o.patience or 1.0)) + beam <= 24)
+        n_fin = round(beam * float(o.patience or 1.0))       # finished hypotheses a window collects before it stops
+        device_beam = (not device_loop and self.device_beam and beam in (2, 3, 4, 5, 6, 8) and n_fin + beam <= 24
+                       and (self.FLAVOR == "fw" or n_fin >= beam))
         if not identity and not (device_loop or device_beam):
             # host-driven search over the step API addresses windows 0..n-1 only: decode the resident prefix, keep ours
             hi = max(slots) + 1
@@ -496,18 +497,21 @@ class HipWhisperModel:
             return [full[i] for i in slots]
         out = []
         if device_beam:
-            # CTranslate2's beam search, device resident (wj_whisper_decode_beam); the host-driven restatement in
-            # search.py stays available (device_beam = False) and is what the GPU tests cross-check it with
+            # beam search, device resident: CTranslate2's rules (wj_whisper_decode_beam) for the faster-whisper flavour,
+            # openai-whisper's BeamSearchDecoder (wj_whisper_decode_beam_openai) for the fidelity flavour; the host-driven
+            # restatements in search.py stay available (device_beam = False) and are what the GPU tests cross-check with
             lp = o.length_penalty
+            ow = self.FLAVOR == "ow"
             res = self.model.decode_beam(
                 np.array(prompts, dtype=np.int32),
                 engine.DecodeOptions(max_new_tokens=max_new, suppress_blank=o.suppress_blank,
                                      without_timestamps=o.without_timestamps, suppress_tokens=suppress,
                                      max_initial_timestamp=mit_s,
-                                     repetition_penalty=float(o.repetition_penalty),
-                                     no_repeat_ngram_size=int(o.no_repeat_ngram_size)),
-                beam_size=beam, patience=float(o.patience or 1.0), length_penalty=(1.0 if lp is None else float(lp)),
-                slots=None if identity else slots)
+                                     repetition_penalty=1.0 if ow else float(o.repetition_penalty),
+                                     no_repeat_ngram_size=0 if ow else int(o.no_repeat_ngram_size)),
+                beam_size=beam, patience=float(o.patience or 1.0),
+                length_penalty=(None if lp is None else float(lp)) if ow else (1.0 if lp is None else float(lp)),
+                slots=None if identity else slots, flavor="openai" if ow else "ct2")
             for r in range(n):
                 toks = res.tokens[r, : res.n_tokens[r]].tolist()
                 out.append((toks, float(res.sum_logprob[r]) / (len(toks) + 1), float(res.no_speech_prob[r])))
