@@ -168,7 +168,7 @@ def roofline_from_stages(stages, dtype, tag_hint=None):
         # wide-read correction, MI355X_MICROARCH.md "HBM"), kept per window and scaled to this run's windows per launch
         pmc = json.load(open(pmc_file))
         traffic = pmc["hbm_read_bytes_per_window"] * e["windows_per_launch"]
-        traffic_source = f"stored PMC pass ({os.path.basename(pmc_file)}: {pmc.get('command', 'bench.py')}), scaled per window; not collected in this run"
+        traffic_source = f"stored PMC pass ({os.path.basename(pmc_file)}: {pmc.get('source', 'bench.py')}), scaled per window; not collected in this run"
     return {"kernel": dom, "bound": e["bound"], "achieved": e["achieved"],
             "peak": HBM_PEAK_GBS if e["bound"] == "hbm" else MFMA_PEAK_TFLOPS[dtype], "unit": e["unit"], "frac": e["frac"],
             "traffic": traffic, "traffic_source": traffic_source,

@@ -7,7 +7,8 @@
 #   smoke                    __graft_entry__.smoke()
 #   bench [bench.py args]    python bench.py ... -> gpurun_out/bench_<tag>.json  (tag = $BENCH_TAG, default "default")
 #   prof  [bench.py args]    rocprofv3 --kernel-trace --stats of bench.py ... -> gpurun_out/prof_<tag>/
-#   pmc <counters> <kernel> <windows/launch> [bench.py args]   rocprofv3 --pmc (own pass) -> gpurun_out/pmc_<tag>_summary.json
+#   pmc <counters> <kernel> <windows/launch | auto> [bench.py args]   rocprofv3 --pmc (own pass) -> gpurun_out/pmc_<tag>_summary.json
+#   pmcmfma [bench.py args]  MfmaUtil per kernel class (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE) -> gpurun_out/pmc_<tag>_summary.json
 #   py <file> [args]         python <file> ... -> gpurun_out/<basename>.log
 #   seq "<plan a...>" "<plan b...>"   several plans in one call
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
@@ -43,7 +44,16 @@ case "$plan" in
     (cd /tmp && timeout ${BENCH_TIMEOUT:-900} rocprofv3 --pmc $counters -d "$OLDPWD/gpurun_out/pmc_${TAG}" -o pmc --output-format csv -- \
         python "$OLDPWD/bench.py" "$@" > "$OLDPWD/gpurun_out/pmc_${TAG}.json" 2> "$OLDPWD/gpurun_out/pmc_${TAG}.err")
     note "pmc[$TAG] $counters $* rc=$?"
+    [ "$wpl" = "auto" ] && wpl="auto:gpurun_out/pmc_${TAG}.json"
     python scripts/rocprof_summarise.py pmc "gpurun_out/pmc_${TAG}" "gpurun_out/pmc_${TAG}_summary.json" "$kern" "$wpl" python bench.py "$@"; note "pmc summary rc=$?"
+    rm -rf "gpurun_out/pmc_${TAG}" ;;
+  pmcmfma)
+    # MfmaUtil per kernel class: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128), own pass with --kernel-trace only
+    rm -rf "gpurun_out/pmc_${TAG}"
+    (cd /tmp && timeout ${BENCH_TIMEOUT:-900} rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d "$OLDPWD/gpurun_out/pmc_${TAG}" -o pmc --output-format csv -- \
+        python "$OLDPWD/bench.py" "$@" > "$OLDPWD/gpurun_out/pmc_${TAG}.json" 2> "$OLDPWD/gpurun_out/pmc_${TAG}.err")
+    note "pmcmfma[$TAG] $* rc=$?"
+    python scripts/rocprof_summarise.py mfma "gpurun_out/pmc_${TAG}" "gpurun_out/pmc_${TAG}_summary.json" python bench.py "$@"; note "pmcmfma summary rc=$?"
     rm -rf "gpurun_out/pmc_${TAG}" ;;
   py)
     f="$1"; shift

@@ -1,7 +1,8 @@
 """Turn rocprofv3 output directories into the small summaries committed under profiles/.
 
     python scripts/rocprof_summarise.py stats <dir> <out.csv>        # --kernel-trace --stats run: top kernels by time
-    python scripts/rocprof_summarise.py pmc <dir> <out.json> <kernel substring> <windows per launch> <bench command>
+    python scripts/rocprof_summarise.py pmc <dir> <out.json> <kernel substring> <windows per launch | auto:bench.json> <bench command>
+    python scripts/rocprof_summarise.py mfma <dir> <out.json> <bench command>     # --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 
 ``pmc``: FETCH_SIZE of a `rocprofv3 --pmc FETCH_SIZE` pass (own pass, no tracing domains), averaged over the
 dispatches of the named kernel.  FETCH_SIZE counts kilobytes of 64-byte fabric requests; on gfx950 a wide coalesced
@@ -37,7 +38,62 @@ def stats(d, out):
         print(f"{float(r['Percentage']):6.2f}%  {int(r['Calls']):7d} x {float(r['AverageNs']) / 1e3:9.2f} us  {r['Name'][:90]}")
 
 
+KERNEL_CLASSES = (        # kernel-name substring(s) -> class of the encoder / decode step (first match wins)
+    ("attn_enc", "encoder attention"), ("attn_cross_mfma", "decode cross attention"), ("attn_dec", "decode self attention"),
+    ("gemm_h_big", "encoder GEMMs (256-tile: qk, v, out, fc1, fc2, cross K/V)"), ("gemm_h_tile", "conv stem + decode tile GEMMs"),
+    ("gemm_h_skinny", "decode skinny GEMMs"), ("gemm_h_rows", "decode row GEMMs"), ("layernorm", "LayerNorm"),
+    ("beam_topk", "beam top-2K"), ("beam_merge", "beam merge"))
+
+
+def mfma(d, out, command):
+    """MfmaUtil per kernel class = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128): GUI_ACTIVE is summed over the 8 XCDs,
+    each with 32 CUs x 4 SIMDs; busy cycles are per SIMD (MI355X_MICROARCH.md, profiling section)."""
+    acc = {}
+    per_kernel = {}
+    for path in find(d, "*counter_collection.csv"):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                name, cn = r.get("Kernel_Name", ""), r.get("Counter_Name")
+                if cn not in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES"):
+                    continue
+                label = next((lab for sub, lab in KERNEL_CLASSES if sub in name), None)
+                if label is None:
+                    continue
+                e = acc.setdefault(label, {"SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "GRBM_GUI_ACTIVE": 0.0, "SQ_BUSY_CYCLES": 0.0, "rows": 0})
+                e[cn] += float(r["Counter_Value"])
+                e["rows"] += cn == "GRBM_GUI_ACTIVE"
+                short = name.split("(")[0][-120:]
+                k = per_kernel.setdefault(short, {"SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "GRBM_GUI_ACTIVE": 0.0, "dispatches": 0})
+                if cn in k:
+                    k[cn] += float(r["Counter_Value"])
+                k["dispatches"] += cn == "GRBM_GUI_ACTIVE"
+    if not acc:
+        raise SystemExit("no SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE rows found")
+    rep = {"source": f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- {command}",
+           "formula": "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128)", "classes": {}, "kernels": {}}
+    enc_busy = enc_gui = 0.0
+    for label, e in sorted(acc.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"]):
+        util = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * 128.0) if e["GRBM_GUI_ACTIVE"] else 0.0
+        rep["classes"][label] = {"dispatches": e["rows"], "mfma_busy_cycles": e["SQ_VALU_MFMA_BUSY_CYCLES"],
+                                 "gui_active_cycles": e["GRBM_GUI_ACTIVE"], "mfma_util": round(util, 4)}
+        if label.startswith("encoder"):
+            enc_busy += e["SQ_VALU_MFMA_BUSY_CYCLES"]; enc_gui += e["GRBM_GUI_ACTIVE"]
+    for name, k in sorted(per_kernel.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])[:24]:
+        util = k["SQ_VALU_MFMA_BUSY_CYCLES"] / (k["GRBM_GUI_ACTIVE"] * 128.0) if k["GRBM_GUI_ACTIVE"] else 0.0
+        rep["kernels"][name] = {"dispatches": k["dispatches"], "gui_active_cycles": k["GRBM_GUI_ACTIVE"], "mfma_util": round(util, 4)}
+    if enc_gui:
+        rep["encoder_time_weighted_mfma_util"] = round(enc_busy / (enc_gui * 128.0), 4)
+    with open(out, "w") as f:
+        json.dump(rep, f, indent=1)
+    print(json.dumps({"encoder_time_weighted_mfma_util": rep.get("encoder_time_weighted_mfma_util"),
+                      **{k: v["mfma_util"] for k, v in rep["classes"].items()}}))
+
+
 def pmc(d, out, kernel, windows, command):
+    if isinstance(windows, str) and windows.startswith("auto:"):      # windows of a full-batch launch from the bench line
+        line = json.load(open(windows[5:]))
+        total = line["workload_facts"]["decode_last_step"]["windows"]
+        windows = min(int(line["config"]["windows_per_batch"]), int(total))
     vals = []
     for path in find(d, "*counter_collection.csv"):
         with open(path) as f:
@@ -67,6 +123,8 @@ def pmc(d, out, kernel, windows, command):
 if __name__ == "__main__":
     if len(sys.argv) >= 4 and sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif len(sys.argv) >= 5 and sys.argv[1] == "mfma":
+        mfma(sys.argv[2], sys.argv[3], " ".join(sys.argv[4:]))
     elif len(sys.argv) >= 7 and sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], " ".join(sys.argv[6:]))
     else:
