@@ -179,10 +179,12 @@ def roofline_from_stages(stages, dtype, tag_hint=None):
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (port of the reference's upstream math) on a bounded sample
 # ---------------------------------------------------------------------------------------------------------------
-def cpu_baseline_cfg3(dims, w, clips, n_groups, audio_s, max_new, beam, threads):
+def cpu_baseline_cfg3(dims, w, clips, n_groups, audio_s, max_new, beam, threads, step_cap=0, steps_per_window=None):
     """A bounded sample of the recording's VAD groups on this host's cores: log-mel + the full encoder (the sample's
-    windows as one batch) + the cfg3 beam search of every sampled group run to its END (EOT-bearing weights: the search
-    stops on patience like the GPU's), timed whole; the recording costs ``n_groups / len(clips)`` such samples."""
+    windows as one batch) + the cfg3 beam search of every sampled group, to its END (EOT-bearing weights: the search stops
+    on patience like the GPU's) or for ``step_cap`` iterations -- then the decode time per group is scaled from the
+    iterations measured to ``steps_per_window``, the iterations the GPU run's searches actually took per window (stated in
+    the result).  The recording costs ``n_groups / len(clips)`` such samples."""
     from oracle import decoding, logmel, whisper_ref
     torch.set_num_threads(threads)
     oracle = whisper_ref.WhisperOracle(whisper_ref.WhisperDims(**dims.as_dict()), w)
@@ -199,19 +201,28 @@ def cpu_baseline_cfg3(dims, w, clips, n_groups, audio_s, max_new, beam, threads)
         t0 = time.perf_counter()
         for g in range(len(clips)):
             tr = {}
-            hyps, _ = decoding.beam_search(oracle, enc[g:g + 1], prompt, decoding.BeamConfig(beam, 1.2, 1.0, 1.5, 3, max_new),
+            hyps, _ = decoding.beam_search(oracle, enc[g:g + 1], prompt,
+                                           decoding.BeamConfig(beam, 1.2, 1.0, 1.5, 3, min(max_new, step_cap) if step_cap else max_new),
                                            decoding.FilterConfig(max_initial_timestamp_index=0), trace=tr)
             steps.append(tr["steps"]); lens.append(len(hyps[0][0]))
         t_dec = time.perf_counter() - t0
     sample_audio = sum(len(c) for c in clips) / 16000.0
-    total = t_mel + t_enc + t_dec
+    capped = bool(step_cap) and any(st >= step_cap for st in steps)
+    scale = 1.0
+    if capped and steps_per_window:       # measured iterations -> the iterations a search of this workload runs per window
+        scale = steps_per_window * len(clips) / max(1, sum(steps))
+    total = t_mel + t_enc + t_dec * scale
     return {"value": audio_s / (total * n_groups / len(clips)), "unit": UNIT, "cores": threads, "kind": "port",
+            "decode_scaled": ({"measured_steps_per_group": step_cap, "scaled_to_steps_per_window": round(steps_per_window, 1),
+                               "factor": round(scale, 3)} if scale != 1.0 else None),
             "sample_groups": len(clips), "sample_audio_s": round(sample_audio, 2), "sample_seconds": round(total, 2),
             "beam_steps_run": steps, "tokens_of_the_winner": lens, "t_mel_s": round(t_mel, 3), "t_encoder_s": round(t_enc, 2),
             "t_beam_search_s": round(t_dec, 2), "arithmetic": "fp32 (PyTorch-CPU); no int8: the reference's CPU path is CTranslate2 int8 on 4 threads",
             "sample": (f"{len(clips)} of the recording's {n_groups} VAD groups ({sample_audio:.1f} s of audio -> {len(clips)} x 30 s windows): "
-                       f"log-mel + full large-v3-shaped encoder (one batch) + beam-{beam} / patience 1.2 search of every group to its end "
-                       f"({steps} steps), PyTorch-CPU fp32 oracle on {threads} threads; value = recording seconds / (groups x per-group "
+                       f"log-mel + full large-v3-shaped encoder (one batch) + beam-{beam} / patience 1.2 search of every group "
+                       + (f"for {step_cap} iterations (decode time scaled x{scale:.2f} to the {steps_per_window:.1f} iterations per window the GPU run's searches took)"
+                          if scale != 1.0 else "to its end")
+                       + f" ({steps} steps), PyTorch-CPU fp32 oracle on {threads} threads; value = recording seconds / (groups x per-group "
                        f"time); the reference's own CPU pipeline (faster-whisper int8, 4 CT2 threads) cannot run offline -- wheels absent")}
 
 
@@ -487,40 +498,6 @@ def run_cfg3(args, info, dims):
         model.word_reseek = True
         line["word_timestamps"] = {"rtfx": round(60.0 * minutes / tw, 2), "ms": round(1e3 * tw, 1),
                                    "what": "the same step with word_timestamps=True (alignment pass + DTW per window); word-driven re-seek off"}
-        # BASELINE cfg2 on the same model: 384 x 30 s windows, log-mel + encoder + greedy decode of 224 tokens (no VAD)
-        from whisperjav_amd import engine
-        B = args.batch
-        clips = [synth.speech_like(30.0, seed=1234 + i) for i in range(4)]
-        pcm = torch.from_numpy(np.concatenate([clips[i % 4] for i in range(B)])).to(dev)
-        offs = [i * 480000 for i in range(B + 1)]
-        fe = engine.HipLogMel(dims.n_mels, "fw", device=info.local_rank)
-        eng = model.model
-        prompt = np.tile(np.array(eng.sot_prompt("ja", "transcribe"), dtype=np.int32), (B, 1))
-        t = eng.tokens
-        opts = engine.DecodeOptions(max_new_tokens=224, max_initial_timestamp=1.0,
-                                    suppress_tokens=(t.sot, t.translate, t.transcribe, t.sot_lm, t.sot_prev, t.no_speech))
-
-        def cfg2(n, pr, of):
-            eng.encode(fe.from_device(pcm[: of[-1]], of))
-            eng.decode_greedy(pr, opts)
-        cfg2(B, prompt, offs)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        cfg2(B, prompt, offs)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter() - t1
-        line["cfg2_batched"] = {"rtfx": round(30.0 * B / t2, 2), "ms": round(1e3 * t2, 1),
-                                "what": f"BASELINE cfg2 batched: {B} x 30 s windows resident in HBM, log-mel + encoder + greedy 224 tokens, no VAD"}
-        best = float("inf")
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            cfg2(1, prompt[:1], offs[:2])
-            torch.cuda.synchronize()
-            best = min(best, time.perf_counter() - t1)
-        line["single_window"] = {"rtfx": round(30.0 / best, 2), "ms": round(1e3 * best, 2),
-                                 "what": "BASELINE cfg2 read literally: ONE 30 s window, batch 1 (the reference's call pattern): a latency figure"}
-        del pcm
     # the groups of the recording, for the CPU baseline's scaling (before the model goes away)
     n_groups = None
     sample_clips = []
@@ -540,11 +517,51 @@ def run_cfg3(args, info, dims):
     del model, module, runner, dev_blob
     torch.cuda.empty_cache()
 
+    if info.rank == 0 and info.world == 1 and not args.no_extras:
+        # BASELINE cfg2 on the same weights: 384 x 30 s windows, log-mel + encoder + greedy decode of 224 tokens (no VAD); its
+        # own engine (KV cache for 224 tokens; the main one is sized for max_new_tokens)
+        from whisperjav_amd import engine
+        B = min(384, args.batch)
+        blob2, offs2 = pweights.pack_blob_device(dims, box["w"], dtype, dev)
+        eng = engine.HipWhisper(dims, blob=blob2, offsets=offs2, dtype=dtype, device=info.local_rank, max_batch=B, max_beam=1, kv_len=232)
+        clips = [synth.speech_like(30.0, seed=1234 + i) for i in range(4)]
+        pcm = torch.from_numpy(np.concatenate([clips[i % 4] for i in range(B)])).to(dev)
+        offs = [i * 480000 for i in range(B + 1)]
+        fe = engine.HipLogMel(dims.n_mels, "fw", device=info.local_rank)
+        prompt = np.tile(np.array(eng.sot_prompt("ja", "transcribe"), dtype=np.int32), (B, 1))
+        t = eng.tokens
+        opts = engine.DecodeOptions(max_new_tokens=224, max_initial_timestamp=1.0,
+                                    suppress_tokens=(t.sot, t.translate, t.transcribe, t.sot_lm, t.sot_prev, t.no_speech))
+
+        def cfg2(n, pr, of):
+            eng.encode(fe.from_device(pcm[: of[-1]], of))
+            return eng.decode_greedy(pr, opts)
+        cfg2(B, prompt, offs)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        r2 = cfg2(B, prompt, offs)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter() - t1
+        line["cfg2_batched"] = {"rtfx": round(30.0 * B / t2, 2), "ms": round(1e3 * t2, 1), "tokens_per_window_mean": round(float(r2.n_tokens.mean()), 1),
+                                "decode_steps_run": eng.last_decode_info()["steps"],
+                                "what": f"BASELINE cfg2 batched: {B} x 30 s windows resident in HBM, log-mel + encoder + greedy decode (<= 224 tokens, to EOT), no VAD"}
+        best = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cfg2(1, prompt[:1], offs[:2])
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t1)
+        line["single_window"] = {"rtfx": round(30.0 / best, 2), "ms": round(1e3 * best, 2),
+                                 "what": "BASELINE cfg2 read literally: ONE 30 s window, batch 1 (the reference's call pattern): a latency figure"}
+        eng.close()
+        del pcm, eng
+        torch.cuda.empty_cache()
     if info.rank == 0 and info.world == 1 and not args.no_extras and args.mode == "balanced":
         # BASELINE cfg4's mode on one GPU: the fidelity pipeline's classes (openai-whisper mel padding, device-resident
         # BeamSearchDecoder search with beam 2 / patience 1.2, post-model gate) on the same recording, second of two passes
         saved_beam, args.beam = args.beam, 2
-        mf, modf, runf = build_stack(args, info, dims, dtype, args.batch, weights=box["w"], mode="fidelity")
+        mf, modf, runf = build_stack(args, info, dims, dtype, args.batch, blob=blob2, offsets=offs2, mode="fidelity")
         run_recording(runf, audio)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -559,6 +576,7 @@ def run_cfg3(args, info, dims):
                             **sf_}
         del mf, modf, runf
         torch.cuda.empty_cache()
+    blob2 = None
     if info.rank == 0 and info.world == 1 and not args.no_extras:
         # the exact-fp32 compute type (north-star parity type, 1e-5 of the oracle) on a bounded sample of the same recording
         fp32_audio = audio[: int(16000 * 60 * args.fp32_minutes)]
@@ -575,8 +593,11 @@ def run_cfg3(args, info, dims):
         del m32, mod32, run32
         torch.cuda.empty_cache()
     if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
+        dst = (stats or {}).get("decode") or {}
+        spw = dst["window_steps_run"] / dst["windows"] if dst.get("windows") else None
         line["cpu_baseline"] = cpu_baseline_cfg3(dims, box["w"], sample_clips, n_groups, 60.0 * minutes, args.max_new_tokens,
-                                                 args.beam, args.cpu_threads or min(32, os.cpu_count() or 1))
+                                                 args.beam, args.cpu_threads or min(32, os.cpu_count() or 1),
+                                                 step_cap=args.cpu_beam_steps, steps_per_window=spw)
     if info.rank == 0:
         print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
@@ -677,6 +698,8 @@ def main():
     ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16", "float32"])
     ap.add_argument("--fp32-minutes", type=float, default=3.0, help="cfg3: audio minutes of the fp32-mode figure")
     ap.add_argument("--cpu-sample-groups", type=int, default=4, help="cpu_baseline: VAD groups of the recording run on the host")
+    ap.add_argument("--cpu-beam-steps", type=int, default=10, help="cpu_baseline: beam-search iterations measured per group (0 = every group to EOT, "
+                    "~40 s of host time per group); the decode time is scaled to the iterations per window the GPU run took")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cpu_baseline: PyTorch threads (0 = min(32, cores): more threads slow the small decode GEMMs)")
     ap.add_argument("--weights", default="speechlike", choices=["speechlike", "plain"],
                     help="speechlike: EOT-bearing synthetic weights (searches end, token count grows with the audio in the window); plain: never EOT")

@@ -3,7 +3,9 @@
 The decode cross-attention streams 245.8 MB of fp16 K/V per window per step and runs at the HBM ceiling, so halving those
 bytes is the one remaining lever on the dominant kernel.  This runs the fp32 oracle with ONLY the
 cross K/V quantised to fp8 and reports the teacher-forced per-token log-prob error on the large-v3 geometry -- the
-number that decides whether it may ship as a default.  Writes profiles/r02_precision_fp8_kv_cpu.json.
+number that decides whether it may ship as a default.  Writes profiles/r02_precision_fp8_kv_cpu.json; with
+``--speechlike`` (round 3) the weights are ``weights.SPEECHLIKE`` -- PEAKED cross-attention, as in a trained model, and
+searches that end -- on a 6 s clip, and the file is profiles/r03_precision_fp8_kv_speechlike_cpu.json.
 """
 import json
 import os
@@ -39,16 +41,17 @@ class Fp8KV(whisper_ref.WhisperOracle):
 
 
 def main():
+    speechlike = "--speechlike" in sys.argv
     dims = pdims.dims_for("large-v3")
-    audio = synth.speech_like(30.0, seed=1234)
+    audio = synth.speech_like(6.0 if speechlike else 30.0, seed=1234)
     mel = torch.from_numpy(logmel.window_features(audio, 128, "fw")[None])
     toks = pdims.special_tokens(dims.n_vocab)
     prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
     suppress = (1, 2, 7, 8, 9, 10, 14, 25, toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
     cfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=50)
-    w = pweights.synth_weights(dims, seed=1234, exact="float16")
+    w = pweights.synth_weights(dims, seed=1234, exact="float16", **(pweights.SPEECHLIKE if speechlike else {}))
     ref = whisper_ref.WhisperOracle(helpers.oracle_dims(dims), w)
-    out = {"what": __doc__.split("\n\n")[0], "cases": []}
+    out = {"what": __doc__.split("\n\n")[0], "weights": "SPEECHLIKE (peaked cross-attention)" if speechlike else "plain", "cases": []}
     with torch.no_grad():
         enc = ref.encode(mel)
         res = decoding.greedy_decode(ref, enc, prompt, 32, cfg)
@@ -64,10 +67,11 @@ def main():
             d = (lp_e[pos, idx] - lp_ref[pos, idx]).abs()
             flips = int((lp_e[pos].argmax(-1) != lp_ref[pos].argmax(-1)).sum())
             case = {"fp8_tensors": which, "token_logprob_max_abs": float(d.max()), "token_logprob_mean_abs": float(d.mean()),
-                    "argmax_flips_of_32": flips}
+                    "argmax_flips": flips, "tokens": int(len(idx))}
             out["cases"].append(case)
             print(json.dumps(case), flush=True)
-    with open(os.path.join(ROOT, "profiles", "r02_precision_fp8_kv_cpu.json"), "w") as f:
+    name = "r03_precision_fp8_kv_speechlike_cpu.json" if speechlike else "r02_precision_fp8_kv_cpu.json"
+    with open(os.path.join(ROOT, "profiles", name), "w") as f:
         json.dump(out, f, indent=1)
 
 
