@@ -269,6 +269,8 @@ class HipWhisperModel:
     # weights the alignment is noise and that re-seek multiplies the windows, so bench.py switches it off for its
     # word-timestamp figure (and says so); everything else keeps upstream's behaviour
     word_reseek = True
+    bucket_by_length = True      # transcribe_many: batches are formed from windows of similar content length
+    decode_stats = None          # counters of the decode calls, see reset_decode_stats()
 
     def __init__(self, model_size_or_path: str = "large-v3", device: str = "cuda", device_index: int = 0,
                  compute_type: str = "float16", cpu_threads: int = 0, num_workers: int = 1,
@@ -307,7 +309,6 @@ class HipWhisperModel:
         self.seed = 0               # base seed of the device sampler's counter-based generator
         self.device_beam = True     # beam search on the device (False: host-driven search.py over the step API)
         self._sample_calls = 0
-        self.bucket_by_length = True     # transcribe_many: batches are formed from windows of similar content length
 
     # ---- loading ---------------------------------------------------------------------------
     def _load_checkpoint(self, path: str):
@@ -384,9 +385,9 @@ class HipWhisperModel:
             prompt.append(t.sot_prev)
             if hot:
                 ht = self.tokenizer.encode(" " + hot.strip())
-                prompt.extend(ht[: self.n_text_ctx // 2 - 1])
+                prompt.extend(ht[: self._n_text_ctx() // 2 - 1])
             if previous:
-                prompt.extend(list(previous)[-(self.n_text_ctx // 2 - 1):])
+                prompt.extend(list(previous)[-(self._n_text_ctx() // 2 - 1):])
         lang = language or o.language or "ja"
         prompt.extend([t.sot, t.language_token(pdims.language_index(lang)),
                        t.transcribe if o.task == "transcribe" else t.translate])
@@ -396,13 +397,13 @@ class HipWhisperModel:
             pt = self.tokenizer.encode(" " + o.prefix.strip())
             if not o.without_timestamps:
                 prompt.append(t.timestamp_begin)
-            prompt.extend(pt[: self.n_text_ctx // 2 - 1])
+            prompt.extend(pt[: self._n_text_ctx() // 2 - 1])
         return prompt
 
     # ---- decoding of one batch of windows ------------------------------------------------------
     def _max_new(self, o: TranscribeOptions, P: int) -> int:
         if self.FLAVOR == "ow":
-            max_new = self.n_text_ctx // 2                      # DecodingOptions.sample_len default
+            max_new = self._n_text_ctx() // 2                      # DecodingOptions.sample_len default
             if o.max_new_tokens is not None:
                 max_new = min(max_new, int(o.max_new_tokens))
         else:
@@ -417,6 +418,10 @@ class HipWhisperModel:
         if self.FLAVOR == "ow":
             return sum_lp / (n if lp is None else ((5 + n) / 6) ** float(lp))
         return sum_lp / (n ** float(1.0 if lp is None else lp))
+
+    def _n_text_ctx(self) -> int:
+        """The model's text context (prompt truncation, whisper's sample_len default) -- not the KV positions of this engine."""
+        return int(getattr(self, "n_text_ctx", None) or self.max_length)
 
     def reset_decode_stats(self) -> None:
         """Counters over the decode calls since the last reset (bench.py reports them: realised tokens per window,
