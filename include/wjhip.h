@@ -226,6 +226,41 @@ int wj_whisper_decode_beam_openai(wj_whisper* m, int batch, int beam, const int3
                                   int32_t* tokens_out, int32_t* n_tokens_out, float* score_out, float* sum_logprob_out,
                                   float* no_speech_prob_out, void* stream);
 
+/* ---- Qwen3 text decoder (the LLM of Qwen3-ASR; BASELINE cfg5, SURVEY.md 8f-3: first correct path) ---------------------
+ * Replaces (un-vendored upstream): the `qwen_asr` package's generation loop behind QwenASR.transcribe
+ * (whisperjav/modules/qwen_asr.py:638-757; checkpoints Qwen/Qwen3-ASR-1.7B and Qwen3-ForcedAligner-0.6B named at :192-193),
+ * i.e. what a TextGenerator (whisperjav/modules/subtitle_pipeline/protocols.py:60-110) runs per VAD group.  RMSNorm, fused
+ * QKV projection, per-head RMSNorm on q / k, rotary embedding (rotate-half), grouped-query causal attention with head_dim
+ * 128, SwiGLU MLP, tied LM head.  The prompt enters as EMBEDDINGS (fp32, device, rows of all sequences packed back to
+ * back), so audio embeddings -- the projected output of the audio tower, not part of this slice -- simply replace the rows
+ * of the <audio> placeholder tokens.
+ * Blob: matrices [out][in] row-major in the compute type, vectors fp32, every tensor 256-byte aligned, offsets in the order
+ * of the enumerators below (globals, then WJ_QL_* per layer).  QKV = q rows, then k rows, then v rows; GATEUP = gate rows,
+ * then up rows. */
+typedef struct wj_qwen wj_qwen;
+typedef struct {
+  int32_t hidden, n_layer, n_head, n_kv_head, head_dim, ffn, vocab;
+  float rope_theta, rms_eps;
+} wj_qwen_dims;
+enum { WJ_Q_EMBED = 0, WJ_Q_NORM_W, WJ_Q_N_GLOBAL };
+enum { WJ_QL_LN1_W = 0, WJ_QL_QKV_W, WJ_QL_QNORM_W, WJ_QL_KNORM_W, WJ_QL_O_W, WJ_QL_LN2_W, WJ_QL_GATEUP_W, WJ_QL_DOWN_W, WJ_QL_N };
+/* max_seqs sequences of up to max_ctx positions (KV cache [layer][seq][kv_head][max_ctx][128] x 2), max_rows = packed
+ * prompt tokens of one prefill call */
+int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void* blob_dev, size_t blob_bytes,
+                   const int64_t* offsets_host, int n_offsets, int max_seqs, int max_ctx, int max_rows, wj_qwen** out);
+int wj_qwen_free(wj_qwen* m);
+/* token embeddings (fp32 [n][hidden], device) of n host token ids: the caller scatters its audio rows over the result */
+int wj_qwen_embed(wj_qwen* m, const int32_t* tokens_host, int n, float* out_dev, void* stream);
+/* Runs the prompts of n_seqs sequences (embeds_dev: fp32 [sum(n_tokens)][hidden], sequence after sequence) through the
+ * decoder, fills the KV caches and leaves every sequence at the position after its prompt.  logits_out_dev (may be NULL):
+ * fp32 [n_seqs][vocab] logits of every sequence's last prompt position. */
+int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32_t* n_tokens_host, float* logits_out_dev, void* stream);
+/* Greedy continuation of the prefilled sequences until one of the EOS ids (not stored) or max_new tokens.  Host outputs:
+ * tokens_out [n_seqs][max_new], n_tokens_out [n_seqs], token_logprob_out [n_seqs][max_new + 1] (may be NULL; entry n of a
+ * sequence that stopped at EOS after n tokens is the EOS token's log-prob). */
+int wj_qwen_generate_greedy(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, int max_new, int32_t* tokens_out, int32_t* n_tokens_out,
+                            float* token_logprob_out, void* stream);
+
 /* Word-timestamp alignment.  Replaces: ctranslate2 Whisper.align (faster_whisper.transcribe.WhisperModel
  * .find_alignment, reached with word_timestamps=True from faster_whisper_pro_asr.py:819) and whisper/timing.py
  * find_alignment (whisper_pro_asr.py:433).  Teacher-forced decoder pass over tokens_host [batch][n_tokens_max]

@@ -1,0 +1,440 @@
+// qwen.hip -- Qwen3 text decoder (the LLM of Qwen3-ASR, SURVEY.md 8f-3 / BASELINE cfg5): first correct path.
+//
+// Replaces (reference, un-vendored): the ``qwen_asr`` package's generate() behind
+// whisperjav/modules/qwen_asr.py:638-757 (checkpoints named at :192-193).  Architecture as published and as restated in
+// oracle/qwen3_ref.py (pinned against transformers.models.qwen3_asr): RMSNorm, fused QKV projection, per-head RMSNorm on q / k,
+// rotary position embedding (rotate-half), grouped-query causal attention (head_dim 128), SwiGLU MLP, tied LM head.
+// The audio embeddings enter as rows of the prompt's embedding matrix (wj_qwen_prefill takes EMBEDDINGS, not token ids), so
+// the same entry points serve text-only and audio-conditioned prompts.
+//
+// Layout: sequences are PACKED -- row m belongs to sequence row_seq[m] at position row_pos[m] -- so ragged prompts cost no
+// padding; K / V caches are [layer][sequence][kv_head][position][128] in the compute type; the residual stream is fp32.
+// GEMMs are the library's (gemm.hip: MFMA tile / skinny kernels, exact fp32 kernel) through launch_gemm; the kernels here
+// are the glue a decoder-only LLM adds: RMSNorm, q/k-norm + RoPE + cache append, GQA attention, SwiGLU, row gather, advance.
+// What bounds them at scale (not yet measured: this is the parity slice): the decode step streams 3.4 GB of fp16 weights
+// for the 1.7 B model, i.e. it is HBM-bound on the GEMMs, not on these kernels.
+#include <algorithm>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace wj;
+
+namespace {
+
+constexpr int HD = 128;   // head_dim of every published Qwen3 size
+
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ out,
+                                                      int M, int D, float eps) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * D;
+  float ss = 0.f;
+  for (int c = lane; c < D; c += 64) ss += xr[c] * xr[c];
+  const float r = rsqrtf(wave_sum(ss) / (float)D + eps);
+  T* o = out + (int64_t)row * D;
+  for (int c = lane; c < D; c += 64) Elem<T>::st(o + c, w[c] * (xr[c] * r));
+}
+
+// One wave per (row, head slot): slots 0..H-1 = query heads, H..H+KV-1 = key heads, H+KV.. = value heads of the fused
+// projection.  q / k: RMSNorm over the 128 dims, then RoPE in the rotate-half convention (lane i owns dims i and i + 64,
+// the two halves of one rotation pair); k and v go to the caches at (sequence, position).
+template <typename T>
+__global__ __launch_bounds__(64) void qk_norm_rope_kernel(const T* __restrict__ qkv, const float* __restrict__ q_w,
+                                                          const float* __restrict__ k_w, const int32_t* __restrict__ row_seq,
+                                                          const int32_t* __restrict__ row_pos, T* __restrict__ q_out,
+                                                          T* __restrict__ kc, T* __restrict__ vc, int H, int KV, int ctx,
+                                                          float log2_theta, float eps) {
+  const int m = blockIdx.x, slot = blockIdx.y, lane = threadIdx.x;
+  const int W = (H + 2 * KV) * HD;
+  const T* src = qkv + (int64_t)m * W + (int64_t)slot * HD;
+  float a = Elem<T>::ld(src + lane), b = Elem<T>::ld(src + lane + 64);
+  const int b_seq = row_seq[m], pos = row_pos[m];
+  if (slot >= H + KV) {      // value head: straight to the cache
+    T* dst = vc + (((int64_t)b_seq * KV + (slot - H - KV)) * ctx + pos) * HD;
+    Elem<T>::st(dst + lane, a); Elem<T>::st(dst + lane + 64, b);
+    return;
+  }
+  const float* w = slot < H ? q_w : k_w;
+  const float r = rsqrtf(wave_sum(a * a + b * b) / (float)HD + eps);
+  a = w[lane] * (a * r); b = w[lane + 64] * (b * r);
+  const float inv_freq = exp2f(-(float)(2 * lane) / (float)HD * log2_theta);
+  float sn, cs;
+  sincosf((float)pos * inv_freq, &sn, &cs);
+  const float ra = a * cs - b * sn, rb = b * cs + a * sn;
+  T* dst = slot < H ? q_out + ((int64_t)m * H + slot) * HD : kc + (((int64_t)b_seq * KV + (slot - H)) * ctx + pos) * HD;
+  Elem<T>::st(dst + lane, ra); Elem<T>::st(dst + lane + 64, rb);
+}
+
+// Causal grouped-query attention, one wave per (row, query head).  Keys are taken 64 at a time: lane j scores key
+// base + j against the whole query (q broadcast from LDS), an online softmax keeps (max, sum) across chunks, and the
+// weighted values are accumulated with lane i owning output dims i and i + 64 (each key's V row is one coalesced read).
+template <typename T>
+__global__ __launch_bounds__(64) void gqa_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
+                                                      const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_pos,
+                                                      T* __restrict__ out, int H, int KV, int ctx) {
+  __shared__ float sq[HD];
+  const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  const int b_seq = row_seq[m], n_keys = row_pos[m] + 1, kvh = h / (H / KV);
+  const T* qr = q + ((int64_t)m * H + h) * HD;
+  sq[lane] = Elem<T>::ld(qr + lane); sq[lane + 64] = Elem<T>::ld(qr + lane + 64);
+  __syncthreads();
+  const T* Kb = kc + ((int64_t)b_seq * KV + kvh) * (int64_t)ctx * HD;
+  const T* Vb = vc + ((int64_t)b_seq * KV + kvh) * (int64_t)ctx * HD;
+  const float scale = rsqrtf((float)HD);
+  float run_max = -INFINITY, run_sum = 0.f, acc0 = 0.f, acc1 = 0.f;
+  for (int base = 0; base < n_keys; base += 64) {
+    const int j = base + lane;
+    float s = -INFINITY;
+    if (j < n_keys) {
+      const T* kr = Kb + (int64_t)j * HD;
+      float d = 0.f;
+#pragma unroll 4
+      for (int c = 0; c < HD; c += 8) {
+        float kv[8];
+        ld8(kr + c, kv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf(sq[c + e], kv[e], d);
+      }
+      s = d * scale;
+    }
+    const float new_max = fmaxf(run_max, wave_max(s));
+    const float corr = expf(run_max - new_max);       // exp(-inf) = 0 on the first chunk
+    const float p = j < n_keys ? expf(s - new_max) : 0.f;
+    run_sum = run_sum * corr + wave_sum(p);
+    acc0 *= corr; acc1 *= corr;
+    const int n_here = min(64, n_keys - base);
+    for (int jj = 0; jj < n_here; ++jj) {
+      const float pj = __shfl(p, jj, 64);
+      const T* vr = Vb + (int64_t)(base + jj) * HD;
+      acc0 = fmaf(pj, Elem<T>::ld(vr + lane), acc0);
+      acc1 = fmaf(pj, Elem<T>::ld(vr + lane + 64), acc1);
+    }
+    run_max = new_max;
+  }
+  T* o = out + ((int64_t)m * H + h) * HD;
+  const float inv = 1.f / run_sum;
+  Elem<T>::st(o + lane, acc0 * inv); Elem<T>::st(o + lane + 64, acc1 * inv);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gu, T* __restrict__ out, int M, int F) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)M * F) return;
+  const int64_t m = i / F, c = i - m * F;
+  const float g = Elem<T>::ld(gu + m * 2 * F + c), u = Elem<T>::ld(gu + m * 2 * F + F + c);
+  Elem<T>::st(out + i, g / (1.f + expf(-g)) * u);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_rows_kernel(const T* __restrict__ emb, const int32_t* __restrict__ tokens,
+                                                         float* __restrict__ out, int D) {
+  const int m = blockIdx.x;
+  const T* e = emb + (int64_t)tokens[m] * D;
+  for (int c = threadIdx.x; c < D; c += 256) out[(int64_t)m * D + c] = Elem<T>::ld(e + c);
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ rows,
+                                                          float* __restrict__ out, int D) {
+  const int m = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += 256) out[(int64_t)m * D + c] = x[(int64_t)rows[m] * D + c];
+}
+
+// After the logits of a decode step: record the arg-max token and its log-prob, stop a sequence at an EOS id, advance
+// its position.  `next_tok` feeds the embedding lookup of the following step.
+__global__ void advance_kernel(const int32_t* __restrict__ top_id, const float* __restrict__ top_lp, const int32_t* __restrict__ eos,
+                               int n_eos, int32_t* __restrict__ finished, int32_t* __restrict__ n_out, int32_t* __restrict__ row_pos,
+                               int32_t* __restrict__ next_tok, int32_t* __restrict__ tokens_out, float* __restrict__ lp_out,
+                               int max_new, int n_seqs, int ctx, int first) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= n_seqs) return;
+  if (!first) row_pos[b] = min(row_pos[b] + 1, ctx - 1);       // the token fed this step now occupies its position
+  if (finished[b]) return;
+  const int t = top_id[b];
+  const int n = n_out[b];
+  lp_out[(int64_t)b * (max_new + 1) + n] = top_lp[b];
+  bool stop = false;
+  for (int e = 0; e < n_eos; ++e) stop |= t == eos[e];
+  if (stop || n >= max_new) { finished[b] = 1; return; }
+  tokens_out[(int64_t)b * max_new + n] = t;
+  n_out[b] = n + 1;
+  next_tok[b] = t;
+}
+
+}  // namespace
+
+struct wj_qwen {
+  wj_ctx* ctx = nullptr;
+  wj_qwen_dims d{};
+  int dtype = WJ_F16;
+  size_t esz = 2;
+  const char* blob = nullptr;
+  std::vector<int64_t> off;
+  int max_seqs = 0, max_ctx = 0, max_rows = 0;
+  std::vector<void*> allocs;
+  float* x = nullptr;        // f32 [rows][D] residual stream
+  void* h = nullptr;         // T   [rows][D]
+  void* qkv = nullptr;       // T   [rows][(H + 2 KV) * 128]
+  void* q = nullptr;         // T   [rows][H][128]
+  void* attn = nullptr;      // T   [rows][H * 128]
+  void* gu = nullptr;        // T   [rows][2 F]
+  void* act = nullptr;       // T   [rows][F]
+  void* kc = nullptr;        // T   [L][seqs][KV][ctx][128]
+  void* vc = nullptr;
+  float* xl = nullptr;       // f32 [seqs][D] rows that produce logits
+  float* logits = nullptr;   // f32 [seqs][ldl]
+  int64_t ldl = 0;
+  int32_t *row_seq = nullptr, *row_pos = nullptr, *last_rows = nullptr, *next_tok = nullptr, *finished = nullptr, *n_out = nullptr;
+  int32_t *top_id = nullptr, *tokens_out = nullptr, *eos = nullptr;
+  float *top_lp = nullptr, *top_lse = nullptr, *lp_out = nullptr;
+  int n_seqs = 0;            // sequences of the last prefill
+  const void* W(int i) const { return blob + off[i]; }
+  const float* F(int i) const { return reinterpret_cast<const float*>(blob + off[i]); }
+  int layer_base(int l) const { return WJ_Q_N_GLOBAL + l * WJ_QL_N; }
+  void* at(void* base, int64_t elems) const { return reinterpret_cast<char*>(base) + elems * (int64_t)esz; }
+};
+
+namespace {
+
+#define WJ_TRYQ(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+#define TP(T, p) reinterpret_cast<T*>(p)
+
+// rows [0, M) through every decoder layer; row_seq / row_pos describe them
+int run_layers(wj_qwen* m, int M, hipStream_t s) {
+  const wj_qwen_dims& d = m->d;
+  const int D = d.hidden, H = d.n_head, KV = d.n_kv_head, F = d.ffn, dt = m->dtype;
+  const int W = (H + 2 * KV) * HD;
+  const int64_t layer_kv = (int64_t)m->max_seqs * KV * m->max_ctx * HD;
+  for (int l = 0; l < d.n_layer; ++l) {
+    const int b0 = m->layer_base(l);
+    void* kc = m->at(m->kc, l * layer_kv);
+    void* vc = m->at(m->vc, l * layer_kv);
+    auto rms = [&](const float* w, void* out) -> int {
+      if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(ceil_div(M, 4)), dim3(256), 0, s, m->x, w, TP(float, out), M, D, d.rms_eps);
+      else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(ceil_div(M, 4)), dim3(256), 0, s, m->x, w, TP(f16_t, out), M, D, d.rms_eps);
+      else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(ceil_div(M, 4)), dim3(256), 0, s, m->x, w, TP(bf16_t, out), M, D, d.rms_eps);
+      WJ_LAUNCH_CHECK();
+      return WJ_OK;
+    };
+    WJ_TRYQ(rms(m->F(b0 + WJ_QL_LN1_W), m->h));
+    {
+      GemmArgs g;
+      g.A = m->h; g.lda = D; g.W = m->W(b0 + WJ_QL_QKV_W); g.ldw = D; g.M = M; g.N = W; g.K = D; g.out = m->qkv; g.ldc = W;
+      WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, 0));
+    }
+    const float l2t = log2f(d.rope_theta);
+    if (dt == WJ_F32)
+      hipLaunchKernelGGL((qk_norm_rope_kernel<float>), dim3(M, H + 2 * KV), dim3(64), 0, s, TP(const float, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
+                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(float, m->q), TP(float, kc), TP(float, vc), H, KV, m->max_ctx, l2t, d.rms_eps);
+    else if (dt == WJ_F16)
+      hipLaunchKernelGGL((qk_norm_rope_kernel<f16_t>), dim3(M, H + 2 * KV), dim3(64), 0, s, TP(const f16_t, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
+                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(f16_t, m->q), TP(f16_t, kc), TP(f16_t, vc), H, KV, m->max_ctx, l2t, d.rms_eps);
+    else
+      hipLaunchKernelGGL((qk_norm_rope_kernel<bf16_t>), dim3(M, H + 2 * KV), dim3(64), 0, s, TP(const bf16_t, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
+                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(bf16_t, m->q), TP(bf16_t, kc), TP(bf16_t, vc), H, KV, m->max_ctx, l2t, d.rms_eps);
+    WJ_LAUNCH_CHECK();
+    if (dt == WJ_F32)
+      hipLaunchKernelGGL((gqa_attn_kernel<float>), dim3(M, H), dim3(64), 0, s, TP(const float, m->q), TP(const float, kc), TP(const float, vc),
+                         m->row_seq, m->row_pos, TP(float, m->attn), H, KV, m->max_ctx);
+    else if (dt == WJ_F16)
+      hipLaunchKernelGGL((gqa_attn_kernel<f16_t>), dim3(M, H), dim3(64), 0, s, TP(const f16_t, m->q), TP(const f16_t, kc), TP(const f16_t, vc),
+                         m->row_seq, m->row_pos, TP(f16_t, m->attn), H, KV, m->max_ctx);
+    else
+      hipLaunchKernelGGL((gqa_attn_kernel<bf16_t>), dim3(M, H), dim3(64), 0, s, TP(const bf16_t, m->q), TP(const bf16_t, kc), TP(const bf16_t, vc),
+                         m->row_seq, m->row_pos, TP(bf16_t, m->attn), H, KV, m->max_ctx);
+    WJ_LAUNCH_CHECK();
+    {
+      GemmArgs g;
+      g.A = m->attn; g.lda = H * HD; g.W = m->W(b0 + WJ_QL_O_W); g.ldw = H * HD; g.M = M; g.N = D; g.K = H * HD; g.out = m->x; g.ldc = D;
+      WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, 0));
+    }
+    WJ_TRYQ(rms(m->F(b0 + WJ_QL_LN2_W), m->h));
+    {
+      GemmArgs g;
+      g.A = m->h; g.lda = D; g.W = m->W(b0 + WJ_QL_GATEUP_W); g.ldw = D; g.M = M; g.N = 2 * F; g.K = D; g.out = m->gu; g.ldc = 2 * F;
+      WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, 0));
+    }
+    {
+      const dim3 grid((unsigned)ceil_div64((int64_t)M * F, 256));
+      if (dt == WJ_F32) hipLaunchKernelGGL((swiglu_kernel<float>), grid, dim3(256), 0, s, TP(const float, m->gu), TP(float, m->act), M, F);
+      else if (dt == WJ_F16) hipLaunchKernelGGL((swiglu_kernel<f16_t>), grid, dim3(256), 0, s, TP(const f16_t, m->gu), TP(f16_t, m->act), M, F);
+      else hipLaunchKernelGGL((swiglu_kernel<bf16_t>), grid, dim3(256), 0, s, TP(const bf16_t, m->gu), TP(bf16_t, m->act), M, F);
+      WJ_LAUNCH_CHECK();
+    }
+    {
+      GemmArgs g;
+      g.A = m->act; g.lda = F; g.W = m->W(b0 + WJ_QL_DOWN_W); g.ldw = F; g.M = M; g.N = D; g.K = F; g.out = m->x; g.ldc = D;
+      WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, 0));
+    }
+  }
+  return WJ_OK;
+}
+
+// final RMSNorm + tied LM head for `n` rows of `xin` (f32 [n][D]) -> m->logits, then arg-max + log-prob per row
+int run_head(wj_qwen* m, const float* xin, int n, hipStream_t s) {
+  const wj_qwen_dims& d = m->d;
+  const int D = d.hidden, dt = m->dtype;
+  if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(ceil_div(n, 4)), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(float, m->h), n, D, d.rms_eps);
+  else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(ceil_div(n, 4)), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(f16_t, m->h), n, D, d.rms_eps);
+  else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(ceil_div(n, 4)), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(bf16_t, m->h), n, D, d.rms_eps);
+  WJ_LAUNCH_CHECK();
+  GemmArgs g;
+  g.A = m->h; g.lda = D; g.W = m->W(WJ_Q_EMBED); g.ldw = D; g.M = n; g.N = d.vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
+  WJ_TRYQ(launch_gemm(dt, EPI_F32, g, s, 0));
+  return launch_topk_logprob(m->logits, m->ldl, n, d.vocab, 1, nullptr, m->top_id, m->top_lp, m->top_lse, s);
+}
+
+int qalloc(wj_qwen* m, void** p, size_t bytes) {
+  bytes = align_up(bytes ? bytes : 256, 256);
+  WJ_HIP(hipMalloc(p, bytes));
+  m->allocs.push_back(*p);
+  WJ_HIP(hipMemsetAsync(*p, 0, bytes, m->ctx->stream));
+  return WJ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wj_qwen_free(wj_qwen* m) {
+  if (!m) return WJ_OK;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  for (void* p : m->allocs) (void)hipFree(p);
+  delete m;
+  return WJ_OK;
+}
+
+int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void* blob_dev, size_t blob_bytes,
+                   const int64_t* offsets_host, int n_offsets, int max_seqs, int max_ctx, int max_rows, wj_qwen** out) {
+  WJ_REQUIRE(ctx && dims && blob_dev && offsets_host && out, "wj_qwen_create: NULL argument");
+  const wj_qwen_dims& d = *dims;
+  WJ_REQUIRE(d.head_dim == HD, "wj_qwen_create: head_dim %d (the kernels are specialised for 128, every published Qwen3 size)", d.head_dim);
+  WJ_REQUIRE(d.hidden > 0 && d.hidden % 8 == 0 && d.ffn % 8 == 0 && d.n_head >= 1 && d.n_kv_head >= 1 && d.n_head % d.n_kv_head == 0 &&
+             d.n_layer >= 1 && d.vocab >= 2, "wj_qwen_create: bad dimensions");
+  WJ_REQUIRE(dtype == WJ_F32 || dtype == WJ_F16 || dtype == WJ_BF16, "wj_qwen_create: unknown dtype %d", dtype);
+  WJ_REQUIRE(n_offsets == WJ_Q_N_GLOBAL + d.n_layer * WJ_QL_N, "wj_qwen_create: %d tensor offsets expected, got %d",
+             WJ_Q_N_GLOBAL + d.n_layer * WJ_QL_N, n_offsets);
+  WJ_REQUIRE(max_seqs >= 1 && max_ctx >= 8 && max_rows >= max_seqs, "wj_qwen_create: need max_rows >= max_seqs >= 1 and max_ctx >= 8");
+  for (int i = 0; i < n_offsets; ++i)
+    WJ_REQUIRE(offsets_host[i] >= 0 && (size_t)offsets_host[i] < blob_bytes && offsets_host[i] % 16 == 0, "wj_qwen_create: bad offset %d", i);
+  WJ_HIP(hipSetDevice(ctx->device));
+  wj_qwen* m = new wj_qwen();
+  m->ctx = ctx; m->d = d; m->dtype = dtype; m->esz = dtype_size(dtype);
+  m->blob = reinterpret_cast<const char*>(blob_dev);
+  m->off.assign(offsets_host, offsets_host + n_offsets);
+  m->max_seqs = max_seqs; m->max_ctx = max_ctx; m->max_rows = max_rows;
+  const size_t e = m->esz, R = max_rows, S = max_seqs;
+  const int D = d.hidden, H = d.n_head, KV = d.n_kv_head, F = d.ffn;
+  m->ldl = (d.vocab + 63) / 64 * 64;
+  int rc = 0;
+#define QA(field, bytes) do { if (!rc) rc = qalloc(m, reinterpret_cast<void**>(&m->field), (bytes)); } while (0)
+  QA(x, R * D * sizeof(float)); QA(h, R * D * e); QA(qkv, R * (size_t)(H + 2 * KV) * HD * e); QA(q, R * (size_t)H * HD * e);
+  QA(attn, R * (size_t)H * HD * e); QA(gu, R * 2 * (size_t)F * e); QA(act, R * (size_t)F * e);
+  QA(kc, (size_t)d.n_layer * S * KV * max_ctx * HD * e); QA(vc, (size_t)d.n_layer * S * KV * max_ctx * HD * e);
+  QA(xl, S * D * sizeof(float)); QA(logits, S * m->ldl * sizeof(float));
+  QA(row_seq, R * 4); QA(row_pos, R * 4); QA(last_rows, S * 4); QA(next_tok, S * 4); QA(finished, S * 4); QA(n_out, S * 4);
+  QA(top_id, S * 4); QA(top_lp, S * 4); QA(top_lse, S * 4); QA(eos, 64);
+#undef QA
+  if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error("wj_qwen_create: allocation failed"); rc = WJ_E_HIP; }
+  if (rc) { wj_qwen_free(m); return rc; }
+  *out = m;
+  return WJ_OK;
+}
+
+int wj_qwen_embed(wj_qwen* m, const int32_t* tokens_host, int n, float* out_dev, void* stream) {
+  WJ_REQUIRE(m && tokens_host && out_dev && n >= 1 && n <= m->max_rows, "wj_qwen_embed: bad argument (n = %d, max_rows %d)", n, m ? m->max_rows : 0);
+  for (int i = 0; i < n; ++i) WJ_REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < m->d.vocab, "wj_qwen_embed: token %d out of range", tokens_host[i]);
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  WJ_HIP(hipMemcpyAsync(m->row_seq, tokens_host, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));     // staging
+  if (m->dtype == WJ_F32) hipLaunchKernelGGL((embed_rows_kernel<float>), dim3(n), dim3(256), 0, s, TP(const float, m->W(WJ_Q_EMBED)), m->row_seq, out_dev, m->d.hidden);
+  else if (m->dtype == WJ_F16) hipLaunchKernelGGL((embed_rows_kernel<f16_t>), dim3(n), dim3(256), 0, s, TP(const f16_t, m->W(WJ_Q_EMBED)), m->row_seq, out_dev, m->d.hidden);
+  else hipLaunchKernelGGL((embed_rows_kernel<bf16_t>), dim3(n), dim3(256), 0, s, TP(const bf16_t, m->W(WJ_Q_EMBED)), m->row_seq, out_dev, m->d.hidden);
+  WJ_LAUNCH_CHECK();
+  WJ_HIP(hipStreamSynchronize(s));
+  return WJ_OK;
+}
+
+int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32_t* n_tokens_host, float* logits_out_dev, void* stream) {
+  WJ_REQUIRE(m && embeds_dev && n_tokens_host, "wj_qwen_prefill: NULL argument");
+  WJ_REQUIRE(n_seqs >= 1 && n_seqs <= m->max_seqs, "wj_qwen_prefill: %d sequences (max %d)", n_seqs, m->max_seqs);
+  std::vector<int32_t> seq, pos, last(n_seqs);
+  for (int b = 0; b < n_seqs; ++b) {
+    WJ_REQUIRE(n_tokens_host[b] >= 1 && n_tokens_host[b] < m->max_ctx, "wj_qwen_prefill: sequence %d has %d tokens (context %d)", b,
+               n_tokens_host[b], m->max_ctx);
+    for (int t = 0; t < n_tokens_host[b]; ++t) { seq.push_back(b); pos.push_back(t); }
+    last[b] = (int32_t)seq.size() - 1;
+  }
+  const int M = (int)seq.size();
+  WJ_REQUIRE(M <= m->max_rows, "wj_qwen_prefill: %d prompt tokens in all (max_rows %d)", M, m->max_rows);
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  WJ_HIP(hipMemcpyAsync(m->row_seq, seq.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(m->row_pos, pos.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(m->last_rows, last.data(), sizeof(int32_t) * n_seqs, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(m->x, embeds_dev, sizeof(float) * (size_t)M * m->d.hidden, hipMemcpyDeviceToDevice, s));   // packed rows
+  WJ_TRYQ(run_layers(m, M, s));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n_seqs), dim3(256), 0, s, m->x, m->last_rows, m->xl, m->d.hidden);
+  WJ_LAUNCH_CHECK();
+  WJ_TRYQ(run_head(m, m->xl, n_seqs, s));
+  if (logits_out_dev)
+    WJ_HIP(hipMemcpy2DAsync(logits_out_dev, sizeof(float) * m->d.vocab, m->logits, sizeof(float) * m->ldl, sizeof(float) * m->d.vocab, n_seqs,
+                            hipMemcpyDeviceToDevice, s));
+  // decode state: one row per sequence from here on, at the position after the prompt
+  std::vector<int32_t> ids(n_seqs), p1(n_seqs);
+  for (int b = 0; b < n_seqs; ++b) { ids[b] = b; p1[b] = n_tokens_host[b]; }
+  WJ_HIP(hipStreamSynchronize(s));
+  WJ_HIP(hipMemcpyAsync(m->row_seq, ids.data(), sizeof(int32_t) * n_seqs, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(m->row_pos, p1.data(), sizeof(int32_t) * n_seqs, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipStreamSynchronize(s));
+  m->n_seqs = n_seqs;
+  return WJ_OK;
+}
+
+int wj_qwen_generate_greedy(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, int max_new, int32_t* tokens_out, int32_t* n_tokens_out,
+                            float* token_logprob_out, void* stream) {
+  WJ_REQUIRE(m && eos_ids_host && tokens_out && n_tokens_out, "wj_qwen_generate_greedy: NULL argument");
+  WJ_REQUIRE(m->n_seqs >= 1, "wj_qwen_generate_greedy: call wj_qwen_prefill first");
+  WJ_REQUIRE(n_eos >= 1 && n_eos <= 16 && max_new >= 1, "wj_qwen_generate_greedy: 1..16 EOS ids and max_new >= 1");
+  const int S = m->n_seqs;
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  int32_t* d_tok = nullptr;
+  float* d_lp = nullptr;
+  WJ_HIP(hipMalloc(&d_tok, sizeof(int32_t) * (size_t)S * max_new));
+  if (hipMalloc(&d_lp, sizeof(float) * (size_t)S * (max_new + 1)) != hipSuccess) { (void)hipFree(d_tok); set_error("wj_qwen_generate_greedy: out of memory"); return WJ_E_HIP; }
+  struct Guard { int32_t* a; float* b; ~Guard() { (void)hipFree(a); (void)hipFree(b); } } guard{d_tok, d_lp};
+  WJ_HIP(hipMemsetAsync(d_tok, 0, sizeof(int32_t) * (size_t)S * max_new, s));
+  WJ_HIP(hipMemsetAsync(d_lp, 0, sizeof(float) * (size_t)S * (max_new + 1), s));
+  WJ_HIP(hipMemsetAsync(m->finished, 0, sizeof(int32_t) * S, s));
+  WJ_HIP(hipMemsetAsync(m->n_out, 0, sizeof(int32_t) * S, s));
+  WJ_HIP(hipMemcpyAsync(m->eos, eos_ids_host, sizeof(int32_t) * n_eos, hipMemcpyHostToDevice, s));
+  std::vector<int32_t> fin(S);
+  // the prefill left the arg-max of every sequence's last prompt position in top_id / top_lp
+  for (int i = 0; i <= max_new; ++i) {
+    hipLaunchKernelGGL(advance_kernel, dim3(ceil_div(S, 64)), dim3(64), 0, s, m->top_id, m->top_lp, m->eos, n_eos, m->finished, m->n_out,
+                       m->row_pos, m->next_tok, d_tok, d_lp, max_new, S, m->max_ctx, i == 0 ? 1 : 0);
+    WJ_LAUNCH_CHECK();
+    if (i == max_new) break;
+    if ((i & 7) == 7) {
+      WJ_HIP(hipMemcpyAsync(fin.data(), m->finished, sizeof(int32_t) * S, hipMemcpyDeviceToHost, s));
+      WJ_HIP(hipStreamSynchronize(s));
+      if (std::all_of(fin.begin(), fin.end(), [](int32_t f) { return f != 0; })) break;
+    }
+    if (m->dtype == WJ_F32) hipLaunchKernelGGL((embed_rows_kernel<float>), dim3(S), dim3(256), 0, s, TP(const float, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
+    else if (m->dtype == WJ_F16) hipLaunchKernelGGL((embed_rows_kernel<f16_t>), dim3(S), dim3(256), 0, s, TP(const f16_t, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
+    else hipLaunchKernelGGL((embed_rows_kernel<bf16_t>), dim3(S), dim3(256), 0, s, TP(const bf16_t, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
+    WJ_LAUNCH_CHECK();
+    WJ_TRYQ(run_layers(m, S, s));
+    WJ_TRYQ(run_head(m, m->x, S, s));
+  }
+  WJ_HIP(hipMemcpyAsync(tokens_out, d_tok, sizeof(int32_t) * (size_t)S * max_new, hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipMemcpyAsync(n_tokens_out, m->n_out, sizeof(int32_t) * S, hipMemcpyDeviceToHost, s));
+  if (token_logprob_out) WJ_HIP(hipMemcpyAsync(token_logprob_out, d_lp, sizeof(float) * (size_t)S * (max_new + 1), hipMemcpyDeviceToHost, s));
+  WJ_HIP(hipStreamSynchronize(s));
+  return WJ_OK;
+}
+
+}  // extern "C"

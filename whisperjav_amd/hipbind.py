@@ -71,6 +71,11 @@ _SIGNATURES = {
                                     C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _P]),
     "wj_whisper_decode_beam_openai": (_I, [_P, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), _F, _F,
                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _P]),
+    "wj_qwen_create": (_I, [_P, _P, _I, _P, C.c_size_t, C.POINTER(C.c_int64), _I, _I, _I, _I, C.POINTER(_P)]),
+    "wj_qwen_free": (_I, [_P]),
+    "wj_qwen_embed": (_I, [_P, C.POINTER(C.c_int32), _I, _P, _P]),
+    "wj_qwen_prefill": (_I, [_P, _P, _I, C.POINTER(C.c_int32), _P, _P]),
+    "wj_qwen_generate_greedy": (_I, [_P, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),
     "wj_whisper_align": (_I, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I,
                               C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32),
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),

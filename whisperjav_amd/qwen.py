@@ -1,0 +1,271 @@
+"""Qwen3-ASR on the MI355X -- first slice (BASELINE cfg5): the Qwen3 text decoder on the device.
+
+The reference's qwen mode drives three duck-typed components per scene (``TemporalFramer`` / ``TextGenerator`` /
+``TextAligner``, /root/reference/whisperjav/modules/subtitle_pipeline/protocols.py:28-179); its generator wraps the
+un-vendored ``qwen_asr`` package (modules/qwen_asr.py:545-757).  What exists here:
+
+  * ``HipQwen3Decoder``: the LLM of Qwen3-ASR (RMSNorm, q/k-norm, RoPE, grouped-query attention, SwiGLU, tied head) behind
+    ``wj_qwen_*`` (csrc/qwen.hip): ragged batched prefill from EMBEDDINGS + greedy generation until EOS, parity-tested on
+    the GPU against ``oracle/qwen3_ref.py`` (itself pinned against ``transformers.models.qwen3_asr``);
+  * ``HipQwenTextGenerator``: the ``TextGenerator`` surface over it.  The audio tower (three stride-2 convolutions +
+    windowed-attention encoder + projector) is NOT on the device yet: the generator takes an ``audio_embedder`` plug-in
+    (callable: 16 kHz mono float32 -> projected audio embeddings ``[n_tokens, hidden]``) and refuses to run without one --
+    there is no silent CPU path;
+  * weight packing from the published state-dict names (``model.language_model.layers.N...``), seeded synthetic weights for
+    the tests.
+
+Not here yet: the audio tower kernels, the forced aligner (``TextAligner``), fp8 weight streaming (cfg5's "fp8 MFMA"), beam
+search for the LLM (upstream decodes greedily), measurements.  DESIGN.md section 7 has the plan.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import hipbind
+from .hipbind import DTYPES, check
+
+ALIGN = 256
+LAYER_TENSORS = ("LN1_W", "QKV_W", "QNORM_W", "KNORM_W", "O_W", "LN2_W", "GATEUP_W", "DOWN_W")     # order of WJ_QL_* in wjhip.h
+
+
+@dataclass(frozen=True)
+class Qwen3Dims:
+    hidden: int = 2048
+    n_layer: int = 28
+    n_head: int = 16
+    n_kv_head: int = 8
+    head_dim: int = 128
+    ffn: int = 6144
+    vocab: int = 151936
+    rope_theta: float = 1000000.0
+    rms_eps: float = 1e-6
+    audio_token_id: int = 151676
+    eos_token_ids: Tuple[int, ...] = (151643, 151645)
+
+
+class Qwen3DimsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("hidden", "n_layer", "n_head", "n_kv_head", "head_dim", "ffn", "vocab")] + \
+               [("rope_theta", C.c_float), ("rms_eps", C.c_float)]
+
+
+def synth_weights(d: Qwen3Dims, seed: int = 7) -> Dict[str, np.ndarray]:
+    """Seeded decoder weights under the published names (activations O(1) through the stack, logits spread ~1.5)."""
+    rng = np.random.default_rng(seed)
+    p = "model.language_model."
+    w: Dict[str, np.ndarray] = {p + "embed_tokens.weight": (rng.standard_normal((d.vocab, d.hidden)) * 1.5 / np.sqrt(d.hidden)).astype(np.float32)}
+
+    def mat(name, out, inp, gain=1.0):
+        w[name] = (rng.standard_normal((out, inp)) * gain / np.sqrt(inp)).astype(np.float32)
+
+    def vec(name, n):
+        w[name] = (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+
+    for l in range(d.n_layer):
+        q = f"{p}layers.{l}."
+        vec(q + "input_layernorm.weight", d.hidden)
+        mat(q + "self_attn.q_proj.weight", d.n_head * d.head_dim, d.hidden)
+        mat(q + "self_attn.k_proj.weight", d.n_kv_head * d.head_dim, d.hidden)
+        mat(q + "self_attn.v_proj.weight", d.n_kv_head * d.head_dim, d.hidden)
+        mat(q + "self_attn.o_proj.weight", d.hidden, d.n_head * d.head_dim, 0.5)
+        vec(q + "self_attn.q_norm.weight", d.head_dim)
+        vec(q + "self_attn.k_norm.weight", d.head_dim)
+        vec(q + "post_attention_layernorm.weight", d.hidden)
+        mat(q + "mlp.gate_proj.weight", d.ffn, d.hidden)
+        mat(q + "mlp.up_proj.weight", d.ffn, d.hidden)
+        mat(q + "mlp.down_proj.weight", d.hidden, d.ffn, 0.5)
+    vec(p + "norm.weight", d.hidden)
+    return w
+
+
+def engine_tensors(d: Qwen3Dims, w: Dict[str, np.ndarray]) -> List[Tuple[str, np.ndarray, bool]]:
+    p = "model.language_model."
+    out = [("EMBED", w[p + "embed_tokens.weight"], True), ("NORM_W", w[p + "norm.weight"], False)]
+    for l in range(d.n_layer):
+        q = f"{p}layers.{l}."
+        qkv = np.concatenate([w[q + "self_attn.q_proj.weight"], w[q + "self_attn.k_proj.weight"], w[q + "self_attn.v_proj.weight"]], 0)
+        gate_up = np.concatenate([w[q + "mlp.gate_proj.weight"], w[q + "mlp.up_proj.weight"]], 0)
+        t = {"LN1_W": (w[q + "input_layernorm.weight"], False), "QKV_W": (qkv, True),
+             "QNORM_W": (w[q + "self_attn.q_norm.weight"], False), "KNORM_W": (w[q + "self_attn.k_norm.weight"], False),
+             "O_W": (w[q + "self_attn.o_proj.weight"], True), "LN2_W": (w[q + "post_attention_layernorm.weight"], False),
+             "GATEUP_W": (gate_up, True), "DOWN_W": (w[q + "mlp.down_proj.weight"], True)}
+        out.extend((f"l{l}.{n}", t[n][0], t[n][1]) for n in LAYER_TENSORS)
+    return out
+
+
+def pack_blob(d: Qwen3Dims, w: Dict[str, np.ndarray], dtype: str) -> Tuple[torch.Tensor, np.ndarray]:
+    """(host uint8 blob, int64 offsets) for ``wj_qwen_create``: matrices in ``dtype``, vectors fp32, 256-byte aligned."""
+    half = {"bfloat16": torch.bfloat16, "float16": torch.float16}.get(dtype)
+    tensors = engine_tensors(d, w)
+    offsets = np.zeros(len(tensors), dtype=np.int64)
+    cursor, sizes = 0, []
+    for i, (_, arr, is_mat) in enumerate(tensors):
+        nbytes = int(arr.size) * (2 if (is_mat and half is not None) else 4)
+        offsets[i] = cursor
+        sizes.append(nbytes)
+        cursor += (nbytes + ALIGN - 1) // ALIGN * ALIGN
+    blob = torch.zeros(cursor, dtype=torch.uint8)
+    for (_, arr, is_mat), off, nbytes in zip(tensors, offsets, sizes):
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+        if is_mat and half is not None:
+            t = t.to(half)
+        blob[off:off + nbytes] = t.reshape(-1).view(torch.uint8)
+    return blob, offsets
+
+
+@dataclass
+class GenerateResult:
+    tokens: List[List[int]]
+    token_logprob: List[List[float]]      # one entry per token, + the EOS token's when the sequence ended on one
+
+
+class HipQwen3Decoder:
+    """The Qwen3 decoder resident in HBM (``wj_qwen_*``).  No CPU path: raises without the library or an MI355X."""
+
+    def __init__(self, dims: Qwen3Dims, weights: Dict[str, np.ndarray], *, dtype: str = "float16", device: int = 0,
+                 max_seqs: int = 8, max_ctx: int = 512, max_rows: Optional[int] = None):
+        if dtype not in DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(DTYPES)}")
+        if not torch.cuda.is_available():
+            raise hipbind.WjError("no ROCm device visible: the HIP path has no CPU fallback")
+        self.dims, self.dtype, self.device = dims, dtype, int(device)
+        self.dev = torch.device("cuda", device)
+        self.ctx = hipbind.context(device)
+        self._lib = hipbind.lib()
+        host, offsets = pack_blob(dims, weights, dtype)
+        self.blob = host.to(self.dev)
+        self.max_seqs, self.max_ctx = int(max_seqs), int(max_ctx)
+        self.max_rows = int(max_rows or max_seqs * max_ctx)
+        cd = Qwen3DimsC(dims.hidden, dims.n_layer, dims.n_head, dims.n_kv_head, dims.head_dim, dims.ffn, dims.vocab,
+                        float(dims.rope_theta), float(dims.rms_eps))
+        off = (C.c_int64 * len(offsets))(*offsets.tolist())
+        handle = C.c_void_p()
+        torch.cuda.current_stream().synchronize()
+        check(self._lib.wj_qwen_create(self.ctx.handle, C.byref(cd), DTYPES[dtype], C.c_void_p(self.blob.data_ptr()), self.blob.numel(),
+                                       off, len(offsets), self.max_seqs, self.max_ctx, self.max_rows, C.byref(handle)), "wj_qwen_create")
+        self.handle = handle
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._lib.wj_qwen_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def embed(self, tokens: Sequence[int]) -> torch.Tensor:
+        """fp32 CUDA ``[n, hidden]`` embeddings of host token ids."""
+        ids = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = torch.empty((len(ids), self.dims.hidden), dtype=torch.float32, device=self.dev)
+        torch.cuda.current_stream().synchronize()
+        check(self._lib.wj_qwen_embed(self.handle, ids.ctypes.data_as(C.POINTER(C.c_int32)), len(ids), C.c_void_p(out.data_ptr()), None),
+              "wj_qwen_embed")
+        return out
+
+    def prompt_embeddings(self, tokens: Sequence[int], audio: Optional[torch.Tensor]) -> torch.Tensor:
+        """Embeddings of one prompt with the rows of its ``<audio>`` placeholders replaced, in order, by ``audio``."""
+        x = self.embed(tokens)
+        if audio is not None:
+            mask = torch.as_tensor([t == self.dims.audio_token_id for t in tokens], device=self.dev)
+            if int(mask.sum()) != audio.shape[0]:
+                raise ValueError(f"{int(mask.sum())} <audio> placeholders for {audio.shape[0]} audio embeddings")
+            x[mask] = audio.to(self.dev, torch.float32)
+        return x
+
+    def prefill(self, embeds: Sequence[torch.Tensor], want_logits: bool = False) -> Optional[torch.Tensor]:
+        """``embeds[b]``: fp32 CUDA ``[n_b, hidden]`` prompt embeddings of sequence b."""
+        n = np.array([int(e.shape[0]) for e in embeds], dtype=np.int32)
+        packed = torch.cat([e.to(self.dev, torch.float32) for e in embeds], 0).contiguous()
+        out = torch.empty((len(embeds), self.dims.vocab), dtype=torch.float32, device=self.dev) if want_logits else None
+        torch.cuda.current_stream().synchronize()
+        check(self._lib.wj_qwen_prefill(self.handle, C.c_void_p(packed.data_ptr()), len(embeds), n.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        C.c_void_p(out.data_ptr()) if out is not None else None, None), "wj_qwen_prefill")
+        self._n_seqs = len(embeds)
+        return out
+
+    def generate(self, max_new_tokens: int = 256, eos_token_ids: Optional[Sequence[int]] = None) -> GenerateResult:
+        eos = np.ascontiguousarray(eos_token_ids if eos_token_ids is not None else self.dims.eos_token_ids, dtype=np.int32)
+        S, n = self._n_seqs, int(max_new_tokens)
+        toks = np.zeros((S, n), dtype=np.int32)
+        cnt = np.zeros(S, dtype=np.int32)
+        lps = np.zeros((S, n + 1), dtype=np.float32)
+        check(self._lib.wj_qwen_generate_greedy(self.handle, eos.ctypes.data_as(C.POINTER(C.c_int32)), len(eos), n,
+                                                toks.ctypes.data_as(C.POINTER(C.c_int32)), cnt.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                lps.ctypes.data_as(C.POINTER(C.c_float)), None), "wj_qwen_generate_greedy")
+        out_t, out_l = [], []
+        for b in range(S):
+            k = int(cnt[b])
+            out_t.append(toks[b, :k].tolist())
+            out_l.append(lps[b, : k + 1 if k < n else k].tolist())
+        return GenerateResult(out_t, out_l)
+
+
+@dataclass
+class TranscriptionResult:      # mirror of subtitle_pipeline/types.py:72-78 (the reference's type is used when importable)
+    text: str
+    language: str
+    metadata: Dict[str, Any]
+
+
+class HipQwenTextGenerator:
+    """``TextGenerator`` (protocols.py:60-110) over the device decoder: ``generate`` / ``generate_batch`` / ``load`` /
+    ``unload`` / ``cleanup``.  ``audio_embedder`` supplies the audio tower until it has HIP kernels; ``prompt_builder(n_audio,
+    language, context)`` returns the token ids of the chat prompt with ``n_audio`` placeholders; ``detokenize`` turns ids
+    into text.  All three are required -- nothing is guessed."""
+
+    def __init__(self, dims: Qwen3Dims, weights: Dict[str, np.ndarray], *, audio_embedder: Optional[Callable] = None,
+                 prompt_builder: Optional[Callable] = None, detokenize: Optional[Callable] = None, dtype: str = "float16",
+                 device: int = 0, batch_size: int = 8, max_ctx: int = 1024, max_new_tokens: int = 256):
+        self.dims, self._weights, self.dtype, self.device = dims, weights, dtype, device
+        self.audio_embedder, self.prompt_builder, self.detokenize = audio_embedder, prompt_builder, detokenize
+        self.batch_size, self.max_ctx, self.max_new_tokens = int(batch_size), int(max_ctx), int(max_new_tokens)
+        self._model: Optional[HipQwen3Decoder] = None
+
+    def load(self) -> None:
+        if self._model is None:
+            self._model = HipQwen3Decoder(self.dims, self._weights, dtype=self.dtype, device=self.device, max_seqs=self.batch_size,
+                                          max_ctx=self.max_ctx)
+
+    def unload(self) -> None:
+        if self._model is not None:
+            self._model.close()
+            self._model = None
+
+    cleanup = unload
+
+    def _require(self) -> None:
+        missing = [n for n in ("audio_embedder", "prompt_builder", "detokenize") if getattr(self, n) is None]
+        if missing:
+            raise hipbind.WjError("HipQwenTextGenerator: " + ", ".join(missing) + " not supplied -- the Qwen3-ASR audio tower and "
+                                  "tokenizer are not part of this slice (whisperjav_amd/qwen.py) and nothing falls back to the CPU")
+
+    def generate_batch(self, audio_paths: Sequence[Path], language: str = "ja", contexts: Optional[Sequence[Optional[str]]] = None,
+                       **kwargs: Any) -> List[TranscriptionResult]:
+        from .asr import read_audio
+        self._require()
+        self.load()
+        out: List[TranscriptionResult] = []
+        contexts = list(contexts) if contexts is not None else [None] * len(audio_paths)
+        for lo in range(0, len(audio_paths), self.batch_size):
+            embeds = []
+            for path, ctx_text in zip(audio_paths[lo: lo + self.batch_size], contexts[lo: lo + self.batch_size]):
+                audio, sr = read_audio(Path(path))
+                a = self.audio_embedder(audio, sr)
+                ids = self.prompt_builder(int(a.shape[0]), language, ctx_text)
+                embeds.append(self._model.prompt_embeddings(ids, torch.as_tensor(a)))
+            self._model.prefill(embeds)
+            res = self._model.generate(int(kwargs.get("max_new_tokens", self.max_new_tokens)))
+            for toks in res.tokens:
+                out.append(TranscriptionResult(text=self.detokenize(toks), language=language, metadata={"n_tokens": len(toks)}))
+        return out
+
+    def generate(self, audio_path: Path, language: str = "ja", context: Optional[str] = None, **kwargs: Any) -> TranscriptionResult:
+        return self.generate_batch([audio_path], language, [context], **kwargs)[0]
