@@ -39,7 +39,8 @@ enum {
  * softmax and logits.  WJ_F16 is the arithmetic the reference runs on a GPU (ctranslate2 compute_type="float16",
  * whisper fp16=True: whisperjav/modules/whisper_pro_asr.py:201-218). */
 enum { WJ_F32 = 0, WJ_BF16 = 1, WJ_F16 = 2 };
-enum { WJ_MEL_FW = 0, WJ_MEL_OW = 1 };     /* faster-whisper vs openai-whisper mel semantics */
+enum { WJ_MEL_FW = 0, WJ_MEL_OW = 1, WJ_MEL_RAW = 2 };   /* faster-whisper / openai-whisper mel semantics; RAW = no zero padding
+                                                         * (Qwen3-ASR's feature extractor: the same formula on the clip as it is) */
 
 typedef struct wj_ctx wj_ctx;
 typedef struct wj_whisper wj_whisper;
@@ -92,7 +93,7 @@ int wj_profile_stop_ex(wj_ctx* ctx, double* total_ms, int64_t* counts, int64_t* 
  *
  * Batched over `n_clips` clips resident in HBM: clip i is pcm_dev[offsets[i] .. offsets[i+1])
  * (float32 mono 16 kHz; offsets is a HOST array of n_clips+1 sample offsets).
- * Frames per clip: FW: (n+160)/160, OW: (n+480000)/160  (wj_logmel_frames()).
+ * Frames per clip: FW: (n+160)/160, OW: (n+480000)/160, RAW: n/160  (wj_logmel_frames()).
  * out_dev receives float32 [n_clips][n_mels][out_frames]; frames past a clip's own count are
  * filled with 0.0 (FW pad_or_trim semantics) / are real zero-audio frames (OW), frames beyond
  * out_frames are dropped.  scratch is managed by the context. */
@@ -260,6 +261,33 @@ int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32
  * sequence that stopped at EOS after n tokens is the EOS token's log-prob). */
 int wj_qwen_generate_greedy(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, int max_new, int32_t* tokens_out, int32_t* n_tokens_out,
                             float* token_logprob_out, void* stream);
+
+/* ---- Qwen3-ASR audio tower (same slice): log-mel -> audio embeddings for the decoder's <audio> placeholders ----------
+ * Replaces (un-vendored upstream): the audio encoder of the `qwen_asr` model (whisperjav/modules/qwen_asr.py:545-636,
+ * run per VAD group from :638-757).  mel: wj_logmel_f32(..., WJ_MEL_RAW, ...) of every clip, frame axis zero-padded to a
+ * multiple of 100.  Chunks of 100 frames -> three 3x3 stride-2 convolutions (GELU) as GEMMs over gathered patches ->
+ * linear to d_model -> + 13-position sinusoid table per chunk -> padding tokens dropped -> pre-LN transformer layers with
+ * self-attention inside windows of n_window_infer / 100 chunks -> ln_post -> projector (linear, GELU, linear).
+ * Blob: matrices in the compute type, vectors fp32, 256-byte aligned, order of the enumerators below; the patch-matrix
+ * orders the convolution weights need are documented in whisperjav_amd/qwen.py::pack_audio_blob. */
+typedef struct wj_qwen_audio wj_qwen_audio;
+typedef struct {
+  int32_t n_mels, n_layer, n_head, ffn, d_model, n_window, n_window_infer, conv_hidden, out_dim;
+} wj_qwen_audio_dims;
+enum { WJ_QA_CONV1_W = 0, WJ_QA_CONV1_B, WJ_QA_CONV2_W, WJ_QA_CONV2_B, WJ_QA_CONV3_W, WJ_QA_CONV3_B, WJ_QA_CONVOUT_W, WJ_QA_POS,
+       WJ_QA_LNPOST_W, WJ_QA_LNPOST_B, WJ_QA_PROJ1_W, WJ_QA_PROJ1_B, WJ_QA_PROJ2_W, WJ_QA_PROJ2_B, WJ_QA_N_GLOBAL };
+enum { WJ_QAL_LN1_W = 0, WJ_QAL_LN1_B, WJ_QAL_QKV_W, WJ_QAL_QKV_B, WJ_QAL_OUT_W, WJ_QAL_OUT_B, WJ_QAL_LN2_W, WJ_QAL_LN2_B,
+       WJ_QAL_FC1_W, WJ_QAL_FC1_B, WJ_QAL_FC2_W, WJ_QAL_FC2_B, WJ_QAL_N };
+/* max_chunks = 1 s chunks of one encode call (all clips together) */
+int wj_qwen_audio_create(wj_ctx* ctx, const wj_qwen_audio_dims* dims, int dtype, const void* blob_dev, size_t blob_bytes,
+                         const int64_t* offsets_host, int n_offsets, int max_chunks, wj_qwen_audio** out);
+int wj_qwen_audio_free(wj_qwen_audio* m);
+/* audio tokens a clip of n_frames mel frames yields (13 per full chunk + the tail chunk's share) */
+int wj_qwen_audio_tokens(int n_frames);
+/* mel_dev: fp32 [n_clips][n_mels][frames_max] (device); n_frames_host[c] valid frames.  out_dev: fp32 [sum tokens][out_dim]
+ * (device, clip after clip); n_tokens_out_host[c] = tokens of clip c. */
+int wj_qwen_audio_encode(wj_qwen_audio* m, const float* mel_dev, int n_clips, int frames_max, const int32_t* n_frames_host,
+                         float* out_dev, int32_t* n_tokens_out_host, void* stream);
 
 /* Word-timestamp alignment.  Replaces: ctranslate2 Whisper.align (faster_whisper.transcribe.WhisperModel
  * .find_alignment, reached with word_timestamps=True from faster_whisper_pro_asr.py:819) and whisper/timing.py

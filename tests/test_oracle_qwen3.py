@@ -88,3 +88,24 @@ def test_decoder_logits_cache_and_greedy_match_transformers():
     ref_new = gen[0, len(prompt):].tolist()
     ref_new = ref_new[: next((i for i, t in enumerate(ref_new) if t in DIMS.eos_token_ids), len(ref_new))]
     assert toks == ref_new and len(lps) >= len(toks)
+
+
+def test_feature_extractor_is_whispers_formula_without_padding():
+    """``Qwen3ASRFeatureExtractor`` == ``oracle.logmel.logmel_ow(audio, 128, padding=0)`` on the clip zero-padded to its
+    8000-sample minimum (what the HIP extractor's RAW mode computes; csrc/logmel.hip)."""
+    from transformers.models.qwen3_asr.feature_extraction_qwen3_asr import Qwen3ASRFeatureExtractor
+    from oracle import logmel
+    from whisperjav_amd import synth
+    fe = Qwen3ASRFeatureExtractor()
+    for seconds, seed in ((0.3, 1), (2.37, 2), (7.0, 3)):
+        audio = synth.speech_like(seconds, seed=seed)
+        out = fe(audio, sampling_rate=16000, padding=True, return_attention_mask=True)
+        n = int(out["attention_mask"][0].sum()) if "attention_mask" in out else None
+        feats = out["input_features"][0].numpy()
+        padded = np.pad(audio, (0, max(0, 8000 - len(audio))))
+        ref = logmel.logmel_ow(padded, 128, padding=0)
+        if n is None:
+            n = ref.shape[1]
+        assert n == ref.shape[1] == len(padded) // 160, (n, ref.shape)
+        assert np.abs(feats[:, :n] - ref).max() < 5e-5
+        assert feats.shape[1] % 100 == 0 and np.abs(feats[:, n:]).max() == 0.0 if feats.shape[1] > n else True

@@ -768,7 +768,7 @@ int wj_tune(const char* key, int value) {
 
 int64_t wj_logmel_frames(int64_t n_samples, int mode) {
   if (n_samples <= 0) return 0;
-  return (n_samples + (mode == WJ_MEL_FW ? 160 : 480000)) / 160;
+  return (n_samples + (mode == WJ_MEL_FW ? 160 : mode == WJ_MEL_OW ? 480000 : 0)) / 160;
 }
 
 int wj_logmel_f32(wj_ctx* ctx, const float* pcm_dev, const int64_t* offsets_host, int n_clips, int n_mels, int mode,

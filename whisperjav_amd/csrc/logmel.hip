@@ -104,7 +104,7 @@ __device__ __forceinline__ void atomic_max_float(float* addr, float v) {
 struct ClipDesc {
   int64_t offset;    // first sample in pcm
   int64_t n;         // samples in the clip
-  int64_t n_pad;     // n + zero padding (160 FW / 480000 OW)
+  int64_t n_pad;     // n + zero padding (160 FW / 480000 OW / 0 RAW)
   int32_t n_frames;  // n_pad / 160
   int32_t pad_;
 };
@@ -226,7 +226,7 @@ __global__ void fill_kernel(float* p, float v, int n) {
 int logmel_run(wj_ctx* ctx, const float* pcm, const int64_t* offsets_host, int n_clips, int n_mels, int mode,
                int out_frames, float* out, hipStream_t s) {
   WJ_REQUIRE(n_mels == 80 || n_mels == 128, "logmel: n_mels must be 80 or 128 (got %d)", n_mels);
-  WJ_REQUIRE(mode == WJ_MEL_FW || mode == WJ_MEL_OW, "logmel: unknown mode %d", mode);
+  WJ_REQUIRE(mode == WJ_MEL_FW || mode == WJ_MEL_OW || mode == WJ_MEL_RAW, "logmel: unknown mode %d", mode);
   WJ_REQUIRE(n_clips > 0 && out_frames > 0, "logmel: empty batch");
   int rc = ensure_tables(ctx);
   if (rc) return rc;
@@ -239,7 +239,7 @@ int logmel_run(wj_ctx* ctx, const float* pcm, const int64_t* offsets_host, int n
     c.offset = offsets_host[i];
     c.n = offsets_host[i + 1] - offsets_host[i];
     WJ_REQUIRE(c.n > NFFT / 2, "logmel: clip %d has %lld samples; need more than %d", i, (long long)c.n, NFFT / 2);
-    c.n_pad = c.n + (mode == WJ_MEL_FW ? 160 : 480000);
+    c.n_pad = c.n + (mode == WJ_MEL_FW ? 160 : mode == WJ_MEL_OW ? 480000 : 0);
     c.n_frames = (int32_t)(c.n_pad / HOP);
     c.pad_ = 0;
     max_frames = c.n_frames > max_frames ? c.n_frames : max_frames;

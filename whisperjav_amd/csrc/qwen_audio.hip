@@ -1,0 +1,281 @@
+// qwen_audio.hip -- the audio tower of Qwen3-ASR (SURVEY.md 8f-3 / BASELINE cfg5): first correct path.
+//
+// Replaces (reference, un-vendored): the audio encoder inside the ``qwen_asr`` package's model, loaded at
+// whisperjav/modules/qwen_asr.py:545-636 and run per VAD group from :638-757.  Architecture as published and as restated
+// in oracle/qwen3_ref.py (``audio_tokens``; pinned against transformers.models.qwen3_asr):
+//   mel [128][frames] cut into chunks of 100 frames -> three 3x3 stride-2 convolutions over (frequency x time) with GELU
+//   (1 -> 480 -> 480 -> 480 channels; 128 x 100 -> 64 x 50 -> 32 x 25 -> 16 x 13) -> linear over (channel, frequency) to
+//   d_model -> + a 13-position sinusoid table per chunk -> padding tokens dropped (tokens of all chunks of all clips
+//   PACKED) -> pre-LN transformer layers whose self-attention runs inside windows of 8 chunks' worth of tokens -> ln_post
+//   -> projector (linear, GELU, linear) to the decoder width.
+// The convolutions run on the matrix cores as GEMMs over gathered patches (im2col kernels below + gemm.hip): channels-last
+// activations make a patch row 9 contiguous runs of C elements; the last convolution's rows are ordered (chunk, time,
+// frequency) so that its output IS the [chunk x time][frequency x channel] operand of the following linear (the linear's
+// columns are permuted to that order when the blob is packed).  Everything else reuses the library: LayerNorm, the GEMM
+// epilogues (bias, GELU, fp32 residual read-modify-write).  The windowed attention is a plain one-wave-per-(token, head)
+// kernel: windows hold <= 104 tokens, the tower is a few per cent of the model's work.
+#include <algorithm>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace wj;
+
+namespace {
+
+constexpr int CHUNK = 100, TOK = 13;      // mel frames per chunk; tokens a full chunk yields
+
+// rows (chunk, f, t) of the first convolution: 9 taps of the single input channel, padded to 16 columns
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_mel_kernel(const float* __restrict__ mel, const int32_t* __restrict__ chunk_clip,
+                                                         const int32_t* __restrict__ chunk_f0, T* __restrict__ out, int n_mels,
+                                                         int frames_max, int Fo, int To, int64_t n_rows) {
+  const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int k = threadIdx.x & 15;
+  if (r >= n_rows) return;
+  const int c = (int)(r / (Fo * To)), rem = (int)(r - (int64_t)c * Fo * To), f = rem / To, t = rem - f * To;
+  float v = 0.f;
+  if (k < 9) {
+    const int mf = 2 * f - 1 + k / 3, tt = 2 * t - 1 + k % 3;
+    if (mf >= 0 && mf < n_mels && tt >= 0 && tt < CHUNK) {
+      const int fr = chunk_f0[c] + tt;
+      if (fr < frames_max) v = mel[((int64_t)chunk_clip[c] * n_mels + mf) * frames_max + fr];
+    }
+  }
+  Elem<T>::st(out + r * 16 + k, v);
+}
+
+// 3x3 stride-2 patches of a channels-last activation [chunk][Fi][Ti][C] -> rows of 9 * C elements (tap-major).  Row order:
+// t_major = 0: (chunk, f, t); 1: (chunk, t, f).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_cl_kernel(const T* __restrict__ in, T* __restrict__ out, int Fi, int Ti, int Fo, int To,
+                                                        int C, int t_major) {
+  const int64_t r = blockIdx.x;
+  const int c = (int)(r / (Fo * To)), rem = (int)(r - (int64_t)c * Fo * To);
+  const int f = t_major ? rem % Fo : rem / To, t = t_major ? rem / Fo : rem % To;
+  T* o = out + r * 9 * C;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int fi = 2 * f - 1 + tap / 3, ti = 2 * t - 1 + tap % 3;
+    const bool ok = fi >= 0 && fi < Fi && ti >= 0 && ti < Ti;
+    const T* src = in + (((int64_t)c * Fi + (ok ? fi : 0)) * Ti + (ok ? ti : 0)) * C;
+    for (int ch = threadIdx.x; ch < C; ch += 256) o[(int64_t)tap * C + ch] = ok ? src[ch] : (T)0;
+  }
+}
+
+// packed token i = (chunk, t): x[i] = conv_out[chunk * 13 + t] + pos[t]
+__global__ __launch_bounds__(256) void pos_select_kernel(const float* __restrict__ y, const float* __restrict__ pos,
+                                                         const int32_t* __restrict__ tok_src, float* __restrict__ x, int D) {
+  const int i = blockIdx.x, src = tok_src[i], t = src % TOK;
+  for (int c = threadIdx.x; c < D; c += 256) x[(int64_t)i * D + c] = y[(int64_t)src * D + c] + pos[(int64_t)t * D + c];
+}
+
+// non-causal attention inside [lo, hi) of the packed token axis; head_dim 64: lane j scores key base + j, lane i owns dim i
+template <typename T>
+__global__ __launch_bounds__(64) void win_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_lo,
+                                                      const int32_t* __restrict__ win_hi, T* __restrict__ out, int D) {
+  __shared__ float sq[64];
+  const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  const int lo = win_lo[i], hi = win_hi[i];
+  sq[lane] = Elem<T>::ld(qkv + (int64_t)i * 3 * D + h * 64 + lane);
+  __syncthreads();
+  float run_max = -INFINITY, run_sum = 0.f, acc = 0.f;
+  for (int base = lo; base < hi; base += 64) {
+    const int j = base + lane;
+    float s = -INFINITY;
+    if (j < hi) {
+      const T* kr = qkv + (int64_t)j * 3 * D + D + h * 64;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < 64; c += 8) {
+        float kv[8];
+        ld8(kr + c, kv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d = fmaf(sq[c + e], kv[e], d);
+      }
+      s = d * 0.125f;
+    }
+    const float new_max = fmaxf(run_max, wave_max(s));
+    const float corr = expf(run_max - new_max);
+    const float p = j < hi ? expf(s - new_max) : 0.f;
+    run_sum = run_sum * corr + wave_sum(p);
+    acc *= corr;
+    const int n_here = min(64, hi - base);
+    for (int jj = 0; jj < n_here; ++jj)
+      acc = fmaf(__shfl(p, jj, 64), Elem<T>::ld(qkv + (int64_t)(base + jj) * 3 * D + 2 * D + h * 64 + lane), acc);
+    run_max = new_max;
+  }
+  Elem<T>::st(out + (int64_t)i * D + h * 64 + lane, acc / run_sum);
+}
+
+}  // namespace
+
+struct wj_qwen_audio {
+  wj_ctx* ctx = nullptr;
+  wj_qwen_audio_dims d{};
+  int dtype = WJ_F16;
+  size_t esz = 2;
+  const char* blob = nullptr;
+  std::vector<int64_t> off;
+  int max_chunks = 0;
+  std::vector<void*> allocs;
+  void *col = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;   // im2col buffer, activations of the three convolutions
+  float* y = nullptr;        // f32 [chunks * 13][D]   conv_out
+  float* x = nullptr;        // f32 [tokens][D]        residual stream
+  void *h = nullptr, *qkv = nullptr, *attn = nullptr, *ff = nullptr;
+  int32_t *chunk_clip = nullptr, *chunk_f0 = nullptr, *tok_src = nullptr, *win_lo = nullptr, *win_hi = nullptr;
+  const void* W(int i) const { return blob + off[i]; }
+  const float* F(int i) const { return reinterpret_cast<const float*>(blob + off[i]); }
+  int layer_base(int l) const { return WJ_QA_N_GLOBAL + l * WJ_QAL_N; }
+};
+
+namespace {
+#define WJ_TRYA(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+#define TPA(T, p) reinterpret_cast<T*>(p)
+
+int aalloc(wj_qwen_audio* m, void** p, size_t bytes) {
+  bytes = align_up(bytes ? bytes : 256, 256);
+  WJ_HIP(hipMalloc(p, bytes));
+  m->allocs.push_back(*p);
+  return WJ_OK;
+}
+
+int post_cnn(int n) {
+  for (int i = 0; i < 3; ++i) n = n > 0 ? (n - 1) / 2 + 1 : 0;
+  return n;
+}
+}  // namespace
+
+extern "C" {
+
+int wj_qwen_audio_free(wj_qwen_audio* m) {
+  if (!m) return WJ_OK;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  for (void* p : m->allocs) (void)hipFree(p);
+  delete m;
+  return WJ_OK;
+}
+
+int wj_qwen_audio_create(wj_ctx* ctx, const wj_qwen_audio_dims* dims, int dtype, const void* blob_dev, size_t blob_bytes,
+                         const int64_t* offsets_host, int n_offsets, int max_chunks, wj_qwen_audio** out) {
+  WJ_REQUIRE(ctx && dims && blob_dev && offsets_host && out, "wj_qwen_audio_create: NULL argument");
+  const wj_qwen_audio_dims& d = *dims;
+  WJ_REQUIRE(d.n_mels == 128 && d.n_window == 50, "wj_qwen_audio_create: 128 mel bins and 100-frame chunks (n_window 50) expected");
+  WJ_REQUIRE(d.d_model % 64 == 0 && d.d_model / 64 == d.n_head && d.d_model <= 1280, "wj_qwen_audio_create: head_dim 64 and d_model <= 1280 expected");
+  WJ_REQUIRE(d.conv_hidden % 8 == 0 && d.ffn % 8 == 0 && d.out_dim % 8 == 0 && d.n_layer >= 1 && d.n_window_infer % 100 == 0 && d.n_window_infer >= 100,
+             "wj_qwen_audio_create: bad dimensions");
+  WJ_REQUIRE(dtype == WJ_F32 || dtype == WJ_F16 || dtype == WJ_BF16, "wj_qwen_audio_create: unknown dtype %d", dtype);
+  WJ_REQUIRE(n_offsets == WJ_QA_N_GLOBAL + d.n_layer * WJ_QAL_N, "wj_qwen_audio_create: %d tensor offsets expected, got %d",
+             WJ_QA_N_GLOBAL + d.n_layer * WJ_QAL_N, n_offsets);
+  WJ_REQUIRE(max_chunks >= 1, "wj_qwen_audio_create: max_chunks >= 1");
+  for (int i = 0; i < n_offsets; ++i)
+    WJ_REQUIRE(offsets_host[i] >= 0 && (size_t)offsets_host[i] < blob_bytes && offsets_host[i] % 16 == 0, "wj_qwen_audio_create: bad offset %d", i);
+  WJ_HIP(hipSetDevice(ctx->device));
+  wj_qwen_audio* m = new wj_qwen_audio();
+  m->ctx = ctx; m->d = d; m->dtype = dtype; m->esz = dtype_size(dtype);
+  m->blob = reinterpret_cast<const char*>(blob_dev);
+  m->off.assign(offsets_host, offsets_host + n_offsets);
+  m->max_chunks = max_chunks;
+  const size_t e = m->esz, C = d.conv_hidden, NC = max_chunks, N = NC * TOK, D = d.d_model;
+  int rc = 0;
+#define AA(field, bytes) do { if (!rc) rc = aalloc(m, reinterpret_cast<void**>(&m->field), (bytes)); } while (0)
+  AA(col, NC * 32 * 25 * 9 * C * e);                 // the largest patch matrix (second convolution)
+  AA(a1, NC * 64 * 50 * C * e); AA(a2, NC * 32 * 25 * C * e); AA(a3, NC * TOK * 16 * C * e);
+  AA(y, N * D * sizeof(float)); AA(x, N * D * sizeof(float));
+  AA(h, N * std::max<size_t>(D, d.out_dim) * e); AA(qkv, N * 3 * D * e); AA(attn, N * D * e); AA(ff, N * (size_t)d.ffn * e);
+  AA(chunk_clip, NC * 4); AA(chunk_f0, NC * 4); AA(tok_src, N * 4); AA(win_lo, N * 4); AA(win_hi, N * 4);
+#undef AA
+  if (rc) { wj_qwen_audio_free(m); return rc; }
+  *out = m;
+  return WJ_OK;
+}
+
+int wj_qwen_audio_tokens(int n_frames) {
+  int n = (n_frames / CHUNK) * TOK;
+  return n + post_cnn(n_frames % CHUNK);
+}
+
+int wj_qwen_audio_encode(wj_qwen_audio* m, const float* mel_dev, int n_clips, int frames_max, const int32_t* n_frames_host,
+                         float* out_dev, int32_t* n_tokens_out_host, void* stream) {
+  WJ_REQUIRE(m && mel_dev && n_frames_host && out_dev && n_tokens_out_host, "wj_qwen_audio_encode: NULL argument");
+  WJ_REQUIRE(n_clips >= 1 && frames_max >= 1, "wj_qwen_audio_encode: empty batch");
+  const wj_qwen_audio_dims& d = m->d;
+  const int D = d.d_model, C = d.conv_hidden, H = d.n_head, dt = m->dtype;
+  std::vector<int32_t> cclip, cf0, tsrc, wlo, whi;
+  const int win = TOK * (d.n_window_infer / CHUNK);
+  for (int c = 0; c < n_clips; ++c) {
+    const int nf = n_frames_host[c];
+    WJ_REQUIRE(nf >= 1 && nf <= frames_max, "wj_qwen_audio_encode: clip %d has %d frames (buffer %d)", c, nf, frames_max);
+    const int first_tok = (int)tsrc.size();
+    for (int f0 = 0; f0 < nf; f0 += CHUNK) {
+      const int chunk = (int)cclip.size(), n_tok = post_cnn(std::min(CHUNK, nf - f0));
+      cclip.push_back(c); cf0.push_back(f0);
+      for (int t = 0; t < n_tok; ++t) tsrc.push_back(chunk * TOK + t);
+    }
+    const int n_tok = (int)tsrc.size() - first_tok;
+    n_tokens_out_host[c] = n_tok;
+    for (int t = 0; t < n_tok; ++t) {      // attention windows restart with every clip
+      const int lo = first_tok + t / win * win;
+      wlo.push_back(lo); whi.push_back(std::min(lo + win, first_tok + n_tok));
+    }
+  }
+  const int NC = (int)cclip.size(), N = (int)tsrc.size();
+  WJ_REQUIRE(NC <= m->max_chunks, "wj_qwen_audio_encode: %d chunks of 1 s in the batch (max_chunks %d)", NC, m->max_chunks);
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  WJ_HIP(hipMemcpyAsync(m->chunk_clip, cclip.data(), 4 * (size_t)NC, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(m->chunk_f0, cf0.data(), 4 * (size_t)NC, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(m->tok_src, tsrc.data(), 4 * (size_t)N, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(m->win_lo, wlo.data(), 4 * (size_t)N, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(m->win_hi, whi.data(), 4 * (size_t)N, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipStreamSynchronize(s));       // the host vectors die at return
+  auto gemm = [&](Epi epi, const void* A, int64_t lda, int wi, int bi, int M, int Nn, int K, void* out, int64_t ldc) -> int {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = m->W(wi); g.ldw = K; g.bias = bi >= 0 ? m->F(bi) : nullptr; g.M = M; g.N = Nn; g.K = K; g.out = out; g.ldc = ldc;
+    return launch_gemm(dt, epi, g, s, 0);
+  };
+  // ---- convolution stem -------------------------------------------------------------------------------------------
+  {
+    const int64_t rows = (int64_t)NC * 64 * 50;
+    const dim3 grid((unsigned)ceil_div64(rows, 16));
+    if (dt == WJ_F32) hipLaunchKernelGGL((im2col_mel_kernel<float>), grid, dim3(256), 0, s, mel_dev, m->chunk_clip, m->chunk_f0, TPA(float, m->col), d.n_mels, frames_max, 64, 50, rows);
+    else if (dt == WJ_F16) hipLaunchKernelGGL((im2col_mel_kernel<f16_t>), grid, dim3(256), 0, s, mel_dev, m->chunk_clip, m->chunk_f0, TPA(f16_t, m->col), d.n_mels, frames_max, 64, 50, rows);
+    else hipLaunchKernelGGL((im2col_mel_kernel<bf16_t>), grid, dim3(256), 0, s, mel_dev, m->chunk_clip, m->chunk_f0, TPA(bf16_t, m->col), d.n_mels, frames_max, 64, 50, rows);
+    WJ_LAUNCH_CHECK();
+    WJ_TRYA(gemm(EPI_GELU_T, m->col, 16, WJ_QA_CONV1_W, WJ_QA_CONV1_B, (int)rows, C, 16, m->a1, C));
+  }
+  auto conv = [&](const void* in, int Fi, int Ti, int Fo, int To, int t_major, int wi, int bi, void* out) -> int {
+    const int64_t rows = (int64_t)NC * Fo * To;
+    if (dt == WJ_F32) hipLaunchKernelGGL((im2col_cl_kernel<float>), dim3((unsigned)rows), dim3(256), 0, s, TPA(const float, in), TPA(float, m->col), Fi, Ti, Fo, To, C, t_major);
+    else if (dt == WJ_F16) hipLaunchKernelGGL((im2col_cl_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, s, TPA(const f16_t, in), TPA(f16_t, m->col), Fi, Ti, Fo, To, C, t_major);
+    else hipLaunchKernelGGL((im2col_cl_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, s, TPA(const bf16_t, in), TPA(bf16_t, m->col), Fi, Ti, Fo, To, C, t_major);
+    WJ_LAUNCH_CHECK();
+    return gemm(EPI_GELU_T, m->col, 9 * C, wi, bi, (int)rows, C, 9 * C, out, C);
+  };
+  WJ_TRYA(conv(m->a1, 64, 50, 32, 25, 0, WJ_QA_CONV2_W, WJ_QA_CONV2_B, m->a2));
+  WJ_TRYA(conv(m->a2, 32, 25, 16, TOK, 1, WJ_QA_CONV3_W, WJ_QA_CONV3_B, m->a3));      // rows (chunk, t, f)
+  WJ_TRYA(gemm(EPI_F32, m->a3, 16 * C, WJ_QA_CONVOUT_W, -1, NC * TOK, D, 16 * C, m->y, D));
+  hipLaunchKernelGGL(pos_select_kernel, dim3(N), dim3(256), 0, s, m->y, m->F(WJ_QA_POS), m->tok_src, m->x, D);
+  WJ_LAUNCH_CHECK();
+  // ---- transformer layers over the packed tokens ------------------------------------------------------------------
+  for (int l = 0; l < d.n_layer; ++l) {
+    const int b0 = m->layer_base(l);
+    WJ_TRYA(launch_layernorm(dt, m->x, m->F(b0 + WJ_QAL_LN1_W), m->F(b0 + WJ_QAL_LN1_B), m->h, N, D, s, 0));
+    WJ_TRYA(gemm(EPI_T, m->h, D, b0 + WJ_QAL_QKV_W, b0 + WJ_QAL_QKV_B, N, 3 * D, D, m->qkv, 3 * D));
+    if (dt == WJ_F32) hipLaunchKernelGGL((win_attn_kernel<float>), dim3(N, H), dim3(64), 0, s, TPA(const float, m->qkv), m->win_lo, m->win_hi, TPA(float, m->attn), D);
+    else if (dt == WJ_F16) hipLaunchKernelGGL((win_attn_kernel<f16_t>), dim3(N, H), dim3(64), 0, s, TPA(const f16_t, m->qkv), m->win_lo, m->win_hi, TPA(f16_t, m->attn), D);
+    else hipLaunchKernelGGL((win_attn_kernel<bf16_t>), dim3(N, H), dim3(64), 0, s, TPA(const bf16_t, m->qkv), m->win_lo, m->win_hi, TPA(bf16_t, m->attn), D);
+    WJ_LAUNCH_CHECK();
+    WJ_TRYA(gemm(EPI_RESID_F32, m->attn, D, b0 + WJ_QAL_OUT_W, b0 + WJ_QAL_OUT_B, N, D, D, m->x, D));
+    WJ_TRYA(launch_layernorm(dt, m->x, m->F(b0 + WJ_QAL_LN2_W), m->F(b0 + WJ_QAL_LN2_B), m->h, N, D, s, 0));
+    WJ_TRYA(gemm(EPI_GELU_T, m->h, D, b0 + WJ_QAL_FC1_W, b0 + WJ_QAL_FC1_B, N, d.ffn, D, m->ff, d.ffn));
+    WJ_TRYA(gemm(EPI_RESID_F32, m->ff, d.ffn, b0 + WJ_QAL_FC2_W, b0 + WJ_QAL_FC2_B, N, D, d.ffn, m->x, D));
+  }
+  WJ_TRYA(launch_layernorm(dt, m->x, m->F(WJ_QA_LNPOST_W), m->F(WJ_QA_LNPOST_B), m->h, N, D, s, 0));
+  WJ_TRYA(gemm(EPI_GELU_T, m->h, D, WJ_QA_PROJ1_W, WJ_QA_PROJ1_B, N, D, D, m->attn, D));
+  WJ_TRYA(gemm(EPI_F32, m->attn, D, WJ_QA_PROJ2_W, WJ_QA_PROJ2_B, N, d.out_dim, D, out_dev, d.out_dim));
+  WJ_HIP(hipStreamSynchronize(s));
+  return WJ_OK;
+}
+
+}  // extern "C"

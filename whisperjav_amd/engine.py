@@ -16,10 +16,10 @@ import torch
 
 from . import hipbind
 from .dims import SpecialTokens, WhisperDims, special_tokens
-from .hipbind import DTYPES, WJ_MEL_FW, WJ_MEL_OW, check
+from .hipbind import DTYPES, WJ_MEL_FW, WJ_MEL_OW, WJ_MEL_RAW, check
 
 N_FRAMES = 3000
-MEL_MODES = {"fw": WJ_MEL_FW, "ow": WJ_MEL_OW}
+MEL_MODES = {"fw": WJ_MEL_FW, "ow": WJ_MEL_OW, "raw": WJ_MEL_RAW}
 TORCH_DTYPES = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}
 
 

@@ -17,7 +17,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwjhip.so"
 _lib: Optional[C.CDLL] = None
 
 WJ_F32, WJ_BF16, WJ_F16 = 0, 1, 2
-WJ_MEL_FW, WJ_MEL_OW = 0, 1
+WJ_MEL_FW, WJ_MEL_OW, WJ_MEL_RAW = 0, 1, 2
 DTYPES = {"float32": WJ_F32, "bfloat16": WJ_BF16, "float16": WJ_F16}
 
 
@@ -76,6 +76,10 @@ _SIGNATURES = {
     "wj_qwen_embed": (_I, [_P, C.POINTER(C.c_int32), _I, _P, _P]),
     "wj_qwen_prefill": (_I, [_P, _P, _I, C.POINTER(C.c_int32), _P, _P]),
     "wj_qwen_generate_greedy": (_I, [_P, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),
+    "wj_qwen_audio_create": (_I, [_P, _P, _I, _P, C.c_size_t, C.POINTER(C.c_int64), _I, _I, C.POINTER(_P)]),
+    "wj_qwen_audio_free": (_I, [_P]),
+    "wj_qwen_audio_tokens": (_I, [_I]),
+    "wj_qwen_audio_encode": (_I, [_P, _P, _I, _I, C.POINTER(C.c_int32), _P, C.POINTER(C.c_int32), _P]),
     "wj_whisper_align": (_I, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I,
                               C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32),
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),

@@ -7,14 +7,16 @@ un-vendored ``qwen_asr`` package (modules/qwen_asr.py:545-757).  What exists her
   * ``HipQwen3Decoder``: the LLM of Qwen3-ASR (RMSNorm, q/k-norm, RoPE, grouped-query attention, SwiGLU, tied head) behind
     ``wj_qwen_*`` (csrc/qwen.hip): ragged batched prefill from EMBEDDINGS + greedy generation until EOS, parity-tested on
     the GPU against ``oracle/qwen3_ref.py`` (itself pinned against ``transformers.models.qwen3_asr``);
-  * ``HipQwenTextGenerator``: the ``TextGenerator`` surface over it.  The audio tower (three stride-2 convolutions +
-    windowed-attention encoder + projector) is NOT on the device yet: the generator takes an ``audio_embedder`` plug-in
-    (callable: 16 kHz mono float32 -> projected audio embeddings ``[n_tokens, hidden]``) and refuses to run without one --
-    there is no silent CPU path;
+  * ``HipQwenAudioTower``: log-mel (``wj_logmel_f32``, RAW mode = Qwen3-ASR's feature extractor) -> three stride-2
+    convolutions as GEMMs over gathered patches -> windowed-attention encoder -> projector (``wj_qwen_audio_*``,
+    csrc/qwen_audio.hip), all clips of a call batched, parity-tested against the same oracle;
+  * ``HipQwenTextGenerator``: the ``TextGenerator`` surface over both.  The tokenizer / chat template are not part of the
+    slice (no vocabulary offline): ``prompt_builder`` and ``detokenize`` are required plug-ins, nothing is guessed and
+    nothing falls back to the CPU;
   * weight packing from the published state-dict names (``model.language_model.layers.N...``), seeded synthetic weights for
     the tests.
 
-Not here yet: the audio tower kernels, the forced aligner (``TextAligner``), fp8 weight streaming (cfg5's "fp8 MFMA"), beam
+Not here yet: the forced aligner (``TextAligner``), fp8 weight streaming (cfg5's "fp8 MFMA"), beam
 search for the LLM (upstream decodes greedily), measurements.  DESIGN.md section 7 has the plan.
 """
 from __future__ import annotations
@@ -100,8 +102,104 @@ def engine_tensors(d: Qwen3Dims, w: Dict[str, np.ndarray]) -> List[Tuple[str, np
 
 def pack_blob(d: Qwen3Dims, w: Dict[str, np.ndarray], dtype: str) -> Tuple[torch.Tensor, np.ndarray]:
     """(host uint8 blob, int64 offsets) for ``wj_qwen_create``: matrices in ``dtype``, vectors fp32, 256-byte aligned."""
+    return _pack(engine_tensors(d, w), dtype)
+
+
+# ---- audio tower ---------------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Qwen3AudioDims:
+    n_mels: int = 128
+    n_layer: int = 24
+    n_head: int = 16
+    ffn: int = 4096
+    d_model: int = 1024
+    n_window: int = 50
+    n_window_infer: int = 800
+    conv_hidden: int = 480
+    out_dim: int = 2048
+
+
+class Qwen3AudioDimsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_mels", "n_layer", "n_head", "ffn", "d_model", "n_window", "n_window_infer",
+                                          "conv_hidden", "out_dim")]
+
+
+AUDIO_GLOBALS = ("CONV1_W", "CONV1_B", "CONV2_W", "CONV2_B", "CONV3_W", "CONV3_B", "CONVOUT_W", "POS", "LNPOST_W", "LNPOST_B",
+                 "PROJ1_W", "PROJ1_B", "PROJ2_W", "PROJ2_B")                                    # order of WJ_QA_* in wjhip.h
+AUDIO_LAYER = ("LN1_W", "LN1_B", "QKV_W", "QKV_B", "OUT_W", "OUT_B", "LN2_W", "LN2_B", "FC1_W", "FC1_B", "FC2_W", "FC2_B")
+
+
+def synth_audio_weights(d: Qwen3AudioDims, seed: int = 11) -> Dict[str, np.ndarray]:
+    """Seeded audio-tower + projector weights under the published names."""
+    rng = np.random.default_rng(seed)
+    p, w = "model.audio_tower.", {}
+
+    def t(name, shape, fan_in, gain=1.0):
+        w[name] = (rng.standard_normal(shape) * gain / np.sqrt(fan_in)).astype(np.float32)
+
+    def b(name, n, base=0.0):
+        w[name] = (base + 0.1 * rng.standard_normal(n)).astype(np.float32)
+
+    C_ = d.conv_hidden
+    t(p + "conv2d1.weight", (C_, 1, 3, 3), 9, 1.5); b(p + "conv2d1.bias", C_)
+    t(p + "conv2d2.weight", (C_, C_, 3, 3), 9 * C_, 1.5); b(p + "conv2d2.bias", C_)
+    t(p + "conv2d3.weight", (C_, C_, 3, 3), 9 * C_, 1.5); b(p + "conv2d3.bias", C_)
+    t(p + "conv_out.weight", (d.d_model, C_ * 16), C_ * 16)
+    for l in range(d.n_layer):
+        q = f"{p}layers.{l}."
+        b(q + "self_attn_layer_norm.weight", d.d_model, 1.0); b(q + "self_attn_layer_norm.bias", d.d_model)
+        for n in ("q_proj", "k_proj", "v_proj"):
+            t(q + f"self_attn.{n}.weight", (d.d_model, d.d_model), d.d_model, 1.5); b(q + f"self_attn.{n}.bias", d.d_model)
+        t(q + "self_attn.out_proj.weight", (d.d_model, d.d_model), d.d_model, 0.5); b(q + "self_attn.out_proj.bias", d.d_model)
+        b(q + "final_layer_norm.weight", d.d_model, 1.0); b(q + "final_layer_norm.bias", d.d_model)
+        t(q + "fc1.weight", (d.ffn, d.d_model), d.d_model); b(q + "fc1.bias", d.ffn)
+        t(q + "fc2.weight", (d.d_model, d.ffn), d.ffn, 0.5); b(q + "fc2.bias", d.d_model)
+    b(p + "ln_post.weight", d.d_model, 1.0); b(p + "ln_post.bias", d.d_model)
+    m = "model.multi_modal_projector."
+    t(m + "linear_1.weight", (d.d_model, d.d_model), d.d_model); b(m + "linear_1.bias", d.d_model)
+    t(m + "linear_2.weight", (d.out_dim, d.d_model), d.d_model); b(m + "linear_2.bias", d.out_dim)
+    return w
+
+
+def _sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.ndarray:
+    inc = np.log(max_timescale) / (channels // 2 - 1)
+    inv = np.exp(-inc * np.arange(channels // 2, dtype=np.float32)).astype(np.float32)
+    tt = np.arange(length, dtype=np.float32)[:, None] * inv[None, :]
+    return np.concatenate([np.sin(tt), np.cos(tt)], axis=1).astype(np.float32)
+
+
+def audio_engine_tensors(d: Qwen3AudioDims, w: Dict[str, np.ndarray]) -> List[Tuple[str, np.ndarray, bool]]:
+    """Patch-matrix orders (csrc/qwen_audio.hip): conv1 ``[C][16]`` = its 9 taps (frequency-major) zero-padded to 16; conv2 /
+    conv3 ``[C][9 * C]`` with column = tap * C + input channel (channels-last activations); conv_out's columns re-ordered from
+    (channel, frequency) to (frequency, channel), the order the third convolution's (chunk, time, frequency) rows produce."""
+    p, C_ = "model.audio_tower.", d.conv_hidden
+    c1 = np.zeros((C_, 16), dtype=np.float32)
+    c1[:, :9] = w[p + "conv2d1.weight"].reshape(C_, 9)
+    conv = lambda k: np.ascontiguousarray(w[p + k].transpose(0, 2, 3, 1).reshape(C_, 9 * C_))      # noqa: E731  [o][kf][kt][ch]
+    co = w[p + "conv_out.weight"].reshape(d.d_model, C_, 16).transpose(0, 2, 1).reshape(d.d_model, 16 * C_)
+    m = "model.multi_modal_projector."
+    g = {"CONV1_W": (c1, True), "CONV1_B": (w[p + "conv2d1.bias"], False), "CONV2_W": (conv("conv2d2.weight"), True),
+         "CONV2_B": (w[p + "conv2d2.bias"], False), "CONV3_W": (conv("conv2d3.weight"), True), "CONV3_B": (w[p + "conv2d3.bias"], False),
+         "CONVOUT_W": (np.ascontiguousarray(co), True), "POS": (_sinusoids(13, d.d_model), False),
+         "LNPOST_W": (w[p + "ln_post.weight"], False), "LNPOST_B": (w[p + "ln_post.bias"], False),
+         "PROJ1_W": (w[m + "linear_1.weight"], True), "PROJ1_B": (w[m + "linear_1.bias"], False),
+         "PROJ2_W": (w[m + "linear_2.weight"], True), "PROJ2_B": (w[m + "linear_2.bias"], False)}
+    out = [(n, g[n][0], g[n][1]) for n in AUDIO_GLOBALS]
+    for l in range(d.n_layer):
+        q = f"{p}layers.{l}."
+        qkv_w = np.concatenate([w[q + f"self_attn.{n}.weight"] for n in ("q_proj", "k_proj", "v_proj")], 0)
+        qkv_b = np.concatenate([w[q + f"self_attn.{n}.bias"] for n in ("q_proj", "k_proj", "v_proj")], 0)
+        t = {"LN1_W": (w[q + "self_attn_layer_norm.weight"], False), "LN1_B": (w[q + "self_attn_layer_norm.bias"], False),
+             "QKV_W": (qkv_w, True), "QKV_B": (qkv_b, False), "OUT_W": (w[q + "self_attn.out_proj.weight"], True),
+             "OUT_B": (w[q + "self_attn.out_proj.bias"], False), "LN2_W": (w[q + "final_layer_norm.weight"], False),
+             "LN2_B": (w[q + "final_layer_norm.bias"], False), "FC1_W": (w[q + "fc1.weight"], True), "FC1_B": (w[q + "fc1.bias"], False),
+             "FC2_W": (w[q + "fc2.weight"], True), "FC2_B": (w[q + "fc2.bias"], False)}
+        out.extend((f"l{l}.{n}", t[n][0], t[n][1]) for n in AUDIO_LAYER)
+    return out
+
+
+def _pack(tensors, dtype: str) -> Tuple[torch.Tensor, np.ndarray]:
     half = {"bfloat16": torch.bfloat16, "float16": torch.float16}.get(dtype)
-    tensors = engine_tensors(d, w)
     offsets = np.zeros(len(tensors), dtype=np.int64)
     cursor, sizes = 0, []
     for i, (_, arr, is_mat) in enumerate(tensors):
@@ -116,6 +214,71 @@ def pack_blob(d: Qwen3Dims, w: Dict[str, np.ndarray], dtype: str) -> Tuple[torch
             t = t.to(half)
         blob[off:off + nbytes] = t.reshape(-1).view(torch.uint8)
     return blob, offsets
+
+
+def pack_audio_blob(d: Qwen3AudioDims, w: Dict[str, np.ndarray], dtype: str) -> Tuple[torch.Tensor, np.ndarray]:
+    return _pack(audio_engine_tensors(d, w), dtype)
+
+
+class HipQwenAudioTower:
+    """Clips (16 kHz mono float32) -> projected audio embeddings, one fp32 CUDA ``[n_tokens, out_dim]`` tensor per clip.
+    Feature extraction as ``Qwen3ASRFeatureExtractor``: clips shorter than 0.5 s are zero-padded to 8000 samples, Whisper's
+    log-mel formula on the clip as it is (``wj_logmel_f32`` RAW mode), frame axis padded to a multiple of 100."""
+
+    MIN_SAMPLES = 8000
+
+    def __init__(self, dims: Qwen3AudioDims, weights: Dict[str, np.ndarray], *, dtype: str = "float16", device: int = 0,
+                 max_seconds: int = 240):
+        from . import engine
+        if not torch.cuda.is_available():
+            raise hipbind.WjError("no ROCm device visible: the HIP path has no CPU fallback")
+        self.dims, self.dtype, self.device = dims, dtype, int(device)
+        self.dev = torch.device("cuda", device)
+        self.ctx = hipbind.context(device)
+        self._lib = hipbind.lib()
+        host, offsets = pack_audio_blob(dims, weights, dtype)
+        self.blob = host.to(self.dev)
+        self.max_chunks = int(max_seconds)
+        self.fe = engine.HipLogMel(dims.n_mels, "raw", device=device)
+        cd = Qwen3AudioDimsC(dims.n_mels, dims.n_layer, dims.n_head, dims.ffn, dims.d_model, dims.n_window, dims.n_window_infer,
+                             dims.conv_hidden, dims.out_dim)
+        off = (C.c_int64 * len(offsets))(*offsets.tolist())
+        handle = C.c_void_p()
+        torch.cuda.current_stream().synchronize()
+        check(self._lib.wj_qwen_audio_create(self.ctx.handle, C.byref(cd), DTYPES[dtype], C.c_void_p(self.blob.data_ptr()),
+                                             self.blob.numel(), off, len(offsets), self.max_chunks, C.byref(handle)), "wj_qwen_audio_create")
+        self.handle = handle
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._lib.wj_qwen_audio_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def features(self, clips: Sequence[np.ndarray]) -> Tuple[torch.Tensor, np.ndarray]:
+        """(mel fp32 CUDA ``[n, n_mels, frames_max]`` zero-padded, valid frames per clip)."""
+        padded = [np.pad(np.asarray(c, dtype=np.float32).reshape(-1), (0, max(0, self.MIN_SAMPLES - len(c)))) for c in clips]
+        frames = np.array([len(c) // 160 for c in padded], dtype=np.int32)
+        width = int((frames.max() + 99) // 100 * 100)
+        return self.fe(padded, out_frames=width), frames
+
+    def encode(self, clips: Sequence[np.ndarray]) -> List[torch.Tensor]:
+        mel, frames = self.features(clips)
+        n_tok = np.array([int(self._lib.wj_qwen_audio_tokens(int(f))) for f in frames], dtype=np.int32)
+        out = torch.empty((int(n_tok.sum()), self.dims.out_dim), dtype=torch.float32, device=self.dev)
+        got = np.zeros(len(clips), dtype=np.int32)
+        torch.cuda.current_stream().synchronize()
+        check(self._lib.wj_qwen_audio_encode(self.handle, C.c_void_p(mel.data_ptr()), len(clips), int(mel.shape[2]),
+                                             frames.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(out.data_ptr()),
+                                             got.ctypes.data_as(C.POINTER(C.c_int32)), None), "wj_qwen_audio_encode")
+        assert (got == n_tok).all(), (got, n_tok)
+        edges = np.concatenate([[0], np.cumsum(n_tok)])
+        return [out[edges[i]: edges[i + 1]] for i in range(len(clips))]
 
 
 @dataclass
@@ -221,10 +384,15 @@ class HipQwenTextGenerator:
     language, context)`` returns the token ids of the chat prompt with ``n_audio`` placeholders; ``detokenize`` turns ids
     into text.  All three are required -- nothing is guessed."""
 
-    def __init__(self, dims: Qwen3Dims, weights: Dict[str, np.ndarray], *, audio_embedder: Optional[Callable] = None,
-                 prompt_builder: Optional[Callable] = None, detokenize: Optional[Callable] = None, dtype: str = "float16",
-                 device: int = 0, batch_size: int = 8, max_ctx: int = 1024, max_new_tokens: int = 256):
+    def __init__(self, dims: Qwen3Dims, weights: Dict[str, np.ndarray], *, audio_dims: Optional[Qwen3AudioDims] = None,
+                 audio_embedder: Optional[Callable] = None, prompt_builder: Optional[Callable] = None,
+                 detokenize: Optional[Callable] = None, dtype: str = "float16", device: int = 0, batch_size: int = 8,
+                 max_ctx: int = 1024, max_new_tokens: int = 256):
+        """``weights``: one state dict under the published names (decoder; audio tower + projector when ``audio_dims`` is
+        given, in which case the device tower is the embedder).  ``audio_embedder`` overrides it with any callable
+        ``(clips) -> [embeddings per clip]``."""
         self.dims, self._weights, self.dtype, self.device = dims, weights, dtype, device
+        self.audio_dims, self._tower = audio_dims, None
         self.audio_embedder, self.prompt_builder, self.detokenize = audio_embedder, prompt_builder, detokenize
         self.batch_size, self.max_ctx, self.max_new_tokens = int(batch_size), int(max_ctx), int(max_new_tokens)
         self._model: Optional[HipQwen3Decoder] = None
@@ -233,19 +401,26 @@ class HipQwenTextGenerator:
         if self._model is None:
             self._model = HipQwen3Decoder(self.dims, self._weights, dtype=self.dtype, device=self.device, max_seqs=self.batch_size,
                                           max_ctx=self.max_ctx)
+        if self._tower is None and self.audio_embedder is None and self.audio_dims is not None:
+            self._tower = HipQwenAudioTower(self.audio_dims, self._weights, dtype=self.dtype, device=self.device)
 
     def unload(self) -> None:
         if self._model is not None:
             self._model.close()
             self._model = None
+        if self._tower is not None:
+            self._tower.close()
+            self._tower = None
 
     cleanup = unload
 
     def _require(self) -> None:
-        missing = [n for n in ("audio_embedder", "prompt_builder", "detokenize") if getattr(self, n) is None]
+        missing = [n for n in ("prompt_builder", "detokenize") if getattr(self, n) is None]
+        if self.audio_embedder is None and self.audio_dims is None:
+            missing.insert(0, "audio_dims (device audio tower) or audio_embedder")
         if missing:
-            raise hipbind.WjError("HipQwenTextGenerator: " + ", ".join(missing) + " not supplied -- the Qwen3-ASR audio tower and "
-                                  "tokenizer are not part of this slice (whisperjav_amd/qwen.py) and nothing falls back to the CPU")
+            raise hipbind.WjError("HipQwenTextGenerator: " + ", ".join(missing) + " not supplied -- the tokenizer / chat template "
+                                  "are not part of this slice (whisperjav_amd/qwen.py) and nothing falls back to the CPU")
 
     def generate_batch(self, audio_paths: Sequence[Path], language: str = "ja", contexts: Optional[Sequence[Optional[str]]] = None,
                        **kwargs: Any) -> List[TranscriptionResult]:
@@ -255,10 +430,16 @@ class HipQwenTextGenerator:
         out: List[TranscriptionResult] = []
         contexts = list(contexts) if contexts is not None else [None] * len(audio_paths)
         for lo in range(0, len(audio_paths), self.batch_size):
-            embeds = []
-            for path, ctx_text in zip(audio_paths[lo: lo + self.batch_size], contexts[lo: lo + self.batch_size]):
+            clips = []
+            for path in audio_paths[lo: lo + self.batch_size]:
                 audio, sr = read_audio(Path(path))
-                a = self.audio_embedder(audio, sr)
+                if sr != 16000:
+                    from .pipeline import to_16k
+                    audio = to_16k(audio, sr)
+                clips.append(audio)
+            audio_embeds = (self.audio_embedder or self._tower.encode)(clips)       # one launch chain for the batch's clips
+            embeds = []
+            for a, ctx_text in zip(audio_embeds, contexts[lo: lo + self.batch_size]):
                 ids = self.prompt_builder(int(a.shape[0]), language, ctx_text)
                 embeds.append(self._model.prompt_embeddings(ids, torch.as_tensor(a)))
             self._model.prefill(embeds)
