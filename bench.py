@@ -675,12 +675,69 @@ def run_cfg2(args, info, dims):
     return 0
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# cfg5, first slice: Qwen3-ASR audio tower + decoder on the device (greedy), synthetic weights of the published geometry
+# ---------------------------------------------------------------------------------------------------------------
+def run_cfg5(args, info):
+    from whisperjav_amd import qwen
+    dev = torch.device("cuda", info.local_rank)
+    d, ad = qwen.Qwen3Dims(), qwen.Qwen3AudioDims()
+    t0 = time.perf_counter()
+    w = {**qwen.synth_weights(d, seed=1), **qwen.synth_audio_weights(ad, seed=2)}
+    B, n_new = args.qwen_batch, args.qwen_tokens
+    tower = qwen.HipQwenAudioTower(ad, w, dtype=args.dtype, device=info.local_rank, max_seconds=8 * B)
+    model = qwen.HipQwen3Decoder(d, w, dtype=args.dtype, device=info.local_rank, max_seqs=B, max_ctx=192, max_rows=B * 128)
+    del w
+    log(f"[bench] cfg5: weights + engines ready after {time.perf_counter() - t0:.1f}s")
+    rng = np.random.default_rng(5)
+    secs = rng.uniform(2.0, 6.0, B)
+    clips = [synth.speech_like(float(sv), seed=500 + i) for i, sv in enumerate(secs)]
+    audio_s = float(sum(len(c) for c in clips)) / 16000.0
+
+    def step():
+        emb = tower.encode(clips)
+        prompts = [model.prompt_embeddings([151644, 872] + [d.audio_token_id] * int(a.shape[0]) + [151645, 198, 151644, 77091], a) for a in emb]
+        model.prefill(prompts)
+        return model.generate(max_new_tokens=n_new, eos_token_ids=(d.vocab - 1,))
+    for _ in range(args.warmup):
+        step()
+    sharding.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    sharding.barrier()
+    elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
+    rtfx = audio_s * args.steps * info.world / elapsed
+    if info.rank == 0:
+        esz = 4 if args.dtype == "float32" else 2
+        dec_params = d.n_layer * (d.hidden * (d.n_head + 2 * d.n_kv_head) * d.head_dim + d.n_head * d.head_dim * d.hidden + 3 * d.hidden * d.ffn) + d.vocab * d.hidden
+        print(json.dumps({
+            "metric": METRIC, "value": round(rtfx, 2), "unit": UNIT, "audio_hours_per_sec": round(rtfx / 3600.0, 5), "n_gpus": info.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": DT_LABEL[args.dtype], "data": "synthetic",
+            "config": {"workload": (f"cfg5, first slice: Qwen3-ASR-1.7B geometry (seeded random weights), {B} clips of 2-6 s per step: RAW log-mel -> "
+                                    f"audio tower -> ragged prefill -> greedy decode of {n_new} tokens (random weights never emit EOS); no TEN-VAD, "
+                                    f"no forced aligner, no fp8, unoptimised glue kernels: a first measured number, not a tuned one"),
+                       "clips_per_step": B, "audio_seconds_per_step": round(audio_s, 1), "decode_tokens": n_new,
+                       "tokens_generated": int(sum(len(t) for t in res.tokens)),
+                       "decoder_weight_bytes_per_step": dec_params * esz},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    tower.close(); model.close()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5"])
+    ap.add_argument("--qwen-batch", type=int, default=64, help="cfg5: clips per step")
+    ap.add_argument("--qwen-tokens", type=int, default=32, help="cfg5: greedy tokens per clip")
     ap.add_argument("--minutes", type=float, default=120.0, help="cfg3: length of the synthetic recording")
     ap.add_argument("--mode", default="balanced", choices=["balanced", "fidelity"],
                     help="cfg3 = balanced (faster-whisper contract); fidelity = the openai-whisper contract of FidelityPipeline (BASELINE cfg4 with --strong)")
@@ -735,6 +792,8 @@ def main():
     if not args.kv_fit and args.batch > 384:
         log("[bench] --no-kv-fit: a 448-position KV cache leaves room for 384 windows per call")
         args.batch = 384
+    if args.workload == "cfg5":
+        return run_cfg5(args, info)
     dims = pdims.dims_for(args.model)
     return run_cfg3(args, info, dims) if args.workload == "cfg3" else run_cfg2(args, info, dims)
 

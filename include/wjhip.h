@@ -262,6 +262,15 @@ int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32
 int wj_qwen_generate_greedy(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, int max_new, int32_t* tokens_out, int32_t* n_tokens_out,
                             float* token_logprob_out, void* stream);
 
+/* Token classification over a full (non-generative) pass: the forced aligner (Qwen3-ForcedAligner-0.6B, reference
+ * whisperjav/modules/qwen_asr.py:1198-1320 -> TextAligner, protocols.py:128-179) is this decoder + audio tower with a
+ * linear head over time bins, read at the <timestamp> marker positions of a prompt that interleaves the transcript's words
+ * with markers.  rows_host: indices into the packed token axis; head_w_dev: [n_labels][hidden] in the compute type (device),
+ * head_b_dev: fp32 [n_labels] or NULL.  argmax_out_host [n_rows]; logits_out_dev (may be NULL): fp32 [n_rows][n_labels]. */
+int wj_qwen_classify(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32_t* n_tokens_host, const int32_t* rows_host, int n_rows,
+                     const void* head_w_dev, const float* head_b_dev, int n_labels, int32_t* argmax_out_host, float* logits_out_dev,
+                     void* stream);
+
 /* ---- Qwen3-ASR audio tower (same slice): log-mel -> audio embeddings for the decoder's <audio> placeholders ----------
  * Replaces (un-vendored upstream): the audio encoder of the `qwen_asr` model (whisperjav/modules/qwen_asr.py:545-636,
  * run per VAD group from :638-757).  mel: wj_logmel_f32(..., WJ_MEL_RAW, ...) of every clip, frame axis zero-padded to a

@@ -82,6 +82,51 @@ def audio_token_count(n_frames: int, n_window: int = 50) -> int:
     return ((t - 1) // 2 + 1 - 1) // 2 + 1 + (n_frames // chunk) * 13
 
 
+def fix_timestamps(raw: Sequence[float]) -> List[int]:
+    """The forced aligner's monotonic repair (qwen_asr ``qwen3_forced_aligner.py``; transformers ``_fix_timestamps``): the
+    longest non-decreasing subsequence is kept, outlier blocks of <= 2 snap to the nearer good neighbour, longer ones are
+    interpolated linearly between the surrounding good values; result truncated to int."""
+    data = [float(v) for v in raw]
+    n = len(data)
+    if n == 0:
+        return []
+    dp, parent = [1] * n, [-1] * n
+    for i in range(1, n):
+        for j in range(i):
+            if data[j] <= data[i] and dp[j] + 1 > dp[i]:
+                dp[i], parent[i] = dp[j] + 1, j
+    idx = dp.index(max(dp))
+    good = [False] * n
+    while idx != -1:
+        good[idx] = True
+        idx = parent[idx]
+    out = list(data)
+    i = 0
+    while i < n:
+        if good[i]:
+            i += 1
+            continue
+        j = i
+        while j < n and not good[j]:
+            j += 1
+        left = next((out[k] for k in range(i - 1, -1, -1) if good[k]), None)
+        right = next((out[k] for k in range(j, n) if good[k]), None)
+        for pos in range(i, j):
+            if j - i <= 2:
+                if left is None:
+                    out[pos] = right
+                elif right is None:
+                    out[pos] = left
+                else:
+                    out[pos] = left if (pos - (i - 1)) <= (j - pos) else right
+            elif left is not None and right is not None:
+                out[pos] = left + (right - left) / (j - i + 1) * (pos - i + 1)
+            else:
+                out[pos] = left if left is not None else right
+        i = j
+    return [int(v) for v in out]
+
+
 def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     return w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
 
@@ -190,6 +235,15 @@ class Qwen3AsrOracle:
             x = self.decoder_layer(x, l, pos0, cache)
         x = rms_norm(x, self.w["model.language_model.norm.weight"], self.dims.rms_eps)
         return x @ self.w["model.language_model.embed_tokens.weight"].T
+
+    def classify(self, x: torch.Tensor, head_w: torch.Tensor, head_b: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Token classification (the forced aligner's head over time bins): embeddings [T, d] -> logits [T, n_labels] of the
+        final-normed hidden states; the aligner reads them at the ``<timestamp>`` marker positions."""
+        for l in range(self.dims.layers):
+            x = self.decoder_layer(x, l, 0, None)
+        x = rms_norm(x, self.w["model.language_model.norm.weight"], self.dims.rms_eps)
+        y = x @ head_w.T
+        return y if head_b is None else y + head_b
 
     def greedy(self, prompt: Sequence[int], audio: Optional[torch.Tensor], max_new: int) -> Tuple[List[int], List[float]]:
         """Greedy generation until an EOS id (not returned) or ``max_new`` tokens; per-token log-probs."""

@@ -156,3 +156,95 @@ def test_text_generator_end_to_end_on_the_device(hip, tmp_path):
             toks, _ = oracle.greedy(build(a.shape[0], "ja", None), a, 12)
         assert res.text == " ".join(map(str, toks)), (path.name, res.text, toks)
     gen.cleanup()
+
+
+def test_forced_aligner_on_the_device(hip, tmp_path):
+    """TextAligner surface (protocols.py:128-179): one full pass + the linear head over time bins at the <timestamp> markers
+    (``wj_qwen_classify``) == the oracle's ``classify`` (float32: identical bins, logits 2e-3), then the monotonic repair
+    and the bins -> seconds conversion of the upstream processor."""
+    import wave
+    from oracle import logmel
+    from whisperjav_amd import qwen, synth
+    d = qwen.Qwen3Dims(hidden=256, n_layer=2, n_head=2, n_kv_head=1, head_dim=128, ffn=512, vocab=2048, rope_theta=10000.0,
+                       audio_token_id=9, eos_token_ids=(1, 2))
+    ad = qwen.Qwen3AudioDims(n_layer=2, n_head=2, ffn=256, d_model=128, conv_hidden=16, out_dim=d.hidden, n_window_infer=400)
+    rng = np.random.default_rng(2)
+    w = {**qwen.synth_weights(d, seed=15), **qwen.synth_audio_weights(ad, seed=16),
+         "score.weight": (rng.standard_normal((96, d.hidden)) * 2.0 / np.sqrt(d.hidden)).astype(np.float32),
+         "score.bias": (0.1 * rng.standard_normal(96)).astype(np.float32)}
+    od = qwen3_ref.Qwen3AsrDims(n_mels=128, a_layers=2, a_heads=2, a_ffn=256, a_d=128, n_window=50, n_window_infer=400, conv_hidden=16,
+                                d=d.hidden, layers=d.n_layer, heads=d.n_head, kv_heads=d.n_kv_head, head_dim=128, ffn=d.ffn, vocab=d.vocab,
+                                rope_theta=d.rope_theta, audio_token_id=9, eos_token_ids=(1, 2))
+    oracle = qwen3_ref.Qwen3AsrOracle(od, w)
+    TS = 5                                                               # the <timestamp> marker's token id in this toy vocabulary
+
+    def word_prompt(n_audio, words, language):
+        ids = [11] + [d.audio_token_id] * n_audio
+        marks = []
+        for wd in words:
+            ids += [100 + (hash(wd) % 900)]
+            marks += [len(ids), len(ids) + 1]
+            ids += [TS, TS]
+        return ids, marks
+    split = lambda text, language: text.split()      # noqa: E731
+    al = qwen.HipQwenForcedAligner(d, ad, w, segment_ms=80.0, word_prompt=word_prompt, split_words=split, dtype="float32", batch_size=2,
+                                   max_ctx=256)
+    paths, texts = [], ["ka ki ku ke", "sa shi su", "ta"]
+    for i, s in enumerate((2.1, 1.3, 0.8)):
+        audio = synth.speech_like(s, seed=90 + i)
+        path = tmp_path / f"a{i}.wav"
+        with wave.open(str(path), "wb") as wf:
+            wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000)
+            wf.writeframes(np.clip(np.rint(audio * 32767), -32768, 32767).astype("<i2").tobytes())
+        paths.append(path)
+    results = al.align_batch(paths, texts, language="ja")
+    for path, text, res in zip(paths, texts, results):
+        with wave.open(str(path), "rb") as wf:
+            audio = np.frombuffer(wf.readframes(wf.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+        padded = np.pad(audio, (0, max(0, 8000 - len(audio))))
+        words = text.split()
+        with torch.no_grad():
+            a = oracle.audio_tokens(torch.from_numpy(logmel.logmel_ow(padded, 128, padding=0)))
+            ids, marks = word_prompt(a.shape[0], words, "ja")
+            lg = oracle.classify(oracle.embed(ids, a), torch.from_numpy(w["score.weight"]), torch.from_numpy(w["score.bias"]))
+        bins = lg[marks].argmax(-1).numpy()
+        assert res.metadata["raw_bins"] == bins.tolist(), (path.name, res.metadata["raw_bins"], bins.tolist())
+        ms = qwen3_ref.fix_timestamps(bins.astype(np.float64) * 80.0)
+        assert [w_.word for w_ in res.words] == words
+        assert [(w_.start, w_.end) for w_ in res.words] == [(round(ms[2 * i] / 1000.0, 3), round(ms[2 * i + 1] / 1000.0, 3)) for i in range(len(words))]
+    al.cleanup()
+
+
+def test_published_geometry_one_clip(hip):
+    """Qwen3-ASR-1.7B's own dimensions (audio tower 24 x 1024 / conv 480, decoder 28 x 2048, 16 / 8 heads of 128, vocabulary
+    151 936) on seeded weights, float16 on the device against the fp32 oracle: audio embeddings of a 4 s clip, the logits
+    of the prompt's last position, the first greedy tokens."""
+    import psutil
+    if psutil.virtual_memory().available < 40 * 2 ** 30:
+        pytest.skip("needs ~30 GB of host memory for the 1.7 B-parameter fp32 weights and their fp16 blob")
+    from oracle import logmel
+    from whisperjav_amd import qwen, synth
+    d, ad = qwen.Qwen3Dims(), qwen.Qwen3AudioDims()
+    w = {**qwen.synth_weights(d, seed=1), **qwen.synth_audio_weights(ad, seed=2)}
+    od = qwen3_ref.Qwen3AsrDims()
+    oracle = qwen3_ref.Qwen3AsrOracle(od, w)
+    tower = qwen.HipQwenAudioTower(ad, w, dtype="float16", max_seconds=8)
+    model = qwen.HipQwen3Decoder(d, w, dtype="float16", max_seqs=1, max_ctx=256)
+    clip = synth.speech_like(4.0, seed=7)
+    a = tower.encode([clip])[0]
+    with torch.no_grad():
+        ref_a = oracle.audio_tokens(torch.from_numpy(logmel.logmel_ow(clip, 128, padding=0)))
+    err_a = float((a.cpu() - ref_a).abs().max()) / max(1.0, float(ref_a.abs().max()))
+    ids = [151644, 872] + [d.audio_token_id] * int(a.shape[0]) + [151645, 198, 151644, 77091]
+    logits = model.prefill([model.prompt_embeddings(ids, a)], want_logits=True).cpu()[0]
+    res = model.generate(max_new_tokens=6, eos_token_ids=(d.vocab - 1,))
+    with torch.no_grad():
+        x = oracle.embed(ids, ref_a)
+        ref_l = oracle.logits(x)[-1]
+        toks, lps = oracle.greedy(ids, ref_a, 6)
+    err_l = float((logits - ref_l).abs().max())
+    same = sum(1 for g, r in zip(res.tokens[0], toks) if g == r)
+    print(f"published geometry: audio rel err {err_a:.2e}, logits abs err {err_l:.3f} (spread {float(ref_l.std()):.2f}), tokens {res.tokens[0]} vs {toks}")
+    assert err_a < 5e-2 and err_l < 0.15 * max(1.0, float(ref_l.std())) and same >= 3
+    assert abs(res.token_logprob[0][0] - lps[0]) < 0.1
+    tower.close(); model.close()

@@ -109,3 +109,48 @@ def test_feature_extractor_is_whispers_formula_without_padding():
         assert n == ref.shape[1] == len(padded) // 160, (n, ref.shape)
         assert np.abs(feats[:, :n] - ref).max() < 5e-5
         assert feats.shape[1] % 100 == 0 and np.abs(feats[:, n:]).max() == 0.0 if feats.shape[1] > n else True
+
+
+def test_fix_timestamps_matches_transformers():
+    """The forced aligner's monotonic repair: oracle and product restatements == transformers' ``_fix_timestamps`` on random
+    sequences with planted outliers (short blocks, long blocks, outliers at both ends)."""
+    from transformers.models.qwen3_asr.processing_qwen3_asr import _fix_timestamps
+    from whisperjav_amd import qwen
+    rng = np.random.default_rng(0)
+    for trial in range(60):
+        n = int(rng.integers(1, 40))
+        base = np.sort(rng.integers(0, 6000, n)).astype(np.float64) * 80.0
+        k = int(rng.integers(0, max(1, n // 2) + 1))
+        idx = rng.choice(n, size=min(k, n), replace=False)
+        base[idx] = rng.integers(0, 6000, len(idx)) * 80.0
+        ref = _fix_timestamps(base.copy())
+        assert qwen3_ref.fix_timestamps(base) == ref, (trial, base.tolist())
+        assert qwen.fix_timestamps(base) == ref
+
+
+def test_token_classification_head_matches_transformers():
+    """The forced aligner's forward (``Qwen3ASRForTokenClassification``: the model + a linear ``score`` head) == the
+    oracle's ``classify`` on the same weights."""
+    from transformers import Qwen3ASRForTokenClassification
+    model, sd = tiny(DIMS, seed=4)
+    cfg = model.config
+    cfg.num_labels = 50
+    torch.manual_seed(1)
+    clf = Qwen3ASRForTokenClassification(cfg).eval()
+    clf.model.load_state_dict(model.model.state_dict())
+    sd2 = {k: v.detach().float().numpy() for k, v in clf.state_dict().items()}
+    oracle = qwen3_ref.Qwen3AsrOracle(DIMS, sd2)
+    n_frames = 260
+    mel = torch.randn(DIMS.n_mels, n_frames, generator=torch.Generator().manual_seed(9))
+    n_audio = qwen3_ref.audio_token_count(n_frames, DIMS.n_window)
+    prompt = [11] + [DIMS.audio_token_id] * n_audio + [20, 5, 21, 22, 5, 5, 23, 5]
+    feats = torch.zeros(1, DIMS.n_mels, 300)
+    feats[0, :, :n_frames] = mel
+    mask = torch.zeros(1, 300, dtype=torch.long)
+    mask[0, :n_frames] = 1
+    with torch.no_grad():
+        ref = clf(input_ids=torch.tensor([prompt]), input_features=feats, input_features_mask=mask).logits[0]
+        x = oracle.embed(prompt, oracle.audio_tokens(mel))
+        head_b = torch.from_numpy(sd2["score.bias"]) if "score.bias" in sd2 else None
+        got = oracle.classify(x, torch.from_numpy(sd2["score.weight"]), head_b)
+    assert got.shape == ref.shape and float((got - ref).abs().max()) < 5e-4

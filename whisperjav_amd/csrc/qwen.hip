@@ -393,6 +393,66 @@ int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32
   return WJ_OK;
 }
 
+int wj_qwen_classify(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32_t* n_tokens_host, const int32_t* rows_host, int n_rows,
+                     const void* head_w_dev, const float* head_b_dev, int n_labels, int32_t* argmax_out_host, float* logits_out_dev,
+                     void* stream) {
+  WJ_REQUIRE(m && embeds_dev && n_tokens_host && rows_host && head_w_dev && argmax_out_host, "wj_qwen_classify: NULL argument");
+  WJ_REQUIRE(n_seqs >= 1 && n_seqs <= m->max_seqs && n_rows >= 1 && n_rows <= m->max_rows, "wj_qwen_classify: %d sequences / %d rows do not fit", n_seqs, n_rows);
+  WJ_REQUIRE(n_labels >= 2 && n_labels <= m->d.vocab, "wj_qwen_classify: %d labels (the logits buffer holds up to the vocabulary's %d)", n_labels, m->d.vocab);
+  std::vector<int32_t> seq, pos;
+  for (int b = 0; b < n_seqs; ++b) {
+    WJ_REQUIRE(n_tokens_host[b] >= 1 && n_tokens_host[b] <= m->max_ctx, "wj_qwen_classify: sequence %d has %d tokens (context %d)", b, n_tokens_host[b], m->max_ctx);
+    for (int t = 0; t < n_tokens_host[b]; ++t) { seq.push_back(b); pos.push_back(t); }
+  }
+  const int M = (int)seq.size();
+  WJ_REQUIRE(M <= m->max_rows, "wj_qwen_classify: %d tokens in all (max_rows %d)", M, m->max_rows);
+  for (int i = 0; i < n_rows; ++i) WJ_REQUIRE(rows_host[i] >= 0 && rows_host[i] < M, "wj_qwen_classify: row %d out of range", rows_host[i]);
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  WJ_HIP(hipMemcpyAsync(m->row_seq, seq.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(m->row_pos, pos.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, s));
+  WJ_HIP(hipMemcpyAsync(m->x, embeds_dev, sizeof(float) * (size_t)M * m->d.hidden, hipMemcpyDeviceToDevice, s));
+  WJ_TRYQ(run_layers(m, M, s));
+  // the selected rows (e.g. the <timestamp> markers of a forced-alignment prompt): final RMSNorm + the caller's head.  The
+  // gather goes through a scratch allocation because x is the residual stream being read.
+  int32_t* tmp_rows = nullptr;
+  float* gathered = nullptr;
+  if (hipMalloc(&gathered, sizeof(float) * (size_t)n_rows * m->d.hidden) != hipSuccess) { set_error("wj_qwen_classify: out of memory"); return WJ_E_HIP; }
+  if (hipMalloc(&tmp_rows, sizeof(int32_t) * (size_t)n_rows) != hipSuccess) { (void)hipFree(gathered); set_error("wj_qwen_classify: out of memory"); return WJ_E_HIP; }
+  float* d_logits = nullptr;
+  int32_t* d_ids = nullptr;
+  float* d_lp = nullptr;
+  const int64_t ldl = (n_labels + 63) / 64 * 64;
+  struct Guard { void *a, *b, *c, *d, *e; ~Guard() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); (void)hipFree(d); (void)hipFree(e); } } guard{gathered, tmp_rows, nullptr, nullptr, nullptr};
+  if (hipMalloc(&d_logits, sizeof(float) * (size_t)n_rows * ldl) != hipSuccess || hipMalloc(&d_ids, sizeof(int32_t) * n_rows) != hipSuccess ||
+      hipMalloc(&d_lp, sizeof(float) * 2 * n_rows) != hipSuccess) {
+    guard.c = d_logits; guard.d = d_ids; guard.e = d_lp;
+    set_error("wj_qwen_classify: out of memory");
+    return WJ_E_HIP;
+  }
+  guard.c = d_logits; guard.d = d_ids; guard.e = d_lp;
+  WJ_HIP(hipMemcpyAsync(tmp_rows, rows_host, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n_rows), dim3(256), 0, s, m->x, tmp_rows, gathered, m->d.hidden);
+  WJ_LAUNCH_CHECK();
+  const int D = m->d.hidden, dt = m->dtype;
+  // normed rows go to the head GEMM in the compute type; h holds max_rows x D elements
+  if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(ceil_div(n_rows, 4)), dim3(256), 0, s, gathered, m->F(WJ_Q_NORM_W), TP(float, m->h), n_rows, D, m->d.rms_eps);
+  else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(ceil_div(n_rows, 4)), dim3(256), 0, s, gathered, m->F(WJ_Q_NORM_W), TP(f16_t, m->h), n_rows, D, m->d.rms_eps);
+  else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(ceil_div(n_rows, 4)), dim3(256), 0, s, gathered, m->F(WJ_Q_NORM_W), TP(bf16_t, m->h), n_rows, D, m->d.rms_eps);
+  WJ_LAUNCH_CHECK();
+  GemmArgs g;
+  g.A = m->h; g.lda = D; g.W = head_w_dev; g.ldw = D; g.bias = head_b_dev; g.M = n_rows; g.N = n_labels; g.K = D; g.out = d_logits; g.ldc = ldl;
+  WJ_TRYQ(launch_gemm(dt, EPI_F32, g, s, 0));
+  WJ_TRYQ(launch_topk_logprob(d_logits, ldl, n_rows, n_labels, 1, nullptr, d_ids, d_lp, d_lp + n_rows, s));
+  WJ_HIP(hipMemcpyAsync(argmax_out_host, d_ids, sizeof(int32_t) * n_rows, hipMemcpyDeviceToHost, s));
+  if (logits_out_dev)
+    WJ_HIP(hipMemcpy2DAsync(logits_out_dev, sizeof(float) * n_labels, d_logits, sizeof(float) * ldl, sizeof(float) * n_labels, n_rows,
+                            hipMemcpyDeviceToDevice, s));
+  WJ_HIP(hipStreamSynchronize(s));
+  m->n_seqs = 0;       // the caches hold a classification pass: generation needs its own prefill
+  return WJ_OK;
+}
+
 int wj_qwen_generate_greedy(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, int max_new, int32_t* tokens_out, int32_t* n_tokens_out,
                             float* token_logprob_out, void* stream) {
   WJ_REQUIRE(m && eos_ids_host && tokens_out && n_tokens_out, "wj_qwen_generate_greedy: NULL argument");

@@ -354,6 +354,31 @@ class HipQwen3Decoder:
         self._n_seqs = len(embeds)
         return out
 
+    def classify(self, embeds: Sequence[torch.Tensor], rows: Sequence[Sequence[int]], head_w: torch.Tensor,
+                 head_b: Optional[torch.Tensor] = None, want_logits: bool = False):
+        """One full pass over the prompts ``embeds`` and a linear head (``head_w`` [n_labels, hidden], CUDA, in the compute
+        type; ``head_b`` fp32 or None) on the positions ``rows[b]`` of sequence b: the forced aligner's computation.
+        Returns the arg-max label per selected position (one int array per sequence) and, optionally, the logits."""
+        n = np.array([int(e.shape[0]) for e in embeds], dtype=np.int32)
+        starts = np.concatenate([[0], np.cumsum(n)])
+        flat = np.ascontiguousarray([starts[b] + int(r) for b, rs in enumerate(rows) for r in rs], dtype=np.int32)
+        packed = torch.cat([e.to(self.dev, torch.float32) for e in embeds], 0).contiguous()
+        n_labels = int(head_w.shape[0])
+        want = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16}[self.dtype]
+        hw = head_w.to(self.dev, want).contiguous()
+        hb = head_b.to(self.dev, torch.float32).contiguous() if head_b is not None else None
+        out = np.zeros(len(flat), dtype=np.int32)
+        logits = torch.empty((len(flat), n_labels), dtype=torch.float32, device=self.dev) if want_logits else None
+        torch.cuda.current_stream().synchronize()
+        check(self._lib.wj_qwen_classify(self.handle, C.c_void_p(packed.data_ptr()), len(embeds), n.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         flat.ctypes.data_as(C.POINTER(C.c_int32)), len(flat), C.c_void_p(hw.data_ptr()),
+                                         C.c_void_p(hb.data_ptr()) if hb is not None else None, n_labels,
+                                         out.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(logits.data_ptr()) if logits is not None else None,
+                                         None), "wj_qwen_classify")
+        edges = np.concatenate([[0], np.cumsum([len(rs) for rs in rows])])
+        per_seq = [out[edges[b]: edges[b + 1]].copy() for b in range(len(embeds))]
+        return (per_seq, logits) if want_logits else per_seq
+
     def generate(self, max_new_tokens: int = 256, eos_token_ids: Optional[Sequence[int]] = None) -> GenerateResult:
         eos = np.ascontiguousarray(eos_token_ids if eos_token_ids is not None else self.dims.eos_token_ids, dtype=np.int32)
         S, n = self._n_seqs, int(max_new_tokens)
@@ -450,3 +475,125 @@ class HipQwenTextGenerator:
 
     def generate(self, audio_path: Path, language: str = "ja", context: Optional[str] = None, **kwargs: Any) -> TranscriptionResult:
         return self.generate_batch([audio_path], language, [context], **kwargs)[0]
+
+
+# ---- forced aligner (TextAligner) ------------------------------------------------------------------------------------------
+@dataclass
+class WordTimestamp:            # mirror of subtitle_pipeline/types.py:19-25
+    word: str
+    start: float
+    end: float
+
+
+@dataclass
+class AlignmentResult:          # mirror of subtitle_pipeline/types.py:86-104
+    words: List[WordTimestamp]
+    metadata: Dict[str, Any]
+
+
+def fix_timestamps(raw: Sequence[float]) -> List[int]:
+    """Monotonic repair of the predicted time bins (upstream ``qwen3_forced_aligner.py`` ``fix_timestamp``): keep the longest
+    non-decreasing subsequence, snap outlier blocks of <= 2 to the nearer good neighbour, interpolate longer ones."""
+    data = [float(v) for v in raw]
+    n = len(data)
+    if n == 0:
+        return []
+    dp, parent = [1] * n, [-1] * n
+    for i in range(1, n):
+        for j in range(i):
+            if data[j] <= data[i] and dp[j] + 1 > dp[i]:
+                dp[i], parent[i] = dp[j] + 1, j
+    idx = dp.index(max(dp))
+    good = [False] * n
+    while idx != -1:
+        good[idx] = True
+        idx = parent[idx]
+    out = list(data)
+    i = 0
+    while i < n:
+        if good[i]:
+            i += 1
+            continue
+        j = i
+        while j < n and not good[j]:
+            j += 1
+        left = next((out[k] for k in range(i - 1, -1, -1) if good[k]), None)
+        right = next((out[k] for k in range(j, n) if good[k]), None)
+        for pos in range(i, j):
+            if j - i <= 2:
+                out[pos] = right if left is None else left if right is None else (left if (pos - (i - 1)) <= (j - pos) else right)
+            elif left is not None and right is not None:
+                out[pos] = left + (right - left) / (j - i + 1) * (pos - i + 1)
+            else:
+                out[pos] = left if left is not None else right
+        i = j
+    return [int(v) for v in out]
+
+
+class HipQwenForcedAligner:
+    """``TextAligner`` (protocols.py:128-179) on the device: the aligner checkpoint is the same architecture (audio tower +
+    Qwen3 decoder) with a linear head over time bins, read at the ``<timestamp>`` markers of a prompt that interleaves the
+    transcript's words with markers -- one pass, no generation.  ``word_prompt(n_audio, words, language)`` -> (token ids,
+    marker positions) and ``split_words(text, language)`` are tokenizer business and required plug-ins; the rest
+    (audio tower, decoder pass, head, arg-max, ``fix_timestamps``, bins -> seconds) runs here."""
+
+    def __init__(self, dims: Qwen3Dims, audio_dims: Qwen3AudioDims, weights: Dict[str, np.ndarray], *, head_key: str = "score",
+                 segment_ms: float = 80.0, word_prompt: Optional[Callable] = None, split_words: Optional[Callable] = None,
+                 dtype: str = "float16", device: int = 0, batch_size: int = 8, max_ctx: int = 2048):
+        self.dims, self.audio_dims, self._weights, self.dtype, self.device = dims, audio_dims, weights, dtype, device
+        self.head_key, self.segment_ms = head_key, float(segment_ms)
+        self.word_prompt, self.split_words = word_prompt, split_words
+        self.batch_size, self.max_ctx = int(batch_size), int(max_ctx)
+        self._model: Optional[HipQwen3Decoder] = None
+        self._tower: Optional[HipQwenAudioTower] = None
+
+    def load(self) -> None:
+        if self._model is None:
+            self._model = HipQwen3Decoder(self.dims, self._weights, dtype=self.dtype, device=self.device, max_seqs=self.batch_size,
+                                          max_ctx=self.max_ctx)
+            self._tower = HipQwenAudioTower(self.audio_dims, self._weights, dtype=self.dtype, device=self.device)
+            self._head_w = torch.from_numpy(np.ascontiguousarray(self._weights[self.head_key + ".weight"], dtype=np.float32))
+            b = self._weights.get(self.head_key + ".bias")
+            self._head_b = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)) if b is not None else None
+
+    def unload(self) -> None:
+        for obj in (self._model, self._tower):
+            if obj is not None:
+                obj.close()
+        self._model = self._tower = None
+
+    cleanup = unload
+
+    def align_batch(self, audio_paths: Sequence[Path], texts: Sequence[str], language: str = "ja", **kwargs: Any) -> List[AlignmentResult]:
+        from .asr import read_audio
+        if self.word_prompt is None or self.split_words is None:
+            raise hipbind.WjError("HipQwenForcedAligner: word_prompt / split_words not supplied -- the tokenizer is not part of this "
+                                  "slice (whisperjav_amd/qwen.py) and nothing falls back to the CPU")
+        self.load()
+        out: List[AlignmentResult] = []
+        for lo in range(0, len(audio_paths), self.batch_size):
+            clips, words = [], []
+            for path, text in zip(audio_paths[lo: lo + self.batch_size], texts[lo: lo + self.batch_size]):
+                audio, sr = read_audio(Path(path))
+                if sr != 16000:
+                    from .pipeline import to_16k
+                    audio = to_16k(audio, sr)
+                clips.append(audio)
+                words.append(list(self.split_words(text, language)))
+            audio_embeds = self._tower.encode(clips)
+            embeds, rows = [], []
+            for a, wl in zip(audio_embeds, words):
+                ids, marks = self.word_prompt(int(a.shape[0]), wl, language)
+                if len(marks) != 2 * len(wl):
+                    raise ValueError(f"{len(marks)} <timestamp> markers for {len(wl)} words (two per word expected)")
+                embeds.append(self._model.prompt_embeddings(ids, a))
+                rows.append(list(marks))
+            labels = self._model.classify(embeds, rows, self._head_w, self._head_b)
+            for wl, lab in zip(words, labels):
+                ms = fix_timestamps(lab.astype(np.float64) * self.segment_ms)
+                out.append(AlignmentResult(words=[WordTimestamp(w, round(ms[2 * i] / 1000.0, 3), round(ms[2 * i + 1] / 1000.0, 3))
+                                                  for i, w in enumerate(wl)], metadata={"raw_bins": lab.tolist()}))
+        return out
+
+    def align(self, audio_path: Path, text: str, language: str = "ja", **kwargs: Any) -> AlignmentResult:
+        return self.align_batch([audio_path], [text], language, **kwargs)[0]
