@@ -262,6 +262,9 @@ int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32
 int wj_qwen_generate_greedy(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, int max_new, int32_t* tokens_out, int32_t* n_tokens_out,
                             float* token_logprob_out, void* stream);
 
+/* 1 if the last wj_qwen_generate_greedy replayed its decode iteration from a hipGraph */
+int wj_qwen_last_used_graph(const wj_qwen* m);
+
 /* Token classification over a full (non-generative) pass: the forced aligner (Qwen3-ForcedAligner-0.6B, reference
  * whisperjav/modules/qwen_asr.py:1198-1320 -> TextAligner, protocols.py:128-179) is this decoder + audio tower with a
  * linear head over time bins, read at the <timestamp> marker positions of a prompt that interleaves the transcript's words

@@ -41,6 +41,7 @@ def test_prefill_logits_and_greedy_generation_match_oracle(hip, dtype):
     embeds = [model.prompt_embeddings(ids, audio) for ids, audio in prompts]
     logits = model.prefill(embeds, want_logits=True).cpu()
     res = model.generate(max_new_tokens=24)
+    assert model._lib.wj_qwen_last_used_graph(model.handle) == 1          # the decode iteration is replayed from a hipGraph
     tol = {"float32": 2e-4, "float16": 3e-2, "bfloat16": 0.25}[dtype]
     agree = 0
     with torch.no_grad():

@@ -207,3 +207,24 @@ def test_device_gate(ref_modules, monkeypatch):
     monkeypatch.setattr(device, "hip_path_available", lambda: (False, "AMD Instinct MI355X"))
     if not torch.cuda.is_available():
         assert dd.get_best_device() == "cpu"                             # device seen, library unusable: the reference's answer
+
+
+def test_qwen_adapters_satisfy_the_reference_protocols(ref_modules):
+    """``HipQwenTextGenerator`` / ``HipQwenForcedAligner`` are instances of the reference's runtime-checkable
+    ``TextGenerator`` / ``TextAligner`` protocols (modules/subtitle_pipeline/protocols.py:60-179), and their result objects
+    carry the fields of the reference's ``TranscriptionResult`` / ``AlignmentResult`` / ``WordTimestamp`` (types.py)."""
+    import dataclasses
+    from whisperjav_amd import qwen
+    sys.modules["whisperjav.modules.subtitle_pipeline"] = types.ModuleType("whisperjav.modules.subtitle_pipeline")
+    sys.modules["whisperjav.modules.subtitle_pipeline"].__path__ = [f"{REF}/whisperjav/modules/subtitle_pipeline"]
+    protocols = importlib.import_module("whisperjav.modules.subtitle_pipeline.protocols")
+    ref_types = importlib.import_module("whisperjav.modules.subtitle_pipeline.types")
+    d = qwen.Qwen3Dims(hidden=64, n_layer=1, n_head=1, n_kv_head=1, head_dim=128, ffn=64, vocab=32)
+    ad = qwen.Qwen3AudioDims(n_layer=1, n_head=1, ffn=64, d_model=64, conv_hidden=8, out_dim=64)
+    w = {**qwen.synth_weights(d), **qwen.synth_audio_weights(ad)}
+    gen = qwen.HipQwenTextGenerator(d, w, audio_dims=ad)
+    al = qwen.HipQwenForcedAligner(d, ad, w)
+    assert isinstance(gen, protocols.TextGenerator) and isinstance(al, protocols.TextAligner)
+    for mine, ref in ((qwen.TranscriptionResult, ref_types.TranscriptionResult), (qwen.AlignmentResult, ref_types.AlignmentResult),
+                      (qwen.WordTimestamp, ref_types.WordTimestamp)):
+        assert [f.name for f in dataclasses.fields(mine)] == [f.name for f in dataclasses.fields(ref)]

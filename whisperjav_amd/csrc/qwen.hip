@@ -189,6 +189,7 @@ struct wj_qwen {
   int32_t *top_id = nullptr, *tokens_out = nullptr, *eos = nullptr;
   float *top_lp = nullptr, *top_lse = nullptr, *lp_out = nullptr;
   int n_seqs = 0;            // sequences of the last prefill
+  int last_used_graph = 0;   // the last generation replayed its iteration from a hipGraph
   const void* W(int i) const { return blob + off[i]; }
   const float* F(int i) const { return reinterpret_cast<const float*>(blob + off[i]); }
   int layer_base(int l) const { return WJ_Q_N_GLOBAL + l * WJ_QL_N; }
@@ -393,6 +394,8 @@ int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32
   return WJ_OK;
 }
 
+int wj_qwen_last_used_graph(const wj_qwen* m) { return m ? m->last_used_graph : 0; }
+
 int wj_qwen_classify(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32_t* n_tokens_host, const int32_t* rows_host, int n_rows,
                      const void* head_w_dev, const float* head_b_dev, int n_labels, int32_t* argmax_out_host, float* logits_out_dev,
                      void* stream) {
@@ -472,24 +475,63 @@ int wj_qwen_generate_greedy(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, 
   WJ_HIP(hipMemsetAsync(m->n_out, 0, sizeof(int32_t) * S, s));
   WJ_HIP(hipMemcpyAsync(m->eos, eos_ids_host, sizeof(int32_t) * n_eos, hipMemcpyHostToDevice, s));
   std::vector<int32_t> fin(S);
-  // the prefill left the arg-max of every sequence's last prompt position in top_id / top_lp
-  for (int i = 0; i <= max_new; ++i) {
+  auto advance = [&](int first) -> int {
     hipLaunchKernelGGL(advance_kernel, dim3(ceil_div(S, 64)), dim3(64), 0, s, m->top_id, m->top_lp, m->eos, n_eos, m->finished, m->n_out,
-                       m->row_pos, m->next_tok, d_tok, d_lp, max_new, S, m->max_ctx, i == 0 ? 1 : 0);
+                       m->row_pos, m->next_tok, d_tok, d_lp, max_new, S, m->max_ctx, first);
     WJ_LAUNCH_CHECK();
-    if (i == max_new) break;
-    if ((i & 7) == 7) {
-      WJ_HIP(hipMemcpyAsync(fin.data(), m->finished, sizeof(int32_t) * S, hipMemcpyDeviceToHost, s));
-      WJ_HIP(hipStreamSynchronize(s));
-      if (std::all_of(fin.begin(), fin.end(), [](int32_t f) { return f != 0; })) break;
-    }
+    return WJ_OK;
+  };
+  // one decode iteration: embed the token chosen last -> layers -> head -> record the next token.  Every step-dependent
+  // value (positions, tokens, counters) lives in device memory, so the iteration is captured once and replayed from a
+  // hipGraph: ~260 launches of a few microseconds each would otherwise be issued by the host per token.
+  auto iteration = [&]() -> int {
     if (m->dtype == WJ_F32) hipLaunchKernelGGL((embed_rows_kernel<float>), dim3(S), dim3(256), 0, s, TP(const float, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
     else if (m->dtype == WJ_F16) hipLaunchKernelGGL((embed_rows_kernel<f16_t>), dim3(S), dim3(256), 0, s, TP(const f16_t, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
     else hipLaunchKernelGGL((embed_rows_kernel<bf16_t>), dim3(S), dim3(256), 0, s, TP(const bf16_t, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
     WJ_LAUNCH_CHECK();
     WJ_TRYQ(run_layers(m, S, s));
     WJ_TRYQ(run_head(m, m->x, S, s));
+    return advance(0);
+  };
+  // the prefill left the arg-max of every sequence's last prompt position in top_id / top_lp
+  WJ_TRYQ(advance(1));
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  const char* env = getenv("WJ_NO_GRAPH");
+  bool use_graph = !(env && env[0] == '1') && max_new > 2;
+  int rc_loop = WJ_OK;
+  m->last_used_graph = 0;
+  for (int k = 1; k <= max_new && rc_loop == WJ_OK; ++k) {
+    if (k == 2 && use_graph) {       // the first iteration ran eagerly (one-time kernel attributes are set); capture the second
+      if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const int rc = iteration();
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc || e != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+          (void)hipGetLastError();
+          if (exec) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
+          use_graph = false;
+        }
+      } else {
+        (void)hipGetLastError();
+        use_graph = false;
+      }
+      m->last_used_graph = use_graph ? 1 : 0;
+    }
+    if (exec) {
+      if (hipGraphLaunch(exec, s) != hipSuccess) { set_error("wj_qwen_generate_greedy: graph launch failed"); rc_loop = WJ_E_HIP; }
+    } else {
+      rc_loop = iteration();
+    }
+    if ((k & 7) == 0 && k < max_new && rc_loop == WJ_OK) {
+      if (hipMemcpyAsync(fin.data(), m->finished, sizeof(int32_t) * S, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        set_error("wj_qwen_generate_greedy: poll failed"); rc_loop = WJ_E_HIP; break;
+      }
+      if (std::all_of(fin.begin(), fin.end(), [](int32_t f) { return f != 0; })) break;
+    }
   }
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
+  if (rc_loop) return rc_loop;
   WJ_HIP(hipMemcpyAsync(tokens_out, d_tok, sizeof(int32_t) * (size_t)S * max_new, hipMemcpyDeviceToHost, s));
   WJ_HIP(hipMemcpyAsync(n_tokens_out, m->n_out, sizeof(int32_t) * S, hipMemcpyDeviceToHost, s));
   if (token_logprob_out) WJ_HIP(hipMemcpyAsync(token_logprob_out, d_lp, sizeof(float) * (size_t)S * (max_new + 1), hipMemcpyDeviceToHost, s));
