@@ -257,6 +257,8 @@ def build_stack(args, info, dims, dtype, batch, blob=None, offsets=None, weights
     model = cls(args.model, compute_type=dtype, weights=weights, dims=dims, blob=blob, offsets=offsets,
                 max_batch=batch, max_beam=beam, device_index=info.local_rank,
                 kv_len=(4 + args.max_new_tokens + 4) if args.kv_fit else None, enc_batch=min(batch, args.enc_batch))
+    model.overlap_encode = bool(args.overlap) or int(args.encoder_cus) > 0
+    model.encoder_cus = int(args.encoder_cus)
     # the balanced preset's Silero parameters (config/components/vad/silero.py:105-114)
     vad = dict(threshold=args.vad_threshold, min_speech_duration_ms=100, min_silence_duration_ms=300, speech_pad_ms=400,
                chunk_threshold_s=2.5, max_group_duration_s=6.0)
@@ -744,6 +746,10 @@ def main():
     ap.add_argument("--strong", action="store_true", help="cfg3 with --gpus N: ONE recording, scenes LPT-sharded over the ranks (cfg4)")
     ap.add_argument("--batch", type=int, default=768, help="30 s windows resident per GPU per engine call (768: cross K/V = 189 GB, "
                     "self-attention KV cache sized for max_new_tokens = 46 GB, encoder slices of --enc-batch windows; 238 GiB in all)")
+    ap.add_argument("--encoder-cus", type=int, default=0, help="> 0: the encoder of the next chunk runs on this many compute units beside "
+                    "the decode loop of the current chunk on the others (CU-masked streams); 0 = plain second stream")
+    ap.add_argument("--overlap", action="store_true", help="A/B: encode the next half batch on a second stream while the current one decodes "
+                    "(measured: no gain, see whisper_model.HipWhisperModel.overlap_encode)")
     ap.add_argument("--enc-batch", type=int, default=384, help="windows per encoder slice (bounds the encoder workspaces)")
     ap.add_argument("--no-kv-fit", dest="kv_fit", action="store_false",
                     help="size the self-attention KV cache for n_text_ctx positions instead of prompt + max_new_tokens")

@@ -54,6 +54,14 @@ const char* wj_last_error(void);
 int wj_init(int device_ordinal, wj_ctx** out);
 int wj_shutdown(wj_ctx* ctx);
 int wj_sync(wj_ctx* ctx);
+/* Extra streams for the entry points that take a `stream` argument.  cu_count > 0 restricts the stream to the compute units
+ * cu_first .. cu_first + cu_count - 1 (hipExtStreamCreateWithCUMask): two such streams over disjoint CU sets let the encoder
+ * of the next chunk of windows (matrix-core bound) and the decode loop of the current one (HBM / latency bound) run SIDE BY
+ * SIDE instead of time-slicing the chip (the 256-tile GEMM workgroups take a CU's whole register file and LDS, so unmasked
+ * streams only alternate).  cu_count <= 0: a plain non-blocking stream. */
+int wj_stream_create(wj_ctx* ctx, int cu_first, int cu_count, void** out);
+int wj_stream_sync(wj_ctx* ctx, void* stream);
+int wj_stream_destroy(wj_ctx* ctx, void* stream);
 /* device properties for roofline reporting: out[0]=CU count, out[1]=clock kHz, out[2]=HBM bytes (lo32), out[3]=(hi32) */
 int wj_device_info(wj_ctx* ctx, int64_t out[4]);
 
@@ -158,6 +166,12 @@ int64_t wj_whisper_workspace_bytes(const wj_whisper* m);
  * layer-bisection parity tests).  enc_out_dev (optional, may be NULL): float32 [batch][1500][d]. */
 int wj_whisper_encode(wj_whisper* m, const float* mel_dev, int batch, int n_layers,
                       float* enc_out_dev, void* stream);
+/* The same, leaving the windows' cross K/V in the resident slots slot0 .. slot0 + batch - 1, asynchronously on `stream`
+ * (NULL = the context's stream): the encoder's workspaces are its own, so a caller may encode the NEXT batch of windows on a
+ * second stream while a decode call runs on the slots of the current one -- the encoder is matrix-core bound, the decode step
+ * HBM / latency bound, and the two overlap (whisper_model.transcribe_many does this).  Not to be overlapped with
+ * wj_whisper_align, which borrows the encoder workspaces. */
+int wj_whisper_encode_at(wj_whisper* m, const float* mel_dev, int batch, int slot0, void* stream);
 
 typedef struct {
   int32_t max_new_tokens;         /* <= n_text_ctx/2 */

@@ -1100,3 +1100,46 @@ def test_cabi_weight_broadcast_single_rank(hip):
     assert any(b != 0 for b in uid.raw)
     comm = C.c_void_p()
     assert hip.wj_comm_init(hipbind.context(0).handle, 2, 5, uid.raw, C.byref(comm)) != 0          # rank outside the communicator
+
+
+@pytest.mark.parametrize("flavour", ["fw", "ow"])
+def test_encoder_of_the_next_chunk_overlaps_the_decode_of_this_one(hip, flavour):
+    """``transcribe_many`` encodes chunk i + 1 on a second stream into the other half of the resident window slots while
+    chunk i decodes (``wj_whisper_encode_at``): the segments must be the ones the sequential schedule produces, for the
+    CTranslate2-flavoured model (beam 5) and the openai-flavoured one (beam 2), on searches that end."""
+    from whisperjav_amd import synth, weights as pweights, whisper_model as wm
+    d = helpers.small_dims()
+    w = pweights.synth_weights(d, seed=33, **pweights.SPEECHLIKE)
+    cls = wm.HipWhisperModel if flavour == "fw" else wm.HipOpenAIWhisperModel
+    model = cls("tiny", compute_type="float32", weights=w, dims=d, max_batch=4, max_beam=5, kv_len=3 + 48 + 5)
+    clips = [synth.speech_like(0.7 + 0.55 * i, seed=200 + i) for i in range(11)]
+    if flavour == "fw":
+        kw = dict(task="transcribe", language="ja", beam_size=5, patience=1.2, repetition_penalty=1.5, no_repeat_ngram_size=3,
+                  temperature=0.0, condition_on_previous_text=False, max_new_tokens=48, no_speech_threshold=None,
+                  max_initial_timestamp=0.0, word_timestamps=False, log_prob_threshold=None, compression_ratio_threshold=None)
+    else:
+        kw = dict(task="transcribe", language="ja", beam_size=2, patience=1.2, temperature=0.0, condition_on_previous_text=False,
+                  sample_len=48, no_speech_threshold=None, logprob_threshold=None, compression_ratio_threshold=None, fp16=False)
+    key = lambda per_clip: [[(s.seek, tuple(s.tokens), round(s.avg_logprob, 4)) for s in segs] for segs in per_clip]     # noqa: E731
+    model.overlap_encode = False
+    if flavour == "fw":
+        seq, _ = model.transcribe_many(clips, **kw)
+    else:
+        seq = [model.transcribe(c, **kw)["segments"] for c in clips]
+    model.overlap_encode = True          # an opt-in schedule (measured: no gain on MI355X), kept correct
+    if flavour == "fw":
+        ovl, _ = model.transcribe_many(clips, **kw)
+        assert key(ovl) == key(seq)
+        assert any(len(s) for s in seq) and len({sum(len(x.tokens) for x in s) for s in seq}) > 2      # ragged, non-trivial
+    else:
+        many, _ = model.transcribe_many(clips, **{k: v for k, v in kw.items() if k != "fp16"})
+        got = [[(s.seek, tuple(s.tokens)) for s in segs] for segs in many]
+        ref = [[(s["seek"], tuple(s["tokens"])) for s in segs] for segs in seq]
+        assert got == ref
+    assert model._overlapped                                             # the overlapped path ran
+    # ... and with the pair on disjoint compute units (CU-masked streams)
+    model.encoder_cus = 160
+    if flavour == "fw":
+        cus, _ = model.transcribe_many(clips, **kw)
+        assert key(cus) == key(seq) and model.model._split is not None
+    model.close()

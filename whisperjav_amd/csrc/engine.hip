@@ -684,6 +684,37 @@ int wj_sync(wj_ctx* ctx) {
   return WJ_OK;
 }
 
+int wj_stream_create(wj_ctx* ctx, int cu_first, int cu_count, void** out) {
+  WJ_REQUIRE(ctx && out, "wj_stream_create: NULL argument");
+  WJ_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = nullptr;
+  if (cu_count <= 0) {
+    WJ_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  } else {
+    WJ_REQUIRE(cu_first >= 0 && cu_first + cu_count <= ctx->cu_count, "wj_stream_create: CUs %d..%d outside the device's %d", cu_first,
+               cu_first + cu_count - 1, ctx->cu_count);
+    const int words = (ctx->cu_count + 31) / 32;
+    std::vector<uint32_t> mask(words, 0u);
+    for (int c = cu_first; c < cu_first + cu_count; ++c) mask[c >> 5] |= 1u << (c & 31);
+    WJ_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask.data()));
+  }
+  *out = s;
+  return WJ_OK;
+}
+
+int wj_stream_sync(wj_ctx* ctx, void* stream) {
+  WJ_REQUIRE(ctx && stream, "wj_stream_sync: NULL argument");
+  WJ_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  return WJ_OK;
+}
+
+int wj_stream_destroy(wj_ctx* ctx, void* stream) {
+  if (!ctx || !stream) return WJ_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));
+  return WJ_OK;
+}
+
 int wj_device_info(wj_ctx* ctx, int64_t out[4]) {
   WJ_REQUIRE(ctx && out, "wj_device_info: NULL argument");
   hipDeviceProp_t prop;
@@ -897,6 +928,20 @@ int wj_whisper_encode(wj_whisper* m, const float* mel_dev, int batch, int n_laye
   for (int w0 = 0; w0 < batch; w0 += m->enc_batch) {      // slices of the encoder workspaces; cross K/V of all windows stays resident
     const int bc = std::min(m->enc_batch, batch - w0);
     WJ_TRY(run_encoder(m, mel_dev + w0 * mel_win, bc, n_layers, enc_out_dev ? enc_out_dev + w0 * out_win : nullptr, s, w0));
+  }
+  return WJ_OK;
+}
+
+int wj_whisper_encode_at(wj_whisper* m, const float* mel_dev, int batch, int slot0, void* stream) {
+  WJ_REQUIRE(m && mel_dev, "wj_whisper_encode_at: NULL argument");
+  WJ_REQUIRE(batch >= 1 && slot0 >= 0 && slot0 + batch <= m->max_batch, "wj_whisper_encode_at: windows %d..%d outside the %d resident slots",
+             slot0, slot0 + batch - 1, m->max_batch);
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  hipStream_t s = m->ctx->pick(stream);
+  const int64_t mel_win = (int64_t)m->d.n_mels * m->frames;
+  for (int w0 = 0; w0 < batch; w0 += m->enc_batch) {
+    const int bc = std::min(m->enc_batch, batch - w0);
+    WJ_TRY(run_encoder(m, mel_dev + w0 * mel_win, bc, -1, nullptr, s, slot0 + w0));
   }
   return WJ_OK;
 }

@@ -153,12 +153,18 @@ class HipWhisper:
         hipbind.tune("self_kv_len", 0)
         hipbind.tune("enc_batch", 0)
         self.handle = handle
+        self.decode_stream = None        # raw stream handle the decode calls run on (None = the context's stream)
+        self._split = None               # (encoder stream, decode stream) over disjoint CU sets, see cu_split()
         self._suppress_mask: Optional[torch.Tensor] = None
         self._suppress_key = None
 
     # ---- lifetime -------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "handle", None):
+            if getattr(self, "_split", None):
+                for h in self._split:
+                    self._lib.wj_stream_destroy(self.ctx.handle, h)
+                self._split = None
             self._lib.wj_whisper_free(self.handle)
             self.handle = None
 
@@ -189,6 +195,41 @@ class HipWhisper:
                                           _ptr(out) if out is not None else None, None), "wj_whisper_encode")
         self.ctx.sync()
         return out
+
+    def cu_split(self, encoder_cus: int):
+        """Two streams over disjoint compute units: the first ``encoder_cus`` CUs for ``encode_at``, the rest for the decode
+        calls (``wj_stream_create``).  Returns ``(encoder stream, decode stream)`` as raw handles; ``encoder_cus <= 0``
+        drops the split.  Plain streams only alternate on the chip: a 256-tile GEMM workgroup takes a CU's whole register
+        file and LDS, so a decode kernel cannot co-reside with the encoder unless the encoder is kept off some CUs."""
+        if self._split is not None:
+            for h in self._split:
+                self._lib.wj_stream_destroy(self.ctx.handle, h)
+            self._split = None
+        if encoder_cus and encoder_cus > 0:
+            n = int(self.ctx.device_info()["cu_count"]) if hasattr(self.ctx, "device_info") else 256
+            if not 0 < encoder_cus < n:
+                raise ValueError(f"encoder_cus must be in 1..{n - 1}")
+            enc, dec = C.c_void_p(), C.c_void_p()
+            check(self._lib.wj_stream_create(self.ctx.handle, 0, int(encoder_cus), C.byref(enc)), "wj_stream_create")
+            check(self._lib.wj_stream_create(self.ctx.handle, int(encoder_cus), n - int(encoder_cus), C.byref(dec)), "wj_stream_create")
+            self._split = (enc, dec)
+        return self._split
+
+    def stream_sync(self, handle) -> None:
+        check(self._lib.wj_stream_sync(self.ctx.handle, handle), "wj_stream_sync")
+
+    def encode_at(self, mel: torch.Tensor, slot0: int, stream=None) -> None:
+        """Encode ``mel`` [B, n_mels, 3000] into the resident window slots ``slot0 .. slot0 + B - 1`` WITHOUT waiting:
+        the launches go to ``stream`` (a torch stream, or a raw handle from ``cu_split``) or the context's stream.  The
+        caller synchronises that stream before decoding those slots and keeps ``mel`` alive until then."""
+        d = self.dims
+        if mel.dtype != torch.float32 or not mel.is_cuda or not mel.is_contiguous():
+            raise ValueError("mel must be a contiguous float32 CUDA tensor")
+        if mel.dim() != 3 or mel.shape[1] != d.n_mels or mel.shape[2] != 2 * d.n_audio_ctx:
+            raise ValueError(f"mel must be [B, {d.n_mels}, {2 * d.n_audio_ctx}], got {tuple(mel.shape)}")
+        _torch_sync()           # mel was produced on torch's stream
+        raw = None if stream is None else (C.c_void_p(stream.cuda_stream) if hasattr(stream, "cuda_stream") else stream)
+        check(self._lib.wj_whisper_encode_at(self.handle, _ptr(mel), int(mel.shape[0]), int(slot0), raw), "wj_whisper_encode_at")
 
     # ---- decoding -------------------------------------------------------------------------
     def _mask_for(self, suppress: Sequence[int]) -> Optional[torch.Tensor]:
@@ -233,7 +274,7 @@ class HipWhisper:
         as_i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
         as_f = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
         check(self._lib.wj_whisper_decode_greedy(self.handle, B, as_i(prompts), P, C.byref(oc), as_i(toks), as_i(ntok),
-                                                 as_f(slp), as_f(nsp), as_f(tlp), None), "wj_whisper_decode_greedy")
+                                                 as_f(slp), as_f(nsp), as_f(tlp), self.decode_stream), "wj_whisper_decode_greedy")
         return GreedyResult(toks, ntok, slp, nsp, tlp)
 
     def decode_sample(self, prompts: np.ndarray, options: Optional[DecodeOptions] = None, *, temperature: float = 0.0,
@@ -260,7 +301,7 @@ class HipWhisper:
             sl = as_i(sl_arr)
         check(self._lib.wj_whisper_decode_sample(self.handle, B, int(best_of), sl, as_i(prompts), P, C.byref(oc),
                                                  float(temperature), int(seed) & 0xFFFFFFFF, as_i(toks), as_i(ntok), as_f(slp),
-                                                 as_f(nsp), as_f(tlp), None), "wj_whisper_decode_sample")
+                                                 as_f(nsp), as_f(tlp), self.decode_stream), "wj_whisper_decode_sample")
         return GreedyResult(toks, ntok, slp, nsp, tlp)
 
     def decode_beam(self, prompts: np.ndarray, options: Optional[DecodeOptions] = None, *, beam_size: int = 5,
@@ -297,7 +338,7 @@ class HipWhisper:
             sl = as_i(sl_arr)
         fn = self._lib.wj_whisper_decode_beam if flavor == "ct2" else self._lib.wj_whisper_decode_beam_openai
         check(fn(self.handle, B, int(beam_size), sl, as_i(prompts), P, C.byref(oc), float(patience), float(length_penalty),
-                 as_i(toks), as_i(ntok), as_f(score), as_f(slp), as_f(nsp), None), "wj_whisper_decode_beam")
+                 as_i(toks), as_i(ntok), as_f(score), as_f(slp), as_f(nsp), self.decode_stream), "wj_whisper_decode_beam")
         return GreedyResult(toks, ntok, slp, nsp, score.reshape(B, 1))
 
     def align(self, token_rows: Sequence[Sequence[int]], n_prefix: int, heads: Sequence[Tuple[int, int]],

@@ -48,6 +48,9 @@ _SIGNATURES = {
     "wj_init": (_I, [_I, C.POINTER(_P)]),
     "wj_shutdown": (_I, [_P]),
     "wj_sync": (_I, [_P]),
+    "wj_stream_create": (_I, [_P, _I, _I, C.POINTER(_P)]),
+    "wj_stream_sync": (_I, [_P, _P]),
+    "wj_stream_destroy": (_I, [_P, _P]),
     "wj_device_info": (_I, [_P, C.POINTER(_I64)]),
     "wj_tune": (_I, [C.c_char_p, _I]),
     "wj_profile_start": (_I, [_P]),
@@ -62,6 +65,7 @@ _SIGNATURES = {
     "wj_whisper_free": (_I, [_P]),
     "wj_whisper_workspace_bytes": (_I64, [_P]),
     "wj_whisper_encode": (_I, [_P, _P, _I, _I, _P, _P]),
+    "wj_whisper_encode_at": (_I, [_P, _P, _I, _I, _P]),
     "wj_whisper_decode_greedy": (_I, [_P, _I, C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _P]),
     "wj_whisper_decode_sample": (_I, [_P, _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(DecodeOptsC), _F,

@@ -270,6 +270,15 @@ class HipWhisperModel:
     # word-timestamp figure (and says so); everything else keeps upstream's behaviour
     word_reseek = True
     bucket_by_length = True      # transcribe_many: batches are formed from windows of similar content length
+    # Measured and NOT the default (profiles/r03_bench_overlap_*.json): encoding the next chunk on a second stream while the
+    # current one decodes -- 8.66 s vs 8.70 s for the sequential 768-window schedule (the 256-tile GEMM workgroups take a
+    # CU's whole register file and LDS: the two streams alternate instead of sharing the chip); on disjoint compute units
+    # (encoder_cus > 0, CU-masked streams) it is slower -- 9.9 / 13.0 / 22.5 s with 144 / 176 / 208 CUs for the encoder: both
+    # sides scale linearly with their CU count (the cross-attention's 6 TB/s needs all 256 CUs issuing), so no split wins.
+    overlap_encode = False       # the next chunk is encoded on a second stream while the current one decodes
+    encoder_cus = 0              # > 0: ... on that many compute units, the decode loop on the others (wj_stream_create)
+    _side_stream = None
+    _overlapped = False
     decode_stats = None          # counters of the decode calls, see reset_decode_stats()
 
     def __init__(self, model_size_or_path: str = "large-v3", device: str = "cuda", device_index: int = 0,
@@ -846,19 +855,24 @@ class HipWhisperModel:
             active = [st for st in states if st.active]
             if not active:
                 break
-            if self.bucket_by_length and len(active) > self.max_batch:
+            half = self.max_batch // 2
+            overlap = bool(self.overlap_encode and half >= 1 and len(active) > half and not o.word_timestamps)
+            step = half if overlap else self.max_batch
+            if self.bucket_by_length and len(active) > step:
                 # length bucketing: windows holding similar amounts of audio decode together.  A search ends when its
                 # window's text does, the number of tokens grows with the audio in the window, and a batch runs until its
                 # slowest window is done -- so batches of similar windows end together instead of idling behind a few long
                 # ones (results are stored per clip: the order of the work does not show in the output)
                 active.sort(key=lambda st: -min(N_FRAMES, st.n_frames_content - st.seek))
-            # full batches + a tail.  Even batches were measured and are slower (120-min recording, 1544 windows: 5 x 309
-            # = 13.47 s against 4 x 384 + 8 = 13.03 s): 384 windows x 5 beams = 1920 rows fill the 128-row GEMM tiles
-            # exactly, and the per-step fixed costs are paid on fewer full-size steps
-            for lo in range(0, len(active), self.max_batch):
-                batch = active[lo: lo + self.max_batch]
-                # windows with equal prompt lengths decode together (the common case: no previous text)
-                groups: Dict[int, List[Tuple[_ClipState, List[int], int]]] = {}
+            # Windows go through the engine in chunks.  Without overlap: full batches + a tail (even batches were measured
+            # and are slower: 384 windows x 5 beams = 1920 rows fill the 128-row GEMM tiles exactly).  With overlap (the
+            # default when there is more than half a batch of work and no word alignment is asked for): chunks of HALF the
+            # resident slots, and while chunk i decodes out of one half, chunk i + 1 is ENCODED into the other half on a
+            # second stream -- the encoder is matrix-core bound, the decode step HBM / latency bound, they share the chip
+            # instead of taking turns (wj_whisper_encode_at).
+            chunks = [active[lo: lo + step] for lo in range(0, len(active), step)]
+
+            def make_mel(batch):
                 mel = torch.empty((len(batch), self.dims.n_mels, N_FRAMES), dtype=torch.float32, device=feats.device)
                 sizes = []
                 for j, st in enumerate(batch):
@@ -867,18 +881,56 @@ class HipWhisperModel:
                     mel[j] = feats[st.index, :, st.seek: st.seek + N_FRAMES]
                     if size < N_FRAMES:
                         mel[j, :, size:] = 0.0
-                self.model.encode(mel)
+                return mel, sizes
+
+            side = None
+            pending = None
+            split = None
+            if overlap:
+                # encoder_cus > 0: the overlapped pair runs on disjoint compute units (engine.HipWhisper.cu_split); the first
+                # chunk's encoder and the last chunk's decode have nothing beside them and take the whole chip
+                split = self.model.cu_split(self.encoder_cus) if self.encoder_cus else None
+                if split is None and self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=feats.device)
+                side = split[0] if split is not None else self._side_stream
+                self._overlapped = True
+                pending = make_mel(chunks[0])
+                self.model.encode_at(pending[0], 0, None)
+                self.model.ctx.sync()
+            for ci, batch in enumerate(chunks):
+                base = (ci % 2) * half if overlap else 0
+                if overlap:
+                    mel, sizes = pending
+                    paired = ci + 1 < len(chunks)
+                    if paired:                           # the next chunk's encoder runs beside this chunk's decode
+                        pending = make_mel(chunks[ci + 1])
+                        self.model.encode_at(pending[0], ((ci + 1) % 2) * half, side)
+                    self.model.decode_stream = split[1] if (split is not None and paired) else None
+                else:
+                    mel, sizes = make_mel(batch)
+                    self.model.encode(mel)
+                # windows with equal prompt lengths decode together (the common case: no previous text)
+                groups: Dict[int, List[Tuple[_ClipState, List[int], int]]] = {}
                 prompts = [self._prompt(o, st.all_tokens[st.prompt_reset_since:], st.seek == 0, st.language) for st in batch]
                 for j, p in enumerate(prompts):
                     groups.setdefault(len(p), []).append((batch[j], p, j))
                 if len(groups) == 1:
-                    decoded = self._decode_windows(prompts, o, suppress)
-                    self._finish_windows(o, batch, sizes, decoded, list(range(len(batch))), tb)
+                    slots = [base + j for j in range(len(batch))]
+                    decoded = self._decode_windows(prompts, o, suppress, slots=None if base == 0 else slots)
+                    self._finish_windows(o, batch, sizes, decoded, slots, tb)
                 else:   # heterogeneous prompt lengths: one decode per length, addressing the resident windows by slot
                     for _, members in groups.items():
                         idx = [j for _, _, j in members]
-                        res = self._decode_windows([p for _, p, _ in members], o, suppress, slots=idx)
-                        self._finish_windows(o, [batch[j] for j in idx], [sizes[j] for j in idx], res, idx, tb)
+                        res = self._decode_windows([p for _, p, _ in members], o, suppress, slots=[base + j for j in idx])
+                        self._finish_windows(o, [batch[j] for j in idx], [sizes[j] for j in idx], res, [base + j for j in idx], tb)
+                del mel
+                if overlap:
+                    self.model.decode_stream = None
+                    if paired:                           # chunk ci + 1 is encoded before its decode starts
+                        if split is not None:
+                            self.model.stream_sync(side)
+                        else:
+                            side.synchronize()
         infos = [TranscriptionInfo(language=st.language, language_probability=st.language_probability, duration=st.duration,
                                    duration_after_vad=st.duration, all_language_probs=st.all_language_probs,
                                    transcription_options=dict(kwargs))
