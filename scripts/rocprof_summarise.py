@@ -50,6 +50,16 @@ def mfma(d, out, command):
     each with 32 CUs x 4 SIMDs; busy cycles are per SIMD (MI355X_MICROARCH.md, profiling section)."""
     acc = {}
     per_kernel = {}
+    # kernel durations of the same run (it carries --kernel-trace): dispatch id -> ns, for the clock the part sustained
+    dur = {}
+    for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                try:
+                    dur[r.get("Dispatch_Id")] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                except (KeyError, ValueError):
+                    pass
+    seen = set()
     for path in find(d, "*counter_collection.csv"):
         with open(path) as f:
             for r in csv.DictReader(f):
@@ -59,9 +69,13 @@ def mfma(d, out, command):
                 label = next((lab for sub, lab in KERNEL_CLASSES if sub in name), None)
                 if label is None:
                     continue
-                e = acc.setdefault(label, {"SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "GRBM_GUI_ACTIVE": 0.0, "SQ_BUSY_CYCLES": 0.0, "rows": 0})
+                e = acc.setdefault(label, {"SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "GRBM_GUI_ACTIVE": 0.0, "SQ_BUSY_CYCLES": 0.0, "rows": 0, "ns": 0.0})
                 e[cn] += float(r["Counter_Value"])
                 e["rows"] += cn == "GRBM_GUI_ACTIVE"
+                did = r.get("Dispatch_Id")
+                if cn == "GRBM_GUI_ACTIVE" and did in dur and (label, did) not in seen:
+                    seen.add((label, did))
+                    e["ns"] += dur[did]
                 short = name.split("(")[0][-120:]
                 k = per_kernel.setdefault(short, {"SQ_VALU_MFMA_BUSY_CYCLES": 0.0, "GRBM_GUI_ACTIVE": 0.0, "dispatches": 0})
                 if cn in k:
@@ -76,13 +90,26 @@ def mfma(d, out, command):
         util = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] * 128.0) if e["GRBM_GUI_ACTIVE"] else 0.0
         rep["classes"][label] = {"dispatches": e["rows"], "mfma_busy_cycles": e["SQ_VALU_MFMA_BUSY_CYCLES"],
                                  "gui_active_cycles": e["GRBM_GUI_ACTIVE"], "mfma_util": round(util, 4)}
+        if e["ns"] > 0:      # GUI_ACTIVE is summed over the 8 XCDs: cycles per XCD / wall time = the clock under this kernel
+            ghz = e["GRBM_GUI_ACTIVE"] / 8.0 / e["ns"]
+            rep["classes"][label].update({"kernel_time_ms": round(e["ns"] * 1e-6, 3), "effective_clock_ghz": round(ghz, 3),
+                                          "mfma_util_x_clock_over_2p4ghz": round(util * ghz / 2.4, 4)})
         if label.startswith("encoder"):
             enc_busy += e["SQ_VALU_MFMA_BUSY_CYCLES"]; enc_gui += e["GRBM_GUI_ACTIVE"]
+            enc_ns = rep.setdefault("_enc_ns", 0.0) + e["ns"]
+            rep["_enc_ns"] = enc_ns
     for name, k in sorted(per_kernel.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])[:24]:
         util = k["SQ_VALU_MFMA_BUSY_CYCLES"] / (k["GRBM_GUI_ACTIVE"] * 128.0) if k["GRBM_GUI_ACTIVE"] else 0.0
         rep["kernels"][name] = {"dispatches": k["dispatches"], "gui_active_cycles": k["GRBM_GUI_ACTIVE"], "mfma_util": round(util, 4)}
+    enc_ns = rep.pop("_enc_ns", 0.0)
     if enc_gui:
         rep["encoder_time_weighted_mfma_util"] = round(enc_busy / (enc_gui * 128.0), 4)
+        if enc_ns > 0:
+            ghz = enc_gui / 8.0 / enc_ns
+            rep["encoder_effective_clock_ghz"] = round(ghz, 3)
+            rep["encoder_mfma_util_at_nominal_2p4ghz"] = round(enc_busy / (enc_gui * 128.0) * ghz / 2.4, 4)
+            rep["note"] = ("mfma_util counts matrix-pipe busy cycles per ACTIVE cycle; FLOP / wall time against the 2.5 PFLOP/s peak (quoted at "
+                           "2.4 GHz) is lower by effective_clock / 2.4 GHz -- the clock the part sustains under this load")
     with open(out, "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps({"encoder_time_weighted_mfma_util": rep.get("encoder_time_weighted_mfma_util"),
