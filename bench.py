@@ -687,7 +687,7 @@ def run_cfg5(args, info):
     t0 = time.perf_counter()
     w = {**qwen.synth_weights(d, seed=1), **qwen.synth_audio_weights(ad, seed=2)}
     B, n_new = args.qwen_batch, args.qwen_tokens
-    tower = qwen.HipQwenAudioTower(ad, w, dtype=args.dtype, device=info.local_rank, max_seconds=8 * B)
+    tower = qwen.HipQwenAudioTower(ad, w, dtype=args.dtype, device=info.local_rank, max_seconds=min(8 * B, 1024))
     model = qwen.HipQwen3Decoder(d, w, dtype=args.dtype, device=info.local_rank, max_seqs=B, max_ctx=192, max_rows=B * 128)
     del w
     log(f"[bench] cfg5: weights + engines ready after {time.perf_counter() - t0:.1f}s")
@@ -696,10 +696,12 @@ def run_cfg5(args, info):
     clips = [synth.speech_like(float(sv), seed=500 + i) for i, sv in enumerate(secs)]
     audio_s = float(sum(len(c) for c in clips)) / 16000.0
 
+    def prompt_ids(a):      # <|im_start|>user\n <audio> x n <|im_end|>\n<|im_start|>assistant\n, as the reference's chat template lays it out
+        return [151644, 872] + [d.audio_token_id] * int(a.shape[0]) + [151645, 198, 151644, 77091]
+
     def step():
         emb = tower.encode(clips)
-        prompts = [model.prompt_embeddings([151644, 872] + [d.audio_token_id] * int(a.shape[0]) + [151645, 198, 151644, 77091], a) for a in emb]
-        model.prefill(prompts)
+        model.prefill_packed(*model.prompt_embeddings_many([prompt_ids(a) for a in emb], emb))
         return model.generate(max_new_tokens=n_new, eos_token_ids=(d.vocab - 1,))
     for _ in range(args.warmup):
         step()
@@ -712,6 +714,21 @@ def run_cfg5(args, info):
     sharding.barrier()
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
     rtfx = audio_s * args.steps * info.world / elapsed
+    stages = {}
+    if info.rank == 0 and not args.no_profile:      # one more, untimed pass with a device sync after every stage
+        def timed(name, fn):
+            torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+            stages[name] = round(1e3 * (time.perf_counter() - t), 2)
+            return r
+        mel, frames = timed("log_mel_ms", lambda: tower.features(clips[:min(len(clips), 128)]))
+        stages["log_mel_ms"] = round(stages["log_mel_ms"] * len(clips) / min(len(clips), 128), 2)      # measured on 128 clips, scaled
+        emb = timed("audio_tower_ms", lambda: tower.encode(clips))
+        packed, n_tok = timed("prompt_assembly_ms", lambda: model.prompt_embeddings_many([prompt_ids(a) for a in emb], emb))
+        timed("prefill_ms", lambda: model.prefill_packed(packed, n_tok))
+        timed("generate_ms", lambda: model.generate(max_new_tokens=n_new, eos_token_ids=(d.vocab - 1,)))
+        stages["audio_tower_ms"] = round(stages["audio_tower_ms"] - stages["log_mel_ms"], 2)      # encode() recomputes the features
+        stages["prompt_rows"] = int(n_tok.sum())
+        del mel, frames
     if info.rank == 0:
         esz = 4 if args.dtype == "float32" else 2
         dec_params = d.n_layer * (d.hidden * (d.n_head + 2 * d.n_kv_head) * d.head_dim + d.n_head * d.head_dim * d.hidden + 3 * d.hidden * d.ffn) + d.vocab * d.hidden
@@ -724,8 +741,13 @@ def run_cfg5(args, info):
                                     f"no forced aligner, no fp8, unoptimised glue kernels: a first measured number, not a tuned one"),
                        "clips_per_step": B, "audio_seconds_per_step": round(audio_s, 1), "decode_tokens": n_new,
                        "tokens_generated": int(sum(len(t) for t in res.tokens)),
-                       "decoder_weight_bytes_per_step": dec_params * esz},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+                       "decoder_weight_bytes_per_step": dec_params * esz, "stages": stages},
+            "roofline": ({"bound": "hbm", "kernel": "greedy decode iteration (every decoder weight read once per generated position)",
+                          "achieved": round(dec_params * esz * n_new / (stages["generate_ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": round(dec_params * esz * n_new / (stages["generate_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "traffic": None, "timing": "host wall clock around wj_qwen_generate_greedy, device synchronised either side"}
+                         if stages.get("generate_ms") else None),
+            "cpu_baseline": None}), flush=True)
     tower.close(); model.close()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

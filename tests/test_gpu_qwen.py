@@ -249,3 +249,66 @@ def test_published_geometry_one_clip(hip):
     assert err_a < 5e-2 and err_l < 0.15 * max(1.0, float(ref_l.std())) and same >= 3
     assert abs(res.token_logprob[0][0] - lps[0]) < 0.1
     tower.close(); model.close()
+
+
+def test_packed_prompt_assembly_equals_the_per_prompt_path(hip):
+    """``prompt_embeddings_many`` (one embedding launch + one scatter for the batch) and ``prefill_packed`` give what the
+    per-prompt calls give, bit for bit, and refuse a placeholder / audio-row mismatch per prompt."""
+    d, w, oracle, model = _setup("float32", seed=9)
+    rng = np.random.default_rng(6)
+    prompts = _prompts(d, rng)
+    one_by_one = [model.prompt_embeddings(ids, audio) for ids, audio in prompts]
+    packed, n = model.prompt_embeddings_many([p[0] for p in prompts], [p[1] for p in prompts])
+    assert n.tolist() == [len(p[0]) for p in prompts]
+    assert torch.equal(packed, torch.cat(one_by_one, 0))
+    a = model.prefill(one_by_one, want_logits=True).clone()
+    b = model.prefill_packed(packed, n, want_logits=True)
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError, match="prompt 1"):
+        model.prompt_embeddings_many([[11, 12], [d.audio_token_id] * 3], [None, torch.zeros((2, d.hidden))])
+    model.close()
+
+
+def test_lm_head_with_1024_rows_runs_on_the_padded_vocabulary(hip):
+    """From 1024 sequences on, the tied LM head goes through the 256-wide MFMA tile kernel over the vocabulary padded to a
+    multiple of 256 with zero rows (``qwen.engine_tensors``); the padding columns must never be chosen or reach the caller."""
+    from whisperjav_amd import qwen
+    d = qwen.Qwen3Dims(hidden=256, n_layer=1, n_head=2, n_kv_head=1, head_dim=128, ffn=256, vocab=1000, rope_theta=10000.0,
+                       audio_token_id=9, eos_token_ids=(1, 2))
+    w = qwen.synth_weights(d, seed=4)
+    od = qwen3_ref.Qwen3AsrDims(d=d.hidden, layers=d.n_layer, heads=d.n_head, kv_heads=d.n_kv_head, head_dim=d.head_dim, ffn=d.ffn,
+                                vocab=d.vocab, rope_theta=d.rope_theta, rms_eps=d.rms_eps, audio_token_id=d.audio_token_id,
+                                eos_token_ids=d.eos_token_ids)
+    oracle = qwen3_ref.Qwen3AsrOracle(od, w)
+    rng = np.random.default_rng(12)
+    S = 1030
+    prompts = [rng.integers(20, d.vocab, int(rng.integers(1, 4))).tolist() for _ in range(S)]
+    big = qwen.HipQwen3Decoder(d, w, dtype="float16", max_seqs=S, max_ctx=16)
+    packed, n = big.prompt_embeddings_many(prompts, [None] * S)
+    logits = big.prefill_packed(packed, n, want_logits=True)
+    assert logits.shape == (S, d.vocab)
+    res = big.generate(max_new_tokens=4)
+    assert all(0 <= t < d.vocab for toks in res.tokens for t in toks)
+    small = qwen.HipQwen3Decoder(d, w, dtype="float16", max_seqs=8, max_ctx=16)
+    for b in (0, 517, S - 1):
+        one = small.prefill([small.embed(prompts[b])], want_logits=True)[0]
+        assert float((one - logits[b]).abs().max()) < 2e-2          # the tile kernel and the skinny kernel sum in different orders
+        with torch.no_grad():
+            ref = oracle.logits(oracle.embed(prompts[b], None))[-1]
+        assert float((logits[b].cpu() - ref).abs().max()) < 3e-2 * max(1.0, float(ref.abs().max()))
+    big.close(); small.close()
+
+
+def test_audio_tower_slices_a_batch_that_exceeds_its_workspace(hip):
+    """``encode`` cuts the batch at ``max_seconds`` one-second chunks; clips are independent, so the slices give what one pass gives."""
+    from whisperjav_amd import qwen, synth
+    ad = qwen.Qwen3AudioDims(n_layer=2, n_head=2, ffn=256, d_model=128, conv_hidden=16, out_dim=256, n_window_infer=400)
+    aw = qwen.synth_audio_weights(ad, seed=11)
+    clips = [synth.speech_like(s, seed=70 + i) for i, s in enumerate((2.37, 5.0, 0.3, 3.1, 4.9))]
+    whole = qwen.HipQwenAudioTower(ad, aw, dtype="float32", max_seconds=40)
+    sliced = qwen.HipQwenAudioTower(ad, aw, dtype="float32", max_seconds=6)
+    a, b = whole.encode(clips), sliced.encode(clips)
+    assert [tuple(x.shape) for x in a] == [tuple(x.shape) for x in b]
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max()) < 1e-5 * max(1.0, float(x.abs().max()))
+    whole.close(); sliced.close()

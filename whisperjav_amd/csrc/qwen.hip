@@ -24,17 +24,34 @@ namespace {
 
 constexpr int HD = 128;   // head_dim of every published Qwen3 size
 
+// One workgroup per row: 16-byte reads, the row stays in registers between the sum of squares and the scaling when it has
+// at most 2048 columns (every published size), LDS carries the four wave sums.
 template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ out,
                                                       int M, int D, float eps) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  __shared__ float part[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
   const float* xr = x + (int64_t)row * D;
+  float4 keep[2];
   float ss = 0.f;
-  for (int c = lane; c < D; c += 64) ss += xr[c] * xr[c];
-  const float r = rsqrtf(wave_sum(ss) / (float)D + eps);
+  int it = 0;
+  for (int c = tid * 4; c < D; c += 1024, ++it) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    if (it < 2) keep[it] = v;
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) part[tid >> 6] = ss;
+  __syncthreads();
+  const float r = rsqrtf((part[0] + part[1] + part[2] + part[3]) / (float)D + eps);
   T* o = out + (int64_t)row * D;
-  for (int c = lane; c < D; c += 64) Elem<T>::st(o + c, w[c] * (xr[c] * r));
+  it = 0;
+  for (int c = tid * 4; c < D; c += 1024, ++it) {
+    const float4 v = it < 2 ? keep[it] : *reinterpret_cast<const float4*>(xr + c);
+    const float4 g = *reinterpret_cast<const float4*>(w + c);
+    const float y[4] = {g.x * (v.x * r), g.y * (v.y * r), g.z * (v.z * r), g.w * (v.w * r)};
+    st4(o + c, y);
+  }
 }
 
 // One wave per (row, head slot): slots 0..H-1 = query heads, H..H+KV-1 = key heads, H+KV.. = value heads of the fused
@@ -67,55 +84,104 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const T* __restrict__ 
   Elem<T>::st(dst + lane, ra); Elem<T>::st(dst + lane + 64, rb);
 }
 
-// Causal grouped-query attention, one wave per (row, query head).  Keys are taken 64 at a time: lane j scores key
-// base + j against the whole query (q broadcast from LDS), an online softmax keeps (max, sum) across chunks, and the
-// weighted values are accumulated with lane i owning output dims i and i + 64 (each key's V row is one coalesced read).
-template <typename T>
+// Causal grouped-query attention, one wave per (row, KV head): the G = H / KV query heads that share the KV head are
+// scored together, so every K and V row is read ONCE per group (the kernel is bound by those reads: 512 B per key per KV
+// head).  A lane is (kq = lane >> 4, dq = lane & 15): one load instruction covers 4 keys x 256 B -- lane (kq, dq) holds
+// dims 8 dq .. 8 dq + 7 of key base + kq -- i.e. 1 KiB contiguous; the 16 lanes of a key reduce the dot product with four
+// row-local exchanges.  Keys are taken 64 at a time (16 such loads in flight), an online softmax carries (max, sum)
+// across chunks; the weights stay in the registers that held the scores (all 16 lanes of key kq hold that key's weight),
+// so the value pass needs no broadcast: acc[g][8] += p[g][key] * V[key][8 dq ..], summed over the four kq rows at the end.
+template <typename T, int G>
 __global__ __launch_bounds__(64) void gqa_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
                                                       const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_pos,
                                                       T* __restrict__ out, int H, int KV, int ctx) {
-  __shared__ float sq[HD];
-  const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-  const int b_seq = row_seq[m], n_keys = row_pos[m] + 1, kvh = h / (H / KV);
-  const T* qr = q + ((int64_t)m * H + h) * HD;
-  sq[lane] = Elem<T>::ld(qr + lane); sq[lane + 64] = Elem<T>::ld(qr + lane + 64);
-  __syncthreads();
-  const T* Kb = kc + ((int64_t)b_seq * KV + kvh) * (int64_t)ctx * HD;
-  const T* Vb = vc + ((int64_t)b_seq * KV + kvh) * (int64_t)ctx * HD;
-  const float scale = rsqrtf((float)HD);
-  float run_max = -INFINITY, run_sum = 0.f, acc0 = 0.f, acc1 = 0.f;
-  for (int base = 0; base < n_keys; base += 64) {
-    const int j = base + lane;
-    float s = -INFINITY;
-    if (j < n_keys) {
-      const T* kr = Kb + (int64_t)j * HD;
-      float d = 0.f;
-#pragma unroll 4
-      for (int c = 0; c < HD; c += 8) {
-        float kv[8];
-        ld8(kr + c, kv);
+  constexpr int STEPS = 16;
+  const int m = blockIdx.x, kvh = blockIdx.y, lane = threadIdx.x, kq = lane >> 4, dq = lane & 15;
+  const int b_seq = row_seq[m], n_keys = row_pos[m] + 1;
+  const int64_t kvoff = ((int64_t)b_seq * KV + kvh) * (int64_t)ctx * HD + dq * 8;
+  const T* Kb = kc + kvoff;
+  const T* Vb = vc + kvoff;
+  float qv[G][8], acc[G][8], run_max[G], run_sum[G];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d = fmaf(sq[c + e], kv[e], d);
-      }
-      s = d * scale;
-    }
-    const float new_max = fmaxf(run_max, wave_max(s));
-    const float corr = expf(run_max - new_max);       // exp(-inf) = 0 on the first chunk
-    const float p = j < n_keys ? expf(s - new_max) : 0.f;
-    run_sum = run_sum * corr + wave_sum(p);
-    acc0 *= corr; acc1 *= corr;
-    const int n_here = min(64, n_keys - base);
-    for (int jj = 0; jj < n_here; ++jj) {
-      const float pj = __shfl(p, jj, 64);
-      const T* vr = Vb + (int64_t)(base + jj) * HD;
-      acc0 = fmaf(pj, Elem<T>::ld(vr + lane), acc0);
-      acc1 = fmaf(pj, Elem<T>::ld(vr + lane + 64), acc1);
-    }
-    run_max = new_max;
+  for (int g = 0; g < G; ++g) {
+    ld8(q + ((int64_t)m * H + kvh * G + g) * HD + dq * 8, qv[g]);
+    run_max[g] = -INFINITY; run_sum[g] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
   }
-  T* o = out + ((int64_t)m * H + h) * HD;
-  const float inv = 1.f / run_sum;
-  Elem<T>::st(o + lane, acc0 * inv); Elem<T>::st(o + lane + 64, acc1 * inv);
+  const float scale = rsqrtf((float)HD);
+  for (int base = 0; base < n_keys; base += 4 * STEPS) {
+    float s[G][STEPS];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int key = base + st * 4 + kq;
+      if (base + st * 4 < n_keys) {                 // wave-uniform
+        float kv[8];
+        ld8(Kb + (int64_t)min(key, n_keys - 1) * HD, kv);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          float d = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d = fmaf(qv[g][e], kv[e], d);
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) d += __shfl_xor(d, o, 64);
+          s[g][st] = key < n_keys ? d * scale : -INFINITY;
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) s[g][st] = -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float cm = s[g][0];
+#pragma unroll
+      for (int st = 1; st < STEPS; ++st) cm = fmaxf(cm, s[g][st]);
+      cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+      cm = fmaxf(cm, __shfl_xor(cm, 32, 64));       // key `base` is always valid, so the chunk maximum is finite
+      const float new_max = fmaxf(run_max[g], cm);
+      const float corr = expf(run_max[g] - new_max);  // exp(-inf) = 0 on the first chunk
+      float ps = 0.f;
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        s[g][st] = expf(s[g][st] - new_max);          // masked keys: exp(-inf) = 0
+        ps += s[g][st];
+      }
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      run_sum[g] = run_sum[g] * corr + ps;
+      run_max[g] = new_max;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[g][e] *= corr;
+    }
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      if (base + st * 4 < n_keys) {
+        float vv[8];
+        ld8(Vb + (int64_t)min(base + st * 4 + kq, n_keys - 1) * HD, vv);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(s[g][st], vv[e], acc[g][e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      acc[g][e] += __shfl_xor(acc[g][e], 16, 64);
+      acc[g][e] += __shfl_xor(acc[g][e], 32, 64);
+    }
+    if (kq == 0) {
+      const float inv = 1.f / run_sum[g];
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = acc[g][e] * inv;
+      T* dst = out + ((int64_t)m * H + kvh * G + g) * HD + dq * 8;
+      st4(dst, o); st4(dst + 4, o + 4);
+    }
+  }
 }
 
 template <typename T>
@@ -185,6 +251,7 @@ struct wj_qwen {
   float* xl = nullptr;       // f32 [seqs][D] rows that produce logits
   float* logits = nullptr;   // f32 [seqs][ldl]
   int64_t ldl = 0;
+  int vocab_pad = 0;         // vocabulary rounded up to 256 when the blob carries the zero rows (qwen.py pads), else the vocabulary
   int32_t *row_seq = nullptr, *row_pos = nullptr, *last_rows = nullptr, *next_tok = nullptr, *finished = nullptr, *n_out = nullptr;
   int32_t *top_id = nullptr, *tokens_out = nullptr, *eos = nullptr;
   float *top_lp = nullptr, *top_lse = nullptr, *lp_out = nullptr;
@@ -212,9 +279,9 @@ int run_layers(wj_qwen* m, int M, hipStream_t s) {
     void* kc = m->at(m->kc, l * layer_kv);
     void* vc = m->at(m->vc, l * layer_kv);
     auto rms = [&](const float* w, void* out) -> int {
-      if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(ceil_div(M, 4)), dim3(256), 0, s, m->x, w, TP(float, out), M, D, d.rms_eps);
-      else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(ceil_div(M, 4)), dim3(256), 0, s, m->x, w, TP(f16_t, out), M, D, d.rms_eps);
-      else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(ceil_div(M, 4)), dim3(256), 0, s, m->x, w, TP(bf16_t, out), M, D, d.rms_eps);
+      if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(M), dim3(256), 0, s, m->x, w, TP(float, out), M, D, d.rms_eps);
+      else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(M), dim3(256), 0, s, m->x, w, TP(f16_t, out), M, D, d.rms_eps);
+      else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(M), dim3(256), 0, s, m->x, w, TP(bf16_t, out), M, D, d.rms_eps);
       WJ_LAUNCH_CHECK();
       return WJ_OK;
     };
@@ -235,15 +302,16 @@ int run_layers(wj_qwen* m, int M, hipStream_t s) {
       hipLaunchKernelGGL((qk_norm_rope_kernel<bf16_t>), dim3(M, H + 2 * KV), dim3(64), 0, s, TP(const bf16_t, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
                          m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(bf16_t, m->q), TP(bf16_t, kc), TP(bf16_t, vc), H, KV, m->max_ctx, l2t, d.rms_eps);
     WJ_LAUNCH_CHECK();
-    if (dt == WJ_F32)
-      hipLaunchKernelGGL((gqa_attn_kernel<float>), dim3(M, H), dim3(64), 0, s, TP(const float, m->q), TP(const float, kc), TP(const float, vc),
-                         m->row_seq, m->row_pos, TP(float, m->attn), H, KV, m->max_ctx);
-    else if (dt == WJ_F16)
-      hipLaunchKernelGGL((gqa_attn_kernel<f16_t>), dim3(M, H), dim3(64), 0, s, TP(const f16_t, m->q), TP(const f16_t, kc), TP(const f16_t, vc),
-                         m->row_seq, m->row_pos, TP(f16_t, m->attn), H, KV, m->max_ctx);
-    else
-      hipLaunchKernelGGL((gqa_attn_kernel<bf16_t>), dim3(M, H), dim3(64), 0, s, TP(const bf16_t, m->q), TP(const bf16_t, kc), TP(const bf16_t, vc),
-                         m->row_seq, m->row_pos, TP(bf16_t, m->attn), H, KV, m->max_ctx);
+#define WJ_GQA(T_, G_) hipLaunchKernelGGL((gqa_attn_kernel<T_, G_>), dim3(M, KV), dim3(64), 0, s, TP(const T_, m->q), TP(const T_, kc), \
+                                          TP(const T_, vc), m->row_seq, m->row_pos, TP(T_, m->attn), H, KV, m->max_ctx)
+#define WJ_GQA_T(G_) do { if (dt == WJ_F32) WJ_GQA(float, G_); else if (dt == WJ_F16) WJ_GQA(f16_t, G_); else WJ_GQA(bf16_t, G_); } while (0)
+    switch (H / KV) {      // query heads per KV head (wj_qwen_create admits 1, 2, 4)
+      case 1: WJ_GQA_T(1); break;
+      case 2: WJ_GQA_T(2); break;
+      default: WJ_GQA_T(4); break;
+    }
+#undef WJ_GQA_T
+#undef WJ_GQA
     WJ_LAUNCH_CHECK();
     {
       GemmArgs g;
@@ -276,12 +344,14 @@ int run_layers(wj_qwen* m, int M, hipStream_t s) {
 int run_head(wj_qwen* m, const float* xin, int n, hipStream_t s) {
   const wj_qwen_dims& d = m->d;
   const int D = d.hidden, dt = m->dtype;
-  if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(ceil_div(n, 4)), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(float, m->h), n, D, d.rms_eps);
-  else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(ceil_div(n, 4)), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(f16_t, m->h), n, D, d.rms_eps);
-  else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(ceil_div(n, 4)), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(bf16_t, m->h), n, D, d.rms_eps);
+  if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(n), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(float, m->h), n, D, d.rms_eps);
+  else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(n), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(f16_t, m->h), n, D, d.rms_eps);
+  else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(n), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(bf16_t, m->h), n, D, d.rms_eps);
   WJ_LAUNCH_CHECK();
   GemmArgs g;
-  g.A = m->h; g.lda = D; g.W = m->W(WJ_Q_EMBED); g.ldw = D; g.M = n; g.N = d.vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
+  // >= 1024 rows: N a multiple of 256 admits the 256-tile kernel (the surplus columns are dot products with zero rows; top-1 below
+  // reads the first d.vocab columns only)
+  g.A = m->h; g.lda = D; g.W = m->W(WJ_Q_EMBED); g.ldw = D; g.M = n; g.N = n >= 1024 ? m->vocab_pad : d.vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
   WJ_TRYQ(launch_gemm(dt, EPI_F32, g, s, 0));
   return launch_topk_logprob(m->logits, m->ldl, n, d.vocab, 1, nullptr, m->top_id, m->top_lp, m->top_lse, s);
 }
@@ -314,6 +384,8 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   WJ_REQUIRE(d.head_dim == HD, "wj_qwen_create: head_dim %d (the kernels are specialised for 128, every published Qwen3 size)", d.head_dim);
   WJ_REQUIRE(d.hidden > 0 && d.hidden % 8 == 0 && d.ffn % 8 == 0 && d.n_head >= 1 && d.n_kv_head >= 1 && d.n_head % d.n_kv_head == 0 &&
              d.n_layer >= 1 && d.vocab >= 2, "wj_qwen_create: bad dimensions");
+  WJ_REQUIRE(d.n_head / d.n_kv_head == 1 || d.n_head / d.n_kv_head == 2 || d.n_head / d.n_kv_head == 4,
+             "wj_qwen_create: %d query heads per KV head (the attention kernel is instantiated for 1, 2 and 4)", d.n_head / d.n_kv_head);
   WJ_REQUIRE(dtype == WJ_F32 || dtype == WJ_F16 || dtype == WJ_BF16, "wj_qwen_create: unknown dtype %d", dtype);
   WJ_REQUIRE(n_offsets == WJ_Q_N_GLOBAL + d.n_layer * WJ_QL_N, "wj_qwen_create: %d tensor offsets expected, got %d",
              WJ_Q_N_GLOBAL + d.n_layer * WJ_QL_N, n_offsets);
@@ -328,7 +400,12 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   m->max_seqs = max_seqs; m->max_ctx = max_ctx; m->max_rows = max_rows;
   const size_t e = m->esz, R = max_rows, S = max_seqs;
   const int D = d.hidden, H = d.n_head, KV = d.n_kv_head, F = d.ffn;
-  m->ldl = (d.vocab + 63) / 64 * 64;
+  {
+    const int vp = (d.vocab + 255) / 256 * 256;
+    const int64_t room = (n_offsets > 1 ? offsets_host[WJ_Q_EMBED + 1] : (int64_t)blob_bytes) - offsets_host[WJ_Q_EMBED];
+    m->vocab_pad = room >= (int64_t)vp * d.hidden * (int64_t)m->esz ? vp : d.vocab;
+  }
+  m->ldl = (m->vocab_pad + 63) / 64 * 64;
   int rc = 0;
 #define QA(field, bytes) do { if (!rc) rc = qalloc(m, reinterpret_cast<void**>(&m->field), (bytes)); } while (0)
   QA(x, R * D * sizeof(float)); QA(h, R * D * e); QA(qkv, R * (size_t)(H + 2 * KV) * HD * e); QA(q, R * (size_t)H * HD * e);
@@ -439,9 +516,9 @@ int wj_qwen_classify(wj_qwen* m, const float* embeds_dev, int n_seqs, const int3
   WJ_LAUNCH_CHECK();
   const int D = m->d.hidden, dt = m->dtype;
   // normed rows go to the head GEMM in the compute type; h holds max_rows x D elements
-  if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(ceil_div(n_rows, 4)), dim3(256), 0, s, gathered, m->F(WJ_Q_NORM_W), TP(float, m->h), n_rows, D, m->d.rms_eps);
-  else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(ceil_div(n_rows, 4)), dim3(256), 0, s, gathered, m->F(WJ_Q_NORM_W), TP(f16_t, m->h), n_rows, D, m->d.rms_eps);
-  else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(ceil_div(n_rows, 4)), dim3(256), 0, s, gathered, m->F(WJ_Q_NORM_W), TP(bf16_t, m->h), n_rows, D, m->d.rms_eps);
+  if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(n_rows), dim3(256), 0, s, gathered, m->F(WJ_Q_NORM_W), TP(float, m->h), n_rows, D, m->d.rms_eps);
+  else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(n_rows), dim3(256), 0, s, gathered, m->F(WJ_Q_NORM_W), TP(f16_t, m->h), n_rows, D, m->d.rms_eps);
+  else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(n_rows), dim3(256), 0, s, gathered, m->F(WJ_Q_NORM_W), TP(bf16_t, m->h), n_rows, D, m->d.rms_eps);
   WJ_LAUNCH_CHECK();
   GemmArgs g;
   g.A = m->h; g.lda = D; g.W = head_w_dev; g.ldw = D; g.bias = head_b_dev; g.M = n_rows; g.N = n_labels; g.K = D; g.out = d_logits; g.ldc = ldl;

@@ -87,7 +87,11 @@ def synth_weights(d: Qwen3Dims, seed: int = 7) -> Dict[str, np.ndarray]:
 
 def engine_tensors(d: Qwen3Dims, w: Dict[str, np.ndarray]) -> List[Tuple[str, np.ndarray, bool]]:
     p = "model.language_model."
-    out = [("EMBED", w[p + "embed_tokens.weight"], True), ("NORM_W", w[p + "norm.weight"], False)]
+    emb = w[p + "embed_tokens.weight"]
+    pad = -emb.shape[0] % 256       # zero rows up to a multiple of 256: the tied LM head then qualifies for the 256-wide MFMA tile kernel
+    if pad:
+        emb = np.concatenate([emb, np.zeros((pad, emb.shape[1]), dtype=emb.dtype)], 0)
+    out = [("EMBED", emb, True), ("NORM_W", w[p + "norm.weight"], False)]
     for l in range(d.n_layer):
         q = f"{p}layers.{l}."
         qkv = np.concatenate([w[q + "self_attn.q_proj.weight"], w[q + "self_attn.k_proj.weight"], w[q + "self_attn.v_proj.weight"]], 0)
@@ -268,6 +272,21 @@ class HipQwenAudioTower:
         return self.fe(padded, out_frames=width), frames
 
     def encode(self, clips: Sequence[np.ndarray]) -> List[torch.Tensor]:
+        """One tensor of audio embeddings per clip.  The batch is cut into slices of at most ``max_seconds`` one-second
+        chunks (clips are independent, the workspaces of the engine are sized for one slice)."""
+        n_chunks = [max(1, -(-max(len(c), self.MIN_SAMPLES) // 160 // 100)) for c in clips]
+        out: List[torch.Tensor] = []
+        lo = 0
+        while lo < len(clips):
+            hi, used = lo, 0
+            while hi < len(clips) and (hi == lo or used + n_chunks[hi] <= self.max_chunks):
+                used += n_chunks[hi]
+                hi += 1
+            out.extend(self._encode_slice(clips[lo:hi]))
+            lo = hi
+        return out
+
+    def _encode_slice(self, clips: Sequence[np.ndarray]) -> List[torch.Tensor]:
         mel, frames = self.features(clips)
         n_tok = np.array([int(self._lib.wj_qwen_audio_tokens(int(f))) for f in frames], dtype=np.int32)
         out = torch.empty((int(n_tok.sum()), self.dims.out_dim), dtype=torch.float32, device=self.dev)
@@ -343,15 +362,42 @@ class HipQwen3Decoder:
             x[mask] = audio.to(self.dev, torch.float32)
         return x
 
+    def prompt_embeddings_many(self, prompts: Sequence[Sequence[int]], audios: Sequence[Optional[torch.Tensor]]) -> Tuple[torch.Tensor, np.ndarray]:
+        """``prompt_embeddings`` for a whole batch in one embedding launch and one scatter: the PACKED fp32 ``[sum n_b, hidden]``
+        matrix (sequence after sequence) and the token count of every sequence -- what ``prefill_packed`` takes."""
+        if len(prompts) != len(audios):
+            raise ValueError("one audio tensor (or None) per prompt")
+        ids = [np.asarray(p, dtype=np.int32).reshape(-1) for p in prompts]
+        n = np.array([len(p) for p in ids], dtype=np.int32)
+        flat = np.concatenate(ids)
+        x = self.embed(flat)
+        for b, (p, a) in enumerate(zip(ids, audios)):
+            want = int((p == self.dims.audio_token_id).sum())
+            have = 0 if a is None else int(a.shape[0])
+            if want != have:
+                raise ValueError(f"prompt {b}: {want} <audio> placeholders for {have} audio embeddings")
+        rows = np.flatnonzero(flat == self.dims.audio_token_id)
+        if len(rows):
+            a = torch.cat([a.to(self.dev, torch.float32) for a in audios if a is not None and a.shape[0]], 0)
+            x.index_copy_(0, torch.as_tensor(rows, device=self.dev), a)
+        return x, n
+
     def prefill(self, embeds: Sequence[torch.Tensor], want_logits: bool = False) -> Optional[torch.Tensor]:
         """``embeds[b]``: fp32 CUDA ``[n_b, hidden]`` prompt embeddings of sequence b."""
         n = np.array([int(e.shape[0]) for e in embeds], dtype=np.int32)
         packed = torch.cat([e.to(self.dev, torch.float32) for e in embeds], 0).contiguous()
-        out = torch.empty((len(embeds), self.dims.vocab), dtype=torch.float32, device=self.dev) if want_logits else None
+        return self.prefill_packed(packed, n, want_logits)
+
+    def prefill_packed(self, packed: torch.Tensor, n_tokens: np.ndarray, want_logits: bool = False) -> Optional[torch.Tensor]:
+        """Prompts already packed sequence after sequence (``prompt_embeddings_many``)."""
+        n = np.ascontiguousarray(n_tokens, dtype=np.int32)
+        if packed.dtype != torch.float32 or not packed.is_contiguous() or packed.shape != (int(n.sum()), self.dims.hidden):
+            raise ValueError("packed prompts: contiguous fp32 [sum(n_tokens), hidden] expected")
+        out = torch.empty((len(n), self.dims.vocab), dtype=torch.float32, device=self.dev) if want_logits else None
         torch.cuda.current_stream().synchronize()
-        check(self._lib.wj_qwen_prefill(self.handle, C.c_void_p(packed.data_ptr()), len(embeds), n.ctypes.data_as(C.POINTER(C.c_int32)),
+        check(self._lib.wj_qwen_prefill(self.handle, C.c_void_p(packed.data_ptr()), len(n), n.ctypes.data_as(C.POINTER(C.c_int32)),
                                         C.c_void_p(out.data_ptr()) if out is not None else None, None), "wj_qwen_prefill")
-        self._n_seqs = len(embeds)
+        self._n_seqs = len(n)
         return out
 
     def classify(self, embeds: Sequence[torch.Tensor], rows: Sequence[Sequence[int]], head_w: torch.Tensor,
@@ -463,11 +509,10 @@ class HipQwenTextGenerator:
                     audio = to_16k(audio, sr)
                 clips.append(audio)
             audio_embeds = (self.audio_embedder or self._tower.encode)(clips)       # one launch chain for the batch's clips
-            embeds = []
-            for a, ctx_text in zip(audio_embeds, contexts[lo: lo + self.batch_size]):
-                ids = self.prompt_builder(int(a.shape[0]), language, ctx_text)
-                embeds.append(self._model.prompt_embeddings(ids, torch.as_tensor(a)))
-            self._model.prefill(embeds)
+            audio_embeds = [torch.as_tensor(a) for a in audio_embeds]
+            ids = [self.prompt_builder(int(a.shape[0]), language, ctx_text)
+                   for a, ctx_text in zip(audio_embeds, contexts[lo: lo + self.batch_size])]
+            self._model.prefill_packed(*self._model.prompt_embeddings_many(ids, audio_embeds))     # one embedding launch, one scatter
             res = self._model.generate(int(kwargs.get("max_new_tokens", self.max_new_tokens)))
             for toks in res.tokens:
                 out.append(TranscriptionResult(text=self.detokenize(toks), language=language, metadata={"n_tokens": len(toks)}))
