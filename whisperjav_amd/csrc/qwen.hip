@@ -268,6 +268,25 @@ namespace {
 #define WJ_TRYQ(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 #define TP(T, p) reinterpret_cast<T*>(p)
 
+// Which kernel of gemm.hip carries a decoder GEMM of M rows (scripts/qwen_gemm_sweep.py on the MI355X, 1.7 B geometry,
+// profiles/r03_qwen_gemm_sweep.jsonl).  The dispatcher's own choice (0) is the skinny kernel up to 512 rows and the 256-wide
+// ping-pong kernel from 1024: right for a few dozen rows and for the wide gate/up projection of a prompt, but between the two
+// the 128-tile kernels win by 2-6x (skinny re-reads the activations per 16 columns), and from 1024 rows the 2048-column
+// projections (o, down: 32-64 tiles of 256 x 256) leave most of the 256 CUs idle under the 256-tile kernel.
+enum QGemm { QG_QKV, QG_O, QG_GATEUP, QG_DOWN };
+int gemm_variant(QGemm which, int M, int K, int dt) {
+  if (dt == WJ_F32 || K % 64) return 0;             // the exact fp32 kernel has one form; the LDS-DMA tiles take whole 64-column steps
+  if (M <= 64) return which == QG_GATEUP && M > 32 ? 73 : 0;
+  if (M < 1024) return which == QG_DOWN ? 74 : 3;
+  if (M >= 8192) return 0;                          // prompts: every projection fills the chip with 256-wide tiles
+  switch (which) {
+    case QG_QKV: return M >= 2048 ? 3 : 74;
+    case QG_O: return 73;
+    case QG_GATEUP: return 0;
+    default: return 74;
+  }
+}
+
 // rows [0, M) through every decoder layer; row_seq / row_pos describe them
 int run_layers(wj_qwen* m, int M, hipStream_t s) {
   const wj_qwen_dims& d = m->d;
@@ -289,7 +308,7 @@ int run_layers(wj_qwen* m, int M, hipStream_t s) {
     {
       GemmArgs g;
       g.A = m->h; g.lda = D; g.W = m->W(b0 + WJ_QL_QKV_W); g.ldw = D; g.M = M; g.N = W; g.K = D; g.out = m->qkv; g.ldc = W;
-      WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, 0));
+      WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, gemm_variant(QG_QKV, M, D, dt)));
     }
     const float l2t = log2f(d.rope_theta);
     if (dt == WJ_F32)
@@ -316,13 +335,13 @@ int run_layers(wj_qwen* m, int M, hipStream_t s) {
     {
       GemmArgs g;
       g.A = m->attn; g.lda = H * HD; g.W = m->W(b0 + WJ_QL_O_W); g.ldw = H * HD; g.M = M; g.N = D; g.K = H * HD; g.out = m->x; g.ldc = D;
-      WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, 0));
+      WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, gemm_variant(QG_O, M, H * HD, dt)));
     }
     WJ_TRYQ(rms(m->F(b0 + WJ_QL_LN2_W), m->h));
     {
       GemmArgs g;
       g.A = m->h; g.lda = D; g.W = m->W(b0 + WJ_QL_GATEUP_W); g.ldw = D; g.M = M; g.N = 2 * F; g.K = D; g.out = m->gu; g.ldc = 2 * F;
-      WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, 0));
+      WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, gemm_variant(QG_GATEUP, M, D, dt)));
     }
     {
       const dim3 grid((unsigned)ceil_div64((int64_t)M * F, 256));
@@ -334,7 +353,7 @@ int run_layers(wj_qwen* m, int M, hipStream_t s) {
     {
       GemmArgs g;
       g.A = m->act; g.lda = F; g.W = m->W(b0 + WJ_QL_DOWN_W); g.ldw = F; g.M = M; g.N = D; g.K = F; g.out = m->x; g.ldc = D;
-      WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, 0));
+      WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, gemm_variant(QG_DOWN, M, F, dt)));
     }
   }
   return WJ_OK;

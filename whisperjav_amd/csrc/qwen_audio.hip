@@ -15,6 +15,7 @@
 // epilogues (bias, GELU, fp32 residual read-modify-write).  The windowed attention is a plain one-wave-per-(token, head)
 // kernel: windows hold <= 104 tokens, the tower is a few per cent of the model's work.
 #include <algorithm>
+#include <climits>
 #include <vector>
 
 #include "kernels.hpp"
@@ -69,42 +70,95 @@ __global__ __launch_bounds__(256) void pos_select_kernel(const float* __restrict
   for (int c = threadIdx.x; c < D; c += 256) x[(int64_t)i * D + c] = y[(int64_t)src * D + c] + pos[(int64_t)t * D + c];
 }
 
-// non-causal attention inside [lo, hi) of the packed token axis; head_dim 64: lane j scores key base + j, lane i owns dim i
-template <typename T>
+// Non-causal attention inside [lo, hi) of the packed token axis, head_dim 64.  One wave per (QB consecutive query tokens,
+// head): the QB queries share every K / V load (consecutive tokens almost always share their window; at a window edge the
+// wave walks the union of the two windows and masks per query), which divides the L2 traffic that bounded the one-query form
+// (26 KB of K / V re-read per query and head) by QB.  A lane is (kq = lane >> 3, dq = lane & 7): one load instruction
+// covers 8 keys x 128 B, lane (kq, dq) holding dims 8 dq .. 8 dq + 7 of key base + kq; the 8 lanes of a key reduce the dot
+// product with three exchanges; the softmax weights stay in the score registers for the value pass (see gqa_attn_kernel).
+template <typename T, int QB>
 __global__ __launch_bounds__(64) void win_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_lo,
-                                                      const int32_t* __restrict__ win_hi, T* __restrict__ out, int D) {
-  __shared__ float sq[64];
-  const int i = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-  const int lo = win_lo[i], hi = win_hi[i];
-  sq[lane] = Elem<T>::ld(qkv + (int64_t)i * 3 * D + h * 64 + lane);
-  __syncthreads();
-  float run_max = -INFINITY, run_sum = 0.f, acc = 0.f;
-  for (int base = lo; base < hi; base += 64) {
-    const int j = base + lane;
-    float s = -INFINITY;
-    if (j < hi) {
-      const T* kr = qkv + (int64_t)j * 3 * D + D + h * 64;
-      float d = 0.f;
+                                                      const int32_t* __restrict__ win_hi, T* __restrict__ out, int D, int N) {
+  constexpr int STEPS = 8;
+  const int i0 = blockIdx.x * QB, h = blockIdx.y, lane = threadIdx.x, kq = lane >> 3, dq = lane & 7;
+  int lo[QB], hi[QB], ulo = INT_MAX, uhi = 0;
+  float qv[QB][8], acc[QB][8], run_max[QB], run_sum[QB];
 #pragma unroll
-      for (int c = 0; c < 64; c += 8) {
-        float kv[8];
-        ld8(kr + c, kv);
+  for (int b = 0; b < QB; ++b) {
+    const int i = min(i0 + b, N - 1);
+    lo[b] = win_lo[i]; hi[b] = win_hi[i];
+    ulo = min(ulo, lo[b]); uhi = max(uhi, hi[b]);
+    ld8(qkv + (int64_t)i * 3 * D + h * 64 + dq * 8, qv[b]);
+    run_max[b] = -INFINITY; run_sum[b] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d = fmaf(sq[c + e], kv[e], d);
-      }
-      s = d * 0.125f;
-    }
-    const float new_max = fmaxf(run_max, wave_max(s));
-    const float corr = expf(run_max - new_max);
-    const float p = j < hi ? expf(s - new_max) : 0.f;
-    run_sum = run_sum * corr + wave_sum(p);
-    acc *= corr;
-    const int n_here = min(64, hi - base);
-    for (int jj = 0; jj < n_here; ++jj)
-      acc = fmaf(__shfl(p, jj, 64), Elem<T>::ld(qkv + (int64_t)(base + jj) * 3 * D + 2 * D + h * 64 + lane), acc);
-    run_max = new_max;
+    for (int e = 0; e < 8; ++e) acc[b][e] = 0.f;
   }
-  Elem<T>::st(out + (int64_t)i * D + h * 64 + lane, acc / run_sum);
+  const T* Kb = qkv + D + h * 64 + dq * 8;
+  const T* Vb = qkv + 2 * D + h * 64 + dq * 8;
+  for (int base = ulo; base < uhi; base += 8 * STEPS) {
+    float s[QB][STEPS];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int key = base + st * 8 + kq;
+      if (base + st * 8 < uhi) {                    // wave-uniform
+        float kv[8];
+        ld8(Kb + (int64_t)min(key, uhi - 1) * 3 * D, kv);
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+          float d = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d = fmaf(qv[b][e], kv[e], d);
+          d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+          s[b][st] = (key >= lo[b] && key < hi[b]) ? d * 0.125f : -INFINITY;
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < QB; ++b) s[b][st] = -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      float cm = s[b][0];
+#pragma unroll
+      for (int st = 1; st < STEPS; ++st) cm = fmaxf(cm, s[b][st]);
+      cm = fmaxf(cm, __shfl_xor(cm, 8, 64)); cm = fmaxf(cm, __shfl_xor(cm, 16, 64)); cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+      const float new_max = fmaxf(run_max[b], cm);
+      const float ref = new_max == -INFINITY ? 0.f : new_max;      // no key of this query seen yet: every weight below is exp(-inf) = 0
+      const float corr = expf(run_max[b] - ref);
+      float ps = 0.f;
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) { s[b][st] = expf(s[b][st] - ref); ps += s[b][st]; }
+      ps += __shfl_xor(ps, 8, 64); ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
+      run_sum[b] = run_sum[b] * corr + ps;
+      run_max[b] = new_max;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[b][e] *= corr;
+    }
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      if (base + st * 8 < uhi) {
+        float vv[8];
+        ld8(Vb + (int64_t)min(base + st * 8 + kq, uhi - 1) * 3 * D, vv);
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[b][e] = fmaf(s[b][st], vv[e], acc[b][e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = acc[b][e];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      acc[b][e] = v / run_sum[b];
+    }
+    if (kq == 0 && i0 + b < N) {
+      T* dst = out + (int64_t)(i0 + b) * D + h * 64 + dq * 8;
+      st4(dst, acc[b]); st4(dst + 4, acc[b] + 4);
+    }
+  }
 }
 
 }  // namespace
@@ -262,9 +316,13 @@ int wj_qwen_audio_encode(wj_qwen_audio* m, const float* mel_dev, int n_clips, in
     const int b0 = m->layer_base(l);
     WJ_TRYA(launch_layernorm(dt, m->x, m->F(b0 + WJ_QAL_LN1_W), m->F(b0 + WJ_QAL_LN1_B), m->h, N, D, s, 0));
     WJ_TRYA(gemm(EPI_T, m->h, D, b0 + WJ_QAL_QKV_W, b0 + WJ_QAL_QKV_B, N, 3 * D, D, m->qkv, 3 * D));
-    if (dt == WJ_F32) hipLaunchKernelGGL((win_attn_kernel<float>), dim3(N, H), dim3(64), 0, s, TPA(const float, m->qkv), m->win_lo, m->win_hi, TPA(float, m->attn), D);
-    else if (dt == WJ_F16) hipLaunchKernelGGL((win_attn_kernel<f16_t>), dim3(N, H), dim3(64), 0, s, TPA(const f16_t, m->qkv), m->win_lo, m->win_hi, TPA(f16_t, m->attn), D);
-    else hipLaunchKernelGGL((win_attn_kernel<bf16_t>), dim3(N, H), dim3(64), 0, s, TPA(const bf16_t, m->qkv), m->win_lo, m->win_hi, TPA(bf16_t, m->attn), D);
+    {
+      constexpr int QB = 4;
+      const dim3 grid(ceil_div(N, QB), H);
+      if (dt == WJ_F32) hipLaunchKernelGGL((win_attn_kernel<float, QB>), grid, dim3(64), 0, s, TPA(const float, m->qkv), m->win_lo, m->win_hi, TPA(float, m->attn), D, N);
+      else if (dt == WJ_F16) hipLaunchKernelGGL((win_attn_kernel<f16_t, QB>), grid, dim3(64), 0, s, TPA(const f16_t, m->qkv), m->win_lo, m->win_hi, TPA(f16_t, m->attn), D, N);
+      else hipLaunchKernelGGL((win_attn_kernel<bf16_t, QB>), grid, dim3(64), 0, s, TPA(const bf16_t, m->qkv), m->win_lo, m->win_hi, TPA(bf16_t, m->attn), D, N);
+    }
     WJ_LAUNCH_CHECK();
     WJ_TRYA(gemm(EPI_RESID_F32, m->attn, D, b0 + WJ_QAL_OUT_W, b0 + WJ_QAL_OUT_B, N, D, D, m->x, D));
     WJ_TRYA(launch_layernorm(dt, m->x, m->F(b0 + WJ_QAL_LN2_W), m->F(b0 + WJ_QAL_LN2_B), m->h, N, D, s, 0));
