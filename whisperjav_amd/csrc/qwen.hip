@@ -324,6 +324,10 @@ int run_layers(wj_qwen* m, int M, hipStream_t s) {
 #define WJ_GQA(T_, G_) hipLaunchKernelGGL((gqa_attn_kernel<T_, G_>), dim3(M, KV), dim3(64), 0, s, TP(const T_, m->q), TP(const T_, kc), \
                                           TP(const T_, vc), m->row_seq, m->row_pos, TP(T_, m->attn), H, KV, m->max_ctx)
 #define WJ_GQA_T(G_) do { if (dt == WJ_F32) WJ_GQA(float, G_); else if (dt == WJ_F16) WJ_GQA(f16_t, G_); else WJ_GQA(bf16_t, G_); } while (0)
+    // Prompt rows use the same one-row-per-wave kernel: a form that gave a wave 4 consecutive rows of a sequence (8 (row, head)
+    // pairs sharing every K / V load, per-row causal limits) was measured on the 104 k prompt rows of the 120-minute batch and
+    // was SLOWER (prefill 443 -> 481 ms): the kernel is bound by its per-pair arithmetic and exchanges, not by the L2 reads the
+    // blocking saves, and 4x fewer waves hide less latency.  The next step for prompts is an MFMA tile kernel, not blocking.
     switch (H / KV) {      // query heads per KV head (wj_qwen_create admits 1, 2, 4)
       case 1: WJ_GQA_T(1); break;
       case 2: WJ_GQA_T(2); break;

@@ -24,7 +24,7 @@ from __future__ import annotations
 import ctypes as C
 from dataclasses import dataclass
 from pathlib import Path
-from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -264,17 +264,23 @@ class HipQwenAudioTower:
         except Exception:
             pass
 
-    def features(self, clips: Sequence[np.ndarray]) -> Tuple[torch.Tensor, np.ndarray]:
-        """(mel fp32 CUDA ``[n, n_mels, frames_max]`` zero-padded, valid frames per clip)."""
-        padded = [np.pad(np.asarray(c, dtype=np.float32).reshape(-1), (0, max(0, self.MIN_SAMPLES - len(c)))) for c in clips]
-        frames = np.array([len(c) // 160 for c in padded], dtype=np.int32)
+    def features(self, clips: Sequence[Union[np.ndarray, torch.Tensor]]) -> Tuple[torch.Tensor, np.ndarray]:
+        """(mel fp32 CUDA ``[n, n_mels, frames_max]`` zero-padded, valid frames per clip).  Clips may be host arrays or float32
+        CUDA tensors (views of an uploaded recording: no host copy is made)."""
+        if len(clips) and all(isinstance(c, torch.Tensor) and c.is_cuda for c in clips):
+            padded = [torch.nn.functional.pad(c.reshape(-1), (0, self.MIN_SAMPLES - c.numel())) if c.numel() < self.MIN_SAMPLES
+                      else c.reshape(-1) for c in clips]
+            frames = np.array([int(c.numel()) // 160 for c in padded], dtype=np.int32)
+        else:
+            padded = [np.pad(np.asarray(c, dtype=np.float32).reshape(-1), (0, max(0, self.MIN_SAMPLES - len(c)))) for c in clips]
+            frames = np.array([len(c) // 160 for c in padded], dtype=np.int32)
         width = int((frames.max() + 99) // 100 * 100)
         return self.fe(padded, out_frames=width), frames
 
-    def encode(self, clips: Sequence[np.ndarray]) -> List[torch.Tensor]:
+    def encode(self, clips: Sequence[Union[np.ndarray, torch.Tensor]]) -> List[torch.Tensor]:
         """One tensor of audio embeddings per clip.  The batch is cut into slices of at most ``max_seconds`` one-second
         chunks (clips are independent, the workspaces of the engine are sized for one slice)."""
-        n_chunks = [max(1, -(-max(len(c), self.MIN_SAMPLES) // 160 // 100)) for c in clips]
+        n_chunks = [max(1, -(-(max(int(c.shape[-1]) if hasattr(c, "shape") else len(c), self.MIN_SAMPLES) // 160) // 100)) for c in clips]
         out: List[torch.Tensor] = []
         lo = 0
         while lo < len(clips):
