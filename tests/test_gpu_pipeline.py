@@ -1102,6 +1102,43 @@ def test_cabi_weight_broadcast_single_rank(hip):
     assert hip.wj_comm_init(hipbind.context(0).handle, 2, 5, uid.raw, C.byref(comm)) != 0          # rank outside the communicator
 
 
+_BCAST_WORKER = """
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["WJ_REPO"])
+from whisperjav_amd import sharding
+info = sharding.init_distributed()
+dev = torch.device("cuda", info.local_rank)
+torch.cuda.set_device(dev)
+blob = offsets = None
+if info.rank == 0:
+    blob = torch.arange(1 << 22, dtype=torch.int32).view(torch.uint8)
+    offsets = np.arange(0, blob.numel(), 4096, dtype=np.int64)
+out, offs = sharding.broadcast_blob_cabi(blob, offsets, dev)
+want = torch.arange(1 << 22, dtype=torch.int32).view(torch.uint8)
+ok = bool(torch.equal(out.cpu(), want)) and len(offs) == want.numel() // 4096
+print(f"rank {info.rank} ok={ok}", flush=True)
+torch.distributed.destroy_process_group()
+sys.exit(0 if ok else 1)
+"""
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the multi-rank C-ABI broadcast needs two GPUs (the gpurun boxes lease one)")
+def test_cabi_weight_broadcast_two_ranks(hip, tmp_path):
+    """Two processes, one GPU each: the communicator id travels through the process group as an object, ``wj_comm_init`` /
+    ``wj_bcast_weights`` move the blob over RCCL on the library's own stream (this path was single-rank only)."""
+    import os
+    import subprocess
+    import sys
+    worker = tmp_path / "bcast_worker.py"
+    worker.write_text(_BCAST_WORKER)
+    env = dict(os.environ, WJ_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", str(worker)], env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "rank 0 ok=True" in run.stdout and "rank 1 ok=True" in run.stdout
+
+
 @pytest.mark.parametrize("flavour", ["fw", "ow"])
 def test_encoder_of_the_next_chunk_overlaps_the_decode_of_this_one(hip, flavour):
     """``transcribe_many`` encodes chunk i + 1 on a second stream into the other half of the resident window slots while
