@@ -228,3 +228,54 @@ def test_qwen_adapters_satisfy_the_reference_protocols(ref_modules):
     for mine, ref in ((qwen.TranscriptionResult, ref_types.TranscriptionResult), (qwen.AlignmentResult, ref_types.AlignmentResult),
                       (qwen.WordTimestamp, ref_types.WordTimestamp)):
         assert [f.name for f in dataclasses.fields(mine)] == [f.name for f in dataclasses.fields(ref)]
+
+
+def test_reference_vad_grouped_framer_frames_scenes_through_the_hip_segmenter(ref_modules, monkeypatch):
+    """INTEGRATION.md section f: qwen mode needs no framer of ours -- the reference's ``VadGroupedFramer``
+    (framers/vad_grouped.py:67-76, loaded from source) creates its segmenter through ``SpeechSegmenterFactory``, so
+    registering the HIP segmenter there makes the device VAD frame the scenes.  Run here with the speech-timestamp seam of
+    the segmenter scripted (no GPU): frames, per-frame speech regions, the short-group filter and the step-down ``reframe``
+    (a NEW segmenter with the tighter group limit, then the original one restored) must come out of the reference's code."""
+    import numpy as np
+    from unittest.mock import MagicMock
+    from whisperjav_amd import hipbind, segmenters
+    monkeypatch.setattr(hipbind, "context", lambda device=0: types.SimpleNamespace(handle=None, device=device))
+    factory = importlib.import_module("whisperjav.modules.speech_segmentation.factory")
+    for name, target in segmenters.REGISTRY_ENTRIES.items():
+        factory._BACKEND_REGISTRY[name] = target
+        factory._BACKEND_DEPENDENCIES[name] = {"packages": ["whisperjav_amd"], "install_hint": "build libwjhip.so",
+                                                "always_available": False}
+    factory._PARAM_SCHEMAS["silero-hip"] = factory._PARAM_SCHEMAS["silero-v6.2"]
+    stamps = [{"start": 16000, "end": 40000}, {"start": 48000, "end": 80000},          # 1.0-2.5 s, 3.0-5.0 s: one group
+              {"start": 160000, "end": 160800},                                         # 10.0-10.05 s: its own group, too short
+              {"start": 240000, "end": 400000}, {"start": 408000, "end": 560000}]      # 15-25 s, 25.5-35 s: split by the group limit
+    created = []
+    real_create = factory.SpeechSegmenterFactory.create
+
+    def create(name, *a, **kw):
+        seg = real_create(name, *a, **kw)
+        seg._model = MagicMock()
+        seg._get_speech_timestamps = lambda audio, model, **k: [dict(t) for t in stamps]
+        created.append(seg)
+        return seg
+    monkeypatch.setattr(factory.SpeechSegmenterFactory, "create", staticmethod(create))
+    framers = importlib.import_module("whisperjav.modules.subtitle_pipeline.framers.vad_grouped")
+    protocols = importlib.import_module("whisperjav.modules.subtitle_pipeline.protocols")
+    framer = framers.VadGroupedFramer(segmenter_backend="silero-hip", max_group_duration_s=29.0, chunk_threshold_s=1.0,
+                                      segmenter_config={"speech_pad_ms": 0, "threshold": 0.3})
+    assert isinstance(framer, protocols.TemporalFramer)
+    audio = np.zeros(16000 * 40, dtype=np.float32)
+    res = framer.frame(audio, 16000)
+    assert type(created[0]).__name__ == "HipSileroV6SpeechSegmenter" and created[0].max_group_duration_s == 29.0
+    got = [(round(f.start, 3), round(f.end, 3), f.source) for f in res.frames]
+    assert got == [(1.0, 5.0, "vad-grouped"), (15.0, 35.0, "vad-grouped")], got
+    assert res.metadata["groups_skipped"] == 1 and res.metadata["total_segments"] == 5
+    assert res.metadata["segmenter_backend"].endswith("-hip")
+    assert [[(round(a, 2), round(b, 2)) for a, b in regs] for regs in res.metadata["speech_regions"]] == \
+        [[(1.0, 2.5), (3.0, 5.0)], [(15.0, 25.0), (25.5, 35.0)]]
+    # step-down retry (orchestrator._run_stepdown_pass): tighter groups from a fresh segmenter, the original one kept
+    tight = framer.reframe(audio, 16000, max_group_duration_s=12.0)
+    assert len(created) == 2 and created[1].max_group_duration_s == 12.0
+    assert [(round(f.start, 2), round(f.end, 2)) for f in tight.frames] == [(1.0, 5.0), (15.0, 25.0), (25.5, 35.0)]
+    assert framer._segmenter is created[0] and framer._max_group == 29.0
+    framer.cleanup()
