@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 2
+#define WJ_ABI_VERSION 3
 
 enum {
   WJ_OK = 0,
@@ -275,6 +275,18 @@ int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32
  * sequence that stopped at EOS after n tokens is the EOS token's log-prob). */
 int wj_qwen_generate_greedy(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, int max_new, int32_t* tokens_out, int32_t* n_tokens_out,
                             float* token_logprob_out, void* stream);
+
+/* The same with the two generation controls the reference's pipeline sets (pipelines/qwen_pipeline.py:157-158 ->
+ * modules/qwen_asr.py:382-437):
+ *  - max_new_per_seq_host (may be NULL): a token budget per sequence, clamped to max_new -- the reference scales
+ *    max_new_tokens with each clip's duration (max_tokens_per_audio_second, floor 256);
+ *  - repetition_penalty (1 = off): transformers' RepetitionPenaltyLogitsProcessor -- before every choice the logit of each id
+ *    already in the sequence (PROMPT ids included: seen_ids_host holds them, sequence b's at [seen_offsets_host[b],
+ *    seen_offsets_host[b + 1])) is divided by the penalty when positive and multiplied when negative.  Reported log-probs are
+ *    those of the penalised distribution (transformers' `scores`). */
+int wj_qwen_generate_greedy_ex(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, int max_new, const int32_t* max_new_per_seq_host,
+                               float repetition_penalty, const int32_t* seen_ids_host, const int32_t* seen_offsets_host,
+                               int32_t* tokens_out, int32_t* n_tokens_out, float* token_logprob_out, void* stream);
 
 /* 1 if the last wj_qwen_generate_greedy replayed its decode iteration from a hipGraph */
 int wj_qwen_last_used_graph(const wj_qwen* m);

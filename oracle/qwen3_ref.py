@@ -131,6 +131,29 @@ def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     return w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
 
 
+def repetition_penalised(logits: torch.Tensor, input_ids: Sequence[int], penalty: float) -> torch.Tensor:
+    """transformers ``RepetitionPenaltyLogitsProcessor.__call__`` (generation/logits_process.py) for one row: the logit of every
+    id in ``input_ids`` (the prompt AND what has been generated) is divided by ``penalty`` when positive, multiplied when
+    negative; gather-then-scatter, so an id that occurs twice is still penalised once."""
+    if penalty == 1.0 or not len(input_ids):
+        return logits
+    ids = torch.as_tensor(list(input_ids), dtype=torch.long)
+    score = logits[ids]
+    score = torch.where(score < 0, score * penalty, score / penalty)
+    out = logits.clone()
+    out[ids] = score
+    return out
+
+
+def dynamic_token_limit(audio_duration_sec: float, max_new_tokens: int, max_tokens_per_audio_second: float,
+                        min_tokens_floor: int = 256) -> int:
+    """``QwenASR._compute_dynamic_token_limit`` (modules/qwen_asr.py:414-437): the budget of a clip grows with its duration,
+    never under the floor, never over the static limit; rate or duration <= 0 disables the scaling."""
+    if max_tokens_per_audio_second <= 0 or audio_duration_sec <= 0:
+        return max_new_tokens
+    return min(max(min_tokens_floor, int(audio_duration_sec * max_tokens_per_audio_second)), max_new_tokens)
+
+
 class Qwen3AsrOracle:
     def __init__(self, dims: Qwen3AsrDims, weights: Dict[str, np.ndarray]):
         self.dims = dims
@@ -245,20 +268,25 @@ class Qwen3AsrOracle:
         y = x @ head_w.T
         return y if head_b is None else y + head_b
 
-    def greedy(self, prompt: Sequence[int], audio: Optional[torch.Tensor], max_new: int) -> Tuple[List[int], List[float]]:
-        """Greedy generation until an EOS id (not returned) or ``max_new`` tokens; per-token log-probs."""
+    def greedy(self, prompt: Sequence[int], audio: Optional[torch.Tensor], max_new: int,
+               repetition_penalty: float = 1.0) -> Tuple[List[int], List[float]]:
+        """Greedy generation until an EOS id (not returned) or ``max_new`` tokens; per-token log-probs (of the penalised
+        distribution when ``repetition_penalty`` != 1, as transformers' ``scores``).  The reference's pipeline generates with
+        ``repetition_penalty=1.1`` and a per-clip ``max_new`` (pipelines/qwen_pipeline.py:157-158, modules/qwen_asr.py:382-437)."""
         cache: list = [None] * self.dims.layers
         x = self.embed(prompt, audio)
         lg = self.logits(x, 0, cache)[-1]
         out, lps = [], []
+        seen = [int(t) for t in prompt]
         pos = len(prompt)
         for _ in range(max_new):
+            lg = repetition_penalised(lg, seen, repetition_penalty)
             lp = torch.log_softmax(lg, -1)
             t = int(lp.argmax())
             if t in self.dims.eos_token_ids:
                 lps.append(float(lp[t]))
                 break
-            out.append(t); lps.append(float(lp[t]))
+            out.append(t); lps.append(float(lp[t])); seen.append(t)
             lg = self.logits(self.w["model.language_model.embed_tokens.weight"][t][None], pos, cache)[-1]
             pos += 1
         return out, lps

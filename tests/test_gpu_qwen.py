@@ -137,25 +137,31 @@ def test_text_generator_end_to_end_on_the_device(hip, tmp_path):
     oracle = qwen3_ref.Qwen3AsrOracle(od, w)
     build = lambda n_audio, language, context: [11, 12] + [d.audio_token_id] * n_audio + [13, 14]      # noqa: E731
     gen = qwen.HipQwenTextGenerator(d, w, audio_dims=ad, prompt_builder=build, detokenize=lambda t: " ".join(map(str, t)),
-                                    dtype="float32", batch_size=2, max_ctx=256, max_new_tokens=12)
+                                    dtype="float32", batch_size=2, max_ctx=256, max_new_tokens=12, max_tokens_per_audio_second=3.0,
+                                    min_tokens_floor=2)
+    assert gen.repetition_penalty == 1.1          # the reference generator's default (generators/qwen3.py:39)
+    seconds = (1.7, 3.2, 0.9)
+    budgets = [qwen.dynamic_token_limit(s, 12, 3.0, 2) for s in seconds]
+    assert budgets == [5, 9, 2]
     paths = []
-    for i, s in enumerate((1.7, 3.2, 0.9)):
+    for i, s in enumerate(seconds):
         audio = synth.speech_like(s, seed=80 + i)
         pcm = np.clip(np.rint(audio * 32767), -32768, 32767).astype("<i2")
         path = tmp_path / f"scene_{i}.wav"
         with wave.open(str(path), "wb") as wf:
             wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000); wf.writeframes(pcm.tobytes())
         paths.append(path)
-    results = gen.generate_batch(paths, language="ja")
+    results = gen.generate_batch(paths, language="ja", audio_durations=list(seconds))     # what the orchestrator passes (step 3)
     assert len(results) == 3 and all(r.language == "ja" for r in results)
-    for path, res in zip(paths, results):
+    for path, res, budget in zip(paths, results, budgets):
         with wave.open(str(path), "rb") as wf:
             audio = np.frombuffer(wf.readframes(wf.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
         padded = np.pad(audio, (0, max(0, 8000 - len(audio))))
         with torch.no_grad():
             a = oracle.audio_tokens(torch.from_numpy(logmel.logmel_ow(padded, 128, padding=0)))
-            toks, _ = oracle.greedy(build(a.shape[0], "ja", None), a, 12)
+            toks, _ = oracle.greedy(build(a.shape[0], "ja", None), a, budget, repetition_penalty=1.1)
         assert res.text == " ".join(map(str, toks)), (path.name, res.text, toks)
+        assert res.metadata["n_tokens"] <= budget
     gen.cleanup()
 
 
@@ -312,3 +318,33 @@ def test_audio_tower_slices_a_batch_that_exceeds_its_workspace(hip):
     for x, y in zip(a, b):
         assert float((x - y).abs().max()) < 1e-5 * max(1.0, float(x.abs().max()))
     whole.close(); sliced.close()
+
+
+def test_generation_controls_match_oracle(hip):
+    """The two generation controls the reference's pipeline sets (pipelines/qwen_pipeline.py:157-158): transformers' repetition
+    penalty over prompt + generated ids (the oracle's restatement is pinned against ``RepetitionPenaltyLogitsProcessor`` and
+    against ``generate(repetition_penalty=...)``) and a token budget per sequence.  float32: tokens identical, the log-probs
+    are those of the penalised distribution."""
+    d, w, oracle, model = _setup("float32", seed=10)
+    rng = np.random.default_rng(8)
+    prompts = _prompts(d, rng)
+    budgets = [24, 3, 24, 7]
+    packed, n = model.prompt_embeddings_many([p[0] for p in prompts], [p[1] for p in prompts])
+    model.prefill_packed(packed, n)
+    plain = model.generate(max_new_tokens=24)
+    model.prefill_packed(packed, n)
+    res = model.generate(max_new_tokens=24, repetition_penalty=1.6, prompt_ids=[p[0] for p in prompts], max_new_per_seq=budgets)
+    assert model._lib.wj_qwen_last_used_graph(model.handle) == 1
+    changed = 0
+    with torch.no_grad():
+        for b, (ids, audio) in enumerate(prompts):
+            toks, lps = oracle.greedy(ids, audio, budgets[b], repetition_penalty=1.6)
+            assert res.tokens[b] == toks, (b, res.tokens[b], toks)
+            assert len(res.tokens[b]) <= budgets[b]
+            assert len(res.token_logprob[b]) == len(lps)
+            assert np.abs(np.array(res.token_logprob[b]) - np.array(lps)).max() < 1e-3
+            changed += res.tokens[b] != plain.tokens[b][: len(res.tokens[b])]
+    assert changed >= 1                      # the penalty changed at least one continuation on this seed
+    with pytest.raises(ValueError, match="prompt_ids"):
+        model.generate(max_new_tokens=4, repetition_penalty=1.2)
+    model.close()

@@ -88,6 +88,36 @@ def test_decoder_logits_cache_and_greedy_match_transformers():
     ref_new = gen[0, len(prompt):].tolist()
     ref_new = ref_new[: next((i for i, t in enumerate(ref_new) if t in DIMS.eos_token_ids), len(ref_new))]
     assert toks == ref_new and len(lps) >= len(toks)
+    # the reference's pipeline default: repetition_penalty 1.1 (here stronger, so that it changes the tokens), prompt ids included
+    with torch.no_grad():
+        gen_p = model.generate(input_ids=ids, input_features=feats, input_features_mask=mask, max_new_tokens=12, do_sample=False,
+                               repetition_penalty=1.6)
+        toks_p, _ = oracle.greedy(prompt, audio, 12, repetition_penalty=1.6)
+    ref_p = gen_p[0, len(prompt):].tolist()
+    ref_p = ref_p[: next((i for i, t in enumerate(ref_p) if t in DIMS.eos_token_ids), len(ref_p))]
+    assert toks_p == ref_p
+    assert toks_p != toks            # the penalty took effect on this seed
+
+
+def test_repetition_penalty_matches_transformers_processor():
+    from transformers import RepetitionPenaltyLogitsProcessor
+    g = torch.Generator().manual_seed(9)
+    for penalty in (1.1, 1.5, 0.8):
+        logits = torch.randn(50, generator=g) * 3
+        ids = torch.randint(0, 50, (17,), generator=g)          # with repeats
+        ref = RepetitionPenaltyLogitsProcessor(penalty)(ids[None], logits[None].clone())[0]
+        got = qwen3_ref.repetition_penalised(logits, ids.tolist(), penalty)
+        assert torch.equal(got, ref)
+    assert qwen3_ref.repetition_penalised(logits, [], 1.3) is logits
+
+
+def test_dynamic_token_limit_follows_the_reference_formula():
+    f = qwen3_ref.dynamic_token_limit
+    assert f(10.0, 4096, 20.0) == 256            # floor
+    assert f(30.0, 4096, 20.0) == 600
+    assert f(1000.0, 4096, 20.0) == 4096         # static ceiling
+    assert f(30.0, 4096, 0.0) == 4096 and f(0.0, 4096, 20.0) == 4096     # disabled
+    assert f(30.0, 100, 20.0) == 100             # the floor never lifts the budget over the static limit
 
 
 def test_feature_extractor_is_whispers_formula_without_padding():

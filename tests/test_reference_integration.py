@@ -279,3 +279,31 @@ def test_reference_vad_grouped_framer_frames_scenes_through_the_hip_segmenter(re
     assert [(round(f.start, 2), round(f.end, 2)) for f in tight.frames] == [(1.0, 5.0), (15.0, 25.0), (25.5, 35.0)]
     assert framer._segmenter is created[0] and framer._max_group == 29.0
     framer.cleanup()
+
+
+def test_dynamic_token_budget_equals_the_reference_method(ref_modules, monkeypatch):
+    """``QwenASR._compute_dynamic_token_limit`` (modules/qwen_asr.py:414-437) run from source on an instance built without
+    its constructor, against the product helper and the oracle's restatement, over a grid of durations / rates / limits."""
+    import itertools
+    from oracle import qwen3_ref
+    from whisperjav_amd import qwen
+    sw = types.ModuleType("stable_whisper")
+    sw.WhisperResult = object                 # only named in annotations of the module
+    monkeypatch.setitem(sys.modules, "stable_whisper", sw)
+    jp = types.ModuleType("whisperjav.modules.japanese_postprocessor")
+    jp.JapanesePostProcessor = object
+    monkeypatch.setitem(sys.modules, "whisperjav.modules.japanese_postprocessor", jp)
+    ref = importlib.import_module("whisperjav.modules.qwen_asr")
+    asr = ref.QwenASR.__new__(ref.QwenASR)
+    for rate, floor, max_new, dur in itertools.product((0.0, 5.0, 20.0, 33.3), (0, 64, 256), (100, 512, 4096),
+                                                       (0.0, 0.4, 2.49, 12.8, 29.99, 31.0, 250.0)):
+        asr.max_tokens_per_audio_second, asr.min_tokens_floor, asr.max_new_tokens = rate, floor, max_new
+        want = asr._compute_dynamic_token_limit(dur)
+        assert qwen.dynamic_token_limit(dur, max_new, rate, floor) == want == qwen3_ref.dynamic_token_limit(dur, max_new, rate, floor)
+    # the defaults the HIP generator carries are the reference generator's (generators/qwen3.py:32-42)
+    gen = importlib.import_module("whisperjav.modules.subtitle_pipeline.generators.qwen3")
+    import inspect
+    sig = inspect.signature(gen.Qwen3TextGenerator.__init__).parameters
+    mine = inspect.signature(qwen.HipQwenTextGenerator.__init__).parameters
+    for name in ("repetition_penalty", "max_tokens_per_audio_second"):
+        assert mine[name].default == sig[name].default

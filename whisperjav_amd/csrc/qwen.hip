@@ -207,12 +207,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   for (int c = threadIdx.x; c < D; c += 256) out[(int64_t)m * D + c] = x[(int64_t)rows[m] * D + c];
 }
 
-// After the logits of a decode step: record the arg-max token and its log-prob, stop a sequence at an EOS id, advance
-// its position.  `next_tok` feeds the embedding lookup of the following step.
+// After the logits of a decode step: record the arg-max token and its log-prob, stop a sequence at an EOS id or at ITS
+// token budget lim[b] (the reference scales max_new_tokens with the clip's duration, qwen_asr.py:414-437), advance its
+// position.  `next_tok` feeds the embedding lookup of the following step.  With a repetition penalty the accepted token
+// joins the sequence's set of seen ids (kept duplicate-free, so the penalty kernel touches every logit once).
 __global__ void advance_kernel(const int32_t* __restrict__ top_id, const float* __restrict__ top_lp, const int32_t* __restrict__ eos,
                                int n_eos, int32_t* __restrict__ finished, int32_t* __restrict__ n_out, int32_t* __restrict__ row_pos,
                                int32_t* __restrict__ next_tok, int32_t* __restrict__ tokens_out, float* __restrict__ lp_out,
-                               int max_new, int n_seqs, int ctx, int first) {
+                               int max_new, int n_seqs, int ctx, int first, const int32_t* __restrict__ lim,
+                               int32_t* __restrict__ seen, int32_t* __restrict__ seen_n, int seen_cap) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= n_seqs) return;
   if (!first) row_pos[b] = min(row_pos[b] + 1, ctx - 1);       // the token fed this step now occupies its position
@@ -222,10 +225,33 @@ __global__ void advance_kernel(const int32_t* __restrict__ top_id, const float* 
   lp_out[(int64_t)b * (max_new + 1) + n] = top_lp[b];
   bool stop = false;
   for (int e = 0; e < n_eos; ++e) stop |= t == eos[e];
-  if (stop || n >= max_new) { finished[b] = 1; return; }
+  if (stop || n >= lim[b]) { finished[b] = 1; return; }
   tokens_out[(int64_t)b * max_new + n] = t;
   n_out[b] = n + 1;
   next_tok[b] = t;
+  if (seen) {
+    int32_t* mine = seen + (int64_t)b * seen_cap;
+    const int cnt = seen_n[b];
+    bool known = false;
+    for (int i = 0; i < cnt; ++i) known |= mine[i] == t;
+    if (!known && cnt < seen_cap) { mine[cnt] = t; seen_n[b] = cnt + 1; }
+  }
+}
+
+// transformers' RepetitionPenaltyLogitsProcessor on the rows of a decode step: every id of the sequence so far (prompt
+// and generated; here a duplicate-free list) has its logit divided by the penalty when positive, multiplied when negative.
+__global__ __launch_bounds__(256) void rep_penalty_kernel(float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ seen,
+                                                          const int32_t* __restrict__ seen_n, int seen_cap, float penalty,
+                                                          const int32_t* __restrict__ finished) {
+  const int b = blockIdx.x;
+  if (finished[b]) return;
+  const int n = seen_n[b];
+  float* row = logits + (int64_t)b * ldl;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int t = seen[(int64_t)b * seen_cap + i];
+    const float l = row[t];
+    row[t] = l < 0.f ? l * penalty : l / penalty;
+  }
 }
 
 }  // namespace
@@ -255,6 +281,9 @@ struct wj_qwen {
   int32_t *row_seq = nullptr, *row_pos = nullptr, *last_rows = nullptr, *next_tok = nullptr, *finished = nullptr, *n_out = nullptr;
   int32_t *top_id = nullptr, *tokens_out = nullptr, *eos = nullptr;
   float *top_lp = nullptr, *top_lse = nullptr, *lp_out = nullptr;
+  int32_t *lim = nullptr, *seen = nullptr, *seen_n = nullptr;   // per-sequence token budget; ids the repetition penalty applies to
+  int seen_cap = 0;
+  float cur_penalty = 1.f;   // != 1 only while wj_qwen_generate_greedy_ex runs its iterations (run_head applies it)
   int n_seqs = 0;            // sequences of the last prefill
   int last_used_graph = 0;   // the last generation replayed its iteration from a hipGraph
   const void* W(int i) const { return blob + off[i]; }
@@ -376,6 +405,10 @@ int run_head(wj_qwen* m, const float* xin, int n, hipStream_t s) {
   // reads the first d.vocab columns only)
   g.A = m->h; g.lda = D; g.W = m->W(WJ_Q_EMBED); g.ldw = D; g.M = n; g.N = n >= 1024 ? m->vocab_pad : d.vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
   WJ_TRYQ(launch_gemm(dt, EPI_F32, g, s, 0));
+  if (m->cur_penalty != 1.f) {
+    hipLaunchKernelGGL(rep_penalty_kernel, dim3(n), dim3(256), 0, s, m->logits, m->ldl, m->seen, m->seen_n, m->seen_cap, m->cur_penalty, m->finished);
+    WJ_LAUNCH_CHECK();
+  }
   return launch_topk_logprob(m->logits, m->ldl, n, d.vocab, 1, nullptr, m->top_id, m->top_lp, m->top_lse, s);
 }
 
@@ -437,6 +470,8 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   QA(xl, S * D * sizeof(float)); QA(logits, S * m->ldl * sizeof(float));
   QA(row_seq, R * 4); QA(row_pos, R * 4); QA(last_rows, S * 4); QA(next_tok, S * 4); QA(finished, S * 4); QA(n_out, S * 4);
   QA(top_id, S * 4); QA(top_lp, S * 4); QA(top_lse, S * 4); QA(eos, 64);
+  m->seen_cap = 2 * max_ctx;      // unique prompt ids (< max_ctx) + generated ids (positions stop at max_ctx)
+  QA(lim, S * 4); QA(seen_n, S * 4); QA(seen, S * (size_t)m->seen_cap * 4);
 #undef QA
   if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error("wj_qwen_create: allocation failed"); rc = WJ_E_HIP; }
   if (rc) { wj_qwen_free(m); return rc; }
@@ -558,9 +593,19 @@ int wj_qwen_classify(wj_qwen* m, const float* embeds_dev, int n_seqs, const int3
 
 int wj_qwen_generate_greedy(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, int max_new, int32_t* tokens_out, int32_t* n_tokens_out,
                             float* token_logprob_out, void* stream) {
+  return wj_qwen_generate_greedy_ex(m, eos_ids_host, n_eos, max_new, nullptr, 1.0f, nullptr, nullptr, tokens_out, n_tokens_out, token_logprob_out, stream);
+}
+
+int wj_qwen_generate_greedy_ex(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, int max_new, const int32_t* max_new_per_seq_host,
+                               float repetition_penalty, const int32_t* seen_ids_host, const int32_t* seen_offsets_host,
+                               int32_t* tokens_out, int32_t* n_tokens_out, float* token_logprob_out, void* stream) {
   WJ_REQUIRE(m && eos_ids_host && tokens_out && n_tokens_out, "wj_qwen_generate_greedy: NULL argument");
   WJ_REQUIRE(m->n_seqs >= 1, "wj_qwen_generate_greedy: call wj_qwen_prefill first");
   WJ_REQUIRE(n_eos >= 1 && n_eos <= 16 && max_new >= 1, "wj_qwen_generate_greedy: 1..16 EOS ids and max_new >= 1");
+  WJ_REQUIRE(repetition_penalty > 0.f, "wj_qwen_generate_greedy_ex: repetition_penalty must be positive (1 = off)");
+  const bool penalise = repetition_penalty != 1.0f;
+  WJ_REQUIRE(!penalise || (seen_ids_host && seen_offsets_host), "wj_qwen_generate_greedy_ex: a repetition penalty needs the prompts' token ids "
+             "(transformers penalises every id of input_ids, prompt included)");
   const int S = m->n_seqs;
   WJ_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->pick(stream);
@@ -574,10 +619,39 @@ int wj_qwen_generate_greedy(wj_qwen* m, const int32_t* eos_ids_host, int n_eos, 
   WJ_HIP(hipMemsetAsync(m->finished, 0, sizeof(int32_t) * S, s));
   WJ_HIP(hipMemsetAsync(m->n_out, 0, sizeof(int32_t) * S, s));
   WJ_HIP(hipMemcpyAsync(m->eos, eos_ids_host, sizeof(int32_t) * n_eos, hipMemcpyHostToDevice, s));
-  std::vector<int32_t> fin(S);
+  std::vector<int32_t> fin(S), lim_h(S, max_new);
+  if (max_new_per_seq_host)
+    for (int b = 0; b < S; ++b) {
+      WJ_REQUIRE(max_new_per_seq_host[b] >= 0, "wj_qwen_generate_greedy_ex: negative token budget for sequence %d", b);
+      lim_h[b] = std::min(max_new_per_seq_host[b], max_new);
+    }
+  WJ_HIP(hipMemcpyAsync(m->lim, lim_h.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, s));
+  std::vector<int32_t> seen_h, seen_cnt(S, 0);
+  if (penalise) {
+    seen_h.assign((size_t)S * m->seen_cap, 0);
+    for (int b = 0; b < S; ++b) {
+      WJ_REQUIRE(seen_offsets_host[b + 1] >= seen_offsets_host[b], "wj_qwen_generate_greedy_ex: seen_offsets must not decrease");
+      std::vector<int32_t> u(seen_ids_host + seen_offsets_host[b], seen_ids_host + seen_offsets_host[b + 1]);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+      WJ_REQUIRE(u.empty() || (u.front() >= 0 && u.back() < m->d.vocab), "wj_qwen_generate_greedy_ex: token id out of range in sequence %d", b);
+      WJ_REQUIRE((int)u.size() <= m->max_ctx, "wj_qwen_generate_greedy_ex: %d distinct prompt ids for sequence %d (context %d)", (int)u.size(), b, m->max_ctx);
+      std::copy(u.begin(), u.end(), seen_h.begin() + (size_t)b * m->seen_cap);
+      seen_cnt[b] = (int32_t)u.size();
+    }
+    WJ_HIP(hipMemcpyAsync(m->seen, seen_h.data(), sizeof(int32_t) * seen_h.size(), hipMemcpyHostToDevice, s));
+    WJ_HIP(hipMemcpyAsync(m->seen_n, seen_cnt.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, s));
+    // the prefill left UNPENALISED logits of the last prompt positions in m->logits: penalise them, choose again
+    hipLaunchKernelGGL(rep_penalty_kernel, dim3(S), dim3(256), 0, s, m->logits, m->ldl, m->seen, m->seen_n, m->seen_cap, repetition_penalty, m->finished);
+    WJ_LAUNCH_CHECK();
+    WJ_TRYQ(launch_topk_logprob(m->logits, m->ldl, S, m->d.vocab, 1, nullptr, m->top_id, m->top_lp, m->top_lse, s));
+  }
+  struct PenaltyScope { wj_qwen* m; ~PenaltyScope() { m->cur_penalty = 1.f; } } penalty_scope{m};
+  m->cur_penalty = repetition_penalty;
   auto advance = [&](int first) -> int {
     hipLaunchKernelGGL(advance_kernel, dim3(ceil_div(S, 64)), dim3(64), 0, s, m->top_id, m->top_lp, m->eos, n_eos, m->finished, m->n_out,
-                       m->row_pos, m->next_tok, d_tok, d_lp, max_new, S, m->max_ctx, first);
+                       m->row_pos, m->next_tok, d_tok, d_lp, max_new, S, m->max_ctx, first, m->lim, penalise ? m->seen : nullptr, m->seen_n,
+                       m->seen_cap);
     WJ_LAUNCH_CHECK();
     return WJ_OK;
   };

@@ -12,7 +12,7 @@ import os
 from pathlib import Path
 from typing import Optional
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwjhip.so"
 _lib: Optional[C.CDLL] = None
 
@@ -80,6 +80,8 @@ _SIGNATURES = {
     "wj_qwen_embed": (_I, [_P, C.POINTER(C.c_int32), _I, _P, _P]),
     "wj_qwen_prefill": (_I, [_P, _P, _I, C.POINTER(C.c_int32), _P, _P]),
     "wj_qwen_generate_greedy": (_I, [_P, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),
+    "wj_qwen_generate_greedy_ex": (_I, [_P, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32), _F, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),
     "wj_qwen_last_used_graph": (_I, [_P]),
     "wj_qwen_classify": (_I, [_P, _P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _P, _P, _I, C.POINTER(C.c_int32), _P, _P]),
     "wj_qwen_audio_create": (_I, [_P, _P, _I, _P, C.c_size_t, C.POINTER(C.c_int64), _I, _I, C.POINTER(_P)]),

@@ -431,21 +431,51 @@ class HipQwen3Decoder:
         per_seq = [out[edges[b]: edges[b + 1]].copy() for b in range(len(embeds))]
         return (per_seq, logits) if want_logits else per_seq
 
-    def generate(self, max_new_tokens: int = 256, eos_token_ids: Optional[Sequence[int]] = None) -> GenerateResult:
+    def generate(self, max_new_tokens: int = 256, eos_token_ids: Optional[Sequence[int]] = None, *, repetition_penalty: float = 1.0,
+                 prompt_ids: Optional[Sequence[Sequence[int]]] = None, max_new_per_seq: Optional[Sequence[int]] = None) -> GenerateResult:
+        """Greedy continuation of the prefilled sequences (``wj_qwen_generate_greedy_ex``).  ``repetition_penalty`` != 1 is
+        transformers' ``RepetitionPenaltyLogitsProcessor`` and needs ``prompt_ids`` (the token ids of every prompt, audio
+        placeholders included: the processor penalises every id of ``input_ids``); ``max_new_per_seq`` gives each sequence its
+        own budget (clamped to ``max_new_tokens``)."""
         eos = np.ascontiguousarray(eos_token_ids if eos_token_ids is not None else self.dims.eos_token_ids, dtype=np.int32)
         S, n = self._n_seqs, int(max_new_tokens)
         toks = np.zeros((S, n), dtype=np.int32)
         cnt = np.zeros(S, dtype=np.int32)
         lps = np.zeros((S, n + 1), dtype=np.float32)
-        check(self._lib.wj_qwen_generate_greedy(self.handle, eos.ctypes.data_as(C.POINTER(C.c_int32)), len(eos), n,
-                                                toks.ctypes.data_as(C.POINTER(C.c_int32)), cnt.ctypes.data_as(C.POINTER(C.c_int32)),
-                                                lps.ctypes.data_as(C.POINTER(C.c_float)), None), "wj_qwen_generate_greedy")
+        lim = np.full(S, n, dtype=np.int32)
+        if max_new_per_seq is not None:
+            lim = np.minimum(np.ascontiguousarray(max_new_per_seq, dtype=np.int32).reshape(-1), n).astype(np.int32)
+            if lim.shape != (S,):
+                raise ValueError(f"max_new_per_seq: {S} budgets expected")
+        seen = offs = None
+        if float(repetition_penalty) != 1.0:
+            if prompt_ids is None or len(prompt_ids) != S:
+                raise ValueError("a repetition penalty needs prompt_ids, one id list per prefilled sequence")
+            ids = [np.asarray(p, dtype=np.int32).reshape(-1) for p in prompt_ids]
+            seen = np.ascontiguousarray(np.concatenate(ids) if ids else np.zeros(0, np.int32))
+            offs = np.concatenate([[0], np.cumsum([len(p) for p in ids])]).astype(np.int32)
+        i32 = C.POINTER(C.c_int32)
+        check(self._lib.wj_qwen_generate_greedy_ex(self.handle, eos.ctypes.data_as(i32), len(eos), n, lim.ctypes.data_as(i32),
+                                                   C.c_float(float(repetition_penalty)),
+                                                   seen.ctypes.data_as(i32) if seen is not None else None,
+                                                   offs.ctypes.data_as(i32) if offs is not None else None,
+                                                   toks.ctypes.data_as(i32), cnt.ctypes.data_as(i32),
+                                                   lps.ctypes.data_as(C.POINTER(C.c_float)), None), "wj_qwen_generate_greedy_ex")
         out_t, out_l = [], []
         for b in range(S):
             k = int(cnt[b])
             out_t.append(toks[b, :k].tolist())
-            out_l.append(lps[b, : k + 1 if k < n else k].tolist())
+            out_l.append(lps[b, : k + 1 if k < int(lim[b]) else k].tolist())      # + the EOS token's when the sequence ended on one
         return GenerateResult(out_t, out_l)
+
+
+def dynamic_token_limit(audio_duration_sec: float, max_new_tokens: int, max_tokens_per_audio_second: float,
+                        min_tokens_floor: int = 256) -> int:
+    """The reference's per-clip token budget (``QwenASR._compute_dynamic_token_limit``, modules/qwen_asr.py:414-437):
+    ``clamp(int(duration * rate), floor, max_new_tokens)``; a rate or duration <= 0 leaves the static limit."""
+    if max_tokens_per_audio_second <= 0 or audio_duration_sec <= 0:
+        return int(max_new_tokens)
+    return min(max(int(min_tokens_floor), int(audio_duration_sec * max_tokens_per_audio_second)), int(max_new_tokens))
 
 
 @dataclass
@@ -464,10 +494,15 @@ class HipQwenTextGenerator:
     def __init__(self, dims: Qwen3Dims, weights: Dict[str, np.ndarray], *, audio_dims: Optional[Qwen3AudioDims] = None,
                  audio_embedder: Optional[Callable] = None, prompt_builder: Optional[Callable] = None,
                  detokenize: Optional[Callable] = None, dtype: str = "float16", device: int = 0, batch_size: int = 8,
-                 max_ctx: int = 1024, max_new_tokens: int = 256):
+                 max_ctx: int = 1024, max_new_tokens: int = 256, repetition_penalty: float = 1.1,
+                 max_tokens_per_audio_second: float = 20.0, min_tokens_floor: int = 256):
         """``weights``: one state dict under the published names (decoder; audio tower + projector when ``audio_dims`` is
         given, in which case the device tower is the embedder).  ``audio_embedder`` overrides it with any callable
-        ``(clips) -> [embeddings per clip]``."""
+        ``(clips) -> [embeddings per clip]``.  ``repetition_penalty`` / ``max_tokens_per_audio_second``: the generation controls
+        of the reference's generator with ITS defaults (generators/qwen3.py:39-41: 1.1 and 20.0; the budget applies when the
+        caller passes ``audio_durations``, as the orchestrator does)."""
+        self.repetition_penalty, self.max_tokens_per_audio_second = float(repetition_penalty), float(max_tokens_per_audio_second)
+        self.min_tokens_floor = int(min_tokens_floor)
         self.dims, self._weights, self.dtype, self.device = dims, weights, dtype, device
         self.audio_dims, self._tower = audio_dims, None
         self.audio_embedder, self.prompt_builder, self.detokenize = audio_embedder, prompt_builder, detokenize
@@ -519,7 +554,13 @@ class HipQwenTextGenerator:
             ids = [self.prompt_builder(int(a.shape[0]), language, ctx_text)
                    for a, ctx_text in zip(audio_embeds, contexts[lo: lo + self.batch_size])]
             self._model.prefill_packed(*self._model.prompt_embeddings_many(ids, audio_embeds))     # one embedding launch, one scatter
-            res = self._model.generate(int(kwargs.get("max_new_tokens", self.max_new_tokens)))
+            max_new = int(kwargs.get("max_new_tokens", self.max_new_tokens))
+            durations = kwargs.get("audio_durations")
+            budgets = None
+            if durations is not None:          # the reference scales each scene's budget with its duration (qwen_asr.py:1277-1279)
+                budgets = [dynamic_token_limit(float(d or 0), max_new, self.max_tokens_per_audio_second, self.min_tokens_floor)
+                           for d in list(durations)[lo: lo + self.batch_size]]
+            res = self._model.generate(max_new, repetition_penalty=self.repetition_penalty, prompt_ids=ids, max_new_per_seq=budgets)
             for toks in res.tokens:
                 out.append(TranscriptionResult(text=self.detokenize(toks), language=language, metadata={"n_tokens": len(toks)}))
         return out
