@@ -681,6 +681,37 @@ def run_cfg2(args, info, dims):
 # ---------------------------------------------------------------------------------------------------------------
 # cfg5, first slice: Qwen3-ASR audio tower + decoder on the device (greedy), synthetic weights of the published geometry
 # ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline_cfg5(d, ad, w, clips, n_new, threads):
+    """A bounded sample of the step's clips on this host's cores, one clip at a time as the reference's generator does
+    (modules/qwen_asr.py:1270-1290): log-mel, audio tower, prompt, prefill and `n_new` greedy tokens through the fp32 oracle."""
+    from oracle import logmel, qwen3_ref
+    torch.set_num_threads(threads)
+    od = qwen3_ref.Qwen3AsrDims(n_mels=ad.n_mels, a_layers=ad.n_layer, a_heads=ad.n_head, a_ffn=ad.ffn, a_d=ad.d_model, n_window=ad.n_window,
+                                n_window_infer=ad.n_window_infer, conv_hidden=ad.conv_hidden, d=d.hidden, layers=d.n_layer, heads=d.n_head,
+                                kv_heads=d.n_kv_head, head_dim=d.head_dim, ffn=d.ffn, vocab=d.vocab, rope_theta=d.rope_theta, rms_eps=d.rms_eps,
+                                audio_token_id=d.audio_token_id, eos_token_ids=(d.vocab - 1,))
+    oracle = qwen3_ref.Qwen3AsrOracle(od, w)
+    t_tower = t_dec = 0.0
+    n_tok = []
+    with torch.no_grad():
+        for c in clips:
+            t0 = time.perf_counter()
+            padded = np.pad(c, (0, max(0, 8000 - len(c))))
+            a = oracle.audio_tokens(torch.from_numpy(logmel.logmel_ow(padded, ad.n_mels, padding=0)))
+            t1 = time.perf_counter()
+            toks, _ = oracle.greedy([151644 % d.vocab, 872 % d.vocab] + [d.audio_token_id] * int(a.shape[0]) +
+                                    [151645 % d.vocab, 198, 151644 % d.vocab, 77091 % d.vocab], a, n_new)
+            t_tower += t1 - t0; t_dec += time.perf_counter() - t1
+            n_tok.append(len(toks))
+    audio = sum(len(c) for c in clips) / 16000.0
+    total = t_tower + t_dec
+    return {"value": audio / total, "unit": UNIT, "cores": threads, "kind": "port", "sample_clips": len(clips), "sample_audio_s": round(audio, 2),
+            "sample_seconds": round(total, 2), "t_mel_and_tower_s": round(t_tower, 2), "t_prefill_and_decode_s": round(t_dec, 2), "tokens": n_tok,
+            "arithmetic": "fp32 (PyTorch-CPU)",
+            "sample": (f"{len(clips)} of the step's clips ({audio:.1f} s of audio), one at a time: log-mel + audio tower + prefill + "
+                       f"{n_new} greedy tokens through oracle/qwen3_ref.py on {threads} threads")}
+
+
 def cfg5_roofline(dec_params, esz, clips, n_new, stages):
     """The greedy decode iteration: every decoder weight is read once per iteration and multiplied by `clips` rows, i.e.
     `clips` FLOP per weight byte pair -- under the 310 FLOP/B ridge of the part the iteration is bound by the weight stream
@@ -709,12 +740,14 @@ def run_cfg5(args, info):
     B, n_new = args.qwen_batch, args.qwen_tokens
     tower = qwen.HipQwenAudioTower(ad, w, dtype=args.dtype, device=info.local_rank, max_seconds=min(8 * B, 1024))
     model = qwen.HipQwen3Decoder(d, w, dtype=args.dtype, device=info.local_rank, max_seqs=B, max_ctx=192, max_rows=B * 128)
-    del w
+    if args.no_cpu_baseline or info.rank != 0:
+        w = None
     log(f"[bench] cfg5: weights + engines ready after {time.perf_counter() - t0:.1f}s")
     rng = np.random.default_rng(5)
     secs = rng.uniform(2.0, 6.0, B)
     clips = [synth.speech_like(float(sv), seed=500 + i) for i, sv in enumerate(secs)]
     audio_s = float(sum(len(c) for c in clips)) / 16000.0
+    host_sample = [c.copy() for c in clips[:3]]
     clips = [torch.from_numpy(c).to(dev) for c in clips]      # inputs resident in HBM before the timed region (views of an uploaded recording)
 
     def prompt_ids(a):      # <|im_start|>user\n <audio> x n <|im_end|>\n<|im_start|>assistant\n, as the reference's chat template lays it out
@@ -750,6 +783,14 @@ def run_cfg5(args, info):
         stages["audio_tower_ms"] = round(stages["audio_tower_ms"] - stages["log_mel_ms"], 2)      # encode() recomputes the features
         stages["prompt_rows"] = int(n_tok.sum())
         del mel, frames
+    cpu = None
+    if info.rank == 0 and w is not None:
+        try:
+            threads = args.cpu_threads or min(32, os.cpu_count() or 1)
+            cpu = cpu_baseline_cfg5(d, ad, w, host_sample, n_new, threads)
+        except Exception as e:      # a reported figure, never a reason to lose the measured line
+            log(f"[bench] cfg5 cpu_baseline skipped: {type(e).__name__}: {e}")
+        w = None
     if info.rank == 0:
         esz = 4 if args.dtype == "float32" else 2
         dec_params = d.n_layer * (d.hidden * (d.n_head + 2 * d.n_kv_head) * d.head_dim + d.n_head * d.head_dim * d.hidden + 3 * d.hidden * d.ffn) + d.vocab * d.hidden
@@ -765,7 +806,7 @@ def run_cfg5(args, info):
                        "tokens_generated": int(sum(len(t) for t in res.tokens)),
                        "decoder_weight_bytes_per_step": dec_params * esz, "stages": stages},
             "roofline": cfg5_roofline(dec_params, esz, B, n_new, stages),
-            "cpu_baseline": None}), flush=True)
+            "cpu_baseline": cpu}), flush=True)
     tower.close(); model.close()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
