@@ -145,3 +145,62 @@ def test_timestamp_rules_match_transformers_logits_processor():
             assert torch.equal(got[keep], ref[keep])
             checked += 1
     assert checked == 48
+
+
+def test_greedy_loop_to_eot_matches_a_transformers_driven_loop():
+    """Loop-level pin of ``oracle.decoding.greedy_decode`` on EOT-bearing weights (``weights.SPEECHLIKE``: hypotheses END, at
+    lengths that grow with the audio in the window): transformers' model computes the logits of the whole history at every
+    step (no cache of ours), transformers' own processors (SuppressTokens, SuppressTokensAtBegin, WhisperTimeStamp) filter
+    them, arg-max until ``eos``.  Tokens, stop position and the summed log-prob must equal the oracle's cached loop."""
+    from types import SimpleNamespace
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+    from transformers.generation.logits_process import (SuppressTokensAtBeginLogitsProcessor, SuppressTokensLogitsProcessor,
+                                                        WhisperTimeStampLogitsProcessor)
+    from oracle import decoding, logmel
+    from whisperjav_amd import dims as pdims, synth, weights as pweights
+    d = helpers.small_dims(n_mels=80, d_model=64, heads=1, layers=1, n_vocab=51865)
+    oracle, w = helpers.make_oracle(d, seed=5, **pweights.SPEECHLIKE)
+    cfg = WhisperConfig(vocab_size=d.n_vocab, num_mel_bins=d.n_mels, d_model=d.n_audio_state, encoder_layers=d.n_audio_layer,
+                        decoder_layers=d.n_text_layer, encoder_attention_heads=d.n_audio_head, decoder_attention_heads=d.n_text_head,
+                        encoder_ffn_dim=4 * d.n_audio_state, decoder_ffn_dim=4 * d.n_text_state, max_source_positions=d.n_audio_ctx,
+                        max_target_positions=d.n_text_ctx, activation_function="gelu", dropout=0.0, attention_dropout=0.0,
+                        activation_dropout=0.0, attn_implementation="eager")
+    hf = WhisperForConditionalGeneration(cfg).eval()
+    _, unexpected = hf.load_state_dict(helpers.hf_state_dict(d, w), strict=False)
+    assert not unexpected
+    lay = decoding.TokenLayout.for_vocab(d.n_vocab)
+    toks = pdims.special_tokens(d.n_vocab)
+    prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    fcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=50, suppress_blank=True)
+    gen_cfg = SimpleNamespace(no_timestamps_token_id=lay.no_timestamps, eos_token_id=lay.eot, bos_token_id=lay.eot,
+                              max_initial_timestamp_index=50, _detect_timestamp_from_logprob=True)
+    procs = [SuppressTokensLogitsProcessor(list(suppress)), SuppressTokensAtBeginLogitsProcessor([lay.blank, lay.eot], begin_index=len(prompt)),
+             WhisperTimeStampLogitsProcessor(gen_cfg, begin_index=len(prompt))]
+    mel = torch.from_numpy(np.stack([logmel.window_features(synth.speech_like(s, seed=40 + i), 80, "fw") for i, s in enumerate((1.0, 4.0))]))
+    max_new = 40
+    with torch.no_grad():
+        xa = oracle.encode(mel)
+        out = decoding.greedy_decode(oracle, xa, prompt, max_new, fcfg)
+        lengths = set()
+        for b in range(mel.shape[0]):
+            enc = hf.model.encoder(mel[b:b + 1])
+            hist, total = list(prompt), 0.0
+            for _ in range(max_new):
+                ids = torch.tensor([hist])
+                logits = hf(encoder_outputs=enc, decoder_input_ids=ids).logits[:, -1].float()
+                for p in procs:
+                    logits = p(ids, logits)
+                lp = torch.log_softmax(logits, -1)
+                t = int(lp.argmax())
+                total += float(lp[0, t])
+                hist.append(t)
+                if t == lay.eot:
+                    break
+            ref = [t for t in hist[len(prompt):] if t != lay.eot]
+            assert hist[-1] == lay.eot, "this window did not end within max_new: the fixture lost its point"
+            got = [int(t) for t in out.tokens[b]]
+            assert got == ref, (b, got, ref)
+            assert abs(float(out.sum_logprob[b]) - total) < 2e-3, (b, float(out.sum_logprob[b]), total)
+            lengths.add(len(ref))
+    assert len(lengths) == 2          # the two windows ended at different lengths
