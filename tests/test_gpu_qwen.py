@@ -193,11 +193,12 @@ def test_forced_aligner_on_the_device(hip, tmp_path):
             marks += [len(ids), len(ids) + 1]
             ids += [TS, TS]
         return ids, marks
-    split = lambda text, language: text.split()      # noqa: E731
+    strip = str.maketrans("", "", "「」、。")
+    split = lambda text, language: text.translate(strip).split()      # noqa: E731  the upstream splitter drops punctuation
     al = qwen.HipQwenForcedAligner(d, ad, w, segment_ms=80.0, word_prompt=word_prompt, split_words=split, dtype="float32", batch_size=2,
                                    max_ctx=256)
-    paths, texts = [], ["ka ki ku ke", "sa shi su", "ta"]
-    for i, s in enumerate((2.1, 1.3, 0.8)):
+    paths, texts = [], ["「ka、 ki ku。 ke」", "sa shi su", "ta", "  "]          # the last scene has no text: not aligned
+    for i, s in enumerate((2.1, 1.3, 0.8, 0.6)):
         audio = synth.speech_like(s, seed=90 + i)
         path = tmp_path / f"a{i}.wav"
         with wave.open(str(path), "wb") as wf:
@@ -205,11 +206,13 @@ def test_forced_aligner_on_the_device(hip, tmp_path):
             wf.writeframes(np.clip(np.rint(audio * 32767), -32768, 32767).astype("<i2").tobytes())
         paths.append(path)
     results = al.align_batch(paths, texts, language="ja")
-    for path, text, res in zip(paths, texts, results):
+    assert len(results) == 4 and results[3].words == [] and results[3].metadata == {"scene_index": 3, "skipped": True}
+    assert [w_.word for w_ in results[0].words] == ["「ka、 ", "ki ", "ku。 ", "ke」"]      # punctuation back from the transcript
+    for path, text, res in list(zip(paths, texts, results))[:3]:
         with wave.open(str(path), "rb") as wf:
             audio = np.frombuffer(wf.readframes(wf.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
         padded = np.pad(audio, (0, max(0, 8000 - len(audio))))
-        words = text.split()
+        words = split(text, "ja")
         with torch.no_grad():
             a = oracle.audio_tokens(torch.from_numpy(logmel.logmel_ow(padded, 128, padding=0)))
             ids, marks = word_prompt(a.shape[0], words, "ja")
@@ -217,7 +220,8 @@ def test_forced_aligner_on_the_device(hip, tmp_path):
         bins = lg[marks].argmax(-1).numpy()
         assert res.metadata["raw_bins"] == bins.tolist(), (path.name, res.metadata["raw_bins"], bins.tolist())
         ms = qwen3_ref.fix_timestamps(bins.astype(np.float64) * 80.0)
-        assert [w_.word for w_ in res.words] == words
+        assert [w_.word.translate(strip).strip() for w_ in res.words] == words
+        assert res.metadata["raw_word_count"] == res.metadata["merged_word_count"] == len(words)
         assert [(w_.start, w_.end) for w_ in res.words] == [(round(ms[2 * i] / 1000.0, 3), round(ms[2 * i + 1] / 1000.0, 3)) for i in range(len(words))]
     al.cleanup()
 

@@ -307,3 +307,42 @@ def test_dynamic_token_budget_equals_the_reference_method(ref_modules, monkeypat
     mine = inspect.signature(qwen.HipQwenTextGenerator.__init__).parameters
     for name in ("repetition_penalty", "max_tokens_per_audio_second"):
         assert mine[name].default == sig[name].default
+
+
+def test_punctuation_merge_equals_the_reference_function(ref_modules, monkeypatch):
+    """``merge_master_with_timestamps`` (modules/qwen_asr.py:33-151, run from source) against the product's restatement on
+    the docstring's example, the edge cases the reference names (empty transcript, no timestamps, leading / trailing
+    punctuation, a word the transcript lacks, empty words, repeated words) and 400 random transcripts."""
+    import random
+    from whisperjav_amd import qwen
+    sw = types.ModuleType("stable_whisper"); sw.WhisperResult = object
+    monkeypatch.setitem(sys.modules, "stable_whisper", sw)
+    jp = types.ModuleType("whisperjav.modules.japanese_postprocessor"); jp.JapanesePostProcessor = object
+    monkeypatch.setitem(sys.modules, "whisperjav.modules.japanese_postprocessor", jp)
+    ref = importlib.import_module("whisperjav.modules.qwen_asr").merge_master_with_timestamps
+
+    def both(master, items):
+        want = ref(master, [{"text": w, "start_time": a, "end_time": b} for w, a, b in items])
+        got = qwen.merge_words_with_master(master, items)
+        assert [(d["word"], d["start"], d["end"]) for d in want] == got, (master, items, want, got)
+        return got
+    assert both("けども、お前が。", [("けども", 1.0, 1.5), ("お前", 2.0, 2.3), ("が", 2.3, 2.5)])[0][0] == "けども、"
+    both("", [("a", 0.0, 1.0)]); both("   ", []); both("そう。", []); both("「はい」 そう", [("はい", 0, 1), ("xx", 1, 2), ("そう", 2, 3)])
+    both("。。。", [("", 0, 1)]); both("ああああ", [("あ", 0, 1), ("ああ", 1, 2), ("あ", None, 3)]); both("abc", [("zzz", None, None)])
+    rng = random.Random(7)
+    alphabet = "あいうえおかきくけこ"
+    punct = "、。！？「」… "
+    for _ in range(400):
+        words = ["".join(rng.choice(alphabet) for _ in range(rng.randint(1, 4))) for _ in range(rng.randint(0, 7))]
+        master = "".join(rng.choice(punct) for _ in range(rng.randint(0, 2)))
+        for w in words:
+            if rng.random() < 0.85:
+                master += w
+            master += "".join(rng.choice(punct) for _ in range(rng.choice((0, 0, 1, 2))))
+        t, items = 0.0, []
+        for w in words:
+            if rng.random() < 0.1:
+                w = rng.choice(("", "ん", w[::-1]))
+            items.append((w, round(t, 2), round(t + 0.3, 2)))
+            t += 0.4
+        both(master, items)

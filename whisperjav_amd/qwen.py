@@ -622,6 +622,43 @@ def fix_timestamps(raw: Sequence[float]) -> List[int]:
     return [int(v) for v in out]
 
 
+def merge_words_with_master(master_text: str, items: Sequence[Tuple[str, Optional[float], Optional[float]]]) -> List[Tuple[str, float, float]]:
+    """What the reference's aligner adapter does after the forced aligner (aligners/qwen3.py:131-217 ->
+    ``merge_master_with_timestamps``, modules/qwen_asr.py:33-151): the aligner times words WITHOUT punctuation, the transcript
+    has it; the words are located in the transcript left to right and whatever lies between two of them (punctuation, spaces)
+    joins the preceding word -- or the first word when nothing precedes it; the transcript's tail joins the last word; a word
+    the transcript does not contain is kept as the aligner gave it.  Pinned against the reference's function run from source
+    (``tests/test_reference_integration.py``)."""
+    if not master_text or not master_text.strip():
+        return []
+    if not items:
+        return [(master_text.strip(), 0.0, 0.0)]
+    out: List[List[Any]] = []
+    cursor = 0
+    for word, start, end in items:
+        if not word:
+            continue
+        t0 = float(start) if start is not None else 0.0
+        t1 = float(end) if end is not None else 0.0
+        at = master_text.find(word, cursor)
+        if at < 0:                          # not in the transcript from here on: as given, the cursor stays
+            out.append([word, t0, t1])
+            continue
+        between = master_text[cursor:at]
+        if between and out:
+            out[-1][0] += between
+            between = ""
+        out.append([between + word, t0, t1])
+        cursor = at + len(word)
+    tail = master_text[cursor:]
+    if tail:
+        if out:
+            out[-1][0] += tail
+        elif tail.strip():
+            out.append([tail, 0.0, 0.0])
+    return [(w, a, b) for w, a, b in out]
+
+
 class HipQwenForcedAligner:
     """``TextAligner`` (protocols.py:128-179) on the device: the aligner checkpoint is the same architecture (audio tower +
     Qwen3 decoder) with a linear head over time bins, read at the ``<timestamp>`` markers of a prompt that interleaves the
@@ -631,7 +668,10 @@ class HipQwenForcedAligner:
 
     def __init__(self, dims: Qwen3Dims, audio_dims: Qwen3AudioDims, weights: Dict[str, np.ndarray], *, head_key: str = "score",
                  segment_ms: float = 80.0, word_prompt: Optional[Callable] = None, split_words: Optional[Callable] = None,
-                 dtype: str = "float16", device: int = 0, batch_size: int = 8, max_ctx: int = 2048):
+                 dtype: str = "float16", device: int = 0, batch_size: int = 8, max_ctx: int = 2048, merge_punctuation: bool = True):
+        """``merge_punctuation``: give the words the transcript's punctuation back, as the reference's adapter does after its
+        aligner (``merge_words_with_master``); False returns the aligner's words as split."""
+        self.merge_punctuation = bool(merge_punctuation)
         self.dims, self.audio_dims, self._weights, self.dtype, self.device = dims, audio_dims, weights, dtype, device
         self.head_key, self.segment_ms = head_key, float(segment_ms)
         self.word_prompt, self.split_words = word_prompt, split_words
@@ -662,30 +702,40 @@ class HipQwenForcedAligner:
             raise hipbind.WjError("HipQwenForcedAligner: word_prompt / split_words not supplied -- the tokenizer is not part of this "
                                   "slice (whisperjav_amd/qwen.py) and nothing falls back to the CPU")
         self.load()
-        out: List[AlignmentResult] = []
-        for lo in range(0, len(audio_paths), self.batch_size):
+        # scenes without text are not aligned (aligners/qwen3.py:171-179); the others go to the device in batches
+        todo = [i for i, t in enumerate(texts) if t and t.strip()]
+        out: List[Optional[AlignmentResult]] = [None if (t and t.strip()) else AlignmentResult(words=[], metadata={"scene_index": i, "skipped": True})
+                                                for i, t in enumerate(texts)]
+        for lo in range(0, len(todo), self.batch_size):
+            idx = todo[lo: lo + self.batch_size]
             clips, words = [], []
-            for path, text in zip(audio_paths[lo: lo + self.batch_size], texts[lo: lo + self.batch_size]):
-                audio, sr = read_audio(Path(path))
+            for i in idx:
+                audio, sr = read_audio(Path(audio_paths[i]))
                 if sr != 16000:
                     from .pipeline import to_16k
                     audio = to_16k(audio, sr)
                 clips.append(audio)
-                words.append(list(self.split_words(text, language)))
+                words.append(list(self.split_words(texts[i], language)))
             audio_embeds = self._tower.encode(clips)
-            embeds, rows = [], []
+            prompts, rows = [], []
             for a, wl in zip(audio_embeds, words):
                 ids, marks = self.word_prompt(int(a.shape[0]), wl, language)
                 if len(marks) != 2 * len(wl):
                     raise ValueError(f"{len(marks)} <timestamp> markers for {len(wl)} words (two per word expected)")
-                embeds.append(self._model.prompt_embeddings(ids, a))
+                prompts.append(ids)
                 rows.append(list(marks))
+            packed, n = self._model.prompt_embeddings_many(prompts, audio_embeds)
+            edges = np.concatenate([[0], np.cumsum(n)])
+            embeds = [packed[edges[k]: edges[k + 1]] for k in range(len(idx))]
             labels = self._model.classify(embeds, rows, self._head_w, self._head_b)
-            for wl, lab in zip(words, labels):
+            for i, wl, lab in zip(idx, words, labels):
                 ms = fix_timestamps(lab.astype(np.float64) * self.segment_ms)
-                out.append(AlignmentResult(words=[WordTimestamp(w, round(ms[2 * i] / 1000.0, 3), round(ms[2 * i + 1] / 1000.0, 3))
-                                                  for i, w in enumerate(wl)], metadata={"raw_bins": lab.tolist()}))
-        return out
+                timed = [(w, round(ms[2 * k] / 1000.0, 3), round(ms[2 * k + 1] / 1000.0, 3)) for k, w in enumerate(wl)]
+                merged = merge_words_with_master(texts[i], timed) if self.merge_punctuation else timed
+                out[i] = AlignmentResult(words=[WordTimestamp(w, a, b) for w, a, b in merged],
+                                         metadata={"scene_index": i, "aligner": "qwen3-hip", "raw_word_count": len(timed),
+                                                   "merged_word_count": len(merged), "raw_bins": lab.tolist()})
+        return out      # type: ignore[return-value]
 
     def align(self, audio_path: Path, text: str, language: str = "ja", **kwargs: Any) -> AlignmentResult:
         return self.align_batch([audio_path], [text], language, **kwargs)[0]
