@@ -561,8 +561,9 @@ class HipQwenTextGenerator:
                 budgets = [dynamic_token_limit(float(d or 0), max_new, self.max_tokens_per_audio_second, self.min_tokens_floor)
                            for d in list(durations)[lo: lo + self.batch_size]]
             res = self._model.generate(max_new, repetition_penalty=self.repetition_penalty, prompt_ids=ids, max_new_per_seq=budgets)
-            for toks in res.tokens:
-                out.append(TranscriptionResult(text=self.detokenize(toks), language=language, metadata={"n_tokens": len(toks)}))
+            for toks, path in zip(res.tokens, audio_paths[lo: lo + self.batch_size]):      # text stripped, metadata keys as generators/qwen3.py:186-195
+                out.append(TranscriptionResult(text=str(self.detokenize(toks)).strip(), language=language,
+                                               metadata={"generator": "qwen3-hip", "audio_path": str(path), "n_tokens": len(toks)}))
         return out
 
     def generate(self, audio_path: Path, language: str = "ja", context: Optional[str] = None, **kwargs: Any) -> TranscriptionResult:
