@@ -162,6 +162,13 @@ def test_text_generator_end_to_end_on_the_device(hip, tmp_path):
             toks, _ = oracle.greedy(build(a.shape[0], "ja", None), a, budget, repetition_penalty=1.1)
         assert res.text == " ".join(map(str, toks)), (path.name, res.text, toks)
         assert res.metadata["n_tokens"] <= budget
+    # pooling seam (qwen_pipeline.HipDecoupledSubtitlePipeline): every clip announced once, the orchestrator's per-scene calls
+    # are answered from the pooled results -- same texts as the per-scene computation above
+    gen.prime(paths, language="ja", audio_durations=list(seconds))
+    assert len(gen._primed) == 3
+    one_by_one = [gen.generate_batch([p], language="ja", audio_durations=[s])[0] for p, s in zip(paths, seconds)]
+    assert [r.text for r in one_by_one] == [r.text for r in results] and not gen._primed
+    assert gen.generate_batch([paths[1]], language="ja", audio_durations=[seconds[1]])[0].text == results[1].text      # nothing primed: computed
     gen.cleanup()
 
 
@@ -223,6 +230,12 @@ def test_forced_aligner_on_the_device(hip, tmp_path):
         assert [w_.word.translate(strip).strip() for w_ in res.words] == words
         assert res.metadata["raw_word_count"] == res.metadata["merged_word_count"] == len(words)
         assert [(w_.start, w_.end) for w_ in res.words] == [(round(ms[2 * i] / 1000.0, 3), round(ms[2 * i + 1] / 1000.0, 3)) for i in range(len(words))]
+    al.prime(paths[:3], texts[:3], language="ja")                       # pooling seam: per-scene calls answered from one pooled pass
+    for i in range(3):
+        again = al.align_batch([paths[i]], [texts[i]], language="ja")[0]
+        assert [(w_.word, w_.start, w_.end) for w_ in again.words] == [(w_.word, w_.start, w_.end) for w_ in results[i].words]
+        assert again.metadata["scene_index"] == 0
+    assert not al._primed
     al.cleanup()
 
 

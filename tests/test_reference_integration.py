@@ -346,3 +346,115 @@ def test_punctuation_merge_equals_the_reference_function(ref_modules, monkeypatc
             items.append((w, round(t, 2), round(t + 0.3, 2)))
             t += 0.4
         both(master, items)
+
+
+def _wav_sf_stub():
+    """A two-function stand-in for soundfile over the stdlib ``wave`` module (PCM16), for the orchestrator's audio I/O."""
+    import wave
+    import numpy as np
+    sf = types.ModuleType("soundfile")
+
+    def read(path, dtype="float32", **kw):
+        with wave.open(str(path), "rb") as wf:
+            pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
+            return pcm, wf.getframerate()
+
+    def write(path, audio, sr, **kw):
+        with wave.open(str(path), "wb") as wf:
+            wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(sr)
+            wf.writeframes(np.clip(np.rint(np.asarray(audio) * 32767), -32768, 32767).astype("<i2").tobytes())
+    sf.read, sf.write = read, write
+    return sf
+
+
+def test_reference_orchestrator_steps_run_pooled_over_the_hip_adapters(ref_modules, monkeypatch, tmp_path):
+    """``qwen_pipeline.hip_decoupled_pipeline_class()``: the reference's ``DecoupledSubtitlePipeline`` (from source) frames the
+    scenes, then its generation and alignment steps run over the HIP adapters (device engines replaced by doubles: no GPU
+    here).  Pooled, the decoder sees ONE batch with every scene's clip and the aligner one batch with every (clip, text);
+    texts, word timings and the inherited per-scene bookkeeping equal the un-pooled reference class's, which makes one engine
+    call per scene."""
+    import numpy as np
+    import torch
+    import wave
+    from whisperjav_amd import qwen, qwen_pipeline
+    monkeypatch.setitem(sys.modules, "soundfile", _wav_sf_stub())
+    orch = importlib.import_module("whisperjav.modules.subtitle_pipeline.orchestrator")
+    monkeypatch.setattr(orch, "sf", sys.modules["soundfile"])
+    stypes = importlib.import_module("whisperjav.modules.subtitle_pipeline.types")
+    FullScene = importlib.import_module("whisperjav.modules.subtitle_pipeline.framers.full_scene").FullSceneFramer
+    Passthrough = importlib.import_module("whisperjav.modules.subtitle_pipeline.cleaners.passthrough").PassthroughCleaner
+    d = qwen.Qwen3Dims(hidden=64, n_layer=1, n_head=1, n_kv_head=1, head_dim=128, ffn=64, vocab=400, audio_token_id=9)
+    ad = qwen.Qwen3AudioDims(n_layer=1, n_head=1, ffn=64, d_model=64, conv_hidden=8, out_dim=64)
+    calls = {"generate": [], "classify": []}
+
+    class Tower:
+        def encode(self, clips):
+            return [torch.full((max(1, len(c) // 4000), d.hidden), float(len(c) % 97)) for c in clips]
+
+        def close(self):
+            pass
+
+    class Decoder:
+        def prompt_embeddings_many(self, prompts, audios):
+            self.prompts = [list(p) for p in prompts]
+            n = np.array([len(p) for p in prompts], dtype=np.int32)
+            return torch.zeros((int(n.sum()), d.hidden)), n
+
+        def prefill_packed(self, packed, n, want_logits=False):
+            self.n = n
+
+        def generate(self, max_new, repetition_penalty=1.0, prompt_ids=None, max_new_per_seq=None):
+            calls["generate"].append(len(self.n))
+            return qwen.GenerateResult([[100 + int(k) % 200, 7, 8][: (max_new_per_seq[b] if max_new_per_seq else 3)] for b, k in enumerate(self.n)],
+                                       [[0.0] * 3 for _ in self.n])
+
+        def classify(self, embeds, rows, head_w, head_b):
+            calls["classify"].append(len(embeds))
+            return [np.arange(len(r), dtype=np.int32) * 3 + int(e.shape[0]) % 5 for e, r in zip(embeds, rows)]
+
+        def close(self):
+            pass
+
+    class Gen(qwen.HipQwenTextGenerator):
+        def load(self):
+            self._model, self._tower = self._model or Decoder(), self._tower or Tower()
+
+    class Al(qwen.HipQwenForcedAligner):
+        def load(self):
+            self._model, self._tower = self._model or Decoder(), self._tower or Tower()
+            self._head_w = self._head_b = None
+
+    def word_prompt(n_audio, words, language):
+        ids, marks = [11] + [d.audio_token_id] * n_audio, []
+        for wd in words:
+            ids += [20 + len(wd)]
+            marks += [len(ids), len(ids) + 1]
+            ids += [5, 5]
+        return ids, marks
+
+    def build(pooled):
+        gen = Gen(d, {}, audio_dims=ad, prompt_builder=lambda n, lang, ctx: [11] + [d.audio_token_id] * n + [12],
+                  detokenize=lambda t: "t" + "、".join(map(str, t)) + "。", batch_size=64, max_new_tokens=3)
+        al = Al(d, ad, {}, word_prompt=word_prompt, split_words=lambda text, lang: text.replace("。", "").split("、"), batch_size=64)
+        cls = qwen_pipeline.hip_decoupled_pipeline_class() if pooled else orch.DecoupledSubtitlePipeline
+        return cls(FullScene(), gen, Passthrough(), al, stypes.HardeningConfig(), language="ja", context="cast: A")
+    paths, durations = [], []
+    for i, sec in enumerate((1.5, 2.25, 0.75)):
+        path = tmp_path / f"scene_{i}.wav"
+        sys.modules["soundfile"].write(path, 0.1 * np.sin(np.arange(int(sec * 16000)) * 0.01 * (i + 1)), 16000)
+        paths.append(path); durations.append(sec)
+    out = {}
+    for pooled in (True, False):
+        calls["generate"].clear(); calls["classify"].clear()
+        pipe = build(pooled)
+        assert isinstance(pipe.generator, importlib.import_module("whisperjav.modules.subtitle_pipeline.protocols").TextGenerator)
+        frames, fpaths, _ = pipe._step1_frame_and_slice(paths, durations)
+        texts = pipe._step2_4_generate_and_clean(frames, fpaths, durations)
+        words = pipe._step5_7_align(frames, fpaths, texts, durations)
+        out[pooled] = (texts, words, list(calls["generate"]), list(calls["classify"]))
+        assert pipe.generator._model is None and pipe.aligner._model is None          # unloaded by the inherited finally blocks
+    assert out[True][2] == [3] and out[True][3] == [3]              # one decoder batch, one aligner batch for the three scenes
+    assert out[False][2] == [1, 1, 1] and out[False][3] == [1, 1, 1]
+    assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
+    assert all(len(t) == 1 and t[0].startswith("t1") for t in out[True][0])
+    assert [len(w[0]) for w in out[True][1]] == [3, 3, 3] and out[True][1][0][0][0]["word"].endswith("、")       # punctuation merged back

@@ -517,6 +517,7 @@ class HipQwenTextGenerator:
             self._tower = HipQwenAudioTower(self.audio_dims, self._weights, dtype=self.dtype, device=self.device)
 
     def unload(self) -> None:
+        self._primed = None
         if self._model is not None:
             self._model.close()
             self._model = None
@@ -534,13 +535,32 @@ class HipQwenTextGenerator:
             raise hipbind.WjError("HipQwenTextGenerator: " + ", ".join(missing) + " not supplied -- the tokenizer / chat template "
                                   "are not part of this slice (whisperjav_amd/qwen.py) and nothing falls back to the CPU")
 
+    def prime(self, audio_paths: Sequence[Path], language: str = "ja", contexts: Optional[Sequence[Optional[str]]] = None,
+              **kwargs: Any) -> None:
+        """Pooling seam (the analogue of ``HipFasterWhisperProASR.prime_scenes``).  The reference's orchestrator calls
+        ``generate_batch`` once PER SCENE (orchestrator.py:461-492; with the default full-scene framer that is one clip per
+        call), which would run the decoder at batch 1; ``qwen_pipeline.HipDecoupledSubtitlePipeline`` announces every frame of
+        every scene here first: they are transcribed in batches of ``batch_size`` and the per-scene calls that follow are
+        answered from the results (same path, language and context; anything else is computed as usual)."""
+        contexts = list(contexts) if contexts is not None else [None] * len(audio_paths)
+        results = self._generate_uncached(audio_paths, language, contexts, **kwargs)
+        self._primed = {(str(p), language, c): r for p, c, r in zip(audio_paths, contexts, results)}
+
     def generate_batch(self, audio_paths: Sequence[Path], language: str = "ja", contexts: Optional[Sequence[Optional[str]]] = None,
                        **kwargs: Any) -> List[TranscriptionResult]:
+        contexts = list(contexts) if contexts is not None else [None] * len(audio_paths)
+        keys = [(str(p), language, c) for p, c in zip(audio_paths, contexts)]
+        primed = getattr(self, "_primed", None)
+        if primed and all(k in primed for k in keys):
+            return [primed.pop(k) for k in keys]
+        return self._generate_uncached(audio_paths, language, contexts, **kwargs)
+
+    def _generate_uncached(self, audio_paths: Sequence[Path], language: str, contexts: Sequence[Optional[str]],
+                           **kwargs: Any) -> List[TranscriptionResult]:
         from .asr import read_audio
         self._require()
         self.load()
         out: List[TranscriptionResult] = []
-        contexts = list(contexts) if contexts is not None else [None] * len(audio_paths)
         for lo in range(0, len(audio_paths), self.batch_size):
             clips = []
             for path in audio_paths[lo: lo + self.batch_size]:
@@ -690,6 +710,7 @@ class HipQwenForcedAligner:
             self._head_b = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)) if b is not None else None
 
     def unload(self) -> None:
+        self._primed = None
         for obj in (self._model, self._tower):
             if obj is not None:
                 obj.close()
@@ -697,7 +718,23 @@ class HipQwenForcedAligner:
 
     cleanup = unload
 
+    def prime(self, audio_paths: Sequence[Path], texts: Sequence[str], language: str = "ja", **kwargs: Any) -> None:
+        """Pooling seam: every (frame, text) of every scene aligned in batches of ``batch_size``; the orchestrator's per-scene
+        ``align_batch`` calls (orchestrator.py:632-638) are then answered from the results (see ``HipQwenTextGenerator.prime``)."""
+        results = self._align_uncached(audio_paths, texts, language, **kwargs)
+        self._primed = {(str(p), t, language): r for p, t, r in zip(audio_paths, texts, results)}
+
     def align_batch(self, audio_paths: Sequence[Path], texts: Sequence[str], language: str = "ja", **kwargs: Any) -> List[AlignmentResult]:
+        keys = [(str(p), t, language) for p, t in zip(audio_paths, texts)]
+        primed = getattr(self, "_primed", None)
+        if primed and all(k in primed for k in keys):
+            out = [primed.pop(k) for k in keys]
+            for i, r in enumerate(out):         # scene_index is the position within THIS call (aligners/qwen3.py:175,209)
+                r.metadata["scene_index"] = i
+            return out
+        return self._align_uncached(audio_paths, texts, language, **kwargs)
+
+    def _align_uncached(self, audio_paths: Sequence[Path], texts: Sequence[str], language: str = "ja", **kwargs: Any) -> List[AlignmentResult]:
         from .asr import read_audio
         if self.word_prompt is None or self.split_words is None:
             raise hipbind.WjError("HipQwenForcedAligner: word_prompt / split_words not supplied -- the tokenizer is not part of this "
