@@ -747,7 +747,7 @@ def run_cfg5(args, info):
     secs = rng.uniform(2.0, 6.0, B)
     clips = [synth.speech_like(float(sv), seed=500 + i) for i, sv in enumerate(secs)]
     audio_s = float(sum(len(c) for c in clips)) / 16000.0
-    host_sample = [c.copy() for c in clips[:8]]          # ~10-30 s of host work at the 1.7 B geometry
+    host_sample = [c.copy() for c in clips[:4]]          # ~15-30 s of host work at the 1.7 B geometry
     clips = [torch.from_numpy(c).to(dev) for c in clips]      # inputs resident in HBM before the timed region (views of an uploaded recording)
 
     def prompt_ids(a):      # <|im_start|>user\n <audio> x n <|im_end|>\n<|im_start|>assistant\n, as the reference's chat template lays it out
