@@ -174,6 +174,427 @@ static void run_dma(const char* name, const _Float16* A, const _Float16* W, int 
   fflush(stdout);
 }
 
+
+// ---- LDS-DMA + MFMA overlap micro-benchmark (round 4) -------------------------------------------------------------------
+// The ping-pong schedule of gemm_h_big_pp64_kernel with the ds_reads removed (the MFMAs run on registers), so that what is
+// timed is how the LDS-DMA stream of a 256 x 256 tile sweep overlaps with the matrix pipe -- by source layout and request form:
+//   MODE 0  global_load_lds, row-major operands, 8 rows x 128 B per wave request         (what the library does)
+//   MODE 1  global_load_lds, operands BLOCKED [M/256][K/64][256][64]: a wave request is 1 KiB contiguous
+//   MODE 2  buffer_load ... lds (SGPR descriptor + 32-bit lane offset + SGPR offset), row-major
+//   MODE 3  buffer_load ... lds, blocked
+//   MF 0 no MFMAs, 1: 32 x v_mfma_f32_16x16x32_f16 per phase, 2: 16 x v_mfma_f32_32x32x16_f16 per phase
+//   W4 = 1: FOUR waves (one per SIMD), each 64 MFMAs of 32x32x16 per 64-wide k step with its 16 requests spread between them
+typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
+typedef __attribute__((ext_vector_type(4))) float f4_t;
+typedef __attribute__((ext_vector_type(16))) float f16v_t;
+
+template <int MODE>
+struct DmaSrc {
+  const _Float16* base_a;
+  const _Float16* base_w;
+  __amdgpu_buffer_rsrc_t ra, rw;
+  int voff;          // lane offset in BYTES (buffer forms) within a request group
+  int64_t lane_el;   // lane offset in elements (global forms)
+  int64_t piece_el;  // elements between consecutive pieces of one wave
+  int64_t step_el;   // elements between k steps
+};
+
+template <int MODE, int MF, int W4>
+__global__ __launch_bounds__(W4 ? 256 : 512) void dma_pp_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                                int M, int N, int K, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  constexpr int NW = W4 ? 4 : 8;
+  constexpr int PIECES = 32 / NW;                  // requests per wave, operand and 64-wide step (8 rows x 128 B each)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nx = gridDim.x, ntiles = gridDim.x * gridDim.y;
+  const int lin = blockIdx.y * nx + blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  constexpr int GM = 8;
+  const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
+  const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
+  const int mt = first_m + in_group % gsz, nt = in_group / gsz;
+  constexpr bool BLK = (MODE & 1) != 0, BUF = (MODE & 2) != 0;
+  const int np = K / 64;
+  // element offset of (tile row block t, local row r, k step p, chunk c): row-major (t*256 + r) * K + p*64 + c*8;  blocked ((t * np + p) * 256 + r) * 64 + c*8
+  const int r_in = lane >> 3, c = (lane & 7) ^ (r_in & 7);
+  int64_t a_off, w_off, piece_el, step_el;
+  if (BLK) {
+    a_off = ((int64_t)mt * np * 256 + wave * PIECES * 8 + r_in) * 64 + c * 8;
+    w_off = ((int64_t)nt * np * 256 + wave * PIECES * 8 + r_in) * 64 + c * 8;
+    piece_el = 8 * 64; step_el = 256 * 64;
+  } else {
+    a_off = ((int64_t)mt * 256 + wave * PIECES * 8 + r_in) * K + c * 8;
+    w_off = ((int64_t)nt * 256 + wave * PIECES * 8 + r_in) * K + c * 8;
+    piece_el = 8 * (int64_t)K; step_el = 64;
+  }
+  // buffer forms: descriptor base = the tile's first element of this wave (wave-uniform), lane offset in a VGPR, piece / step offsets in SGPRs
+  __amdgpu_buffer_rsrc_t ra, rw;
+  int voff = 0;
+  if constexpr (BUF) {
+    const int64_t wa = BLK ? ((int64_t)mt * np * 256 + wave * PIECES * 8) * 64 : ((int64_t)mt * 256 + wave * PIECES * 8) * K;
+    const int64_t ww = BLK ? ((int64_t)nt * np * 256 + wave * PIECES * 8) * 64 : ((int64_t)nt * 256 + wave * PIECES * 8) * K;
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + wa), 0, 0x7fffffff, 0x00020000);
+    rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + ww), 0, 0x7fffffff, 0x00020000);
+    voff = (int)((BLK ? (int64_t)r_in * 64 : (int64_t)r_in * K) + c * 8) * 2;
+  }
+  const _Float16* pa = A + a_off;
+  const _Float16* pw = W + w_off;
+  int sstep = 0;   // byte offset of the current k step (buffer forms)
+  auto issue = [&](int buf) {
+    _Float16* la = lds + (size_t)buf * 2 * 256 * 64 + wave * PIECES * 512;
+    _Float16* lw = la + 256 * 64;
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+      if constexpr (BUF) {
+        const int so = __builtin_amdgcn_readfirstlane(sstep + (int)(q * piece_el * 2));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(la + q * 512), 16, voff, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lw + q * 512), 16, voff, so, 0, 0);
+      } else {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + q * piece_el),
+            (__attribute__((address_space(3))) void*)(la + q * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw + q * piece_el),
+            (__attribute__((address_space(3))) void*)(lw + q * 512), 16, 0, 0);
+      }
+    }
+    pa += step_el; pw += step_el; sstep += (int)(step_el * 2);
+  };
+  // register operands: pseudo-random halves (the power drawn by the matrix pipe depends on the data)
+  h8_t af[8], wf[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      uint32_t h = (uint32_t)(tid * 131 + i * 17 + e) * 2654435761u; h ^= h >> 13;
+      af[i][e] = (_Float16)(((int)(h & 0xffff) - 32768) * (1.0f / 32768.0f));
+      if (i < 4) wf[i][e] = (_Float16)(((int)((h >> 8) & 0xffff) - 32768) * (0.05f / 32768.0f));
+    }
+  f4_t acc[8][4];
+  f16v_t acc32[4][2];
+  if constexpr (MF == 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (MF == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+  }
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfma_phase = [&](int half) {
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (MF == 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if constexpr (MF == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j * 2 + ks], af[i * 2 + ks], acc32[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if constexpr (!W4) {
+    const int wm = wave >> 2;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+    if (wm == 1) bar();
+    for (int p = 0; p < np; ++p) {
+      const int b = p & 1;
+      if (p + 1 < np) issue(b ^ 1);
+      bar();
+      mfma_phase(0);
+      bar();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bar();
+      mfma_phase(1);
+      bar();
+    }
+    if (wm == 0) bar();
+  } else {
+    // one wave per SIMD: per 64-wide step 4 quarter steps of 16 x (32x32x16) MFMAs on a 128 x 128 wave tile (4 x 4 accumulators
+    // of 16 registers); the 16 requests of the next step go out 6 + 6 + 4 + 0 between them, one barrier per step
+    f16v_t accw[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[i][j][e] = 0.f;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+    for (int p = 0; p < np; ++p) {
+      const int b = p & 1;
+      _Float16* la = lds + (size_t)(b ^ 1) * 2 * 256 * 64 + wave * PIECES * 512;
+      _Float16* lw = la + 256 * 64;
+      const bool more = p + 1 < np;
+#pragma unroll
+      for (int qs = 0; qs < 4; ++qs) {
+        if (qs == 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); bar(); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (more && qs < 3 && (qs < 2 || i < 2)) {
+            // requests 4 qs + i of A and of W ... (qs 0,1: 4 A+W pairs each = 8 requests; qs 2: 2 pairs... ) -> simple split: q = qs * 3 + i for i < 3
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (MF != 0) accw[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i + (qs & 1) * 4], accw[i][j], 0, 0, 0);
+          }
+          // one A and one W request after every row of 4 MFMAs, 8 rows of them in quarter steps 0..1 -> 8 pairs = 16 requests
+          if (more && qs < 2) {
+            const int q = qs * 4 + i;
+            if constexpr (BUF) {
+              const int so = __builtin_amdgcn_readfirstlane(sstep + (int)(q * piece_el * 2));
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(la + q * 512), 16, voff, so, 0, 0);
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(lw + q * 512), 16, voff, so, 0, 0);
+            } else {
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + q * piece_el),
+                  (__attribute__((address_space(3))) void*)(la + q * 512), 16, 0, 0);
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pw + q * piece_el),
+                  (__attribute__((address_space(3))) void*)(lw + q * 512), 16, 0, 0);
+            }
+          }
+        }
+      }
+      pa += step_el; pw += step_el; sstep += (int)(step_el * 2);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += accw[i][j][0] + accw[i][j][7];
+    if (s == 12345.678f) sink[0] = s;
+  }
+  float s = 0.f;
+  if constexpr (MF == 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+  }
+  if constexpr (MF == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) s += acc32[i][j][0] + acc32[i][j][9];
+  }
+  if (s == 12345.678f || lds[tid] == (_Float16)12345.0f) sink[0] = s;
+}
+
+template <int MODE, int MF, int W4>
+static void run_dma_pp(const char* name, const _Float16* A, const _Float16* W, int M, int N, int K, float* sink, int reps) {
+  constexpr size_t smem = 2 * 2 * 256 * 64 * 2;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dma_pp_kernel<MODE, MF, W4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  dim3 grid(N / 256, M / 256);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int threads = W4 ? 256 : 512;
+  dma_pp_kernel<MODE, MF, W4><<<grid, threads, smem>>>(A, W, M, N, K, sink);
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; ++r) dma_pp_kernel<MODE, MF, W4><<<grid, threads, smem>>>(A, W, M, N, K, sink);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  const double bytes = (double)grid.x * grid.y * (double)K * 512 * 2;
+  printf("{\"dma_pp\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"mode\": %d, \"mfma\": %d, \"waves\": %d, \"ms\": %.4f, \"dma_tb_s\": %.2f, "
+         "\"tflops_equiv\": %.0f}\n", name, M, N, K, MODE, MF, W4 ? 4 : 8, ms, bytes / ms * 1e-9, 2.0 * M * N * (double)K / ms * 1e-9);
+  fflush(stdout);
+}
+
+
+// ---- schedule variants of the ping-pong loop, blocked operands only (round 4) -------------------------------------------
+//   ST 1  the 8 requests of a pair split 4 + 4 over the two MEM phases (A half-pair / W half-pair into a ring of five 32 KiB slots),
+//         counted waits (vmcnt(4)): every MEM phase carries the same 4 requests
+//   ST 2  the requests go out BETWEEN the MFMAs of the MFMA phases (one per 8 MFMAs), waits as ST 1
+//   ST 3  ring of NSTG 32-wide stages (16 KiB A + 16 KiB W each; a wave request = 16 rows x 64 B = 1 KiB contiguous in the
+//         [M/256][K/32][256][32] layout), 4 requests per MEM phase, NSTG-1 stages in flight (the schedule of gemm_h_big_pp_kernel)
+//   BUF   buffer_load ... lds instead of global_load_lds
+template <int ST, int NSTG, int BUF, int AUX>
+__global__ __launch_bounds__(512) void dma_pp2_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                      int M, int N, int K, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nx = gridDim.x, ntiles = gridDim.x * gridDim.y;
+  const int lin = blockIdx.y * nx + blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  constexpr int GM = 8;
+  const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
+  const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
+  const int mt = first_m + in_group % gsz, nt = in_group / gsz;
+  constexpr int KB = ST == 3 ? 32 : 64;                 // k elements per block of the blocked layout
+  const int nb = K / KB;
+  // a wave owns 32 rows of A and of W of every block: 4 requests of 1 KiB each per operand (KB = 64: 8 rows x 128 B; 32: 16 rows x 64 B)
+  const int64_t blk_el = 256 * KB;
+  const int64_t wa = ((int64_t)mt * nb * 256 + wave * 32) * KB, ww = ((int64_t)nt * nb * 256 + wave * 32) * KB;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + wa), 0, 0x7fffffff, 0x00020000);
+  __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(W + ww), 0, 0x7fffffff, 0x00020000);
+  const int voff = lane * 16;
+  const _Float16* pa = A + wa + lane * 8;
+  const _Float16* pw = W + ww + lane * 8;
+  auto req = [&](bool isw, int q, int blk, _Float16* dst) {   // request q (0..3) of block blk of A or W into dst
+    if constexpr (BUF) {
+      const int so = __builtin_amdgcn_readfirstlane((int)(blk * blk_el * 2) + q * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isw ? rw : ra, (__attribute__((address_space(3))) void*)dst, 16, voff, so, 0, AUX);
+    } else {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((isw ? pw : pa) + blk * blk_el + q * 512),
+          (__attribute__((address_space(3))) void*)dst, 16, 0, AUX);
+    }
+  };
+  h8_t af[8], wf[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      uint32_t h = (uint32_t)(tid * 131 + i * 17 + e) * 2654435761u; h ^= h >> 13;
+      af[i][e] = (_Float16)(((int)(h & 0xffff) - 32768) * (1.0f / 32768.0f));
+      if (i < 4) wf[i][e] = (_Float16)(((int)((h >> 8) & 0xffff) - 32768) * (0.05f / 32768.0f));
+    }
+  f4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const int wm = wave >> 2;
+  if constexpr (ST == 1 || ST == 2) {
+    // half-pair h = 2 p + x (x = 0: A of pair p, 1: W of pair p) lives in ring slot h % 5 (32 KiB each)
+    const int nh = 2 * nb;
+    auto issue_half = [&](int h) {
+      _Float16* dst = lds + (size_t)(h % 5) * 256 * 64 + wave * 4 * 512;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) req(h & 1, q, h >> 1, dst + q * 512);
+    };
+    issue_half(0); issue_half(1); issue_half(2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    bar();
+    if (wm == 1) bar();
+    for (int p = 0; p < nb; ++p) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int h = 2 * p + x + 3;     // half-pair requested in this phase
+        if constexpr (ST == 1) {
+          if (h < nh) issue_half(h);
+          if (h < nh) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          bar();
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          bar();
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          bar();
+          __builtin_amdgcn_s_setprio(1);
+          _Float16* dst = lds + (size_t)(h % 5) * 256 * 64 + wave * 4 * 512;
+          const int hh = h < nh ? h : nh - 1;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            if (i & 1) req(hh & 1, i >> 1, hh >> 1, dst + (i >> 1) * 512);
+          }
+          __builtin_amdgcn_s_setprio(0);
+          bar();
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wm == 0) bar();
+  } else {
+    constexpr int D = NSTG - 1;
+    auto issue_stage = [&](int st) {
+      _Float16* dst = lds + (size_t)(st % NSTG) * 2 * 256 * 32 + wave * 2 * 512;
+      req(false, 0, st, dst); req(false, 1, st, dst + 512);
+      req(true, 0, st, dst + 256 * 32); req(true, 1, st, dst + 256 * 32 + 512);
+    };
+    // a wave owns 32 rows of a 32-wide block = 2 requests per operand and stage -> blocks of 256 x 32: wa / ww computed with KB = 32 above
+#pragma unroll
+    for (int st = 0; st < D; ++st) issue_stage(st);
+    if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (D == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    bar();
+    if (wm == 1) bar();
+    for (int kt = 0; kt < nb; ++kt) {
+      if (kt + D < nb) {
+        issue_stage(kt + D);
+        if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if constexpr (D == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      bar();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      bar();
+    }
+    if (wm == 0) bar();
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+  if (s == 12345.678f || lds[tid] == (_Float16)12345.0f) sink[0] = s;
+}
+
+template <int ST, int NSTG, int BUF, int AUX>
+static void run_dma_pp2(const char* name, const _Float16* A, const _Float16* W, int M, int N, int K, float* sink, int reps) {
+  constexpr size_t smem = ST == 3 ? (size_t)NSTG * 2 * 256 * 32 * 2 : (size_t)5 * 256 * 64 * 2;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dma_pp2_kernel<ST, NSTG, BUF, AUX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  dim3 grid(N / 256, M / 256);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  dma_pp2_kernel<ST, NSTG, BUF, AUX><<<grid, 512, smem>>>(A, W, M, N, K, sink);
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < reps; ++r) dma_pp2_kernel<ST, NSTG, BUF, AUX><<<grid, 512, smem>>>(A, W, M, N, K, sink);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  printf("{\"dma_pp2\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"sched\": %d, \"stages\": %d, \"buf\": %d, \"aux\": %d, \"ms\": %.4f, \"tflops_equiv\": %.0f}\n",
+         name, M, N, K, ST, NSTG, BUF, AUX, ms, 2.0 * M * N * (double)K / ms * 1e-9);
+  fflush(stdout);
+}
+
 struct Shape { const char* name; int M, N, K, gelu, f32; };
 
 int main(int argc, char** argv) {
@@ -265,7 +686,7 @@ int main(int argc, char** argv) {
     std::vector<Shape> enc = {
         {"enc_fc1", M, 5120, 1280, 1, 0}, {"enc_fc2", M, 1280, 5120, 0, 0}, {"enc_qk", M, 2560, 1280, 0, 0},
         {"enc_out", M, 1280, 1280, 0, 0}, {"enc_out_f32", M, 1280, 1280, 0, 1}};
-    run_set(enc, 6, {86, 87}, {});
+    run_set(enc, 6, {86, 83, 88, 89}, {});
   }
   if (what == "dma") {
     for (auto sh : {Shape{"fc2", 144128, 1280, 5120, 0, 0}, Shape{"qk", 144128, 2560, 1280, 0, 0}, Shape{"fc1", 144128, 5120, 1280, 0, 0}}) {
@@ -281,6 +702,51 @@ int main(int argc, char** argv) {
       run_dma<65, 1>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
       run_dma<128, 1>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
       run_dma<256, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(sink));
+    }
+  }
+
+  if (what == "dmapp") {   // LDS-DMA x MFMA overlap by source layout / request form (round 4)
+    for (auto sh : {Shape{"fc2", 144128, 1280, 5120, 0, 0}, Shape{"fc1", 144128, 5120, 1280, 0, 0}}) {
+      _Float16 *A, *W;
+      float* sink;
+      CK(hipMalloc(&A, (int64_t)sh.M * sh.K * 2)); CK(hipMalloc(&W, (int64_t)sh.N * sh.K * 2)); CK(hipMalloc(&sink, 4));
+      fill_f16<<<2048, 256>>>(A, (int64_t)sh.M * sh.K, 1u, 1.0f);
+      fill_f16<<<2048, 256>>>(W, (int64_t)sh.N * sh.K, 2u, 1.0f);
+      CK(hipDeviceSynchronize());
+#define RUN_ALL(MF_, W4_)                                                          \
+      run_dma_pp<0, MF_, W4_>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);          \
+      run_dma_pp<1, MF_, W4_>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);          \
+      run_dma_pp<2, MF_, W4_>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);          \
+      run_dma_pp<3, MF_, W4_>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      RUN_ALL(0, 0) RUN_ALL(1, 0) RUN_ALL(2, 0) RUN_ALL(0, 1) RUN_ALL(2, 1)
+#undef RUN_ALL
+      CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(sink));
+    }
+  }
+
+  if (what == "dmapp2") {   // schedule variants on blocked operands (round 4)
+    for (auto sh : {Shape{"fc2", 144128, 1280, 5120, 0, 0}, Shape{"fc1", 144128, 5120, 1280, 0, 0}, Shape{"out", 144128, 1280, 1280, 0, 0}}) {
+      _Float16 *A, *W;
+      float* sink;
+      CK(hipMalloc(&A, (int64_t)sh.M * sh.K * 2)); CK(hipMalloc(&W, (int64_t)sh.N * sh.K * 2)); CK(hipMalloc(&sink, 4));
+      fill_f16<<<2048, 256>>>(A, (int64_t)sh.M * sh.K, 1u, 1.0f);
+      fill_f16<<<2048, 256>>>(W, (int64_t)sh.N * sh.K, 2u, 1.0f);
+      CK(hipDeviceSynchronize());
+      run_dma_pp<1, 1, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp<3, 1, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<1, 0, 0, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<1, 0, 1, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<2, 0, 0, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<2, 0, 1, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<3, 3, 0, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<3, 3, 1, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<3, 4, 0, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<3, 4, 1, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<3, 5, 0, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<3, 5, 1, 0>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<3, 4, 1, 2>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
+      run_dma_pp2<1, 0, 1, 2>(sh.name, A, W, sh.M, sh.N, sh.K, sink, reps);
       CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(sink));
     }
   }

@@ -51,17 +51,20 @@ GEMM_SHAPES = [
     (5, 1003, 128),      # N not a multiple of 4 (logits path, f32 out)
     (320, 512, 640),     # beam-sized M
     (1100, 256, 192),    # 256-tile kernel with an M tail
+    (700, 512, 160),     # blocked operands: the shortest k loop the ring takes (5 stages), M below the 256-tile threshold
 ]
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
-@pytest.mark.parametrize("variant", [4, 2, 3, 5, 54, 6, 7, 73, 75, 83, 84, 85, 86])
+@pytest.mark.parametrize("variant", [4, 2, 3, 5, 54, 6, 7, 73, 75, 83, 84, 85, 86, 88, 89])
 def test_gemm(hip, dtype, shape, variant):
     from whisperjav_amd import engine
     M, N, K = shape
     if dtype == "float32" and variant != 4:
         pytest.skip("the fp32 compute type has a single GEMM kernel")
+    if variant in (88, 89) and (N % 256 or K % 32 or K < 160):
+        pytest.skip("blocked operands (88: row-major output, 89: blocked output) take N % 256 == 0, K % 32 == 0, K >= 160")
     if variant in (3, 5, 54, 6, 7, 73, 75, 83, 84, 85, 86) and K % 64:
         pytest.skip("the LDS-DMA tile kernels and the rows kernel need K % 64 == 0")
     if variant in (6, 83, 84, 85, 86) and (N % 256 or M < 1024):
@@ -113,7 +116,8 @@ def test_gemm_split_activations(hip, dtype, shape, variant):
 def test_gemm_kernel_families_and_store_widths_are_bit_identical(hip, dtype, gelu):
     """Every 16-bit MFMA tile kernel accumulates k in ascending blocks of 32 into fp32 and shares one epilogue: the
     128-tile kernels (3 LDS-DMA, 4 register staging, 73 three-stage ring), the lockstep 256-tile kernel (6) and its
-    ping-pong successors (83-85: 32-wide ring stages, 86: 64-wide pairs, the default) must agree to the bit, with the
+    ping-pong successors (83-85: 32-wide ring stages, 86: 64-wide pairs; 88 / 89: the ring over BLOCKED operands, the
+    encoder's default since round 4, with a row-major / blocked output) must agree to the bit, with the
     16-byte permlane-swapped epilogue stores (wj_tune epi_wide=1, default) and with the 8-byte ones."""
     from whisperjav_amd import engine, hipbind
     g = torch.Generator().manual_seed(77)
@@ -125,7 +129,7 @@ def test_gemm_kernel_families_and_store_widths_are_bit_identical(hip, dtype, gel
     try:
         for wide in (1, 0):
             hipbind.tune("epi_wide", wide)
-            for variant in (3, 4, 73, 6, 83, 84, 85, 86):
+            for variant in (3, 4, 73, 6, 83, 84, 85, 86, 88, 89):
                 outs[(wide, variant)] = engine.k_gemm(a, w, bias, dtype, gelu=gelu, variant=variant).cpu()
     finally:
         hipbind.tune("epi_wide", 1)
@@ -150,7 +154,7 @@ def test_gemm_gelu(hip, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
-@pytest.mark.parametrize("D", [128, 384, 1280])
+@pytest.mark.parametrize("D", [128, 256, 384, 1280])
 def test_layernorm(hip, dtype, D):
     from whisperjav_amd import engine
     g = torch.Generator().manual_seed(D)

@@ -116,6 +116,42 @@ def test_encoder_layer_bisection(hip, dtype):
     model.close()
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_encoder_blocked_operands_equal_row_major(hip, dtype):
+    """Round 4: models with d_model % 256 == 0 run the encoder's big GEMMs on BLOCKED operands (weights copied into
+    [N/256][K/32][256][32] at create, LayerNorm / attention / fc1 write the activations in that layout, the head-split
+    epilogues take the window from the flat row index).  Same kernels' arithmetic in the same order: the encoder output and
+    everything decoded from the cross K/V must be BIT-identical to the row-major path (wj_tune enc_blocked=0), and both
+    within the 16-bit bound of the oracle.  3 windows of 1500 positions = 4500 rows: row blocks straddle windows and the
+    last block is partial."""
+    from whisperjav_amd import engine, hipbind
+    dims_kw = dict(n_mels=80, d_model=256, heads=4, layers=2, n_vocab=51865)
+    d = helpers.small_dims(**dims_kw)
+    oracle, w = helpers.make_oracle(d, seed=33, emulate=dtype)
+    mel = torch.from_numpy(helpers.synth_mel(3, d.n_mels, seed=9))
+    toks = __import__("whisperjav_amd.dims", fromlist=["x"]).special_tokens(d.n_vocab)
+    prompt = np.array([[toks.sot, toks.language_token(0), toks.transcribe]] * 3, dtype=np.int32)
+    outs = {}
+    try:
+        for blocked in (1, 0):
+            hipbind.tune("enc_blocked", blocked)
+            model = engine.HipWhisper(d, w, dtype=dtype, max_batch=3)
+            enc = model.encode(mel.cuda(), want_output=True).cpu()
+            res = model.decode_greedy(prompt, engine.DecodeOptions(max_new_tokens=6))
+            outs[blocked] = (enc, res.tokens.copy(), res.sum_logprob.copy())
+            model.close()
+    finally:
+        hipbind.tune("enc_blocked", 1)
+    assert torch.equal(outs[1][0], outs[0][0])
+    assert np.array_equal(outs[1][1], outs[0][1]) and np.array_equal(outs[1][2], outs[0][2])
+    with torch.no_grad():
+        ref = oracle.encode(mel)
+    tol = _tol(dtype, 2e-3, 6e-2, 8e-3)
+    err = float((outs[1][0] - ref).abs().max())
+    _diag("encoder_blocked", {"dtype": dtype, "max_abs": err, "ref_max": float(ref.abs().max())})
+    assert err < tol * max(1.0, float(ref.abs().max())), err
+
+
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 @pytest.mark.parametrize("without_timestamps", [False, True])
 def test_greedy_decode_matches_oracle(hip, dtype, without_timestamps):

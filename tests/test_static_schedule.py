@@ -22,6 +22,7 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(OBJDUMP) and os.path.exists(
 GEMM_ARGS = "EEvNS_8GemmArgsE"
 PP64 = "_ZN2wj22gemm_h_big_pp64_kernelIDF16_Li%dE" + GEMM_ARGS            # <f16, EPI>
 PP = "_ZN2wj20gemm_h_big_pp_kernelIDF16_Li0ELi%dELi0ELi0E" + GEMM_ARGS    # <f16, EPI_T, NS, ABL 0, PLACE 0>
+PPB = "_ZN2wj21gemm_h_big_ppb_kernelIDF16_Li%dELi4E" + GEMM_ARGS             # <f16, EPI, NS 4>: blocked operands (round 4)
 MS = "_ZN2wj21gemm_h_tile_ms_kernelIDF16_Li0ELi%dE" + GEMM_ARGS           # <f16, EPI_T, NS>
 BIG = "_ZN2wj17gemm_h_big_kernelIDF16_Li0ELi0E" + GEMM_ARGS               # lockstep kernel (drains by design)
 
@@ -82,6 +83,23 @@ def test_ring_kernel_keeps_requests_in_flight_across_barriers(code_object, ns):
     counted = f"s_waitcnt vmcnt({4 * (ns - 2)})"
     assert sum(l == counted for l in ins) == 2, (counted, [l for l in ins if l.startswith("s_waitcnt vmcnt")])
     assert sum(l.startswith("v_mfma") for l in ins) == 32
+
+
+@pytest.mark.parametrize("epi", [0, 1, 3, 5, 6])
+def test_blocked_ring_kernel_keeps_requests_in_flight_across_barriers(code_object, epi):
+    """The encoder's default since round 4 (bias, GELU, residual, Q/K heads, transposed V epilogues): the ring schedule over
+    blocked operands -- two stages stay in flight across every barrier of the main loop, no fence, one 32-MFMA phase."""
+    ins = _disasm(code_object, PPB % epi)
+    pre = _before_barriers(ins, window=3)
+    assert len(pre) == 5
+    assert not any(_is_fence(l) for w in pre for l in w), pre
+    loop = ins[:max(k for k, l in enumerate(ins) if l.startswith("s_barrier"))]     # everything before the epilogue
+    assert sum(l == "s_waitcnt vmcnt(8)" for l in loop) == 2, [l for l in loop if l.startswith("s_waitcnt vmcnt")]
+    assert sum(l.startswith("v_mfma") for l in ins) == 32
+    assert sum("global_load_lds_dwordx4" in l for l in ins) == 16      # 3 prologue stages + one per loop trip, 4 requests each
+    k = ins.index("s_setprio 1")
+    body = [l for l in ins[k + 1:ins.index("s_setprio 0", k)] if l != "s_waitcnt lgkmcnt(0)"]
+    assert len(body) == 32 and all(l.startswith("v_mfma") for l in body), body[:40]
 
 
 @pytest.mark.parametrize("ns", [3, 4, 5])
@@ -162,7 +180,7 @@ def test_encoder_attention_masks_padding_keys_on_the_last_tile_only(tmp_path):
     shutil.copy(build.CSRC / "build" / "attention.o", local)
     subprocess.run([OBJDUMP, "--offloading", str(local)], check=True, capture_output=True)
     co = [p for p in tmp_path.iterdir() if "gfx950" in p.name][0]
-    ins = _disasm(co, "_ZN2wj17attn_enc_h_kernelIDF16_Li9EEEvPKtS2_S2_PT_iii")       # <f16, default variant>
+    ins = _disasm(co, "_ZN2wj17attn_enc_h_kernelIDF16_Li9EEEvPKtS2_S2_PT_iiii")       # <f16, default variant>
     blocks, cur = [], []
     for l in ins:                       # straight-line runs between branches
         cur.append(l)

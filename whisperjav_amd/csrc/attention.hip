@@ -29,7 +29,7 @@ __device__ __forceinline__ int kswz(int prow, int chunk) { return prow * 64 + ((
 template <typename E, int VAR>
 __global__ __launch_bounds__(256) void attn_enc_h_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                          const bf16_t* __restrict__ Vt, E* __restrict__ out,
-                                                         int T, int Tpad, int H) {
+                                                         int T, int Tpad, int H, int out_blk) {
   typedef typename Vec8<E>::type vec8_t;       // the operand vector of this instantiation (bf16 or fp16 lanes)
   typedef typename Lane16<E>::type lane_t;
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * 64 * 64];  // [buf][K|Vt][64][64] = 32 KiB
@@ -261,7 +261,12 @@ __global__ __launch_bounds__(256) void attn_enc_h_kernel(const bf16_t* __restric
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         float v[4] = {o[f][d][0] * inv, o[f][d][1] * inv, o[f][d][2] * inv, o[f][d][3] * inv};
-        st4(out + ((int64_t)b * T + t) * (H * 64) + h * 64 + d * 16 + lg * 4, v);
+        if (out_blk) {   // blocked GEMM-operand layout [rows / 256][D / 32][256][32] (GemmArgs::blk): the out-projection's A
+          const int row = b * T + t, c = h * 64 + d * 16 + lg * 4;
+          st4(out + (((int64_t)(row >> 8) * (H * 2) + (c >> 5)) << 13) + ((row & 255) << 5) + (c & 31), v);
+        } else {
+          st4(out + ((int64_t)b * T + t) * (H * 64) + h * 64 + d * 16 + lg * 4, v);
+        }
       }
     }
   }
@@ -325,8 +330,9 @@ __global__ __launch_bounds__(64) void attn_enc_f32_kernel(const float* __restric
 int g_attn_enc_variant = 9;   // wj_tune("attn_enc_variant"): bit0 XCD remap, bit1 base-2 softmax, bit2 lazy rescale, bit3 lean softmax
 
 int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt, void* out, int B, int T, int Tpad,
-                         int H, hipStream_t s) {
+                         int H, hipStream_t s, int out_blk) {
   if (Tpad % 128 || Tpad < T) { set_error("attention_enc: Tpad must be a multiple of 128 and >= T"); return WJ_E_INVALID; }
+  if (out_blk && dtype == WJ_F32) { set_error("attention_enc: a blocked output is a 16-bit feature"); return WJ_E_INVALID; }
   if (dtype == WJ_F32) {
     dim3 grid(Tpad / 64, H, B);
     hipLaunchKernelGGL(attn_enc_f32_kernel, grid, dim3(64), 0, s, (const float*)Q, (const float*)K, (const float*)Vt,
@@ -337,10 +343,10 @@ int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt
   do {                                                                                                             \
     if (dtype == WJ_F16)                                                                                           \
       hipLaunchKernelGGL((attn_enc_h_kernel<f16_t, V>), grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
-                         (const bf16_t*)Vt, (f16_t*)out, T, Tpad, H);                                              \
+                         (const bf16_t*)Vt, (f16_t*)out, T, Tpad, H, out_blk);                                     \
     else                                                                                                           \
       hipLaunchKernelGGL((attn_enc_h_kernel<bf16_t, V>), grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
-                         (const bf16_t*)Vt, (bf16_t*)out, T, Tpad, H);                                             \
+                         (const bf16_t*)Vt, (bf16_t*)out, T, Tpad, H, out_blk);                                    \
   } while (0)
     switch (g_attn_enc_variant & 15) {
       case 0: WJ_ATTN(0); break;

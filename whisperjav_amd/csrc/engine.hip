@@ -115,6 +115,9 @@ struct Tunables {
   int beam_poll = 4;        // decode iterations between two polls of the per-window done flags
   int beam_compact_pct = 12;  // compact when at least this share of the batch's windows ...
   int beam_compact_min = 8;   // ... and at least this many of them have finished
+  int enc_blocked = 1;      // 16-bit models with d_model % 256 == 0 (read at create): the encoder's big GEMMs take BLOCKED operands
+                            // ([rows / 256][K / 32][256][32]: every LDS-DMA wave request 1 KiB contiguous) -- weights copied
+                            // once into that layout, LayerNorm / attention / fc1 write it; +5..+20 % per GEMM (r04 gemm probe)
   int dec_big_min_m = 0;    // rows from which the wide decode projections (qkv, fc1) use the 256x256 kernel; measured at 1920 rows: 14.00 s vs 13.89 s for the 128-tile kernel (160 workgroups do not fill 256 CUs), so off
 };
 static Tunables g_tune;
@@ -148,6 +151,14 @@ struct wj_whisper {
   void* cross_k = nullptr;    // T   [L][max_batch][H][ctx][64]
   void* cross_v = nullptr;    // same, or (cross_tpad > 0) transposed per head: [L][max_batch][H][64][cross_tpad]
   int cross_tpad = 0;
+  // blocked GEMM operands of the encoder (wj_tune "enc_blocked"): copies of the encoder / cross-K/V matrices in the layout
+  // [N / 256][K / 32][256][32]; wblk_off[tensor index] = element offset of the copy, -1 = none
+  bool blk = false;
+  void* wblk = nullptr;
+  std::vector<int64_t> wblk_off;
+  const void* WB(int idx, int64_t row0 = 0, int K = 0) const {   // blocked copy of tensor idx from row row0 (a multiple of 256) on
+    return reinterpret_cast<const char*>(wblk) + (wblk_off[idx] + row0 * K) * (int64_t)esz;
+  }
   // fp16: the decode-step GEMMs read their activations as [hi | lo] rows (x to ~22 bits; profiles/r02_precision_*):
   // the decode step is HBM / latency bound, the second MFMA per fragment is free, and the per-token log-probs move
   // from ~2e-3 to ~3e-4 of the fp32 evaluation.  dh / dattn / dff rows are then twice as wide.
@@ -261,38 +272,44 @@ static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, flo
   }
   const int L = n_layers < 0 ? d.n_audio_layer : n_layers;
   const int M = B * T;
+  const int blk = m->blk ? 1 : 0;   // blocked operands: flat rows (the head-split epilogues take the window from the row index)
   for (int l = 0; l < L; ++l) {
     const int b0 = m->enc_base(l);
-    PROF(PT_E_LN, launch_layernorm(dt, m->x, m->F(b0 + WJ_TE_LN1_W), m->F(b0 + WJ_TE_LN1_B), m->h, M, D, s));
+    PROF(PT_E_LN, launch_layernorm(dt, m->x, m->F(b0 + WJ_TE_LN1_W), m->F(b0 + WJ_TE_LN1_B), m->h, M, D, s, 0, blk));
     {
       GemmArgs g;
       g.A = m->h; g.lda = D; g.a_batch = (int64_t)T * D;
       g.W = m->W(b0 + WJ_TE_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TE_QKV_B);
       g.M = T; g.N = 2 * D; g.K = D; g.nbatch = B;
       g.out = m->q; g.out2 = m->k; g.D = D; g.H = H; g.Tpad = m->Tpad;
+      if (blk) { g.blk = 1; g.seq_T = T; g.M = M; g.nbatch = 1; g.a_batch = 0; g.W = m->WB(b0 + WJ_TE_QKV_W); }
       PROF(PT_E_QK, launch_gemm(dt, EPI_QK_HEADS, g, s, 1));
       GemmArgs v = g;
-      v.W = reinterpret_cast<const char*>(m->W(b0 + WJ_TE_QKV_W)) + (int64_t)2 * D * D * m->esz;
+      v.W = blk ? m->WB(b0 + WJ_TE_QKV_W, 2 * D, D)
+                : reinterpret_cast<const char*>(m->W(b0 + WJ_TE_QKV_W)) + (int64_t)2 * D * D * m->esz;
       v.bias = m->F(b0 + WJ_TE_QKV_B) + 2 * D;
       v.N = D; v.out = m->vt; v.out2 = nullptr;
       PROF(PT_E_V, launch_gemm(dt, EPI_VT, v, s, 1));
     }
-    PROF(PT_E_ATTN, launch_attention_enc(dt, m->q, m->k, m->vt, m->attn, B, T, m->Tpad, H, s));
+    PROF(PT_E_ATTN, launch_attention_enc(dt, m->q, m->k, m->vt, m->attn, B, T, m->Tpad, H, s, blk));
     {
       GemmArgs g;
       g.A = m->attn; g.lda = D; g.W = m->W(b0 + WJ_TE_OUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TE_OUT_B);
       g.M = M; g.N = D; g.K = D; g.out = m->x; g.ldc = D;
+      if (blk) { g.blk = 1; g.W = m->WB(b0 + WJ_TE_OUT_W); }
       PROF(PT_E_OUT, launch_gemm(dt, EPI_RESID_F32, g, s, 1));
     }
-    PROF(PT_E_LN, launch_layernorm(dt, m->x, m->F(b0 + WJ_TE_LN2_W), m->F(b0 + WJ_TE_LN2_B), m->h, M, D, s));
+    PROF(PT_E_LN, launch_layernorm(dt, m->x, m->F(b0 + WJ_TE_LN2_W), m->F(b0 + WJ_TE_LN2_B), m->h, M, D, s, 0, blk));
     {
       GemmArgs g;
       g.A = m->h; g.lda = D; g.W = m->W(b0 + WJ_TE_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TE_FC1_B);
       g.M = M; g.N = 4 * D; g.K = D; g.out = m->ff; g.ldc = 4 * D;
+      if (blk) { g.blk = 1; g.out_blk = 1; g.W = m->WB(b0 + WJ_TE_FC1_W); }
       PROF(PT_E_FC1, launch_gemm(dt, EPI_GELU_T, g, s, 1));
       GemmArgs g2;
       g2.A = m->ff; g2.lda = 4 * D; g2.W = m->W(b0 + WJ_TE_FC2_W); g2.ldw = 4 * D; g2.bias = m->F(b0 + WJ_TE_FC2_B);
       g2.M = M; g2.N = D; g2.K = 4 * D; g2.out = m->x; g2.ldc = D;
+      if (blk) { g2.blk = 1; g2.W = m->WB(b0 + WJ_TE_FC2_W); }
       PROF(PT_E_FC2, launch_gemm(dt, EPI_RESID_F32, g2, s, 1));
     }
   }
@@ -300,7 +317,7 @@ static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, flo
     if (enc_out) WJ_HIP(hipMemcpyAsync(enc_out, m->x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, s));
     return WJ_OK;
   }
-  PROF(PT_E_LN, launch_layernorm(dt, m->x, m->F(WJ_T_ENC_LNPOST_W), m->F(WJ_T_ENC_LNPOST_B), m->h, M, D, s));
+  PROF(PT_E_LN, launch_layernorm(dt, m->x, m->F(WJ_T_ENC_LNPOST_W), m->F(WJ_T_ENC_LNPOST_B), m->h, M, D, s, 0, blk));
   if (enc_out)
     WJ_TRY(launch_layernorm(WJ_F32, m->x, m->F(WJ_T_ENC_LNPOST_W), m->F(WJ_T_ENC_LNPOST_B), enc_out, M, D, s));
   // cross-attention K/V of every decoder layer, computed once per window and kept in HBM
@@ -310,6 +327,7 @@ static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, flo
     g.A = m->h; g.lda = D; g.a_batch = (int64_t)T * D;
     g.W = m->W(b0 + WJ_TD_CKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CKV_B);
     g.M = T; g.N = 2 * D; g.K = D; g.nbatch = B;
+    if (blk) { g.blk = 1; g.seq_T = T; g.M = M; g.nbatch = 1; g.a_batch = 0; g.W = m->WB(b0 + WJ_TD_CKV_W); }
     // the slice's windows land at window slots win0 .. win0 + B - 1 of the resident cross K/V
     const int64_t kwin = (int64_t)d.n_text_head * T * 64, vwin = (int64_t)d.n_text_head * 64 * (m->cross_tpad > 0 ? m->cross_tpad : T);
     g.out = m->at(m->cross_k, l * m->cross_layer_elems() + win0 * kwin);
@@ -319,7 +337,7 @@ static int run_encoder(wj_whisper* m, const float* mel, int B, int n_layers, flo
       GemmArgs v = g;
       g.N = D; g.out2 = nullptr;
       PROF(PT_E_CKV, launch_gemm(dt, EPI_QK_HEADS, g, s, 1));
-      v.W = reinterpret_cast<const char*>(m->W(b0 + WJ_TD_CKV_W)) + (int64_t)D * D * m->esz;
+      v.W = blk ? m->WB(b0 + WJ_TD_CKV_W, D, D) : reinterpret_cast<const char*>(m->W(b0 + WJ_TD_CKV_W)) + (int64_t)D * D * m->esz;
       v.bias = m->F(b0 + WJ_TD_CKV_B) + D;
       v.N = D; v.out = m->at(m->cross_v, l * m->cross_v_layer_elems() + win0 * vwin); v.out2 = nullptr;
       v.Tpad = m->cross_tpad;
@@ -775,6 +793,8 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_big_min_m")) g_tune.dec_big_min_m = value;
   else if (!strcmp(key, "self_kv_len")) g_tune.self_kv_len = value;
   else if (!strcmp(key, "enc_batch")) g_tune.enc_batch = value;
+  else if (!strcmp(key, "enc_blocked")) g_tune.enc_blocked = value;
+  else if (!strcmp(key, "ln_vec")) wj::g_ln_vec = value;
   else if (!strcmp(key, "beam_compact")) g_tune.beam_compact = value;
   else if (!strcmp(key, "beam_poll")) g_tune.beam_poll = value;
   else if (!strcmp(key, "beam_compact_pct")) g_tune.beam_compact_pct = value;
@@ -858,13 +878,42 @@ int wj_whisper_create(wj_ctx* ctx, const wj_whisper_dims* dims, int dtype, const
   const size_t B = max_batch, R = max_rows, EB = m->enc_batch;
   WJ_ALLOC(mel_rows, EB * (F + 2) * d.n_mels * e, true);
   WJ_ALLOC(conv1_out, EB * (F + 2) * D * e, true);
+  m->blk = is16(dtype) && g_tune.enc_blocked && D % 256 == 0 && D >= 256 && T % 4 == 0 && (int64_t)EB * T < (1 << 24);
+  const size_t EBT = m->blk ? (EB * T + 255) / 256 * 256 : EB * T;   // blocked activations: whole 256-row blocks
   WJ_ALLOC(x, EB * T * D * sizeof(float), false);
-  WJ_ALLOC(h, EB * T * D * e, false);
+  WJ_ALLOC(h, EBT * D * e, false);
   WJ_ALLOC(q, EB * H * m->Tpad * 64 * e, true);
   WJ_ALLOC(k, EB * H * m->Tpad * 64 * e, true);
   WJ_ALLOC(vt, EB * H * 64 * m->Tpad * e, true);
-  WJ_ALLOC(attn, EB * T * D * e, false);
-  WJ_ALLOC(ff, EB * T * 4 * D * e, false);
+  WJ_ALLOC(attn, EBT * D * e, false);
+  WJ_ALLOC(ff, EBT * 4 * D * e, false);
+  if (m->blk) {
+    // blocked copies of the matrices the 256-tile kernel streams: per encoder layer qkv [3D][D], out [D][D], fc1 [4D][D],
+    // fc2 [D][4D]; per decoder layer the cross K/V projection [2D][D]
+    m->wblk_off.assign(n_offsets, -1);
+    int64_t total = 0;
+    auto reserve = [&](int idx, int64_t rows, int64_t cols) { m->wblk_off[idx] = total; total += rows * cols; };
+    for (int l = 0; l < d.n_audio_layer; ++l) {
+      const int b0 = m->enc_base(l);
+      reserve(b0 + WJ_TE_QKV_W, 3 * D, D); reserve(b0 + WJ_TE_OUT_W, D, D);
+      reserve(b0 + WJ_TE_FC1_W, 4 * D, D); reserve(b0 + WJ_TE_FC2_W, D, 4 * D);
+    }
+    for (int l = 0; l < d.n_text_layer; ++l) reserve(m->dec_base(l) + WJ_TD_CKV_W, 2 * D, D);
+    WJ_ALLOC(wblk, (size_t)total * e, false);
+    auto convert = [&](int idx, int rows, int cols) {
+      return launch_to_blocked(m->W(idx), cols, rows, cols, reinterpret_cast<char*>(m->wblk) + m->wblk_off[idx] * (int64_t)e, ctx->stream);
+    };
+    int rc = WJ_OK;
+    for (int l = 0; l < d.n_audio_layer && !rc; ++l) {
+      const int b0 = m->enc_base(l);
+      rc = convert(b0 + WJ_TE_QKV_W, 3 * D, D);
+      if (!rc) rc = convert(b0 + WJ_TE_OUT_W, D, D);
+      if (!rc) rc = convert(b0 + WJ_TE_FC1_W, 4 * D, D);
+      if (!rc) rc = convert(b0 + WJ_TE_FC2_W, D, 4 * D);
+    }
+    for (int l = 0; l < d.n_text_layer && !rc; ++l) rc = convert(m->dec_base(l) + WJ_TD_CKV_W, 2 * D, D);
+    if (rc) { wj_whisper_free(m); return rc; }
+  }
   WJ_ALLOC(cross_k, (size_t)d.n_text_layer * m->cross_layer_elems() * e, false);
   m->cross_tpad = (is16(dtype) && g_tune.dec_cross_mfma) ? (d.n_audio_ctx + 31) / 32 * 32 : 0;
   WJ_ALLOC(cross_v, (size_t)d.n_text_layer * m->cross_v_layer_elems() * e, true);   // pad keys stay zero forever
@@ -1604,6 +1653,52 @@ int wj_decode_no_speech(wj_whisper* m, int rows, int no_speech_id, float* out_ho
   return WJ_OK;
 }
 
+}  // extern "C"
+
+// wj_k_gemm / wj_k_gemm_timed, variant 88 (blocked operands, row-major output) and 89 (blocked output as well, converted
+// back for the caller): the entry builds the blocked copies itself, so a test hands over ordinary row-major matrices and can
+// compare the result bit for bit with the other kernels.  reps > 0: only the GEMM launches are timed.
+static int k_gemm_blocked(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev, int M,
+                          int N, int K, int act_gelu, int out_f32, int variant, hipStream_t s, int reps, float* ms_per_launch) {
+  WJ_REQUIRE(is16(dtype), "wj_k_gemm: blocked operands are a 16-bit feature");
+  WJ_REQUIRE(!(variant == 89 && out_f32), "wj_k_gemm: variant 89 (blocked output) needs a 16-bit output");
+  const int64_t mp = ((int64_t)M + 255) / 256 * 256;
+  void *ab = nullptr, *wb = nullptr, *cb = nullptr;
+  int rc = WJ_OK;
+  auto cleanup = [&]() { if (ab) (void)hipFree(ab); if (wb) (void)hipFree(wb); if (cb) (void)hipFree(cb); };
+  if (hipMalloc(&ab, (size_t)mp * K * 2) != hipSuccess || hipMalloc(&wb, (size_t)N * K * 2) != hipSuccess ||
+      (variant == 89 && hipMalloc(&cb, (size_t)mp * N * 2) != hipSuccess)) {
+    cleanup();
+    set_error("wj_k_gemm: out of device memory for the blocked copies");
+    return WJ_E_HIP;
+  }
+  rc = launch_to_blocked(a_dev, K, M, K, ab, s);
+  if (!rc) rc = launch_to_blocked(w_dev, K, N, K, wb, s);
+  GemmArgs g;
+  g.A = ab; g.W = wb; g.bias = bias_dev; g.M = M; g.N = N; g.K = K; g.out = variant == 89 ? cb : c_dev; g.ldc = N;
+  g.blk = 1; g.out_blk = variant == 89;
+  const Epi e = out_f32 ? EPI_F32 : (act_gelu ? EPI_GELU_T : EPI_T);
+  if (!rc) rc = launch_gemm(dtype, e, g, s, 0);
+  if (!rc && reps > 0) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < reps && !rc; ++i) rc = launch_gemm(dtype, e, g, s, 0);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / reps;
+  }
+  if (!rc && variant == 89) rc = launch_from_blocked(cb, M, N, c_dev, N, s);
+  (void)hipStreamSynchronize(s);
+  cleanup();
+  return rc;
+}
+
+extern "C" {
+
 // ---- kernel-level entry points (tests / micro-benchmarks) ---------------------------------------
 int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev, void* c_dev, int M,
               int N, int K, int act_gelu, int out_f32, int variant, void* stream) {
@@ -1613,6 +1708,8 @@ int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, cons
   g.A = a_dev; g.lda = K; g.W = w_dev; g.ldw = K; g.bias = bias_dev; g.M = M; g.N = N; g.K = K; g.out = c_dev; g.ldc = N;
   Epi e = out_f32 ? EPI_F32 : (act_gelu ? EPI_GELU_T : EPI_T);
   WJ_REQUIRE(!(out_f32 && act_gelu), "wj_k_gemm: gelu with f32 output is not a fused variant");
+  if (variant == 88 || variant == 89)
+    return k_gemm_blocked(ctx, dtype, a_dev, w_dev, bias_dev, c_dev, M, N, K, act_gelu, out_f32, variant, ctx->pick(stream), 0, nullptr);
   return launch_gemm(dtype, e, g, ctx->pick(stream), variant);
 }
 
@@ -1643,6 +1740,8 @@ int wj_k_gemm_timed(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev
   GemmArgs g;
   g.A = a_dev; g.lda = K; g.W = w_dev; g.ldw = K; g.bias = bias_dev; g.M = M; g.N = N; g.K = K; g.out = c_dev; g.ldc = N;
   Epi e = out_f32 ? EPI_F32 : (act_gelu ? EPI_GELU_T : EPI_T);
+  if (variant == 88 || variant == 89)
+    return k_gemm_blocked(ctx, dtype, a_dev, w_dev, bias_dev, c_dev, M, N, K, act_gelu, out_f32, variant, s, reps, ms_per_launch);
   int rc = launch_gemm(dtype, e, g, s, variant);  // warm-up + argument validation
   if (rc) return rc;
   hipEvent_t e0, e1;

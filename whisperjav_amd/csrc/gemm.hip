@@ -27,9 +27,27 @@ namespace wj {
 // --------------------------------------------------------------------------------------------
 // epilogues
 // --------------------------------------------------------------------------------------------
+// Flat rows (GemmArgs::seq_T > 0, the blocked-operand path): row m of the GEMM is position m % seq_T of window m / seq_T.
+// One float multiply + at most one correction instead of an integer division (m < 2^24, checked by launch_gemm).
+__device__ __forceinline__ void flat_zt(const GemmArgs& g, int& z, int& m) {
+  if (g.seq_T) {
+    int zz = (int)((float)m * g.inv_seq_T);
+    int t = m - zz * g.seq_T;
+    if (t < 0) { --zz; t += g.seq_T; }
+    if (t >= g.seq_T) { ++zz; t -= g.seq_T; }
+    z = zz;
+    m = t;
+  }
+}
+// element offset of (row m, column n) in the blocked layout [rows / 256][cols / 32][256][32] (GemmArgs::blk / out_blk)
+__device__ __forceinline__ int64_t blk_off(int m, int n, int cols) {
+  return (((int64_t)(m >> 8) * (cols >> 5) + (n >> 5)) << 13) + ((m & 255) << 5) + (n & 31);
+}
+
 template <typename T>
 __device__ __forceinline__ void epi_vt_store(const GemmArgs& g, int z, int m, int n, float v[4]) {
   // v[i] belongs to (row m + i, column n), bias already added; m % 4 == 0; m < M (M % 4 == 0), n < N.
+  flat_zt(g, z, m);
   const int h = n >> 6, dd = n & 63;
   st4(reinterpret_cast<T*>(g.out) + (((int64_t)z * g.H + h) * 64 + dd) * g.Tpad + m, v);
 }
@@ -53,6 +71,7 @@ __device__ __forceinline__ void epi_nm_store(const GemmArgs& g, int z, int m, in
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = gelu_for<T>(v[j]);
     }
+    if (g.out_blk) { st4(reinterpret_cast<T*>(g.out) + blk_off(m, n, g.N), v); return; }
     T* o = reinterpret_cast<T*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n;
     if constexpr (sizeof(T) == 2) {
       if (g.split_out) { st4_split<T>(o, g.N, v); return; }
@@ -72,6 +91,7 @@ __device__ __forceinline__ void epi_nm_store(const GemmArgs& g, int z, int m, in
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (int64_t)z * g.c_batch +
                                (int64_t)m * g.ldc + n) = x;
   } else if constexpr (EPI == EPI_QK_HEADS || EPI == EPI_CKV) {
+    flat_zt(g, z, m);
     const int which = n >= g.D;
     const int nn = n - which * g.D;
     const int h = nn >> 6, dd = nn & 63;
@@ -116,8 +136,10 @@ __device__ __forceinline__ void epi_nm(const GemmArgs& g, int z, int m, int n, f
 template <int EPI, typename T>
 __device__ __forceinline__ T* epi_addr8(const GemmArgs& g, int z, int m, int n, int posv) {
   if constexpr (EPI == EPI_T || EPI == EPI_GELU_T) {
+    if (g.out_blk) return reinterpret_cast<T*>(g.out) + blk_off(m, n, g.N);
     return reinterpret_cast<T*>(g.out) + (int64_t)z * g.c_batch + (int64_t)m * g.ldc + n;
   } else if constexpr (EPI == EPI_QK_HEADS || EPI == EPI_CKV) {
+    flat_zt(g, z, m);
     const int which = n >= g.D;
     const int nn = n - which * g.D;
     const int h = nn >> 6, dd = nn & 63;
@@ -743,6 +765,169 @@ __global__ __launch_bounds__(512) void gemm_h_big_pp_kernel(const GemmArgs g) {
 #undef WJ_PP_ISSUE
 
   tile_epilogue<EPI, T, 8>(g, z, m0 + wm * 128, n0 + wn * 64, lane, acc);
+}
+
+
+// --------------------------------------------------------------------------------------------
+// Ping-pong 256-tile kernel over BLOCKED operands (round 4; GemmArgs::blk): the schedule, LDS image and accumulation order
+// of gemm_h_big_pp_kernel, with A stored as [ceil(M / 256)][K / 32][256][32] and W as [N / 256][K / 32][256][32].
+// One 32-wide stage of a tile is then 16 KiB contiguous per operand and every LDS-DMA wave request (16 rows x 64 B) is
+// 1 KiB contiguous.  Measured with the matrix pipe running beside the DMA stream (scripts/gemm_probe.hip `dmapp2`, no
+// ds_reads): row-major operands with 128-byte segments bound the loop at 1120-1320 TFLOP/s-equivalent, blocked operands
+// with 4 requests per MEM phase at 1390-1480 on all three encoder shapes -- rows K elements apart put the 8 segments of a
+// request on a few L2 channels (K = 5120: stride 10 KiB), a contiguous KiB spreads over all of them.
+// Rows past M inside the last row block are never written by the producers and never stored by the epilogue (a row of C
+// depends on its own row of A only).  Flat rows only (no batch dimension): the head-split epilogues take the window from
+// the row index (GemmArgs::seq_T).
+// --------------------------------------------------------------------------------------------
+template <typename T, int EPI, int NS>
+__global__ __launch_bounds__(512) void gemm_h_big_ppb_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds_pb[];   // [stage][A|W][256][32]
+  constexpr int D = NS - 1;                                          // stages in flight
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nx = gridDim.x, ntiles = gridDim.x * gridDim.y;
+  const int lin = blockIdx.y * nx + blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  constexpr int GM = 8;
+  const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
+  const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
+  const int mt = first_m + in_group % gsz, nt = in_group / gsz;
+  const int nk = g.K / PBK;      // launch guarantees nk >= NS
+  constexpr int BLK = BBM * PBK; // elements of one block
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)mt * nk * BLK;
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(g.W) + (int64_t)nt * nk * BLK;
+
+  // a wave request deposits 16 rows of 64 B lane-linear; slot s = lane & 3 of row r fetches chunk s ^ f(r) of the same row
+  const bf16_t* ga[2];
+  const bf16_t* gw[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row = (wave * 2 + p) * 16 + (lane >> 2);
+    const int off = row * PBK + (((lane & 3) ^ pp_f(row)) << 3);
+    ga[p] = A + off;
+    gw[p] = W + off;
+  }
+#define WJ_PB_ISSUE(buf)                                                                                      \
+  _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga[p],                    \
+        (__attribute__((address_space(3))) void*)(&lds_pb[(buf) * PSTAGE + (wave * 2 + p) * 16 * PBK]), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw[p],                    \
+        (__attribute__((address_space(3))) void*)(&lds_pb[(buf) * PSTAGE + BBM * PBK + (wave * 2 + p) * 16 * PBK]), 16, 0, 0); \
+    ga[p] += BLK;                                                                                             \
+    gw[p] += BLK;                                                                                             \
+  }
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frag = (lane & 15) * PBK + (((lane >> 4) ^ pp_f(lane & 15)) << 3);
+  const int a_frag = wm * 128 * PBK + frag;
+  const int w_frag = BBM * PBK + wn * 64 * PBK + frag;
+
+#pragma unroll
+  for (int st = 0; st < D; ++st) { WJ_PB_ISSUE(st) }
+  wait_vmcnt<4 * (D - 1)>();     // own requests of stage 0 have landed
+  wg_barrier();                  // P: stage 0 visible to every wave
+  if (wm == 1) wg_barrier();     // B0: group 1 runs one barrier behind group 0
+
+  int cbuf = 0, ibuf = D;        // buffer of stage kt / of stage kt + D
+  typename Vec8<T>::type af[8], wf[4];
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- MEM(kt)
+    const bf16_t* ls = &lds_pb[cbuf * PSTAGE];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const typename Vec8<T>::type*>(&ls[w_frag + j * 16 * PBK]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const typename Vec8<T>::type*>(&ls[a_frag + i * 16 * PBK]);
+    if (kt + D < nk) {
+      WJ_PB_ISSUE(ibuf)
+      wait_vmcnt<4 * (D - 1)>();   // stage kt+1 landed; stages kt+2 .. kt+D stay in flight
+    } else {
+      wait_vmcnt<0>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wg_barrier();
+    // ---- MFMA(kt)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (EPI == EPI_VT) acc[i][j] = mfma16(af[i], wf[j], acc[i][j]);
+        else acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+      }
+    __builtin_amdgcn_s_setprio(0);
+    wg_barrier();
+    cbuf = cbuf + 1 == NS ? 0 : cbuf + 1;
+    ibuf = ibuf + 1 == NS ? 0 : ibuf + 1;
+  }
+  if (wm == 0) wg_barrier();     // every wave has taken part in the same number of barriers
+#undef WJ_PB_ISSUE
+
+  tile_epilogue<EPI, T, 8>(g, 0, mt * BBM + wm * 128, nt * BBN + wn * 64, lane, acc);
+}
+
+template <typename T, int EPI>
+static int launch_big_ppb(const GemmArgs& a, hipStream_t s) {
+  if constexpr (EPI == EPI_PARTIAL_F32 || EPI == EPI_QKV_DEC || EPI == EPI_GELU_POS_F32) {
+    set_error("gemm: blocked operands are an encoder-path feature (no split-K / decode / conv epilogues)");
+    return WJ_E_INVALID;
+  } else {
+    constexpr int NS = 4;
+    if ((a.N % BBN) || (a.K % PBK) || a.K / PBK < NS + 1 || a.nbatch != 1 || a.split || a.split_out) {
+      set_error("gemm: blocked operands need N %% 256 == 0, K %% 32 == 0, K >= 160, one batch, no split activations (N=%d K=%d)",
+                a.N, a.K);
+      return WJ_E_INVALID;
+    }
+    constexpr size_t smem = (size_t)NS * PSTAGE * sizeof(bf16_t);   // 128 KiB
+    static AttrOnce attr_set;
+    if (attr_set.need()) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_h_big_ppb_kernel<T, EPI, NS>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) { set_error("hipFuncSetAttribute(%d KiB LDS): %s", (int)(smem >> 10), hipGetErrorString(e)); return WJ_E_HIP; }
+      attr_set.done();
+    }
+    dim3 grid(a.N / BBN, ceil_div(a.M, BBM), 1);
+    hipLaunchKernelGGL((gemm_h_big_ppb_kernel<T, EPI, NS>), grid, dim3(512), smem, s, a);
+    WJ_LAUNCH_CHECK();
+    return WJ_OK;
+  }
+}
+
+// row-major [rows][ld] <-> blocked [ceil(rows / 256)][cols / 32][256][32] (2-byte elements, 16-byte granules); rows past
+// `rows` of the last block are zero-filled by to_blocked
+__global__ __launch_bounds__(256) void to_blocked_kernel(const uint4* __restrict__ src, int64_t ld8, int rows, int cols8,
+                                                         uint4* __restrict__ dst, int back) {
+  const int rows_pad = (rows + 255) & ~255;
+  const int64_t total = (int64_t)rows_pad * cols8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / cols8), c8 = (int)(i - (int64_t)m * cols8);
+    const int64_t b = ((((int64_t)(m >> 8) * (cols8 >> 2) + (c8 >> 2)) << 13) + ((m & 255) << 5) + ((c8 & 3) << 3)) >> 3;
+    if (back) {
+      if (m < rows) dst[(int64_t)m * ld8 + c8] = src[b];
+    } else {
+      dst[b] = m < rows ? src[(int64_t)m * ld8 + c8] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+}
+
+int launch_to_blocked(const void* src, int64_t ld, int rows, int cols, void* dst, hipStream_t s) {
+  if ((cols % 32) || (ld % 8) || rows <= 0) { set_error("to_blocked: cols %% 32 == 0 and ld %% 8 == 0 required"); return WJ_E_INVALID; }
+  hipLaunchKernelGGL(to_blocked_kernel, dim3(2048), dim3(256), 0, s, (const uint4*)src, ld / 8, rows, cols / 8, (uint4*)dst, 0);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+int launch_from_blocked(const void* src, int rows, int cols, void* dst, int64_t ld, hipStream_t s) {
+  if ((cols % 32) || (ld % 8) || rows <= 0) { set_error("from_blocked: cols %% 32 == 0 and ld %% 8 == 0 required"); return WJ_E_INVALID; }
+  hipLaunchKernelGGL(to_blocked_kernel, dim3(2048), dim3(256), 0, s, (const uint4*)src, ld / 8, rows, cols / 8, (uint4*)dst, 1);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1499,6 +1684,7 @@ int launch_splitk_reduce(int dtype, Epi epi, const GemmArgs& a, const float* sla
 // --------------------------------------------------------------------------------------------
 template <typename T, int EPI>
 static int launch_epi16(const GemmArgs& a, hipStream_t s, int variant) {
+  if (a.blk) return launch_big_ppb<T, EPI>(a, s);
   if (variant == 5 || (variant >= 50 && variant < 70)) return launch_rows<T, EPI>(a, s, variant == 5 ? 0 : variant - 50);
   if (variant == 7 || (variant >= 73 && variant <= 75)) return launch_ms<T, EPI>(a, s, variant == 7 ? 4 : variant - 70);
   const bool skinny_ok = (EPI != EPI_VT) && a.nbatch == 1;
@@ -1608,6 +1794,18 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
 int launch_gemm(int dtype, Epi epi, const GemmArgs& a_in, hipStream_t s, int variant) {
   GemmArgs a = a_in;
   a.epi_wide = g_epi_wide;
+  if (a.blk && !is16(dtype)) { set_error("gemm: blocked operands are a 16-bit feature"); return WJ_E_INVALID; }
+  if (a.out_blk && (!a.blk || (epi != EPI_T && epi != EPI_GELU_T) || (a.N % 32))) {
+    set_error("gemm: a blocked output needs blocked operands, an EPI_T / EPI_GELU_T epilogue and N %% 32 == 0");
+    return WJ_E_INVALID;
+  }
+  if (a.seq_T) {
+    if (a.seq_T < 4 || (a.seq_T % 4) || a.M >= (1 << 24) || a.nbatch != 1) {
+      set_error("gemm: flat rows need seq_T %% 4 == 0, M < 2^24 and one batch (seq_T=%d M=%d)", a.seq_T, a.M);
+      return WJ_E_INVALID;
+    }
+    a.inv_seq_T = 1.0f / (float)a.seq_T;
+  }
   const int kalign = is16(dtype) ? 8 : 4;
   if (a.K % kalign || a.lda % kalign || a.ldw % kalign || a.a_batch % kalign) {
     set_error("gemm: K/lda/ldw/a_batch must be multiples of %d elements (K=%d lda=%lld ldw=%lld)", kalign, a.K,

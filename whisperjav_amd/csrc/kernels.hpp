@@ -46,11 +46,21 @@ struct GemmArgs {
   // 2-byte row-major / head-split epilogues of the MFMA tile kernels: 16-byte stores after a v_permlane16_swap of
   // neighbouring fragments (set by launch_gemm from wj_tune "epi_wide"; 0 = the 8-byte stores, for A/B and cross-checks)
   int epi_wide = 1;
+  // Blocked operands (round 4, encoder GEMMs): A is [ceil(M / 256)][K / 32][256][32], W is [N / 256][K / 32][256][32]
+  // (lda / ldw / a_batch unused); out_blk: the EPI_T / EPI_GELU_T output is written in the same layout with N columns
+  // (it is the next GEMM's A).  seq_T > 0: flat rows -- the head-split epilogues (EPI_QK_HEADS / EPI_VT / EPI_CKV) take
+  // window z = m / seq_T and position m % seq_T from the row index instead of from the batch dimension.
+  int blk = 0, out_blk = 0, seq_T = 0;
+  float inv_seq_T = 0.f;          // set by launch_gemm
 };
 
 // variant: 0 = auto; 1 = tiled MFMA kernel (default staging); 2 = skinny (decode) kernel;
 //          3 = tiled kernel with LDS-DMA staging; 4 = tiled kernel with register staging
 int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int variant = 0);
+
+// row-major 2-byte [rows][ld] -> blocked [ceil(rows / 256)][cols / 32][256][32] (pad rows zero-filled) and back
+int launch_to_blocked(const void* src, int64_t ld, int rows, int cols, void* dst, hipStream_t s);
+int launch_from_blocked(const void* src, int rows, int cols, void* dst, int64_t ld, hipStream_t s);
 
 // second half of a split-K GEMM whose epilogue has no consumer kernel to fold the reduction into:
 // out = EPI(bias + sum_s slab[s][M][N]); `a` carries the epilogue operands exactly as for launch_gemm
@@ -58,8 +68,10 @@ int launch_splitk_reduce(int dtype, Epi epi, const GemmArgs& a, const float* sla
 
 // ---------------- normalisation / elementwise ------------------------------------------------
 // split != 0 (16-bit types): out rows are [hi(D) | lo(D)] (row stride 2 D), see GemmArgs::split
+// blk != 0 (16-bit types, D % 256 == 0): out is written in the blocked GEMM-operand layout (GemmArgs::blk)
+extern int g_ln_vec;
 int launch_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, int M, int D,
-                     hipStream_t s, int split = 0);
+                     hipStream_t s, int split = 0, int blk = 0);
 // residual update fused with LayerNorm: x[m][:] += bias + sum_s partial[s][m][:]  (fixed order -> deterministic),
 // then out = LayerNorm(x).  Consumer side of the split-K decode GEMMs.
 int launch_layernorm_resid(int dtype, float* x, const float* partial, int ksplit, const float* bias, const float* w,
@@ -76,8 +88,9 @@ int launch_f32_to_T(int dtype, const float* in, void* out, int64_t n, hipStream_
 // ---------------- attention --------------------------------------------------------------------
 // encoder: Q,K [B][H][Tpad][64], Vt [B][H][64][Tpad] (T dtype) -> out T [B][T][H*64]
 extern int g_attn_enc_variant;
+// out_blk != 0 (16-bit): out is written in the blocked GEMM-operand layout (GemmArgs::blk) over B*T rows, H*64 columns
 int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt, void* out, int B, int T,
-                         int Tpad, int H, hipStream_t s);
+                         int Tpad, int H, hipStream_t s, int out_blk = 0);
 // decode: q T [G*nb][H*64]; K,V laid out [group][H][kv_stride][64]. n_keys from n_keys_ptr (device,
 // +1 applied when SELF) or the constant n_keys.  row_map (device, may be NULL): for SELF attention,
 // src_row[r][j] = physical cache row holding position j of logical row r (beam indirection).

@@ -49,10 +49,75 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+
+// Vectorised form for D % 256 == 0 (the encoder widths: 1280 = 5 x 256): one wave per row, lane owns columns
+// 256 i + 4 lane .. + 3, so x / gamma / beta are 16-byte loads and the output an 8-byte store (the scalar kernel above moves
+// 4 + 2 bytes per lane and instruction: 1.7 TB/s on the 144 000 x 1280 encoder rows).  blk != 0: the output goes out in the
+// blocked GEMM-operand layout [ceil(M / 256)][D / 32][256][32] (GemmArgs::blk) -- a lane's 4 columns never straddle a
+// 32-column block.  Same two-pass statistics; the summation order differs from the scalar kernel's (different partial sums).
+template <typename T, int NV4>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, T* __restrict__ out, int M, int blk) {
+  constexpr int D = NV4 * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+  float4 v[NV4], g[NV4], be[NV4];
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    v[i] = xr[i * 64 + lane];
+    g[i] = reinterpret_cast<const float4*>(w)[i * 64 + lane];
+    be[i] = reinterpret_cast<const float4*>(b)[i * 64 + lane];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+    q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int c = i * 256 + lane * 4;
+    float y[4] = {(v[i].x - mean) * rstd * g[i].x + be[i].x, (v[i].y - mean) * rstd * g[i].y + be[i].y,
+                  (v[i].z - mean) * rstd * g[i].z + be[i].z, (v[i].w - mean) * rstd * g[i].w + be[i].w};
+    const int64_t off = blk ? (((int64_t)(row >> 8) * (D >> 5) + (c >> 5)) << 13) + ((row & 255) << 5) + (c & 31)
+                            : (int64_t)row * D + c;
+    st4(out + off, y);
+  }
+}
+
+template <typename T>
+static bool launch_ln_vec(const float* x, const float* w, const float* b, T* out, int M, int D, int blk, hipStream_t s) {
+  dim3 grid(ceil_div(M, 4));
+  switch (D) {
+    case 256: hipLaunchKernelGGL((layernorm_vec_kernel<T, 1>), grid, dim3(256), 0, s, x, w, b, out, M, blk); return true;
+    case 512: hipLaunchKernelGGL((layernorm_vec_kernel<T, 2>), grid, dim3(256), 0, s, x, w, b, out, M, blk); return true;
+    case 768: hipLaunchKernelGGL((layernorm_vec_kernel<T, 3>), grid, dim3(256), 0, s, x, w, b, out, M, blk); return true;
+    case 1024: hipLaunchKernelGGL((layernorm_vec_kernel<T, 4>), grid, dim3(256), 0, s, x, w, b, out, M, blk); return true;
+    case 1280: hipLaunchKernelGGL((layernorm_vec_kernel<T, 5>), grid, dim3(256), 0, s, x, w, b, out, M, blk); return true;
+    default: return false;
+  }
+}
+
+int g_ln_vec = 1;   // wj_tune("ln_vec"): 0 = always the scalar kernel (A/B)
+
 int launch_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, int M, int D,
-                     hipStream_t s, int split) {
+                     hipStream_t s, int split, int blk) {
   if (D > 64 * 20 || D <= 0) { set_error("layernorm: D=%d unsupported (max 1280)", D); return WJ_E_INVALID; }
   if (M <= 0) return WJ_OK;
+  if (blk && (split || !is16(dtype) || (D % 256))) { set_error("layernorm: a blocked output needs a 16-bit type, D %% 256 == 0, no split"); return WJ_E_INVALID; }
+  if ((blk || g_ln_vec) && !split && is16(dtype) && (D % 256) == 0) {
+    const bool ok = dtype == WJ_F16 ? launch_ln_vec<f16_t>(x, w, b, (f16_t*)out, M, D, blk, s)
+                                    : launch_ln_vec<bf16_t>(x, w, b, (bf16_t*)out, M, D, blk, s);
+    if (ok) { WJ_LAUNCH_CHECK(); return WJ_OK; }
+    if (blk) { set_error("layernorm: no blocked-output kernel for D=%d", D); return WJ_E_INVALID; }
+  }
   dim3 grid(ceil_div(M, 4));
 #define WJ_LN(NV)                                                                                          \
   do {                                                                                                     \
