@@ -25,6 +25,7 @@ stream), ``cpu_baseline`` (the oracle on a bounded sample), ``stages``, and the 
 """
 import argparse
 import json
+import zlib
 import os
 import socket
 import subprocess
@@ -298,7 +299,10 @@ def run_recording(runner, audio, scene_subset=None, pooled=True):
     vad = runner.asr.get_vad_segments_per_scene()
     import zlib
     crc = zlib.crc32("|".join(f"{s['start']:.2f},{s['end']:.2f},{s['text']}" for s in merged).encode())    # A/B runs must agree
+    seg_hash = [zlib.crc32(f"{s['start']:.2f},{s['end']:.2f},{s['text']}".encode()) for s in merged]
     out = {"scenes": len(scenes), "segments": len(merged), "vad_segments": sum(len(v) for v in vad), "transcript_crc32": crc,
+           "segment_digest": int(sum(seg_hash) % (1 << 32)),        # order-independent: the ranks' digests of a sharded run add up
+           **({"segment_hashes": seg_hash} if os.environ.get("WJ_BENCH_SEGMENT_HASHES") == "1" and len(seg_hash) <= 4000 else {}),
            "scene_audio_s": round(sum(b - a for a, b in scenes), 1), "t_scene": round(t1 - t0, 4), "t_asr_incl_vad": round(t2 - t1, 4)}
     st = getattr(wm, "decode_stats", None)
     if st and st["windows"]:
@@ -410,7 +414,8 @@ def run_cfg3(args, info, dims):
     dev_blob, offsets = sharding.broadcast_blob(box.get("blob"), box.get("offsets"), dev)     # the ONE collective
     box.pop("blob", None)
     model, module, runner = build_stack(args, info, dims, dtype, args.batch, blob=dev_blob, offsets=offsets, mode=args.mode)
-    log(f"[bench] rank {info.rank}: audio {t_audio:.1f}s, weights + broadcast + model ready after {time.perf_counter() - t_start:.1f}s; "
+    init_s = time.perf_counter() - t_start
+    log(f"[bench] rank {info.rank}: audio {t_audio:.1f}s, weights + broadcast + model ready after {init_s:.1f}s; "
         f"workspace {model.model.workspace_bytes / 2**30:.1f} GiB, blob {dev_blob.numel() / 2**30:.2f} GiB")
 
     subset = None
@@ -420,8 +425,14 @@ def run_cfg3(args, info, dims):
 
     stats = None
     pooled = not args.per_scene
-    for _ in range(args.warmup):
+    cold_s = None
+    for i in range(args.warmup):
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
         stats = run_recording(runner, audio, subset, pooled)
+        torch.cuda.synchronize()
+        if i == 0:
+            cold_s = time.perf_counter() - tc          # the first pass of the process: kernel attributes, graph captures, allocator growth
     sharding.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -467,6 +478,12 @@ def run_cfg3(args, info, dims):
                     "max_new_tokens": args.max_new_tokens, "beam": args.beam, "patience": 1.2,
                     "decode_last_step": (stats or {}).get("decode"), "scenes": (stats or {}).get("scenes"),
                     "vad_segments": (stats or {}).get("vad_segments")},
+                # what ONE file costs a user who starts the process for it: synthetic-weight generation +
+                # pack + broadcast + engine creation (a real checkpoint load replaces the first part), then the first, cold pass
+                "cold_start": {"init_s": round(init_s, 1), "first_pass_s": None if cold_s is None else round(cold_s, 2),
+                               "single_file_rtfx": None if cold_s is None else round(60.0 * minutes / (init_s + cold_s), 1),
+                               "what": ("init_s = synthetic weights + pack + broadcast + workspaces of this rank; single_file_rtfx = recording seconds / "
+                                        "(init_s + first pass): one cold %g-min file end to end, against `value` = the steady state of a resident engine" % minutes)},
                 "roofline": None, "cpu_baseline": None, "stages": {}}
 
     # ---- extras on rank 0 of a single-GPU run: live stage profile, CPU baseline, secondary figures ---------------
@@ -595,6 +612,22 @@ def run_cfg3(args, info, dims):
                                       f"of the same recording, same pipeline, 64 windows per batch, one cold pass"), **s32}
         del m32, mod32, run32
         torch.cuda.empty_cache()
+    if info.rank == 0 and info.world == 1 and not args.no_extras and args.cfg5_clips > 0 and args.mode == "balanced":
+        # BASELINE cfg5 (Qwen3-ASR + forced aligner) in the same line, so that the driver's run records it: see cfg5_measure
+        if time.perf_counter() - t_start > args.extras_budget_s:
+            line["config"]["cfg5_skipped"] = "time budget"
+        else:
+            saved = args.qwen_batch
+            args.qwen_batch = args.cfg5_clips
+            try:
+                c5 = cfg5_measure(args, info, steps=2, warmup=1, want_cpu=not args.no_cpu_baseline, want_stages=True)
+                line["cfg5"] = {"rtfx": c5["value"], "ms": c5["ms_per_step"], "config": c5["config"], "roofline": c5["roofline"],
+                                "cpu_baseline": c5["cpu_baseline"],
+                                "what": "python bench.py --workload cfg5 (2 timed steps after 1 warm-up) run inside the default command"}
+            except Exception as e:
+                log(f"[bench] cfg5 figure failed: {type(e).__name__}: {e}")
+                line["cfg5"] = {"error": f"{type(e).__name__}: {e}"}
+            args.qwen_batch = saved
     if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
         dst = (stats or {}).get("decode") or {}
         spw = dst["window_steps_run"] / dst["windows"] if dst.get("windows") else None
@@ -681,26 +714,27 @@ def run_cfg2(args, info, dims):
 # ---------------------------------------------------------------------------------------------------------------
 # cfg5, first slice: Qwen3-ASR audio tower + decoder on the device (greedy), synthetic weights of the published geometry
 # ---------------------------------------------------------------------------------------------------------------
-def cpu_baseline_cfg5(d, ad, w, clips, n_new, threads):
+def cpu_baseline_cfg5(d, ad, w, clips, budgets, penalty, threads):
     """A bounded sample of the step's clips on this host's cores, one clip at a time as the reference's generator does
-    (modules/qwen_asr.py:1270-1290): log-mel, audio tower, prompt, prefill and `n_new` greedy tokens through the fp32 oracle."""
+    (modules/qwen_asr.py:1270-1290): log-mel, audio tower, prompt, prefill and greedy generation to EOS (per-clip budget,
+    repetition penalty) through the fp32 oracle."""
     from oracle import logmel, qwen3_ref
     torch.set_num_threads(threads)
     od = qwen3_ref.Qwen3AsrDims(n_mels=ad.n_mels, a_layers=ad.n_layer, a_heads=ad.n_head, a_ffn=ad.ffn, a_d=ad.d_model, n_window=ad.n_window,
                                 n_window_infer=ad.n_window_infer, conv_hidden=ad.conv_hidden, d=d.hidden, layers=d.n_layer, heads=d.n_head,
                                 kv_heads=d.n_kv_head, head_dim=d.head_dim, ffn=d.ffn, vocab=d.vocab, rope_theta=d.rope_theta, rms_eps=d.rms_eps,
-                                audio_token_id=d.audio_token_id, eos_token_ids=(d.vocab - 1,))
+                                audio_token_id=d.audio_token_id, eos_token_ids=tuple(d.eos_token_ids))
     oracle = qwen3_ref.Qwen3AsrOracle(od, w)
     t_tower = t_dec = 0.0
     n_tok = []
     with torch.no_grad():
-        for c in clips:
+        for c, lim in zip(clips, budgets):
             t0 = time.perf_counter()
             padded = np.pad(c, (0, max(0, 8000 - len(c))))
             a = oracle.audio_tokens(torch.from_numpy(logmel.logmel_ow(padded, ad.n_mels, padding=0)))
             t1 = time.perf_counter()
-            toks, _ = oracle.greedy([151644 % d.vocab, 872 % d.vocab] + [d.audio_token_id] * int(a.shape[0]) +
-                                    [151645 % d.vocab, 198, 151644 % d.vocab, 77091 % d.vocab], a, n_new)
+            toks, _ = oracle.greedy([151644, 872] + [d.audio_token_id] * int(a.shape[0]) + [151645, 198, 151644, 77091], a, int(lim),
+                                    repetition_penalty=penalty)
             t_tower += t1 - t0; t_dec += time.perf_counter() - t1
             n_tok.append(len(toks))
     audio = sum(len(c) for c in clips) / 16000.0
@@ -708,18 +742,18 @@ def cpu_baseline_cfg5(d, ad, w, clips, n_new, threads):
     return {"value": audio / total, "unit": UNIT, "cores": threads, "kind": "port", "sample_clips": len(clips), "sample_audio_s": round(audio, 2),
             "sample_seconds": round(total, 2), "t_mel_and_tower_s": round(t_tower, 2), "t_prefill_and_decode_s": round(t_dec, 2), "tokens": n_tok,
             "arithmetic": "fp32 (PyTorch-CPU)",
-            "sample": (f"{len(clips)} of the step's clips ({audio:.1f} s of audio), one at a time: log-mel + audio tower + prefill + "
-                       f"{n_new} greedy tokens through oracle/qwen3_ref.py on {threads} threads")}
+            "sample": (f"{len(clips)} of the step's clips ({audio:.1f} s of audio), one at a time: log-mel + audio tower + prefill + greedy "
+                       f"generation to EOS (repetition penalty {penalty:g}) through oracle/qwen3_ref.py on {threads} threads; no aligner pass")}
 
 
-def cfg5_roofline(dec_params, esz, clips, n_new, stages):
+def cfg5_roofline(dec_params, esz, clips, n_iter, stages):
     """The greedy decode iteration: every decoder weight is read once per iteration and multiplied by `clips` rows, i.e.
     `clips` FLOP per weight byte pair -- under the 310 FLOP/B ridge of the part the iteration is bound by the weight stream
     (HBM), above it by the matrix pipes.  Timing: host wall clock around wj_qwen_generate_greedy (a hipGraph replay per
     iteration), device synchronised either side, divided by the iterations."""
     if not stages.get("generate_ms"):
         return None
-    sec = stages["generate_ms"] * 1e-3 / n_new
+    sec = stages["generate_ms"] * 1e-3 / max(1, n_iter)
     if clips * 2.0 / esz < MFMA_RIDGE_FLOP_PER_BYTE:
         ach = dec_params * esz / sec / 1e9
         return {"bound": "hbm", "kernel": "greedy decode iteration (decoder weights streamed once)", "achieved": round(ach, 1),
@@ -731,20 +765,47 @@ def cfg5_roofline(dec_params, esz, clips, n_new, stages):
             "traffic": None, "note": "attention, norms, top-1 and the launch gaps of the iteration are inside the time; GEMM-only figures: DESIGN.md"}
 
 
-def run_cfg5(args, info):
+QWEN_TS_TOKEN = 151705          # <timestamp> marker id (transformers' Qwen3ASRConfig.timestamp_token_id default)
+
+
+def cfg5_measure(args, info, steps, warmup, want_cpu, want_stages=True):
+    """BASELINE cfg5's hot path on one GPU, as the reference's Qwen pipeline configures it (pipelines/qwen_pipeline.py:157-158,
+    389-530; modules/qwen_asr.py:382-437, 1270-1290): per step, for every clip of the recording -- RAW log-mel -> audio tower ->
+    chat prompt -> ragged prefill -> greedy generation with repetition_penalty 1.1 and the per-clip token budget
+    (max_tokens_per_audio_second 20, floor 256) TO EOS (QwenEosRamp weights: sequences end at clip-dependent lengths) -> forced
+    aligner pass (its own tower + decoder + time-bin head, one classification pass over audio + words + <timestamp> markers).
+    Returns the bench line (metric / value / config / roofline / cpu_baseline) as a dict."""
     from whisperjav_amd import qwen
     dev = torch.device("cuda", info.local_rank)
     d, ad = qwen.Qwen3Dims(), qwen.Qwen3AudioDims()
+    ramp = qwen.QwenEosRamp.for_dims(d)
     t0 = time.perf_counter()
-    w = {**qwen.synth_weights(d, seed=1), **qwen.synth_audio_weights(ad, seed=2)}
-    B, n_new = args.qwen_batch, args.qwen_tokens
-    tower = qwen.HipQwenAudioTower(ad, w, dtype=args.dtype, device=info.local_rank, max_seconds=min(8 * B, 1024))
-    model = qwen.HipQwen3Decoder(d, w, dtype=args.dtype, device=info.local_rank, max_seqs=B, max_ctx=192, max_rows=B * 128)
-    if args.no_cpu_baseline or info.rank != 0:
-        w = None
-    log(f"[bench] cfg5: weights + engines ready after {time.perf_counter() - t0:.1f}s")
+    w = {**qwen.synth_weights(d, seed=1, eos=ramp), **qwen.synth_audio_weights(ad, seed=2, ramp=ramp)}
+    B = args.qwen_batch
+    penalty, rate, floor, max_new = args.qwen_repetition_penalty, args.qwen_tokens_per_second, args.qwen_token_floor, args.qwen_max_new
     rng = np.random.default_rng(5)
     secs = rng.uniform(2.0, 6.0, B)
+    budgets = [qwen.dynamic_token_limit(float(sv), max_new, rate, floor) for sv in secs]
+    ctx = 96 + max(budgets)                                  # <= 78 audio tokens + 6 template tokens, + the largest budget
+    tower = qwen.HipQwenAudioTower(ad, w, dtype=args.dtype, device=info.local_rank, max_seconds=min(8 * B, 1024))
+    model = qwen.HipQwen3Decoder(d, w, dtype=args.dtype, device=info.local_rank, max_seqs=B, max_ctx=ctx, max_rows=B * 128)
+    aligner = None
+    if args.qwen_aligner:
+        # Qwen3-ForcedAligner-0.6B (modules/qwen_asr.py:201): the published Qwen3-0.6B decoder geometry (28 x 1024, 16 / 8 heads of
+        # 128, ffn 3072) under the same audio tower geometry (assumed: the aligner's own config is not available offline) and a
+        # linear head over 80 ms time bins
+        da = qwen.Qwen3Dims(hidden=1024, n_layer=28, n_head=16, n_kv_head=8, head_dim=128, ffn=3072)
+        ada = qwen.Qwen3AudioDims(out_dim=1024)
+        wa = {**qwen.synth_weights(da, seed=3), **qwen.synth_audio_weights(ada, seed=4)}
+        n_bins = 512
+        head_w = torch.from_numpy((np.random.default_rng(6).standard_normal((n_bins, da.hidden)) * 2.0 / np.sqrt(da.hidden)).astype(np.float32))
+        a_tower = qwen.HipQwenAudioTower(ada, wa, dtype=args.dtype, device=info.local_rank, max_seconds=min(8 * B, 1024))
+        a_model = qwen.HipQwen3Decoder(da, wa, dtype=args.dtype, device=info.local_rank, max_seqs=B, max_ctx=96 + 3 * 80, max_rows=B * 288)
+        aligner = (da, a_tower, a_model, head_w.to(dev, torch.float16 if args.dtype == "float16" else torch.bfloat16 if args.dtype == "bfloat16" else torch.float32))
+        wa = None
+    if not want_cpu:
+        w = None
+    log(f"[bench] cfg5: weights + engines ready after {time.perf_counter() - t0:.1f}s")
     clips = [synth.speech_like(float(sv), seed=500 + i) for i, sv in enumerate(secs)]
     audio_s = float(sum(len(c) for c in clips)) / 16000.0
     host_sample = [c.copy() for c in clips[:4]]          # ~15-30 s of host work at the 1.7 B geometry
@@ -754,28 +815,53 @@ def run_cfg5(args, info):
         return [151644, 872] + [d.audio_token_id] * int(a.shape[0]) + [151645, 198, 151644, 77091]
 
     def generate(emb):
-        if args.qwen_repetition_penalty == 1.0:
-            return model.generate(max_new_tokens=n_new, eos_token_ids=(d.vocab - 1,))
-        return model.generate(max_new_tokens=n_new, eos_token_ids=(d.vocab - 1,), repetition_penalty=args.qwen_repetition_penalty,
-                              prompt_ids=[prompt_ids(a) for a in emb])
+        ids = [prompt_ids(a) for a in emb]
+        model.prefill_packed(*model.prompt_embeddings_many(ids, emb))
+        return model.generate(max_new_tokens=max(budgets), repetition_penalty=penalty, prompt_ids=ids if penalty != 1.0 else None,
+                              max_new_per_seq=budgets)
+
+    def align(res):
+        """every generated token is a "word": prompt = audio placeholders + (word, <timestamp>, <timestamp>) per word, one
+        classification pass, arg-max bin at every marker (HipQwenForcedAligner._align_uncached without the tokenizer plug-ins)"""
+        da, a_tower, a_model, head_w = aligner
+        emb = a_tower.encode(clips)
+        prompts, rows = [], []
+        for a, toks in zip(emb, res.tokens):
+            toks = toks[:80]
+            ids = [151644, 872] + [da.audio_token_id] * int(a.shape[0])
+            marks = []
+            for t in toks:
+                ids.append(int(t) if int(t) != da.audio_token_id else 0)
+                marks += [len(ids), len(ids) + 1]
+                ids += [QWEN_TS_TOKEN, QWEN_TS_TOKEN]
+            if not marks:                       # a clip whose transcript is empty is not aligned (aligners/qwen3.py:171-179): a one-marker dummy keeps the batch rectangular
+                marks = [len(ids)]
+                ids.append(QWEN_TS_TOKEN)
+            prompts.append(ids); rows.append(marks)
+        packed, n = a_model.prompt_embeddings_many(prompts, emb)
+        edges = np.concatenate([[0], np.cumsum(n)])
+        labels = a_model.classify([packed[edges[k]: edges[k + 1]] for k in range(len(prompts))], rows, head_w)
+        return labels, int(n.sum())
 
     def step():
         emb = tower.encode(clips)
-        model.prefill_packed(*model.prompt_embeddings_many([prompt_ids(a) for a in emb], emb))
-        return generate(emb)
-    for _ in range(args.warmup):
+        res = generate(emb)
+        lab = align(res) if aligner else None
+        return res, lab
+    for _ in range(warmup):
         step()
     sharding.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    for _ in range(steps):
+        res, lab = step()
     torch.cuda.synchronize()
     sharding.barrier()
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev)
-    rtfx = audio_s * args.steps * info.world / elapsed
+    rtfx = audio_s * steps * info.world / elapsed
+    lens = np.array([len(t) for t in res.tokens])
     stages = {}
-    if info.rank == 0 and not args.no_profile:      # one more, untimed pass with a device sync after every stage
+    if info.rank == 0 and want_stages:      # one more, untimed pass with a device sync after every stage
         def timed(name, fn):
             torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize()
             stages[name] = round(1e3 * (time.perf_counter() - t), 2)
@@ -783,9 +869,15 @@ def run_cfg5(args, info):
         mel, frames = timed("log_mel_ms", lambda: tower.features(clips[:min(len(clips), 128)]))
         stages["log_mel_ms"] = round(stages["log_mel_ms"] * len(clips) / min(len(clips), 128), 2)      # measured on 128 clips, scaled
         emb = timed("audio_tower_ms", lambda: tower.encode(clips))
-        packed, n_tok = timed("prompt_assembly_ms", lambda: model.prompt_embeddings_many([prompt_ids(a) for a in emb], emb))
+        ids = [prompt_ids(a) for a in emb]
+        packed, n_tok = timed("prompt_assembly_ms", lambda: model.prompt_embeddings_many(ids, emb))
         timed("prefill_ms", lambda: model.prefill_packed(packed, n_tok))
-        timed("generate_ms", lambda: generate(emb))
+        r2 = timed("generate_ms", lambda: model.generate(max_new_tokens=max(budgets), repetition_penalty=penalty,
+                                                         prompt_ids=ids if penalty != 1.0 else None, max_new_per_seq=budgets))
+        stages["decode_iterations"] = r2.steps
+        if aligner:
+            _, arows = timed("aligner_ms", lambda: align(r2))
+            stages["aligner_rows"] = arows
         stages["audio_tower_ms"] = round(stages["audio_tower_ms"] - stages["log_mel_ms"], 2)      # encode() recomputes the features
         stages["prompt_rows"] = int(n_tok.sum())
         del mel, frames
@@ -793,28 +885,46 @@ def run_cfg5(args, info):
     if info.rank == 0 and w is not None:
         try:
             threads = args.cpu_threads or min(32, os.cpu_count() or 1)
-            cpu = cpu_baseline_cfg5(d, ad, w, host_sample, n_new, threads)
+            cpu = cpu_baseline_cfg5(d, ad, w, host_sample, [budgets[i] for i in range(len(host_sample))], penalty, threads)
         except Exception as e:      # a reported figure, never a reason to lose the measured line
             log(f"[bench] cfg5 cpu_baseline skipped: {type(e).__name__}: {e}")
         w = None
+    line = None
     if info.rank == 0:
         esz = 4 if args.dtype == "float32" else 2
         dec_params = d.n_layer * (d.hidden * (d.n_head + 2 * d.n_kv_head) * d.head_dim + d.n_head * d.head_dim * d.hidden + 3 * d.hidden * d.ffn) + d.vocab * d.hidden
-        print(json.dumps({
+        line = {
             "metric": METRIC, "value": round(rtfx, 2), "unit": UNIT, "audio_hours_per_sec": round(rtfx / 3600.0, 5), "n_gpus": info.world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": DT_LABEL[args.dtype], "data": "synthetic",
-            "config": {"workload": (f"cfg5, first slice: Qwen3-ASR-1.7B geometry (seeded random weights), {B} clips of 2-6 s per step: RAW log-mel -> "
-                                    f"audio tower -> ragged prefill -> greedy decode of {n_new} tokens (random weights never emit EOS, so every clip "
-                                    f"decodes all {n_new}); no TEN-VAD, no forced aligner, fp16 weights; the clips' samples are resident in "
-                                    f"HBM when the step starts; repetition_penalty {args.qwen_repetition_penalty:g} (the reference pipeline's "
-                                    f"default is 1.1 = one more small kernel per iteration, transformers' processor: --qwen-repetition-penalty 1.1)"),
-                       "clips_per_step": B, "audio_seconds_per_step": round(audio_s, 1), "decode_tokens": n_new,
-                       "tokens_generated": int(sum(len(t) for t in res.tokens)),
-                       "decoder_weight_bytes_per_step": dec_params * esz, "stages": stages},
-            "roofline": cfg5_roofline(dec_params, esz, B, n_new, stages),
-            "cpu_baseline": cpu}), flush=True)
+            "config": {"workload": (f"cfg5: Qwen3-ASR-1.7B geometry (seeded random weights with the end-of-sequence ramp of qwen.QwenEosRamp), {B} clips of "
+                                    f"2-6 s per step (= {audio_s / 60:.0f} min of audio in one batch), samples resident in HBM: RAW log-mel -> audio tower -> "
+                                    f"ragged prefill -> greedy generation TO EOS with repetition_penalty {penalty:g} and per-clip budgets "
+                                    f"(max_tokens_per_audio_second {rate:g}, floor {floor}, cap {max_new}: the reference pipeline's controls)"
+                                    + (" -> forced-aligner pass (Qwen3-0.6B decoder geometry + audio tower + 512-bin head, every generated token a word)"
+                                       if aligner else " ; no aligner pass")
+                                    + f"; float16 with split activations (wj_tune qwen_split_act, default 2); no TEN-VAD (clips are given), fp16 weights (no fp8)"),
+                       "clips_per_step": B, "audio_seconds_per_step": round(audio_s, 1),
+                       "tokens_generated": int(lens.sum()), "tokens_per_clip": {"mean": round(float(lens.mean()), 1), "min": int(lens.min()), "max": int(lens.max())},
+                       "ended_on_eos": int((lens < np.array(budgets)).sum()), "decode_iterations": res.steps,
+                       "context_limited": int(sum(res.context_limited or [])),
+                       "aligner_bins_crc32": (zlib.crc32(np.concatenate(lab[0]).astype(np.int32).tobytes()) if lab else None),
+                       "tokens_crc32": zlib.crc32(np.concatenate([np.asarray(t, dtype=np.int32) for t in res.tokens] + [np.zeros(0, np.int32)]).tobytes()),
+                       "decoder_weight_bytes_per_iteration": dec_params * esz, "stages": stages},
+            "roofline": cfg5_roofline(dec_params, esz, B, stages.get("decode_iterations") or res.steps, stages),
+            "cpu_baseline": cpu}
     tower.close(); model.close()
+    if aligner:
+        aligner[1].close(); aligner[2].close()
+    del clips
+    torch.cuda.empty_cache()
+    return line
+
+
+def run_cfg5(args, info):
+    line = cfg5_measure(args, info, args.steps, args.warmup, want_cpu=not args.no_cpu_baseline and info.rank == 0, want_stages=not args.no_profile)
+    if info.rank == 0:
+        print(json.dumps(line), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     return 0
@@ -827,9 +937,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg2", "cfg5"])
     ap.add_argument("--qwen-batch", type=int, default=1800, help="cfg5: clips per step (1800 clips of 2-6 s = the 120-minute recording of BASELINE cfg5 in one batch)")
-    ap.add_argument("--qwen-tokens", type=int, default=32, help="cfg5: greedy tokens per clip")
-    ap.add_argument("--qwen-repetition-penalty", type=float, default=1.0, help="cfg5: transformers' repetition penalty over prompt + "
-                    "generated ids (reference pipeline default 1.1; the round-3 figures were measured at 1.0)")
+    ap.add_argument("--qwen-max-new", type=int, default=4096, help="cfg5: cap of the per-clip token budget (the reference's max_new_tokens)")
+    ap.add_argument("--qwen-tokens-per-second", type=float, default=20.0, help="cfg5: max_tokens_per_audio_second (reference default)")
+    ap.add_argument("--qwen-token-floor", type=int, default=256, help="cfg5: floor of the per-clip budget (reference: 256)")
+    ap.add_argument("--qwen-repetition-penalty", type=float, default=1.1, help="cfg5: transformers' repetition penalty over prompt + "
+                    "generated ids (reference pipeline default 1.1)")
+    ap.add_argument("--no-qwen-aligner", dest="qwen_aligner", action="store_false", help="cfg5: leave the forced-aligner pass out of the step")
+    ap.add_argument("--cfg5-clips", type=int, default=1800, help="default line: clips of the cfg5 figure (0 = skip it)")
     ap.add_argument("--minutes", type=float, default=120.0, help="cfg3: length of the synthetic recording")
     ap.add_argument("--mode", default="balanced", choices=["balanced", "fidelity"],
                     help="cfg3 = balanced (faster-whisper contract); fidelity = the openai-whisper contract of FidelityPipeline (BASELINE cfg4 with --strong)")

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 3
+#define WJ_ABI_VERSION 4
 
 enum {
   WJ_OK = 0,
@@ -290,6 +290,12 @@ int wj_qwen_generate_greedy_ex(wj_qwen* m, const int32_t* eos_ids_host, int n_eo
 
 /* 1 if the last wj_qwen_generate_greedy replayed its decode iteration from a hipGraph */
 int wj_qwen_last_used_graph(const wj_qwen* m);
+/* ABI 4.  Decode iterations the last generation ran (the loop polls the per-sequence finished flags every 8 iterations and
+ * leaves when every sequence has ended on EOS or on its budget), and the number of sequences whose token budget was cut to the
+ * room left in the KV cache (max_ctx - prompt length; the reference budgets up to 4096 new tokens, qwen_asr.py:414-437 --
+ * size max_ctx for prompt + budget, or read this count). */
+int wj_qwen_last_steps(const wj_qwen* m);
+int wj_qwen_last_truncated(const wj_qwen* m);
 
 /* Token classification over a full (non-generative) pass: the forced aligner (Qwen3-ForcedAligner-0.6B, reference
  * whisperjav/modules/qwen_asr.py:1198-1320 -> TextAligner, protocols.py:128-179) is this decoder + audio tower with a
@@ -407,6 +413,8 @@ typedef struct wj_comm wj_comm;
 int wj_comm_unique_id(char out[128]);
 int wj_comm_init(wj_ctx* ctx, int nranks, int rank, const char id[128], wj_comm** out);
 int wj_bcast_weights(wj_comm* comm, void* blob_dev, int64_t bytes, int root, void* stream);
+/* ABI 4: the rank count RCCL reports for the communicator (ncclCommCount), for multi-GPU assertions */
+int wj_comm_count(wj_comm* comm, int* n_ranks_out);
 int wj_comm_destroy(wj_comm* comm);
 
 /* ---- kernel-level entry points (parity tests and micro-benchmarks only) ----------------- */

@@ -610,6 +610,8 @@ int main(int argc, char** argv) {
   unsigned long long* d_cnt;
   CK(hipMalloc(&d_cnt, 8));
 
+  struct Sweep { const char* key; int value, dflt, variant; };
+  std::vector<Sweep> sweeps;   // extra runs: wj_tune(key, value), variant, wj_tune(key, dflt)
   auto run_set = [&](const std::vector<Shape>& shapes, int ref_variant, const std::vector<int>& variants,
                      const std::vector<std::pair<const char*, int>>& tune_ab) {
     for (const Shape& sh : shapes) {
@@ -676,6 +678,7 @@ int main(int argc, char** argv) {
       for (auto& t : tune_ab) { one(ref_variant, t.first, t.second); }
       for (auto& t : tune_ab) WJ(L.tune(t.first, 1));   // back to the defaults (all A/B keys used here default to 1)
       for (int v : variants) one(v, nullptr, 0);
+      for (auto& sw : sweeps) { one(sw.variant, sw.key, sw.value); WJ(L.tune(sw.key, sw.dflt)); }
       CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(bias)); CK(hipFree(Cref)); CK(hipFree(C));
     }
   };
@@ -687,6 +690,14 @@ int main(int argc, char** argv) {
         {"enc_fc1", M, 5120, 1280, 1, 0}, {"enc_fc2", M, 1280, 5120, 0, 0}, {"enc_qk", M, 2560, 1280, 0, 0},
         {"enc_out", M, 1280, 1280, 0, 0}, {"enc_out_f32", M, 1280, 1280, 0, 1}};
     run_set(enc, 6, {86, 83, 88, 89}, {});
+  }
+  if (what == "ppb") {   // blocked ring kernel: ring depth and tile-group size (round 4)
+    const int M = 144128;
+    std::vector<Shape> enc = {{"enc_fc1", M, 5120, 1280, 1, 0}, {"enc_fc2", M, 1280, 5120, 0, 0}, {"enc_qk", M, 2560, 1280, 0, 0},
+                              {"enc_out_f32", M, 1280, 1280, 0, 1}};
+    sweeps = {{"ppb_ns", 3, 4, 88}, {"ppb_ns", 5, 4, 88}, {"ppb_gm", 4, 8, 88}, {"ppb_gm", 16, 8, 88}, {"ppb_gm", 32, 8, 88}};
+    run_set(enc, 6, {88, 88}, {});
+    sweeps.clear();
   }
   if (what == "dma") {
     for (auto sh : {Shape{"fc2", 144128, 1280, 5120, 0, 0}, Shape{"qk", 144128, 2560, 1280, 0, 0}, Shape{"fc1", 144128, 5120, 1280, 0, 0}}) {

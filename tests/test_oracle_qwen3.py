@@ -41,7 +41,7 @@ DIMS = qwen3_ref.Qwen3AsrDims(n_mels=32, a_layers=2, a_heads=2, a_ffn=96, a_d=48
                               audio_token_id=7, eos_token_ids=(1, 2))
 
 
-@pytest.mark.parametrize("n_frames", [100, 250, 730])
+@pytest.mark.parametrize("n_frames", [30, 60, 100, 250, 730])      # 30 / 60: a sub-second clip alone (its tail chunk is 100 frames wide here AND in transformers)
 def test_audio_tower_and_projector_match_transformers(n_frames):
     model, sd = tiny(DIMS)
     oracle = qwen3_ref.Qwen3AsrOracle(DIMS, sd)

@@ -118,6 +118,96 @@ def test_silero_v31_v40_never_substitutes_the_network():
         vad_weights.classify_state_dict({"foo.weight": np.zeros(1)})
 
 
+def _fake_hub_archive():
+    """Stand-in for ``torch.hub.load("snakers4/silero-vad:v3.1", "silero_vad")``: a "model" and a ``get_speech_timestamps``
+    with the v3.1 / v4.0 keyword API that records how it was called (the reference's own suite fakes this seam the same way,
+    tests/test_vad_threshold_padding_e2e.py:400-575)."""
+    calls = []
+
+    def get_speech_timestamps(audio, model, sampling_rate=16000, threshold=0.5, min_speech_duration_ms=250,
+                              min_silence_duration_ms=100, speech_pad_ms=30):
+        import torch
+        assert isinstance(audio, torch.Tensor) and audio.dtype == torch.float32 and audio.device.type == "cpu"
+        calls.append(dict(n=len(audio), model=model, sampling_rate=sampling_rate, threshold=threshold,
+                          min_speech_duration_ms=min_speech_duration_ms, min_silence_duration_ms=min_silence_duration_ms,
+                          speech_pad_ms=speech_pad_ms))
+        n = len(audio)
+        return [{"start": 1536 * 3, "end": 1536 * 9}, {"start": 1536 * 10, "end": min(n, 1536 * 30)}, {"start": n - 4000, "end": n - 100}]
+    return ("jit-model", (get_speech_timestamps, None, None, None, None)), calls
+
+
+@pytest.mark.parametrize("version", ["v3.1", "v4.0"])
+def test_silero_v31_v40_host_scorer_seam_equals_the_reference_class(version):
+    """``scorer=`` keeps the reference's own v3.1 / v4.0 network (scoring on the host through the archive's
+    ``get_speech_timestamps``) and the HIP path takes over downstream.  With the same fake archive behind both, the drop-in and
+    the REFERENCE's ``SileroSpeechSegmenter`` (run from source) must make the same call and return the same segments and groups."""
+    import importlib.util
+    import sys
+    import types
+    archive, calls = _fake_hub_archive()
+    seg = segmenters.HipSileroSpeechSegmenter(version=version, scorer=lambda: archive, threshold=0.2, speech_pad_ms=500)
+    assert seg.can_score and seg.name == f"silero-{version}-hip+hostnet" and "host" in seg.display_name
+    rng = np.random.default_rng(4)
+    audio = (0.1 * rng.standard_normal(16000 * 9)).astype(np.float32)
+    got = seg.segment(audio, sample_rate=16000)
+    assert len(calls) == 1 and calls[0]["model"] == "jit-model"
+    assert {k: calls[0][k] for k in ("sampling_rate", "threshold", "min_speech_duration_ms", "min_silence_duration_ms", "speech_pad_ms")} == \
+        dict(sampling_rate=16000, threshold=0.2, min_speech_duration_ms=seg.min_speech_duration_ms,
+             min_silence_duration_ms=seg.min_silence_duration_ms, speech_pad_ms=500)
+    assert [(s_.start_sample, s_.end_sample) for s_ in got.segments][0] == (max(0, 1536 * 3 - 11200), 1536 * 9 + 20800)
+    # the reference's class over the same archive
+    base = "/root/reference/whisperjav/modules/speech_segmentation"
+    if not __import__("os").path.exists(base):
+        pytest.skip("reference tree not present")
+    pkg = "refseg_r4"
+    for name, rel in ((pkg, None), (pkg + ".backends", None), (pkg + ".base", "base.py"), (pkg + ".backends.silero", "backends/silero.py")):
+        if rel is None:
+            mod = types.ModuleType(name); mod.__path__ = []
+        else:
+            spec = importlib.util.spec_from_file_location(name, f"{base}/{rel}")
+            mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        if rel is not None:
+            sys.modules.setdefault("whisperjav", types.ModuleType("whisperjav"))
+            if "whisperjav.utils.logger" not in sys.modules:
+                import logging
+                lg = types.ModuleType("whisperjav.utils.logger"); lg.logger = logging.getLogger("ref")
+                sys.modules["whisperjav.utils"] = types.ModuleType("whisperjav.utils"); sys.modules["whisperjav.utils.logger"] = lg
+            try:
+                spec.loader.exec_module(mod)
+            except Exception as e:      # the reference module imports siblings relatively: fall back to the committed fixtures' loader
+                pytest.skip(f"reference silero backend not importable stand-alone: {type(e).__name__}: {e}")
+    ref_cls = sys.modules[pkg + ".backends.silero"].SileroSpeechSegmenter
+    ref = ref_cls(version=version, threshold=0.2, speech_pad_ms=500)
+    ref._model, ref._utils = archive[0], archive[1]
+    ref._get_speech_timestamps = archive[1][0]
+    want = ref.segment(audio, sample_rate=16000)
+    assert [(s_.start_sample, s_.end_sample) for s_ in got.segments] == [(s_.start_sample, s_.end_sample) for s_ in want.segments]
+    assert [[(s_.start_sample, s_.end_sample) for s_ in g] for g in got.groups] == [[(s_.start_sample, s_.end_sample) for s_ in g] for g in want.groups]
+    assert calls[1] == calls[0]
+
+
+def test_standalone_factory_fails_before_any_audio_for_the_kernel_less_network():
+    """the stand-alone factory (no whisperjav package) raises when asked for silero-v3.1 / v4.0 without a scorer,
+    instead of constructing a segmenter that refuses at its first ``segment`` call."""
+    import sys
+    from whisperjav_amd import asr, hipbind
+    if "whisperjav.modules.speech_segmentation" in sys.modules:
+        pytest.skip("the reference's factory is importable: its registry decides")
+    try:
+        import whisperjav.modules.speech_segmentation  # noqa: F401
+        pytest.skip("the reference's factory is importable: its registry decides")
+    except Exception:
+        pass
+    for backend in ("silero", "silero-v3.1", "silero-v4.0-hip"):
+        with pytest.raises(hipbind.WjError, match="silero-v6.2-hip"):
+            asr.HipFasterWhisperProASR._create_segmenter(backend, {})
+    archive, _ = _fake_hub_archive()
+    seg = asr.HipFasterWhisperProASR._create_segmenter("silero-v3.1", {"scorer": archive})
+    assert seg.can_score and seg.version == "v3.1"
+    assert asr.HipFasterWhisperProASR._create_segmenter("silero-v4.0", {"network": "v6", "weights": "synthetic"}).can_score
+
+
 def test_silero_torchscript_archives_light_up_when_present(tmp_path):
     """Skipped offline.  With the ``silero_vad`` wheel: its bundled archive classifies as v5/v6 and feeds the HIP blob
     packer; with a torch.hub cache of snakers4/silero-vad v3.1 / v4.0: the archive classifies as the legacy generation and

@@ -164,3 +164,25 @@ def test_silero_vad_probabilities_and_timestamps():
         mine = silero_ref.speech_timestamps(silero_ref.SileroOracle(w).probs(audio), len(audio), threshold=thr,
                                             min_speech_duration_ms=100, min_silence_duration_ms=100, speech_pad_ms=pad)
         assert [(s["start"], s["end"]) for s in stamps] == [(s["start"], s["end"]) for s in mine]
+
+
+def test_silero_v31_hub_archive_behind_the_hip_segmenter():
+    """W-test (skipped offline): with the ``snakers4/silero-vad:v3.1`` archive in the torch.hub cache, ``scorer="torch.hub"``
+    loads it exactly as the reference does (backends/silero.py:199-206) and the drop-in returns what the archive's own
+    ``get_speech_timestamps`` returns plus the reference's padding -- ``--mode balanced`` with the reference defaults, end to end."""
+    import os
+    import torch
+    hub = os.path.join(torch.hub.get_dir(), "snakers4_silero-vad_v3.1")
+    if not os.path.isdir(hub):
+        pytest.skip("torch.hub cache has no snakers4/silero-vad:v3.1 archive (no network here)")
+    from whisperjav_amd import segmenters, synth
+    seg = segmenters.HipSileroSpeechSegmenter(version="v3.1", scorer="torch.hub")
+    audio = synth.speech_like(12.0, seed=3)
+    got = seg.segment(audio, sample_rate=16000)
+    model, utils = torch.hub.load(repo_or_dir="snakers4/silero-vad:v3.1", model="silero_vad", onnx=False, trust_repo=True)
+    ref = utils[0](torch.from_numpy(audio), model, sampling_rate=16000, threshold=seg.threshold,
+                   min_speech_duration_ms=seg.min_speech_duration_ms, min_silence_duration_ms=seg.min_silence_duration_ms,
+                   speech_pad_ms=seg.speech_pad_ms)
+    assert len(got.segments) == len(ref)
+    for s_, r in zip(got.segments, ref):
+        assert s_.end_sample == min(len(audio) - 16, r["end"] + 20800)

@@ -251,7 +251,17 @@ class HipFasterWhisperProASR:
                 import inspect
                 accepted = set(inspect.signature(cls.__init__).parameters)
                 config = {k: v for k, v in config.items() if k in accepted}
-            return cls(**config)
+            seg = cls(**config)
+            if getattr(seg, "can_score", True) is False:
+                # the v3.1 / v4.0 class used to be constructed here and to refuse only at its first segment() call --
+                # after the model load and the scene split.  Fail before any audio is processed, and say what works.
+                from .hipbind import WjError
+                raise WjError(f"speech segmenter {backend!r}: the Silero {seg.version} network has no HIP kernel and is never replaced "
+                              "silently.  Options: 'silero-v6.2-hip' (the v5/v6 network on the device, its own thresholds); "
+                              f"HipSileroSpeechSegmenter(version={seg.version!r}, scorer='torch.hub') when the torch.hub archive is on "
+                              "this box (the reference's own network scores on the host); or network='v6' to run the v6 scorer behind "
+                              f"the {seg.version} call contract knowingly")
+            return seg
 
     # ---- statistics hooks used by the pipelines -------------------------------------------------
     def _reset_runtime_statistics(self) -> None:

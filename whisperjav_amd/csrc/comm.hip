@@ -19,6 +19,7 @@ typedef int (*fn_init_rank)(rccl_comm_t*, int, rccl_unique_id, int);
 typedef int (*fn_bcast)(const void*, void*, size_t, int /*ncclDataType_t*/, int, rccl_comm_t, hipStream_t);
 typedef int (*fn_destroy)(rccl_comm_t);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_count)(rccl_comm_t, int*);
 
 struct Rccl {
   void* lib = nullptr;
@@ -27,6 +28,7 @@ struct Rccl {
   fn_bcast bcast = nullptr;
   fn_destroy destroy = nullptr;
   fn_errstr errstr = nullptr;
+  fn_count count = nullptr;       // ncclCommCount (optional: diagnostics)
 };
 Rccl g_rccl;
 
@@ -53,6 +55,7 @@ int load_rccl() {
   r.bcast = reinterpret_cast<fn_bcast>(dlsym(h, "ncclBroadcast"));
   r.destroy = reinterpret_cast<fn_destroy>(dlsym(h, "ncclCommDestroy"));
   r.errstr = reinterpret_cast<fn_errstr>(dlsym(h, "ncclGetErrorString"));
+  r.count = reinterpret_cast<fn_count>(dlsym(h, "ncclCommCount"));
   if (!r.get_id || !r.init_rank || !r.bcast || !r.destroy) { set_error("librccl lacks the expected nccl* symbols"); return WJ_E_UNSUPPORTED; }
   g_rccl = r;
   return WJ_OK;
@@ -106,6 +109,18 @@ int wj_bcast_weights(wj_comm* comm, void* blob_dev, int64_t bytes, int root, voi
   int rc = check_rccl(g_rccl.bcast(blob_dev, blob_dev, (size_t)bytes, /*ncclUint8*/ 1, root, comm->comm, s), "ncclBroadcast");
   if (rc) return rc;
   WJ_HIP(hipStreamSynchronize(s));
+  return WJ_OK;
+}
+
+int wj_comm_count(wj_comm* comm, int* n_ranks_out) {
+  WJ_REQUIRE(comm && n_ranks_out, "wj_comm_count: NULL argument");
+  // what RCCL itself says about the communicator this rank built (ncclCommCount through the same dlsym table), not the number
+  // the caller passed to wj_comm_init: a multi-GPU test asserts on it
+  if (!g_rccl.count) { set_error("wj_comm_count: this librccl exports no ncclCommCount"); return WJ_E_UNSUPPORTED; }
+  int n = 0;
+  int rc = check_rccl(g_rccl.count(comm->comm, &n), "ncclCommCount");
+  if (rc) return rc;
+  *n_ranks_out = n;
   return WJ_OK;
 }
 

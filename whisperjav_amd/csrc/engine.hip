@@ -801,6 +801,9 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "beam_compact_min")) g_tune.beam_compact_min = value;
   else if (!strcmp(key, "beam_topk_reg")) g_beam_topk_reg = value;
   else if (!strcmp(key, "gemm_big")) g_gemm_big = value;
+  else if (!strcmp(key, "ppb_ns")) g_ppb_ns = value;
+  else if (!strcmp(key, "qwen_split_act")) wj::g_qwen_split_act = value;
+  else if (!strcmp(key, "ppb_gm")) g_ppb_gm = value;
   else if (!strcmp(key, "epi_wide")) g_epi_wide = value;
   else if (!strcmp(key, "dec_ms_stages")) g_tune.dec_ms_stages = value;
   else if (!strcmp(key, "dec_ms_resid")) g_tune.dec_ms_resid = value;

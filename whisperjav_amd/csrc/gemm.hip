@@ -791,7 +791,7 @@ __global__ __launch_bounds__(512) void gemm_h_big_ppb_kernel(const GemmArgs g) {
   const int lin = blockIdx.y * nx + blockIdx.x;
   const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
-  constexpr int GM = 8;
+  const int GM = g.gm;
   const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
   const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
   const int mt = first_m + in_group % gsz, nt = in_group / gsz;
@@ -873,13 +873,29 @@ __global__ __launch_bounds__(512) void gemm_h_big_ppb_kernel(const GemmArgs g) {
   tile_epilogue<EPI, T, 8>(g, 0, mt * BBM + wm * 128, nt * BBN + wn * 64, lane, acc);
 }
 
+int g_ppb_ns = 4;   // wj_tune("ppb_ns"): ring stages of the blocked kernel (3 / 4 / 5)
+int g_ppb_gm = 8;   // wj_tune("ppb_gm"): row tiles per group of the tile order (L2 reuse of the W panels)
+
+template <typename T, int EPI, int NS>
+static int launch_big_ppb_ns(const GemmArgs& a, hipStream_t s);
+
 template <typename T, int EPI>
 static int launch_big_ppb(const GemmArgs& a, hipStream_t s) {
   if constexpr (EPI == EPI_PARTIAL_F32 || EPI == EPI_QKV_DEC || EPI == EPI_GELU_POS_F32) {
     set_error("gemm: blocked operands are an encoder-path feature (no split-K / decode / conv epilogues)");
     return WJ_E_INVALID;
   } else {
-    constexpr int NS = 4;
+    if (g_ppb_ns == 3) return launch_big_ppb_ns<T, EPI, 3>(a, s);
+    if (g_ppb_ns == 5) return launch_big_ppb_ns<T, EPI, 5>(a, s);
+    return launch_big_ppb_ns<T, EPI, 4>(a, s);
+  }
+}
+
+template <typename T, int EPI, int NS>
+static int launch_big_ppb_ns(const GemmArgs& a_in, hipStream_t s) {
+  {
+    GemmArgs a = a_in;
+    a.gm = g_ppb_gm > 0 ? g_ppb_gm : 8;
     if ((a.N % BBN) || (a.K % PBK) || a.K / PBK < NS + 1 || a.nbatch != 1 || a.split || a.split_out) {
       set_error("gemm: blocked operands need N %% 256 == 0, K %% 32 == 0, K >= 160, one batch, no split activations (N=%d K=%d)",
                 a.N, a.K);

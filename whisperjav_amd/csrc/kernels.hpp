@@ -52,6 +52,7 @@ struct GemmArgs {
   // window z = m / seq_T and position m % seq_T from the row index instead of from the batch dimension.
   int blk = 0, out_blk = 0, seq_T = 0;
   float inv_seq_T = 0.f;          // set by launch_gemm
+  int gm = 8;                     // row tiles per group of the blocked kernel's tile order (set by its launcher)
 };
 
 // variant: 0 = auto; 1 = tiled MFMA kernel (default staging); 2 = skinny (decode) kernel;
@@ -129,6 +130,8 @@ struct DecAttnArgs {
 extern int g_dec_cross_u;
 extern int g_dec_cross_nt;
 extern int g_gemm_big;
+extern int g_ppb_ns, g_ppb_gm;
+extern int g_qwen_split_act;      // qwen.hip
 extern int g_epi_wide;
 int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s);
 

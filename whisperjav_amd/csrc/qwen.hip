@@ -18,6 +18,9 @@
 
 #include "kernels.hpp"
 
+namespace wj {
+int g_qwen_split_act = 2;   // wj_tune("qwen_split_act"), read at wj_qwen_create
+}
 using namespace wj;
 
 namespace {
@@ -28,7 +31,7 @@ constexpr int HD = 128;   // head_dim of every published Qwen3 size
 // at most 2048 columns (every published size), LDS carries the four wave sums.
 template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ out,
-                                                      int M, int D, float eps) {
+                                                      int M, int D, float eps, int split = 0) {
   __shared__ float part[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const float* xr = x + (int64_t)row * D;
@@ -44,12 +47,15 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   if ((tid & 63) == 0) part[tid >> 6] = ss;
   __syncthreads();
   const float r = rsqrtf((part[0] + part[1] + part[2] + part[3]) / (float)D + eps);
-  T* o = out + (int64_t)row * D;
+  T* o = out + (int64_t)row * D * (split ? 2 : 1);        // split: [hi(D) | lo(D)] rows (GemmArgs::split)
   it = 0;
   for (int c = tid * 4; c < D; c += 1024, ++it) {
     const float4 v = it < 2 ? keep[it] : *reinterpret_cast<const float4*>(xr + c);
     const float4 g = *reinterpret_cast<const float4*>(w + c);
     const float y[4] = {g.x * (v.x * r), g.y * (v.y * r), g.z * (v.z * r), g.w * (v.w * r)};
+    if constexpr (sizeof(T) == 2) {
+      if (split) { st4_split<T>(o + c, D, y); continue; }
+    }
     st4(o + c, y);
   }
 }
@@ -62,11 +68,15 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const T* __restrict__ 
                                                           const float* __restrict__ k_w, const int32_t* __restrict__ row_seq,
                                                           const int32_t* __restrict__ row_pos, T* __restrict__ q_out,
                                                           T* __restrict__ kc, T* __restrict__ vc, int H, int KV, int ctx,
-                                                          float log2_theta, float eps) {
+                                                          float log2_theta, float eps, int split_in) {
   const int m = blockIdx.x, slot = blockIdx.y, lane = threadIdx.x;
   const int W = (H + 2 * KV) * HD;
-  const T* src = qkv + (int64_t)m * W + (int64_t)slot * HD;
+  const T* src = qkv + (int64_t)m * W * (split_in ? 2 : 1) + (int64_t)slot * HD;
   float a = Elem<T>::ld(src + lane), b = Elem<T>::ld(src + lane + 64);
+  if (split_in) {      // the projection stored [hi(W) | lo(W)] rows (GemmArgs::split_out): the fp32 accumulator to ~22 bits
+    a += Elem<T>::ld(src + W + lane);
+    b += Elem<T>::ld(src + W + lane + 64);
+  }
   const int b_seq = row_seq[m], pos = row_pos[m];
   if (slot >= H + KV) {      // value head: straight to the cache
     T* dst = vc + (((int64_t)b_seq * KV + (slot - H - KV)) * ctx + pos) * HD;
@@ -94,7 +104,7 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const T* __restrict__ 
 template <typename T, int G>
 __global__ __launch_bounds__(64) void gqa_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
                                                       const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_pos,
-                                                      T* __restrict__ out, int H, int KV, int ctx) {
+                                                      T* __restrict__ out, int H, int KV, int ctx, int split) {
   constexpr int STEPS = 16;
   const int m = blockIdx.x, kvh = blockIdx.y, lane = threadIdx.x, kq = lane >> 4, dq = lane & 15;
   const int b_seq = row_seq[m], n_keys = row_pos[m] + 1;
@@ -178,19 +188,34 @@ __global__ __launch_bounds__(64) void gqa_attn_kernel(const T* __restrict__ q, c
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = acc[g][e] * inv;
-      T* dst = out + ((int64_t)m * H + kvh * G + g) * HD + dq * 8;
+      T* dst = out + ((int64_t)m * H * (split ? 2 : 1) + kvh * G + g) * HD + dq * 8;
+      if constexpr (sizeof(T) == 2) {
+        if (split) { st4_split<T>(dst, (int64_t)H * HD, o); st4_split<T>(dst + 4, (int64_t)H * HD, o + 4); continue; }
+      }
       st4(dst, o); st4(dst + 4, o + 4);
     }
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gu, T* __restrict__ out, int M, int F) {
+__global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gu, T* __restrict__ out, int M, int F, int split) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)M * F) return;
   const int64_t m = i / F, c = i - m * F;
-  const float g = Elem<T>::ld(gu + m * 2 * F + c), u = Elem<T>::ld(gu + m * 2 * F + F + c);
-  Elem<T>::st(out + i, g / (1.f + expf(-g)) * u);
+  float g, u;
+  if (split) {         // gate / up arrive as [hi(2F) | lo(2F)] rows as well
+    const T* r = gu + m * 4 * F;
+    g = Elem<T>::ld(r + c) + Elem<T>::ld(r + 2 * F + c);
+    u = Elem<T>::ld(r + F + c) + Elem<T>::ld(r + 3 * F + c);
+  } else {
+    g = Elem<T>::ld(gu + m * 2 * F + c);
+    u = Elem<T>::ld(gu + m * 2 * F + F + c);
+  }
+  const float y = g / (1.f + expf(-g)) * u;
+  if constexpr (sizeof(T) == 2) {
+    if (split) { st_split<T>(out + m * 2 * F + c, F, y); return; }     // [hi(F) | lo(F)] rows
+  }
+  Elem<T>::st(out + i, y);
 }
 
 template <typename T>
@@ -285,7 +310,15 @@ struct wj_qwen {
   int seen_cap = 0;
   float cur_penalty = 1.f;   // != 1 only while wj_qwen_generate_greedy_ex runs its iterations (run_head applies it)
   int n_seqs = 0;            // sequences of the last prefill
+  std::vector<int32_t> prompt_len;   // their prompt lengths (the token budgets are clamped to the room left in the KV cache)
+  int32_t* embed_ids = nullptr;      // staging of wj_qwen_embed (its own buffer: row_seq holds decode state between prefill and generate)
+  // float16: the GEMMs that write the residual stream (o_proj, down_proj) and the LM head read their activations as
+  // [hi | lo] fp16 pairs (x to ~22 bits, W.hi + W.lo in one fp32 accumulator) -- the measure that brought the Whisper
+  // decoder inside 1e-3.  wj_tune "qwen_split_act": 0 = off, 1 = decode iterations and the head, 2 (default) = also prompts
+  int split_mode = 0;
   int last_used_graph = 0;   // the last generation replayed its iteration from a hipGraph
+  int last_steps = 0;        // decode iterations the last generation ran (it leaves the loop when every sequence has ended)
+  int last_truncated = 0;    // sequences whose token budget was cut to the room left in the KV cache
   const void* W(int i) const { return blob + off[i]; }
   const float* F(int i) const { return reinterpret_cast<const float*>(blob + off[i]); }
   int layer_base(int l) const { return WJ_Q_N_GLOBAL + l * WJ_QL_N; }
@@ -316,8 +349,9 @@ int gemm_variant(QGemm which, int M, int K, int dt) {
   }
 }
 
-// rows [0, M) through every decoder layer; row_seq / row_pos describe them
-int run_layers(wj_qwen* m, int M, hipStream_t s) {
+// rows [0, M) through every decoder layer; row_seq / row_pos describe them.  split: the attention output and the SwiGLU
+// output are stored as [hi | lo] rows and o_proj / down_proj consume them as split activations (float16 only)
+int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
   const wj_qwen_dims& d = m->d;
   const int D = d.hidden, H = d.n_head, KV = d.n_kv_head, F = d.ffn, dt = m->dtype;
   const int W = (H + 2 * KV) * HD;
@@ -337,21 +371,22 @@ int run_layers(wj_qwen* m, int M, hipStream_t s) {
     {
       GemmArgs g;
       g.A = m->h; g.lda = D; g.W = m->W(b0 + WJ_QL_QKV_W); g.ldw = D; g.M = M; g.N = W; g.K = D; g.out = m->qkv; g.ldc = W;
+      if (split) { g.split_out = 1; g.ldc = 2 * W; }
       WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, gemm_variant(QG_QKV, M, D, dt)));
     }
     const float l2t = log2f(d.rope_theta);
     if (dt == WJ_F32)
       hipLaunchKernelGGL((qk_norm_rope_kernel<float>), dim3(M, H + 2 * KV), dim3(64), 0, s, TP(const float, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
-                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(float, m->q), TP(float, kc), TP(float, vc), H, KV, m->max_ctx, l2t, d.rms_eps);
+                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(float, m->q), TP(float, kc), TP(float, vc), H, KV, m->max_ctx, l2t, d.rms_eps, split ? 1 : 0);
     else if (dt == WJ_F16)
       hipLaunchKernelGGL((qk_norm_rope_kernel<f16_t>), dim3(M, H + 2 * KV), dim3(64), 0, s, TP(const f16_t, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
-                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(f16_t, m->q), TP(f16_t, kc), TP(f16_t, vc), H, KV, m->max_ctx, l2t, d.rms_eps);
+                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(f16_t, m->q), TP(f16_t, kc), TP(f16_t, vc), H, KV, m->max_ctx, l2t, d.rms_eps, split ? 1 : 0);
     else
       hipLaunchKernelGGL((qk_norm_rope_kernel<bf16_t>), dim3(M, H + 2 * KV), dim3(64), 0, s, TP(const bf16_t, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
-                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(bf16_t, m->q), TP(bf16_t, kc), TP(bf16_t, vc), H, KV, m->max_ctx, l2t, d.rms_eps);
+                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(bf16_t, m->q), TP(bf16_t, kc), TP(bf16_t, vc), H, KV, m->max_ctx, l2t, d.rms_eps, split ? 1 : 0);
     WJ_LAUNCH_CHECK();
 #define WJ_GQA(T_, G_) hipLaunchKernelGGL((gqa_attn_kernel<T_, G_>), dim3(M, KV), dim3(64), 0, s, TP(const T_, m->q), TP(const T_, kc), \
-                                          TP(const T_, vc), m->row_seq, m->row_pos, TP(T_, m->attn), H, KV, m->max_ctx)
+                                          TP(const T_, vc), m->row_seq, m->row_pos, TP(T_, m->attn), H, KV, m->max_ctx, split ? 1 : 0)
 #define WJ_GQA_T(G_) do { if (dt == WJ_F32) WJ_GQA(float, G_); else if (dt == WJ_F16) WJ_GQA(f16_t, G_); else WJ_GQA(bf16_t, G_); } while (0)
     // Prompt rows use the same one-row-per-wave kernel: a form that gave a wave 4 consecutive rows of a sequence (8 (row, head)
     // pairs sharing every K / V load, per-row causal limits) was measured on the 104 k prompt rows of the 120-minute batch and
@@ -367,25 +402,29 @@ int run_layers(wj_qwen* m, int M, hipStream_t s) {
     WJ_LAUNCH_CHECK();
     {
       GemmArgs g;
-      g.A = m->attn; g.lda = H * HD; g.W = m->W(b0 + WJ_QL_O_W); g.ldw = H * HD; g.M = M; g.N = D; g.K = H * HD; g.out = m->x; g.ldc = D;
+      g.A = m->attn; g.lda = (split ? 2 : 1) * H * HD; g.split = split ? 1 : 0;
+      g.W = m->W(b0 + WJ_QL_O_W); g.ldw = H * HD; g.M = M; g.N = D; g.K = H * HD; g.out = m->x; g.ldc = D;
       WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, gemm_variant(QG_O, M, H * HD, dt)));
     }
     WJ_TRYQ(rms(m->F(b0 + WJ_QL_LN2_W), m->h));
     {
       GemmArgs g;
       g.A = m->h; g.lda = D; g.W = m->W(b0 + WJ_QL_GATEUP_W); g.ldw = D; g.M = M; g.N = 2 * F; g.K = D; g.out = m->gu; g.ldc = 2 * F;
+      if (split) { g.split_out = 1; g.ldc = 4 * F; }
       WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, gemm_variant(QG_GATEUP, M, D, dt)));
     }
     {
       const dim3 grid((unsigned)ceil_div64((int64_t)M * F, 256));
-      if (dt == WJ_F32) hipLaunchKernelGGL((swiglu_kernel<float>), grid, dim3(256), 0, s, TP(const float, m->gu), TP(float, m->act), M, F);
-      else if (dt == WJ_F16) hipLaunchKernelGGL((swiglu_kernel<f16_t>), grid, dim3(256), 0, s, TP(const f16_t, m->gu), TP(f16_t, m->act), M, F);
-      else hipLaunchKernelGGL((swiglu_kernel<bf16_t>), grid, dim3(256), 0, s, TP(const bf16_t, m->gu), TP(bf16_t, m->act), M, F);
+      const int sp = split ? 1 : 0;
+      if (dt == WJ_F32) hipLaunchKernelGGL((swiglu_kernel<float>), grid, dim3(256), 0, s, TP(const float, m->gu), TP(float, m->act), M, F, 0);
+      else if (dt == WJ_F16) hipLaunchKernelGGL((swiglu_kernel<f16_t>), grid, dim3(256), 0, s, TP(const f16_t, m->gu), TP(f16_t, m->act), M, F, sp);
+      else hipLaunchKernelGGL((swiglu_kernel<bf16_t>), grid, dim3(256), 0, s, TP(const bf16_t, m->gu), TP(bf16_t, m->act), M, F, sp);
       WJ_LAUNCH_CHECK();
     }
     {
       GemmArgs g;
-      g.A = m->act; g.lda = F; g.W = m->W(b0 + WJ_QL_DOWN_W); g.ldw = F; g.M = M; g.N = D; g.K = F; g.out = m->x; g.ldc = D;
+      g.A = m->act; g.lda = (split ? 2 : 1) * F; g.split = split ? 1 : 0;
+      g.W = m->W(b0 + WJ_QL_DOWN_W); g.ldw = F; g.M = M; g.N = D; g.K = F; g.out = m->x; g.ldc = D;
       WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, gemm_variant(QG_DOWN, M, F, dt)));
     }
   }
@@ -396,14 +435,16 @@ int run_layers(wj_qwen* m, int M, hipStream_t s) {
 int run_head(wj_qwen* m, const float* xin, int n, hipStream_t s) {
   const wj_qwen_dims& d = m->d;
   const int D = d.hidden, dt = m->dtype;
-  if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(n), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(float, m->h), n, D, d.rms_eps);
-  else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(n), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(f16_t, m->h), n, D, d.rms_eps);
-  else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(n), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(bf16_t, m->h), n, D, d.rms_eps);
+  const int sp = m->split_mode >= 1 ? 1 : 0;
+  if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(n), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(float, m->h), n, D, d.rms_eps, 0);
+  else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(n), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(f16_t, m->h), n, D, d.rms_eps, sp);
+  else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(n), dim3(256), 0, s, xin, m->F(WJ_Q_NORM_W), TP(bf16_t, m->h), n, D, d.rms_eps, sp);
   WJ_LAUNCH_CHECK();
   GemmArgs g;
+  g.split = sp;
   // >= 1024 rows: N a multiple of 256 admits the 256-tile kernel (the surplus columns are dot products with zero rows; top-1 below
   // reads the first d.vocab columns only)
-  g.A = m->h; g.lda = D; g.W = m->W(WJ_Q_EMBED); g.ldw = D; g.M = n; g.N = n >= 1024 ? m->vocab_pad : d.vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
+  g.A = m->h; g.lda = (sp ? 2 : 1) * D; g.W = m->W(WJ_Q_EMBED); g.ldw = D; g.M = n; g.N = n >= 1024 ? m->vocab_pad : d.vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
   WJ_TRYQ(launch_gemm(dt, EPI_F32, g, s, 0));
   if (m->cur_penalty != 1.f) {
     hipLaunchKernelGGL(rep_penalty_kernel, dim3(n), dim3(256), 0, s, m->logits, m->ldl, m->seen, m->seen_n, m->seen_cap, m->cur_penalty, m->finished);
@@ -456,6 +497,8 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   m->max_seqs = max_seqs; m->max_ctx = max_ctx; m->max_rows = max_rows;
   const size_t e = m->esz, R = max_rows, S = max_seqs;
   const int D = d.hidden, H = d.n_head, KV = d.n_kv_head, F = d.ffn;
+  m->split_mode = dtype == WJ_F16 && (D % 64) == 0 && (F % 64) == 0 ? std::max(0, std::min(2, g_qwen_split_act)) : 0;
+  const size_t sm = m->split_mode ? 2 : 1;
   {
     const int vp = (d.vocab + 255) / 256 * 256;
     const int64_t room = (n_offsets > 1 ? offsets_host[WJ_Q_EMBED + 1] : (int64_t)blob_bytes) - offsets_host[WJ_Q_EMBED];
@@ -464,8 +507,8 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   m->ldl = (m->vocab_pad + 63) / 64 * 64;
   int rc = 0;
 #define QA(field, bytes) do { if (!rc) rc = qalloc(m, reinterpret_cast<void**>(&m->field), (bytes)); } while (0)
-  QA(x, R * D * sizeof(float)); QA(h, R * D * e); QA(qkv, R * (size_t)(H + 2 * KV) * HD * e); QA(q, R * (size_t)H * HD * e);
-  QA(attn, R * (size_t)H * HD * e); QA(gu, R * 2 * (size_t)F * e); QA(act, R * (size_t)F * e);
+  QA(x, R * D * sizeof(float)); QA(h, R * D * e * sm); QA(qkv, R * (size_t)(H + 2 * KV) * HD * e * sm); QA(q, R * (size_t)H * HD * e);
+  QA(attn, R * (size_t)H * HD * e * sm); QA(gu, R * 2 * (size_t)F * e * sm); QA(act, R * (size_t)F * e * sm); QA(embed_ids, R * 4);
   QA(kc, (size_t)d.n_layer * S * KV * max_ctx * HD * e); QA(vc, (size_t)d.n_layer * S * KV * max_ctx * HD * e);
   QA(xl, S * D * sizeof(float)); QA(logits, S * m->ldl * sizeof(float));
   QA(row_seq, R * 4); QA(row_pos, R * 4); QA(last_rows, S * 4); QA(next_tok, S * 4); QA(finished, S * 4); QA(n_out, S * 4);
@@ -484,10 +527,11 @@ int wj_qwen_embed(wj_qwen* m, const int32_t* tokens_host, int n, float* out_dev,
   for (int i = 0; i < n; ++i) WJ_REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < m->d.vocab, "wj_qwen_embed: token %d out of range", tokens_host[i]);
   WJ_HIP(hipSetDevice(m->ctx->device));
   hipStream_t s = m->ctx->pick(stream);
-  WJ_HIP(hipMemcpyAsync(m->row_seq, tokens_host, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));     // staging
-  if (m->dtype == WJ_F32) hipLaunchKernelGGL((embed_rows_kernel<float>), dim3(n), dim3(256), 0, s, TP(const float, m->W(WJ_Q_EMBED)), m->row_seq, out_dev, m->d.hidden);
-  else if (m->dtype == WJ_F16) hipLaunchKernelGGL((embed_rows_kernel<f16_t>), dim3(n), dim3(256), 0, s, TP(const f16_t, m->W(WJ_Q_EMBED)), m->row_seq, out_dev, m->d.hidden);
-  else hipLaunchKernelGGL((embed_rows_kernel<bf16_t>), dim3(n), dim3(256), 0, s, TP(const bf16_t, m->W(WJ_Q_EMBED)), m->row_seq, out_dev, m->d.hidden);
+  // own staging buffer: between wj_qwen_prefill and wj_qwen_generate_greedy row_seq holds the decode rows' sequence ids
+  WJ_HIP(hipMemcpyAsync(m->embed_ids, tokens_host, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+  if (m->dtype == WJ_F32) hipLaunchKernelGGL((embed_rows_kernel<float>), dim3(n), dim3(256), 0, s, TP(const float, m->W(WJ_Q_EMBED)), m->embed_ids, out_dev, m->d.hidden);
+  else if (m->dtype == WJ_F16) hipLaunchKernelGGL((embed_rows_kernel<f16_t>), dim3(n), dim3(256), 0, s, TP(const f16_t, m->W(WJ_Q_EMBED)), m->embed_ids, out_dev, m->d.hidden);
+  else hipLaunchKernelGGL((embed_rows_kernel<bf16_t>), dim3(n), dim3(256), 0, s, TP(const bf16_t, m->W(WJ_Q_EMBED)), m->embed_ids, out_dev, m->d.hidden);
   WJ_LAUNCH_CHECK();
   WJ_HIP(hipStreamSynchronize(s));
   return WJ_OK;
@@ -511,7 +555,8 @@ int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32
   WJ_HIP(hipMemcpyAsync(m->row_pos, pos.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, s));
   WJ_HIP(hipMemcpyAsync(m->last_rows, last.data(), sizeof(int32_t) * n_seqs, hipMemcpyHostToDevice, s));
   WJ_HIP(hipMemcpyAsync(m->x, embeds_dev, sizeof(float) * (size_t)M * m->d.hidden, hipMemcpyDeviceToDevice, s));   // packed rows
-  WJ_TRYQ(run_layers(m, M, s));
+  m->n_seqs = 0;
+  WJ_TRYQ(run_layers(m, M, s, m->split_mode >= 2));
   hipLaunchKernelGGL(gather_rows_kernel, dim3(n_seqs), dim3(256), 0, s, m->x, m->last_rows, m->xl, m->d.hidden);
   WJ_LAUNCH_CHECK();
   WJ_TRYQ(run_head(m, m->xl, n_seqs, s));
@@ -526,10 +571,13 @@ int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32
   WJ_HIP(hipMemcpyAsync(m->row_pos, p1.data(), sizeof(int32_t) * n_seqs, hipMemcpyHostToDevice, s));
   WJ_HIP(hipStreamSynchronize(s));
   m->n_seqs = n_seqs;
+  m->prompt_len.assign(n_tokens_host, n_tokens_host + n_seqs);
   return WJ_OK;
 }
 
 int wj_qwen_last_used_graph(const wj_qwen* m) { return m ? m->last_used_graph : 0; }
+int wj_qwen_last_steps(const wj_qwen* m) { return m ? m->last_steps : 0; }
+int wj_qwen_last_truncated(const wj_qwen* m) { return m ? m->last_truncated : 0; }
 
 int wj_qwen_classify(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32_t* n_tokens_host, const int32_t* rows_host, int n_rows,
                      const void* head_w_dev, const float* head_b_dev, int n_labels, int32_t* argmax_out_host, float* logits_out_dev,
@@ -550,7 +598,8 @@ int wj_qwen_classify(wj_qwen* m, const float* embeds_dev, int n_seqs, const int3
   WJ_HIP(hipMemcpyAsync(m->row_seq, seq.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, s));
   WJ_HIP(hipMemcpyAsync(m->row_pos, pos.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, s));
   WJ_HIP(hipMemcpyAsync(m->x, embeds_dev, sizeof(float) * (size_t)M * m->d.hidden, hipMemcpyDeviceToDevice, s));
-  WJ_TRYQ(run_layers(m, M, s));
+  m->n_seqs = 0;       // the caches are about to hold a classification pass: generation needs its own prefill
+  WJ_TRYQ(run_layers(m, M, s, m->split_mode >= 2));
   // the selected rows (e.g. the <timestamp> markers of a forced-alignment prompt): final RMSNorm + the caller's head.  The
   // gather goes through a scratch allocation because x is the residual stream being read.
   int32_t* tmp_rows = nullptr;
@@ -625,6 +674,14 @@ int wj_qwen_generate_greedy_ex(wj_qwen* m, const int32_t* eos_ids_host, int n_eo
       WJ_REQUIRE(max_new_per_seq_host[b] >= 0, "wj_qwen_generate_greedy_ex: negative token budget for sequence %d", b);
       lim_h[b] = std::min(max_new_per_seq_host[b], max_new);
     }
+  // A sequence can never outgrow its KV cache: token g of sequence b is fed at position prompt_len + g - 1, so at most
+  // max_ctx - prompt_len tokens fit.  The budget is cut to that room (wj_qwen_last_truncated tells how many sequences were
+  // cut): past it the cache position used to be clamped silently and the sequence decoded garbage.
+  m->last_truncated = 0;
+  for (int b = 0; b < S; ++b) {
+    const int room = std::max(0, m->max_ctx - m->prompt_len[b]);
+    if (lim_h[b] > room) { lim_h[b] = room; ++m->last_truncated; }
+  }
   WJ_HIP(hipMemcpyAsync(m->lim, lim_h.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, s));
   std::vector<int32_t> seen_h, seen_cnt(S, 0);
   if (penalise) {
@@ -663,7 +720,7 @@ int wj_qwen_generate_greedy_ex(wj_qwen* m, const int32_t* eos_ids_host, int n_eo
     else if (m->dtype == WJ_F16) hipLaunchKernelGGL((embed_rows_kernel<f16_t>), dim3(S), dim3(256), 0, s, TP(const f16_t, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
     else hipLaunchKernelGGL((embed_rows_kernel<bf16_t>), dim3(S), dim3(256), 0, s, TP(const bf16_t, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
     WJ_LAUNCH_CHECK();
-    WJ_TRYQ(run_layers(m, S, s));
+    WJ_TRYQ(run_layers(m, S, s, m->split_mode >= 1));
     WJ_TRYQ(run_head(m, m->x, S, s));
     return advance(0);
   };
@@ -675,7 +732,12 @@ int wj_qwen_generate_greedy_ex(wj_qwen* m, const int32_t* eos_ids_host, int n_eo
   bool use_graph = !(env && env[0] == '1') && max_new > 2;
   int rc_loop = WJ_OK;
   m->last_used_graph = 0;
+  m->last_steps = 0;
+  const int n_seqs_gen = m->n_seqs;
+  m->n_seqs = 0;            // one generation per prefill: the decode state (positions, penalised logits) is consumed below
+  (void)n_seqs_gen;
   for (int k = 1; k <= max_new && rc_loop == WJ_OK; ++k) {
+    m->last_steps = k;
     if (k == 2 && use_graph) {       // the first iteration ran eagerly (one-time kernel attributes are set); capture the second
       if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         const int rc = iteration();

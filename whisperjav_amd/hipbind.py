@@ -12,7 +12,7 @@ import os
 from pathlib import Path
 from typing import Optional
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwjhip.so"
 _lib: Optional[C.CDLL] = None
 
@@ -83,6 +83,8 @@ _SIGNATURES = {
     "wj_qwen_generate_greedy_ex": (_I, [_P, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32), _F, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),
     "wj_qwen_last_used_graph": (_I, [_P]),
+    "wj_qwen_last_steps": (_I, [_P]),
+    "wj_qwen_last_truncated": (_I, [_P]),
     "wj_qwen_classify": (_I, [_P, _P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _P, _P, _I, C.POINTER(C.c_int32), _P, _P]),
     "wj_qwen_audio_create": (_I, [_P, _P, _I, _P, C.c_size_t, C.POINTER(C.c_int64), _I, _I, C.POINTER(_P)]),
     "wj_qwen_audio_free": (_I, [_P]),
@@ -106,6 +108,7 @@ _SIGNATURES = {
     "wj_comm_unique_id": (_I, [C.c_char_p]),
     "wj_comm_init": (_I, [_P, _I, _I, C.c_char_p, C.POINTER(_P)]),
     "wj_bcast_weights": (_I, [_P, _P, _I64, _I, _P]),
+    "wj_comm_count": (_I, [_P, C.POINTER(_I)]),
     "wj_comm_destroy": (_I, [_P]),
     "wj_k_gemm": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "wj_k_gemm_split": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -16,8 +16,10 @@ un-vendored ``qwen_asr`` package (modules/qwen_asr.py:545-757).  What exists her
   * weight packing from the published state-dict names (``model.language_model.layers.N...``), seeded synthetic weights for
     the tests.
 
-Not here yet: the forced aligner (``TextAligner``), fp8 weight streaming (cfg5's "fp8 MFMA"), beam
-search for the LLM (upstream decodes greedily), measurements.  DESIGN.md section 7 has the plan.
+  * ``HipQwenForcedAligner``: the ``TextAligner`` surface (classification pass + the reference's timestamp repair);
+  * ``QwenEosRamp``: synthetic weights whose generations END (round 4), at clip-dependent lengths.
+
+Not here: beam search for the LLM (upstream decodes greedily), a tokenizer.  DESIGN.md section 7 has the status.
 """
 from __future__ import annotations
 
@@ -56,8 +58,79 @@ class Qwen3DimsC(C.Structure):
                [("rope_theta", C.c_float), ("rms_eps", C.c_float)]
 
 
-def synth_weights(d: Qwen3Dims, seed: int = 7) -> Dict[str, np.ndarray]:
-    """Seeded decoder weights under the published names (activations O(1) through the stack, logits spread ~1.5)."""
+@dataclass(frozen=True)
+class QwenEosRamp:
+    """End-of-sequence behaviour planted in the synthetic Qwen3 decoder (round 4; the Whisper side has ``weights.EotRamp``):
+    random weights never emit EOS, so every test and benchmark ran to its budget.  Mechanism, all inside the published
+    architecture (no positional table to write into, only RoPE -- so the counter is an attention average):
+
+    * hidden coordinate ``a = hidden - 2`` marks AUDIO rows: token embeddings carry 0 there, audio embeddings carry 1 (the
+      synthetic projector's bias, or ``plant_audio_rows`` for hand-made rows); no layer writes it (output rows of every
+      ``o_proj`` / ``down_proj`` are zero there);
+    * layer 0, query head 0 has a ZERO query projection: its scores are all 0, the causal softmax is uniform, and with a value
+      projection that reads the normalised marker it returns (audio rows so far) / (positions so far) ~ A / (P + g) -- a quantity
+      that falls as tokens are generated and is larger for longer clips;
+    * ``o_proj`` writes ``-gain`` times that into coordinate ``u = hidden - 1``, which nothing else writes; every token embedding
+      carries ``offset`` there and the EOS rows ``offset + kappa`` (constant shifts of all logits cancel in the softmax), EOS rows
+      are zero elsewhere: EOS's logit relative to the others is ``kappa * norm_w[u] * (offset - gain * A / n) / rms(x)`` -- it
+      rises with every generated token and crosses the best text logit later for clips with more audio.
+
+    So sequences END, at clip-dependent lengths, inside the budget.  kappa and offset are fp16-representable."""
+    kappa: float = 64.0
+    offset: float = 0.625
+    gain: float = 1.0
+
+    @classmethod
+    def for_dims(cls, d: "Qwen3Dims") -> "QwenEosRamp":
+        """The final hidden state's rms grows with the depth of the stack (measured with the fp32 oracle: ~1.2 after 3 layers of
+        256, ~2.0 after 28 layers of 2048), and the EOS logit is ``kappa * x_u / rms``: deep stacks get twice the gain so that a
+        2-6 s clip still ends after ~0.4-1 tokens per audio token."""
+        if d.n_layer >= 16:      # measured on the 1.7 B geometry: EOS after ~0.57 A - 6 tokens for A audio tokens (13 per second): ~6 tokens/s
+            return cls(kappa=128.0, offset=0.75)
+        return cls()
+
+
+def plant_audio_rows(audio, d: "Qwen3Dims", ramp: QwenEosRamp):
+    """Hand-made audio embeddings (tests): set the marker coordinate to 1 and the ramp coordinate to ``offset``, as the
+    synthetic projector of ``synth_audio_weights(..., ramp=...)`` does."""
+    audio = audio.clone()
+    audio[:, d.hidden - 2] = 1.0
+    audio[:, d.hidden - 1] = ramp.offset
+    return audio
+
+
+def synth_weights(d: Qwen3Dims, seed: int = 7, eos: Optional[QwenEosRamp] = None) -> Dict[str, np.ndarray]:
+    """Seeded decoder weights under the published names (activations O(1) through the stack, logits spread ~1.5).
+    ``eos``: plant the end-of-sequence ramp described at ``QwenEosRamp`` (same draws for everything else)."""
+    w = _synth_weights_plain(d, seed)
+    if eos is None:
+        return w
+    p = "model.language_model."
+    a, u = d.hidden - 2, d.hidden - 1
+    emb = w[p + "embed_tokens.weight"]
+    emb[:, a] = 0.0
+    emb[:, u] = eos.offset
+    for t in d.eos_token_ids:
+        emb[t, :] = 0.0
+        emb[t, u] = eos.offset + eos.kappa
+    for l in range(d.n_layer):
+        q = f"{p}layers.{l}."
+        w[q + "self_attn.o_proj.weight"][[a, u], :] = 0.0
+        w[q + "mlp.down_proj.weight"][[a, u], :] = 0.0
+    q = p + "layers.0."
+    w[q + "self_attn.q_proj.weight"][: d.head_dim, :] = 0.0          # query head 0: uniform attention
+    v = w[q + "self_attn.v_proj.weight"]
+    v[0, :] = 0.0
+    v[0, a] = 1.0                                                     # value dim 0 of KV head 0 = the normalised marker
+    w[q + "input_layernorm.weight"][a] = 1.0
+    o = w[q + "self_attn.o_proj.weight"]
+    o[:, 0] = 0.0                                                     # (head 0, dim 0) feeds the ramp coordinate only
+    o[u, 0] = -eos.gain
+    w[p + "norm.weight"][u] = 1.0
+    return w
+
+
+def _synth_weights_plain(d: Qwen3Dims, seed: int = 7) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     p = "model.language_model."
     w: Dict[str, np.ndarray] = {p + "embed_tokens.weight": (rng.standard_normal((d.vocab, d.hidden)) * 1.5 / np.sqrt(d.hidden)).astype(np.float32)}
@@ -133,8 +206,21 @@ AUDIO_GLOBALS = ("CONV1_W", "CONV1_B", "CONV2_W", "CONV2_B", "CONV3_W", "CONV3_B
 AUDIO_LAYER = ("LN1_W", "LN1_B", "QKV_W", "QKV_B", "OUT_W", "OUT_B", "LN2_W", "LN2_B", "FC1_W", "FC1_B", "FC2_W", "FC2_B")
 
 
-def synth_audio_weights(d: Qwen3AudioDims, seed: int = 11) -> Dict[str, np.ndarray]:
-    """Seeded audio-tower + projector weights under the published names."""
+def synth_audio_weights(d: Qwen3AudioDims, seed: int = 11, ramp: Optional[QwenEosRamp] = None) -> Dict[str, np.ndarray]:
+    """Seeded audio-tower + projector weights under the published names.  ``ramp``: the projector marks its rows for the
+    decoder's end-of-sequence ramp (``QwenEosRamp``: coordinate out_dim - 2 = 1, out_dim - 1 = offset, whatever the audio)."""
+    w = _synth_audio_weights_plain(d, seed)
+    if ramp is not None:
+        m = "model.multi_modal_projector."
+        w[m + "linear_2.weight"][[d.out_dim - 2, d.out_dim - 1], :] = 0.0
+        # the marker at the rms of the projector's other outputs (unit-variance pre-activations through GELU: sqrt(0.425 + 0.01)),
+        # so that the decoder's first RMSNorm turns it into ~1, as plant_audio_rows' unit marker is on unit-variance rows
+        w[m + "linear_2.bias"][d.out_dim - 2] = 0.66
+        w[m + "linear_2.bias"][d.out_dim - 1] = ramp.offset
+    return w
+
+
+def _synth_audio_weights_plain(d: Qwen3AudioDims, seed: int = 11) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     p, w = "model.audio_tower.", {}
 
@@ -310,6 +396,8 @@ class HipQwenAudioTower:
 class GenerateResult:
     tokens: List[List[int]]
     token_logprob: List[List[float]]      # one entry per token, + the EOS token's when the sequence ended on one
+    steps: int = 0                        # decode iterations the call ran (it stops when every sequence has ended)
+    context_limited: Optional[List[bool]] = None   # sequences whose budget was cut to the room left in the KV cache
 
 
 class HipQwen3Decoder:
@@ -404,6 +492,7 @@ class HipQwen3Decoder:
         check(self._lib.wj_qwen_prefill(self.handle, C.c_void_p(packed.data_ptr()), len(n), n.ctypes.data_as(C.POINTER(C.c_int32)),
                                         C.c_void_p(out.data_ptr()) if out is not None else None, None), "wj_qwen_prefill")
         self._n_seqs = len(n)
+        self._n_prompt = n.copy()
         return out
 
     def classify(self, embeds: Sequence[torch.Tensor], rows: Sequence[Sequence[int]], head_w: torch.Tensor,
@@ -436,7 +525,9 @@ class HipQwen3Decoder:
         """Greedy continuation of the prefilled sequences (``wj_qwen_generate_greedy_ex``).  ``repetition_penalty`` != 1 is
         transformers' ``RepetitionPenaltyLogitsProcessor`` and needs ``prompt_ids`` (the token ids of every prompt, audio
         placeholders included: the processor penalises every id of ``input_ids``); ``max_new_per_seq`` gives each sequence its
-        own budget (clamped to ``max_new_tokens``)."""
+        own budget (clamped to ``max_new_tokens``).  A sequence cannot outgrow the KV cache: every budget is also cut to
+        ``max_ctx - prompt length`` (``context_limited`` in the result; size ``max_ctx`` for prompt + budget to avoid it).
+        One generation per prefill."""
         eos = np.ascontiguousarray(eos_token_ids if eos_token_ids is not None else self.dims.eos_token_ids, dtype=np.int32)
         S, n = self._n_seqs, int(max_new_tokens)
         toks = np.zeros((S, n), dtype=np.int32)
@@ -461,12 +552,17 @@ class HipQwen3Decoder:
                                                    offs.ctypes.data_as(i32) if offs is not None else None,
                                                    toks.ctypes.data_as(i32), cnt.ctypes.data_as(i32),
                                                    lps.ctypes.data_as(C.POINTER(C.c_float)), None), "wj_qwen_generate_greedy_ex")
+        room = np.maximum(0, self.max_ctx - self._n_prompt[:S]).astype(np.int32)
+        limited = (lim > room).tolist()
+        lim = np.minimum(lim, room)
         out_t, out_l = [], []
         for b in range(S):
             k = int(cnt[b])
             out_t.append(toks[b, :k].tolist())
             out_l.append(lps[b, : k + 1 if k < int(lim[b]) else k].tolist())      # + the EOS token's when the sequence ended on one
-        return GenerateResult(out_t, out_l)
+        self._n_seqs = 0
+        assert int(self._lib.wj_qwen_last_truncated(self.handle)) == sum(limited)
+        return GenerateResult(out_t, out_l, int(self._lib.wj_qwen_last_steps(self.handle)), limited)
 
 
 def dynamic_token_limit(audio_duration_sec: float, max_new_tokens: int, max_tokens_per_audio_second: float,
@@ -515,6 +611,15 @@ class HipQwenTextGenerator:
                                           max_ctx=self.max_ctx)
         if self._tower is None and self.audio_embedder is None and self.audio_dims is not None:
             self._tower = HipQwenAudioTower(self.audio_dims, self._weights, dtype=self.dtype, device=self.device)
+
+    def _ensure_ctx(self, need: int) -> None:
+        """Re-create the decoder with a larger KV cache when a batch needs more than ``max_ctx`` positions per sequence."""
+        if need <= self._model.max_ctx:
+            return
+        self.max_ctx = (int(need) + 255) // 256 * 256
+        self._model.close()
+        self._model = HipQwen3Decoder(self.dims, self._weights, dtype=self.dtype, device=self.device, max_seqs=self.batch_size,
+                                      max_ctx=self.max_ctx)
 
     def unload(self) -> None:
         self._primed = None
@@ -573,14 +678,20 @@ class HipQwenTextGenerator:
             audio_embeds = [torch.as_tensor(a) for a in audio_embeds]
             ids = [self.prompt_builder(int(a.shape[0]), language, ctx_text)
                    for a, ctx_text in zip(audio_embeds, contexts[lo: lo + self.batch_size])]
-            self._model.prefill_packed(*self._model.prompt_embeddings_many(ids, audio_embeds))     # one embedding launch, one scatter
             max_new = int(kwargs.get("max_new_tokens", self.max_new_tokens))
             durations = kwargs.get("audio_durations")
             budgets = None
             if durations is not None:          # the reference scales each scene's budget with its duration (qwen_asr.py:1277-1279)
                 budgets = [dynamic_token_limit(float(d or 0), max_new, self.max_tokens_per_audio_second, self.min_tokens_floor)
                            for d in list(durations)[lo: lo + self.batch_size]]
+            # the KV cache must hold the longest prompt PLUS its budget (48 s scenes at 20 tokens/s: ~640 + 960 positions --
+            # more than any fixed default): grow the decoder's context when this batch needs it
+            need = max(len(p) + (budgets[i] if budgets is not None else max_new) for i, p in enumerate(ids))
+            self._ensure_ctx(need)
+            self._model.prefill_packed(*self._model.prompt_embeddings_many(ids, audio_embeds))     # one embedding launch, one scatter
             res = self._model.generate(max_new, repetition_penalty=self.repetition_penalty, prompt_ids=ids, max_new_per_seq=budgets)
+            if res.context_limited and any(res.context_limited):
+                raise hipbind.WjError("HipQwenTextGenerator: a token budget was cut by the KV cache after the context was sized for it")
             for toks, path in zip(res.tokens, audio_paths[lo: lo + self.batch_size]):      # text stripped, metadata keys as generators/qwen3.py:186-195
                 out.append(TranscriptionResult(text=str(self.detokenize(toks)).strip(), language=language,
                                                metadata={"generator": "qwen3-hip", "audio_path": str(path), "n_tokens": len(toks)}))

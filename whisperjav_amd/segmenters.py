@@ -256,7 +256,18 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
     to score (``WjError`` from ``segment``) unless the caller asks for the substitution by name: ``network="v6"`` runs
     the v5/v6 HIP scorer behind this contract -- a different network, different probabilities, NOT the reference's VAD
     frames -- and says so in ``name`` / ``display_name``.  A scorer seam injected by a test double (``_model`` /
-    ``_get_speech_timestamps``) bypasses the check, as in the reference's own suite."""
+    ``_get_speech_timestamps``) bypasses the check, as in the reference's own suite.
+
+    ``scorer`` (round 4) keeps the reference's OWN network when its archive is on the box: the reference's JIT model scores on
+    the host, on its 1536-sample grid, through the archive's own ``get_speech_timestamps`` -- exactly the call of
+    backends/silero.py:258-273 -- and everything downstream (padding, grouping, log-mel, encoder, search) stays on the device.
+    Accepted: ``"torch.hub"`` (``torch.hub.load("snakers4/silero-vad:<version>", "silero_vad", onnx=False)``, the reference's
+    loader :199-206, served from the local hub cache), a ``(model, get_speech_timestamps)`` pair, the ``(model, utils)`` pair
+    ``torch.hub.load`` returns, or a zero-argument callable returning one of these (loaded on first use).  ``--mode balanced``
+    with the reference's default segmenter then runs end to end: ``HipSileroSpeechSegmenter(version="v3.1",
+    scorer="torch.hub")``."""
+
+    REPOS = {"v4.0": "snakers4/silero-vad:v4.0", "v3.1": "snakers4/silero-vad:v3.1"}      # backends/silero.py:68-72
 
     VERSION_DEFAULTS = {
         "v4.0": {"threshold": 0.25, "min_speech_duration_ms": 150, "min_silence_duration_ms": 300,
@@ -271,11 +282,14 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
                  max_group_duration_s: Optional[float] = None, max_speech_duration_s: Optional[float] = None,
                  start_pad_samples: int = 11200, end_pad_samples: int = 20800,
                  weights: Union[Dict[str, np.ndarray], str, None] = None, device: int = 0,
-                 weights_path: Optional[str] = None, network: Optional[str] = None, **kwargs):
+                 weights_path: Optional[str] = None, network: Optional[str] = None, scorer: Any = None, **kwargs):
         self._weights_path = weights_path
         if network not in (None, "v6", "v5/v6"):
             raise ValueError("network must be None (the version's own network: no HIP kernel, refuses) or 'v6'")
+        if scorer is not None and network:
+            raise ValueError("scorer= (the version's own network on the host) and network='v6' (the v6 HIP network) are alternatives")
         self.network = "v6" if network else None
+        self._scorer = scorer
         self.version = version if version in self.VERSION_DEFAULTS else "v4.0"
         dflt = self.VERSION_DEFAULTS[self.version]
         self.threshold = float(threshold) if threshold is not None else dflt["threshold"]
@@ -303,15 +317,42 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
 
     @property
     def name(self) -> str:
-        return f"silero-{self.version}-hip" + ("+v6net" if self.network else "")
+        return f"silero-{self.version}-hip" + ("+v6net" if self.network else "+hostnet" if self._scorer is not None else "")
 
     @property
     def display_name(self) -> str:
         if self.network:
             return f"Silero VAD {self.version} call contract over the v6 network (MI355X HIP)"
+        if self._scorer is not None:
+            return f"Silero VAD {self.version} (the reference's own network scoring on the host; MI355X HIP downstream)"
         return f"Silero VAD {self.version} (MI355X HIP; no kernel for this network: refuses to score)"
 
+    @property
+    def can_score(self) -> bool:
+        """False = ``segment`` would refuse (no HIP kernel for this network, no scorer seam, no v6 substitution asked for)."""
+        return self.network is not None or self._scorer is not None or self._model is not None
+
+    def _resolve_scorer(self) -> None:
+        sc = self._scorer
+        if sc == "torch.hub":
+            import torch
+            model, utils = torch.hub.load(repo_or_dir=self.REPOS[self.version], model="silero_vad", onnx=False, trust_repo=True)
+            sc = (model, utils)
+        elif callable(sc) and not isinstance(sc, (tuple, list)):
+            sc = sc()
+        if not isinstance(sc, (tuple, list)) or len(sc) != 2:
+            raise TypeError("scorer must be 'torch.hub', (model, get_speech_timestamps), torch.hub.load's (model, utils), or a callable returning one")
+        model, second = sc
+        gst = second[0] if isinstance(second, (tuple, list)) else second         # utils = (get_speech_timestamps, save_audio, ...)
+        if not callable(gst):
+            raise TypeError("scorer: no callable get_speech_timestamps found")
+        self._model, self._get_speech_timestamps = model, gst
+        self._host_scorer = True
+
     def _ensure_model(self) -> None:
+        if self._model is None and self._scorer is not None:
+            self._resolve_scorer()
+            return
         if self._model is None and self.network is None:
             from .hipbind import WjError
             raise WjError(
@@ -336,13 +377,22 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
         min_speech = kwargs.get("min_speech_duration_ms", self.min_speech_duration_ms)
         min_silence = kwargs.get("min_silence_duration_ms", self.min_silence_duration_ms)
         pad_ms = kwargs.get("speech_pad_ms", self.speech_pad_ms)
-        if _on_device(data) and sr != VAD_SR:
+        if _on_device(data) and (sr != VAD_SR or getattr(self, "_host_scorer", False)):
             data = data.detach().cpu().numpy()
         audio16 = data if _on_device(data) else np.asarray(_resample(data, sr, VAD_SR), dtype=np.float32)
-        stamps = self._get_speech_timestamps(audio16, self._model, sampling_rate=VAD_SR, threshold=threshold,
-                                             min_speech_duration_ms=min_speech, min_silence_duration_ms=min_silence,
-                                             speech_pad_ms=pad_ms,
-                                             **({"probs": kwargs["_probs"]} if kwargs.get("_probs") is not None else {}))
+        if getattr(self, "_host_scorer", False):
+            # the reference's own call (backends/silero.py:258-273): a host FloatTensor, the archive's get_speech_timestamps,
+            # the four keyword arguments the v3.1 / v4.0 API takes -- the network's 1536-sample windows and state live in there
+            import torch
+            stamps = self._get_speech_timestamps(torch.from_numpy(np.ascontiguousarray(audio16, dtype=np.float32)), self._model,
+                                                 sampling_rate=VAD_SR, threshold=threshold, min_speech_duration_ms=min_speech,
+                                                 min_silence_duration_ms=min_silence, speech_pad_ms=pad_ms)
+            stamps = [dict(ts) for ts in stamps]
+        else:
+            stamps = self._get_speech_timestamps(audio16, self._model, sampling_rate=VAD_SR, threshold=threshold,
+                                                 min_speech_duration_ms=min_speech, min_silence_duration_ms=min_silence,
+                                                 speech_pad_ms=pad_ms,
+                                                 **({"probs": kwargs["_probs"]} if kwargs.get("_probs") is not None else {}))
         if not stamps:
             return SegmentationResult(segments=[], groups=[], method=self.name, audio_duration_sec=duration,
                                       parameters=self._get_parameters(), processing_time_sec=time.time() - t0)

@@ -102,11 +102,19 @@ def broadcast_blob_cabi(blob: Optional[torch.Tensor], offsets: Optional[np.ndarr
     comm = C.c_void_p()
     hipbind.check(lib.wj_comm_init(ctx.handle, info.world, info.rank, uid_raw, C.byref(comm)), "wj_comm_init")
     torch.cuda.current_stream().synchronize()
+    global LAST_COMM_RANKS
     try:
+        n = C.c_int(0)
+        LAST_COMM_RANKS = int(n.value) if lib.wj_comm_count(comm, C.byref(n)) else int(n.value)     # what RCCL says it built
+        if LAST_COMM_RANKS and LAST_COMM_RANKS != info.world:
+            raise hipbind.WjError(f"RCCL built a communicator of {LAST_COMM_RANKS} ranks for a world of {info.world}")
         hipbind.check(lib.wj_bcast_weights(comm, C.c_void_p(dev_blob.data_ptr()), nbytes, src, None), "wj_bcast_weights")
     finally:
         lib.wj_comm_destroy(comm)
     return dev_blob, offs
+
+
+LAST_COMM_RANKS = 0      # ncclCommCount of the communicator the last broadcast_blob_cabi built on this rank
 
 
 def assign_lpt(costs: Sequence[float], world: int) -> List[List[int]]:
