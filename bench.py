@@ -189,6 +189,10 @@ def cpu_baseline_cfg3(dims, w, clips, n_groups, audio_s, max_new, beam, threads,
     the result).  The recording costs ``n_groups / len(clips)`` such samples."""
     from oracle import decoding, logmel, whisper_ref
     torch.set_num_threads(threads)
+    try:
+        torch.set_num_interop_threads(1)
+    except RuntimeError:
+        pass            # already set / parallel work started: the intra-op limit above is the one that matters
     oracle = whisper_ref.WhisperOracle(whisper_ref.WhisperDims(**dims.as_dict()), w)
     toks = pdims.special_tokens(dims.n_vocab)
     prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
@@ -288,6 +292,8 @@ def run_recording(runner, audio, scene_subset=None, pooled=True):
     wm = getattr(runner.asr, "whisper_model", None)
     if hasattr(wm, "reset_decode_stats"):
         wm.reset_decode_stats()
+    if hasattr(runner.asr, "_pregate"):
+        runner.asr._pregate = {"segments": 0, "digest": 0}
     t0 = time.perf_counter()
     scenes = runner.detect(audio, pipeline.SR)
     if scene_subset is not None:
@@ -304,6 +310,9 @@ def run_recording(runner, audio, scene_subset=None, pooled=True):
            "segment_digest": int(sum(seg_hash) % (1 << 32)),        # order-independent: the ranks' digests of a sharded run add up
            **({"segment_hashes": seg_hash} if os.environ.get("WJ_BENCH_SEGMENT_HASHES") == "1" and len(seg_hash) <= 4000 else {}),
            "scene_audio_s": round(sum(b - a for a, b in scenes), 1), "t_scene": round(t1 - t0, 4), "t_asr_incl_vad": round(t2 - t1, 4)}
+    pg = getattr(runner.asr, "_pregate", None)
+    if pg is not None:      # candidates before the post-model gate (fidelity mode's gate drops every synthetic-weight segment)
+        out["pre_gate_segments"], out["pre_gate_digest"] = pg["segments"], pg["digest"]
     st = getattr(wm, "decode_stats", None)
     if st and st["windows"]:
         out["decode"] = {"windows": st["windows"], "engine_calls": st["calls"], "tokens_per_window_mean": round(st["tokens"] / st["windows"], 2),
@@ -518,6 +527,24 @@ def run_cfg3(args, info, dims):
         model.word_reseek = True
         line["word_timestamps"] = {"rtfx": round(60.0 * minutes / tw, 2), "ms": round(1e3 * tw, 1),
                                    "what": "the same step with word_timestamps=True (alignment pass + DTW per window); word-driven re-seek off"}
+    if info.rank == 0 and info.world == 1 and not args.no_extras and args.ref_gate_minutes > 0:
+        # the reference's own scene gates (32 / 38 dB, config/components/features/scene_detection.py:74-100) on a recording whose
+        # noise floor lets them work: same speech statistics, pink floor at -66 dBFS (24 dB in auditok's scale), no hum
+        from whisperjav_amd import pipeline as _pl, scenes as _sc
+        quiet = synth.speech_like_long(60.0 * args.ref_gate_minutes, seed=4321, noisy=False, floor_db=-66.0)
+        det_ref = _sc.HipAuditokSceneDetector(device=info.local_rank)          # constructor defaults = the reference's
+        run_ref = _pl.RecordingTranscriber(module, det_ref)
+        run_recording(run_ref, quiet)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        s_ref = run_recording(run_ref, quiet)
+        torch.cuda.synchronize()
+        tr = time.perf_counter() - t1
+        line["reference_scene_gates"] = {"rtfx": round(60.0 * args.ref_gate_minutes / tr, 2), "ms": round(1e3 * tr, 1),
+                                         "gate_db": [det_ref._config.pass1_energy_threshold, det_ref._config.pass2_energy_threshold],
+                                         "what": (f"{args.ref_gate_minutes:g} min of the same synthetic speech over a -66 dBFS floor, scene detector at "
+                                                  "its (= the reference's) default gates, same engine; second of two passes"), **s_ref}
+        del quiet, run_ref
     # the groups of the recording, for the CPU baseline's scaling (before the model goes away)
     n_groups = None
     sample_clips = []
@@ -596,6 +623,25 @@ def run_cfg3(args, info, dims):
                             **sf_}
         del mf, modf, runf
         torch.cuda.empty_cache()
+    if info.rank == 0 and info.world == 1 and not args.no_extras and args.mode == "balanced":
+        # transcribe(max_new_tokens=None) as the reference passes it (config/components/asr/faster_whisper.py:269,309): the KV cache
+        # is sized for n_text_ctx // 2 = 224 new tokens, which costs batch size (512 windows per call instead of 768)
+        import copy
+        a224 = copy.copy(args)
+        a224.max_new_tokens, a224.batch = 224, min(args.batch, 512)
+        m2, mod2, run2 = build_stack(a224, info, dims, dtype, a224.batch, blob=blob2, offsets=offs2, mode="balanced")
+        run_recording(run2, audio)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        s224 = run_recording(run2, audio)
+        torch.cuda.synchronize()
+        t224 = time.perf_counter() - t1
+        mod2.cleanup()
+        line["max_new_tokens_none"] = {"rtfx": round(60.0 * minutes / t224, 2), "ms": round(1e3 * t224, 1), "windows_per_batch": a224.batch,
+                                       "what": ("the same step with max_new_tokens=None (224 new tokens allowed per window, KV cache sized for them, "
+                                                f"{a224.batch} windows per engine call); second of two passes"), **s224}
+        del m2, mod2, run2
+        torch.cuda.empty_cache()
     blob2 = None
     if info.rank == 0 and info.world == 1 and not args.no_extras:
         # the exact-fp32 compute type (north-star parity type, 1e-5 of the oracle) on a bounded sample of the same recording
@@ -632,7 +678,7 @@ def run_cfg3(args, info, dims):
         dst = (stats or {}).get("decode") or {}
         spw = dst["window_steps_run"] / dst["windows"] if dst.get("windows") else None
         line["cpu_baseline"] = cpu_baseline_cfg3(dims, box["w"], sample_clips, n_groups, 60.0 * minutes, args.max_new_tokens,
-                                                 args.beam, args.cpu_threads or min(32, os.cpu_count() or 1),
+                                                 args.beam, args.cpu_threads or min(16, os.cpu_count() or 1),
                                                  step_cap=args.cpu_beam_steps, steps_per_window=spw)
     if info.rank == 0:
         print(json.dumps(line), flush=True)
@@ -746,7 +792,7 @@ def cpu_baseline_cfg5(d, ad, w, clips, budgets, penalty, threads):
                        f"generation to EOS (repetition penalty {penalty:g}) through oracle/qwen3_ref.py on {threads} threads; no aligner pass")}
 
 
-def cfg5_roofline(dec_params, esz, clips, n_iter, stages):
+def cfg5_roofline(dec_params, esz, clips, n_iter, stages, qdt="float16", layer_params=0):
     """The greedy decode iteration: every decoder weight is read once per iteration and multiplied by `clips` rows, i.e.
     `clips` FLOP per weight byte pair -- under the 310 FLOP/B ridge of the part the iteration is bound by the weight stream
     (HBM), above it by the matrix pipes.  Timing: host wall clock around wj_qwen_generate_greedy (a hipGraph replay per
@@ -759,9 +805,12 @@ def cfg5_roofline(dec_params, esz, clips, n_iter, stages):
         return {"bound": "hbm", "kernel": "greedy decode iteration (decoder weights streamed once)", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
     ach = 2.0 * dec_params * clips / sec / 1e12
+    peak = MFMA_PEAK_TFLOPS["float16"]
+    if qdt == "float8w":      # the layers' projections run at the fp8 rate (5 PFLOP/s dense), the LM head at the fp16 rate: time-weighted roof
+        peak = dec_params / (layer_params / 5000.0 + (dec_params - layer_params) / MFMA_PEAK_TFLOPS["float16"])
     return {"bound": "mfma", "kernel": f"greedy decode iteration ({clips} rows through every decoder GEMM and the tied LM head)",
-            "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS["float16"], "unit": "TFLOP/s",
-            "frac": round(ach / MFMA_PEAK_TFLOPS["float16"], 4),
+            "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4),
             "traffic": None, "note": "attention, norms, top-1 and the launch gaps of the iteration are inside the time; GEMM-only figures: DESIGN.md"}
 
 
@@ -788,7 +837,8 @@ def cfg5_measure(args, info, steps, warmup, want_cpu, want_stages=True):
     budgets = [qwen.dynamic_token_limit(float(sv), max_new, rate, floor) for sv in secs]
     ctx = 96 + max(budgets)                                  # <= 78 audio tokens + 6 template tokens, + the largest budget
     tower = qwen.HipQwenAudioTower(ad, w, dtype=args.dtype, device=info.local_rank, max_seconds=min(8 * B, 1024))
-    model = qwen.HipQwen3Decoder(d, w, dtype=args.dtype, device=info.local_rank, max_seqs=B, max_ctx=ctx, max_rows=B * 128)
+    qdt = args.qwen_dtype or args.dtype
+    model = qwen.HipQwen3Decoder(d, w, dtype=qdt, device=info.local_rank, max_seqs=B, max_ctx=ctx, max_rows=B * 128)
     aligner = None
     if args.qwen_aligner:
         # Qwen3-ForcedAligner-0.6B (modules/qwen_asr.py:201): the published Qwen3-0.6B decoder geometry (28 x 1024, 16 / 8 heads of
@@ -884,7 +934,7 @@ def cfg5_measure(args, info, steps, warmup, want_cpu, want_stages=True):
     cpu = None
     if info.rank == 0 and w is not None:
         try:
-            threads = args.cpu_threads or min(32, os.cpu_count() or 1)
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             cpu = cpu_baseline_cfg5(d, ad, w, host_sample, [budgets[i] for i in range(len(host_sample))], penalty, threads)
         except Exception as e:      # a reported figure, never a reason to lose the measured line
             log(f"[bench] cfg5 cpu_baseline skipped: {type(e).__name__}: {e}")
@@ -896,14 +946,17 @@ def cfg5_measure(args, info, steps, warmup, want_cpu, want_stages=True):
         line = {
             "metric": METRIC, "value": round(rtfx, 2), "unit": UNIT, "audio_hours_per_sec": round(rtfx / 3600.0, 5), "n_gpus": info.world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * elapsed / steps, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": DT_LABEL[args.dtype], "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f8 (MX e4m3) x f8, f16 elsewhere" if qdt == "float8w" else DT_LABEL[args.dtype], "data": "synthetic",
             "config": {"workload": (f"cfg5: Qwen3-ASR-1.7B geometry (seeded random weights with the end-of-sequence ramp of qwen.QwenEosRamp), {B} clips of "
                                     f"2-6 s per step (= {audio_s / 60:.0f} min of audio in one batch), samples resident in HBM: RAW log-mel -> audio tower -> "
                                     f"ragged prefill -> greedy generation TO EOS with repetition_penalty {penalty:g} and per-clip budgets "
                                     f"(max_tokens_per_audio_second {rate:g}, floor {floor}, cap {max_new}: the reference pipeline's controls)"
                                     + (" -> forced-aligner pass (Qwen3-0.6B decoder geometry + audio tower + 512-bin head, every generated token a word)"
                                        if aligner else " ; no aligner pass")
-                                    + f"; float16 with split activations (wj_tune qwen_split_act, default 2); no TEN-VAD (clips are given), fp16 weights (no fp8)"),
+                                    + (f"; decoder compute type {qdt}" + (" (MX-fp8 projections on v_mfma_scale_f32_16x16x128_f8f6f4, fp16 LM head)" if qdt == "float8w"
+                                                                           else " with split activations (wj_tune qwen_split_act, default 2)" if qdt == "float16" else "")
+                                       + "; no TEN-VAD (clips are given)")),
+                       "decoder_compute_type": qdt,
                        "clips_per_step": B, "audio_seconds_per_step": round(audio_s, 1),
                        "tokens_generated": int(lens.sum()), "tokens_per_clip": {"mean": round(float(lens.mean()), 1), "min": int(lens.min()), "max": int(lens.max())},
                        "ended_on_eos": int((lens < np.array(budgets)).sum()), "decode_iterations": res.steps,
@@ -911,7 +964,8 @@ def cfg5_measure(args, info, steps, warmup, want_cpu, want_stages=True):
                        "aligner_bins_crc32": (zlib.crc32(np.concatenate(lab[0]).astype(np.int32).tobytes()) if lab else None),
                        "tokens_crc32": zlib.crc32(np.concatenate([np.asarray(t, dtype=np.int32) for t in res.tokens] + [np.zeros(0, np.int32)]).tobytes()),
                        "decoder_weight_bytes_per_iteration": dec_params * esz, "stages": stages},
-            "roofline": cfg5_roofline(dec_params, esz, B, stages.get("decode_iterations") or res.steps, stages),
+            "roofline": cfg5_roofline(dec_params, esz, B, stages.get("decode_iterations") or res.steps, stages, qdt,
+                                      dec_params - d.vocab * d.hidden),
             "cpu_baseline": cpu}
     tower.close(); model.close()
     if aligner:
@@ -942,7 +996,11 @@ def main():
     ap.add_argument("--qwen-token-floor", type=int, default=256, help="cfg5: floor of the per-clip budget (reference: 256)")
     ap.add_argument("--qwen-repetition-penalty", type=float, default=1.1, help="cfg5: transformers' repetition penalty over prompt + "
                     "generated ids (reference pipeline default 1.1)")
+    ap.add_argument("--qwen-dtype", default="", choices=["", "float16", "bfloat16", "float32", "float8w"],
+                    help="cfg5: compute type of the ASR decoder (default: --dtype); float8w = MX-fp8 projections (BASELINE cfg5's 'fp8 MFMA')")
     ap.add_argument("--no-qwen-aligner", dest="qwen_aligner", action="store_false", help="cfg5: leave the forced-aligner pass out of the step")
+    ap.add_argument("--ref-gate-minutes", type=float, default=20.0, help="default line: minutes of the studio-floor recording run with the "
+                    "reference's own scene gates (0 = skip)")
     ap.add_argument("--cfg5-clips", type=int, default=1800, help="default line: clips of the cfg5 figure (0 = skip it)")
     ap.add_argument("--minutes", type=float, default=120.0, help="cfg3: length of the synthetic recording")
     ap.add_argument("--mode", default="balanced", choices=["balanced", "fidelity"],
@@ -964,10 +1022,11 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16", "float32"])
     ap.add_argument("--fp32-minutes", type=float, default=3.0, help="cfg3: audio minutes of the fp32-mode figure")
-    ap.add_argument("--cpu-sample-groups", type=int, default=4, help="cpu_baseline: VAD groups of the recording run on the host")
-    ap.add_argument("--cpu-beam-steps", type=int, default=10, help="cpu_baseline: beam-search iterations measured per group (0 = every group to EOT, "
-                    "~40 s of host time per group); the decode time is scaled to the iterations per window the GPU run took")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="cpu_baseline: PyTorch threads (0 = min(32, cores): more threads slow the small decode GEMMs)")
+    ap.add_argument("--cpu-sample-groups", type=int, default=2, help="cpu_baseline: VAD groups of the recording run on the host")
+    ap.add_argument("--cpu-beam-steps", type=int, default=0, help="cpu_baseline: beam-search iterations measured per group; 0 (default since round 4) = "
+                    "every sampled group's search runs to its END, no extrapolation (round 3 measured 10 iterations and scaled x3.35)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="cpu_baseline: PyTorch threads (0 = min(16, cores), pinned with torch.set_num_threads "
+                    "AND OMP/MKL limits: the small decode GEMMs do not scale past that and the figure varied 2.5x between boxes at 32)")
     ap.add_argument("--weights", default="speechlike", choices=["speechlike", "plain"],
                     help="speechlike: EOT-bearing synthetic weights (searches end, token count grows with the audio in the window); plain: never EOT")
     ap.add_argument("--eot-rate", type=float, default=12.0, help="speechlike: nominal tokens per second of audio content (realised: see workload_facts)")

@@ -38,7 +38,13 @@ enum {
  * GEMM / attention operands on the matrix cores with fp32 accumulation and an fp32 residual stream, LayerNorm,
  * softmax and logits.  WJ_F16 is the arithmetic the reference runs on a GPU (ctranslate2 compute_type="float16",
  * whisper fp16=True: whisperjav/modules/whisper_pro_asr.py:201-218). */
-enum { WJ_F32 = 0, WJ_BF16 = 1, WJ_F16 = 2 };
+enum { WJ_F32 = 0, WJ_BF16 = 1, WJ_F16 = 2,
+       /* ABI 4, wj_qwen_create only (BASELINE cfg5: "fp8 MFMA"): the blob holds float16 matrices; the four projection matrices of
+        * every decoder layer are re-quantised at create to MX-fp8 (OCP e4m3, E8M0 scale per 32 elements) and multiplied with
+        * activations quantised the same way on the fly, on v_mfma_scale_f32_16x16x128_f8f6f4; embeddings, norms, attention, KV
+        * caches and the LM head stay float16 (the head with split activations).  A throughput type: 3 mantissa bits on both GEMM
+        * operands put the log-probs ~1e-1 from the fp32 evaluation (tests/test_gpu_qwen.py states the measured bound). */
+       WJ_F8W = 3 };
 enum { WJ_MEL_FW = 0, WJ_MEL_OW = 1, WJ_MEL_RAW = 2 };   /* faster-whisper / openai-whisper mel semantics; RAW = no zero padding
                                                          * (Qwen3-ASR's feature extractor: the same formula on the clip as it is) */
 
@@ -425,6 +431,15 @@ int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, cons
 int wj_k_gemm_timed(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, const float* bias_dev,
                     void* c_dev, int M, int N, int K, int act_gelu, int out_f32, int variant, int reps,
                     float* ms_per_launch);
+
+/* ABI 4, MX-fp8 GEMM (the arithmetic of the Qwen decoder's WJ_F8W compute type, BASELINE cfg5 "fp8 MFMA"): a and w arrive as fp32
+ * [M][K] / [N][K]; both are quantised on the device to OCP e4m3 with one E8M0 scale per 32-element block (OCP MX v1.0: scale
+ * 2^(floor(log2 amax) - 8), round to nearest even, saturation at +-448) and multiplied on v_mfma_scale_f32_16x16x128_f8f6f4 with
+ * fp32 accumulation.  dtype = type of the 16-bit output (out_f32 != 0: fp32 [M][N]).  The *_out_dev pointers (may be NULL) receive
+ * the quantised bytes and scale bytes, so a test can rebuild the exact product on the host; reps > 0 times the GEMM launches. */
+int wj_k_gemm_mx8(wj_ctx* ctx, int dtype, const float* a_f32_dev, const float* w_f32_dev, const float* bias_dev, void* c_dev, int M, int N,
+                  int K, int out_f32, uint8_t* a8_out_dev, uint8_t* a_scale_out_dev, uint8_t* w8_out_dev, uint8_t* w_scale_out_dev, int reps,
+                  float* ms_per_launch, void* stream);
 /* Split-activation GEMM of the fp16 / bf16 decode step: a_f32_dev float32 [M][K] is stored as [hi | lo] 16-bit rows
  * (hi = T(a), lo = T(a - hi)) and C = W.hi + W.lo is accumulated in one fp32 accumulator; c_dev float32 [M][N].
  * variant as for wj_k_gemm (rows / skinny / LDS-DMA tile kernels). */

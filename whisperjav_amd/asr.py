@@ -266,6 +266,9 @@ class HipFasterWhisperProASR:
     # ---- statistics hooks used by the pipelines -------------------------------------------------
     def _reset_runtime_statistics(self) -> None:
         self._filter_statistics = {"logprob_filtered": 0, "nonverbal_filtered": 0}
+        # every candidate segment BEFORE the suppress lists and the log-prob / nonverbal gate: count and order-independent digest
+        # (a regression check that still works when the gate drops everything, as it does on synthetic weights in fidelity mode)
+        self._pregate = {"segments": 0, "digest": 0}
         self._last_vad_segments: List[Dict] = []
         self._vad_segments_per_scene: List[List[Dict]] = []
 
@@ -460,6 +463,11 @@ class HipFasterWhisperProASR:
             text = (seg.text or "").strip()
             if not text:
                 continue
+            pg = getattr(self, "_pregate", None)
+            if pg is not None:
+                import zlib
+                pg["segments"] += 1
+                pg["digest"] = (pg["digest"] + zlib.crc32(f"{seg.start + start_sec:.2f},{seg.end + start_sec:.2f},{text}".encode())) % (1 << 32)
             if any(s in text for s in self.suppress_high):
                 continue
             avg_lp = seg.avg_logprob

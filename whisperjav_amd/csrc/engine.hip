@@ -1716,6 +1716,49 @@ int wj_k_gemm(wj_ctx* ctx, int dtype, const void* a_dev, const void* w_dev, cons
   return launch_gemm(dtype, e, g, ctx->pick(stream), variant);
 }
 
+int wj_k_gemm_mx8(wj_ctx* ctx, int dtype, const float* a_f32_dev, const float* w_f32_dev, const float* bias_dev, void* c_dev, int M, int N,
+                  int K, int out_f32, uint8_t* a8_out_dev, uint8_t* a_scale_out_dev, uint8_t* w8_out_dev, uint8_t* w_scale_out_dev, int reps,
+                  float* ms_per_launch, void* stream) {
+  WJ_REQUIRE(ctx && a_f32_dev && w_f32_dev && c_dev, "wj_k_gemm_mx8: NULL argument");
+  WJ_REQUIRE(is16(dtype) && M >= 1 && N >= 1 && K >= 128 && K % 128 == 0, "wj_k_gemm_mx8: 16-bit output types, K a multiple of 128");
+  WJ_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->pick(stream);
+  uint8_t *a8 = nullptr, *sa = nullptr, *w8 = nullptr, *sw = nullptr;
+  auto cleanup = [&]() { (void)hipFree(a8); (void)hipFree(sa); (void)hipFree(w8); (void)hipFree(sw); };
+  if (hipMalloc(&a8, (size_t)M * K) != hipSuccess || hipMalloc(&sa, (size_t)M * K / 32) != hipSuccess ||
+      hipMalloc(&w8, (size_t)N * K) != hipSuccess || hipMalloc(&sw, (size_t)N * K / 32) != hipSuccess) {
+    cleanup();
+    set_error("wj_k_gemm_mx8: out of device memory");
+    return WJ_E_HIP;
+  }
+  int rc = launch_mx8_quantize(WJ_F32, a_f32_dev, K, M, K, a8, sa, s);
+  if (!rc) rc = launch_mx8_quantize(WJ_F32, w_f32_dev, K, N, K, w8, sw, s);
+  GemmArgs g;
+  g.A = a8; g.lda = K; g.W = w8; g.ldw = K; g.a_scale = sa; g.w_scale = sw; g.mx8 = 1; g.bias = bias_dev;
+  g.M = M; g.N = N; g.K = K; g.out = c_dev; g.ldc = N;
+  const Epi e = out_f32 ? EPI_F32 : EPI_T;
+  if (!rc) rc = launch_gemm(dtype, e, g, s, 0);
+  if (!rc && reps > 0 && ms_per_launch) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < reps && !rc; ++i) rc = launch_gemm(dtype, e, g, s, 0);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / reps;
+  }
+  if (!rc && a8_out_dev) rc = hipMemcpyAsync(a8_out_dev, a8, (size_t)M * K, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : WJ_E_HIP;
+  if (!rc && a_scale_out_dev) rc = hipMemcpyAsync(a_scale_out_dev, sa, (size_t)M * K / 32, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : WJ_E_HIP;
+  if (!rc && w8_out_dev) rc = hipMemcpyAsync(w8_out_dev, w8, (size_t)N * K, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : WJ_E_HIP;
+  if (!rc && w_scale_out_dev) rc = hipMemcpyAsync(w_scale_out_dev, sw, (size_t)N * K / 32, hipMemcpyDeviceToDevice, s) == hipSuccess ? 0 : WJ_E_HIP;
+  (void)hipStreamSynchronize(s);
+  cleanup();
+  return rc;
+}
+
 int wj_k_gemm_split(wj_ctx* ctx, int dtype, const float* a_f32_dev, const void* w_dev, const float* bias_dev, float* c_dev,
                     int M, int N, int K, int variant, void* stream) {
   WJ_REQUIRE(ctx && a_f32_dev && w_dev && c_dev, "wj_k_gemm_split: NULL argument");

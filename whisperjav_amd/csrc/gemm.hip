@@ -1008,7 +1008,10 @@ __global__ __launch_bounds__(512) void gemm_h_big_pp64_kernel(const GemmArgs g) 
   const int off_h1 = rowoff + (((4 + (lane >> 4)) ^ (lane & 7)) << 3);
   const int a_base = wm * 128 * TBK, w_base = BBM * TBK + wn * 64 * TBK;
 
-  const int np = g.K / TBK;
+  // split activations (GemmArgs::split, round 4: the Qwen prompt / aligner passes at >= 8192 rows): A rows are [hi(K) | lo(K)],
+  // the pair loop runs over 2 K columns of A and the W pointers wrap back to column 0 half way -- the k order (all of hi, then
+  // all of lo) and therefore the bits are those of the 128-tile kernel's split mode
+  const int np = (g.split ? 2 * g.K : g.K) / TBK;
   WJ_P6_ISSUE(0)
   wait_vmcnt<0>();
   wg_barrier();                  // P: pair 0 visible to every wave
@@ -1036,7 +1039,13 @@ __global__ __launch_bounds__(512) void gemm_h_big_pp64_kernel(const GemmArgs g) 
     const int b = p & 1;
     // ---- MEM(2p): k-half 0 of pair p; request pair p+1
     WJ_P6_READ(b, off_h0)
-    if (p + 1 < np) { WJ_P6_ISSUE(b ^ 1) }
+    if (p + 1 < np) {
+      if (g.split && p + 1 == (np >> 1)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gw[q] -= g.K;
+      }
+      WJ_P6_ISSUE(b ^ 1)
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wg_barrier();
     WJ_P6_MFMA()
@@ -1429,6 +1438,191 @@ static int launch_big_pp(const GemmArgs& a, hipStream_t s, int ns) {
   }
 }
 
+
+// --------------------------------------------------------------------------------------------
+// MX-fp8 GEMM (round 4): C = A8 . W8^T with OCP e4m3 operands and one E8M0 scale per 32-element block on BOTH operands,
+// on v_mfma_scale_f32_16x16x128_f8f6f4 (the only large-K low-precision MFMA of gfx950: 2x the fp16 rate, 5 PFLOP/s dense).
+// Operand layout of the instruction, verified on the MI355X by scripts/mx_probe.hip (profiles/r04_mx_mfma_layout_probe.jsonl:
+// the ISA text is not on this box): lane (r = lane & 15, g = lane >> 4) holds row r of its operand, registers 0-3 = bytes
+// k = 16 g .. 16 g + 15 and registers 4-7 = bytes k = 64 + 16 g .. + 15 of the 128-wide step -- i.e. the two 16-byte chunks g
+// and 4 + g of a 128-byte row, exactly the two fragment reads the 16-bit tile kernel makes for its two 32-wide halves -- and
+// the scale VGPR of lane group g carries (byte 0) the scale of MX block g (k = 32 g .. 32 g + 31) of row r.
+// D[lane][i] = sum_k first[4 g + i][k] second[r][k]: with the weights first a lane ends up with 4 consecutive output columns
+// of row r, the orientation of every other tile kernel here, so the epilogues are shared.
+// Tile 128 x 128, 4 waves, k step 128 bytes: the LDS image, the LDS-DMA staging and the XOR swizzle of gemm_h_tile_kernel with
+// a row = 128 bytes of fp8 instead of 64 halves.  Scales come straight from L2 (4 bytes per row and step), one step ahead.
+// --------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_mx8_tile_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds8[2 * 2 * TBM * 128];  // [buf][A|W][128 rows][128 B] = 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nx = gridDim.x, ntiles = gridDim.x * gridDim.y;
+  const int lin = blockIdx.y * nx + blockIdx.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  constexpr int GM = 8;
+  const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
+  const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
+  const int m0 = (first_m + in_group % gsz) * TBM, n0 = (in_group / gsz) * TBN;
+  const uint8_t* __restrict__ A = reinterpret_cast<const uint8_t*>(g.A);
+  const uint8_t* __restrict__ W = reinterpret_cast<const uint8_t*>(g.W);
+  const int nk = g.K / 128, nsc = g.K / 32;      // launch guarantees K % 128 == 0
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#define WJ_MX_STAGE(buf, k0)                                                                       \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                  \
+    const int r0 = (wave * 4 + q) * 8;                                                             \
+    const int row = r0 + (lane >> 3);                                                              \
+    const int c = (lane & 7) ^ (row & 7);                                                          \
+    const uint8_t* ga = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + (k0) + c * 16;               \
+    const uint8_t* gw = W + (int64_t)min(n0 + row, g.N - 1) * g.ldw + (k0) + c * 16;               \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,            \
+        (__attribute__((address_space(3))) void*)(&lds8[((buf) * 2 + 0) * TBM * 128 + r0 * 128]), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,            \
+        (__attribute__((address_space(3))) void*)(&lds8[((buf) * 2 + 1) * TBM * 128 + r0 * 128]), 16, 0, 0); \
+  }
+  // scale bytes of this lane's rows: A rows wm * 64 + i * 16 + r, W rows wn * 64 + j * 16 + r, MX block kt * 4 + g
+  const int r = lane & 15, gq = lane >> 4;
+  const uint8_t* sa_p[4];
+  const uint8_t* sw_p[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    sa_p[i] = g.a_scale + (int64_t)min(m0 + wm * 64 + i * 16 + r, g.M - 1) * nsc + gq;
+    sw_p[i] = g.w_scale + (int64_t)min(n0 + wn * 64 + i * 16 + r, g.N - 1) * nsc + gq;
+  }
+  int sa[4], sw[4], sa_n[4], sw_n[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { sa[i] = sa_p[i][0]; sw[i] = sw_p[i][0]; }
+
+  WJ_MX_STAGE(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      WJ_MX_STAGE(cur ^ 1, (kt + 1) * 128)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sa_n[i] = sa_p[i][(kt + 1) * 4]; sw_n[i] = sw_p[i][(kt + 1) * 4]; }
+    }
+    const uint8_t* la = &lds8[(cur * 2 + 0) * TBM * 128];
+    const uint8_t* lb = &lds8[(cur * 2 + 1) * TBM * 128];
+    i32x8_t af[4], wf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wm * 64 + i * 16 + r;
+      const uint4 lo = *reinterpret_cast<const uint4*>(&la[row * 128 + ((gq ^ (row & 7)) << 4)]);
+      const uint4 hi = *reinterpret_cast<const uint4*>(&la[row * 128 + (((4 + gq) ^ (row & 7)) << 4)]);
+      af[i] = i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wn * 64 + j * 16 + r;
+      const uint4 lo = *reinterpret_cast<const uint4*>(&lb[row * 128 + ((gq ^ (row & 7)) << 4)]);
+      const uint4 hi = *reinterpret_cast<const uint4*>(&lb[row * 128 + (((4 + gq) ^ (row & 7)) << 4)]);
+      wf[j] = i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (EPI == EPI_VT)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i], wf[j], acc[i][j], 0, 0, 0, sa[i], 0, sw[j]);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, sw[j], 0, sa[i]);
+      }
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { sa[i] = sa_n[i]; sw[i] = sw_n[i]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of step kt+1 has landed
+    __syncthreads();
+  }
+#undef WJ_MX_STAGE
+  tile_epilogue<EPI, T, 4>(g, 0, m0 + wm * 64, n0 + wn * 64, lane, acc);
+}
+
+template <typename T, int EPI>
+static int launch_mx8(const GemmArgs& a, hipStream_t s) {
+  if constexpr (EPI == EPI_PARTIAL_F32 || EPI == EPI_QKV_DEC || EPI == EPI_GELU_POS_F32) {
+    set_error("gemm: the MX-fp8 kernel carries the plain / residual / head-split epilogues only");
+    return WJ_E_INVALID;
+  } else {
+    if ((a.K % 128) || a.nbatch != 1 || a.split || a.blk || !a.a_scale || !a.w_scale || a.lda < a.K || a.ldw < a.K) {
+      set_error("gemm: MX-fp8 operands need K %% 128 == 0, one batch, both scale arrays and byte strides >= K (K=%d)", a.K);
+      return WJ_E_INVALID;
+    }
+    dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), 1);
+    hipLaunchKernelGGL((gemm_mx8_tile_kernel<T, EPI>), grid, dim3(256), 0, s, a);
+    WJ_LAUNCH_CHECK();
+    return WJ_OK;
+  }
+}
+
+// One thread per 32-element block: amax -> E8M0 scale 2^(floor(log2 amax) - 8) (OCP MX, e4m3: emax = 8), elements scaled,
+// clamped to +-448 and rounded to nearest even by v_cvt_pk_fp8_f32 (gfx950: OCP e4m3).  An all-zero block gets scale 2^-127.
+template <typename S>
+__global__ __launch_bounds__(256) void mx8_quantize_kernel(const S* __restrict__ src, int64_t ld, int rows, int K,
+                                                           uint8_t* __restrict__ out8, uint8_t* __restrict__ scales) {
+  const int nb = K / 32;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)rows * nb) return;
+  const int row = (int)(idx / nb), b = (int)(idx - (int64_t)row * nb);
+  const S* p = src + (int64_t)row * ld + b * 32;
+  float v[32];
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    if constexpr (sizeof(S) == 4) {
+      const float4 x = *reinterpret_cast<const float4*>(p + i), y = *reinterpret_cast<const float4*>(p + i + 4);
+      v[i] = x.x; v[i + 1] = x.y; v[i + 2] = x.z; v[i + 3] = x.w; v[i + 4] = y.x; v[i + 5] = y.y; v[i + 6] = y.z; v[i + 7] = y.w;
+    } else {
+      ld8(p + i, v + i);
+    }
+  }
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(v[i]));
+  int e = -127;
+  if (amax > 0.f) {
+    e = ((__float_as_int(amax) >> 23) & 0xff) - 127 - 8;      // floor(log2 amax) - emax; subnormal inputs land at the clamp below
+    e = max(-127, min(127, e));
+  }
+  scales[(int64_t)row * nb + b] = (uint8_t)(e + 127);
+  const float inv = __int_as_float((127 - e) << 23 > 0 ? (127 - e) << 23 : 0x00400000);      // 2^-e (e <= 127 -> exponent field >= 0)
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float q[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) q[t] = fminf(448.f, fmaxf(-448.f, v[4 * i + t] * inv));
+    int packed = 0;
+    packed = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], packed, false);
+    packed = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], packed, true);
+    w[i] = (uint32_t)packed;
+  }
+  uint4* o = reinterpret_cast<uint4*>(out8 + (int64_t)row * K + b * 32);
+  o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+int launch_mx8_quantize(int src_dtype, const void* src, int64_t ld, int rows, int K, uint8_t* out8, uint8_t* scales, hipStream_t s) {
+  if ((K % 32) || (ld % 8) || rows <= 0) { set_error("mx8_quantize: K %% 32 == 0 and ld %% 8 == 0 required"); return WJ_E_INVALID; }
+  const unsigned blocks = (unsigned)ceil_div64((int64_t)rows * (K / 32), 256);
+  if (src_dtype == WJ_F32) hipLaunchKernelGGL((mx8_quantize_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)src, ld, rows, K, out8, scales);
+  else if (src_dtype == WJ_F16) hipLaunchKernelGGL((mx8_quantize_kernel<f16_t>), dim3(blocks), dim3(256), 0, s, (const f16_t*)src, ld, rows, K, out8, scales);
+  else hipLaunchKernelGGL((mx8_quantize_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, ld, rows, K, out8, scales);
+  WJ_LAUNCH_CHECK();
+  return WJ_OK;
+}
+
 // --------------------------------------------------------------------------------------------
 // bf16 MFMA, skinny (decode) kernel: 16 output columns per workgroup, 8 waves split K
 // --------------------------------------------------------------------------------------------
@@ -1700,6 +1894,7 @@ int launch_splitk_reduce(int dtype, Epi epi, const GemmArgs& a, const float* sla
 // --------------------------------------------------------------------------------------------
 template <typename T, int EPI>
 static int launch_epi16(const GemmArgs& a, hipStream_t s, int variant) {
+  if (a.mx8) return launch_mx8<T, EPI>(a, s);
   if (a.blk) return launch_big_ppb<T, EPI>(a, s);
   if (variant == 5 || (variant >= 50 && variant < 70)) return launch_rows<T, EPI>(a, s, variant == 5 ? 0 : variant - 50);
   if (variant == 7 || (variant >= 73 && variant <= 75)) return launch_ms<T, EPI>(a, s, variant == 7 ? 4 : variant - 70);
@@ -1728,10 +1923,11 @@ static int launch_epi16(const GemmArgs& a, hipStream_t s, int variant) {
     return WJ_OK;
   }
   // big encoder GEMMs: 256-tile kernel (variant 6 forces it, 0 = auto when the shape qualifies)
-  const bool big_ok = EPI != EPI_PARTIAL_F32 && (a.N % BBN) == 0 && (a.K % TBK) == 0 && a.M >= 1024 && !a.split;
+  const bool big_ok = EPI != EPI_PARTIAL_F32 && (a.N % BBN) == 0 && (a.K % TBK) == 0 && a.M >= 1024 && (!a.split || g_gemm_big == 6);
   if (variant == 6 && !big_ok) { set_error("gemm: the 256-tile kernel needs N %% 256 == 0, K %% 64 == 0, M >= 1024"); return WJ_E_INVALID; }
   // 83 / 84 / 85 force the ping-pong kernel with a 3 / 4 / 5 stage ring; wj_tune("gemm_big", 3 / 4 / 5) makes it the default
-  const bool pp_ok = big_ok && (a.K % PBK) == 0 && a.K / PBK >= 5;
+  const bool pp_ok = big_ok && !a.split && (a.K % PBK) == 0 && a.K / PBK >= 5;
+  if (a.split && (variant == 6 || variant == 87)) { set_error("gemm: of the 256-tile kernels only the pairs kernel (86) takes split activations"); return WJ_E_INVALID; }
   if ((variant >= 100 && variant < 270) || variant == 93 || variant == 94) {   // timing ablations of the ping-pong kernel (wrong results by design): 100 + 10 ABL + NS
     if constexpr (EPI == EPI_T && Elem<T>::dtype == WJ_F16) {
       if (!pp_ok) { set_error("gemm: shape not supported by the ping-pong kernel"); return WJ_E_INVALID; }
@@ -1811,6 +2007,7 @@ int launch_gemm(int dtype, Epi epi, const GemmArgs& a_in, hipStream_t s, int var
   GemmArgs a = a_in;
   a.epi_wide = g_epi_wide;
   if (a.blk && !is16(dtype)) { set_error("gemm: blocked operands are a 16-bit feature"); return WJ_E_INVALID; }
+  if (a.mx8 && !is16(dtype)) { set_error("gemm: MX-fp8 operands take a 16-bit output type"); return WJ_E_INVALID; }
   if (a.out_blk && (!a.blk || (epi != EPI_T && epi != EPI_GELU_T) || (a.N % 32))) {
     set_error("gemm: a blocked output needs blocked operands, an EPI_T / EPI_GELU_T epilogue and N %% 32 == 0");
     return WJ_E_INVALID;

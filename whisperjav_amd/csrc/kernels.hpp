@@ -53,6 +53,12 @@ struct GemmArgs {
   int blk = 0, out_blk = 0, seq_T = 0;
   float inv_seq_T = 0.f;          // set by launch_gemm
   int gm = 8;                     // row tiles per group of the blocked kernel's tile order (set by its launcher)
+  // MX-fp8 operands (round 4, the Qwen decoder's WJ_F8W type): A and W are OCP e4m3 bytes [rows][K] (lda / ldw in BYTES) with one
+  // E8M0 scale byte per 32-element block, a_scale [M][K / 32] and w_scale [N][K / 32]; the product runs on
+  // v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulation, the epilogue is the 16-bit one of the dtype passed to launch_gemm
+  int mx8 = 0;
+  const uint8_t* a_scale = nullptr;
+  const uint8_t* w_scale = nullptr;
 };
 
 // variant: 0 = auto; 1 = tiled MFMA kernel (default staging); 2 = skinny (decode) kernel;
@@ -62,6 +68,10 @@ int launch_gemm(int dtype, Epi epi, const GemmArgs& a, hipStream_t s, int varian
 // row-major 2-byte [rows][ld] -> blocked [ceil(rows / 256)][cols / 32][256][32] (pad rows zero-filled) and back
 int launch_to_blocked(const void* src, int64_t ld, int rows, int cols, void* dst, hipStream_t s);
 int launch_from_blocked(const void* src, int rows, int cols, void* dst, int64_t ld, hipStream_t s);
+
+// MX quantisation of 2-byte / fp32 rows: out8 [rows][K] e4m3 bytes, scales [rows][K / 32] E8M0 bytes (OCP MX: the block's scale is
+// 2^(floor(log2 amax) - 8), elements round to nearest even and saturate at +-448).  src_dtype WJ_F32 / WJ_F16 / WJ_BF16, ld in elements.
+int launch_mx8_quantize(int src_dtype, const void* src, int64_t ld, int rows, int K, uint8_t* out8, uint8_t* scales, hipStream_t s);
 
 // second half of a split-K GEMM whose epilogue has no consumer kernel to fold the reduction into:
 // out = EPI(bias + sum_s slab[s][M][N]); `a` carries the epilogue operands exactly as for launch_gemm

@@ -314,8 +314,16 @@ struct wj_qwen {
   int32_t* embed_ids = nullptr;      // staging of wj_qwen_embed (its own buffer: row_seq holds decode state between prefill and generate)
   // float16: the GEMMs that write the residual stream (o_proj, down_proj) and the LM head read their activations as
   // [hi | lo] fp16 pairs (x to ~22 bits, W.hi + W.lo in one fp32 accumulator) -- the measure that brought the Whisper
-  // decoder inside 1e-3.  wj_tune "qwen_split_act": 0 = off, 1 = decode iterations and the head, 2 (default) = also prompts
+  // decoder inside 1e-3.  wj_tune "qwen_split_act": 0 = off, 1 = decode iterations and the head, 2 (default) = also prompts,
+  // 3 = in addition the RMSNorm outputs that feed the q/k/v and gate/up projections (every GEMM of the decoder then sees ~22-bit activations)
   int split_mode = 0;
+  // WJ_F8W: the layers' projection matrices as MX-fp8 (e4m3 bytes + E8M0 scales per 32 elements), activations quantised per GEMM
+  bool mx8 = false;
+  uint8_t* w8 = nullptr;          // all layers: [qkv | o | gate_up | down] bytes
+  uint8_t* w8s = nullptr;         // ... their scales
+  std::vector<int64_t> w8_off, w8s_off;     // per (layer, matrix 0..3)
+  uint8_t* a8 = nullptr;          // activation scratch [max_rows][max K]
+  uint8_t* a8s = nullptr;
   int last_used_graph = 0;   // the last generation replayed its iteration from a hipGraph
   int last_steps = 0;        // decode iterations the last generation ran (it leaves the loop when every sequence has ended)
   int last_truncated = 0;    // sequences whose token budget was cut to the room left in the KV cache
@@ -352,7 +360,17 @@ int gemm_variant(QGemm which, int M, int K, int dt) {
 // rows [0, M) through every decoder layer; row_seq / row_pos describe them.  split: the attention output and the SwiGLU
 // output are stored as [hi | lo] rows and o_proj / down_proj consume them as split activations (float16 only)
 int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
+  if (m->mx8) split = false;         // MX-fp8 projections: the activations are quantised per GEMM, nothing to split
   const wj_qwen_dims& d = m->d;
+  // WJ_F8W: quantise the GEMM's activation rows (float16 [M][K], row stride ld) into the scratch and point the GEMM at them
+  auto mx = [&](GemmArgs& g, int l, int which) -> int {
+    if (!m->mx8) return WJ_OK;
+    WJ_TRYQ(launch_mx8_quantize(WJ_F16, g.A, g.lda, g.M, g.K, m->a8, m->a8s, s));
+    g.A = m->a8; g.lda = g.K; g.a_scale = m->a8s;
+    g.W = m->w8 + m->w8_off[l * 4 + which]; g.ldw = g.K; g.w_scale = m->w8s + m->w8s_off[l * 4 + which];
+    g.mx8 = 1; g.split = 0;
+    return WJ_OK;
+  };
   const int D = d.hidden, H = d.n_head, KV = d.n_kv_head, F = d.ffn, dt = m->dtype;
   const int W = (H + 2 * KV) * HD;
   const int64_t layer_kv = (int64_t)m->max_seqs * KV * m->max_ctx * HD;
@@ -360,10 +378,11 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
     const int b0 = m->layer_base(l);
     void* kc = m->at(m->kc, l * layer_kv);
     void* vc = m->at(m->vc, l * layer_kv);
+    const int sp_in = (split && m->split_mode >= 3) ? 1 : 0;      // the projections' INPUT (h) as [hi | lo] too
     auto rms = [&](const float* w, void* out) -> int {
-      if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(M), dim3(256), 0, s, m->x, w, TP(float, out), M, D, d.rms_eps);
-      else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(M), dim3(256), 0, s, m->x, w, TP(f16_t, out), M, D, d.rms_eps);
-      else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(M), dim3(256), 0, s, m->x, w, TP(bf16_t, out), M, D, d.rms_eps);
+      if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(M), dim3(256), 0, s, m->x, w, TP(float, out), M, D, d.rms_eps, 0);
+      else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(M), dim3(256), 0, s, m->x, w, TP(f16_t, out), M, D, d.rms_eps, sp_in);
+      else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(M), dim3(256), 0, s, m->x, w, TP(bf16_t, out), M, D, d.rms_eps, sp_in);
       WJ_LAUNCH_CHECK();
       return WJ_OK;
     };
@@ -372,6 +391,8 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
       GemmArgs g;
       g.A = m->h; g.lda = D; g.W = m->W(b0 + WJ_QL_QKV_W); g.ldw = D; g.M = M; g.N = W; g.K = D; g.out = m->qkv; g.ldc = W;
       if (split) { g.split_out = 1; g.ldc = 2 * W; }
+      if (sp_in) { g.split = 1; g.lda = 2 * D; }
+      WJ_TRYQ(mx(g, l, 0));
       WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, gemm_variant(QG_QKV, M, D, dt)));
     }
     const float l2t = log2f(d.rope_theta);
@@ -404,6 +425,7 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
       GemmArgs g;
       g.A = m->attn; g.lda = (split ? 2 : 1) * H * HD; g.split = split ? 1 : 0;
       g.W = m->W(b0 + WJ_QL_O_W); g.ldw = H * HD; g.M = M; g.N = D; g.K = H * HD; g.out = m->x; g.ldc = D;
+      WJ_TRYQ(mx(g, l, 1));
       WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, gemm_variant(QG_O, M, H * HD, dt)));
     }
     WJ_TRYQ(rms(m->F(b0 + WJ_QL_LN2_W), m->h));
@@ -411,6 +433,8 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
       GemmArgs g;
       g.A = m->h; g.lda = D; g.W = m->W(b0 + WJ_QL_GATEUP_W); g.ldw = D; g.M = M; g.N = 2 * F; g.K = D; g.out = m->gu; g.ldc = 2 * F;
       if (split) { g.split_out = 1; g.ldc = 4 * F; }
+      if (sp_in) { g.split = 1; g.lda = 2 * D; }
+      WJ_TRYQ(mx(g, l, 2));
       WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, gemm_variant(QG_GATEUP, M, D, dt)));
     }
     {
@@ -425,6 +449,7 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
       GemmArgs g;
       g.A = m->act; g.lda = (split ? 2 : 1) * F; g.split = split ? 1 : 0;
       g.W = m->W(b0 + WJ_QL_DOWN_W); g.ldw = F; g.M = M; g.N = D; g.K = F; g.out = m->x; g.ldc = D;
+      WJ_TRYQ(mx(g, l, 3));
       WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, gemm_variant(QG_DOWN, M, F, dt)));
     }
   }
@@ -483,7 +508,13 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
              d.n_layer >= 1 && d.vocab >= 2, "wj_qwen_create: bad dimensions");
   WJ_REQUIRE(d.n_head / d.n_kv_head == 1 || d.n_head / d.n_kv_head == 2 || d.n_head / d.n_kv_head == 4,
              "wj_qwen_create: %d query heads per KV head (the attention kernel is instantiated for 1, 2 and 4)", d.n_head / d.n_kv_head);
-  WJ_REQUIRE(dtype == WJ_F32 || dtype == WJ_F16 || dtype == WJ_BF16, "wj_qwen_create: unknown dtype %d", dtype);
+  WJ_REQUIRE(dtype == WJ_F32 || dtype == WJ_F16 || dtype == WJ_BF16 || dtype == WJ_F8W, "wj_qwen_create: unknown dtype %d", dtype);
+  const bool f8w = dtype == WJ_F8W;
+  if (f8w) {
+    dtype = WJ_F16;       // storage / activation type of everything that is not an MX-fp8 projection
+    WJ_REQUIRE(d.hidden % 128 == 0 && d.ffn % 128 == 0 && (d.n_head * d.head_dim) % 128 == 0,
+               "wj_qwen_create: WJ_F8W needs hidden, ffn and heads x head_dim to be multiples of 128 (the k step of the MX matrix-core instruction)");
+  }
   WJ_REQUIRE(n_offsets == WJ_Q_N_GLOBAL + d.n_layer * WJ_QL_N, "wj_qwen_create: %d tensor offsets expected, got %d",
              WJ_Q_N_GLOBAL + d.n_layer * WJ_QL_N, n_offsets);
   WJ_REQUIRE(max_seqs >= 1 && max_ctx >= 8 && max_rows >= max_seqs, "wj_qwen_create: need max_rows >= max_seqs >= 1 and max_ctx >= 8");
@@ -497,7 +528,9 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   m->max_seqs = max_seqs; m->max_ctx = max_ctx; m->max_rows = max_rows;
   const size_t e = m->esz, R = max_rows, S = max_seqs;
   const int D = d.hidden, H = d.n_head, KV = d.n_kv_head, F = d.ffn;
-  m->split_mode = dtype == WJ_F16 && (D % 64) == 0 && (F % 64) == 0 ? std::max(0, std::min(2, g_qwen_split_act)) : 0;
+  m->split_mode = dtype == WJ_F16 && (D % 64) == 0 && (F % 64) == 0 ? std::max(0, std::min(3, g_qwen_split_act)) : 0;
+  m->mx8 = f8w;
+  if (f8w && m->split_mode == 0) m->split_mode = 1;      // the LM head keeps fp16 weights and split activations
   const size_t sm = m->split_mode ? 2 : 1;
   {
     const int vp = (d.vocab + 255) / 256 * 256;
@@ -515,6 +548,23 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   QA(top_id, S * 4); QA(top_lp, S * 4); QA(top_lse, S * 4); QA(eos, 64);
   m->seen_cap = 2 * max_ctx;      // unique prompt ids (< max_ctx) + generated ids (positions stop at max_ctx)
   QA(lim, S * 4); QA(seen_n, S * 4); QA(seen, S * (size_t)m->seen_cap * 4);
+  if (f8w) {
+    const int64_t Wq = (int64_t)(H + 2 * KV) * HD;
+    const int64_t rows_of[4] = {Wq, D, 2 * (int64_t)F, D}, cols_of[4] = {D, (int64_t)H * HD, D, F};
+    const int which[4] = {WJ_QL_QKV_W, WJ_QL_O_W, WJ_QL_GATEUP_W, WJ_QL_DOWN_W};
+    int64_t bytes = 0, sbytes = 0;
+    for (int l = 0; l < d.n_layer; ++l)
+      for (int k = 0; k < 4; ++k) {
+        m->w8_off.push_back(bytes); m->w8s_off.push_back(sbytes);
+        bytes += rows_of[k] * cols_of[k]; sbytes += rows_of[k] * cols_of[k] / 32;
+      }
+    const int64_t maxk = std::max<int64_t>(std::max<int64_t>(D, (int64_t)H * HD), F);
+    QA(w8, (size_t)bytes); QA(w8s, (size_t)sbytes); QA(a8, R * (size_t)maxk); QA(a8s, R * (size_t)maxk / 32);
+    for (int l = 0; l < d.n_layer && !rc; ++l)
+      for (int k = 0; k < 4 && !rc; ++k)
+        rc = launch_mx8_quantize(WJ_F16, m->W(m->layer_base(l) + which[k]), cols_of[k], (int)rows_of[k], (int)cols_of[k],
+                                 m->w8 + m->w8_off[l * 4 + k], m->w8s + m->w8s_off[l * 4 + k], ctx->stream);
+  }
 #undef QA
   if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error("wj_qwen_create: allocation failed"); rc = WJ_E_HIP; }
   if (rc) { wj_qwen_free(m); return rc; }

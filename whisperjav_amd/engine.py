@@ -479,6 +479,31 @@ def k_gemm_split(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
+def k_gemm_mx8(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, dtype: str = "float16", out_f32: bool = True,
+               reps: int = 0, device: int = 0):
+    """C = A @ W^T (+bias) with BOTH operands quantised on the device to MX-fp8 (OCP e4m3, one E8M0 scale per 32 elements) and
+    multiplied on the block-scaled matrix-core instruction (``wj_k_gemm_mx8``: the arithmetic of the Qwen decoder's "float8w"
+    type).  Returns (C, a8, a_scale, w8, w_scale, ms_per_launch): the quantised bytes come back so that a test can rebuild the
+    exact product on the host."""
+    import ctypes as C
+    ctx = hipbind.context(device)
+    lib = hipbind.lib()
+    A, Wt = a.float().contiguous(), w.float().contiguous()
+    M, K = A.shape
+    N = Wt.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else TORCH_DTYPES[dtype], device=a.device)
+    a8 = torch.empty((M, K), dtype=torch.uint8, device=a.device)
+    sa = torch.empty((M, K // 32), dtype=torch.uint8, device=a.device)
+    w8 = torch.empty((N, K), dtype=torch.uint8, device=a.device)
+    sw = torch.empty((N, K // 32), dtype=torch.uint8, device=a.device)
+    ms = C.c_float(0.0)
+    _torch_sync()
+    check(lib.wj_k_gemm_mx8(ctx.handle, DTYPES[dtype], _ptr(A), _ptr(Wt), _ptr(bias) if bias is not None else None, _ptr(out), M, N, K,
+                            int(out_f32), _ptr(a8), _ptr(sa), _ptr(w8), _ptr(sw), int(reps), C.byref(ms), None), "wj_k_gemm_mx8")
+    ctx.sync()
+    return out, a8, sa, w8, sw, float(ms.value)
+
+
 def k_gemm_timed(M: int, N: int, K: int, dtype: str = "bfloat16", variant: int = 0, reps: int = 20,
                  gelu: bool = False, device: int = 0) -> float:
     """Average milliseconds per launch of an [M,K] x [N,K]^T GEMM on uniform random [-1, 1) operands."""

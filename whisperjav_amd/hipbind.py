@@ -16,7 +16,7 @@ ABI_VERSION = 4
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwjhip.so"
 _lib: Optional[C.CDLL] = None
 
-WJ_F32, WJ_BF16, WJ_F16 = 0, 1, 2
+WJ_F32, WJ_BF16, WJ_F16, WJ_F8W = 0, 1, 2, 3      # WJ_F8W: wj_qwen_create only (MX-fp8 decoder projections)
 WJ_MEL_FW, WJ_MEL_OW, WJ_MEL_RAW = 0, 1, 2
 DTYPES = {"float32": WJ_F32, "bfloat16": WJ_BF16, "float16": WJ_F16}
 
@@ -82,6 +82,7 @@ _SIGNATURES = {
     "wj_qwen_generate_greedy": (_I, [_P, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),
     "wj_qwen_generate_greedy_ex": (_I, [_P, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32), _F, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),
+    "wj_k_gemm_mx8": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, C.POINTER(C.c_float), _P]),
     "wj_qwen_last_used_graph": (_I, [_P]),
     "wj_qwen_last_steps": (_I, [_P]),
     "wj_qwen_last_truncated": (_I, [_P]),

@@ -405,15 +405,19 @@ class HipQwen3Decoder:
 
     def __init__(self, dims: Qwen3Dims, weights: Dict[str, np.ndarray], *, dtype: str = "float16", device: int = 0,
                  max_seqs: int = 8, max_ctx: int = 512, max_rows: Optional[int] = None):
-        if dtype not in DTYPES:
-            raise ValueError(f"dtype must be one of {sorted(DTYPES)}")
+        if dtype not in DTYPES and dtype != "float8w":
+            raise ValueError(f"dtype must be one of {sorted(DTYPES)} or 'float8w'")
         if not torch.cuda.is_available():
             raise hipbind.WjError("no ROCm device visible: the HIP path has no CPU fallback")
         self.dims, self.dtype, self.device = dims, dtype, int(device)
         self.dev = torch.device("cuda", device)
         self.ctx = hipbind.context(device)
         self._lib = hipbind.lib()
-        host, offsets = pack_blob(dims, weights, dtype)
+        # "float8w" (BASELINE cfg5's "fp8 MFMA", WJ_F8W): a float16 blob; the library re-quantises the decoder layers' projections
+        # to MX-fp8 at create and runs them on the block-scaled matrix-core instruction, everything else stays float16
+        self.f8w = dtype == "float8w"
+        blob_dtype = "float16" if self.f8w else dtype
+        host, offsets = pack_blob(dims, weights, blob_dtype)
         self.blob = host.to(self.dev)
         self.max_seqs, self.max_ctx = int(max_seqs), int(max_ctx)
         self.max_rows = int(max_rows or max_seqs * max_ctx)
@@ -422,7 +426,7 @@ class HipQwen3Decoder:
         off = (C.c_int64 * len(offsets))(*offsets.tolist())
         handle = C.c_void_p()
         torch.cuda.current_stream().synchronize()
-        check(self._lib.wj_qwen_create(self.ctx.handle, C.byref(cd), DTYPES[dtype], C.c_void_p(self.blob.data_ptr()), self.blob.numel(),
+        check(self._lib.wj_qwen_create(self.ctx.handle, C.byref(cd), hipbind.WJ_F8W if self.f8w else DTYPES[dtype], C.c_void_p(self.blob.data_ptr()), self.blob.numel(),
                                        off, len(offsets), self.max_seqs, self.max_ctx, self.max_rows, C.byref(handle)), "wj_qwen_create")
         self.handle = handle
 
@@ -505,7 +509,7 @@ class HipQwen3Decoder:
         flat = np.ascontiguousarray([starts[b] + int(r) for b, rs in enumerate(rows) for r in rs], dtype=np.int32)
         packed = torch.cat([e.to(self.dev, torch.float32) for e in embeds], 0).contiguous()
         n_labels = int(head_w.shape[0])
-        want = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16}[self.dtype]
+        want = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16, "float8w": torch.float16}[self.dtype]
         hw = head_w.to(self.dev, want).contiguous()
         hb = head_b.to(self.dev, torch.float32).contiguous() if head_b is not None else None
         out = np.zeros(len(flat), dtype=np.int32)

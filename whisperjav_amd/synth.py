@@ -46,8 +46,10 @@ def _utterance(rng: np.random.Generator, dur_s: float) -> np.ndarray:
     return sig * (10 ** (-18 / 20) / rms)
 
 
-def speech_like(duration_s: float, seed: int = 1234, noisy: bool = False) -> np.ndarray:
-    """float32 mono audio in [-1, 1] of exactly ``duration_s`` seconds."""
+def speech_like(duration_s: float, seed: int = 1234, noisy: bool = False, floor_db: float = -45.0, snr_db: float = 10.0) -> np.ndarray:
+    """float32 mono audio in [-1, 1] of exactly ``duration_s`` seconds.  ``floor_db``: level of the pink noise floor (dBFS;
+    -45 = a noisy room: 45 dB in auditok's energy scale, ABOVE the reference's 32 / 38 dB scene gates; -66 = a studio
+    recording on which those gates open and close); ``noisy``: plus hum and pink noise ``snr_db`` below the speech level."""
     rng = np.random.default_rng(seed)
     n = int(round(duration_s * SR))
     out = np.zeros(n, dtype=np.float64)
@@ -63,18 +65,18 @@ def speech_like(duration_s: float, seed: int = 1234, noisy: bool = False) -> np.
             gap = float(rng.uniform(2.5, 6.0))
             next_chapter += 90.0
         pos = end + int(gap * SR)
-    out += _pink(rng, n) * 10 ** (-45 / 20)
+    out += _pink(rng, n) * 10 ** (floor_db / 20)
     if noisy:
         speech_rms = 10 ** (-18 / 20)
         noise = _pink(rng, n) + 0.5 * np.sin(2 * np.pi * 50 * np.arange(n) / SR) + 0.3 * np.sin(
             2 * np.pi * 100 * np.arange(n) / SR)
-        noise *= speech_rms * 10 ** (-10 / 20) / (np.sqrt(np.mean(noise ** 2)) + 1e-12)
+        noise *= speech_rms * 10 ** (-snr_db / 20) / (np.sqrt(np.mean(noise ** 2)) + 1e-12)
         out += noise
     return np.clip(out, -1.0, 1.0).astype(np.float32)
 
 
 def speech_like_long(duration_s: float, seed: int = 1234, noisy: bool = False, chunk_s: float = 600.0,
-                     workers: int = 0) -> np.ndarray:
+                     workers: int = 0, floor_db: float = -45.0, snr_db: float = 10.0) -> np.ndarray:
     """Long recordings (the 120-minute benchmark file) as independent ``chunk_s`` pieces with seeds ``seed + 7919 i``,
     generated in parallel (a single 115 M-sample FFT for the pink floor takes minutes); the result depends only on
     (duration_s, seed, noisy, chunk_s).  Same per-chunk statistics as ``speech_like``.
@@ -85,7 +87,7 @@ def speech_like_long(duration_s: float, seed: int = 1234, noisy: bool = False, c
     n_chunks = max(1, int(np.ceil(duration_s / chunk_s)))
     jobs = [(min(chunk_s, duration_s - i * chunk_s), seed + 7919 * i) for i in range(n_chunks)]
     if n_chunks == 1:
-        return speech_like(duration_s, seed=seed, noisy=noisy)
+        return speech_like(duration_s, seed=seed, noisy=noisy, floor_db=floor_db, snr_db=snr_db)
     import os
     import subprocess
     import sys
@@ -101,7 +103,8 @@ def speech_like_long(duration_s: float, seed: int = 1234, noisy: bool = False, c
             while pending and len(running) < workers:
                 i = pending.pop(0)
                 out = os.path.join(tmp, f"{i}.npy")
-                cmd = [sys.executable, "-m", "whisperjav_amd.synth", out, repr(jobs[i][0]), str(jobs[i][1]), str(int(noisy))]
+                cmd = [sys.executable, "-m", "whisperjav_amd.synth", out, repr(jobs[i][0]), str(jobs[i][1]), str(int(noisy)),
+                       repr(float(floor_db)), repr(float(snr_db))]
                 running[i] = (subprocess.Popen(cmd, env=env, cwd=root), out)
             for i, (proc, out) in list(running.items()):
                 rc = proc.wait() if len(running) >= workers or not pending else proc.poll()
@@ -114,6 +117,7 @@ def speech_like_long(duration_s: float, seed: int = 1234, noisy: bool = False, c
     return np.concatenate(parts)
 
 
-if __name__ == "__main__":      # worker: python -m whisperjav_amd.synth OUT.npy DURATION SEED NOISY
+if __name__ == "__main__":      # worker: python -m whisperjav_amd.synth OUT.npy DURATION SEED NOISY [FLOOR_DB SNR_DB]
     import sys
-    np.save(sys.argv[1], speech_like(float(sys.argv[2]), seed=int(sys.argv[3]), noisy=bool(int(sys.argv[4]))))
+    extra = dict(floor_db=float(sys.argv[5]), snr_db=float(sys.argv[6])) if len(sys.argv) > 6 else {}
+    np.save(sys.argv[1], speech_like(float(sys.argv[2]), seed=int(sys.argv[3]), noisy=bool(int(sys.argv[4])), **extra))
