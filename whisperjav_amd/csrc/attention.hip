@@ -18,6 +18,19 @@ template <typename T> struct Lane16;                       // scalar type of an 
 template <> struct Lane16<bf16_t> { typedef __bf16 type; };
 template <> struct Lane16<f16_t> { typedef _Float16 type; };
 
+// max over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} in registers: v_permlane16_swap / v_permlane32_swap exchange 16- resp.
+// 32-lane rows between two VGPRs (with both operands = x, lane l of the pair holds x[l] and x[l ^ 16] resp. x[l ^ 32]).
+// __shfl_xor compiles to ds_bpermute_b32 here -- an LDS round trip with an s_waitcnt lgkmcnt(0) behind it, four of them in a
+// row per key tile of the encoder attention (seen in the round-4 disassembly: ~400 cycles of exposed latency per tile and wave).
+__device__ __forceinline__ float quad_row_max(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const uint32_t v = __float_as_uint(x);
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 __device__ __forceinline__ int aswz(int row, int chunk) { return row * 64 + ((chunk ^ (row & 7)) << 3); }
 // K tile of the encoder attention: key k of the 64-key tile is stored at the LDS row the MFMA A-operand reads it from
 // (block kb = 2 (k >> 5) + ((k >> 2) & 1), row 4 ((k >> 3) & 3) + (k & 3) of it), so a fragment read touches 16
@@ -147,8 +160,7 @@ __global__ __launch_bounds__(256) void attn_enc_h_kernel(const bf16_t* __restric
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = quad_row_max(mx);
         const float mxs = mx * c2;
         if (mxs > m_run[f] + kSlack || m_run[f] == -INFINITY) {      // rare after the first tiles
           const float m_new = fmaxf(m_run[f], mxs);
@@ -272,6 +284,225 @@ __global__ __launch_bounds__(256) void attn_enc_h_kernel(const bf16_t* __restric
   }
 }
 
+// --------------------------------------------------------------------------------------------
+// Software-pipelined form (round 4; wj_tune attn_enc_variant bit 4): the same tile arithmetic in the same order as the lean
+// variant of attn_enc_h_kernel above (bit-identical output), but the S^T = K.Q^T MFMAs of key tile t+1 are issued in the same
+// straight-line block as the softmax VALU work of tile t, on a second score register set, so ONE wave keeps the matrix pipe busy
+// while its exponentials run (the loop above serialises 16 MFMAs -> ~150 VALU -> 20 MFMAs per wave and relies on other waves to
+// fill the gaps; with 166 VGPRs only three fit a SIMD and the measured matrix-pipe utilisation is 38 %).  K tiles live in a
+// ring of three LDS slots (tile t+1 must be resident while tile t is being consumed), V tiles in two.
+//   iteration t:  global loads of K(t+2), V(t+1) -> registers;  S_next = K(t+1).Q^T  ||  P = softmax(S_cur);
+//                 O^T += V(t)^T.P^T;  registers -> LDS;  barrier;  S_cur <- S_next.
+// WAR: slot of K(t+2) held K(t-1), last read in iteration t-2; slot of V(t+1) held V(t-1), last read in iteration t-1 -- both
+// behind the barrier that ended iteration t-1.  RAW: stored before the barrier of iteration t, read in iteration t+1.
+// --------------------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void attn_enc_p_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                         const bf16_t* __restrict__ Vt, E* __restrict__ out,
+                                                         int T, int Tpad, int H, int out_blk) {
+  typedef typename Vec8<E>::type vec8_t;
+  typedef typename Lane16<E>::type lane_t;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[5 * 4096];  // K ring [3][64][64], then V [2][64][64] = 40 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int nqb = gridDim.x, total = gridDim.x * gridDim.y * gridDim.z;
+  const int lin = blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7;
+  const int id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  const int qb = id % nqb, h = (id / nqb) % H, b = id / (nqb * H);
+  const int q0 = qb * 128 + wave * 32;
+  const int64_t bh = (int64_t)b * H + h;
+  const bf16_t* Qp = Q + bh * Tpad * 64;
+  const bf16_t* Kp = K + bh * Tpad * 64;
+  const bf16_t* Vp = Vt + bh * 64 * Tpad;
+
+  vec8_t qf[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[f][ks] = *reinterpret_cast<const vec8_t*>(Qp + (int64_t)(q0 + f * 16 + li) * 64 + ks * 32 + lg * 8);
+  f32x4_t o[2][4];
+  f32x4_t lsum[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+  vec8_t ones8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones8[e] = (lane_t)1.0f;
+  float m_run[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[f][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = Tpad / 64;
+  const int row0 = tid >> 3, ch0 = tid & 7;            // this thread's two 16-byte granules of a 64 x 64 tile: rows row0, row0 + 32
+  uint4 rk0, rk1, rv0, rv1;
+#define WJ_PK_LOAD(kt)                                                                                   \
+  {                                                                                                      \
+    rk0 = *reinterpret_cast<const uint4*>(Kp + (int64_t)((kt) * 64 + row0) * 64 + ch0 * 8);              \
+    rk1 = *reinterpret_cast<const uint4*>(Kp + (int64_t)((kt) * 64 + row0 + 32) * 64 + ch0 * 8);         \
+  }
+#define WJ_PV_LOAD(kt)                                                                                   \
+  {                                                                                                      \
+    rv0 = *reinterpret_cast<const uint4*>(Vp + (int64_t)row0 * Tpad + (kt) * 64 + ch0 * 8);              \
+    rv1 = *reinterpret_cast<const uint4*>(Vp + (int64_t)(row0 + 32) * Tpad + (kt) * 64 + ch0 * 8);       \
+  }
+#define WJ_PK_STORE(slot)                                                                                \
+  {                                                                                                      \
+    *reinterpret_cast<uint4*>(&lds[(slot) * 4096 + kswz(kperm(row0), ch0)]) = rk0;                        \
+    *reinterpret_cast<uint4*>(&lds[(slot) * 4096 + kswz(kperm(row0 + 32), ch0)]) = rk1;                   \
+  }
+#define WJ_PV_STORE(slot)                                                                                \
+  {                                                                                                      \
+    *reinterpret_cast<uint4*>(&lds[(3 + (slot)) * 4096 + aswz(row0, ch0)]) = rv0;                         \
+    *reinterpret_cast<uint4*>(&lds[(3 + (slot)) * 4096 + aswz(row0 + 32, ch0)]) = rv1;                    \
+  }
+  // S^T = K . Q^T of the K tile in ring slot `slot`
+  auto scores = [&](int slot, f32x4_t (&st)[2][4]) __attribute__((always_inline)) {
+    const bf16_t* lk = &lds[slot * 4096];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int krow = 16 * kb + li;
+      st[0][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      st[1][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const vec8_t kf = *reinterpret_cast<const vec8_t*>(&lk[kswz(krow, ks * 4 + lg)]);
+        st[0][kb] = mfma16(kf, qf[0][ks], st[0][kb]);
+        st[1][kb] = mfma16(kf, qf[1][ks], st[1][kb]);
+      }
+    }
+  };
+  WJ_PK_LOAD(0)
+  WJ_PV_LOAD(0)
+  WJ_PK_STORE(0)
+  WJ_PV_STORE(0)
+  if (nt > 1) {
+    WJ_PK_LOAD(1)
+    WJ_PK_STORE(1)
+  }
+  __syncthreads();
+  f32x4_t sa[2][4], sb[2][4];
+  scores(0, sa);
+
+  // one key tile: `cur` = scores of tile kt (consumed), `nxt` = scores of tile kt + 1 (produced)
+  auto key_tile = [&](const int kt, f32x4_t (&cur)[2][4], f32x4_t (&nxt)[2][4], auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    if (kt + 2 < nt) { WJ_PK_LOAD(kt + 2) }
+    if (kt + 1 < nt) { WJ_PV_LOAD(kt + 1) }
+    const bf16_t* lv = &lds[(3 + (kt & 1)) * 4096];
+    vec8_t pf[2][2];
+    if constexpr (MASKED) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 64 + 32 * (kb >> 1) + 8 * lg + 4 * (kb & 1) + r;
+            if (key >= T) cur[f][kb][r] = -INFINITY;
+          }
+    }
+    constexpr float c2 = 0.125f * 1.44269504088896340736f;
+    constexpr float kSlack = 8.0f;
+    // running maximum and the (rare) accumulator rescale of both query fragments first: the branches end here
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, cur[f][kb][r]);
+      mx = quad_row_max(mx);
+      const float mxs = mx * c2;
+      if (mxs > m_run[f] + kSlack || m_run[f] == -INFINITY) {
+        const float m_new = fmaxf(m_run[f], mxs);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+        m_run[f] = m_new;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[f][d][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lsum[f][r] *= alpha;
+      }
+    }
+    // ONE straight-line block: the 16 score MFMAs of the NEXT tile (unconditional -- past the last tile they read a stale ring
+    // slot and their result is dropped -- so that no branch separates them from the VALU work) beside the 32 fma + 32 exp2 +
+    // 16 cvt_pk of THIS tile's probabilities; the group barriers below ask the scheduler for 1 ds_read : 2 MFMA : 10 VALU
+    scores((kt + 1) % 3, nxt);
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const float nm = -m_run[f];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        vec8_t v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = (lane_t)__builtin_amdgcn_exp2f(fmaf(cur[f][2 * s2][r], c2, nm));
+          v[4 + r] = (lane_t)__builtin_amdgcn_exp2f(fmaf(cur[f][2 * s2 + 1][r], c2, nm));
+        }
+        pf[f][s2] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS_READ: one K fragment
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // the two MFMAs it feeds
+      __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);    // 10 of the 80 VALU instructions
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      lsum[0] = mfma16(ones8, pf[0][s2], lsum[0]);
+      lsum[1] = mfma16(ones8, pf[1][s2], lsum[1]);
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const vec8_t vf = *reinterpret_cast<const vec8_t*>(&lv[aswz(d * 16 + li, s2 * 4 + lg)]);
+        o[0][d] = mfma16(vf, pf[0][s2], o[0][d]);
+        o[1][d] = mfma16(vf, pf[1][s2], o[1][d]);
+      }
+    if (kt + 2 < nt) { WJ_PK_STORE((kt + 2) % 3) }
+    if (kt + 1 < nt) { WJ_PV_STORE((kt + 1) & 1) }
+    __syncthreads();
+  };
+  const int nfull = min(nt, T / 64);
+  int kt = 0;
+  for (; kt + 1 < nfull; kt += 2) {
+    key_tile(kt, sa, sb, std::false_type{});
+    key_tile(kt + 1, sb, sa, std::false_type{});
+  }
+  // the rest, one by one with static register roles: an odd unmasked tile, then the tiles that may hold padding keys
+  for (; kt < nt; ++kt) {
+    const bool masked = kt >= nfull;
+    if ((kt & 1) == 0) { if (masked) key_tile(kt, sa, sb, std::true_type{}); else key_tile(kt, sa, sb, std::false_type{}); }
+    else { if (masked) key_tile(kt, sb, sa, std::true_type{}); else key_tile(kt, sb, sa, std::false_type{}); }
+  }
+#undef WJ_PK_LOAD
+#undef WJ_PV_LOAD
+#undef WJ_PK_STORE
+#undef WJ_PV_STORE
+
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const float inv = 1.0f / lsum[f][0];
+    const int t = q0 + f * 16 + li;
+    if (t < T) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        float v[4] = {o[f][d][0] * inv, o[f][d][1] * inv, o[f][d][2] * inv, o[f][d][3] * inv};
+        if (out_blk) {
+          const int row = b * T + t, c = h * 64 + d * 16 + lg * 4;
+          st4(out + (((int64_t)(row >> 8) * (H * 2) + (c >> 5)) << 13) + ((row & 255) << 5) + (c & 31), v);
+        } else {
+          st4(out + ((int64_t)b * T + t) * (H * 64) + h * 64 + d * 16 + lg * 4, v);
+        }
+      }
+    }
+  }
+}
+
 // Exact fp32 encoder attention: one query row per lane, K / Vt tiles broadcast from LDS.
 __global__ __launch_bounds__(64) void attn_enc_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                           const float* __restrict__ Vt, float* __restrict__ out, int T,
@@ -348,6 +579,14 @@ int launch_attention_enc(int dtype, const void* Q, const void* K, const void* Vt
       hipLaunchKernelGGL((attn_enc_h_kernel<bf16_t, V>), grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
                          (const bf16_t*)Vt, (bf16_t*)out, T, Tpad, H, out_blk);                                    \
   } while (0)
+    if (g_attn_enc_variant & 16) {      // software-pipelined kernel (lean softmax, XCD remap: the arithmetic of variant 9)
+      if (dtype == WJ_F16)
+        hipLaunchKernelGGL((attn_enc_p_kernel<f16_t>), grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, (f16_t*)out, T, Tpad, H, out_blk);
+      else
+        hipLaunchKernelGGL((attn_enc_p_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)out, T, Tpad, H, out_blk);
+      WJ_LAUNCH_CHECK();
+      return WJ_OK;
+    }
     switch (g_attn_enc_variant & 15) {
       case 0: WJ_ATTN(0); break;
       case 1: WJ_ATTN(1); break;

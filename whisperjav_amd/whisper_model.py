@@ -897,40 +897,55 @@ class HipWhisperModel:
                 pending = make_mel(chunks[0])
                 self.model.encode_at(pending[0], 0, None)
                 self.model.ctx.sync()
-            for ci, batch in enumerate(chunks):
-                base = (ci % 2) * half if overlap else 0
-                if overlap:
-                    mel, sizes = pending
-                    paired = ci + 1 < len(chunks)
-                    if paired:                           # the next chunk's encoder runs beside this chunk's decode
-                        pending = make_mel(chunks[ci + 1])
-                        self.model.encode_at(pending[0], ((ci + 1) % 2) * half, side)
-                    self.model.decode_stream = split[1] if (split is not None and paired) else None
-                else:
-                    mel, sizes = make_mel(batch)
-                    self.model.encode(mel)
-                # windows with equal prompt lengths decode together (the common case: no previous text)
-                groups: Dict[int, List[Tuple[_ClipState, List[int], int]]] = {}
-                prompts = [self._prompt(o, st.all_tokens[st.prompt_reset_since:], st.seek == 0, st.language) for st in batch]
-                for j, p in enumerate(prompts):
-                    groups.setdefault(len(p), []).append((batch[j], p, j))
-                if len(groups) == 1:
-                    slots = [base + j for j in range(len(batch))]
-                    decoded = self._decode_windows(prompts, o, suppress, slots=None if base == 0 else slots)
-                    self._finish_windows(o, batch, sizes, decoded, slots, tb)
-                else:   # heterogeneous prompt lengths: one decode per length, addressing the resident windows by slot
-                    for _, members in groups.items():
-                        idx = [j for _, _, j in members]
-                        res = self._decode_windows([p for _, p, _ in members], o, suppress, slots=[base + j for j in idx])
-                        self._finish_windows(o, [batch[j] for j in idx], [sizes[j] for j in idx], res, [base + j for j in idx], tb)
-                del mel
+            # if a decode of the loop raises while the next chunk's encoder is in flight on the side stream, the caller's
+            # retry (asr._run_model bisects and calls transcribe_many again) must not start an encode on the shared workspaces
+            # beside it: whatever the exit, the side stream is drained and the decode stream reset
+            try:
+                for ci, batch in enumerate(chunks):
+                    base = (ci % 2) * half if overlap else 0
+                    if overlap:
+                        mel, sizes = pending
+                        paired = ci + 1 < len(chunks)
+                        if paired:                           # the next chunk's encoder runs beside this chunk's decode
+                            pending = make_mel(chunks[ci + 1])
+                            self.model.encode_at(pending[0], ((ci + 1) % 2) * half, side)
+                        self.model.decode_stream = split[1] if (split is not None and paired) else None
+                    else:
+                        mel, sizes = make_mel(batch)
+                        self.model.encode(mel)
+                    # windows with equal prompt lengths decode together (the common case: no previous text)
+                    groups: Dict[int, List[Tuple[_ClipState, List[int], int]]] = {}
+                    prompts = [self._prompt(o, st.all_tokens[st.prompt_reset_since:], st.seek == 0, st.language) for st in batch]
+                    for j, p in enumerate(prompts):
+                        groups.setdefault(len(p), []).append((batch[j], p, j))
+                    if len(groups) == 1:
+                        slots = [base + j for j in range(len(batch))]
+                        decoded = self._decode_windows(prompts, o, suppress, slots=None if base == 0 else slots)
+                        self._finish_windows(o, batch, sizes, decoded, slots, tb)
+                    else:   # heterogeneous prompt lengths: one decode per length, addressing the resident windows by slot
+                        for _, members in groups.items():
+                            idx = [j for _, _, j in members]
+                            res = self._decode_windows([p for _, p, _ in members], o, suppress, slots=[base + j for j in idx])
+                            self._finish_windows(o, [batch[j] for j in idx], [sizes[j] for j in idx], res, [base + j for j in idx], tb)
+                    del mel
+                    if overlap:
+                        self.model.decode_stream = None
+                        if paired:                           # chunk ci + 1 is encoded before its decode starts
+                            if split is not None:
+                                self.model.stream_sync(side)
+                            else:
+                                side.synchronize()
+            finally:
                 if overlap:
                     self.model.decode_stream = None
-                    if paired:                           # chunk ci + 1 is encoded before its decode starts
+                    try:
                         if split is not None:
                             self.model.stream_sync(side)
-                        else:
+                        elif side is not None:
                             side.synchronize()
+                    except Exception:       # the device is already in an error state: the original exception is the one to report
+                        pass
+                    pending = None
         infos = [TranscriptionInfo(language=st.language, language_probability=st.language_probability, duration=st.duration,
                                    duration_after_vad=st.duration, all_language_probs=st.all_language_probs,
                                    transcription_options=dict(kwargs))
