@@ -163,7 +163,7 @@ def roofline_from_stages(stages, dtype, tag_hint=None):
         return None
     e = stages[dom]
     traffic = traffic_source = None
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_cross_attn_cfg3.json", "r02_pmc_cross_attn_cfg3.json"))
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_cross_attn_cfg3.json", "r03_pmc_cross_attn_cfg3.json", "r02_pmc_cross_attn_cfg3.json"))
                      if os.path.exists(f)), None)
     if dom == "dec_cross_attn" and dtype != "float32" and pmc_file:
         # NOT measured in this run: a stored rocprofv3 --pmc FETCH_SIZE pass of the same command (own pass, x2 gfx950

@@ -389,14 +389,21 @@ def test_golden_large_v3_r2_greedy_and_beam(hip, dtype, exact):
                            beam_size=int(beam), patience=patience, length_penalty=lpen)
     model.close()
     b_got = br.tokens[0, : int(br.n_tokens[0])].tolist()
-    b_ref = g["beam_tokens"][0, : int(g["beam_len"][0])].tolist()
-    d_cum = abs(float(br.sum_logprob[0]) - float(g["beam_cum"][0]))
+    bar = R2_LP_BAR[(dtype, exact)]
     margin = float(g["beam_norm"][0] - g["beam_norm"][1]) if len(g["beam_norm"]) > 1 else float("inf")
+    # The oracle's own winner beats its runner-up by 1.6e-4 in normalised score on this golden -- a tie inside the per-token
+    # bar.  A 16-bit engine may land on either side of it (round 4: a different fp32 summation order in the encoder's
+    # LayerNorm moved the fp16 run across); every oracle hypothesis within the bar of the best is an acceptable winner, anything
+    # else is a flip.
+    accept = [j for j in range(len(g["beam_len"])) if float(g["beam_norm"][0] - g["beam_norm"][j]) <= bar] if dtype != "float32" else [0]
+    j_hit = next((j for j in accept if b_got == g["beam_tokens"][j, : int(g["beam_len"][j])].tolist()), 0)
+    b_ref = g["beam_tokens"][j_hit, : int(g["beam_len"][j_hit])].tolist()
+    d_cum = abs(float(br.sum_logprob[0]) - float(g["beam_cum"][j_hit]))
     _diag("golden_large_v3_r2", {"dtype": dtype, "weights": exact, "probe_max_abs": d_probe, "greedy_common": common,
                                  "greedy_n": len(ref_t), "greedy_lp_max_abs": d_lp, "beam_same": b_got == b_ref,
                                  "beam_cum_abs": d_cum, "beam_len": len(b_ref), "beam_norm_margin_to_runner_up": margin,
+                                 "beam_hypothesis_matched": j_hit, "beam_hypotheses_inside_the_bar": len(accept),
                                  "greedy_sum_abs": abs(float(res.sum_logprob[0]) - float(g["sum_logprob"][0]))})
-    bar = R2_LP_BAR[(dtype, exact)]
     if dtype == "bfloat16":
         assert common >= 3 and d_lp < bar
         return

@@ -55,20 +55,38 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // 4 + 2 bytes per lane and instruction: 1.7 TB/s on the 144 000 x 1280 encoder rows).  blk != 0: the output goes out in the
 // blocked GEMM-operand layout [ceil(M / 256)][D / 32][256][32] (GemmArgs::blk) -- a lane's 4 columns never straddle a
 // 32-column block.  Same two-pass statistics; the summation order differs from the scalar kernel's (different partial sums).
-template <typename T, int NV4>
-__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ b, T* __restrict__ out, int M, int blk) {
+template <typename T, int NV4, bool RESID>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(float* __restrict__ x, const float* __restrict__ partial, int ksplit,
+                                                            const float* __restrict__ bias, const float* __restrict__ w,
+                                                            const float* __restrict__ b, T* __restrict__ out, int M, int blk, int split) {
   constexpr int D = NV4 * 256;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+  float4* xr = reinterpret_cast<float4*>(x + (int64_t)row * D);
   float4 v[NV4], g[NV4], be[NV4];
 #pragma unroll
   for (int i = 0; i < NV4; ++i) {
     v[i] = xr[i * 64 + lane];
     g[i] = reinterpret_cast<const float4*>(w)[i * 64 + lane];
     be[i] = reinterpret_cast<const float4*>(b)[i * 64 + lane];
+  }
+  if constexpr (RESID) {      // x += bias + sum_s partial[s] in slice order (deterministic), written back: the split-K consumer
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+      const float4 bb = reinterpret_cast<const float4*>(bias)[i * 64 + lane];
+      v[i].x += bb.x; v[i].y += bb.y; v[i].z += bb.z; v[i].w += bb.w;
+    }
+    for (int sidx = 0; sidx < ksplit; ++sidx) {
+      const float4* pr = reinterpret_cast<const float4*>(partial + ((int64_t)sidx * M + row) * D);
+#pragma unroll
+      for (int i = 0; i < NV4; ++i) {
+        const float4 p = pr[i * 64 + lane];
+        v[i].x += p.x; v[i].y += p.y; v[i].z += p.z; v[i].w += p.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) xr[i * 64 + lane] = v[i];
   }
   float s = 0.f;
 #pragma unroll
@@ -86,23 +104,30 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
     const int c = i * 256 + lane * 4;
     float y[4] = {(v[i].x - mean) * rstd * g[i].x + be[i].x, (v[i].y - mean) * rstd * g[i].y + be[i].y,
                   (v[i].z - mean) * rstd * g[i].z + be[i].z, (v[i].w - mean) * rstd * g[i].w + be[i].w};
+    if (split) {             // [hi(D) | lo(D)] rows (GemmArgs::split)
+      st4_split<T>(out + (int64_t)row * 2 * D + c, D, y);
+      continue;
+    }
     const int64_t off = blk ? (((int64_t)(row >> 8) * (D >> 5) + (c >> 5)) << 13) + ((row & 255) << 5) + (c & 31)
                             : (int64_t)row * D + c;
     st4(out + off, y);
   }
 }
 
-template <typename T>
-static bool launch_ln_vec(const float* x, const float* w, const float* b, T* out, int M, int D, int blk, hipStream_t s) {
+template <typename T, bool RESID>
+static bool launch_ln_vec(float* x, const float* partial, int ksplit, const float* bias, const float* w, const float* b, T* out, int M,
+                          int D, int blk, int split, hipStream_t s) {
   dim3 grid(ceil_div(M, 4));
+#define WJ_LNV(NV) hipLaunchKernelGGL((layernorm_vec_kernel<T, NV, RESID>), grid, dim3(256), 0, s, x, partial, ksplit, bias, w, b, out, M, blk, split)
   switch (D) {
-    case 256: hipLaunchKernelGGL((layernorm_vec_kernel<T, 1>), grid, dim3(256), 0, s, x, w, b, out, M, blk); return true;
-    case 512: hipLaunchKernelGGL((layernorm_vec_kernel<T, 2>), grid, dim3(256), 0, s, x, w, b, out, M, blk); return true;
-    case 768: hipLaunchKernelGGL((layernorm_vec_kernel<T, 3>), grid, dim3(256), 0, s, x, w, b, out, M, blk); return true;
-    case 1024: hipLaunchKernelGGL((layernorm_vec_kernel<T, 4>), grid, dim3(256), 0, s, x, w, b, out, M, blk); return true;
-    case 1280: hipLaunchKernelGGL((layernorm_vec_kernel<T, 5>), grid, dim3(256), 0, s, x, w, b, out, M, blk); return true;
+    case 256: WJ_LNV(1); return true;
+    case 512: WJ_LNV(2); return true;
+    case 768: WJ_LNV(3); return true;
+    case 1024: WJ_LNV(4); return true;
+    case 1280: WJ_LNV(5); return true;
     default: return false;
   }
+#undef WJ_LNV
 }
 
 int g_ln_vec = 1;   // wj_tune("ln_vec"): 0 = always the scalar kernel (A/B)
@@ -112,9 +137,10 @@ int launch_layernorm(int dtype, const float* x, const float* w, const float* b, 
   if (D > 64 * 20 || D <= 0) { set_error("layernorm: D=%d unsupported (max 1280)", D); return WJ_E_INVALID; }
   if (M <= 0) return WJ_OK;
   if (blk && (split || !is16(dtype) || (D % 256))) { set_error("layernorm: a blocked output needs a 16-bit type, D %% 256 == 0, no split"); return WJ_E_INVALID; }
-  if ((blk || g_ln_vec) && !split && is16(dtype) && (D % 256) == 0) {
-    const bool ok = dtype == WJ_F16 ? launch_ln_vec<f16_t>(x, w, b, (f16_t*)out, M, D, blk, s)
-                                    : launch_ln_vec<bf16_t>(x, w, b, (bf16_t*)out, M, D, blk, s);
+  if ((blk || g_ln_vec) && is16(dtype) && (D % 256) == 0) {
+    float* xm = const_cast<float*>(x);      // not written without RESID
+    const bool ok = dtype == WJ_F16 ? launch_ln_vec<f16_t, false>(xm, nullptr, 0, nullptr, w, b, (f16_t*)out, M, D, blk, split, s)
+                                    : launch_ln_vec<bf16_t, false>(xm, nullptr, 0, nullptr, w, b, (bf16_t*)out, M, D, blk, split, s);
     if (ok) { WJ_LAUNCH_CHECK(); return WJ_OK; }
     if (blk) { set_error("layernorm: no blocked-output kernel for D=%d", D); return WJ_E_INVALID; }
   }
@@ -191,6 +217,11 @@ int launch_layernorm_resid(int dtype, float* x, const float* partial, int ksplit
                            const float* b, void* out, int M, int D, hipStream_t s, int split) {
   if (D > 64 * 20 || D <= 0) { set_error("layernorm: D=%d unsupported (max 1280)", D); return WJ_E_INVALID; }
   if (M <= 0) return WJ_OK;
+  if (g_ln_vec && is16(dtype) && (D % 256) == 0) {      // 16-byte loads of x / slabs / gamma / beta, 8-byte stores (round 4)
+    const bool ok = dtype == WJ_F16 ? launch_ln_vec<f16_t, true>(x, partial, ksplit, bias, w, b, (f16_t*)out, M, D, 0, split, s)
+                                    : launch_ln_vec<bf16_t, true>(x, partial, ksplit, bias, w, b, (bf16_t*)out, M, D, 0, split, s);
+    if (ok) { WJ_LAUNCH_CHECK(); return WJ_OK; }
+  }
   dim3 grid(ceil_div(M, 4));
 #define WJ_LNR(NV)                                                                                              \
   do {                                                                                                          \
