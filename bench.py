@@ -808,7 +808,7 @@ def cfg5_roofline(dec_params, esz, clips, n_iter, stages, qdt="float16", layer_p
     peak = MFMA_PEAK_TFLOPS["float16"]
     if qdt == "float8w":      # the layers' projections run at the fp8 rate (5 PFLOP/s dense), the LM head at the fp16 rate: time-weighted roof
         peak = dec_params / (layer_params / 5000.0 + (dec_params - layer_params) / MFMA_PEAK_TFLOPS["float16"])
-    return {"bound": "mfma", "kernel": f"greedy decode iteration ({clips} rows through every decoder GEMM and the tied LM head)",
+    return {"bound": "mfma", "kernel": f"greedy decode iteration ({clips:.0f} live rows on average through every decoder GEMM and the tied LM head)",
             "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4),
             "traffic": None, "note": "attention, norms, top-1 and the launch gaps of the iteration are inside the time; GEMM-only figures: DESIGN.md"}
@@ -925,6 +925,7 @@ def cfg5_measure(args, info, steps, warmup, want_cpu, want_stages=True):
         r2 = timed("generate_ms", lambda: model.generate(max_new_tokens=max(budgets), repetition_penalty=penalty,
                                                          prompt_ids=ids if penalty != 1.0 else None, max_new_per_seq=budgets))
         stages["decode_iterations"] = r2.steps
+        stages["decode_row_iterations"] = r2.row_steps
         if aligner:
             _, arows = timed("aligner_ms", lambda: align(r2))
             stages["aligner_rows"] = arows
@@ -960,12 +961,13 @@ def cfg5_measure(args, info, steps, warmup, want_cpu, want_stages=True):
                        "clips_per_step": B, "audio_seconds_per_step": round(audio_s, 1),
                        "tokens_generated": int(lens.sum()), "tokens_per_clip": {"mean": round(float(lens.mean()), 1), "min": int(lens.min()), "max": int(lens.max())},
                        "ended_on_eos": int((lens < np.array(budgets)).sum()), "decode_iterations": res.steps,
+                       "batch_compactions": res.compactions, "decode_row_iterations": res.row_steps,
                        "context_limited": int(sum(res.context_limited or [])),
                        "aligner_bins_crc32": (zlib.crc32(np.concatenate(lab[0]).astype(np.int32).tobytes()) if lab else None),
                        "tokens_crc32": zlib.crc32(np.concatenate([np.asarray(t, dtype=np.int32) for t in res.tokens] + [np.zeros(0, np.int32)]).tobytes()),
                        "decoder_weight_bytes_per_iteration": dec_params * esz, "stages": stages},
-            "roofline": cfg5_roofline(dec_params, esz, B, stages.get("decode_iterations") or res.steps, stages, qdt,
-                                      dec_params - d.vocab * d.hidden),
+            "roofline": cfg5_roofline(dec_params, esz, (stages.get("decode_row_iterations") or res.row_steps) / max(1, stages.get("decode_iterations") or res.steps),
+                                      stages.get("decode_iterations") or res.steps, stages, qdt, dec_params - d.vocab * d.hidden),
             "cpu_baseline": cpu}
     tower.close(); model.close()
     if aligner:

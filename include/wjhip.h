@@ -302,6 +302,10 @@ int wj_qwen_last_used_graph(const wj_qwen* m);
  * size max_ctx for prompt + budget, or read this count). */
 int wj_qwen_last_steps(const wj_qwen* m);
 int wj_qwen_last_truncated(const wj_qwen* m);
+/* batch compaction of the greedy loop (finished sequences leave the batch at the polls; wj_tune "qwen_compact_pct"): how often the last
+ * generation re-packed, and the sum over its iterations of the live rows (= the row-iterations of work it did) */
+int wj_qwen_last_compactions(const wj_qwen* m);
+int64_t wj_qwen_last_row_steps(const wj_qwen* m);
 
 /* Token classification over a full (non-generative) pass: the forced aligner (Qwen3-ForcedAligner-0.6B, reference
  * whisperjav/modules/qwen_asr.py:1198-1320 -> TextAligner, protocols.py:128-179) is this decoder + audio tower with a

@@ -458,6 +458,18 @@ def test_generation_ends_on_eos_ragged_batch_matches_oracle(hip):
     assert lens[1] > lens[3] > lens[2] > lens[0], lens                          # more audio, later EOS (78 > 52 > 40 > 26 audio tokens)
     assert max(lens) < res.steps <= max(lens) + 9 < budget, (res.steps, lens)   # early exit: the poll (every 8 iterations) saw all flags
     assert not any(res.context_limited)
+    # finished sequences LEFT the batch (round 4): the batch was re-packed and did fewer row-iterations than rows x iterations;
+    # without compaction (wj_tune qwen_compact_pct = 0) the same tokens and log-probs come out
+    assert res.compactions >= 2 and res.row_steps < 0.75 * res.steps * len(prompts), (res.compactions, res.row_steps, res.steps)
+    from whisperjav_amd import hipbind
+    hipbind.tune("qwen_compact_pct", 0)
+    try:
+        model.prefill(embeds)
+        flat = model.generate(max_new_tokens=budget)
+    finally:
+        hipbind.tune("qwen_compact_pct", 15)
+    assert flat.compactions == 0 and flat.row_steps == flat.steps * len(prompts)
+    assert flat.tokens == res.tokens and flat.token_logprob == res.token_logprob
     for b in (0, 1, 4):                                                         # batch == single, with EOS
         model.prefill([embeds[b]])
         one = model.generate(max_new_tokens=budget)

@@ -20,6 +20,7 @@
 
 namespace wj {
 int g_qwen_split_act = 2;   // wj_tune("qwen_split_act"), read at wj_qwen_create
+int g_qwen_compact_pct = 15; // wj_tune("qwen_compact_pct"): re-pack the decode batch at a poll when this share of its rows has ended (0 = never)
 }
 using namespace wj;
 
@@ -239,21 +240,26 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 __global__ void advance_kernel(const int32_t* __restrict__ top_id, const float* __restrict__ top_lp, const int32_t* __restrict__ eos,
                                int n_eos, int32_t* __restrict__ finished, int32_t* __restrict__ n_out, int32_t* __restrict__ row_pos,
                                int32_t* __restrict__ next_tok, int32_t* __restrict__ tokens_out, float* __restrict__ lp_out,
-                               int max_new, int n_seqs, int ctx, int first, const int32_t* __restrict__ lim,
-                               int32_t* __restrict__ seen, int32_t* __restrict__ seen_n, int seen_cap) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= n_seqs) return;
-  if (!first) row_pos[b] = min(row_pos[b] + 1, ctx - 1);       // the token fed this step now occupies its position
+                               int max_new, int n_rows, int ctx, int first, const int32_t* __restrict__ lim,
+                               int32_t* __restrict__ seen, int32_t* __restrict__ seen_n, int seen_cap,
+                               const int32_t* __restrict__ row_seq) {
+  // Row m of the (possibly compacted) decode batch belongs to sequence b = row_seq[m]: positions, fed tokens and the head's
+  // arg-max are per ROW; flags, counters, budgets, outputs and the penalty's id set are per SEQUENCE (round 4: finished
+  // sequences leave the batch at the polls, the survivors' rows are re-packed)
+  const int mrow = blockIdx.x * 64 + threadIdx.x;
+  if (mrow >= n_rows) return;
+  const int b = row_seq[mrow];
+  if (!first) row_pos[mrow] = min(row_pos[mrow] + 1, ctx - 1);       // the token fed this step now occupies its position
   if (finished[b]) return;
-  const int t = top_id[b];
+  const int t = top_id[mrow];
   const int n = n_out[b];
-  lp_out[(int64_t)b * (max_new + 1) + n] = top_lp[b];
+  lp_out[(int64_t)b * (max_new + 1) + n] = top_lp[mrow];
   bool stop = false;
   for (int e = 0; e < n_eos; ++e) stop |= t == eos[e];
   if (stop || n >= lim[b]) { finished[b] = 1; return; }
   tokens_out[(int64_t)b * max_new + n] = t;
   n_out[b] = n + 1;
-  next_tok[b] = t;
+  next_tok[mrow] = t;
   if (seen) {
     int32_t* mine = seen + (int64_t)b * seen_cap;
     const int cnt = seen_n[b];
@@ -263,15 +269,25 @@ __global__ void advance_kernel(const int32_t* __restrict__ top_id, const float* 
   }
 }
 
+// batch compaction: row r of the shrunk batch continues old row src[r]
+__global__ void compact_decode_rows_kernel(const int32_t* __restrict__ src, int n, const int32_t* __restrict__ seq_in,
+                                           const int32_t* __restrict__ pos_in, const int32_t* __restrict__ tok_in,
+                                           int32_t* __restrict__ seq_out, int32_t* __restrict__ pos_out, int32_t* __restrict__ tok_out) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= n) return;
+  const int o = src[r];
+  seq_out[r] = seq_in[o]; pos_out[r] = pos_in[o]; tok_out[r] = tok_in[o];
+}
+
 // transformers' RepetitionPenaltyLogitsProcessor on the rows of a decode step: every id of the sequence so far (prompt
 // and generated; here a duplicate-free list) has its logit divided by the penalty when positive, multiplied when negative.
 __global__ __launch_bounds__(256) void rep_penalty_kernel(float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ seen,
                                                           const int32_t* __restrict__ seen_n, int seen_cap, float penalty,
-                                                          const int32_t* __restrict__ finished) {
-  const int b = blockIdx.x;
+                                                          const int32_t* __restrict__ finished, const int32_t* __restrict__ row_seq) {
+  const int b = row_seq[blockIdx.x];        // logits row = batch row, id set = the row's sequence
   if (finished[b]) return;
   const int n = seen_n[b];
-  float* row = logits + (int64_t)b * ldl;
+  float* row = logits + (int64_t)blockIdx.x * ldl;
   for (int i = threadIdx.x; i < n; i += 256) {
     const int t = seen[(int64_t)b * seen_cap + i];
     const float l = row[t];
@@ -325,6 +341,9 @@ struct wj_qwen {
   uint8_t* a8 = nullptr;          // activation scratch [max_rows][max K]
   uint8_t* a8s = nullptr;
   int last_used_graph = 0;   // the last generation replayed its iteration from a hipGraph
+  int32_t *cmp_src = nullptr, *cmp_seq = nullptr, *cmp_pos = nullptr, *cmp_tok = nullptr;   // batch compaction scratch [max_seqs]
+  int last_compactions = 0;  // times the last generation re-packed its batch
+  int64_t last_row_steps = 0;  // sum over its iterations of the live rows (the work actually done)
   int last_steps = 0;        // decode iterations the last generation ran (it leaves the loop when every sequence has ended)
   int last_truncated = 0;    // sequences whose token budget was cut to the room left in the KV cache
   const void* W(int i) const { return blob + off[i]; }
@@ -472,7 +491,7 @@ int run_head(wj_qwen* m, const float* xin, int n, hipStream_t s) {
   g.A = m->h; g.lda = (sp ? 2 : 1) * D; g.W = m->W(WJ_Q_EMBED); g.ldw = D; g.M = n; g.N = n >= 1024 ? m->vocab_pad : d.vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
   WJ_TRYQ(launch_gemm(dt, EPI_F32, g, s, 0));
   if (m->cur_penalty != 1.f) {
-    hipLaunchKernelGGL(rep_penalty_kernel, dim3(n), dim3(256), 0, s, m->logits, m->ldl, m->seen, m->seen_n, m->seen_cap, m->cur_penalty, m->finished);
+    hipLaunchKernelGGL(rep_penalty_kernel, dim3(n), dim3(256), 0, s, m->logits, m->ldl, m->seen, m->seen_n, m->seen_cap, m->cur_penalty, m->finished, m->row_seq);
     WJ_LAUNCH_CHECK();
   }
   return launch_topk_logprob(m->logits, m->ldl, n, d.vocab, 1, nullptr, m->top_id, m->top_lp, m->top_lse, s);
@@ -548,6 +567,7 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   QA(top_id, S * 4); QA(top_lp, S * 4); QA(top_lse, S * 4); QA(eos, 64);
   m->seen_cap = 2 * max_ctx;      // unique prompt ids (< max_ctx) + generated ids (positions stop at max_ctx)
   QA(lim, S * 4); QA(seen_n, S * 4); QA(seen, S * (size_t)m->seen_cap * 4);
+  QA(cmp_src, S * 4); QA(cmp_seq, S * 4); QA(cmp_pos, S * 4); QA(cmp_tok, S * 4);
   if (f8w) {
     const int64_t Wq = (int64_t)(H + 2 * KV) * HD;
     const int64_t rows_of[4] = {Wq, D, 2 * (int64_t)F, D}, cols_of[4] = {D, (int64_t)H * HD, D, F};
@@ -628,6 +648,8 @@ int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32
 int wj_qwen_last_used_graph(const wj_qwen* m) { return m ? m->last_used_graph : 0; }
 int wj_qwen_last_steps(const wj_qwen* m) { return m ? m->last_steps : 0; }
 int wj_qwen_last_truncated(const wj_qwen* m) { return m ? m->last_truncated : 0; }
+int wj_qwen_last_compactions(const wj_qwen* m) { return m ? m->last_compactions : 0; }
+int64_t wj_qwen_last_row_steps(const wj_qwen* m) { return m ? m->last_row_steps : 0; }
 
 int wj_qwen_classify(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32_t* n_tokens_host, const int32_t* rows_host, int n_rows,
                      const void* head_w_dev, const float* head_b_dev, int n_labels, int32_t* argmax_out_host, float* logits_out_dev,
@@ -749,16 +771,17 @@ int wj_qwen_generate_greedy_ex(wj_qwen* m, const int32_t* eos_ids_host, int n_eo
     WJ_HIP(hipMemcpyAsync(m->seen, seen_h.data(), sizeof(int32_t) * seen_h.size(), hipMemcpyHostToDevice, s));
     WJ_HIP(hipMemcpyAsync(m->seen_n, seen_cnt.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, s));
     // the prefill left UNPENALISED logits of the last prompt positions in m->logits: penalise them, choose again
-    hipLaunchKernelGGL(rep_penalty_kernel, dim3(S), dim3(256), 0, s, m->logits, m->ldl, m->seen, m->seen_n, m->seen_cap, repetition_penalty, m->finished);
+    hipLaunchKernelGGL(rep_penalty_kernel, dim3(S), dim3(256), 0, s, m->logits, m->ldl, m->seen, m->seen_n, m->seen_cap, repetition_penalty, m->finished, m->row_seq);
     WJ_LAUNCH_CHECK();
     WJ_TRYQ(launch_topk_logprob(m->logits, m->ldl, S, m->d.vocab, 1, nullptr, m->top_id, m->top_lp, m->top_lse, s));
   }
   struct PenaltyScope { wj_qwen* m; ~PenaltyScope() { m->cur_penalty = 1.f; } } penalty_scope{m};
   m->cur_penalty = repetition_penalty;
+  int live = S;          // rows of the decode batch: sequences that have not ended (round 4: the batch is re-packed at the polls)
   auto advance = [&](int first) -> int {
-    hipLaunchKernelGGL(advance_kernel, dim3(ceil_div(S, 64)), dim3(64), 0, s, m->top_id, m->top_lp, m->eos, n_eos, m->finished, m->n_out,
-                       m->row_pos, m->next_tok, d_tok, d_lp, max_new, S, m->max_ctx, first, m->lim, penalise ? m->seen : nullptr, m->seen_n,
-                       m->seen_cap);
+    hipLaunchKernelGGL(advance_kernel, dim3(ceil_div(live, 64)), dim3(64), 0, s, m->top_id, m->top_lp, m->eos, n_eos, m->finished, m->n_out,
+                       m->row_pos, m->next_tok, d_tok, d_lp, max_new, live, m->max_ctx, first, m->lim, penalise ? m->seen : nullptr, m->seen_n,
+                       m->seen_cap, m->row_seq);
     WJ_LAUNCH_CHECK();
     return WJ_OK;
   };
@@ -766,12 +789,12 @@ int wj_qwen_generate_greedy_ex(wj_qwen* m, const int32_t* eos_ids_host, int n_eo
   // value (positions, tokens, counters) lives in device memory, so the iteration is captured once and replayed from a
   // hipGraph: ~260 launches of a few microseconds each would otherwise be issued by the host per token.
   auto iteration = [&]() -> int {
-    if (m->dtype == WJ_F32) hipLaunchKernelGGL((embed_rows_kernel<float>), dim3(S), dim3(256), 0, s, TP(const float, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
-    else if (m->dtype == WJ_F16) hipLaunchKernelGGL((embed_rows_kernel<f16_t>), dim3(S), dim3(256), 0, s, TP(const f16_t, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
-    else hipLaunchKernelGGL((embed_rows_kernel<bf16_t>), dim3(S), dim3(256), 0, s, TP(const bf16_t, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
+    if (m->dtype == WJ_F32) hipLaunchKernelGGL((embed_rows_kernel<float>), dim3(live), dim3(256), 0, s, TP(const float, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
+    else if (m->dtype == WJ_F16) hipLaunchKernelGGL((embed_rows_kernel<f16_t>), dim3(live), dim3(256), 0, s, TP(const f16_t, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
+    else hipLaunchKernelGGL((embed_rows_kernel<bf16_t>), dim3(live), dim3(256), 0, s, TP(const bf16_t, m->W(WJ_Q_EMBED)), m->next_tok, m->x, m->d.hidden);
     WJ_LAUNCH_CHECK();
-    WJ_TRYQ(run_layers(m, S, s, m->split_mode >= 1));
-    WJ_TRYQ(run_head(m, m->x, S, s));
+    WJ_TRYQ(run_layers(m, live, s, m->split_mode >= 1));
+    WJ_TRYQ(run_head(m, m->x, live, s));
     return advance(0);
   };
   // the prefill left the arg-max of every sequence's last prompt position in top_id / top_lp
@@ -783,12 +806,19 @@ int wj_qwen_generate_greedy_ex(wj_qwen* m, const int32_t* eos_ids_host, int n_eo
   int rc_loop = WJ_OK;
   m->last_used_graph = 0;
   m->last_steps = 0;
-  const int n_seqs_gen = m->n_seqs;
+  m->last_compactions = 0;
+  m->last_row_steps = 0;
   m->n_seqs = 0;            // one generation per prefill: the decode state (positions, penalised logits) is consumed below
-  (void)n_seqs_gen;
+  std::vector<int32_t> row_of(S);        // sequence id of every row of the current batch (host mirror of row_seq)
+  for (int b = 0; b < S; ++b) row_of[b] = b;
+  bool capture_next = false;
   for (int k = 1; k <= max_new && rc_loop == WJ_OK; ++k) {
     m->last_steps = k;
-    if (k == 2 && use_graph) {       // the first iteration ran eagerly (one-time kernel attributes are set); capture the second
+    m->last_row_steps += live;
+    if ((k == 2 || capture_next) && use_graph) {       // the first iteration ran eagerly (one-time kernel attributes are set); capture the second
+      capture_next = false;
+      if (exec) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
+      if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
       if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         const int rc = iteration();
         const hipError_t e = hipStreamEndCapture(s, &graph);
@@ -813,6 +843,28 @@ int wj_qwen_generate_greedy_ex(wj_qwen* m, const int32_t* eos_ids_host, int n_eo
         set_error("wj_qwen_generate_greedy: poll failed"); rc_loop = WJ_E_HIP; break;
       }
       if (std::all_of(fin.begin(), fin.end(), [](int32_t f) { return f != 0; })) break;
+      // finished sequences leave the batch: an iteration's cost is proportional to its rows (the GEMMs), and the K/V caches are
+      // addressed through row_seq, so only three small per-row arrays move.  Done when at least g_qwen_compact_pct % of the rows
+      // have ended (each re-pack costs a graph capture).
+      std::vector<int32_t> keep;
+      for (int r = 0; r < live; ++r)
+        if (!fin[row_of[r]]) keep.push_back(r);
+      if (g_qwen_compact_pct > 0 && (int)keep.size() < live && (live - (int)keep.size()) * 100 >= live * g_qwen_compact_pct) {
+        const int nl = (int)keep.size();
+        if (hipMemcpyAsync(m->cmp_src, keep.data(), sizeof(int32_t) * nl, hipMemcpyHostToDevice, s) != hipSuccess) { set_error("wj_qwen_generate_greedy: compaction upload failed"); rc_loop = WJ_E_HIP; break; }
+        hipLaunchKernelGGL(compact_decode_rows_kernel, dim3(ceil_div(nl, 64)), dim3(64), 0, s, m->cmp_src, nl, m->row_seq, m->row_pos, m->next_tok,
+                           m->cmp_seq, m->cmp_pos, m->cmp_tok);
+        (void)hipMemcpyAsync(m->row_seq, m->cmp_seq, sizeof(int32_t) * nl, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(m->row_pos, m->cmp_pos, sizeof(int32_t) * nl, hipMemcpyDeviceToDevice, s);
+        (void)hipMemcpyAsync(m->next_tok, m->cmp_tok, sizeof(int32_t) * nl, hipMemcpyDeviceToDevice, s);
+        if (hipStreamSynchronize(s) != hipSuccess) { set_error("wj_qwen_generate_greedy: compaction failed"); rc_loop = WJ_E_HIP; break; }
+        std::vector<int32_t> nr(nl);
+        for (int r = 0; r < nl; ++r) nr[r] = row_of[keep[r]];
+        row_of.swap(nr);
+        live = nl;
+        ++m->last_compactions;
+        capture_next = true;         // the grids depend on the row count: capture the iteration again
+      }
     }
   }
   if (exec) (void)hipGraphExecDestroy(exec);

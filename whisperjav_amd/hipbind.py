@@ -86,6 +86,8 @@ _SIGNATURES = {
     "wj_qwen_last_used_graph": (_I, [_P]),
     "wj_qwen_last_steps": (_I, [_P]),
     "wj_qwen_last_truncated": (_I, [_P]),
+    "wj_qwen_last_compactions": (_I, [_P]),
+    "wj_qwen_last_row_steps": (C.c_int64, [_P]),
     "wj_qwen_classify": (_I, [_P, _P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _P, _P, _I, C.POINTER(C.c_int32), _P, _P]),
     "wj_qwen_audio_create": (_I, [_P, _P, _I, _P, C.c_size_t, C.POINTER(C.c_int64), _I, _I, C.POINTER(_P)]),
     "wj_qwen_audio_free": (_I, [_P]),

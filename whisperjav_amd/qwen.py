@@ -397,6 +397,8 @@ class GenerateResult:
     tokens: List[List[int]]
     token_logprob: List[List[float]]      # one entry per token, + the EOS token's when the sequence ended on one
     steps: int = 0                        # decode iterations the call ran (it stops when every sequence has ended)
+    compactions: int = 0                  # times the batch was re-packed because sequences had ended
+    row_steps: int = 0                    # sum over the iterations of the live rows
     context_limited: Optional[List[bool]] = None   # sequences whose budget was cut to the room left in the KV cache
 
 
@@ -566,7 +568,8 @@ class HipQwen3Decoder:
             out_l.append(lps[b, : k + 1 if k < int(lim[b]) else k].tolist())      # + the EOS token's when the sequence ended on one
         self._n_seqs = 0
         assert int(self._lib.wj_qwen_last_truncated(self.handle)) == sum(limited)
-        return GenerateResult(out_t, out_l, int(self._lib.wj_qwen_last_steps(self.handle)), limited)
+        return GenerateResult(out_t, out_l, int(self._lib.wj_qwen_last_steps(self.handle)), int(self._lib.wj_qwen_last_compactions(self.handle)),
+                              int(self._lib.wj_qwen_last_row_steps(self.handle)), limited)
 
 
 def dynamic_token_limit(audio_duration_sec: float, max_new_tokens: int, max_tokens_per_audio_second: float,
