@@ -664,3 +664,55 @@ def test_float8w_decoder_matches_the_mx_rounding_oracle_and_states_its_distance_
     assert e_fp32 < 1.5, e_fp32
     assert first_same >= 3
     model.close()
+
+
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_prompt_attention_on_the_matrix_cores_equals_the_row_kernel(hip, dtype):
+    """Prompt passes of the 16-bit types run their causal attention as MFMA tiles (csrc/qwen.hip prompt_attn_kernel; wj_tune
+    qwen_prompt_mfma).  Sequence lengths on both sides of every tile edge (1, 63 / 64 / 65, 128 / 129, 200, 300 = three query
+    blocks): the last-position logits, a classification over interior rows, and the generation that continues from the KV
+    cache agree with the one-row-per-wave kernel (fp32 softmax weights) to the rounding of the probabilities, and with the
+    fp32 oracle to the type's bound."""
+    from whisperjav_amd import hipbind, qwen
+    d = qwen.Qwen3Dims(hidden=256, n_layer=3, n_head=4, n_kv_head=2, head_dim=128, ffn=640, vocab=4096, rope_theta=10000.0,
+                       audio_token_id=9, eos_token_ids=(1, 2))
+    w = qwen.synth_weights(d, seed=11)
+    od = qwen3_ref.Qwen3AsrDims(d=d.hidden, layers=d.n_layer, heads=d.n_head, kv_heads=d.n_kv_head, head_dim=d.head_dim, ffn=d.ffn,
+                                vocab=d.vocab, rope_theta=d.rope_theta, rms_eps=d.rms_eps, audio_token_id=d.audio_token_id,
+                                eos_token_ids=d.eos_token_ids)
+    oracle = qwen3_ref.Qwen3AsrOracle(od, w)
+    lengths = (1, 17, 63, 64, 65, 128, 129, 200, 300)
+    rng = np.random.default_rng(21)
+    model = qwen.HipQwen3Decoder(d, w, dtype=dtype, max_seqs=len(lengths), max_ctx=384)
+    embeds = []
+    for n in lengths:
+        ids = rng.integers(20, d.vocab, n).tolist()
+        embeds.append(model.prompt_embeddings(ids, None))
+    rows = [sorted({0, n // 2, n - 1}) for n in lengths]
+    head_w = torch.from_numpy(rng.standard_normal((24, d.hidden)).astype(np.float32) * 0.2)
+    out = {}
+    try:
+        for mode in (0, 1):
+            hipbind.tune("qwen_prompt_mfma", mode)
+            _, cl = model.classify(embeds, rows, head_w, want_logits=True)
+            logits = model.prefill(embeds, want_logits=True).cpu()
+            gen = model.generate(max_new_tokens=6)
+            out[mode] = (logits, cl.cpu(), gen)
+    finally:
+        hipbind.tune("qwen_prompt_mfma", 1)
+    (l0, c0, g0), (l1, c1, g1) = out[0], out[1]
+    assert torch.isfinite(l1).all() and torch.isfinite(c1).all()
+    scale = float(l0.abs().max())
+    kern = float((l1 - l0).abs().max()) / scale
+    kern_c = float((c1 - c0).abs().max()) / max(1.0, float(c0.abs().max()))
+    with torch.no_grad():
+        ref = torch.stack([oracle.logits(e.cpu())[-1] for e in embeds])
+    e0 = float((l0 - ref).abs().max()) / scale
+    e1 = float((l1 - ref).abs().max()) / scale
+    print(f"{dtype}: tile kernel vs row kernel {kern:.2e} (logits) {kern_c:.2e} (classifier); vs fp32 oracle: row {e0:.2e} tile {e1:.2e}")
+    bound = {"float16": 4e-3, "bfloat16": 3e-2}[dtype]
+    assert kern < bound and kern_c < bound, (kern, kern_c)
+    assert e1 < max(1.5 * e0, bound), (e0, e1)
+    same = sum(a == b for a, b in zip(g0.tokens, g1.tokens))
+    assert same >= len(lengths) - (1 if dtype == "float16" else 3), (g0.tokens, g1.tokens)
+    model.close()

@@ -20,6 +20,7 @@
 
 namespace wj {
 int g_qwen_split_act = 2;   // wj_tune("qwen_split_act"), read at wj_qwen_create
+int g_qwen_prompt_mfma = 1;  // wj_tune("qwen_prompt_mfma"): prompts of the 16-bit types take the MFMA tile attention (0 = the one-row-per-wave kernel)
 int g_qwen_compact_pct = 15; // wj_tune("qwen_compact_pct"): re-pack the decode batch at a poll when this share of its rows has ended (0 = never)
 }
 using namespace wj;
@@ -295,6 +296,222 @@ __global__ __launch_bounds__(256) void rep_penalty_kernel(float* __restrict__ lo
   }
 }
 
+// --------------------------------------------------------------------------------------------
+// Prompt attention on the matrix cores (round 4; wj_tune "qwen_prompt_mfma", 16-bit types).  A prefill or classification pass
+// presents every sequence from position 0, so the causal product of a sequence is a lower-triangular tile problem: one
+// workgroup = 128 consecutive query positions of one (sequence, query head), wave w owns 32 of them, the key/value rows of the
+// sequence's KV head stream through LDS 64 at a time, double-buffered.  The arithmetic is the encoder attention's
+// (attention.hip: S^T = K.Q^T with the key rows permuted so that the probabilities leave the MFMA already in B-operand order,
+// lean online softmax with a slack-bounded running maximum, row sums from a ones block, O^T += V^T.P^T), widened to 128 head
+// dims: 32 + 32 + 4 MFMAs per wave and key tile.  Two things differ:
+//   * V lives in the cache as [key][128]; the PV product wants V^T fragments (8 consecutive KEYS of one dim per lane).  The tile
+//     is transposed on its way into LDS: a lane loads 16 B = 8 dims of ITS key (lane = key), and stores them as 8 two-byte LDS
+//     writes into rows d, column key -- the 64 lanes of a store hit one 128-byte LDS row, conflict-free.
+//   * causality: a key tile is FULL for a wave when its last key <= the wave's first query, MASKED (key > query -> -inf) when it
+//     straddles the diagonal, and skipped (loads and barriers only) when it lies beyond the wave's last query.
+// Cache rows past the sequence end are never trusted: K rows are clamped to the last real key (their scores are masked by the
+// select), V rows are zeroed while staging (0 * p, not NaN * 0).  Work items (sequence slot, first query, first row, length) are
+// built on the host by the pass that owns the rows.
+// --------------------------------------------------------------------------------------------
+template <typename T> struct QLane;
+template <> struct QLane<bf16_t> { typedef __bf16 type; };
+template <> struct QLane<f16_t> { typedef _Float16 type; };
+
+__device__ __forceinline__ int pk_perm(int k) { return 16 * (2 * (k >> 5) + ((k >> 2) & 1)) + 4 * ((k >> 3) & 3) + (k & 3); }
+__device__ __forceinline__ int pk_swz(int prow, int chunk) { return prow * 128 + ((chunk ^ (prow & 15)) << 3); }     // K tile [64][128]
+__device__ __forceinline__ int pv_swz(int d, int chunk) { return d * 64 + ((chunk ^ (d & 7)) << 3); }               // V^T tile [128][64]
+
+__device__ __forceinline__ float pa_quad_max(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const uint32_t v = __float_as_uint(x);
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void prompt_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
+                                                          const int4* __restrict__ work, T* __restrict__ out, int H, int KV, int ctx,
+                                                          int split) {
+  typedef typename Vec8<T>::type vec8_t;
+  typedef typename QLane<T>::type lane_t;
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 2 * 8192];   // [buf][K | V^T][8192] = 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int4 wk = work[blockIdx.x];
+  const int b_seq = wk.x, qb0 = wk.y, row0 = wk.z, n = wk.w;
+  const int h = blockIdx.y, kvh = h / (H / KV);
+  const int q0 = qb0 + wave * 32;                       // this wave's first query position
+  const int64_t kvoff = ((int64_t)b_seq * KV + kvh) * (int64_t)ctx * HD;
+  const T* Kp = kc + kvoff;
+  const T* Vp = vc + kvoff;
+
+  vec8_t qf[2][4];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int qpos = min(q0 + f * 16 + li, n - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[f][ks] = *reinterpret_cast<const vec8_t*>(q + ((int64_t)(row0 + qpos) * H + h) * HD + ks * 32 + lg * 8);
+  }
+  f32x4_t o[2][8];
+  f32x4_t lsum[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+  vec8_t ones8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones8[e] = (lane_t)1.0f;
+  float m_run[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o[f][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (min(qb0 + 128, n) + 63) >> 6;         // key tiles this workgroup walks
+  uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+#define WJ_PLOAD1(i, kt)                                                                               \
+  {                                                                                                    \
+    const int idx = tid + (i) * 256;                                                                   \
+    const int krow = min((kt) * 64 + (idx >> 4), n - 1);                                               \
+    rk##i = *reinterpret_cast<const uint4*>(Kp + (int64_t)krow * HD + (idx & 15) * 8);                 \
+    const int vkey = (kt) * 64 + lane;                                                                 \
+    rv##i = *reinterpret_cast<const uint4*>(Vp + (int64_t)min(vkey, n - 1) * HD + ((i) * 4 + wave) * 8); \
+    if (vkey >= n) rv##i = uint4{0u, 0u, 0u, 0u};                                                      \
+  }
+#define WJ_PLOAD(kt) WJ_PLOAD1(0, kt) WJ_PLOAD1(1, kt) WJ_PLOAD1(2, kt) WJ_PLOAD1(3, kt)
+#define WJ_PSTORE1(i, buf)                                                                             \
+  {                                                                                                    \
+    const int idx = tid + (i) * 256;                                                                   \
+    *reinterpret_cast<uint4*>(&lds[((buf) * 2 + 0) * 8192 + pk_swz(pk_perm(idx >> 4), idx & 15)]) = rk##i; \
+    uint16_t* lvw = &lds[((buf) * 2 + 1) * 8192];                                                      \
+    const int d0 = ((i) * 4 + wave) * 8, kc8 = lane >> 3, ko = lane & 7;                               \
+    lvw[pv_swz(d0 + 0, kc8) + ko] = (uint16_t)(rv##i.x & 0xffffu);                                     \
+    lvw[pv_swz(d0 + 1, kc8) + ko] = (uint16_t)(rv##i.x >> 16);                                         \
+    lvw[pv_swz(d0 + 2, kc8) + ko] = (uint16_t)(rv##i.y & 0xffffu);                                     \
+    lvw[pv_swz(d0 + 3, kc8) + ko] = (uint16_t)(rv##i.y >> 16);                                         \
+    lvw[pv_swz(d0 + 4, kc8) + ko] = (uint16_t)(rv##i.z & 0xffffu);                                     \
+    lvw[pv_swz(d0 + 5, kc8) + ko] = (uint16_t)(rv##i.z >> 16);                                         \
+    lvw[pv_swz(d0 + 6, kc8) + ko] = (uint16_t)(rv##i.w & 0xffffu);                                     \
+    lvw[pv_swz(d0 + 7, kc8) + ko] = (uint16_t)(rv##i.w >> 16);                                         \
+  }
+#define WJ_PSTORE(buf) WJ_PSTORE1(0, buf) WJ_PSTORE1(1, buf) WJ_PSTORE1(2, buf) WJ_PSTORE1(3, buf)
+
+  WJ_PLOAD(0)
+  WJ_PSTORE(0)
+  __syncthreads();
+
+  constexpr float c2 = 0.08838834764831845f * 1.44269504088896340736f;    // 1 / sqrt(128) * log2 e
+  constexpr float kSlack = 8.0f;
+  // MODE 0: every key of the tile is visible to every query of the wave; 1: the tile straddles the diagonal; 2: beyond it
+  auto key_tile = [&](const int kt, auto mode_tag) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    const int cur = kt & 1;
+    if (kt + 1 < nt) { WJ_PLOAD(kt + 1) }
+    if constexpr (MODE < 2) {
+      const uint16_t* lk = &lds[(cur * 2 + 0) * 8192];
+      const uint16_t* lv = &lds[(cur * 2 + 1) * 8192];
+      f32x4_t st[2][4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int krow = 16 * kb + li;
+        st[0][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        st[1][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const vec8_t kf = *reinterpret_cast<const vec8_t*>(&lk[pk_swz(krow, ks * 4 + lg)]);
+          st[0][kb] = mfma16(kf, qf[0][ks], st[0][kb]);
+          st[1][kb] = mfma16(kf, qf[1][ks], st[1][kb]);
+        }
+      }
+      // lane (query li of fragment f, lg) holds, for block kb, keys kt*64 + 32*(kb>>1) + 8*lg + 4*(kb&1) + r
+      if constexpr (MODE == 1) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const int qpos = q0 + f * 16 + li;
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = kt * 64 + 32 * (kb >> 1) + 8 * lg + 4 * (kb & 1) + r;
+              if (key > qpos) st[f][kb][r] = -INFINITY;
+            }
+        }
+      }
+      vec8_t pf[2][2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[f][kb][r]);
+        mx = pa_quad_max(mx);
+        const float mxs = mx * c2;
+        if (mxs > m_run[f] + kSlack || m_run[f] == -INFINITY) {
+          const float m_new = fmaxf(m_run[f], mxs);
+          const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);     // first tile: exp2(-inf) = 0 on zeros
+          m_run[f] = m_new;
+#pragma unroll
+          for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[f][d][r] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lsum[f][r] *= alpha;
+        }
+        const float nm = -m_run[f];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          vec8_t v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = (lane_t)__builtin_amdgcn_exp2f(fmaf(st[f][2 * s2][r], c2, nm));
+            v[4 + r] = (lane_t)__builtin_amdgcn_exp2f(fmaf(st[f][2 * s2 + 1][r], c2, nm));
+          }
+          pf[f][s2] = v;
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        lsum[0] = mfma16(ones8, pf[0][s2], lsum[0]);
+        lsum[1] = mfma16(ones8, pf[1][s2], lsum[1]);
+      }
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const vec8_t vf = *reinterpret_cast<const vec8_t*>(&lv[pv_swz(d * 16 + li, s2 * 4 + lg)]);
+          o[0][d] = mfma16(vf, pf[0][s2], o[0][d]);
+          o[1][d] = mfma16(vf, pf[1][s2], o[1][d]);
+        }
+    }
+    if (kt + 1 < nt) { WJ_PSTORE(cur ^ 1) }
+    __syncthreads();
+  };
+  for (int kt = 0; kt < nt; ++kt) {
+    if (kt * 64 > q0 + 31) key_tile(kt, std::integral_constant<int, 2>{});
+    else if (kt * 64 + 63 <= q0) key_tile(kt, std::integral_constant<int, 0>{});
+    else key_tile(kt, std::integral_constant<int, 1>{});
+  }
+#undef WJ_PLOAD
+#undef WJ_PLOAD1
+#undef WJ_PSTORE
+#undef WJ_PSTORE1
+
+  const int64_t ldo = (int64_t)H * HD * (split ? 2 : 1);
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int qpos = q0 + f * 16 + li;
+    if (qpos >= n) continue;
+    const float inv = 1.0f / lsum[f][0];
+    T* dst = out + (int64_t)(row0 + qpos) * ldo + h * HD + lg * 4;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      float v[4] = {o[f][d][0] * inv, o[f][d][1] * inv, o[f][d][2] * inv, o[f][d][3] * inv};
+      if (split) st4_split<T>(dst + d * 16, (int64_t)H * HD, v);
+      else st4(dst + d * 16, v);
+    }
+  }
+}
+
 }  // namespace
 
 struct wj_qwen {
@@ -342,6 +559,9 @@ struct wj_qwen {
   uint8_t* a8s = nullptr;
   int last_used_graph = 0;   // the last generation replayed its iteration from a hipGraph
   int32_t *cmp_src = nullptr, *cmp_seq = nullptr, *cmp_pos = nullptr, *cmp_tok = nullptr;   // batch compaction scratch [max_seqs]
+  int4* pwork = nullptr;      // prompt attention work items (sequence slot, first query, first row, length), see prompt_attn_kernel
+  int pwork_cap = 0, pwork_n = 0;   // pwork_n > 0 only while a prompt pass (prefill / classify) runs its layers
+  std::vector<int32_t> pwork_host;
   int last_compactions = 0;  // times the last generation re-packed its batch
   int64_t last_row_steps = 0;  // sum over its iterations of the live rows (the work actually done)
   int last_steps = 0;        // decode iterations the last generation ran (it leaves the loop when every sequence has ended)
@@ -428,10 +648,17 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
 #define WJ_GQA(T_, G_) hipLaunchKernelGGL((gqa_attn_kernel<T_, G_>), dim3(M, KV), dim3(64), 0, s, TP(const T_, m->q), TP(const T_, kc), \
                                           TP(const T_, vc), m->row_seq, m->row_pos, TP(T_, m->attn), H, KV, m->max_ctx, split ? 1 : 0)
 #define WJ_GQA_T(G_) do { if (dt == WJ_F32) WJ_GQA(float, G_); else if (dt == WJ_F16) WJ_GQA(f16_t, G_); else WJ_GQA(bf16_t, G_); } while (0)
-    // Prompt rows use the same one-row-per-wave kernel: a form that gave a wave 4 consecutive rows of a sequence (8 (row, head)
-    // pairs sharing every K / V load, per-row causal limits) was measured on the 104 k prompt rows of the 120-minute batch and
-    // was SLOWER (prefill 443 -> 481 ms): the kernel is bound by its per-pair arithmetic and exchanges, not by the L2 reads the
-    // blocking saves, and 4x fewer waves hide less latency.  The next step for prompts is an MFMA tile kernel, not blocking.
+    // Decode rows (and fp32 prompts) use the one-row-per-wave kernel.  Round 3 tried giving a wave 4 consecutive prompt rows
+    // (8 (row, head) pairs sharing every K / V load): SLOWER (prefill 443 -> 481 ms), the kernel is bound by its per-pair
+    // arithmetic and exchanges.  Round 4: 16-bit prompts go to prompt_attn_kernel, the MFMA tile form.
+    if (m->pwork_n > 0 && dt != WJ_F32) {      // a prompt pass: lower-triangular tiles on the matrix cores
+      if (dt == WJ_F16)
+        hipLaunchKernelGGL((prompt_attn_kernel<f16_t>), dim3(m->pwork_n, H), dim3(256), 0, s, TP(const f16_t, m->q), TP(const f16_t, kc),
+                           TP(const f16_t, vc), m->pwork, TP(f16_t, m->attn), H, KV, m->max_ctx, split ? 1 : 0);
+      else
+        hipLaunchKernelGGL((prompt_attn_kernel<bf16_t>), dim3(m->pwork_n, H), dim3(256), 0, s, TP(const bf16_t, m->q), TP(const bf16_t, kc),
+                           TP(const bf16_t, vc), m->pwork, TP(bf16_t, m->attn), H, KV, m->max_ctx, split ? 1 : 0);
+    } else
     switch (H / KV) {      // query heads per KV head (wj_qwen_create admits 1, 2, 4)
       case 1: WJ_GQA_T(1); break;
       case 2: WJ_GQA_T(2); break;
@@ -505,6 +732,24 @@ int qalloc(wj_qwen* m, void** p, size_t bytes) {
   return WJ_OK;
 }
 
+// Work items of the prompt attention for a pass that presents n_seqs whole sequences from position 0, rows packed in order
+int upload_prompt_work(wj_qwen* m, int n_seqs, const int32_t* n_tokens, hipStream_t s) {
+  m->pwork_n = 0;
+  if (m->dtype == WJ_F32 || !g_qwen_prompt_mfma) return WJ_OK;
+  std::vector<int32_t>& w = m->pwork_host;
+  w.clear();
+  int row0 = 0;
+  for (int b = 0; b < n_seqs; ++b) {
+    for (int q0 = 0; q0 < n_tokens[b]; q0 += 128) { w.push_back(b); w.push_back(q0); w.push_back(row0); w.push_back(n_tokens[b]); }
+    row0 += n_tokens[b];
+  }
+  const int n = (int)(w.size() / 4);
+  if (n > m->pwork_cap) { set_error("wj_qwen: %d prompt attention work items (room for %d)", n, m->pwork_cap); return WJ_E_INVALID; }
+  WJ_HIP(hipMemcpyAsync(m->pwork, w.data(), sizeof(int32_t) * w.size(), hipMemcpyHostToDevice, s));
+  m->pwork_n = n;
+  return WJ_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -568,6 +813,8 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   m->seen_cap = 2 * max_ctx;      // unique prompt ids (< max_ctx) + generated ids (positions stop at max_ctx)
   QA(lim, S * 4); QA(seen_n, S * 4); QA(seen, S * (size_t)m->seen_cap * 4);
   QA(cmp_src, S * 4); QA(cmp_seq, S * 4); QA(cmp_pos, S * 4); QA(cmp_tok, S * 4);
+  m->pwork_cap = m->max_rows / 128 + (int)S + 1;
+  QA(pwork, (int64_t)m->pwork_cap * 16);
   if (f8w) {
     const int64_t Wq = (int64_t)(H + 2 * KV) * HD;
     const int64_t rows_of[4] = {Wq, D, 2 * (int64_t)F, D}, cols_of[4] = {D, (int64_t)H * HD, D, F};
@@ -626,7 +873,8 @@ int wj_qwen_prefill(wj_qwen* m, const float* embeds_dev, int n_seqs, const int32
   WJ_HIP(hipMemcpyAsync(m->last_rows, last.data(), sizeof(int32_t) * n_seqs, hipMemcpyHostToDevice, s));
   WJ_HIP(hipMemcpyAsync(m->x, embeds_dev, sizeof(float) * (size_t)M * m->d.hidden, hipMemcpyDeviceToDevice, s));   // packed rows
   m->n_seqs = 0;
-  WJ_TRYQ(run_layers(m, M, s, m->split_mode >= 2));
+  WJ_TRYQ(upload_prompt_work(m, n_seqs, n_tokens_host, s));
+  { const int rc_l = run_layers(m, M, s, m->split_mode >= 2); m->pwork_n = 0; if (rc_l) return rc_l; }
   hipLaunchKernelGGL(gather_rows_kernel, dim3(n_seqs), dim3(256), 0, s, m->x, m->last_rows, m->xl, m->d.hidden);
   WJ_LAUNCH_CHECK();
   WJ_TRYQ(run_head(m, m->xl, n_seqs, s));
@@ -671,7 +919,8 @@ int wj_qwen_classify(wj_qwen* m, const float* embeds_dev, int n_seqs, const int3
   WJ_HIP(hipMemcpyAsync(m->row_pos, pos.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, s));
   WJ_HIP(hipMemcpyAsync(m->x, embeds_dev, sizeof(float) * (size_t)M * m->d.hidden, hipMemcpyDeviceToDevice, s));
   m->n_seqs = 0;       // the caches are about to hold a classification pass: generation needs its own prefill
-  WJ_TRYQ(run_layers(m, M, s, m->split_mode >= 2));
+  WJ_TRYQ(upload_prompt_work(m, n_seqs, n_tokens_host, s));
+  { const int rc_l = run_layers(m, M, s, m->split_mode >= 2); m->pwork_n = 0; if (rc_l) return rc_l; }
   // the selected rows (e.g. the <timestamp> markers of a forced-alignment prompt): final RMSNorm + the caller's head.  The
   // gather goes through a scratch allocation because x is the residual stream being read.
   int32_t* tmp_rows = nullptr;
