@@ -366,6 +366,16 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
  * has ended leave it), out[5] = sum over the iterations of the live windows (window-steps of work actually done) */
 int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[6]);
 
+/* Per-token log-probs of the WINNING hypothesis of every window of the last wj_whisper_decode_beam{,_openai} call, when that
+ * call ran with wj_tune("beam_token_logprobs", 1) (a diagnostic mode: the search then carries the cumulative log-prob after
+ * every token of every hypothesis through its history gathers, and does not compact its batch).  out_host [batch][stride],
+ * stride = that call's max_new_tokens + 1: entries 0 .. n_tokens-1 = log p of each generated token under the masked
+ * distribution the search ranked it in, entry n_tokens = what ending the sequence added (log p(EOT); 0 at the length limit),
+ * NaN beyond.  They sum to sum_logprob_out.  The reference's libraries expose only the sum (ctranslate2 WhisperGenerationResult
+ * .scores, whisper DecodingResult.avg_logprob); this is what the parity tests bound per token.  WJ_E_INVALID when the last
+ * search did not carry them or batch / stride differ from that call's. */
+int wj_whisper_last_beam_token_logprobs(const wj_whisper* m, int batch, int stride, float* out_host);
+
 /* Step-wise decoder for host-driven search (beam search with CTranslate2's patience /
  * repetition-penalty / no-repeat-ngram processors lives in whisperjav_amd/search.py).
  * rows = batch*beam, row r belongs to window r / beam.

@@ -202,6 +202,7 @@ def beam_search(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], b
             if p == 0:
                 nsp = float(torch.softmax(lg[0].float(), -1)[lay.no_speech])
         seqs: List[List[int]] = [[] for _ in range(K)]           # generated tokens per beam
+        cums: List[List[float]] = [[] for _ in range(K)]         # cumulative log-prob after each of them
         scores = torch.full((K,), NEG_INF)
         scores[0] = 0.0
         feed = torch.full((K, 1), prompt[-1])
@@ -225,7 +226,7 @@ def beam_search(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], b
                 s, b, t = cand[k]
                 use = cand[k]
                 if t == lay.eot or last:
-                    finished.append((s, seqs[b] + ([] if t == lay.eot else [t])))
+                    finished.append((s, seqs[b] + ([] if t == lay.eot else [t]), cums[b] + ([] if t == lay.eot else [s])))
                     tr["finish_steps"].append(step)
                     for j in range(secondary, len(cand)):
                         if cand[j][2] != lay.eot:
@@ -240,14 +241,18 @@ def beam_search(model: WhisperOracle, xa: torch.Tensor, prompt: Sequence[int], b
             parents = [b for _, b, _ in nxt] + [0] * (K - len(nxt))
             new_scores = [s for s, _, _ in nxt] + [NEG_INF] * (K - len(nxt))
             new_seqs = [seqs[b] + [t] for _, b, t in nxt] + [list(seqs[0]) for _ in range(K - len(nxt))]
+            cums = [cums[b] + [sc] for sc, b, _ in nxt] + [list(cums[0]) for _ in range(K - len(nxt))]
             dec.reorder(torch.tensor(parents))
             seqs, scores = new_seqs, torch.tensor(new_scores)
             feed = torch.tensor([[t] for _, _, t in nxt] + [[lay.eot]] * (K - len(nxt)))
     lpn = bcfg.length_penalty
-    ranked = sorted(((s / (max(len(t), 1) ** lpn) if lpn != 0 else s, s, t) for s, t in finished), key=lambda x: -x[0])
+    ranked = sorted(((s / (max(len(t), 1) ** lpn) if lpn != 0 else s, s, t, c) for s, t, c in finished), key=lambda x: -x[0])
     if trace is not None:
+        # per hypothesis (best first): log p of each token under the distribution the search ranked it in, then what ending
+        # the sequence added (log p(EOT); 0 at the length limit) -- the differences of the cumulative scores
+        tr["token_logprobs"] = [[c[j] - (c[j - 1] if j else 0.0) for j in range(len(c))] + [s - (c[-1] if c else 0.0)] for _, s, _, c in ranked]
         trace.update(tr)
-    return [(t, n, s) for n, s, t in ranked], nsp
+    return [(t, n, s) for n, s, t, _ in ranked], nsp
 
 
 # --------------------------------------------------------------------------------------------------

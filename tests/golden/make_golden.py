@@ -159,7 +159,9 @@ def run_r3(max_new: int = 64):
                         f"beam{b}_norm": np.array([n for _, n, _ in hyps], dtype=np.float64),
                         f"beam{b}_cum": np.array([c for _, _, c in hyps], dtype=np.float64), f"beam{b}_no_speech": np.float64(nsp),
                         f"beam{b}_refills": tr["refills"], f"beam{b}_steps": tr["steps"], f"beam{b}_stop": tr["stop"],
-                        f"beam{b}_finish_steps": np.array(tr["finish_steps"])})
+                        f"beam{b}_finish_steps": np.array(tr["finish_steps"]),
+                        # the winner's per-token log-probs (+ the EOT's): what wj_whisper_last_beam_token_logprobs is held to
+                        f"beam{b}_token_logprobs": np.array(tr["token_logprobs"][0], dtype=np.float64)})
             gl = len(res.tokens[b])
             out.update({f"greedy{b}_tokens": np.array(res.tokens[b]), f"greedy{b}_logprob": np.array(res.token_logprob[b], dtype=np.float32)})
             assert len(res.token_logprob[b]) == gl + 1 or gl == max_new

@@ -307,6 +307,74 @@ def test_batch_compaction_is_transparent(hip, dtype):
     model.close()
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
+def test_beam_winner_per_token_logprobs(hip, dtype):
+    """``decode_beam(token_logprobs=True)`` (wj_tune beam_token_logprobs): the search carries the cumulative log-prob of every
+    hypothesis through its history gathers; the winner's per-token values equal the oracle's (its beam search records the
+    same differences in ``trace["token_logprobs"]``) -- 1e-4 in float32, the type's per-token bound in float16 on this toy
+    model -- sum to ``sum_logprob``, and the winner itself is the one the plain search returns.  CTranslate2 rules stopped by
+    patience and by the length limit (where the last token is appended and nothing is added for an EOT), and the
+    openai-whisper rules including the top-up from live beams."""
+    from whisperjav_amd import engine, hipbind
+    B = 6
+    d, oracle, model, xa = _setup(dtype, B, 5)
+    toks = model.tokens
+    prompt = model.sot_prompt("ja", "transcribe")
+    P = np.tile(np.array(prompt, dtype=np.int32), (B, 1))
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    fcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=0)
+    tol = {"float32": 1e-4, "float16": 8e-3}[dtype]      # d_model 128 toy: the EOT step carries the largest error (PARITY.md); the 1e-3 bar is asserted at the large-v3 geometry
+    seen_length_stop = seen_eot = 0
+    for max_new in (64, 14):
+        dopt = engine.DecodeOptions(max_new_tokens=max_new, suppress_tokens=suppress, max_initial_timestamp=0.0,
+                                    repetition_penalty=1.5, no_repeat_ngram_size=3)
+        plain = model.decode_beam(P, dopt, beam_size=5, patience=1.2, length_penalty=1.0)
+        res = model.decode_beam(P, dopt, beam_size=5, patience=1.2, length_penalty=1.0, token_logprobs=True)
+        assert model.last_decode_info()["compactions"] == 0
+        assert np.array_equal(plain.tokens, res.tokens) and np.array_equal(plain.sum_logprob, res.sum_logprob)
+        assert res.token_logprob.shape == (B, max_new + 1)
+        bcfg = decoding.BeamConfig(5, 1.2, 1.0, 1.5, 3, max_new)
+        for w in range(B):
+            n = int(res.n_tokens[w])
+            lp = res.token_logprob[w]
+            assert np.isfinite(lp[: n + 1]).all() and np.isnan(lp[n + 1:]).all()
+            assert abs(float(lp[: n + 1].sum()) - float(res.sum_logprob[w])) < 1e-4 * (n + 1)
+            tr = {}
+            ref, _ = decoding.beam_search(oracle, xa[w:w + 1], prompt, bcfg, fcfg, trace=tr)
+            if res.tokens[w, :n].tolist() != ref[0][0]:
+                assert dtype != "float32"
+                continue
+            want = np.array(tr["token_logprobs"][0])
+            assert len(want) == n + 1
+            assert np.abs(lp[: n + 1] - want).max() < tol, (w, lp[: n + 1], want)
+            if n == max_new:
+                seen_length_stop += 1
+                assert lp[n] == 0.0                     # ended by the length limit: no EOT was scored
+            else:
+                seen_eot += 1
+                assert lp[n] < 0.0
+    assert seen_length_stop and seen_eot, (seen_length_stop, seen_eot)
+    # openai-whisper rules (no processors), a length limit short enough that windows are topped up with live beams
+    for max_new in (64, 15):
+        dopt = engine.DecodeOptions(max_new_tokens=max_new, suppress_tokens=suppress, max_initial_timestamp=0.0)
+        plain = model.decode_beam(P, dopt, beam_size=5, patience=1.0, length_penalty=None, flavor="openai")
+        res = model.decode_beam(P, dopt, beam_size=5, patience=1.0, length_penalty=None, flavor="openai", token_logprobs=True)
+        assert np.array_equal(plain.tokens, res.tokens) and np.array_equal(plain.sum_logprob, res.sum_logprob)
+        for w in range(B):
+            n = int(res.n_tokens[w])
+            lp = res.token_logprob[w]
+            assert np.isfinite(lp[: min(n + 1, max_new + 1)]).all()
+            assert abs(float(np.nansum(lp)) - float(res.sum_logprob[w])) < 1e-4 * (n + 1), (w, lp, res.sum_logprob[w])
+            assert (lp[:n] <= 1e-6).all()
+    with pytest.raises(hipbind.WjError, match="beam_token_logprobs"):
+        model.decode_beam(P, dopt, beam_size=5)                                          # a plain search ...
+        out = np.empty((B, dopt.max_new_tokens + 1), dtype=np.float32)
+        import ctypes as C
+        hipbind.check(model._lib.wj_whisper_last_beam_token_logprobs(model.handle, B, dopt.max_new_tokens + 1,
+                                                                    out.ctypes.data_as(C.POINTER(C.c_float))))   # ... carries none
+    model.close()
+
+
 def test_short_kv_cache_and_encoder_slices_change_nothing(hip):
     """``HipWhisper(kv_len=..., enc_batch=...)``: a KV cache sized for prompt + max_new_tokens and an encoder run in slices
     give bit-identical encoder outputs and the same hypotheses as the full-size engine; a decode that does not fit the
@@ -343,7 +411,8 @@ def test_golden_large_v3_r3_searches_that_end(hip, dtype):
     """Large-v3 geometry, fp16-representable ``SPEECHLIKE`` weights, two windows (a 6 s and a 2.5 s clip): greedy until
     EOT and the cfg3 beam search until patience stops it, against the committed oracle vectors
     (tests/golden/make_golden.py --large-r3).  Bars: tokens / winning hypothesis identical, per-token log-probs within
-    1e-3 (the north-star bar) in both compute types."""
+    1e-3 (the north-star bar) in both compute types -- for the greedy rows AND for the beam winner (its per-token values
+    come from the cumulative histories the search carries under wj_tune beam_token_logprobs)."""
     from whisperjav_amd import dims as pdims, engine, synth, weights as pweights
     g = np.load(os.path.join(GOLDEN, "golden_large_v3_r3_eot.npz"))
     dims = pdims.dims_for("large-v3")
@@ -366,6 +435,13 @@ def test_golden_large_v3_r3_searches_that_end(hip, dtype):
                                                         repetition_penalty=rep, no_repeat_ngram_size=int(ngram)),
                            beam_size=int(beam), patience=patience, length_penalty=lpen)
     b_steps = model.last_decode_info()["steps"]
+    # the same search carrying the cumulative score of every hypothesis (wj_tune beam_token_logprobs): same winner, and its
+    # per-token log-probs are read back
+    bl = model.decode_beam(prompts, engine.DecodeOptions(max_new_tokens=max_new, suppress_tokens=sup, max_initial_timestamp=0.0,
+                                                        repetition_penalty=rep, no_repeat_ngram_size=int(ngram)),
+                           beam_size=int(beam), patience=patience, length_penalty=lpen, token_logprobs=True)
+    assert np.array_equal(bl.tokens, br.tokens) and np.array_equal(bl.n_tokens, br.n_tokens)
+    assert np.array_equal(bl.sum_logprob, br.sum_logprob) and np.array_equal(bl.beam_score, br.beam_score)
     model.close()
     bar = 1e-3
     out = {"dtype": dtype, "probe_max_abs": d_probe, "greedy_steps": g_steps, "beam_steps": b_steps}
@@ -381,12 +457,17 @@ def test_golden_large_v3_r3_searches_that_end(hip, dtype):
         b_got = br.tokens[b, : int(br.n_tokens[b])].tolist()
         b_ref = g[f"beam{b}_tokens"][0, : int(g[f"beam{b}_len"][0])].tolist()
         d_cum = abs(float(br.sum_logprob[b]) - float(g[f"beam{b}_cum"][0]))
+        ref_blp = g[f"beam{b}_token_logprobs"]                   # the winner's tokens, then the EOT
+        got_blp = bl.token_logprob[b, : int(bl.n_tokens[b]) + 1]
+        assert np.isnan(bl.token_logprob[b, int(bl.n_tokens[b]) + 1:]).all()
+        assert abs(float(got_blp.sum()) - float(bl.sum_logprob[b])) < 1e-4 * max(1, len(got_blp))
+        d_blp = float(np.abs(got_blp - ref_blp).max()) if b_got == b_ref else float("inf")
         norm = g[f"beam{b}_norm"]
         out.update({f"w{b}_greedy_len": len(ref_t), f"w{b}_greedy_common": c, f"w{b}_greedy_lp_max_abs": d_lp,
-                    f"w{b}_beam_same": b_got == b_ref, f"w{b}_beam_len": len(b_ref), f"w{b}_beam_cum_abs": d_cum,
+                    f"w{b}_beam_same": b_got == b_ref, f"w{b}_beam_len": len(b_ref), f"w{b}_beam_cum_abs": d_cum, f"w{b}_beam_token_lp_max_abs": d_blp,
                     f"w{b}_beam_lens": g[f"beam{b}_len"].tolist(), f"w{b}_beam_margin": float(norm[0] - norm[1]),
                     f"w{b}_oracle_stop": str(g[f"beam{b}_stop"]), f"w{b}_oracle_refills": int(g[f"beam{b}_refills"])})
-        ok = ok and got == ref_t and d_lp < bar and b_got == b_ref and d_cum < bar * max(1, len(b_ref))
+        ok = ok and got == ref_t and d_lp < bar and b_got == b_ref and d_cum < bar * max(1, len(b_ref)) and d_blp < bar
         assert len(ref_t) < max_new and str(g[f"beam{b}_stop"]) == "patience" and int(g[f"beam{b}_refills"]) > 0
         assert len(set(g[f"beam{b}_len"].tolist())) > 1
     _diag("golden_large_v3_r3", out)

@@ -113,6 +113,9 @@ struct Tunables {
   int beam_compact = 1;     // device beam search: windows whose search has ended leave the batch at the next poll (the step's cost
                             // is proportional to the live windows: cross attention reads their K/V, the GEMMs their rows)
   int beam_poll = 4;        // decode iterations between two polls of the per-window done flags
+  int beam_token_logprobs = 0;  // beam search also carries the cumulative log-prob after every token of every hypothesis, so the
+                            // winner's per-token log-probs can be read back (wj_whisper_last_beam_token_logprobs); a diagnostic
+                            // mode: the batch is not compacted while it is on
   int beam_compact_pct = 12;  // compact when at least this share of the batch's windows ...
   int beam_compact_min = 8;   // ... and at least this many of them have finished
   int enc_blocked = 1;      // 16-bit models with d_model % 256 == 0 (read at create): the encoder's big GEMMs take BLOCKED operands
@@ -198,6 +201,10 @@ struct wj_whisper {
   float* fin_score = nullptr;     // [max_batch][kFinCap]
   int32_t* fin_len = nullptr;
   int32_t* fin_tokens = nullptr;  // [max_batch][kFinCap][tok_stride]
+  float* cum2 = nullptr;          // wj_tune beam_token_logprobs: second cumulative-score history (tok_lp is the first), allocated on first use
+  float* fin_cum = nullptr;       // ... and the finished hypotheses' [max_batch][kFinCap][tok_stride]
+  std::vector<float> last_beam_lp;   // winner's per-token log-probs of the last beam search [batch][max_new + 1], NaN padded
+  int last_beam_lp_batch = 0, last_beam_lp_stride = 0;
   // word-timestamp alignment (wj_whisper_align): scratch grown on demand, selection table [L][H]
   void* align_buf = nullptr;
   size_t align_bytes = 0;
@@ -796,6 +803,7 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "enc_blocked")) g_tune.enc_blocked = value;
   else if (!strcmp(key, "ln_vec")) wj::g_ln_vec = value;
   else if (!strcmp(key, "beam_compact")) g_tune.beam_compact = value;
+  else if (!strcmp(key, "beam_token_logprobs")) g_tune.beam_token_logprobs = value;
   else if (!strcmp(key, "beam_poll")) g_tune.beam_poll = value;
   else if (!strcmp(key, "beam_compact_pct")) g_tune.beam_compact_pct = value;
   else if (!strcmp(key, "beam_compact_min")) g_tune.beam_compact_min = value;
@@ -1230,7 +1238,17 @@ static int decode_beam_impl(int flavor, wj_whisper* m, int batch, int beam, cons
   int n_act = batch;                                  // live logical windows; logical window w = rows [w K, (w + 1) K)
   std::vector<int32_t> act_win(batch), act_slot(batch);
   for (int w = 0; w < batch; ++w) { act_win[w] = w; act_slot[w] = slots_host ? slots_host[w] : w; }
-  const bool compact_ok = g_tune.beam_compact != 0;
+  const bool want_lp = g_tune.beam_token_logprobs != 0;
+  float* cbuf[2] = {m->tok_lp, nullptr};
+  m->last_beam_lp.clear(); m->last_beam_lp_batch = 0; m->last_beam_lp_stride = 0;
+  if (want_lp) {
+    if (!m->cum2) WJ_TRY(dev_alloc(m, reinterpret_cast<void**>(&m->cum2), (size_t)m->max_rows * m->tok_stride * sizeof(float), true));
+    if (!m->fin_cum) WJ_TRY(dev_alloc(m, reinterpret_cast<void**>(&m->fin_cum), (size_t)m->max_batch * kFinCap * m->tok_stride * sizeof(float), true));
+    cbuf[1] = m->cum2;
+    WJ_HIP(hipMemsetAsync(cbuf[0], 0, (size_t)R * m->tok_stride * sizeof(float), s));
+    WJ_HIP(hipMemsetAsync(cbuf[1], 0, (size_t)R * m->tok_stride * sizeof(float), s));
+  }
+  const bool compact_ok = g_tune.beam_compact != 0 && !want_lp;
   if (compact_ok) {   // the window -> cross K/V slot and window -> result index maps become explicit
     m->use_slots = true;
     WJ_HIP(hipMemcpyAsync(m->slot_map, act_slot.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
@@ -1256,6 +1274,7 @@ static int decode_beam_impl(int flavor, wj_whisper* m, int batch, int beam, cons
     a.done = m->beam_done; a.n_done = m->beam_done + m->max_batch;
     a.fin_count = m->fin_count; a.fin_score = m->fin_score; a.fin_len = m->fin_len; a.fin_tokens = m->fin_tokens;
     a.fin_cap = kFinCap; a.flavor = flavor;
+    if (want_lp) { a.cum_in = cbuf[par]; a.cum_out = cbuf[par ^ 1]; a.fin_cum = m->fin_cum; }
     WJ_TRY(launch_beam_step(a, Ra, n_act, s));
     WJ_TRY(launch_advance_pos(m->pos, s));
     WJ_TRY(launch_rebind_rows(m->row_map[par], m->row_map[par ^ 1], m->parent, m->pos, Ra, m->kv_len, s));
@@ -1354,6 +1373,13 @@ static int decode_beam_impl(int flavor, wj_whisper* m, int batch, int beam, cons
   WJ_HIP(hipMemcpyAsync(fscore.data(), m->fin_score, sizeof(float) * fscore.size(), hipMemcpyDeviceToHost, s));
   WJ_HIP(hipMemcpyAsync(ftok.data(), m->fin_tokens, sizeof(int32_t) * ftok.size(), hipMemcpyDeviceToHost, s));
   WJ_HIP(hipMemcpyAsync(nsp.data(), m->nsp, sizeof(float) * R, hipMemcpyDeviceToHost, s));
+  std::vector<float> fcum, live_cum;
+  if (want_lp) {
+    fcum.resize(ftok.size());
+    WJ_HIP(hipMemcpyAsync(fcum.data(), m->fin_cum, sizeof(float) * fcum.size(), hipMemcpyDeviceToHost, s));
+    m->last_beam_lp.assign((size_t)batch * (max_new + 1), NAN);
+    m->last_beam_lp_batch = batch; m->last_beam_lp_stride = max_new + 1;
+  }
   // openai flavour: a window that holds fewer than `beam` finished sequences when the loop ends is topped up with its
   // live beams (BeamSearchDecoder.finalize): their histories and cumulative log-probs, in the buffers the next
   // iteration would have read
@@ -1365,17 +1391,21 @@ static int decode_beam_impl(int flavor, wj_whisper* m, int batch, int beam, cons
     live_score.resize((size_t)n_act * K);
     WJ_HIP(hipMemcpyAsync(live_hist.data(), buf[par], sizeof(int32_t) * live_hist.size(), hipMemcpyDeviceToHost, s));
     WJ_HIP(hipMemcpyAsync(live_score.data(), m->beam_score, sizeof(float) * live_score.size(), hipMemcpyDeviceToHost, s));
+    if (want_lp) {
+      live_cum.resize(live_hist.size());
+      WJ_HIP(hipMemcpyAsync(live_cum.data(), cbuf[par], sizeof(float) * live_cum.size(), hipMemcpyDeviceToHost, s));
+    }
     for (int w = 0; w < n_act; ++w) where[act_win[w]] = w;
   }
   WJ_HIP(hipStreamSynchronize(s));
   const int n_gen = m->last_steps;                 // tokens every live beam has generated
   for (int w = 0; w < batch; ++w) {
     const int n = std::min(fcount[w], kFinCap);
-    struct Hyp { double score; int len; const int32_t* tok; };
+    struct Hyp { double score; int len; const int32_t* tok; const float* cum; };
     std::vector<Hyp> hyps;
     for (int i = 0; i < n; ++i)
       hyps.push_back({(double)fscore[(size_t)w * kFinCap + i], flen[(size_t)w * kFinCap + i],
-                      &ftok[((size_t)w * kFinCap + i) * m->tok_stride]});
+                      &ftok[((size_t)w * kFinCap + i) * m->tok_stride], want_lp ? &fcum[((size_t)w * kFinCap + i) * m->tok_stride] : nullptr});
     if (flavor == 1 && n < K) {
       WJ_REQUIRE(where[w] >= 0, "decode_beam: window %d left the batch with %d < %d finished sequences", w, n, K);
       std::vector<int> order(K);
@@ -1390,7 +1420,7 @@ static int decode_beam_impl(int flavor, wj_whisper* m, int batch, int beam, cons
         bool dup = false;                           // sequences are dict keys upstream: an equal one only overwrites
         for (const Hyp& h : hyps)
           if (h.len == len && std::equal(t, t + len, h.tok)) { dup = true; break; }
-        if (!dup) hyps.push_back({(double)sc[b], len, t});
+        if (!dup) hyps.push_back({(double)sc[b], len, t, want_lp ? &live_cum[((size_t)where[w] * K + b) * m->tok_stride + P] : nullptr});
       }
     }
     WJ_REQUIRE(!hyps.empty(), "decode_beam: window %d finished no hypothesis", w);
@@ -1412,6 +1442,12 @@ static int decode_beam_impl(int flavor, wj_whisper* m, int batch, int beam, cons
     n_tokens_out[w] = len;
     sum_logprob_out[w] = (float)hyps[best].score;
     if (score_out) score_out[w] = (float)best_norm;
+    if (want_lp && hyps[best].cum) {     // differences of the cumulative history; entry len = what the end of the sequence added (EOT)
+      float* lp = &m->last_beam_lp[(size_t)w * (max_new + 1)];
+      const float* cum = hyps[best].cum;
+      for (int j = 0; j < len && j < max_new; ++j) lp[j] = cum[j] - (j ? cum[j - 1] : 0.f);
+      if (len <= max_new) lp[len] = (float)hyps[best].score - (len ? cum[len - 1] : 0.f);
+    }
     if (no_speech_prob_out) no_speech_prob_out[w] = nsp[(size_t)w * K];
   }
   return WJ_OK;
@@ -1594,6 +1630,15 @@ int wj_whisper_last_decode_info(const wj_whisper* m, int32_t out[6]) {
   out[3] = m->last_max_new;
   out[4] = m->last_compactions;
   out[5] = (int32_t)std::min<int64_t>(m->last_window_steps, INT32_MAX);
+  return WJ_OK;
+}
+
+int wj_whisper_last_beam_token_logprobs(const wj_whisper* m, int batch, int stride, float* out_host) {
+  WJ_REQUIRE(m && out_host, "wj_whisper_last_beam_token_logprobs: NULL argument");
+  WJ_REQUIRE(m->last_beam_lp_batch > 0, "wj_whisper_last_beam_token_logprobs: the last beam search did not carry them (wj_tune beam_token_logprobs 1 first)");
+  WJ_REQUIRE(batch == m->last_beam_lp_batch && stride == m->last_beam_lp_stride,
+             "wj_whisper_last_beam_token_logprobs: the last beam search had %d windows x (%d + 1) entries", m->last_beam_lp_batch, m->last_beam_lp_stride - 1);
+  memcpy(out_host, m->last_beam_lp.data(), sizeof(float) * m->last_beam_lp.size());
   return WJ_OK;
 }
 

@@ -200,6 +200,11 @@ struct BeamArgs {
   float* fin_score = nullptr;         // [B][fin_cap]
   int32_t* fin_len = nullptr;         // [B][fin_cap]
   int32_t* fin_tokens = nullptr;      // [B][fin_cap][tok_stride]
+  // optional (NULL = off): cumulative log-prob after every history position, gathered like the tokens -- the per-token
+  // log-probs of the winning hypothesis are its differences (wj_whisper_last_beam_token_logprobs)
+  const float* cum_in = nullptr;      // [R][tok_stride]
+  float* cum_out = nullptr;
+  float* fin_cum = nullptr;           // [B][fin_cap][tok_stride]: entries 0..len-1 after each generated token, entry len = the total
   int fin_cap = 0;
   int flavor = 0;                     // 0 = CTranslate2 (faster-whisper), 1 = openai-whisper BeamSearchDecoder
 };

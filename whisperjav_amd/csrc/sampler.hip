@@ -789,12 +789,24 @@ __global__ __launch_bounds__(128) void beam_merge_kernel(const BeamArgs a) {
       a.fin_len[(int64_t)ow * a.fin_cap + slot] = n;
       a.fin_score[(int64_t)ow * a.fin_cap + slot] = fin_sc[f];
     }
+    if (a.cum_in) {
+      const float* csrc = a.cum_in + (int64_t)(w * K + fin_b[f]) * a.tok_stride + a.sample_begin;
+      float* cdst = a.fin_cum + ((int64_t)ow * a.fin_cap + slot) * a.tok_stride;
+      for (int j = tid; j < ng; j += 128) cdst[j] = csrc[j];
+      if (tid == 0) { cdst[ng] = fin_sc[f]; if (fin_tok[f] >= 0) cdst[ng + 1] = fin_sc[f]; }
+    }
   }
   // ---- survivors: history gather + new token, scores, parents
   for (int k = 0; k < K; ++k) {
     const int32_t* src = a.hist_in + (int64_t)(w * K + n_parent[k]) * a.tok_stride;
     int32_t* dst = a.hist_out + (int64_t)(w * K + k) * a.tok_stride;
     for (int j = tid; j < len; j += 128) dst[j] = src[j];
+    if (a.cum_in) {
+      const float* csrc = a.cum_in + (int64_t)(w * K + n_parent[k]) * a.tok_stride;
+      float* cdst = a.cum_out + (int64_t)(w * K + k) * a.tok_stride;
+      for (int j = tid; j < len; j += 128) cdst[j] = csrc[j];
+      if (tid == 0) cdst[len] = n_score[k];
+    }
     if (tid == 0) {
       dst[len] = n_feed[k];
       a.score[w * K + k] = n_score[k];
@@ -911,11 +923,23 @@ __global__ __launch_bounds__(128) void beam_merge_ow_kernel(const BeamArgs a) {
       a.fin_len[(int64_t)ow * a.fin_cap + slot] = ng;
       a.fin_score[(int64_t)ow * a.fin_cap + slot] = fin_sc[f];
     }
+    if (a.cum_in) {
+      const float* csrc = a.cum_in + (int64_t)(w * K + fin_b[f]) * a.tok_stride + a.sample_begin;
+      float* cdst = a.fin_cum + ((int64_t)ow * a.fin_cap + slot) * a.tok_stride;
+      for (int j = tid; j < ng; j += 128) cdst[j] = csrc[j];
+      if (tid == 0) cdst[ng] = fin_sc[f];
+    }
   }
   for (int k = 0; k < K; ++k) {
     const int32_t* src = a.hist_in + (int64_t)(w * K + n_parent[k]) * a.tok_stride;
     int32_t* dst = a.hist_out + (int64_t)(w * K + k) * a.tok_stride;
     for (int j = tid; j < len; j += 128) dst[j] = src[j];
+    if (a.cum_in) {
+      const float* csrc = a.cum_in + (int64_t)(w * K + n_parent[k]) * a.tok_stride;
+      float* cdst = a.cum_out + (int64_t)(w * K + k) * a.tok_stride;
+      for (int j = tid; j < len; j += 128) cdst[j] = csrc[j];
+      if (tid == 0) cdst[len] = n_score[k];
+    }
     if (tid == 0) {
       dst[len] = n_feed[k];
       a.score[w * K + k] = n_score[k];

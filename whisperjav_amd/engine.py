@@ -102,6 +102,7 @@ class GreedyResult:
     sum_logprob: np.ndarray     # float32 [B]
     no_speech_prob: np.ndarray  # float32 [B]
     token_logprob: np.ndarray   # float32 [B, max_new]
+    beam_score: Optional[np.ndarray] = None   # beam search: the normalised score the winner was ranked by, float32 [B]
 
     def avg_logprob(self) -> np.ndarray:
         """``cum_logprob / (len + 1)`` as faster-whisper / openai-whisper report it."""
@@ -306,12 +307,15 @@ class HipWhisper:
 
     def decode_beam(self, prompts: np.ndarray, options: Optional[DecodeOptions] = None, *, beam_size: int = 5,
                     patience: float = 1.0, length_penalty: Optional[float] = 1.0, slots: Optional[Sequence[int]] = None,
-                    flavor: str = "ct2") -> GreedyResult:
+                    flavor: str = "ct2", token_logprobs: bool = False) -> GreedyResult:
         """Beam search of the resident windows, entirely on the device: ``flavor="ct2"`` CTranslate2's rules
         (faster-whisper), ``"openai"`` openai-whisper's ``BeamSearchDecoder`` + ``MaximumLikelihoodRanker`` (fidelity
         mode; ``length_penalty=None`` = rank by ``sum_logprob / length``).  Per window: best hypothesis tokens, count,
-        cumulative log-prob (``sum_logprob``), no-speech probability; ``token_logprob`` carries the normalised score in
-        column 0."""
+        cumulative log-prob (``sum_logprob``), no-speech probability, ``beam_score`` = the normalised score;
+        ``token_logprob`` carries that score in column 0 unless ``token_logprobs=True``: the search then also carries the
+        cumulative log-prob of every hypothesis (wj_tune ``beam_token_logprobs``; no batch compaction while it is on) and
+        ``token_logprob`` is [B, max_new + 1]: log p of each token of the winner, then what ending the sequence added
+        (log p(EOT), 0 at the length limit), NaN beyond -- they sum to ``sum_logprob``."""
         if flavor not in ("ct2", "openai"):
             raise ValueError("flavor must be 'ct2' or 'openai'")
         if length_penalty is None:
@@ -337,9 +341,19 @@ class HipWhisper:
                 raise ValueError("slots must name one resident window per prompt row")
             sl = as_i(sl_arr)
         fn = self._lib.wj_whisper_decode_beam if flavor == "ct2" else self._lib.wj_whisper_decode_beam_openai
-        check(fn(self.handle, B, int(beam_size), sl, as_i(prompts), P, C.byref(oc), float(patience), float(length_penalty),
-                 as_i(toks), as_i(ntok), as_f(score), as_f(slp), as_f(nsp), self.decode_stream), "wj_whisper_decode_beam")
-        return GreedyResult(toks, ntok, slp, nsp, score.reshape(B, 1))
+        if token_logprobs:
+            hipbind.tune("beam_token_logprobs", 1)
+        try:
+            check(fn(self.handle, B, int(beam_size), sl, as_i(prompts), P, C.byref(oc), float(patience), float(length_penalty),
+                     as_i(toks), as_i(ntok), as_f(score), as_f(slp), as_f(nsp), self.decode_stream), "wj_whisper_decode_beam")
+        finally:
+            if token_logprobs:
+                hipbind.tune("beam_token_logprobs", 0)
+        if token_logprobs:
+            tlp = np.empty((B, n + 1), dtype=np.float32)
+            check(self._lib.wj_whisper_last_beam_token_logprobs(self.handle, B, n + 1, as_f(tlp)), "wj_whisper_last_beam_token_logprobs")
+            return GreedyResult(toks, ntok, slp, nsp, tlp, score.copy())
+        return GreedyResult(toks, ntok, slp, nsp, score.reshape(B, 1), score.copy())
 
     def align(self, token_rows: Sequence[Sequence[int]], n_prefix: int, heads: Sequence[Tuple[int, int]],
               num_frames: Sequence[int], *, slots: Optional[Sequence[int]] = None, medfilt_width: int = 7):

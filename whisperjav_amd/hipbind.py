@@ -97,6 +97,7 @@ _SIGNATURES = {
                               C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32),
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),
     "wj_whisper_last_decode_info": (_I, [_P, C.POINTER(C.c_int32)]),
+    "wj_whisper_last_beam_token_logprobs": (_I, [_P, _I, _I, C.POINTER(C.c_float)]),
     "wj_decode_open": (_I, [_P, _I, _I, _P]),
     "wj_decode_step": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _P]),
     "wj_decode_logits_dev": (_P, [_P]),
