@@ -21,6 +21,8 @@
 namespace wj {
 int g_qwen_split_act = 2;   // wj_tune("qwen_split_act"), read at wj_qwen_create
 int g_qwen_prompt_mfma = 1;  // wj_tune("qwen_prompt_mfma"): prompts of the 16-bit types take the MFMA tile attention (0 = the one-row-per-wave kernel)
+int g_qwen_splitk = 4;       // wj_tune("qwen_splitk"): o_proj / down_proj of a 16-bit pass of 65 .. max_seqs rows are cut into this many K slices whose
+                            // raw sums the following RMSNorm adds into the residual stream (1 = the projections add themselves)
 int g_qwen_compact_pct = 15; // wj_tune("qwen_compact_pct"): re-pack the decode batch at a poll when this share of its rows has ended (0 = never)
 }
 using namespace wj;
@@ -31,9 +33,13 @@ constexpr int HD = 128;   // head_dim of every published Qwen3 size
 
 // One workgroup per row: 16-byte reads, the row stays in registers between the sum of squares and the scaling when it has
 // at most 2048 columns (every published size), LDS carries the four wave sums.
+// Fused split-K consumer (wj_tune "qwen_splitk"): when `slab` is given, the projection that precedes this norm (o_proj / down_proj) left
+// `ks` raw fp32 K-slices [ks][M][D] instead of adding into the residual stream; the row is first completed, x += sum_s slab[s] in
+// slice order (deterministic), written back, and then normalised.  out == NULL: only the completion (after the last layer).
 template <typename T>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w, T* __restrict__ out,
-                                                      int M, int D, float eps, int split = 0) {
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, const float* __restrict__ w, T* __restrict__ out,
+                                                      int M, int D, float eps, int split = 0, const float* __restrict__ slab = nullptr,
+                                                      int ks = 0) {
   __shared__ float part[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const float* xr = x + (int64_t)row * D;
@@ -41,10 +47,18 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   float ss = 0.f;
   int it = 0;
   for (int c = tid * 4; c < D; c += 1024, ++it) {
-    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    float4 v = *reinterpret_cast<const float4*>(xr + c);
+    if (slab) {
+      for (int sI = 0; sI < ks; ++sI) {
+        const float4 p = *reinterpret_cast<const float4*>(slab + ((int64_t)sI * M + row) * D + c);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      }
+      *reinterpret_cast<float4*>(const_cast<float*>(xr) + c) = v;      // read back below when the row has more than 2048 columns: same thread, same address
+    }
     if (it < 2) keep[it] = v;
     ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
+  if (!out) return;
   ss = wave_sum(ss);
   if ((tid & 63) == 0) part[tid >> 6] = ss;
   __syncthreads();
@@ -559,6 +573,8 @@ struct wj_qwen {
   uint8_t* a8s = nullptr;
   int last_used_graph = 0;   // the last generation replayed its iteration from a hipGraph
   int32_t *cmp_src = nullptr, *cmp_seq = nullptr, *cmp_pos = nullptr, *cmp_tok = nullptr;   // batch compaction scratch [max_seqs]
+  float* slab = nullptr;      // f32 [g_qwen_splitk at create][max_seqs][hidden]: split-K slices of o_proj / down_proj (decode batches)
+  int slab_ks = 0;
   int4* pwork = nullptr;      // prompt attention work items (sequence slot, first query, first row, length), see prompt_attn_kernel
   int pwork_cap = 0, pwork_n = 0;   // pwork_n > 0 only while a prompt pass (prefill / classify) runs its layers
   std::vector<int32_t> pwork_host;
@@ -613,16 +629,33 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
   const int D = d.hidden, H = d.n_head, KV = d.n_kv_head, F = d.ffn, dt = m->dtype;
   const int W = (H + 2 * KV) * HD;
   const int64_t layer_kv = (int64_t)m->max_seqs * KV * m->max_ctx * HD;
+  const bool use_sk = m->slab_ks > 1 && g_qwen_splitk > 1 && dt != WJ_F32 && !m->mx8 && M > 64 && M <= m->max_seqs;
+  int pending = 0;       // K slices of a projection waiting in m->slab for the next norm
   for (int l = 0; l < d.n_layer; ++l) {
     const int b0 = m->layer_base(l);
     void* kc = m->at(m->kc, l * layer_kv);
     void* vc = m->at(m->vc, l * layer_kv);
     const int sp_in = (split && m->split_mode >= 3) ? 1 : 0;      // the projections' INPUT (h) as [hi | lo] too
-    auto rms = [&](const float* w, void* out) -> int {
-      if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(M), dim3(256), 0, s, m->x, w, TP(float, out), M, D, d.rms_eps, 0);
-      else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(M), dim3(256), 0, s, m->x, w, TP(f16_t, out), M, D, d.rms_eps, sp_in);
-      else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(M), dim3(256), 0, s, m->x, w, TP(bf16_t, out), M, D, d.rms_eps, sp_in);
+    auto rms = [&](const float* w, void* out) -> int {      // completes the residual stream from pending split-K slices first
+      const float* sl = pending ? m->slab : nullptr;
+      if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(M), dim3(256), 0, s, m->x, w, TP(float, out), M, D, d.rms_eps, 0, sl, pending);
+      else if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(M), dim3(256), 0, s, m->x, w, TP(f16_t, out), M, D, d.rms_eps, sp_in, sl, pending);
+      else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(M), dim3(256), 0, s, m->x, w, TP(bf16_t, out), M, D, d.rms_eps, sp_in, sl, pending);
       WJ_LAUNCH_CHECK();
+      pending = 0;
+      return WJ_OK;
+    };
+    // o_proj / down_proj: into the residual stream, or as K slices for the next norm to add (decode batches of the 16-bit types)
+    auto resid_gemm = [&](GemmArgs& g, int variant) -> int {
+      int ks = 1;
+      if (use_sk) {
+        const int keff = g.split ? 2 * g.K : g.K;
+        for (ks = m->slab_ks; ks > 1 && (keff % (64 * ks)); ks >>= 1) {}
+      }
+      if (ks <= 1) return launch_gemm(dt, EPI_RESID_F32, g, s, variant);
+      g.out = m->slab; g.ldc = D; g.ksplit = ks;
+      WJ_TRYQ(launch_gemm(dt, EPI_PARTIAL_F32, g, s, variant));
+      pending = ks;
       return WJ_OK;
     };
     WJ_TRYQ(rms(m->F(b0 + WJ_QL_LN1_W), m->h));
@@ -672,7 +705,7 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
       g.A = m->attn; g.lda = (split ? 2 : 1) * H * HD; g.split = split ? 1 : 0;
       g.W = m->W(b0 + WJ_QL_O_W); g.ldw = H * HD; g.M = M; g.N = D; g.K = H * HD; g.out = m->x; g.ldc = D;
       WJ_TRYQ(mx(g, l, 1));
-      WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, gemm_variant(QG_O, M, H * HD, dt)));
+      WJ_TRYQ(resid_gemm(g, gemm_variant(QG_O, M, H * HD, dt)));
     }
     WJ_TRYQ(rms(m->F(b0 + WJ_QL_LN2_W), m->h));
     {
@@ -696,8 +729,13 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
       g.A = m->act; g.lda = (split ? 2 : 1) * F; g.split = split ? 1 : 0;
       g.W = m->W(b0 + WJ_QL_DOWN_W); g.ldw = F; g.M = M; g.N = D; g.K = F; g.out = m->x; g.ldc = D;
       WJ_TRYQ(mx(g, l, 3));
-      WJ_TRYQ(launch_gemm(dt, EPI_RESID_F32, g, s, gemm_variant(QG_DOWN, M, F, dt)));
+      WJ_TRYQ(resid_gemm(g, gemm_variant(QG_DOWN, M, F, dt)));
     }
+  }
+  if (pending) {      // the last down_proj: complete the residual stream without a norm
+    if (dt == WJ_F16) hipLaunchKernelGGL((rmsnorm_kernel<f16_t>), dim3(M), dim3(256), 0, s, m->x, (const float*)nullptr, (f16_t*)nullptr, M, D, d.rms_eps, 0, m->slab, pending);
+    else hipLaunchKernelGGL((rmsnorm_kernel<bf16_t>), dim3(M), dim3(256), 0, s, m->x, (const float*)nullptr, (bf16_t*)nullptr, M, D, d.rms_eps, 0, m->slab, pending);
+    WJ_LAUNCH_CHECK();
   }
   return WJ_OK;
 }
@@ -813,6 +851,8 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   m->seen_cap = 2 * max_ctx;      // unique prompt ids (< max_ctx) + generated ids (positions stop at max_ctx)
   QA(lim, S * 4); QA(seen_n, S * 4); QA(seen, S * (size_t)m->seen_cap * 4);
   QA(cmp_src, S * 4); QA(cmp_seq, S * 4); QA(cmp_pos, S * 4); QA(cmp_tok, S * 4);
+  m->slab_ks = dtype != WJ_F32 && !m->mx8 ? std::max(1, std::min(8, g_qwen_splitk)) : 1;
+  if (m->slab_ks > 1) QA(slab, (int64_t)m->slab_ks * S * D * 4);
   m->pwork_cap = m->max_rows / 128 + (int)S + 1;
   QA(pwork, (int64_t)m->pwork_cap * 16);
   if (f8w) {
