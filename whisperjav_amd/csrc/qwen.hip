@@ -79,13 +79,26 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, const floa
 // One wave per (row, head slot): slots 0..H-1 = query heads, H..H+KV-1 = key heads, H+KV.. = value heads of the fused
 // projection.  q / k: RMSNorm over the 128 dims, then RoPE in the rotate-half convention (lane i owns dims i and i + 64,
 // the two halves of one rotation pair); k and v go to the caches at (sequence, position).
+// rope_tab [position][lane] = (cos, sin) of position * theta^(-2 lane / 128), built once per model by rope_table_kernel with
+// the expressions this kernel used to evaluate per (row, head slot) -- same values, one 8-byte load instead of exp2f + sincosf.
+// Four head slots per workgroup (one per wave): a quarter of the workgroups of the one-wave form.
+__global__ __launch_bounds__(64) void rope_table_kernel(float2* __restrict__ tab, int n_pos, float log2_theta) {
+  const int pos = blockIdx.x, lane = threadIdx.x;
+  if (pos >= n_pos) return;
+  const float inv_freq = exp2f(-(float)(2 * lane) / (float)HD * log2_theta);
+  float sn, cs;
+  sincosf((float)pos * inv_freq, &sn, &cs);
+  tab[(int64_t)pos * 64 + lane] = float2{cs, sn};
+}
+
 template <typename T>
-__global__ __launch_bounds__(64) void qk_norm_rope_kernel(const T* __restrict__ qkv, const float* __restrict__ q_w,
-                                                          const float* __restrict__ k_w, const int32_t* __restrict__ row_seq,
-                                                          const int32_t* __restrict__ row_pos, T* __restrict__ q_out,
-                                                          T* __restrict__ kc, T* __restrict__ vc, int H, int KV, int ctx,
-                                                          float log2_theta, float eps, int split_in) {
-  const int m = blockIdx.x, slot = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const T* __restrict__ qkv, const float* __restrict__ q_w,
+                                                           const float* __restrict__ k_w, const int32_t* __restrict__ row_seq,
+                                                           const int32_t* __restrict__ row_pos, T* __restrict__ q_out,
+                                                           T* __restrict__ kc, T* __restrict__ vc, int H, int KV, int ctx,
+                                                           const float2* __restrict__ rope_tab, float eps, int split_in) {
+  const int m = blockIdx.x, slot = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slot >= H + 2 * KV) return;
   const int W = (H + 2 * KV) * HD;
   const T* src = qkv + (int64_t)m * W * (split_in ? 2 : 1) + (int64_t)slot * HD;
   float a = Elem<T>::ld(src + lane), b = Elem<T>::ld(src + lane + 64);
@@ -102,9 +115,8 @@ __global__ __launch_bounds__(64) void qk_norm_rope_kernel(const T* __restrict__ 
   const float* w = slot < H ? q_w : k_w;
   const float r = rsqrtf(wave_sum(a * a + b * b) / (float)HD + eps);
   a = w[lane] * (a * r); b = w[lane + 64] * (b * r);
-  const float inv_freq = exp2f(-(float)(2 * lane) / (float)HD * log2_theta);
-  float sn, cs;
-  sincosf((float)pos * inv_freq, &sn, &cs);
+  const float2 t2 = rope_tab[(int64_t)pos * 64 + lane];
+  const float cs = t2.x, sn = t2.y;
   const float ra = a * cs - b * sn, rb = b * cs + a * sn;
   T* dst = slot < H ? q_out + ((int64_t)m * H + slot) * HD : kc + (((int64_t)b_seq * KV + (slot - H)) * ctx + pos) * HD;
   Elem<T>::st(dst + lane, ra); Elem<T>::st(dst + lane + 64, rb);
@@ -573,6 +585,7 @@ struct wj_qwen {
   uint8_t* a8s = nullptr;
   int last_used_graph = 0;   // the last generation replayed its iteration from a hipGraph
   int32_t *cmp_src = nullptr, *cmp_seq = nullptr, *cmp_pos = nullptr, *cmp_tok = nullptr;   // batch compaction scratch [max_seqs]
+  float2* rope_tab = nullptr; // [max_ctx + 1][64] (cos, sin) of the rotary embedding, see qk_norm_rope_kernel
   float* slab = nullptr;      // f32 [g_qwen_splitk at create][max_seqs][hidden]: split-K slices of o_proj / down_proj (decode batches)
   int slab_ks = 0;
   int4* pwork = nullptr;      // prompt attention work items (sequence slot, first query, first row, length), see prompt_attn_kernel
@@ -667,16 +680,16 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
       WJ_TRYQ(mx(g, l, 0));
       WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, gemm_variant(QG_QKV, M, D, dt)));
     }
-    const float l2t = log2f(d.rope_theta);
+    const dim3 rgrid(M, (H + 2 * KV + 3) / 4);
     if (dt == WJ_F32)
-      hipLaunchKernelGGL((qk_norm_rope_kernel<float>), dim3(M, H + 2 * KV), dim3(64), 0, s, TP(const float, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
-                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(float, m->q), TP(float, kc), TP(float, vc), H, KV, m->max_ctx, l2t, d.rms_eps, split ? 1 : 0);
+      hipLaunchKernelGGL((qk_norm_rope_kernel<float>), rgrid, dim3(256), 0, s, TP(const float, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
+                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(float, m->q), TP(float, kc), TP(float, vc), H, KV, m->max_ctx, m->rope_tab, d.rms_eps, split ? 1 : 0);
     else if (dt == WJ_F16)
-      hipLaunchKernelGGL((qk_norm_rope_kernel<f16_t>), dim3(M, H + 2 * KV), dim3(64), 0, s, TP(const f16_t, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
-                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(f16_t, m->q), TP(f16_t, kc), TP(f16_t, vc), H, KV, m->max_ctx, l2t, d.rms_eps, split ? 1 : 0);
+      hipLaunchKernelGGL((qk_norm_rope_kernel<f16_t>), rgrid, dim3(256), 0, s, TP(const f16_t, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
+                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(f16_t, m->q), TP(f16_t, kc), TP(f16_t, vc), H, KV, m->max_ctx, m->rope_tab, d.rms_eps, split ? 1 : 0);
     else
-      hipLaunchKernelGGL((qk_norm_rope_kernel<bf16_t>), dim3(M, H + 2 * KV), dim3(64), 0, s, TP(const bf16_t, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
-                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(bf16_t, m->q), TP(bf16_t, kc), TP(bf16_t, vc), H, KV, m->max_ctx, l2t, d.rms_eps, split ? 1 : 0);
+      hipLaunchKernelGGL((qk_norm_rope_kernel<bf16_t>), rgrid, dim3(256), 0, s, TP(const bf16_t, m->qkv), m->F(b0 + WJ_QL_QNORM_W),
+                         m->F(b0 + WJ_QL_KNORM_W), m->row_seq, m->row_pos, TP(bf16_t, m->q), TP(bf16_t, kc), TP(bf16_t, vc), H, KV, m->max_ctx, m->rope_tab, d.rms_eps, split ? 1 : 0);
     WJ_LAUNCH_CHECK();
 #define WJ_GQA(T_, G_) hipLaunchKernelGGL((gqa_attn_kernel<T_, G_>), dim3(M, KV), dim3(64), 0, s, TP(const T_, m->q), TP(const T_, kc), \
                                           TP(const T_, vc), m->row_seq, m->row_pos, TP(T_, m->attn), H, KV, m->max_ctx, split ? 1 : 0)
@@ -754,7 +767,9 @@ int run_head(wj_qwen* m, const float* xin, int n, hipStream_t s) {
   // >= 1024 rows: N a multiple of 256 admits the 256-tile kernel (the surplus columns are dot products with zero rows; top-1 below
   // reads the first d.vocab columns only)
   g.A = m->h; g.lda = (sp ? 2 : 1) * D; g.W = m->W(WJ_Q_EMBED); g.ldw = D; g.M = n; g.N = n >= 1024 ? m->vocab_pad : d.vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
-  WJ_TRYQ(launch_gemm(dt, EPI_F32, g, s, 0));
+  // 65 .. 1023 rows: the 128-tile kernel.  The dispatcher's own choice up to 512 rows is the skinny kernel, which re-reads the
+  // activations for every 16 of the 151 936 columns (2.9 ms per call in the cfg5 trace against 1.2 ms for 1024+ rows)
+  WJ_TRYQ(launch_gemm(dt, EPI_F32, g, s, (n > 64 && n < 1024 && dt != WJ_F32 && (D % 64) == 0) ? 3 : 0));
   if (m->cur_penalty != 1.f) {
     hipLaunchKernelGGL(rep_penalty_kernel, dim3(n), dim3(256), 0, s, m->logits, m->ldl, m->seen, m->seen_n, m->seen_cap, m->cur_penalty, m->finished, m->row_seq);
     WJ_LAUNCH_CHECK();
@@ -853,6 +868,7 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   QA(cmp_src, S * 4); QA(cmp_seq, S * 4); QA(cmp_pos, S * 4); QA(cmp_tok, S * 4);
   m->slab_ks = dtype != WJ_F32 && !m->mx8 ? std::max(1, std::min(8, g_qwen_splitk)) : 1;
   if (m->slab_ks > 1) QA(slab, (int64_t)m->slab_ks * S * D * 4);
+  QA(rope_tab, (int64_t)(max_ctx + 1) * 64 * 8);
   m->pwork_cap = m->max_rows / 128 + (int)S + 1;
   QA(pwork, (int64_t)m->pwork_cap * 16);
   if (f8w) {
@@ -873,6 +889,10 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
                                  m->w8 + m->w8_off[l * 4 + k], m->w8s + m->w8s_off[l * 4 + k], ctx->stream);
   }
 #undef QA
+  if (!rc) {
+    hipLaunchKernelGGL(rope_table_kernel, dim3(max_ctx + 1), dim3(64), 0, ctx->stream, m->rope_tab, max_ctx + 1, log2f(d.rope_theta));
+    if (hipGetLastError() != hipSuccess) { set_error("wj_qwen_create: rope table launch failed"); rc = WJ_E_HIP; }
+  }
   if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) { set_error("wj_qwen_create: allocation failed"); rc = WJ_E_HIP; }
   if (rc) { wj_qwen_free(m); return rc; }
   *out = m;

@@ -55,6 +55,20 @@ __global__ __launch_bounds__(256) void im2col_cl_kernel(const T* __restrict__ in
   const int c = (int)(r / (Fo * To)), rem = (int)(r - (int64_t)c * Fo * To);
   const int f = t_major ? rem % Fo : rem / To, t = t_major ? rem / Fo : rem % To;
   T* o = out + r * 9 * C;
+  constexpr int V = 16 / (int)sizeof(T);
+  if (C % V == 0) {        // 16-byte copies (C = 480 in the published tower: 60 per tap); rows and taps start 16-byte aligned
+    const int cv = C / V;
+    uint4* ov = reinterpret_cast<uint4*>(o);
+    for (int i = threadIdx.x; i < 9 * cv; i += 256) {
+      const int tap = i / cv, j = i - tap * cv;
+      const int fi = 2 * f - 1 + tap / 3, ti = 2 * t - 1 + tap % 3;
+      const bool ok = fi >= 0 && fi < Fi && ti >= 0 && ti < Ti;
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (ok) v = reinterpret_cast<const uint4*>(in + (((int64_t)c * Fi + fi) * Ti + ti) * C)[j];
+      ov[i] = v;
+    }
+    return;
+  }
   for (int tap = 0; tap < 9; ++tap) {
     const int fi = 2 * f - 1 + tap / 3, ti = 2 * t - 1 + tap % 3;
     const bool ok = fi >= 0 && fi < Fi && ti >= 0 && ti < Ti;
