@@ -249,3 +249,45 @@ def test_greedy_oracle_ends_with_eot(setup_eot):
         assert abs(float(res.sum_logprob[r]) - sum(res.token_logprob[r])) < 1e-4
         one = decoding.greedy_decode(oracle, xa[r:r + 1], prompt, 40, decoding.FilterConfig(max_initial_timestamp_index=0))
         assert one.tokens[0] == res.tokens[r]                             # a ragged batch == per-window decodes
+
+
+@pytest.mark.parametrize("beam,patience,rep,ngram,max_new", [(5, 1.2, 1.5, 3, 40), (5, 1.2, 1.5, 3, 15), (3, 1.0, 1.0, 0, 40)])
+def test_oracle_beam_token_logprobs_equal_teacher_forced_rescoring(setup_eot, beam, patience, rep, ngram, max_new):
+    """``trace["token_logprobs"]`` of the oracle's CTranslate2 search (what ``wj_whisper_last_beam_token_logprobs`` is held to
+    on the GPU) is bookkeeping over parents, refills and the length stop.  Pinned here without that bookkeeping: every
+    hypothesis is fed back through the decoder token by token, the same processors and rules are applied to the logits of each
+    position, and the log-softmax entry of the token actually taken (then of EOT when the hypothesis ended on one) must be the
+    recorded value; the values sum to the hypothesis's cumulative score."""
+    d, oracle, xa = setup_eot
+    lay = decoding.TokenLayout.for_vocab(d.n_vocab)
+    toks = pdims.special_tokens(d.n_vocab)
+    prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    fcfg = decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=0)
+    bcfg = decoding.BeamConfig(beam, patience, 1.0, rep, ngram, max_new)
+    seen_len_stop = seen_eot = 0
+    for w in range(xa.shape[0]):
+        tr = {}
+        hyps, _ = decoding.beam_search(oracle, xa[w:w + 1], prompt, bcfg, fcfg, trace=tr)
+        assert len(tr["token_logprobs"]) == len(hyps)
+        for (seq, _, cum), lps in zip(hyps[:3], tr["token_logprobs"][:3]):
+            assert len(lps) == len(seq) + 1 and abs(sum(lps) - cum) < 1e-4
+            ended_on_eot = len(seq) < max_new
+            with torch.no_grad():
+                dec = decoding.CachedDecoder(oracle, xa[w:w + 1].contiguous())
+                for p in prompt[:-1]:
+                    dec.step(torch.tensor([[p]]))
+                feed, want = prompt[-1], []
+                for i, t in enumerate(list(seq) + ([lay.eot] if ended_on_eot else [])):
+                    logits = dec.step(torch.tensor([[feed]]))
+                    logits = decoding._apply_ct2_processors(logits, [[prompt[-1]] + list(seq[:i])], bcfg)
+                    logits = decoding.filter_logits(logits, [list(prompt) + list(seq[:i])], len(prompt), lay, fcfg)
+                    want.append(float(torch.log_softmax(logits, dim=-1)[0, t]))
+                    feed = t
+            if ended_on_eot:
+                seen_eot += 1
+            else:
+                seen_len_stop += 1
+                want.append(0.0)                        # the length limit ends the hypothesis: nothing was scored for it
+            assert np.allclose(lps, want, atol=2e-4), (w, seq, lps, want)
+    assert seen_eot and (seen_len_stop or max_new == 40)
