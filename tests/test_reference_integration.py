@@ -458,3 +458,100 @@ def test_reference_orchestrator_steps_run_pooled_over_the_hip_adapters(ref_modul
     assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
     assert all(len(t) == 1 and t[0].startswith("t1") for t in out[True][0])
     assert [len(w[0]) for w in out[True][1]] == [3, 3, 3] and out[True][1][0][0][0]["word"].endswith("、")       # punctuation merged back
+
+
+def test_reference_stable_ts_module_drives_the_hip_stable_shim(ref_modules, monkeypatch, tmp_path):
+    """BASELINE cfg1 plumbing: the reference's ``StableTSASR`` (modules/stable_ts_asr.py, turbo mode = the
+    ``faster`` / ``fast`` pipelines) imported from source, with ONE symbol swapped -- ``stable_whisper.load_faster_whisper`` ->
+    ``whisperjav_amd.stable_shim.load_faster_whisper`` -- and its ``balanced`` preset as the legacy resolver packs it
+    (config/components/asr/stable_ts.py:374-436, config/legacy.py:289-328).  The shim (over an engine double here) must accept
+    every keyword ``_prepare_transcribe_parameters`` sends (stable_ts_asr.py:363-420), its result must flow through
+    ``transcribe`` / ``_postprocess`` / ``_save_to_srt`` (:477-509, :623-655) and ``transcribe_to_srt`` must write the SRT and
+    the diagnostic JSON (:570-595).  Both result flavours: the built-in one (stable-ts absent) and a ``WhisperResult`` class
+    supplied by the ``stable_whisper`` module (stable-ts present: regrouping and silence suppression are ITS methods)."""
+    import json
+    import numpy as np
+    import torch
+    from tests import test_asr_adapter as doubles
+    from whisperjav_amd import dims as pdims, stable_shim
+    tb = pdims.special_tokens(51865).timestamp_begin
+    engine = doubles._model([[tb, 11, 12, tb + 100, tb + 100, 13, tb + 150]])
+    engine.model.align = lambda rows, n_prefix, heads, num_frames, slots=None, medfilt_width=7: [
+        (np.repeat(np.arange(len(r) - 4), 10), np.arange(10 * (len(r) - 4)), np.full(len(r) - 5, 0.8, np.float32)) for r in rows]
+    engine.dims = pdims.custom_dims(80, 128, 2, 2, 51865)
+    # the preset searches with beam 2: the scripted engine answers the device beam call with its script
+    beams = []
+    engine.device_beam = True
+    engine.model.decode_beam = lambda prompts, options, beam_size=5, patience=1.0, length_penalty=1.0, **kw: (
+        beams.append((beam_size, patience, length_penalty)), engine.model.decode_greedy(prompts, options))[1]
+    seen, loads = [], []
+    real = engine.transcribe
+
+    def spy(audio, **params):
+        seen.append(params)
+        return real(audio, **params)
+    engine.transcribe = spy
+
+    def load_faster_whisper(name, **kw):
+        loads.append((name, kw))
+        return stable_shim.HipStableWhisperModel(name, model=engine, **kw)
+    sw = types.ModuleType("stable_whisper")
+    sw.WhisperResult = object                     # "stable-ts absent" for the shim; only annotations use it in the module
+    sw.load_faster_whisper = load_faster_whisper
+    sf = types.ModuleType("soundfile")
+    audio = (np.sin(np.arange(16000 * 9) * 0.05) * 0.2).astype(np.float32)
+    sf.read = lambda path, dtype="float32", always_2d=False, **kw: (audio.copy(), 16000)
+    for name, mod in (("stable_whisper", sw), ("soundfile", sf), ("librosa", types.ModuleType("librosa"))):
+        monkeypatch.setitem(sys.modules, name, mod)
+    monkeypatch.setattr(torch.hub, "load", lambda *a, **kw: None)          # _precache_silero_vad: no network here
+    ref = importlib.import_module("whisperjav.modules.stable_ts_asr")
+    monkeypatch.setattr(ref, "snapshot_download", None)                    # _prefetch_faster_whisper_weights returns early
+    decoder = dict(task="transcribe", language="ja", beam_size=2, best_of=1, patience=2.0, suppress_blank=True, without_timestamps=False)
+    provider = dict(temperature=[0.0, 0.1], compression_ratio_threshold=2.4, logprob_threshold=-1.2, logprob_margin=0.2,
+                    no_speech_threshold=0.5, drop_nonverbal_vocals=False, condition_on_previous_text=False, word_timestamps=True,
+                    suppress_ts_tokens=False, gap_padding=" ...", only_ffmpeg=False, max_instant_words=0.5, ignore_compatibility=True,
+                    nonspeech_error=0.1, only_voice_freq=False, regroup=True, ts_num=0, suppress_silence=True, suppress_word_ts=True,
+                    suppress_attention=False, use_word_position=True, q_levels=20, k_size=5, demucs=False, vad=True, vad_threshold=0.25,
+                    vad_repo="snakers4/silero-vad")
+    asr = ref.StableTSASR({"model_name": "large-v2", "device": "cuda", "compute_type": "int8"},
+                          {"decoder": decoder, "provider": provider}, "transcribe", turbo_mode=True)
+    assert loads == [("large-v2", {"device": "cuda", "compute_type": "int8"})]
+    out = asr.transcribe_to_srt(tmp_path / "scene_0001.wav", tmp_path / "out" / "scene_0001.srt")
+    # what reached the HIP model: faster-whisper keywords only, word timings forced, stable-ts's own keywords consumed
+    assert len(seen) == 1
+    p = seen[0]
+    assert p["word_timestamps"] is True and p["vad_filter"] is False and p["beam_size"] == 2 and p["patience"] == 2.0
+    assert p["temperature"] == (0.0, 0.1) and p["language"] == "ja" and p["task"] == "transcribe"
+    assert not ({"vad", "vad_threshold", "regroup", "batch_size", "verbose", "logprob_margin", "q_levels"} & set(p))
+    assert beams and beams[0] == (2, 2.0, 1.0)             # beam 2, patience 2.0, CTranslate2's default length penalty
+    text = out.read_text(encoding="utf-8")
+    assert out == tmp_path / "out" / "scene_0001.srt"
+    # segment edges come from the word timings (faster-whisper moves them there when word_timestamps is on)
+    assert text == "1\n00:00:00,000 --> 00:00:00,400\n<11><12>\n\n2\n00:00:00,400 --> 00:00:00,600\n<13>\n", text
+    dumped = json.loads((tmp_path / "out" / "scene_0001.transcribe.json").read_text(encoding="utf-8"))
+    assert [s["text"] for s in dumped["segments"]] == ["<11><12>", "<13>"] and dumped["language"] == "ja"
+    assert all(len(s["words"]) >= 1 for s in dumped["segments"])
+    # a keyword neither faster-whisper nor stable-ts knows must surface as TypeError: the reference's retry keys on it (:517-548)
+    with pytest.raises(TypeError):
+        asr.model.transcribe(audio, not_an_option=1)
+
+    # ---- stable-ts present: the result is ITS WhisperResult, silence suppression and regrouping are ITS methods -----------
+    calls = []
+
+    class WhisperResult:
+        def __init__(self, result):
+            calls.append(("init", [s["text"] for s in result["segments"]], result["language"]))
+            self.segments = [types.SimpleNamespace(**s) for s in result["segments"]]
+
+        def adjust_by_silence(self, samples, vad=False, vad_threshold=0.35, **kw):
+            calls.append(("silence", len(samples), vad, vad_threshold))
+
+        def regroup(self, algo=True):
+            calls.append(("regroup", algo))
+            return self
+    sw.WhisperResult = WhisperResult
+    res = asr.model.transcribe(audio, task="transcribe", language="ja", temperature=(0.0,), beam_size=2, vad=True, vad_threshold=0.25,
+                               regroup=True, batch_size=8)
+    assert isinstance(res, WhisperResult)
+    assert calls == [("init", ["<11><12>", "<13>"], "ja"), ("silence", len(audio), True, 0.25), ("regroup", True)]
+    asr.cleanup()
