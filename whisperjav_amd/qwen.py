@@ -310,6 +310,104 @@ def pack_audio_blob(d: Qwen3AudioDims, w: Dict[str, np.ndarray], dtype: str) -> 
     return _pack(audio_engine_tensors(d, w), dtype)
 
 
+# ---- checkpoints ---------------------------------------------------------------------------------------------------------
+def dims_from_config(cfg: Dict[str, Any]) -> Tuple[Qwen3Dims, Qwen3AudioDims]:
+    """Engine geometry from a Hugging Face ``config.json`` of the ``qwen3_asr`` family: ``audio_config`` / ``text_config`` at the
+    top level (transformers' own port of the model) or nested under ``thinker_config`` (the layout of the omni-style
+    repositories the un-vendored ``qwen_asr`` package reads, modules/qwen_asr.py:545-608).  Only fields the device path
+    consumes are read; an architecture it does not implement (head_dim != 128, biases in the decoder's attention, untied
+    output embedding) is refused here rather than mis-run."""
+    top = cfg.get("thinker_config", cfg)
+    if "text_config" not in top or "audio_config" not in top:
+        raise ValueError("config.json: no text_config / audio_config (is this a qwen3_asr checkpoint?)")
+    t, a = top["text_config"], top["audio_config"]
+    rope = t.get("rope_theta")
+    if rope is None:
+        rope = (t.get("rope_parameters") or t.get("rope_scaling") or {}).get("rope_theta", 1000000.0)
+    head_dim = int(t.get("head_dim") or t["hidden_size"] // t["num_attention_heads"])
+    if head_dim != 128:
+        raise ValueError(f"head_dim {head_dim}: the device decoder is written for 128 (every published Qwen3 size)")
+    if t.get("attention_bias"):
+        raise ValueError("attention_bias=True: the device decoder has no q/k/v/o biases (no published Qwen3-ASR size has them)")
+    if not (t.get("tie_word_embeddings", True) and top.get("tie_word_embeddings", cfg.get("tie_word_embeddings", True))):
+        raise ValueError("untied output embedding: the device LM head is the embedding matrix (tie_word_embeddings)")
+    eos = top.get("eos_token_id", cfg.get("eos_token_id", t.get("eos_token_id")))
+    if eos is None:
+        eos = Qwen3Dims.eos_token_ids
+    eos = tuple(int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos]))
+    d = Qwen3Dims(hidden=int(t["hidden_size"]), n_layer=int(t["num_hidden_layers"]), n_head=int(t["num_attention_heads"]),
+                  n_kv_head=int(t.get("num_key_value_heads") or t["num_attention_heads"]), head_dim=head_dim,
+                  ffn=int(t["intermediate_size"]), vocab=int(t["vocab_size"]), rope_theta=float(rope),
+                  rms_eps=float(t.get("rms_norm_eps", 1e-6)),
+                  audio_token_id=int(top.get("audio_token_id", cfg.get("audio_token_id", Qwen3Dims.audio_token_id))), eos_token_ids=eos)
+    ad = Qwen3AudioDims(n_mels=int(a.get("num_mel_bins", 128)), n_layer=int(a["encoder_layers"]), n_head=int(a["encoder_attention_heads"]),
+                        ffn=int(a["encoder_ffn_dim"]), d_model=int(a["d_model"]), n_window=int(a.get("n_window", 50)),
+                        n_window_infer=int(a.get("n_window_infer", 800)), conv_hidden=int(a.get("downsample_hidden_size", 480)),
+                        out_dim=int(a.get("output_dim", t["hidden_size"])))
+    if ad.out_dim != d.hidden:
+        raise ValueError(f"audio output_dim {ad.out_dim} != decoder hidden_size {d.hidden}")
+    return d, ad
+
+
+def load_checkpoint(path: Union[str, Path], *, want: Sequence[str] = ("model.language_model.", "model.audio_tower.", "model.multi_modal_projector.", "score.")
+                    ) -> Tuple[Qwen3Dims, Qwen3AudioDims, Dict[str, np.ndarray]]:
+    """A local Hugging Face directory (``config.json`` + ``model.safetensors`` or the shards named by
+    ``model.safetensors.index.json``) -> engine geometry and one fp32 state dict under the names ``engine_tensors`` /
+    ``audio_engine_tensors`` / the forced aligner read (``model.language_model.*``, ``model.audio_tower.*``,
+    ``model.multi_modal_projector.*``, ``score.*``).  A leading ``thinker.`` is stripped; a tied ``lm_head.weight`` is dropped;
+    16-bit tensors are widened exactly.  What the reference does here is ``Qwen3ASRModel.from_pretrained`` inside the
+    un-vendored ``qwen_asr`` package (modules/qwen_asr.py:581-608): the layout accepted is the one transformers' own port of the
+    family writes -- the tests round-trip it through ``save_pretrained`` -- not a file of the published repository, which this
+    container cannot fetch.  Every tensor the engine needs is checked for presence and shape before anything is returned."""
+    import json
+    path = Path(path)
+    cfg = json.loads((path / "config.json").read_text(encoding="utf-8"))
+    d, ad = dims_from_config(cfg)
+    index = path / "model.safetensors.index.json"
+    if index.exists():
+        files = sorted(set(json.loads(index.read_text(encoding="utf-8"))["weight_map"].values()))
+    else:
+        files = ["model.safetensors"]
+    from safetensors import safe_open
+    w: Dict[str, np.ndarray] = {}
+    for f in files:
+        with safe_open(str(path / f), framework="pt", device="cpu") as sf:
+            for name in sf.keys():
+                key = name[len("thinker."):] if name.startswith("thinker.") else name
+                if key == "lm_head.weight" or not key.startswith(tuple(want)):
+                    continue
+                w[key] = sf.get_tensor(name).to(torch.float32).numpy()
+    # presence and shape of everything the packers will read (a KeyError deep inside np.concatenate helps nobody)
+    p, H, KV, hd = "model.language_model.", d.n_head, d.n_kv_head, d.head_dim
+    need = {p + "embed_tokens.weight": (d.vocab, d.hidden), p + "norm.weight": (d.hidden,)}
+    for l in range(d.n_layer):
+        q = f"{p}layers.{l}."
+        need.update({q + "input_layernorm.weight": (d.hidden,), q + "post_attention_layernorm.weight": (d.hidden,),
+                     q + "self_attn.q_proj.weight": (H * hd, d.hidden), q + "self_attn.k_proj.weight": (KV * hd, d.hidden),
+                     q + "self_attn.v_proj.weight": (KV * hd, d.hidden), q + "self_attn.o_proj.weight": (d.hidden, H * hd),
+                     q + "self_attn.q_norm.weight": (hd,), q + "self_attn.k_norm.weight": (hd,),
+                     q + "mlp.gate_proj.weight": (d.ffn, d.hidden), q + "mlp.up_proj.weight": (d.ffn, d.hidden),
+                     q + "mlp.down_proj.weight": (d.hidden, d.ffn)})
+    a, C_ = "model.audio_tower.", ad.conv_hidden
+    need.update({a + "conv2d1.weight": (C_, 1, 3, 3), a + "conv2d2.weight": (C_, C_, 3, 3), a + "conv2d3.weight": (C_, C_, 3, 3),
+                 a + "conv_out.weight": (ad.d_model, C_ * (ad.n_mels // 8)), a + "ln_post.weight": (ad.d_model,),
+                 "model.multi_modal_projector.linear_1.weight": (ad.d_model, ad.d_model),
+                 "model.multi_modal_projector.linear_2.weight": (ad.out_dim, ad.d_model)})
+    for l in range(ad.n_layer):
+        q = f"{a}layers.{l}."
+        need.update({q + "self_attn.q_proj.weight": (ad.d_model, ad.d_model), q + "fc1.weight": (ad.ffn, ad.d_model),
+                     q + "fc2.weight": (ad.d_model, ad.ffn)})
+    missing = [k for k in need if k not in w]
+    if missing:
+        raise KeyError(f"{path}: {len(missing)} tensors of the qwen3_asr layout are missing, e.g. {missing[:4]}")
+    wrong = [(k, tuple(w[k].shape), need[k]) for k in need if tuple(w[k].shape) != tuple(need[k])]
+    if wrong:
+        raise ValueError(f"{path}: tensor shapes do not match config.json, e.g. {wrong[:3]}")
+    if ad.n_mels // 8 != 16:
+        raise ValueError(f"num_mel_bins {ad.n_mels}: the device convolution stem is written for 128 bins (16 frequency rows after three stride-2 steps)")
+    return d, ad, w
+
+
 class HipQwenAudioTower:
     """Clips (16 kHz mono float32) -> projected audio embeddings, one fp32 CUDA ``[n_tokens, out_dim]`` tensor per clip.
     Feature extraction as ``Qwen3ASRFeatureExtractor``: clips shorter than 0.5 s are zero-padded to 8000 samples, Whisper's
@@ -612,6 +710,14 @@ class HipQwenTextGenerator:
         self.batch_size, self.max_ctx, self.max_new_tokens = int(batch_size), int(max_ctx), int(max_new_tokens)
         self._model: Optional[HipQwen3Decoder] = None
 
+    @classmethod
+    def from_pretrained(cls, path: Union[str, Path], **kwargs: Any) -> "HipQwenTextGenerator":
+        """The generator over a local Hugging Face directory (``load_checkpoint``): what ``Qwen3ASRModel.from_pretrained`` is to the
+        reference's generator (modules/qwen_asr.py:581-608).  ``kwargs`` as the constructor's (the tokenizer-side plug-ins
+        included: the directory's tokenizer files are the upstream processor's business)."""
+        d, ad, w = load_checkpoint(path)
+        return cls(d, w, audio_dims=ad, **kwargs)
+
     def load(self) -> None:
         if self._model is None:
             self._model = HipQwen3Decoder(self.dims, self._weights, dtype=self.dtype, device=self.device, max_seqs=self.batch_size,
@@ -818,6 +924,15 @@ class HipQwenForcedAligner:
         self.batch_size, self.max_ctx = int(batch_size), int(max_ctx)
         self._model: Optional[HipQwen3Decoder] = None
         self._tower: Optional[HipQwenAudioTower] = None
+
+    @classmethod
+    def from_pretrained(cls, path: Union[str, Path], **kwargs: Any) -> "HipQwenForcedAligner":
+        """The aligner over a local Hugging Face directory of the forced-aligner checkpoint (same family + ``score.*``)."""
+        d, ad, w = load_checkpoint(path)
+        head = kwargs.get("head_key", "score")
+        if head + ".weight" not in w:
+            raise KeyError(f"{path}: no {head}.weight -- not a forced-aligner checkpoint")
+        return cls(d, ad, w, **kwargs)
 
     def load(self) -> None:
         if self._model is None:
