@@ -141,7 +141,8 @@ extern int g_dec_cross_u;
 extern int g_dec_cross_nt;
 extern int g_gemm_big;
 extern int g_ppb_ns, g_ppb_gm;
-extern int g_qwen_split_act, g_qwen_compact_pct, g_qwen_prompt_mfma, g_qwen_splitk;      // qwen.hip
+extern int g_qwen_split_act, g_qwen_compact_pct, g_qwen_prompt_mfma, g_qwen_splitk;
+extern int g_qwen_conv_kpad;                          // qwen_audio.hip      // qwen.hip
 extern int g_epi_wide;
 int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s);
 

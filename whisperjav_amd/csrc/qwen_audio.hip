@@ -20,6 +20,12 @@
 
 #include "kernels.hpp"
 
+namespace wj {
+int g_qwen_conv_kpad = 0;   // wj_tune("qwen_conv_kpad"), read at wj_qwen_audio_create: pad the 3x3 convolutions' K = 9 C to a multiple of 64 so their
+                            // GEMMs take the LDS-DMA tile kernel.  Measured (scripts/qwen_tower_kpad_ab.py, 512 clips of 4 s, published tower):
+                            // 61.2 ms against 61.7 ms, identical output -- the stem is bound by the patch matrices' HBM traffic, not by operand
+                            // staging.  Off; kept as an A/B switch
+}
 using namespace wj;
 
 namespace {
@@ -50,13 +56,13 @@ __global__ __launch_bounds__(256) void im2col_mel_kernel(const float* __restrict
 // t_major = 0: (chunk, f, t); 1: (chunk, t, f).
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_cl_kernel(const T* __restrict__ in, T* __restrict__ out, int Fi, int Ti, int Fo, int To,
-                                                        int C, int t_major) {
+                                                        int C, int t_major, int ld) {     // ld >= 9 C: row stride, the tail is zeroed
   const int64_t r = blockIdx.x;
   const int c = (int)(r / (Fo * To)), rem = (int)(r - (int64_t)c * Fo * To);
   const int f = t_major ? rem % Fo : rem / To, t = t_major ? rem / Fo : rem % To;
-  T* o = out + r * 9 * C;
+  T* o = out + r * ld;
   constexpr int V = 16 / (int)sizeof(T);
-  if (C % V == 0) {        // 16-byte copies (C = 480 in the published tower: 60 per tap); rows and taps start 16-byte aligned
+  if (C % V == 0 && ld % V == 0) {        // 16-byte copies (C = 480 in the published tower: 60 per tap); rows and taps start 16-byte aligned
     const int cv = C / V;
     uint4* ov = reinterpret_cast<uint4*>(o);
     for (int i = threadIdx.x; i < 9 * cv; i += 256) {
@@ -67,8 +73,10 @@ __global__ __launch_bounds__(256) void im2col_cl_kernel(const T* __restrict__ in
       if (ok) v = reinterpret_cast<const uint4*>(in + (((int64_t)c * Fi + fi) * Ti + ti) * C)[j];
       ov[i] = v;
     }
+    for (int i = 9 * cv + threadIdx.x; i < ld / V; i += 256) ov[i] = uint4{0u, 0u, 0u, 0u};
     return;
   }
+  for (int ch = 9 * C + threadIdx.x; ch < ld; ch += 256) o[ch] = (T)0;
   for (int tap = 0; tap < 9; ++tap) {
     const int fi = 2 * f - 1 + tap / 3, ti = 2 * t - 1 + tap % 3;
     const bool ok = fi >= 0 && fi < Fi && ti >= 0 && ti < Ti;
@@ -187,6 +195,10 @@ struct wj_qwen_audio {
   int max_chunks = 0;
   std::vector<void*> allocs;
   void *col = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;   // im2col buffer, activations of the three convolutions
+  // 16-bit types: K = 9 C of the second and third convolution (4320 in the published tower) padded to a multiple of 64 so that their
+  // GEMMs qualify for the LDS-DMA tile kernels: zero columns in a device copy of the two weight matrices and in the patch rows
+  int kp = 0;                // padded K, 0 = off
+  void *w2p = nullptr, *w3p = nullptr;   // [C][kp]
   float* y = nullptr;        // f32 [chunks * 13][D]   conv_out
   float* x = nullptr;        // f32 [tokens][D]        residual stream
   void *h = nullptr, *qkv = nullptr, *attn = nullptr, *ff = nullptr;
@@ -247,12 +259,30 @@ int wj_qwen_audio_create(wj_ctx* ctx, const wj_qwen_audio_dims* dims, int dtype,
   const size_t e = m->esz, C = d.conv_hidden, NC = max_chunks, N = NC * TOK, D = d.d_model;
   int rc = 0;
 #define AA(field, bytes) do { if (!rc) rc = aalloc(m, reinterpret_cast<void**>(&m->field), (bytes)); } while (0)
-  AA(col, NC * 32 * 25 * 9 * C * e);                 // the largest patch matrix (second convolution)
+  {
+    const size_t k9 = 9 * C, kpad = (k9 + 63) / 64 * 64;
+    m->kp = (g_qwen_conv_kpad && dtype != WJ_F32 && kpad != k9) ? (int)kpad : 0;
+  }
+  const size_t Kc = m->kp ? (size_t)m->kp : 9 * C;
+  AA(col, NC * 32 * 25 * Kc * e);                    // the largest patch matrix (second convolution)
+  if (m->kp) { AA(w2p, C * Kc * e); AA(w3p, C * Kc * e); }
   AA(a1, NC * 64 * 50 * C * e); AA(a2, NC * 32 * 25 * C * e); AA(a3, NC * TOK * 16 * C * e);
   AA(y, N * D * sizeof(float)); AA(x, N * D * sizeof(float));
   AA(h, N * std::max<size_t>(D, d.out_dim) * e); AA(qkv, N * 3 * D * e); AA(attn, N * D * e); AA(ff, N * (size_t)d.ffn * e);
   AA(chunk_clip, NC * 4); AA(chunk_f0, NC * 4); AA(tok_src, N * 4); AA(win_lo, N * 4); AA(win_hi, N * 4);
 #undef AA
+  if (!rc && m->kp) {
+    const int widx[2] = {WJ_QA_CONV2_W, WJ_QA_CONV3_W};
+    void* dst[2] = {m->w2p, m->w3p};
+    hipError_t he = hipSuccess;
+    for (int i = 0; i < 2 && he == hipSuccess; ++i) {
+      he = hipMemsetAsync(dst[i], 0, C * Kc * e, ctx->stream);
+      if (he == hipSuccess)
+        he = hipMemcpy2DAsync(dst[i], Kc * e, m->W(widx[i]), 9 * C * e, 9 * C * e, C, hipMemcpyDeviceToDevice, ctx->stream);
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+    if (he != hipSuccess) { set_error("wj_qwen_audio_create: padding the convolution weights failed: %s", hipGetErrorString(he)); rc = WJ_E_HIP; }
+  }
   if (rc) { wj_qwen_audio_free(m); return rc; }
   *out = m;
   return WJ_OK;
@@ -297,9 +327,10 @@ int wj_qwen_audio_encode(wj_qwen_audio* m, const float* mel_dev, int n_clips, in
   WJ_HIP(hipMemcpyAsync(m->win_lo, wlo.data(), 4 * (size_t)N, hipMemcpyHostToDevice, s));
   WJ_HIP(hipMemcpyAsync(m->win_hi, whi.data(), 4 * (size_t)N, hipMemcpyHostToDevice, s));
   WJ_HIP(hipStreamSynchronize(s));       // the host vectors die at return
-  auto gemm = [&](Epi epi, const void* A, int64_t lda, int wi, int bi, int M, int Nn, int K, void* out, int64_t ldc) -> int {
+  auto gemm = [&](Epi epi, const void* A, int64_t lda, int wi, int bi, int M, int Nn, int K, void* out, int64_t ldc,
+                  const void* w_override = nullptr) -> int {
     GemmArgs g;
-    g.A = A; g.lda = lda; g.W = m->W(wi); g.ldw = K; g.bias = bi >= 0 ? m->F(bi) : nullptr; g.M = M; g.N = Nn; g.K = K; g.out = out; g.ldc = ldc;
+    g.A = A; g.lda = lda; g.W = w_override ? w_override : m->W(wi); g.ldw = K; g.bias = bi >= 0 ? m->F(bi) : nullptr; g.M = M; g.N = Nn; g.K = K; g.out = out; g.ldc = ldc;
     return launch_gemm(dt, epi, g, s, 0);
   };
   // ---- convolution stem -------------------------------------------------------------------------------------------
@@ -314,11 +345,13 @@ int wj_qwen_audio_encode(wj_qwen_audio* m, const float* mel_dev, int n_clips, in
   }
   auto conv = [&](const void* in, int Fi, int Ti, int Fo, int To, int t_major, int wi, int bi, void* out) -> int {
     const int64_t rows = (int64_t)NC * Fo * To;
-    if (dt == WJ_F32) hipLaunchKernelGGL((im2col_cl_kernel<float>), dim3((unsigned)rows), dim3(256), 0, s, TPA(const float, in), TPA(float, m->col), Fi, Ti, Fo, To, C, t_major);
-    else if (dt == WJ_F16) hipLaunchKernelGGL((im2col_cl_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, s, TPA(const f16_t, in), TPA(f16_t, m->col), Fi, Ti, Fo, To, C, t_major);
-    else hipLaunchKernelGGL((im2col_cl_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, s, TPA(const bf16_t, in), TPA(bf16_t, m->col), Fi, Ti, Fo, To, C, t_major);
+    const int K = m->kp ? m->kp : 9 * C;
+    if (dt == WJ_F32) hipLaunchKernelGGL((im2col_cl_kernel<float>), dim3((unsigned)rows), dim3(256), 0, s, TPA(const float, in), TPA(float, m->col), Fi, Ti, Fo, To, C, t_major, K);
+    else if (dt == WJ_F16) hipLaunchKernelGGL((im2col_cl_kernel<f16_t>), dim3((unsigned)rows), dim3(256), 0, s, TPA(const f16_t, in), TPA(f16_t, m->col), Fi, Ti, Fo, To, C, t_major, K);
+    else hipLaunchKernelGGL((im2col_cl_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, s, TPA(const bf16_t, in), TPA(bf16_t, m->col), Fi, Ti, Fo, To, C, t_major, K);
     WJ_LAUNCH_CHECK();
-    return gemm(EPI_GELU_T, m->col, 9 * C, wi, bi, (int)rows, C, 9 * C, out, C);
+    const void* wp = !m->kp ? nullptr : (wi == WJ_QA_CONV2_W ? m->w2p : m->w3p);
+    return gemm(EPI_GELU_T, m->col, K, wi, bi, (int)rows, C, K, out, C, wp);
   };
   WJ_TRYA(conv(m->a1, 64, 50, 32, 25, 0, WJ_QA_CONV2_W, WJ_QA_CONV2_B, m->a2));
   WJ_TRYA(conv(m->a2, 32, 25, 16, TOK, 1, WJ_QA_CONV3_W, WJ_QA_CONV3_B, m->a3));      // rows (chunk, t, f)
