@@ -555,3 +555,83 @@ def test_reference_stable_ts_module_drives_the_hip_stable_shim(ref_modules, monk
     assert isinstance(res, WhisperResult)
     assert calls == [("init", ["<11><12>", "<13>"], "ja"), ("silence", len(audio), True, 0.25), ("regroup", True)]
     asr.cleanup()
+
+
+def test_reference_faster_pipeline_produces_its_srt_through_the_hip_stable_shim(ref_modules, monkeypatch, tmp_path):
+    """BASELINE cfg1 as SURVEY 8 scopes it ("plumbing only: adapters import, SRT produced"): the reference's ``FasterPipeline``
+    (pipelines/faster_pipeline.py:19-270) imported from source, its ``process()`` run unchanged -- audio extraction and SRT
+    post-processing (outside the seam) replaced by file-level doubles -- over ``StableTSASR`` whose
+    ``stable_whisper.load_faster_whisper`` is ``whisperjav_amd.stable_shim``'s.  The final ``<basename>.ja.whisperjav.srt`` must
+    hold what the engine (a double here) decoded, through the shim's result object and the reference's own ``_save_to_srt``."""
+    import wave
+    import numpy as np
+    import torch
+    from tests import test_asr_adapter as doubles
+    from whisperjav_amd import dims as pdims, stable_shim
+    tb = pdims.special_tokens(51865).timestamp_begin
+    engine = doubles._model([[tb, 21, 22, tb + 150, tb + 150, 23, tb + 300]])
+    engine.model.align = lambda rows, n_prefix, heads, num_frames, slots=None, medfilt_width=7: [
+        (np.repeat(np.arange(len(r) - 4), 10), np.arange(10 * (len(r) - 4)), np.full(len(r) - 5, 0.8, np.float32)) for r in rows]
+    engine.dims = pdims.custom_dims(80, 128, 2, 2, 51865)
+    engine.device_beam = True
+    engine.model.decode_beam = lambda prompts, options, **kw: engine.model.decode_greedy(prompts, options)
+
+    def wav(path, seconds):
+        path.parent.mkdir(parents=True, exist_ok=True)
+        pcm = (np.sin(np.arange(int(16000 * seconds)) * 0.05) * 8000).astype(np.int16)
+        with wave.open(str(path), "wb") as wf:
+            wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000); wf.writeframes(pcm.tobytes())
+        return path
+
+    def sf_read(path, dtype="float32", always_2d=False, **kw):
+        with wave.open(str(path), "rb") as wf:
+            data = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+            return data, wf.getframerate()
+    stubs = {name: types.ModuleType(name) for name in ("stable_whisper", "soundfile", "librosa", "pysrt", "srt", "tqdm", "ffmpeg", "jsonschema")}
+    stubs["stable_whisper"].WhisperResult = object
+    stubs["stable_whisper"].load_faster_whisper = lambda name, **kw: stable_shim.HipStableWhisperModel(name, model=engine, **kw)
+    stubs["soundfile"].read = sf_read
+    stubs["soundfile"].SoundFileError = Exception
+    for attr in ("SubRipItem", "SubRipFile", "SubRipTime"):
+        setattr(stubs["pysrt"], attr, type(attr, (), {}))
+    stubs["tqdm"].tqdm = lambda it=None, **kw: it
+    for name, mod in stubs.items():
+        monkeypatch.setitem(sys.modules, name, mod)
+    monkeypatch.setattr(torch.hub, "load", lambda *a, **kw: None)
+    for _ in range(40):                 # anything else the application imports at module level and this container lacks
+        try:
+            fp = importlib.import_module("whisperjav.pipelines.faster_pipeline")
+            break
+        except ModuleNotFoundError as e:
+            if e.name.startswith("whisperjav"):
+                raise
+            monkeypatch.setitem(sys.modules, e.name, types.ModuleType(e.name))
+    else:
+        pytest.skip("reference faster pipeline not importable here")
+    sta = importlib.import_module("whisperjav.modules.stable_ts_asr")
+    monkeypatch.setattr(sta, "snapshot_download", None)
+    monkeypatch.setattr(fp, "AudioExtractor", lambda *a, **kw: types.SimpleNamespace(extract=lambda path, out: (wav(out, 12.0), 12.0)))
+
+    class Post:
+        def __init__(self, language="ja", **kw):
+            self.language = language
+
+        def process(self, srt_path, out_path, **kw):
+            tmp = srt_path.with_suffix(".sanitized.srt")
+            tmp.write_text(srt_path.read_text(encoding="utf-8"), encoding="utf-8")
+            return tmp, {"total_subtitles": 2, "empty_removed": 0}
+    monkeypatch.setattr(fp, "SRTPostProcessor", Post)
+    resolved = {"model": {"model_name": "large-v2", "device": "cuda", "compute_type": "int8"},
+                "params": {"decoder": dict(task="transcribe", language="ja", beam_size=2, best_of=1, patience=2.0),
+                           "provider": dict(temperature=[0.0, 0.1], no_speech_threshold=0.5, condition_on_previous_text=False,
+                                            word_timestamps=True, regroup=True, vad=True, vad_threshold=0.25, vad_repo="snakers4/silero-vad"),
+                           "vad": {}},
+                "features": {"post_processing": {}}, "task": "transcribe"}
+    pipe = fp.FasterPipeline(output_dir=str(tmp_path / "out"), temp_dir=str(tmp_path / "temp"), keep_temp_files=True,
+                             subs_language="native", resolved_config=resolved)
+    assert isinstance(pipe.asr.model, stable_shim.HipStableWhisperModel)
+    media = wav(tmp_path / "movie.wav", 12.0)
+    pipe.process({"path": str(media), "basename": "movie", "type": "audio", "duration": 12.0})
+    final = tmp_path / "out" / "movie.ja.whisperjav.srt"
+    assert final.exists()
+    assert final.read_text(encoding="utf-8") == "1\n00:00:00,000 --> 00:00:00,400\n<21><22>\n\n2\n00:00:00,400 --> 00:00:00,600\n<23>\n"
