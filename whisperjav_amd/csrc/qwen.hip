@@ -357,7 +357,7 @@ __device__ __forceinline__ float pa_quad_max(float x) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void prompt_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
+__global__ __launch_bounds__(256, 2) void prompt_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
                                                           const int4* __restrict__ work, T* __restrict__ out, int H, int KV, int ctx,
                                                           int split) {
   typedef typename Vec8<T>::type vec8_t;
