@@ -486,7 +486,12 @@ def run_cfg3(args, info, dims):
                     "vad_threshold": args.vad_threshold, "scene_gate_db": {"pass1": 52, "pass2": 56, "reference_defaults": [32, 38]},
                     "max_new_tokens": args.max_new_tokens, "beam": args.beam, "patience": 1.2,
                     "decode_last_step": (stats or {}).get("decode"), "scenes": (stats or {}).get("scenes"),
-                    "vad_segments": (stats or {}).get("vad_segments")},
+                    "vad_segments": (stats or {}).get("vad_segments"),
+                    # what "float16" means for parity: where the 1e-3 bar was verified, and where it is not met
+                    "parity_of_compute_type": ("float16: per-token log-probs within 1e-3 of the fp32 oracle verified at the large-v3 geometry on "
+                                               "fp16-representable weights only (greedy 8.8e-4, cfg3 beam winner 7.3e-4 incl. EOT, winners identical: "
+                                               "tests/test_gpu_search_eot.py golden_large_v3_r3); toy geometries sit at 3-8e-3 (PARITY.md); "
+                                               "float32 = the exact 1e-5 type (`fp32_mode` key)") if args.dtype == "float16" else args.dtype},
                 # what ONE file costs a user who starts the process for it: synthetic-weight generation +
                 # pack + broadcast + engine creation (a real checkpoint load replaces the first part), then the first, cold pass
                 "cold_start": {"init_s": round(init_s, 1), "first_pass_s": None if cold_s is None else round(cold_s, 2),
