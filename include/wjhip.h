@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 4
+#define WJ_ABI_VERSION 5
 
 enum {
   WJ_OK = 0,
@@ -358,6 +358,13 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
                      const int32_t* n_tokens_host, int n_prefix, const int32_t* heads_host, int n_heads,
                      const int32_t* num_frames_host, int medfilt_width, int eot, int32_t* path_text_out,
                      int32_t* path_time_out, int32_t* path_len_out, float* token_prob_out, void* stream);
+
+/* ABI 5, diagnostic: the matrix the last wj_whisper_align ran its DTW on -- (w - mean) / std, median filtered, averaged over the
+ * alignment heads (whisper/timing.py find_alignment's `matrix`; the DTW minimises the sum of its NEGATED entries).  out_host
+ * [batch][n_rows][n_cols] float32: row i of window b = text position i (0 = <|notimestamps|>), column j = encoder frame j; entries
+ * past a window's own token / frame counts are scratch.  Lets a test price one pass's path on the other pass's matrix (16-bit
+ * compute types: two summation orders give different paths exactly where the cost surface is flat). */
+int wj_whisper_last_align_matrix(const wj_whisper* m, int batch, int n_rows, int n_cols, float* out_host);
 
 /* diagnostics of the last wj_whisper_decode_{greedy,sample,beam} call: out[0] = 1 if the step was replayed from a
  * hipGraph, out[1] = number of concurrent row chains, out[2] = decode iterations actually run (the loops leave early

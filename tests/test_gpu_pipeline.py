@@ -822,11 +822,16 @@ def test_alignment_matches_oracle(hip, dtype, prefill):
     # windows 2 and 0 through the slot map, then all three in order
     got = model.align([rows[2], rows[0]], len(sot_seq) + 1, heads, [frames[2], frames[0]], slots=[2, 0])
     got = [got[1], model.align([rows[1]], len(sot_seq) + 1, heads, [frames[1]], slots=[1])[0], got[0]]
-    worst_p, worst_t = 0.0, 0
+    worst_p, worst_t, worst_m, worst_x = 0.0, 0, 0.0, 0.0
     with torch.no_grad():
         xa = oracle.encode(mel)
+    dev_m = {}
+    if dtype != "float32":      # the matrices the device ran its DTWs on (one call per window: the export serves the LAST call)
+        for w in range(3):
+            model.align([rows[w]], len(sot_seq) + 1, heads, [frames[w]], slots=[w])
+            dev_m[w] = model.last_align_matrix(1, len(texts[w]) + 1, frames[w] // 2)[0]
     for w in range(3):
-        ti, fi, probs, _ = alignment.find_alignment(oracle, xa[w:w + 1], sot_seq, t.no_timestamps, texts[w], t.eot, frames[w], heads)
+        ti, fi, probs, matrix = alignment.find_alignment(oracle, xa[w:w + 1], sot_seq, t.no_timestamps, texts[w], t.eot, frames[w], heads)
         g_ti, g_fi, g_p = got[w]
         assert g_p.shape == probs.shape
         worst_p = max(worst_p, float(np.abs(g_p - probs).max()))
@@ -837,11 +842,35 @@ def test_alignment_matches_oracle(hip, dtype, prefill):
         else:   # first frame of every token row, compared in 20 ms units
             first = lambda a, b: np.array([b[np.argmax(a == k)] for k in range(len(texts[w]) + 1)])   # noqa: E731
             worst_t = max(worst_t, int(np.abs(first(g_ti, g_fi) - first(ti, fi)).max()))
+            worst_m = max(worst_m, float(np.abs(dev_m[w] - matrix).max()))
+            worst_x = max(worst_x, _path_excess(matrix, (g_ti, g_fi), (ti, fi)))
     hipbind.tune("align_prefill", 1)
-    _diag("alignment", {"dtype": dtype, "prefill": prefill, "max_prob_diff": worst_p, "max_token_start_shift_frames": worst_t})
+    _diag("alignment", {"dtype": dtype, "prefill": prefill, "max_prob_diff": worst_p, "max_token_start_shift_frames": worst_t,
+                        "max_matrix_diff": worst_m, "path_excess_per_cell_on_oracle_matrix": worst_x})
     assert worst_p < _tol(dtype, 1e-4, 2e-2, 4e-3), worst_p
-    assert worst_t <= 25, worst_t
+    # integer outputs get an integer bar: float16 (the default compute type) reproduces the fp32 oracle's token start frames
+    # exactly on this fixture.  bfloat16 (8 mantissa bits): the z-scored matrix itself agrees with the oracle's (bound below) but
+    # where it is flat along a token row the optimal path is not unique to that precision; what IS asserted is that the device's
+    # path, priced on the ORACLE's matrix, costs no more than the bound per path cell above the oracle's optimum (a near-tie),
+    # and the start frames are recorded.  r05 root cause run: scripts/diag_align.py, profiles/r05_diag_align.jsonl
+    if dtype == "float16":
+        assert worst_t == 0, worst_t
+        assert worst_m < 0.5 and worst_x < 1e-3, (worst_m, worst_x)
+    elif dtype == "bfloat16":
+        assert worst_m < 2.0 and worst_x < 5e-2, (worst_m, worst_x)
+        assert worst_t <= 25, worst_t
     model.close()
+
+
+def _path_cost(matrix, path):
+    ti, fi = path
+    return float(-matrix[np.asarray(ti), np.asarray(fi)].astype(np.float64).sum())
+
+
+def _path_excess(matrix, path, optimal):
+    """How much dearer ``path`` is than ``optimal`` under the DTW objective of ``matrix`` (sum of negated entries along the path),
+    per cell of the path: 0 for the optimum itself, ~ the matrix noise for a near-tie, O(1) for a wrong alignment."""
+    return max(0.0, _path_cost(matrix, path) - _path_cost(matrix, optimal)) / max(1, len(path[0]))
 
 
 def test_word_timestamps_through_the_shim(hip):
@@ -967,13 +996,23 @@ def test_scene_detection_matches_reference_fixtures(hip, tmp_path):
     det.cleanup()
 
 
-def test_large_v3_geometry_beam_and_alignment_consistency(hip):
-    """BASELINE geometry (large-v3 shape, bf16): properties that need no CPU oracle run at full size --
-    the device-resident beam search equals the host-driven restatement over the step API, a window's result does not
-    depend on its batch neighbours, and the full-sequence alignment pass agrees with the token-by-token one."""
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_large_v3_geometry_beam_and_alignment_consistency(hip, dtype):
+    """BASELINE geometry (large-v3 shape; float16 = the default compute type, bfloat16 = the throughput type): properties that
+    need no CPU oracle run at full size -- the device-resident beam search equals the host-driven restatement over the step API, a
+    window's result does not depend on its batch neighbours, and the full-sequence alignment pass agrees with the token-by-token
+    one.
+
+    Alignment bar (r05 root cause of the r04 driver failure, scripts/diag_align.py -> profiles/r05_diag_align.jsonl): both passes
+    are deterministic and state-free (bit-identical on repetition and in a fresh engine), they differ in fp32 summation order
+    (tile GEMMs / MFMA attention vs row kernels with split-K), and whisper's (w - mean) / std over the token axis amplifies
+    that noise wherever a frame's weights barely vary over the tokens.  float16: token start frames IDENTICAL (0 frames, also on
+    weights.SPEECHLIKE).  bfloat16: any change of summation order moves the path through flat regions (9 frames with the
+    vectorised LayerNorm, 3 without, 26 on peaked weights): the paths are compared through the DTW objective instead -- each
+    pass's path priced on the OTHER pass's matrix is a near-tie of that matrix's optimum, and the matrices agree."""
     from whisperjav_amd import dims as pdims, engine, hipbind, search, synth, weights as pweights
     dims = pdims.dims_for("large-v3")
-    model = engine.HipWhisper(dims, helpers.cached_weights(dims, 1234), dtype="bfloat16", max_batch=3, max_beam=5)
+    model = engine.HipWhisper(dims, helpers.cached_weights(dims, 1234), dtype=dtype, max_batch=3, max_beam=5)
     fe = engine.HipLogMel(128, "fw")
     clips = [synth.speech_like(30.0, seed=1234), synth.speech_like(11.0, seed=77), synth.speech_like(30.0, seed=5)]
     model.encode(fe(clips))
@@ -999,19 +1038,33 @@ def test_large_v3_geometry_beam_and_alignment_consistency(hip):
     rows = [[*sot_seq, toks.no_timestamps, *[int(t) for t in g3.tokens[w, : g3.n_tokens[w]] if t < toks.eot], toks.eot] for w in range(3)]
     heads = [(7, 0), (10, 17), (12, 18), (13, 12), (16, 1), (17, 14), (19, 11), (21, 4), (24, 1), (25, 6)]
     frames = [3000, 1100, 3000]
+    n_rows = max(len(r) for r in rows) - 4
     a = model.align(rows, 4, heads, frames)
+    ma = model.last_align_matrix(3, n_rows, 1500)
+    a2 = model.align(rows, 4, heads, frames)
     hipbind.tune("align_prefill", 0)
     b = model.align(rows, 4, heads, frames)
+    mb = model.last_align_matrix(3, n_rows, 1500)
+    b2 = model.align(rows, 4, heads, frames)
     hipbind.tune("align_prefill", 1)
-    worst = 0
-    for (ti_a, fi_a, p_a), (ti_b, fi_b, p_b), row, nf in zip(a, b, rows, frames):
+    worst, worst_m, worst_x = 0, 0.0, 0.0
+    for w, ((ti_a, fi_a, p_a), (ti_b, fi_b, p_b), row, nf) in enumerate(zip(a, b, rows, frames)):
         n_text = len(row) - 5
         assert ti_a[-1] == n_text and fi_a[-1] == nf // 2 - 1 and ti_b[-1] == n_text
+        for x, y in ((a[w], a2[w]), (b[w], b2[w])):        # each pass reproduces itself bit for bit
+            assert all(np.array_equal(u, v) for u, v in zip(x, y))
         first = lambda t, f: np.array([f[np.argmax(t == k)] for k in range(n_text + 1)])   # noqa: E731
         worst = max(worst, int(np.abs(first(ti_a, fi_a) - first(ti_b, fi_b)).max()))
         assert np.abs(p_a - p_b).max() < 5e-3
-    _diag("large_v3_consistency", {"align_shift_frames_prefill_vs_steps": worst})
-    assert worst <= 3, worst
+        wa, wb = ma[w, : n_text + 1, : nf // 2], mb[w, : n_text + 1, : nf // 2]
+        worst_m = max(worst_m, float(np.abs(wa - wb).max()))
+        worst_x = max(worst_x, _path_excess(wa, (ti_b, fi_b), (ti_a, fi_a)), _path_excess(wb, (ti_a, fi_a), (ti_b, fi_b)))
+    _diag("large_v3_consistency", {"dtype": dtype, "align_shift_frames_prefill_vs_steps": worst, "max_matrix_diff": worst_m,
+                                   "path_excess_per_cell_on_the_other_matrix": worst_x})
+    if dtype == "float16":
+        assert worst == 0, worst
+    assert worst_m < (0.5 if dtype == "float16" else 2.0), worst_m
+    assert worst_x < (1e-3 if dtype == "float16" else 5e-2), worst_x
     model.close()
 
 
@@ -1071,6 +1124,38 @@ def test_sharded_transcribe_cli_single_rank(hip, tmp_path, mode):
     assert res.returncode == 0, res.stderr[-2000:]
     text = (tmp_path / "out" / "rec.srt").read_text(encoding="utf-8")
     assert text.count("-->") >= 2 and text.startswith("1\n")
+
+
+def test_shim_opens_a_ctranslate2_model_directory(hip, tmp_path):
+    """``HipWhisperModel("<dir with model.bin>")`` = what ``faster_whisper.WhisperModel(model_size_or_path=...)`` opens
+    (faster_whisper_pro_asr.py:246-253): the directory is written here in CTranslate2's format (float16 and int8 storage,
+    whisperjav_amd/ct2_format.py) from seeded EOT-bearing weights; the float16 one must transcribe exactly as the same weights
+    handed over directly, the int8 one must load and run (its weights are the dequantised ones), config.json's alignment heads
+    arrive."""
+    from whisperjav_amd import ct2_format, synth, weights as pweights, whisper_model as wm
+    d = helpers.small_dims()
+    w = pweights.synth_weights(d, seed=33, **pweights.SPEECHLIKE)
+    w = {k: a.astype(np.float16).astype(np.float32) for k, a in w.items()}         # what a float16 conversion stores
+    ct2_format.write_ct2_whisper(str(tmp_path / "f16"), d, w, dtype="float16", alignment_heads=[(1, 0), (1, 1)])
+    ct2_format.write_ct2_whisper(str(tmp_path / "i8"), d, w, dtype="float16", quantization="int8")
+    clips = [synth.speech_like(sec, seed=60 + i) for i, sec in enumerate((1.5, 4.0, 7.0))]
+    kw = dict(task="transcribe", language="ja", beam_size=5, patience=1.2, repetition_penalty=1.5, no_repeat_ngram_size=3,
+              temperature=0.0, condition_on_previous_text=False, max_new_tokens=48, no_speech_threshold=None,
+              max_initial_timestamp=0.0, word_timestamps=False, log_prob_threshold=None, compression_ratio_threshold=None)
+    key = lambda per_clip: [[(s.seek, tuple(s.tokens), round(s.avg_logprob, 5)) for s in segs] for segs in per_clip]     # noqa: E731
+    direct = wm.HipWhisperModel("tiny", compute_type="float32", weights=w, dims=d, max_batch=4, max_beam=5)
+    want = key(direct.transcribe_many(clips, **kw)[0])
+    direct.close()
+    opened = wm.HipWhisperModel(str(tmp_path / "f16"), compute_type="float32", max_batch=4, max_beam=5)
+    assert opened.dims == d and opened._alignment_heads == [(1, 0), (1, 1)]
+    got = key(opened.transcribe_many(clips, **kw)[0])
+    opened.close()
+    assert got == want and any(len(c) for c in got)
+    q = wm.HipWhisperModel(str(tmp_path / "i8"), compute_type="int8_float16", max_batch=4, max_beam=5)
+    assert q.dims == d and q.compute_type == "float16"
+    res = q.transcribe_many(clips, **kw)[0]
+    q.close()
+    assert len(res) == 3
 
 
 # ---------------------------------------------------------------------------------------------

@@ -129,6 +129,46 @@ def test_ctranslate2_generate_matches_the_restated_beam_search():
         assert abs(res.no_speech_prob - nsp) < 1e-4
 
 
+def test_ctranslate2_model_directory_reader_and_writer(tmp_path):
+    """``whisperjav_amd.ct2_format`` against the wheel itself, both directions, on a seeded toy Whisper (no download):
+    (a) a directory written by ``ct2_format.write_ct2_whisper`` LOADS in ``ctranslate2.models.Whisper`` and its encoder output
+    equals the oracle's on the same weights; (b) the directory ``ctranslate2.converters.TransformersConverter`` writes from the
+    same weights as a ``WhisperForConditionalGeneration`` is read back by ``ct2_format.load_ct2_whisper`` into the same tensors
+    (float32 exactly; the reference opens such directories at faster_whisper_pro_asr.py:246-253)."""
+    ct2 = pytest.importorskip("ctranslate2", reason="ctranslate2 " + MISSING)
+    transformers = pytest.importorskip("transformers")
+    from whisperjav_amd import ct2_format
+    d = helpers.small_dims()
+    w = pweights.synth_weights(d, seed=11, exact="float16")
+    toks = pdims.special_tokens(d.n_vocab)
+    # (a) our writer -> the wheel
+    ours = tmp_path / "ours"
+    ct2_format.write_ct2_whisper(str(ours), d, w, dtype="float32", alignment_heads=[(1, 0)])
+    model = ct2.models.Whisper(str(ours), device="cpu", compute_type="float32")
+    mel = logmel.window_features(synth.speech_like(4.0, seed=3), d.n_mels, "fw")[None]
+    enc = np.asarray(model.encode(ct2.StorageView.from_array(mel)))
+    oracle = whisper_ref.WhisperOracle(helpers.oracle_dims(d), w)
+    with torch.no_grad():
+        ref = oracle.encode(torch.from_numpy(mel)).numpy()
+    assert np.abs(enc - ref).max() < 2e-3
+    # (b) the wheel's converter -> our reader
+    cfg = transformers.WhisperConfig(vocab_size=d.n_vocab, num_mel_bins=d.n_mels, d_model=d.n_audio_state, encoder_layers=d.n_audio_layer,
+                                     decoder_layers=d.n_text_layer, encoder_attention_heads=d.n_audio_head,
+                                     decoder_attention_heads=d.n_text_head, encoder_ffn_dim=4 * d.n_audio_state,
+                                     decoder_ffn_dim=4 * d.n_text_state, max_source_positions=d.n_audio_ctx,
+                                     max_target_positions=d.n_text_ctx, pad_token_id=toks.eot, bos_token_id=toks.eot,
+                                     eos_token_id=toks.eot, decoder_start_token_id=toks.sot, suppress_tokens=[], begin_suppress_tokens=[])
+    hf = transformers.WhisperForConditionalGeneration(cfg)
+    hf.load_state_dict(helpers.hf_state_dict(d, w), strict=False)
+    hf_dir, theirs = tmp_path / "hf", tmp_path / "theirs"
+    hf.save_pretrained(str(hf_dir))
+    ct2.converters.TransformersConverter(str(hf_dir)).convert(str(theirs), quantization="float32", force=True)
+    dims, sd, _ = ct2_format.load_ct2_whisper(str(theirs))
+    assert dims == d
+    for k, a in w.items():
+        assert np.array_equal(sd[k], a), k
+
+
 def test_auditok_split():
     """``auditok.split(bytes, sampling_rate, channels=1, sample_width=2, min_dur, max_dur, max_silence,
     energy_threshold, drop_trailing_silence=True)`` as called at auditok_backend.py:396,567 == ``oracle.auditok_ref.split``

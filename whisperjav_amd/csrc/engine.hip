@@ -210,6 +210,8 @@ struct wj_whisper {
   size_t align_bytes = 0;
   int32_t* align_sel = nullptr;
   float* dump_qk = nullptr;     // non-NULL while the teacher-forced pass of wj_whisper_align runs
+  const float* last_align_matrix = nullptr;   // the head-averaged matrix the last wj_whisper_align ran its DTW on (in align_buf)
+  int last_align_batch = 0, last_align_T = 0;
   int dump_nsel = 0, dump_tmax = 0;
   int32_t* topk_ids = nullptr;  // [R][16]
   float* topk_lp = nullptr;
@@ -1558,7 +1560,7 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
   const size_t b_prob = align_up(sizeof(float) * (size_t)batch * T, 256);
   const size_t need = b_qk + b_mx + b_tr + 2 * b_path + 3 * b_meta + b_prob;
   if (need > m->align_bytes) {
-    if (m->align_buf) { WJ_HIP(hipStreamSynchronize(s)); (void)hipFree(m->align_buf); m->align_buf = nullptr; m->align_bytes = 0; }
+    if (m->align_buf) { WJ_HIP(hipStreamSynchronize(s)); (void)hipFree(m->align_buf); m->align_buf = nullptr; m->align_bytes = 0; m->last_align_matrix = nullptr; }
     WJ_HIP(hipMalloc(&m->align_buf, need));
     m->align_bytes = need;
   }
@@ -1611,6 +1613,7 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
     WJ_TRY(launch_advance_pos(m->pos, s));
   }
   WJ_TRY(launch_align_post(qk, matrix, trace, d_ntok, d_nf2, R, n_heads, T, nctx, n0, medfilt_width, p_text, p_time, d_plen, s));
+  m->last_align_matrix = matrix; m->last_align_batch = batch; m->last_align_T = T;
   // device rows are T wide; the ABI's are n_tokens_max wide
   const size_t plen_out = (size_t)n_tokens_max + nctx;
   WJ_HIP(hipMemcpy2DAsync(path_text_out, sizeof(int32_t) * plen_out, p_text, sizeof(int32_t) * plen, sizeof(int32_t) * plen_out,
@@ -1621,6 +1624,20 @@ int wj_whisper_align(wj_whisper* m, int batch, const int32_t* slots_host, const 
   WJ_HIP(hipMemcpy2DAsync(token_prob_out, sizeof(float) * n_tokens_max, d_prob, sizeof(float) * T, sizeof(float) * n_tokens_max,
                           batch, hipMemcpyDeviceToHost, s));
   WJ_HIP(hipStreamSynchronize(s));
+  return WJ_OK;
+}
+
+int wj_whisper_last_align_matrix(const wj_whisper* m, int batch, int n_rows, int n_cols, float* out_host) {
+  WJ_REQUIRE(m && out_host, "wj_whisper_last_align_matrix: NULL argument");
+  WJ_REQUIRE(m->last_align_matrix && m->align_buf, "wj_whisper_last_align_matrix: no wj_whisper_align call on this model yet");
+  WJ_REQUIRE(batch >= 1 && batch <= m->last_align_batch && n_rows >= 1 && n_rows <= m->last_align_T && n_cols >= 1 &&
+             n_cols <= m->d.n_audio_ctx, "wj_whisper_last_align_matrix: [%d][%d][%d] outside the last call's [%d][%d][%d]", batch, n_rows,
+             n_cols, m->last_align_batch, m->last_align_T, m->d.n_audio_ctx);
+  WJ_HIP(hipSetDevice(m->ctx->device));
+  const int nctx = m->d.n_audio_ctx, T = m->last_align_T;
+  for (int b = 0; b < batch; ++b)
+    WJ_HIP(hipMemcpy2D(out_host + (size_t)b * n_rows * n_cols, sizeof(float) * n_cols, m->last_align_matrix + (size_t)b * T * nctx,
+                       sizeof(float) * nctx, sizeof(float) * n_cols, n_rows, hipMemcpyDeviceToHost));
   return WJ_OK;
 }
 

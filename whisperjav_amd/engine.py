@@ -392,6 +392,14 @@ class HipWhisper:
             out.append((p_text[b, :n].copy(), p_time[b, :n].copy(), probs[b, : int(n_tok[b]) - n_prefix - 1].copy()))
         return out
 
+    def last_align_matrix(self, batch: int, n_rows: int, n_cols: int) -> np.ndarray:
+        """Diagnostic (``wj_whisper_last_align_matrix``): the head-averaged, median-filtered matrix the last ``align`` call ran
+        its DTW on, ``[batch][n_rows][n_cols]`` (text position x encoder frame; the DTW minimises the negated sum)."""
+        out = np.empty((int(batch), int(n_rows), int(n_cols)), dtype=np.float32)
+        check(self._lib.wj_whisper_last_align_matrix(self.handle, int(batch), int(n_rows), int(n_cols),
+                                                     out.ctypes.data_as(C.POINTER(C.c_float))), "wj_whisper_last_align_matrix")
+        return out
+
     def last_decode_info(self) -> dict:
         out = (C.c_int32 * 6)()
         check(self._lib.wj_whisper_last_decode_info(self.handle, out), "wj_whisper_last_decode_info")

@@ -12,12 +12,13 @@ import os
 from pathlib import Path
 from typing import Optional
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwjhip.so"
 _lib: Optional[C.CDLL] = None
 
 WJ_F32, WJ_BF16, WJ_F16, WJ_F8W = 0, 1, 2, 3      # WJ_F8W: wj_qwen_create only (MX-fp8 decoder projections)
 WJ_MEL_FW, WJ_MEL_OW, WJ_MEL_RAW = 0, 1, 2
+WJ_E_UNSUPPORTED = -5       # include/wjhip.h: the status of an entry point whose run-time dependency (RCCL symbol) is absent
 DTYPES = {"float32": WJ_F32, "bfloat16": WJ_BF16, "float16": WJ_F16}
 
 
@@ -96,6 +97,7 @@ _SIGNATURES = {
     "wj_whisper_align": (_I, [_P, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I,
                               C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32), _I, _I, C.POINTER(C.c_int32),
                               C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_F), _P]),
+    "wj_whisper_last_align_matrix": (_I, [_P, _I, _I, _I, C.POINTER(_F)]),
     "wj_whisper_last_decode_info": (_I, [_P, C.POINTER(C.c_int32)]),
     "wj_whisper_last_beam_token_logprobs": (_I, [_P, _I, _I, C.POINTER(C.c_float)]),
     "wj_decode_open": (_I, [_P, _I, _I, _P]),

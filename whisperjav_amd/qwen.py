@@ -741,7 +741,10 @@ class HipQwen3Decoder:
             out_t.append(toks[b, :k].tolist())
             out_l.append(lps[b, : k + 1 if k < int(lim[b]) else k].tolist())      # + the EOS token's when the sequence ended on one
         self._n_seqs = 0
-        assert int(self._lib.wj_qwen_last_truncated(self.handle)) == sum(limited)
+        truncated = int(self._lib.wj_qwen_last_truncated(self.handle))
+        if truncated != sum(limited):       # the host mirror of the KV-room clamp disagrees with the library: trust neither silently
+            raise hipbind.WjError(f"wj_qwen_generate_greedy_ex cut {truncated} budgets at the KV cache, the host expected {sum(limited)} "
+                                  f"(max_ctx {self.max_ctx}): the result would mis-report context_limited")
         return GenerateResult(out_t, out_l, int(self._lib.wj_qwen_last_steps(self.handle)), int(self._lib.wj_qwen_last_compactions(self.handle)),
                               int(self._lib.wj_qwen_last_row_steps(self.handle)), limited)
 
@@ -813,10 +816,12 @@ class HipQwenTextGenerator:
         have = getattr(self._model, "max_ctx", None)
         if have is None or need <= have:        # a stand-in decoder (tests) manages its own context
             return
-        self.max_ctx = (int(need) + 255) // 256 * 256
-        self._model.close()
+        max_ctx = (int(need) + 255) // 256 * 256
+        old, self._model = self._model, None        # never leave a closed handle behind: on failure the generator is unloaded
+        old.close()                                 # (the old cache is freed first -- two caches may not fit side by side)
         self._model = HipQwen3Decoder(self.dims, self._weights, dtype=self.dtype, device=self.device, max_seqs=self.batch_size,
-                                      max_ctx=self.max_ctx)
+                                      max_ctx=max_ctx)
+        self.max_ctx = max_ctx
 
     def unload(self) -> None:
         self._primed = None
@@ -883,7 +888,8 @@ class HipQwenTextGenerator:
                            for d in list(durations)[lo: lo + self.batch_size]]
             # the KV cache must hold the longest prompt PLUS its budget (48 s scenes at 20 tokens/s: ~640 + 960 positions --
             # more than any fixed default): grow the decoder's context when this batch needs it
-            need = max(len(p) + (budgets[i] if budgets is not None else max_new) for i, p in enumerate(ids))
+            # (+1 when a budget is 0: the prefill itself needs a free position after the prompt, csrc/qwen.hip wj_qwen_prefill)
+            need = max(len(p) + max(1, budgets[i] if budgets is not None else max_new) for i, p in enumerate(ids))
             self._ensure_ctx(need)
             self._model.prefill_packed(*self._model.prompt_embeddings_many(ids, audio_embeds))     # one embedding launch, one scatter
             res = self._model.generate(max_new, repetition_penalty=self.repetition_penalty, prompt_ids=ids, max_new_per_seq=budgets)

@@ -14,6 +14,7 @@ The reference has no multi-GPU code at all; its work uni
 """
 from __future__ import annotations
 
+import logging
 import os
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence, Tuple
@@ -21,6 +22,9 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+log = logging.getLogger("whisperjav_amd")
 
 
 @dataclass(frozen=True)
@@ -105,8 +109,15 @@ def broadcast_blob_cabi(blob: Optional[torch.Tensor], offsets: Optional[np.ndarr
     global LAST_COMM_RANKS
     try:
         n = C.c_int(0)
-        LAST_COMM_RANKS = int(n.value) if lib.wj_comm_count(comm, C.byref(n)) else int(n.value)     # what RCCL says it built
-        if LAST_COMM_RANKS and LAST_COMM_RANKS != info.world:
+        rc = int(lib.wj_comm_count(comm, C.byref(n)))     # what RCCL says it built
+        if rc == 0:
+            LAST_COMM_RANKS = int(n.value)
+        elif rc == hipbind.WJ_E_UNSUPPORTED:               # a librccl without ncclCommCount: the size is unknown, not wrong
+            LAST_COMM_RANKS = 0
+            log.warning("wj_comm_count: this RCCL has no ncclCommCount; communicator size not verified")
+        else:
+            hipbind.check(rc, "wj_comm_count")
+        if rc == 0 and LAST_COMM_RANKS != info.world:
             raise hipbind.WjError(f"RCCL built a communicator of {LAST_COMM_RANKS} ranks for a world of {info.world}")
         hipbind.check(lib.wj_bcast_weights(comm, C.c_void_p(dev_blob.data_ptr()), nbytes, src, None), "wj_bcast_weights")
     finally:

@@ -43,6 +43,15 @@ _STABLE_TS_KEYS = ("regroup", "vad", "vad_threshold", "verbose", "batch_size", "
                    "extra_models", "stream", "only_ffmpeg", "dynamic_heads", "gap_padding", "time_scale", "demucs", "demucs_options")
 
 
+# ... of which these act here (or are pure UI); every other key that is SET to a non-default value is warned about once
+_HONOURED = frozenset(("regroup", "vad", "vad_threshold", "suppress_silence", "verbose", "batch_size", "progress_callback",
+                       "check_sorted", "ignore_compatibility"))
+# stable-ts's own defaults (transcribe_stable signature): passing them changes nothing there either
+_STABLE_TS_DEFAULTS = {"suppress_word_ts": True, "use_word_position": True, "q_levels": 20, "k_size": 5, "min_word_dur": None,
+                       "nonspeech_error": 0.1, "only_voice_freq": False, "nonspeech_skip": 5.0, "min_silence_dur": None,
+                       "stream": None, "only_ffmpeg": False, "dynamic_heads": None, "gap_padding": " ...", "time_scale": None}
+
+
 def _srt_time(t: float) -> str:
     ms = int(round(max(0.0, float(t)) * 1000.0))
     h, ms = divmod(ms, 3600000)
@@ -177,6 +186,9 @@ class HipStableWhisperModel:
         from .whisper_model import _KNOWN
         p = dict(params)
         stable = {k: p.pop(k) for k in _STABLE_TS_KEYS if k in p}
+        for k, v in stable.items():     # stable-ts features that are not reproduced: say so once instead of changing behaviour silently
+            if k not in _HONOURED and v not in (None, False, {}, [], ()) and v != _STABLE_TS_DEFAULTS.get(k, None):
+                self._warn_once("ignored:" + k, f"transcribe({k}={v!r}): a stable-ts option this shim does not implement; it has no effect here")
         # names stable-ts (and faster-whisper's older signatures) accept for the same thing
         if "logprob_threshold" in p:
             p["log_prob_threshold"] = p.pop("logprob_threshold")

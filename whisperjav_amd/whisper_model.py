@@ -326,6 +326,13 @@ class HipWhisperModel:
             tok = os.path.join(path, "tokenizer.json")
             if os.path.exists(tok):
                 self.tokenizer = HfTokenizer(tok)
+            if os.path.exists(os.path.join(path, "model.bin")):       # a CTranslate2 conversion: what faster_whisper.WhisperModel opens
+                from . import ct2_format                                # (faster_whisper_pro_asr.py:246-253)
+                dims, sd, extras = ct2_format.load_ct2_whisper(path)
+                if extras.get("alignment_heads"):
+                    self._alignment_heads = list(extras["alignment_heads"])
+                self._ct2_extras = extras
+                return dims, sd
             for name in ("model.pt", "whisper.pt"):
                 cand = os.path.join(path, name)
                 if os.path.exists(cand):
@@ -337,10 +344,14 @@ class HipWhisperModel:
                 if extras.get("alignment_heads"):
                     self._alignment_heads = list(extras["alignment_heads"])
                 return dims, sd
-            raise FileNotFoundError(f"{path} holds neither an openai-format checkpoint (model.pt) nor a Hugging Face "
-                                    "one (config.json + model.safetensors); see INTEGRATION.md")
+            raise FileNotFoundError(f"{path} holds neither a CTranslate2 conversion (model.bin), an openai-format checkpoint "
+                                    "(model.pt) nor a Hugging Face one (config.json + model.safetensors); see INTEGRATION.md")
         if os.path.isfile(path):
             return W.load_openai_checkpoint(path)
+        from . import ct2_format
+        cached = ct2_format.resolve_cached_model(path)      # "large-v3" -> Systran/faster-whisper-large-v3 in the local HF cache
+        if cached is not None and os.path.exists(os.path.join(cached, "model.bin")):
+            return self._load_checkpoint(cached)
         raise FileNotFoundError(
             f"model {path!r}: no local checkpoint found and this environment has no network; pass weights=/dims= "
             "(e.g. whisperjav_amd.weights.synth_weights) or a directory with model.pt + tokenizer.json")
