@@ -855,10 +855,10 @@ def test_alignment_matches_oracle(hip, dtype, prefill):
     # and the start frames are recorded.  r05 root cause run: scripts/diag_align.py, profiles/r05_diag_align.jsonl
     if dtype == "float16":
         assert worst_t == 0, worst_t
-        assert worst_m < 0.5 and worst_x < 1e-3, (worst_m, worst_x)
+        assert worst_m < 0.02 and worst_x < 1e-6, (worst_m, worst_x)        # measured 3.9e-3 / 0 (profiles/r05_parity_diag_pipeline.jsonl)
     elif dtype == "bfloat16":
-        assert worst_m < 2.0 and worst_x < 5e-2, (worst_m, worst_x)
-        assert worst_t <= 25, worst_t
+        assert worst_m < 0.15 and worst_x < 1e-4, (worst_m, worst_x)        # measured 4.0e-2 / 4.3e-6
+        assert worst_t <= 25, worst_t                                       # measured 10: recorded, the near-tie bound above is the bar
     model.close()
 
 
@@ -1063,8 +1063,8 @@ def test_large_v3_geometry_beam_and_alignment_consistency(hip, dtype):
                                    "path_excess_per_cell_on_the_other_matrix": worst_x})
     if dtype == "float16":
         assert worst == 0, worst
-    assert worst_m < (0.5 if dtype == "float16" else 2.0), worst_m
-    assert worst_x < (1e-3 if dtype == "float16" else 5e-2), worst_x
+    assert worst_m < (0.02 if dtype == "float16" else 0.15), worst_m         # measured 5.7e-3 / 4.4e-2
+    assert worst_x < (1e-6 if dtype == "float16" else 1e-3), worst_x         # measured 0 / 1.3e-4
     model.close()
 
 
