@@ -246,3 +246,81 @@ def reference_probs(archive, audio: np.ndarray, window: int = 1536, sr: int = 16
                 chunk = F.pad(chunk, (0, window - len(chunk)))
             out.append(float(model(chunk, sr).item()))
     return np.asarray(out, dtype=np.float32)
+
+
+def get_speech_timestamps(audio: torch.Tensor, model, threshold: float = 0.5, sampling_rate: int = 16000, min_speech_duration_ms: int = 250,
+                          min_silence_duration_ms: int = 100, window_size_samples: int = 1536, speech_pad_ms: int = 30,
+                          return_seconds: bool = False):
+    """Stand-in for the hub archive's ``utils_vad.get_speech_timestamps`` at the v3.1 / v4.0 tags (the function the reference
+    unpacks from ``torch.hub.load``'s utils and calls at backends/silero.py:258-273): reset the model, score consecutive
+    zero-padded windows with ``model(chunk, sampling_rate).item()``, then the trigger / temp_end state machine with
+    ``neg_threshold = threshold - 0.15`` and the symmetric padding pass.  Restated from the published source."""
+    if not torch.is_tensor(audio):
+        audio = torch.Tensor(audio)
+    if len(audio.shape) > 1:
+        audio = audio.squeeze()
+    model.reset_states()
+    min_speech_samples = sampling_rate * min_speech_duration_ms / 1000
+    min_silence_samples = sampling_rate * min_silence_duration_ms / 1000
+    speech_pad_samples = sampling_rate * speech_pad_ms / 1000
+    audio_length_samples = len(audio)
+    speech_probs = []
+    for current_start_sample in range(0, audio_length_samples, window_size_samples):
+        chunk = audio[current_start_sample: current_start_sample + window_size_samples]
+        if len(chunk) < window_size_samples:
+            chunk = F.pad(chunk, (0, int(window_size_samples - len(chunk))))
+        speech_probs.append(model(chunk, sampling_rate).item())
+    triggered = False
+    speeches = []
+    current_speech = {}
+    neg_threshold = threshold - 0.15
+    temp_end = 0
+    for i, speech_prob in enumerate(speech_probs):
+        if (speech_prob >= threshold) and temp_end:
+            temp_end = 0
+        if (speech_prob >= threshold) and not triggered:
+            triggered = True
+            current_speech["start"] = window_size_samples * i
+            continue
+        if (speech_prob < neg_threshold) and triggered:
+            if not temp_end:
+                temp_end = window_size_samples * i
+            if (window_size_samples * i) - temp_end < min_silence_samples:
+                continue
+            current_speech["end"] = temp_end
+            if (current_speech["end"] - current_speech["start"]) > min_speech_samples:
+                speeches.append(current_speech)
+            temp_end = 0
+            current_speech = {}
+            triggered = False
+            continue
+    if current_speech and (audio_length_samples - current_speech["start"]) > min_speech_samples:
+        current_speech["end"] = audio_length_samples
+        speeches.append(current_speech)
+    for i, speech in enumerate(speeches):
+        if i == 0:
+            speech["start"] = int(max(0, speech["start"] - speech_pad_samples))
+        if i != len(speeches) - 1:
+            silence_duration = speeches[i + 1]["start"] - speech["end"]
+            if silence_duration < 2 * speech_pad_samples:
+                speech["end"] += int(silence_duration // 2)
+                speeches[i + 1]["start"] = int(max(0, speeches[i + 1]["start"] - silence_duration // 2))
+            else:
+                speech["end"] = int(min(audio_length_samples, speech["end"] + speech_pad_samples))
+                speeches[i + 1]["start"] = int(max(0, speeches[i + 1]["start"] - speech_pad_samples))
+        else:
+            speech["end"] = int(min(audio_length_samples, speech["end"] + speech_pad_samples))
+    if return_seconds:
+        for speech in speeches:
+            speech["start"] = round(speech["start"] / sampling_rate, 1)
+            speech["end"] = round(speech["end"] / sampling_rate, 1)
+    return speeches
+
+
+def bursty_audio(seconds: float, seed: int = 3, gaps=((2.0, 4.5), (7.0, 8.0), (12.0, 15.5))) -> np.ndarray:
+    """Speech-like audio with near-silent stretches (x 0.002), so the stand-in's probabilities cross the thresholds."""
+    from whisperjav_amd import synth
+    a = synth.speech_like(seconds, seed=seed).copy()
+    for s, e in gaps:
+        a[int(s * 16000): int(e * 16000)] *= 0.002
+    return a

@@ -1,0 +1,103 @@
+"""The reference's DEFAULT segmenter network on the device: a TorchScript archive of the silero v3.1 / v4.0
+structure (tests/silero_standin.py -- the real hub archive is unobtainable offline) is lowered by whisperjav_amd/vad_graph.py
+and run by csrc/vadgraph.hip; the device probabilities are compared with THE SAME ARCHIVE executed by torch.jit on the CPU
+(bar: 1e-5, as for the v6 scorer), the regions through the archive's own get_speech_timestamps (the reference's call,
+/root/reference/whisperjav/modules/speech_segmentation/backends/silero.py:258-273), bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from tests import silero_standin as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _streams():
+    a = S.bursty_audio(24.0, seed=3)
+    b = S.bursty_audio(9.3, seed=4, gaps=((1.0, 2.2), (5.0, 6.4)))
+    return [a, b[: 16000 * 9 + 777], a[5000: 5000 + 1536 * 3], b[:1000], a[16000 * 10: 16000 * 21 + 5]]
+
+
+@pytest.mark.parametrize("variant", ["v4", "v3"])
+@pytest.mark.parametrize("window", [1536, 512])
+def test_device_probabilities_equal_the_archive_on_the_cpu(hip, variant, window):
+    """Five ragged streams in ONE call (a stream shorter than a window, lengths that are and are not multiples of it), state
+    carried per stream and reset between streams, host clips and HBM-resident clips: <= 1e-5 on every window probability."""
+    from whisperjav_amd import vad_graph
+    archive = S.build(variant, seed=7)
+    scorer = vad_graph.HipGraphVadScorer(archive, window=window)
+    clips = _streams()
+    got = scorer.scores(clips)
+    worst = 0.0
+    for c, g in zip(clips, got):
+        ref = S.reference_probs(archive, c, window)
+        assert g.shape == ref.shape
+        worst = max(worst, float(np.abs(g - ref).max()))
+    assert worst < 1e-5, worst
+    dev = scorer.scores([torch.from_numpy(c).cuda() for c in clips])
+    assert all(np.array_equal(a, b) for a, b in zip(dev, got))
+    again = scorer.scores(list(reversed(clips)))              # stream order / neighbours do not matter
+    assert all(np.array_equal(a, b) for a, b in zip(reversed(again), got))
+    scorer.close()
+
+
+def test_streams_that_straddle_launch_groups_carry_their_state(hip):
+    """max_windows_per_launch smaller than a stream: its windows are split over several launch groups, the LSTM state row
+    carries it across them -- identical (bit for bit) to the single-group run."""
+    from whisperjav_amd import vad_graph
+    archive = S.build("v4", seed=7)
+    clips = _streams()
+    one = vad_graph.HipGraphVadScorer(archive, window=1536)
+    ref = one.scores(clips)
+    one.close()
+    for cap in (7, 64):
+        small = vad_graph.HipGraphVadScorer(archive, window=1536, max_windows_per_launch=cap)
+        got = small.scores(clips)
+        small.close()
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref)), cap
+
+
+@pytest.mark.parametrize("route", ["hub_pair", "archive_file"])
+def test_default_segmenter_scores_on_the_device(hip, tmp_path, route):
+    """``HipSileroSpeechSegmenter(version="v3.1", ...)`` with the archive's network ON THE DEVICE: through ``scorer=(model,
+    utils)`` -- what torch.hub.load returns; the regions come from the archive's own get_speech_timestamps fed by a replay of the
+    device probabilities -- and through ``weights_path=<archive>`` (regions from the restated v3.1 / v4.0 state machine).  Both
+    must give the segments of the reference's procedure run on the host: the archive's get_speech_timestamps over the JIT model,
+    then the reference's sample padding / overlap fix / grouping; ``segment_many`` scores all scenes in one launch group."""
+    from whisperjav_amd import segmenters
+    archive = S.build("v4", seed=7)
+    utils = (S.get_speech_timestamps, None, None, None, None)
+    if route == "hub_pair":
+        seg = segmenters.HipSileroSpeechSegmenter(version="v3.1", scorer=(archive, utils), threshold=0.5, min_silence_duration_ms=300)
+    else:
+        path = S.save(str(tmp_path / "model.jit"), "v4", seed=7)
+        seg = segmenters.HipSileroSpeechSegmenter(version="v3.1", weights_path=path, threshold=0.5, min_silence_duration_ms=300)
+    host = segmenters.HipSileroSpeechSegmenter(version="v3.1", scorer=(archive, utils), threshold=0.5, min_silence_duration_ms=300,
+                                               device_scoring=False)                      # round 4's host scoring: the yardstick
+    clips = _streams()[:2] + [_streams()[4]]
+    pooled = seg.segment_many(clips, 16000)
+    assert seg.name == "silero-v3.1-hip+graph" and "lowered" in seg.display_name and host.name.endswith("+hostnet")
+    n_seg = 0
+    for c, got in zip(clips, pooled):
+        want = host.segment(c, sample_rate=16000)
+        key = lambda r: [(s.start_sample, s.end_sample) for s in r.segments]       # noqa: E731
+        assert key(got) == key(want) and len(got.groups) == len(want.groups)
+        assert key(seg.segment(c, sample_rate=16000)) == key(want)
+        assert key(seg.segment(torch.from_numpy(c).cuda(), sample_rate=16000)) == key(want)
+        n_seg += len(want.segments)
+    assert n_seg >= 4
+    seg.cleanup()
+
+
+def test_unsupported_graphs_are_refused_before_any_audio(hip):
+    from whisperjav_amd import segmenters, vad_graph
+    import torch.nn as nn
+
+    class Odd(nn.Module):
+        def forward(self, x: torch.Tensor, sr: int) -> torch.Tensor:
+            return torch.softmax(x.view(1, -1), dim=1)[:, :1]
+
+    m = torch.jit.script(Odd().eval())
+    seg = segmenters.HipSileroSpeechSegmenter(version="v3.1", scorer=(m, (S.get_speech_timestamps,)))
+    with pytest.raises(vad_graph.LoweringError, match="aten::softmax"):
+        seg.segment(np.zeros(16000, dtype=np.float32), sample_rate=16000)

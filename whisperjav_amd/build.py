@@ -16,7 +16,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libwjhip.so"
-SOURCES = ["engine.hip", "gemm.hip", "attention.hip", "norm.hip", "sampler.hip", "logmel.hip", "vad.hip", "align.hip", "comm.hip", "qwen.hip", "qwen_audio.hip"]
+SOURCES = ["engine.hip", "gemm.hip", "attention.hip", "norm.hip", "sampler.hip", "logmel.hip", "vad.hip", "vadgraph.hip", "align.hip", "comm.hip", "qwen.hip", "qwen_audio.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "../../include/wjhip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 # attention.hip: MFMA results feed VALU softmax code every key tile; with accumulators in AGPRs the compiler emits

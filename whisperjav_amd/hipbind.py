@@ -111,6 +111,9 @@ _SIGNATURES = {
     "wj_vad_create": (_I, [_P, C.POINTER(_F), _I64, C.POINTER(_P)]),
     "wj_vad_free": (_I, [_P]),
     "wj_vad_scores": (_I, [_P, _P, C.POINTER(_I64), C.POINTER(_I64), _I, _P, _P]),
+    "wj_vadg_create": (_I, [_P, C.POINTER(C.c_int32), _I, _I, C.POINTER(_F), _I64, C.POINTER(_F), _I, _I64, _I, _I, _I, _I, C.POINTER(_P)]),
+    "wj_vadg_free": (_I, [_P]),
+    "wj_vadg_scores": (_I, [_P, _P, C.POINTER(_I64), C.POINTER(_I64), _I, _P, _P]),
     "wj_comm_unique_id": (_I, [C.c_char_p]),
     "wj_comm_init": (_I, [_P, _I, _I, C.c_char_p, C.POINTER(_P)]),
     "wj_bcast_weights": (_I, [_P, _P, _I64, _I, _P]),

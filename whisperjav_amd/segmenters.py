@@ -282,8 +282,15 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
                  max_group_duration_s: Optional[float] = None, max_speech_duration_s: Optional[float] = None,
                  start_pad_samples: int = 11200, end_pad_samples: int = 20800,
                  weights: Union[Dict[str, np.ndarray], str, None] = None, device: int = 0,
-                 weights_path: Optional[str] = None, network: Optional[str] = None, scorer: Any = None, **kwargs):
+                 weights_path: Optional[str] = None, network: Optional[str] = None, scorer: Any = None,
+                 device_scoring: Optional[bool] = None, window_size_samples: Optional[int] = None, **kwargs):
         self._weights_path = weights_path
+        # round 5: a TorchScript archive (weights_path=<model.jit>, or the model of scorer=) is LOWERED onto the device
+        # (vad_graph.py).  device_scoring: None = lower whenever the model is a TorchScript module (a graph outside the loader's
+        # op table raises LoweringError), True = require it, False = round 4's host scoring through the archive's own loop
+        self._device_scoring = device_scoring
+        self._window = int(window_size_samples) if window_size_samples else None
+        self._graph_scorer = None
         if network not in (None, "v6", "v5/v6"):
             raise ValueError("network must be None (the version's own network: no HIP kernel, refuses) or 'v6'")
         if scorer is not None and network:
@@ -317,12 +324,16 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
 
     @property
     def name(self) -> str:
+        if self._graph_scorer is not None or (self._scorer is None and self._is_archive_path()):
+            return f"silero-{self.version}-hip+graph"
         return f"silero-{self.version}-hip" + ("+v6net" if self.network else "+hostnet" if self._scorer is not None else "")
 
     @property
     def display_name(self) -> str:
         if self.network:
             return f"Silero VAD {self.version} call contract over the v6 network (MI355X HIP)"
+        if self._graph_scorer is not None or (self._scorer is None and self._is_archive_path()):
+            return f"Silero VAD {self.version} (the archive's own network lowered onto the MI355X: TorchScript graph -> HIP)"
         if self._scorer is not None:
             return f"Silero VAD {self.version} (the reference's own network scoring on the host; MI355X HIP downstream)"
         return f"Silero VAD {self.version} (MI355X HIP; no kernel for this network: refuses to score)"
@@ -330,7 +341,11 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
     @property
     def can_score(self) -> bool:
         """False = ``segment`` would refuse (no HIP kernel for this network, no scorer seam, no v6 substitution asked for)."""
-        return self.network is not None or self._scorer is not None or self._model is not None
+        return self.network is not None or self._scorer is not None or self._model is not None or self._is_archive_path()
+
+    def _is_archive_path(self) -> bool:
+        p = self._weights_path or (self._weights if isinstance(self._weights, str) and self._weights != "synthetic" else None)
+        return bool(p) and self.network is None and not str(p).lower().endswith((".npz", ".safetensors"))
 
     def _resolve_scorer(self) -> None:
         sc = self._scorer
@@ -348,10 +363,57 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
             raise TypeError("scorer: no callable get_speech_timestamps found")
         self._model, self._get_speech_timestamps = model, gst
         self._host_scorer = True
+        self._lower_if_scripted(model, gst)
+
+    def _lower_if_scripted(self, model: Any, gst: Any) -> None:
+        """The archive's network on the device: lower its graph (vad_graph.lower) and keep the archive's own
+        ``get_speech_timestamps`` for the regions -- it is handed a replay model that answers its ``model(chunk, sr)`` calls
+        from the probabilities the device computed for the same window grid."""
+        import torch
+        if self._device_scoring is False:
+            return
+        scripted = isinstance(model, (torch.jit.ScriptModule, torch.jit.RecursiveScriptModule))
+        if not scripted:
+            if self._device_scoring:
+                from .hipbind import WjError
+                raise WjError(f"silero-{self.version}-hip: device_scoring=True needs a TorchScript model to lower, got {type(model).__name__}")
+            return
+        from . import vad_graph
+        window = self._window
+        if window is None and gst is not None:
+            try:
+                import inspect
+                window = int(inspect.signature(gst).parameters["window_size_samples"].default)
+            except Exception:
+                window = None
+        self._window = int(window or 1536)       # utils_vad.get_speech_timestamps' default grid for the v3.1 / v4.0 hub archives
+        self._graph_scorer = vad_graph.HipGraphVadScorer(model, window=self._window, sample_rate=VAD_SR, device=self._device)
+        self._host_scorer = False
+        self._archive_gst = gst
 
     def _ensure_model(self) -> None:
         if self._model is None and self._scorer is not None:
             self._resolve_scorer()
+            return
+        if self._model is None and self._is_archive_path():
+            from . import vad, vad_graph, vad_weights
+            path = str(self._weights_path or self._weights)
+            archive = vad_graph.load_archive(path)
+            try:
+                generation = vad_weights.classify_state_dict(archive.state_dict())
+            except ValueError:
+                generation = "unknown"
+            if generation == "v5/v6":
+                from .hipbind import WjError
+                raise WjError(f"{path} is a Silero v5/v6 archive (512-sample windows): use 'silero-v6.2-hip' for it, or network='v6' to "
+                              f"run it behind the {self.version} call contract knowingly")
+            self._model = archive
+            self._lower_if_scripted(archive, None)
+            if self._graph_scorer is None:
+                from .hipbind import WjError
+                raise WjError(f"silero-{self.version}-hip: weights_path={path!r} with device_scoring=False: host scoring needs scorer=(model, "
+                              "get_speech_timestamps)")
+            self._get_speech_timestamps = vad.get_speech_timestamps
             return
         if self._model is None and self.network is None:
             from .hipbind import WjError
@@ -361,6 +423,53 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
                 "v5/v6 network, its own thresholds), or pass network='v6' to run the v6 scorer behind the "
                 f"{self.version} call contract knowingly; vad_weights.from_torchscript(path) identifies an archive.")
         super()._ensure_model()
+
+    def _graph_regions(self, audio16, probs, threshold, min_speech, min_silence, pad_ms) -> List[Dict[str, int]]:
+        """Window probabilities from the lowered archive (one launch group; ``probs`` when ``segment_many`` scored the pool
+        already) -> regions: through the archive's own ``get_speech_timestamps`` when the caller handed it over (scorer=), else
+        through the v3.1 / v4.0 state machine restated in ``vad.regions_from_probs`` (no speech cap, lower threshold =
+        threshold - 0.15 as utils_vad has it for these versions)."""
+        from . import vad
+        n = int(audio16.numel()) if _on_device(audio16) else int(len(audio16))
+        if n == 0:
+            return []
+        if probs is None:
+            probs = self._graph_scorer.scores([audio16])[0]
+        gst = getattr(self, "_archive_gst", None)
+        if gst is not None:
+            import torch
+            kw = dict(sampling_rate=VAD_SR, threshold=threshold, min_speech_duration_ms=min_speech, min_silence_duration_ms=min_silence,
+                      speech_pad_ms=pad_ms)
+            try:
+                import inspect
+                if "window_size_samples" in inspect.signature(gst).parameters:
+                    kw["window_size_samples"] = self._window
+            except (TypeError, ValueError):
+                pass
+            # the loop only needs the clip's LENGTH (it slices windows and hands them to the model): zeros of the same length
+            return [dict(ts) for ts in gst(torch.zeros(n, dtype=torch.float32), _ReplayModel(probs, self._window), **kw)]
+        return vad.regions_from_probs(probs, n, threshold=threshold, sampling_rate=VAD_SR, min_speech_duration_ms=min_speech,
+                                      max_speech_duration_s=float("inf"), min_silence_duration_ms=min_silence, speech_pad_ms=pad_ms,
+                                      neg_threshold=threshold - 0.15, window=self._window)
+
+    def segment_many(self, audios, sample_rates) -> List["SegmentationResult"]:
+        self._ensure_model()
+        if self._graph_scorer is None:
+            return super().segment_many(audios, sample_rates)
+        if isinstance(sample_rates, int):
+            sample_rates = [sample_rates] * len(audios)
+        if not all((isinstance(a, np.ndarray) or _on_device(a)) and sr == VAD_SR for a, sr in zip(audios, sample_rates)):
+            return [self.segment(a, sample_rate=sr) for a, sr in zip(audios, sample_rates)]
+        probs = self._graph_scorer.scores(list(audios))       # every scene a stream of ONE launch group
+        return [self.segment(a, sample_rate=sr, _probs=p) for a, sr, p in zip(audios, sample_rates, probs)]
+
+    def cleanup(self) -> None:
+        g, self._graph_scorer = self._graph_scorer, None
+        if g is not None:
+            g.close()
+        if self._model is not None and not hasattr(self._model, "close"):
+            self._model = None
+        super().cleanup()
 
     def _get_parameters(self) -> Dict[str, Any]:
         return {k: getattr(self, k) for k in (
@@ -380,7 +489,9 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
         if _on_device(data) and (sr != VAD_SR or getattr(self, "_host_scorer", False)):
             data = data.detach().cpu().numpy()
         audio16 = data if _on_device(data) else np.asarray(_resample(data, sr, VAD_SR), dtype=np.float32)
-        if getattr(self, "_host_scorer", False):
+        if self._graph_scorer is not None:
+            stamps = self._graph_regions(audio16, kwargs.get("_probs"), threshold, min_speech, min_silence, pad_ms)
+        elif getattr(self, "_host_scorer", False):
             # the reference's own call (backends/silero.py:258-273): a host FloatTensor, the archive's get_speech_timestamps,
             # the four keyword arguments the v3.1 / v4.0 API takes -- the network's 1536-sample windows and state live in there
             import torch
@@ -410,6 +521,28 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
         groups = group_segments(segments, self.max_group_duration_s, self.chunk_threshold_s)
         return SegmentationResult(segments=segments, groups=groups, method=self.name, audio_duration_sec=duration,
                                   parameters=self._get_parameters(), processing_time_sec=time.time() - t0)
+
+
+class _ReplayModel:
+    """What the archive's ``get_speech_timestamps`` sees in place of the JIT model when the network ran on the device: its
+    ``model(chunk, sr)`` calls are answered, in order, from the device's probabilities for the same window grid."""
+
+    def __init__(self, probs: np.ndarray, window: int):
+        self._probs, self._window, self._i = np.asarray(probs, dtype=np.float32), int(window), 0
+
+    def reset_states(self) -> None:
+        self._i = 0
+
+    def __call__(self, chunk, sr=VAD_SR):
+        import torch
+        if int(chunk.shape[-1]) != self._window:
+            raise ValueError(f"the archive's get_speech_timestamps scores {int(chunk.shape[-1])}-sample windows, the device scored "
+                             f"{self._window}-sample ones: pass window_size_samples={int(chunk.shape[-1])}")
+        if self._i >= len(self._probs):
+            raise IndexError(f"the archive's get_speech_timestamps asks for window {self._i} of {len(self._probs)}")
+        p = float(self._probs[self._i])
+        self._i += 1
+        return torch.tensor(p)
 
 
 class NullSpeechSegmenter:

@@ -176,9 +176,12 @@ class _Lowerer:
             hit = (off, a)
         return Sym(SPACE_CONST, hit[0], tuple(a.shape), _contig(a.shape))
 
-    def operand(self, v: Any) -> Sym:
+    def operand(self, v: Any, state_ok: bool = False) -> Sym:
         if isinstance(v, Sym):
-            return self.replaced.get(v, v)
+            v = self.replaced.get(v, v)
+            if v.space == SPACE_STATE and not state_ok:      # state changes window by window: only the sequential LSTM kernel may read it
+                raise LoweringError("module state is read by an op other than the LSTM's initial state")
+            return v
         if isinstance(v, torch.Tensor):
             return self.const(v)
         raise LoweringError(f"a tensor operand was expected, got {type(v).__name__}")
@@ -328,7 +331,7 @@ class _Lowerer:
                     raise LoweringError(f"LSTM initial {name} of shape {tuple(s.shape)}, {want} expected")
                 src.append(("const", s))
             else:
-                s = self.operand(s)
+                s = self.operand(s, state_ok=True)
                 if s.space != SPACE_STATE or s.shape != want or not s.is_contiguous():
                     raise LoweringError(f"the LSTM's initial {name} is computed from the input (only module state or constants are lowered)")
                 src.append(("state", s))
@@ -393,7 +396,7 @@ class _Lowerer:
         extra = [k for k, v in writes.items() if self.replaced.get(v, v) not in (hn, cn)]
         if extra:
             raise LoweringError(f"module attribute {extra[0][1]!r} keeps a tensor that is not LSTM state")
-        self.prog.words[self._lstm_word_pos - 2: self._lstm_word_pos] = slots
+        self.prog.words[self._lstm_word_pos: self._lstm_word_pos + 2] = slots
         self.prog.state_floats = sum(int(np.prod(s[1])) for s in self.state_slots.values())
 
     def _attr(self, obj: Any, name: str) -> Any:
@@ -501,7 +504,14 @@ class _Lowerer:
             raise LoweringError(f"op {kind} is not lowered ({self._where(n)})")
         try:
             with torch.no_grad():
-                res = getattr(torch.ops.aten, name)(*ins)
+                packet = getattr(torch.ops.aten, name)
+                try:        # bind by the node's own schema: TorchScript passes keyword-only arguments positionally
+                    schema = torch._C.parse_schema(n.schema())
+                    args = [v for a, v in zip(schema.arguments, ins) if not a.kwarg_only]
+                    kwargs = {a.name: v for a, v in zip(schema.arguments, ins) if a.kwarg_only}
+                    res = getattr(packet, schema.overload_name or "default")(*args, **kwargs)
+                except (RuntimeError, AttributeError, TypeError):
+                    res = packet(*ins)
         except Exception as e:
             fn = _SCALAR_OPS.get(kind)
             if fn is not None:
@@ -527,38 +537,38 @@ class _Lowerer:
 
         # shape queries
         if base == "aten::size":
-            s = self.operand(x).shape
+            s = self.operand(x, state_ok=True).shape
             return (list(s) if len(ins) == 1 else s[ins[1]],)
         if base == "aten::dim":
-            return (len(self.operand(x).shape),)
+            return (len(self.operand(x, state_ok=True).shape),)
         if base == "aten::numel":
-            return (self.operand(x).numel,)
+            return (self.operand(x, state_ok=True).numel,)
         if base == "aten::len":
-            return (self.operand(x).shape[0],)
+            return (self.operand(x, state_ok=True).shape[0],)
         if base in ("aten::is_floating_point",):
             return (True,)
         # views
         if base == "aten::unsqueeze":
-            s = self.operand(x)
+            s = self.operand(x, state_ok=True)
             d = ins[1] % (len(s.shape) + 1)
             return (Sym(s.space, s.offset, (*s.shape[:d], 1, *s.shape[d:]), (*s.strides[:d], 0, *s.strides[d:])),)
         if base == "aten::squeeze":
-            s = self.operand(x)
+            s = self.operand(x, state_ok=True)
             dims = range(len(s.shape)) if len(ins) == 1 else [ins[1] % len(s.shape)] if isinstance(ins[1], int) else [d % len(s.shape) for d in ins[1]]
             keep = [i for i in range(len(s.shape)) if not (i in dims and s.shape[i] == 1)]
             return (Sym(s.space, s.offset, tuple(s.shape[i] for i in keep), tuple(s.strides[i] for i in keep)),)
         if base == "aten::permute":
-            s = self.operand(x)
+            s = self.operand(x, state_ok=True)
             p = [d % len(s.shape) for d in ins[1]]
             return (Sym(s.space, s.offset, tuple(s.shape[i] for i in p), tuple(s.strides[i] for i in p)),)
         if base in ("aten::transpose", "aten::t"):
-            s = self.operand(x)
+            s = self.operand(x, state_ok=True)
             a, b = (0, 1) if base == "aten::t" else (ins[1] % len(s.shape), ins[2] % len(s.shape))
             p = list(range(len(s.shape)))
             p[a], p[b] = p[b], p[a]
             return (Sym(s.space, s.offset, tuple(s.shape[i] for i in p), tuple(s.strides[i] for i in p)),)
         if base == "aten::slice":
-            s = self.operand(x)
+            s = self.operand(x, state_ok=True)
             d = (ins[1] if len(ins) > 1 and ins[1] is not None else 0) % len(s.shape)
             size = s.shape[d]
             start = 0 if len(ins) < 3 or ins[2] is None else ins[2]
@@ -571,7 +581,7 @@ class _Lowerer:
             shape[d], strides[d] = cnt, s.strides[d] * step
             return (Sym(s.space, s.offset + start * s.strides[d], tuple(shape), tuple(strides)),)
         if base == "aten::select":
-            s = self.operand(x)
+            s = self.operand(x, state_ok=True)
             d = ins[1] % len(s.shape)
             i = ins[2] % s.shape[d]
             return (Sym(s.space, s.offset + i * s.strides[d], s.shape[:d] + s.shape[d + 1:], s.strides[:d] + s.strides[d + 1:]),)
@@ -589,7 +599,7 @@ class _Lowerer:
                 raise LoweringError(f"{kind}: {s.shape} -> {shape} ({where})")
             return (Sym(s.space, s.offset, tuple(shape), _contig(shape)),)
         if base == "aten::expand":
-            s = self.operand(x)
+            s = self.operand(x, state_ok=True)
             shape = [s.shape[i - (len(ins[1]) - len(s.shape))] if d == -1 else d for i, d in enumerate(ins[1])]
             pad = len(shape) - len(s.shape)
             strides = [0] * pad + [0 if s.shape[i] == 1 and shape[pad + i] != 1 else s.strides[i] for i in range(len(s.shape))]

@@ -222,6 +222,47 @@ def apply_eot_ramp(dims: WhisperDims, w: Dict[str, np.ndarray], ramp: EotRamp, s
         plant_duration_cue(dims, w, rnd, seed, u, -ramp.slope * ramp.rate * sigma / beta)
 
 
+def sharpened_logits(dims: WhisperDims, w: Dict[str, np.ndarray], seed: int, ramp: EotRamp, s_logit: float, factor: float) -> Dict[str, np.ndarray]:
+    """The three tensors that turn ``synth_weights(..., eot=ramp, logit_std=s_logit)`` into the SAME model at temperature
+    ``1 / factor``: every logit (text, timestamps and the planted EOT ramp alike) is multiplied by ``factor``, so the arg-max at
+    every step is unchanged while the distributions become as peaked as a trained model's (per-token log-probs around -0.3
+    instead of -3 at factor ~ 2.5: what lets a hypothesis pass the reference's ``logprob_threshold = -1.0`` gate).  The final
+    LayerNorm's gain and bias are scaled; the EOT row of the tied embedding divides by the gain and the ramp's parameters
+    (slope, noise, cap, gain) scale with the logits, so the row, the damping of the block outputs and the duration cue are
+    unchanged; only the ramp's base level ``T`` (``EotRamp``: a function of the logit spread) moves the positional table's
+    component along the reserved direction.  Returns ``{name: array}`` for ``decoder.ln.weight``, ``decoder.ln.bias`` and
+    ``decoder.positional_embedding``; everything else is shared with ``w``."""
+    rng = np.random.default_rng([seed, 0xE07])
+    dt, L = dims.n_text_state, dims.n_text_layer
+    u = rng.standard_normal(dt)
+    u -= u.mean()
+    u /= np.linalg.norm(u)
+    sigma = 0.66 * np.sqrt(L)
+    beta = ramp.gain * sigma
+    level = lambda s_: max(4.3 * s_, np.log(1501.0) + 0.5 * s_ ** 2)       # noqa: E731
+    delta = level(s_logit * factor) / factor - level(s_logit)                # in units of the ORIGINAL logits
+    pos = w["decoder.positional_embedding"].astype(np.float64) + np.outer(np.full(dims.n_text_ctx, delta * sigma / beta), u)
+    return {"decoder.ln.weight": (w["decoder.ln.weight"] * np.float32(factor)).astype(np.float32),
+            "decoder.ln.bias": (w["decoder.ln.bias"] * np.float32(factor)).astype(np.float32),
+            "decoder.positional_embedding": pos.astype(np.float32)}
+
+
+def patch_blob_device(blob, offsets, dims: WhisperDims, updates: Dict[str, np.ndarray]):
+    """A copy of a packed device blob with some fp32 VECTOR / table tensors replaced (``decoder.ln.weight``,
+    ``decoder.ln.bias``, ``decoder.positional_embedding`` ...: the tensors ``engine_tensors`` stores as float32 in every compute
+    type).  A device-to-device clone plus a few KB of uploads instead of re-packing 6 GB."""
+    names = {"decoder.ln.weight": "DEC_LN_W", "decoder.ln.bias": "DEC_LN_B", "decoder.positional_embedding": "DEC_POS",
+             "encoder.positional_embedding": "ENC_POS", "encoder.ln_post.weight": "ENC_LNPOST_W", "encoder.ln_post.bias": "ENC_LNPOST_B"}
+    out = blob.clone()
+    for k, a in updates.items():
+        if k not in names:
+            raise KeyError(f"patch_blob_device: {k!r} is not one of the float32 global tensors {sorted(names)}")
+        off = int(offsets[GLOBAL_TENSORS.index(names[k])])
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).reshape(-1).view(torch.uint8).to(out.device)
+        out[off: off + t.numel()] = t
+    return out
+
+
 def plant_duration_cue(dims: WhisperDims, w: Dict[str, np.ndarray], rnd, seed: int, u: np.ndarray, per_second: float) -> None:
     """Let the synthetic model sense how much audio a window holds: adds ``per_second`` x (seconds of audio content in the
     window) to the ``u`` component of the decoder's residual stream (so with ``EotRamp.rate`` a 6 s clip ends ~``rate`` x 5
