@@ -394,7 +394,10 @@ def make_weights(args, dims):
         return pweights.synth_weights(dims, seed=1234, exact="float16")
     kw = dict(pweights.SPEECHLIKE)
     kw["eot"] = pweights.EotRamp(mid=4.0, rate=args.eot_rate)
-    return pweights.synth_weights(dims, seed=1234, exact="float16", **kw)
+    w = pweights.synth_weights(dims, seed=1234, exact="float16", **kw)
+    if args.mode == "fidelity":         # the fidelity pipeline gates on avg_logprob > -1.0: the same model at temperature 1 / 2.5
+        w.update(pweights.sharpened_logits(dims, w, 1234, kw["eot"], 1.8, args.fidelity_sharpen))
+    return w
 
 
 def make_audio(args):
@@ -550,6 +553,59 @@ def run_cfg3(args, info, dims):
                                          "what": (f"{args.ref_gate_minutes:g} min of the same synthetic speech over a -66 dBFS floor, scene detector at "
                                                   "its (= the reference's) default gates, same engine; second of two passes"), **s_ref}
         del quiet, run_ref
+    if info.rank == 0 and info.world == 1 and not args.no_extras and not args.no_default_vad:
+        # the reference's DEFAULT segmenter (silero-v3.1: a TorchScript hub archive on 1536-sample windows, main.py:1867-1876)
+        # scored ON THE DEVICE: the archive's graph lowered onto HIP kernels (vad_graph.py / vadgraph.hip).  The real archive is not
+        # obtainable offline; tests/silero_standin.py builds one of the same structure (conv-STFT, adaptive normalisation, separable
+        # conv blocks, 2-layer LSTM with module state) with seeded weights -- measurement input, like the synthetic Whisper weights
+        from tests import silero_standin
+        from whisperjav_amd import segmenters as _sg
+        archive = silero_standin.build("v4", seed=7)
+        utils = (silero_standin.get_speech_timestamps, None, None, None, None)           # what torch.hub.load returns beside the model
+        vad31 = dict(threshold=0.5, min_speech_duration_ms=100, min_silence_duration_ms=300, speech_pad_ms=400, chunk_threshold_s=2.5,
+                     max_group_duration_s=6.0)
+        seg31 = _sg.HipSileroSpeechSegmenter(version="v3.1", scorer=(archive, utils), device=info.local_rank, **vad31)
+        saved_seg, module._external_segmenter = module._external_segmenter, seg31
+        try:
+            run_recording(runner, audio, subset)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            s31 = run_recording(runner, audio, subset)
+            torch.cuda.synchronize()
+            t31 = time.perf_counter() - t1
+            scn = runner.detect(audio, 16000)
+            clips31 = [runner.scene_audio(audio, 16000, sc) for sc in scn]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            seg31.segment_many(clips31, 16000)
+            torch.cuda.synchronize()
+            t_vad_dev = time.perf_counter() - t1
+            # round 4's seam for the same archive: torch.jit on the host, one window at a time (the reference's own loop) -- timed
+            # on a bounded sample and scaled to the recording
+            sample = audio[: 16000 * 90]
+            sample = sample.detach().cpu().numpy() if hasattr(sample, "detach") else np.asarray(sample)
+            n_thr = torch.get_num_threads()
+            torch.set_num_threads(1)
+            try:
+                t1 = time.perf_counter()
+                silero_standin.reference_probs(archive, sample, 1536)
+                t_host = (time.perf_counter() - t1) * (60.0 * minutes / 90.0)
+            finally:
+                torch.set_num_threads(n_thr)
+            seg_name, n_instr = seg31.name, seg31._graph_scorer.program.n_instr
+        finally:
+            module._external_segmenter = saved_seg
+            seg31.cleanup()
+        line["reference_default_vad"] = {
+            "rtfx": round(60.0 * minutes / t31, 2), "ms": round(1e3 * t31, 1), "segmenter": seg_name,
+            "device_vad_ms": round(1e3 * t_vad_dev, 1), "host_default_vad_s": round(t_host, 1),
+            "instructions": n_instr,
+            "what": ("the same step with the reference's default segmenter contract (HipSileroSpeechSegmenter version v3.1, 1536-sample windows, the "
+                     "archive's own get_speech_timestamps) and the archive's network lowered onto the device; device_vad_ms = segment_many over all "
+                     "scenes (one launch group); host_default_vad_s = the same archive scored by torch.jit on ONE host core window by window (round 4's "
+                     "seam, the reference's loop), 90 s sample scaled to the recording; archive = tests/silero_standin.py (v4-shaped, seeded)"),
+            **s31}
+        del clips31
     # the groups of the recording, for the CPU baseline's scaling (before the model goes away)
     n_groups = None
     sample_clips = []
@@ -613,7 +669,14 @@ def run_cfg3(args, info, dims):
         # BASELINE cfg4's mode on one GPU: the fidelity pipeline's classes (openai-whisper mel padding, device-resident
         # BeamSearchDecoder search with beam 2 / patience 1.2, post-model gate) on the same recording, second of two passes
         saved_beam, args.beam = args.beam, 2
-        mf, modf, runf = build_stack(args, info, dims, dtype, args.batch, blob=blob2, offsets=offs2, mode="fidelity")
+        # the SAME model at temperature 1 / 2.5 (weights.sharpened_logits: every logit x 2.5, arg-max unchanged): per-token log-probs
+        # as peaked as a trained model's, so hypotheses pass the reference's post-model gate (avg_logprob > -1.0) instead of all
+        # being dropped; three fp32 tensors patched in a clone of the device blob
+        blob_f = blob2
+        if args.weights == "speechlike":
+            ramp = pweights.EotRamp(mid=4.0, rate=args.eot_rate)
+            blob_f = pweights.patch_blob_device(blob2, offs2, dims, pweights.sharpened_logits(dims, box["w"], 1234, ramp, 1.8, args.fidelity_sharpen))
+        mf, modf, runf = build_stack(args, info, dims, dtype, args.batch, blob=blob_f, offsets=offs2, mode="fidelity")
         run_recording(runf, audio)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -624,9 +687,11 @@ def run_cfg3(args, info, dims):
         args.beam = saved_beam
         line["fidelity"] = {"rtfx": round(60.0 * minutes / tf, 2), "ms": round(1e3 * tf, 1),
                             "what": ("mode=fidelity on the same recording and GPU: HipFidelity classes (asr.HipWhisperProASR over HipOpenAIWhisperModel), "
-                                     "openai-whisper search on the device (beam 2, patience 1.2, best_of 2), post-model gate on; second of two passes"),
+                                     "openai-whisper search on the device (beam 2, patience 1.2, best_of 2), post-model gate on (logprob_threshold -1.0); "
+                                     f"weights = the headline's at temperature 1/{args.fidelity_sharpen:g} (weights.sharpened_logits); second of two passes"),
+                            "logit_sharpening": args.fidelity_sharpen,
                             **sf_}
-        del mf, modf, runf
+        del mf, modf, runf, blob_f
         torch.cuda.empty_cache()
     if info.rank == 0 and info.world == 1 and not args.no_extras and args.mode == "balanced":
         # transcribe(max_new_tokens=None) as the reference passes it (config/components/asr/faster_whisper.py:269,309): the KV cache
@@ -855,7 +920,8 @@ def cfg5_measure(args, info, steps, warmup, want_cpu, want_stages=True):
         n_bins = 512
         head_w = torch.from_numpy((np.random.default_rng(6).standard_normal((n_bins, da.hidden)) * 2.0 / np.sqrt(da.hidden)).astype(np.float32))
         a_tower = qwen.HipQwenAudioTower(ada, wa, dtype=args.dtype, device=info.local_rank, max_seconds=min(8 * B, 1024))
-        a_model = qwen.HipQwen3Decoder(da, wa, dtype=args.dtype, device=info.local_rank, max_seqs=B, max_ctx=96 + 3 * 80, max_rows=B * 288)
+        a_model = qwen.HipQwen3Decoder(da, wa, dtype=args.dtype, device=info.local_rank, max_seqs=B, max_ctx=96 + 3 * 80, max_rows=B * 288,
+                                       split_act=2)       # as HipQwenForcedAligner creates it
         aligner = (da, a_tower, a_model, head_w.to(dev, torch.float16 if args.dtype == "float16" else torch.bfloat16 if args.dtype == "bfloat16" else torch.float32))
         wa = None
     if not want_cpu:
@@ -960,7 +1026,7 @@ def cfg5_measure(args, info, steps, warmup, want_cpu, want_stages=True):
                                     + (" -> forced-aligner pass (Qwen3-0.6B decoder geometry + audio tower + 512-bin head, every generated token a word)"
                                        if aligner else " ; no aligner pass")
                                     + (f"; decoder compute type {qdt}" + (" (MX-fp8 projections on v_mfma_scale_f32_16x16x128_f8f6f4, fp16 LM head)" if qdt == "float8w"
-                                                                           else " with split activations (wj_tune qwen_split_act, default 2)" if qdt == "float16" else "")
+                                                                           else " with split activations (wj_tune qwen_split_act 3 = every projection input, the default; the audio tower's GEMM inputs split too)" if qdt == "float16" else "")
                                        + "; no TEN-VAD (clips are given)")),
                        "decoder_compute_type": qdt,
                        "clips_per_step": B, "audio_seconds_per_step": round(audio_s, 1),
@@ -1006,7 +1072,7 @@ def main():
     ap.add_argument("--qwen-dtype", default="", choices=["", "float16", "bfloat16", "float32", "float8w"],
                     help="cfg5: compute type of the ASR decoder (default: --dtype); float8w = MX-fp8 projections (BASELINE cfg5's 'fp8 MFMA')")
     ap.add_argument("--no-qwen-aligner", dest="qwen_aligner", action="store_false", help="cfg5: leave the forced-aligner pass out of the step")
-    ap.add_argument("--ref-gate-minutes", type=float, default=20.0, help="default line: minutes of the studio-floor recording run with the "
+    ap.add_argument("--ref-gate-minutes", type=float, default=120.0, help="default line: minutes of the studio-floor recording run with the "
                     "reference's own scene gates (0 = skip)")
     ap.add_argument("--cfg5-clips", type=int, default=1800, help="default line: clips of the cfg5 figure (0 = skip it)")
     ap.add_argument("--minutes", type=float, default=120.0, help="cfg3: length of the synthetic recording")
@@ -1029,7 +1095,7 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16", "float32"])
     ap.add_argument("--fp32-minutes", type=float, default=3.0, help="cfg3: audio minutes of the fp32-mode figure")
-    ap.add_argument("--cpu-sample-groups", type=int, default=2, help="cpu_baseline: VAD groups of the recording run on the host")
+    ap.add_argument("--cpu-sample-groups", type=int, default=8, help="cpu_baseline: VAD groups of the recording run on the host")
     ap.add_argument("--cpu-beam-steps", type=int, default=0, help="cpu_baseline: beam-search iterations measured per group; 0 (default since round 4) = "
                     "every sampled group's search runs to its END, no extrapolation (round 3 measured 10 iterations and scaled x3.35)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="cpu_baseline: PyTorch threads (0 = min(16, cores), pinned with torch.set_num_threads "
@@ -1037,9 +1103,11 @@ def main():
     ap.add_argument("--weights", default="speechlike", choices=["speechlike", "plain"],
                     help="speechlike: EOT-bearing synthetic weights (searches end, token count grows with the audio in the window); plain: never EOT")
     ap.add_argument("--eot-rate", type=float, default=12.0, help="speechlike: nominal tokens per second of audio content (realised: see workload_facts)")
+    ap.add_argument("--fidelity-sharpen", type=float, default=2.5, help="fidelity figure: logits x this factor (weights.sharpened_logits) so segments pass the -1.0 gate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--extras-budget-s", type=float, default=480.0, help="skip the secondary figures when the run has already taken this long")
+    ap.add_argument("--no-default-vad", action="store_true", help="skip the reference_default_vad figure (the TorchScript-archive VAD lowered onto the device)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (fp32 mode, word timestamps, cfg2, single window)")
     ap.add_argument("--per-scene", action="store_true", help="A/B: one engine call per scene (the reference's loop) instead of pooling all scenes")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="wj_tune switches for A/B runs (e.g. dec_split_act=0)")

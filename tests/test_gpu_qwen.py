@@ -247,8 +247,8 @@ def _bf16_representable(w):
     return out
 
 
-@pytest.mark.parametrize("split", [2, 3])
-def test_published_geometry_one_clip(hip, split):
+@pytest.mark.parametrize("split", [3, 2])
+def test_published_geometry_one_clip_within_the_north_star_bar(hip, split):
     """Qwen3-ASR-1.7B's own dimensions (audio tower 24 x 1024 / conv 480, decoder 28 x 2048, 16 / 8 heads of 128, vocabulary
     151 936) on seeded bf16-representable weights with the EOS ramp, float16 on the device against the fp32 oracle, a 4 s clip
     decoded TO EOS.  Round 4 bar: tokens identical and every per-token log-prob within the north-star's
@@ -269,7 +269,7 @@ def test_published_geometry_one_clip(hip, split):
     try:
         model = qwen.HipQwen3Decoder(d, w, dtype="float16", max_seqs=1, max_ctx=256)
     finally:
-        hipbind.tune("qwen_split_act", 2)
+        hipbind.tune("qwen_split_act", 3)
     clip = synth.speech_like(4.0, seed=7)
     a = tower.encode([clip])[0]
     with torch.no_grad():
@@ -299,13 +299,15 @@ def test_published_geometry_one_clip(hip, split):
         f.write(json.dumps({"test": "qwen_published_geometry_f16", "split_mode": split, "audio_rel_err": err_a, "oracle_tokens": len(toks),
                             "logit_spread": float(ref_l.std()), **rows}) + "\n")
     print("published geometry:", err_a, rows)
-    assert err_a < 5e-3
-    # measured (profiles/r04_parity_diag_qwen.jsonl): split mode 2 (default) 1.02e-3 decoder / 1.28e-3 end to end over 33 tokens
-    # to EOS, tokens identical; mode 3 (every projection input split) is the one asserted to the north-star's 1e-3
+    # The north-star's bar, END TO END (device log-mel -> device tower -> device decoder against the fp32 oracle of all three), in the
+    # mode that ships and is benchmarked: split mode 3 (the default since round 5) with the tower's GEMM inputs split as well
+    # (qwen_tower_split, default on: embedding error 4.6e-4 -> ~1e-4 of their range, scripts/precision_qwen_tower.py).  Mode 2 (the
+    # round-4 default, kept as an A/B switch) is recorded with the bound it was measured at.
+    assert err_a < 2.5e-4, err_a
     bar = 1e-3 if split == 3 else 1.5e-3
     assert rows["decoder"]["identical"] and rows["decoder"]["max_logprob_err"] < bar, rows
     assert rows["decoder"]["steps"] < budget
-    assert rows["end_to_end"]["identical"] and rows["end_to_end"]["max_logprob_err"] < 2 * bar, rows
+    assert rows["end_to_end"]["identical"] and rows["end_to_end"]["max_logprob_err"] < bar, rows
     tower.close(); model.close()
 
 
@@ -530,17 +532,17 @@ def test_budget_is_cut_to_the_room_left_in_the_kv_cache(hip):
 @pytest.mark.parametrize("split", [3, 2, 1, 0])
 def test_float16_generation_to_eos_toy_model(hip, split):
     """float16 on fp16-representable weights, six sequences run to EOS on the TOY geometry (3 layers of 256).  With split
-    activations (wj_tune qwen_split_act 2, the default: o_proj / down_proj / LM head read [hi | lo] pairs, prompts included; 3:
+    activations (wj_tune qwen_split_act 2: o_proj / down_proj / LM head read [hi | lo] pairs, prompts included; 3, the default:
     every projection input) every sequence and its length must equal the fp32 oracle's and the per-token log-probs sit within
     4e-3 (measured 2.7e-3 at mode 2 against 1.3e-2 without the split).  The north-star's 1e-3 is asserted where the averaging
-    over 2048 hidden units exists -- test_published_geometry_one_clip (6.8e-4 at mode 3, 1.0e-3 at mode 2) -- a 256-wide
+    over 2048 hidden units exists -- test_published_geometry_one_clip_within_the_north_star_bar (mode 3, the default) -- a 256-wide
     model sums 8x fewer rounding errors per dot product and its logits are correspondingly noisier, as the Whisper toy model is."""
     from whisperjav_amd import hipbind
     hipbind.tune("qwen_split_act", split)
     try:
         d, ramp, w, oracle, model = _ramp_setup("float16", exact=True)      # noqa: F841
     finally:
-        hipbind.tune("qwen_split_act", 2)
+        hipbind.tune("qwen_split_act", 3)
     prompts = _ramp_prompts(d, ramp, np.random.default_rng(3))
     embeds = [model.prompt_embeddings(ids, audio) for ids, audio in prompts]
     logits = model.prefill(embeds, want_logits=True).cpu()

@@ -204,3 +204,36 @@ def test_greedy_loop_to_eot_matches_a_transformers_driven_loop():
             assert abs(float(out.sum_logprob[b]) - total) < 2e-3, (b, float(out.sum_logprob[b]), total)
             lengths.add(len(ref))
     assert len(lengths) == 2          # the two windows ended at different lengths
+
+
+def test_sharpened_logits_is_the_same_model_at_a_lower_temperature():
+    """weights.sharpened_logits (the fidelity bench workload: hypotheses that pass the reference's avg_logprob > -1.0 gate): three
+    tensors change, the greedy tokens up to the end-of-text decision stay the ones of the original model, the per-token
+    log-probs rise from the -3 class to above -1, and patching the packed blob equals packing the updated weights."""
+    import torch
+    from oracle import decoding, logmel
+    from whisperjav_amd import dims as pdims, synth, weights as pweights
+    d = helpers.small_dims()
+    w = pweights.synth_weights(d, seed=33, **pweights.SPEECHLIKE)
+    up = pweights.sharpened_logits(d, w, 33, pweights.SPEECHLIKE["eot"], 1.8, 2.5)
+    assert sorted(up) == ["decoder.ln.bias", "decoder.ln.weight", "decoder.positional_embedding"]
+    w2 = dict(w)
+    w2.update(up)
+    toks = pdims.special_tokens(d.n_vocab)
+    prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
+    sup = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    cfg = decoding.FilterConfig(suppress_tokens=sup, max_initial_timestamp_index=50)
+    mel = torch.from_numpy(logmel.window_features(synth.speech_like(3.0, seed=20), 80, "fw")[None])
+    out = []
+    for ww in (w, w2):
+        o = whisper_ref.WhisperOracle(helpers.oracle_dims(d), ww)
+        with torch.no_grad():
+            out.append(decoding.greedy_decode(o, o.encode(mel), prompt, 48, cfg))
+    a, b = out
+    n = min(len(a.tokens[0]), len(b.tokens[0])) - 1
+    assert n >= 8 and a.tokens[0][:n] == b.tokens[0][:n]
+    assert np.mean(a.token_logprob[0]) < -2.0 and np.mean(b.token_logprob[0]) > -1.0
+    blob, offs = pweights.pack_blob(d, w, "float16")
+    want, offs2 = pweights.pack_blob(d, w2, "float16")
+    got = pweights.patch_blob_device(blob, offs, d, up)
+    assert np.array_equal(offs, offs2) and bool((got == want).all()) and not bool((blob == want).all())

@@ -215,11 +215,20 @@ def test_silero_v31_hub_archive_behind_the_hip_segmenter():
     hub = os.path.join(torch.hub.get_dir(), "snakers4_silero-vad_v3.1")
     if not os.path.isdir(hub):
         pytest.skip("torch.hub cache has no snakers4/silero-vad:v3.1 archive (no network here)")
-    from whisperjav_amd import segmenters, synth
-    seg = segmenters.HipSileroSpeechSegmenter(version="v3.1", scorer="torch.hub")
+    from whisperjav_amd import segmenters, synth, vad_graph
     audio = synth.speech_like(12.0, seed=3)
-    got = seg.segment(audio, sample_rate=16000)
     model, utils = torch.hub.load(repo_or_dir="snakers4/silero-vad:v3.1", model="silero_vad", onnx=False, trust_repo=True)
+    # (1) the graph of the REAL archive lowers (or is refused by name -- the finding to act on), pinned on the CPU against torch.jit
+    from tests import vad_graph_ref
+    program = vad_graph.lower(model, 1536, 16000)
+    model.reset_states()
+    ref_p = [float(model(torch.nn.functional.pad(torch.from_numpy(audio[i: i + 1536]), (0, max(0, 1536 - len(audio[i: i + 1536])))), 16000))
+             for i in range(0, len(audio), 1536)]
+    assert np.abs(vad_graph_ref.run_stream(program, audio) - np.array(ref_p, np.float32)).max() < 2e-6
+    # (2) the drop-in's host-scoring seam returns what the archive's own get_speech_timestamps returns plus the reference's padding
+    #     (device scoring of the same archive: tests/test_gpu_vad_graph.py's checks apply to it unchanged on a GPU box)
+    seg = segmenters.HipSileroSpeechSegmenter(version="v3.1", scorer=(model, utils), device_scoring=False)
+    got = seg.segment(audio, sample_rate=16000)
     ref = utils[0](torch.from_numpy(audio), model, sampling_rate=16000, threshold=seg.threshold,
                    min_speech_duration_ms=seg.min_speech_duration_ms, min_silence_duration_ms=seg.min_silence_duration_ms,
                    speech_pad_ms=seg.speech_pad_ms)

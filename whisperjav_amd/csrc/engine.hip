@@ -817,6 +817,8 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "qwen_prompt_mfma")) wj::g_qwen_prompt_mfma = value;
   else if (!strcmp(key, "qwen_splitk")) wj::g_qwen_splitk = value;
   else if (!strcmp(key, "qwen_conv_kpad")) wj::g_qwen_conv_kpad = value;
+  else if (!strcmp(key, "qwen_tower_split")) wj::g_qwen_tower_split = value;
+  else if (!strcmp(key, "qwen_fuse_swiglu")) wj::g_qwen_fuse_swiglu = value;
   else if (!strcmp(key, "ppb_gm")) g_ppb_gm = value;
   else if (!strcmp(key, "epi_wide")) g_epi_wide = value;
   else if (!strcmp(key, "dec_ms_stages")) g_tune.dec_ms_stages = value;

@@ -169,7 +169,42 @@ __device__ __forceinline__ bool g_epi_wide_dev(const GemmArgs& g) { return g.epi
 // branch + global_load + s_waitcnt vmcnt(0) per fragment -- 16 to 32 serialised L2 round trips at the end of every tile.
 template <int EPI, typename T, int RI>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, int z, int mw, int nw, int lane, f32x4_t (&acc)[RI][4]) {
-  if constexpr (EPI == EPI_PARTIAL_F32 || EPI == EPI_F32) {
+  if constexpr (EPI == EPI_SWIGLU_T) {
+    // W rows interleaved [16 gate | 16 up]: fragments (0, 1) and (2, 3) of a wave are (gate, up) of the same 16 output columns and
+    // a lane holds the same (row, 4 columns) in both -- silu(gate) * up is register arithmetic, the wave's 64 accumulator columns
+    // become 32 output columns, stored 16 bytes per lane after the same v_permlane16_swap as the plain epilogue.  The gate / up
+    // matrix (2 F columns per row, written and read back by a separate element-wise pass before) never reaches memory.
+    if constexpr (sizeof(T) == 2) {
+      const int q = lane >> 4, Nout = g.N >> 1;
+#pragma unroll
+      for (int i = 0; i < RI; ++i) {
+        const int m = mw + i * 16 + (lane & 15);
+        float va[4], vb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ga = acc[i][0][e], gb = acc[i][2][e];
+          va[e] = ga / (1.f + __expf(-ga)) * acc[i][1][e];
+          vb[e] = gb / (1.f + __expf(-gb)) * acc[i][3][e];
+        }
+        const int n8 = (nw >> 1) + (q & 1) * 16 + (q >> 1) * 8;
+        const bool in = m < g.M && n8 < Nout;
+        T* o = reinterpret_cast<T*>(g.out) + (int64_t)min(m, g.M - 1) * g.ldc + min(n8, Nout - 8);
+        uint32_t a0 = pack2<T>(va[0], va[1]), a1 = pack2<T>(va[2], va[3]);
+        uint32_t c0 = pack2<T>(vb[0], vb[1]), c1 = pack2<T>(vb[2], vb[3]);
+        swap16(a0, c0); swap16(a1, c1);
+        if (g.split_out) {
+          float ra[4], rb[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ra[e] = va[e] - round_T<T>(va[e]); rb[e] = vb[e] - round_T<T>(vb[e]); }
+          uint32_t l0 = pack2<T>(ra[0], ra[1]), l1 = pack2<T>(ra[2], ra[3]);
+          uint32_t d0 = pack2<T>(rb[0], rb[1]), d1 = pack2<T>(rb[2], rb[3]);
+          swap16(l0, d0); swap16(l1, d1);
+          if (in) *reinterpret_cast<uint4*>(o + Nout) = make_uint4(l0, l1, d0, d1);
+        }
+        if (in) *reinterpret_cast<uint4*>(o) = make_uint4(a0, a1, c0, c1);
+      }
+    }
+  } else if constexpr (EPI == EPI_PARTIAL_F32 || EPI == EPI_F32) {
 #pragma unroll
     for (int i = 0; i < RI; ++i)
 #pragma unroll
@@ -1301,7 +1336,7 @@ static int launch_ms_inst(const GemmArgs& a, hipStream_t s) {
 template <typename T, int EPI>
 static int launch_ms(const GemmArgs& a, hipStream_t s, int ns) {
   if constexpr (EPI == EPI_T || EPI == EPI_GELU_T || EPI == EPI_F32 || EPI == EPI_RESID_F32 || EPI == EPI_QKV_DEC ||
-                EPI == EPI_PARTIAL_F32) {
+                EPI == EPI_PARTIAL_F32 || EPI == EPI_SWIGLU_T) {
     const int ks = EPI == EPI_PARTIAL_F32 ? a.ksplit : 1;
     if ((a.split ? 2 * a.K : a.K) % (TBK * ks) || (a.split && a.K % TBK)) {
       set_error("gemm: the multi-stage tile kernel needs K %% (64 * ksplit) == 0");
@@ -1894,6 +1929,20 @@ int launch_splitk_reduce(int dtype, Epi epi, const GemmArgs& a, const float* sla
 // --------------------------------------------------------------------------------------------
 template <typename T, int EPI>
 static int launch_epi16(const GemmArgs& a, hipStream_t s, int variant) {
+  if constexpr (EPI == EPI_SWIGLU_T) {      // the MFMA tile kernels only (their shared tile_epilogue carries the fused form)
+    if (a.mx8 || a.blk || a.nbatch != 1 || (a.N % 64) || (a.ldc % 8) || (a.K % TBK)) {
+      set_error("gemm: the SwiGLU epilogue needs row-major 16-bit operands, one batch, N %% 64 == 0, K %% 64 == 0, ldc %% 8 == 0");
+      return WJ_E_INVALID;
+    }
+    if (variant >= 73 && variant <= 75) return launch_ms<T, EPI>(a, s, variant - 70);
+    const bool big_ok = (a.N % BBN) == 0 && a.M >= 1024 && (!a.split || g_gemm_big == 6);
+    if (variant == 0 && big_ok && g_gemm_big == 6) return launch_big_pp64<T, EPI>(a, s);
+    if (variant == 0 && big_ok && g_gemm_big) return launch_big<T, EPI>(a, s);
+    dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), 1);
+    hipLaunchKernelGGL((gemm_h_tile_kernel<T, EPI, true>), grid, dim3(256), 0, s, a);
+    WJ_LAUNCH_CHECK();
+    return WJ_OK;
+  } else {
   if (a.mx8) return launch_mx8<T, EPI>(a, s);
   if (a.blk) return launch_big_ppb<T, EPI>(a, s);
   if (variant == 5 || (variant >= 50 && variant < 70)) return launch_rows<T, EPI>(a, s, variant == 5 ? 0 : variant - 50);
@@ -1982,6 +2031,7 @@ static int launch_epi16(const GemmArgs& a, hipStream_t s, int variant) {
   else hipLaunchKernelGGL((gemm_h_tile_kernel<T, EPI, false>), grid, dim3(256), 0, s, a);
   WJ_LAUNCH_CHECK();
   return WJ_OK;
+  }
 }
 
 template <int EPI>
@@ -1994,10 +2044,15 @@ static int launch_epi(int dtype, const GemmArgs& a, hipStream_t s, int variant) 
     }
   }
   if (dtype == WJ_F32) {
-    dim3 grid(ceil_div(a.N, 64), ceil_div(a.M, 64), a.nbatch);
-    hipLaunchKernelGGL(gemm_f32_kernel<EPI>, grid, dim3(256), 0, s, a);
-    WJ_LAUNCH_CHECK();
-    return WJ_OK;
+    if constexpr (EPI == EPI_SWIGLU_T) {
+      set_error("gemm: the fused SwiGLU epilogue is a 16-bit-path feature");
+      return WJ_E_INVALID;
+    } else {
+      dim3 grid(ceil_div(a.N, 64), ceil_div(a.M, 64), a.nbatch);
+      hipLaunchKernelGGL(gemm_f32_kernel<EPI>, grid, dim3(256), 0, s, a);
+      WJ_LAUNCH_CHECK();
+      return WJ_OK;
+    }
   }
   if (dtype == WJ_F16) return launch_epi16<f16_t, EPI>(a, s, variant);
   return launch_epi16<bf16_t, EPI>(a, s, variant);
@@ -2031,6 +2086,9 @@ int launch_gemm(int dtype, Epi epi, const GemmArgs& a_in, hipStream_t s, int var
     set_error("gemm: split activations are a 16-bit single-batch feature with lda >= 2 K");
     return WJ_E_INVALID;
   }
+  if (a.split_out && epi == EPI_SWIGLU_T) {
+    if (!is16(dtype) || a.ldc < (int64_t)a.N) { set_error("gemm: split_out of the SwiGLU epilogue needs ldc >= N (two halves of N / 2)"); return WJ_E_INVALID; }
+  } else
   if (a.split_out && (!is16(dtype) || (epi != EPI_T && epi != EPI_GELU_T) || a.ldc < 2 * (int64_t)a.N)) {
     set_error("gemm: split_out needs a 16-bit EPI_T / EPI_GELU_T output with ldc >= 2 N");
     return WJ_E_INVALID;
@@ -2048,6 +2106,7 @@ int launch_gemm(int dtype, Epi epi, const GemmArgs& a_in, hipStream_t s, int var
     case EPI_QKV_DEC: return launch_epi<EPI_QKV_DEC>(dtype, a, s, variant);
     case EPI_CKV: return launch_epi<EPI_CKV>(dtype, a, s, variant);
     case EPI_PARTIAL_F32: return launch_epi<EPI_PARTIAL_F32>(dtype, a, s, variant);
+    case EPI_SWIGLU_T: return launch_epi<EPI_SWIGLU_T>(dtype, a, s, variant);
     default: set_error("gemm: unknown epilogue %d", (int)epi); return WJ_E_INVALID;
   }
 }

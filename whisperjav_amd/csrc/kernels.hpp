@@ -17,6 +17,9 @@ enum Epi : int {
   EPI_QKV_DEC,       // decode step: n<D: out T [M][D]; then K,V -> caches out2/out3 [m][h][cache_len][64] at *pos_ptr
   EPI_CKV,           // cross K/V: n<D: out [z][h][m][64] ; n>=D: out2 [z][h][m][64]; rows/head = Tpad
   EPI_PARTIAL_F32,   // split-K slab: out f32 [ksplit][M][ldc] = raw partial sums (no bias); reduced by the consumer
+  EPI_SWIGLU_T,      // out T [M][ldc] (N / 2 columns) = silu(gate) * up; W's rows are [16 gate | 16 up] blocks (column 32 b + c = gate
+                     // 16 b + c, 32 b + 16 + c = up 16 b + c), so a lane holds a gate / up pair in neighbouring fragments; MFMA tile
+                     // kernels of the 16-bit types only (round 5: the Qwen decoder's gate-up projection), no bias; split_out = lo at + N / 2
   EPI_COUNT
 };
 
@@ -141,8 +144,8 @@ extern int g_dec_cross_u;
 extern int g_dec_cross_nt;
 extern int g_gemm_big;
 extern int g_ppb_ns, g_ppb_gm;
-extern int g_qwen_split_act, g_qwen_compact_pct, g_qwen_prompt_mfma, g_qwen_splitk;
-extern int g_qwen_conv_kpad;                          // qwen_audio.hip      // qwen.hip
+extern int g_qwen_split_act, g_qwen_compact_pct, g_qwen_prompt_mfma, g_qwen_splitk, g_qwen_fuse_swiglu;
+extern int g_qwen_conv_kpad, g_qwen_tower_split;                          // qwen_audio.hip      // qwen.hip
 extern int g_epi_wide;
 int launch_attention_dec(int dtype, const DecAttnArgs& a, hipStream_t s);
 

@@ -19,7 +19,10 @@
 #include "kernels.hpp"
 
 namespace wj {
-int g_qwen_split_act = 2;   // wj_tune("qwen_split_act"), read at wj_qwen_create
+int g_qwen_split_act = 3;   // wj_tune("qwen_split_act"), read at wj_qwen_create.  3 (default since round 5: every projection input travels as a [hi | lo]
+                            // pair) is the mode that meets the 1e-3 per-token bar at the published geometry (decoder 6.5e-4; mode 2 = only the
+                            // o_proj / down_proj / LM-head inputs: 1.06e-3, profiles/r05_parity_diag_qwen*.jsonl)
+int g_qwen_fuse_swiglu = 1;  // wj_tune("qwen_fuse_swiglu"): SwiGLU in the gate-up GEMM's epilogue (0 = the separate element-wise pass, for A/B)
 int g_qwen_prompt_mfma = 1;  // wj_tune("qwen_prompt_mfma"): prompts of the 16-bit types take the MFMA tile attention (0 = the one-row-per-wave kernel)
 int g_qwen_splitk = 4;       // wj_tune("qwen_splitk"): o_proj / down_proj of a 16-bit pass of 65 .. max_seqs rows are cut into this many K slices whose
                             // raw sums the following RMSNorm adds into the residual stream (1 = the projections add themselves)
@@ -225,19 +228,24 @@ __global__ __launch_bounds__(64) void gqa_attn_kernel(const T* __restrict__ q, c
   }
 }
 
+// gate / up columns arrive INTERLEAVED in blocks of 16 (the weight rows are packed [16 gate | 16 up], qwen.engine_tensors): column
+// c of the activation = silu(gu[32 (c >> 4) + (c & 15)]) * gu[... + 16].  The 16-bit types run this inside the gate-up GEMM's
+// epilogue (EPI_SWIGLU_T) whenever an MFMA tile kernel serves the pass; this kernel remains for float32, MX-fp8 and the few-row
+// decode batches on the skinny kernels.
 template <typename T>
 __global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gu, T* __restrict__ out, int M, int F, int split) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)M * F) return;
   const int64_t m = i / F, c = i - m * F;
+  const int64_t cg = ((c >> 4) << 5) + (c & 15);
   float g, u;
   if (split) {         // gate / up arrive as [hi(2F) | lo(2F)] rows as well
     const T* r = gu + m * 4 * F;
-    g = Elem<T>::ld(r + c) + Elem<T>::ld(r + 2 * F + c);
-    u = Elem<T>::ld(r + F + c) + Elem<T>::ld(r + 3 * F + c);
+    g = Elem<T>::ld(r + cg) + Elem<T>::ld(r + 2 * F + cg);
+    u = Elem<T>::ld(r + cg + 16) + Elem<T>::ld(r + 2 * F + cg + 16);
   } else {
-    g = Elem<T>::ld(gu + m * 2 * F + c);
-    u = Elem<T>::ld(gu + m * 2 * F + F + c);
+    g = Elem<T>::ld(gu + m * 2 * F + cg);
+    u = Elem<T>::ld(gu + m * 2 * F + cg + 16);
   }
   const float y = g / (1.f + expf(-g)) * u;
   if constexpr (sizeof(T) == 2) {
@@ -721,15 +729,21 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
       WJ_TRYQ(resid_gemm(g, gemm_variant(QG_O, M, H * HD, dt)));
     }
     WJ_TRYQ(rms(m->F(b0 + WJ_QL_LN2_W), m->h));
+    const int gu_variant = gemm_variant(QG_GATEUP, M, D, dt);
+    // SwiGLU inside the gate-up GEMM's epilogue whenever an MFMA tile kernel serves the pass (16-bit types, more than 64 rows):
+    // the [M][2F] gate / up matrix is never written
+    const bool fused = g_qwen_fuse_swiglu && is16(dt) && !m->mx8 && M > 64 && (F % 32) == 0 && (D % 64) == 0 &&
+                       (gu_variant == 0 || gu_variant == 3 || (gu_variant >= 73 && gu_variant <= 75));
     {
       GemmArgs g;
       g.A = m->h; g.lda = D; g.W = m->W(b0 + WJ_QL_GATEUP_W); g.ldw = D; g.M = M; g.N = 2 * F; g.K = D; g.out = m->gu; g.ldc = 2 * F;
       if (split) { g.split_out = 1; g.ldc = 4 * F; }
       if (sp_in) { g.split = 1; g.lda = 2 * D; }
+      if (fused) { g.out = m->act; g.ldc = (split ? 2 : 1) * F; }
       WJ_TRYQ(mx(g, l, 2));
-      WJ_TRYQ(launch_gemm(dt, EPI_T, g, s, gemm_variant(QG_GATEUP, M, D, dt)));
+      WJ_TRYQ(launch_gemm(dt, fused ? EPI_SWIGLU_T : EPI_T, g, s, gu_variant));
     }
-    {
+    if (!fused) {
       const dim3 grid((unsigned)ceil_div64((int64_t)M * F, 256));
       const int sp = split ? 1 : 0;
       if (dt == WJ_F32) hipLaunchKernelGGL((swiglu_kernel<float>), grid, dim3(256), 0, s, TP(const float, m->gu), TP(float, m->act), M, F, 0);

@@ -21,6 +21,9 @@
 #include "kernels.hpp"
 
 namespace wj {
+int g_qwen_tower_split = 1;   // wj_tune("qwen_tower_split"), read at wj_qwen_audio_create (float16 towers): the inputs of every transformer / projector GEMM
+                              // travel as [hi | lo] fp16 pairs (LayerNorm, attention, GELU outputs): the embeddings' error falls from 4.9e-4 to 1.0e-4 of
+                              // their range (scripts/precision_qwen_tower.py), which is what the decoder's 1e-3 log-prob bar needs end to end
 int g_qwen_conv_kpad = 0;   // wj_tune("qwen_conv_kpad"), read at wj_qwen_audio_create: pad the 3x3 convolutions' K = 9 C to a multiple of 64 so their
                             // GEMMs take the LDS-DMA tile kernel.  Measured (scripts/qwen_tower_kpad_ab.py, 512 clips of 4 s, published tower):
                             // 61.2 ms against 61.7 ms, identical output -- the stem is bound by the patch matrices' HBM traffic, not by operand
@@ -36,7 +39,7 @@ constexpr int CHUNK = 100, TOK = 13;      // mel frames per chunk; tokens a full
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_mel_kernel(const float* __restrict__ mel, const int32_t* __restrict__ chunk_clip,
                                                          const int32_t* __restrict__ chunk_f0, T* __restrict__ out, int n_mels,
-                                                         int frames_max, int Fo, int To, int64_t n_rows) {
+                                                         int frames_max, int Fo, int To, int64_t n_rows, int split) {
   const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int k = threadIdx.x & 15;
   if (r >= n_rows) return;
@@ -48,6 +51,9 @@ __global__ __launch_bounds__(256) void im2col_mel_kernel(const float* __restrict
       const int fr = chunk_f0[c] + tt;
       if (fr < frames_max) v = mel[((int64_t)chunk_clip[c] * n_mels + mf) * frames_max + fr];
     }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (split) { st_split<T>(out + r * 32 + k, 16, v); return; }      // rows [hi(16) | lo(16)] against conv1's weights written twice
   }
   Elem<T>::st(out + r * 16 + k, v);
 }
@@ -100,7 +106,9 @@ __global__ __launch_bounds__(256) void pos_select_kernel(const float* __restrict
 // product with three exchanges; the softmax weights stay in the score registers for the value pass (see gqa_attn_kernel).
 template <typename T, int QB>
 __global__ __launch_bounds__(64) void win_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_lo,
-                                                      const int32_t* __restrict__ win_hi, T* __restrict__ out, int D, int N) {
+                                                      const int32_t* __restrict__ win_hi, T* __restrict__ out, int D, int N, int split) {
+  // split: qkv rows are [hi(3D) | lo(3D)] as well (the QKV GEMM's split_out): every q / k / v load is hi + lo
+  const int64_t ldq = (int64_t)(split ? 6 : 3) * D, lo_off = split ? 3 * D : 0;
   constexpr int STEPS = 8;
   const int i0 = blockIdx.x * QB, h = blockIdx.y, lane = threadIdx.x, kq = lane >> 3, dq = lane & 7;
   int lo[QB], hi[QB], ulo = INT_MAX, uhi = 0;
@@ -110,7 +118,13 @@ __global__ __launch_bounds__(64) void win_attn_kernel(const T* __restrict__ qkv,
     const int i = min(i0 + b, N - 1);
     lo[b] = win_lo[i]; hi[b] = win_hi[i];
     ulo = min(ulo, lo[b]); uhi = max(uhi, hi[b]);
-    ld8(qkv + (int64_t)i * 3 * D + h * 64 + dq * 8, qv[b]);
+    ld8(qkv + (int64_t)i * ldq + h * 64 + dq * 8, qv[b]);
+    if (lo_off) {
+      float t8[8];
+      ld8(qkv + (int64_t)i * ldq + lo_off + h * 64 + dq * 8, t8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[b][e] += t8[e];
+    }
     run_max[b] = -INFINITY; run_sum[b] = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[b][e] = 0.f;
@@ -124,7 +138,13 @@ __global__ __launch_bounds__(64) void win_attn_kernel(const T* __restrict__ qkv,
       const int key = base + st * 8 + kq;
       if (base + st * 8 < uhi) {                    // wave-uniform
         float kv[8];
-        ld8(Kb + (int64_t)min(key, uhi - 1) * 3 * D, kv);
+        ld8(Kb + (int64_t)min(key, uhi - 1) * ldq, kv);
+        if (lo_off) {
+          float t8[8];
+          ld8(Kb + (int64_t)min(key, uhi - 1) * ldq + lo_off, t8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) kv[e] += t8[e];
+        }
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
           float d = 0.f;
@@ -160,7 +180,13 @@ __global__ __launch_bounds__(64) void win_attn_kernel(const T* __restrict__ qkv,
     for (int st = 0; st < STEPS; ++st) {
       if (base + st * 8 < uhi) {
         float vv[8];
-        ld8(Vb + (int64_t)min(base + st * 8 + kq, uhi - 1) * 3 * D, vv);
+        ld8(Vb + (int64_t)min(base + st * 8 + kq, uhi - 1) * ldq, vv);
+        if (lo_off) {
+          float t8[8];
+          ld8(Vb + (int64_t)min(base + st * 8 + kq, uhi - 1) * ldq + lo_off, t8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vv[e] += t8[e];
+        }
 #pragma unroll
         for (int b = 0; b < QB; ++b)
 #pragma unroll
@@ -177,8 +203,13 @@ __global__ __launch_bounds__(64) void win_attn_kernel(const T* __restrict__ qkv,
       acc[b][e] = v / run_sum[b];
     }
     if (kq == 0 && i0 + b < N) {
-      T* dst = out + (int64_t)(i0 + b) * D + h * 64 + dq * 8;
-      st4(dst, acc[b]); st4(dst + 4, acc[b] + 4);
+      if (split) {      // rows [hi(D) | lo(D)]: the out-projection reads them as split activations
+        T* dst = out + (int64_t)(i0 + b) * 2 * D + h * 64 + dq * 8;
+        st4_split(dst, D, acc[b]); st4_split(dst + 4, D, acc[b] + 4);
+      } else {
+        T* dst = out + (int64_t)(i0 + b) * D + h * 64 + dq * 8;
+        st4(dst, acc[b]); st4(dst + 4, acc[b] + 4);
+      }
     }
   }
 }
@@ -197,8 +228,12 @@ struct wj_qwen_audio {
   void *col = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;   // im2col buffer, activations of the three convolutions
   // 16-bit types: K = 9 C of the second and third convolution (4320 in the published tower) padded to a multiple of 64 so that their
   // GEMMs qualify for the LDS-DMA tile kernels: zero columns in a device copy of the two weight matrices and in the patch rows
+  int split = 0;             // float16: [hi | lo] activations into every transformer / projector GEMM (g_qwen_tower_split)
   int kp = 0;                // padded K, 0 = off
   void *w2p = nullptr, *w3p = nullptr;   // [C][kp]
+  // split towers: conv1's weights [C][16] written twice per row ([C][32]) and conv_out's [D][16][C] as [D][16][2C], so that rows
+  // holding [hi | lo] pairs (the first patch matrix; the third convolution's output) multiply as plain GEMMs of twice the K
+  void *w1d = nullptr, *wcod = nullptr;
   float* y = nullptr;        // f32 [chunks * 13][D]   conv_out
   float* x = nullptr;        // f32 [tokens][D]        residual stream
   void *h = nullptr, *qkv = nullptr, *attn = nullptr, *ff = nullptr;
@@ -263,12 +298,15 @@ int wj_qwen_audio_create(wj_ctx* ctx, const wj_qwen_audio_dims* dims, int dtype,
     const size_t k9 = 9 * C, kpad = (k9 + 63) / 64 * 64;
     m->kp = (g_qwen_conv_kpad && dtype != WJ_F32 && kpad != k9) ? (int)kpad : 0;
   }
+  m->split = (dtype == WJ_F16 && g_qwen_tower_split) ? 1 : 0;
+  const size_t sp = m->split ? 2 : 1;
   const size_t Kc = m->kp ? (size_t)m->kp : 9 * C;
   AA(col, NC * 32 * 25 * Kc * e);                    // the largest patch matrix (second convolution)
   if (m->kp) { AA(w2p, C * Kc * e); AA(w3p, C * Kc * e); }
-  AA(a1, NC * 64 * 50 * C * e); AA(a2, NC * 32 * 25 * C * e); AA(a3, NC * TOK * 16 * C * e);
+  AA(a1, NC * 64 * 50 * C * e); AA(a2, NC * 32 * 25 * C * e); AA(a3, NC * TOK * 16 * C * e * sp);
+  if (m->split) { AA(w1d, C * 32 * e); AA(wcod, D * 16 * 2 * C * e); }
   AA(y, N * D * sizeof(float)); AA(x, N * D * sizeof(float));
-  AA(h, N * std::max<size_t>(D, d.out_dim) * e); AA(qkv, N * 3 * D * e); AA(attn, N * D * e); AA(ff, N * (size_t)d.ffn * e);
+  AA(h, N * std::max<size_t>(D, d.out_dim) * e * sp); AA(qkv, N * 3 * D * e * sp); AA(attn, N * D * e * sp); AA(ff, N * (size_t)d.ffn * e * sp);
   AA(chunk_clip, NC * 4); AA(chunk_f0, NC * 4); AA(tok_src, N * 4); AA(win_lo, N * 4); AA(win_hi, N * 4);
 #undef AA
   if (!rc && m->kp) {
@@ -282,6 +320,16 @@ int wj_qwen_audio_create(wj_ctx* ctx, const wj_qwen_audio_dims* dims, int dtype,
     }
     if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
     if (he != hipSuccess) { set_error("wj_qwen_audio_create: padding the convolution weights failed: %s", hipGetErrorString(he)); rc = WJ_E_HIP; }
+  }
+  if (!rc && m->split) {
+    hipError_t he = hipSuccess;
+    for (int half = 0; half < 2 && he == hipSuccess; ++half) {
+      he = hipMemcpy2DAsync(reinterpret_cast<char*>(m->w1d) + half * 16 * e, 32 * e, m->W(WJ_QA_CONV1_W), 16 * e, 16 * e, C, hipMemcpyDeviceToDevice, ctx->stream);
+      if (he == hipSuccess)
+        he = hipMemcpy2DAsync(reinterpret_cast<char*>(m->wcod) + half * C * e, 2 * C * e, m->W(WJ_QA_CONVOUT_W), C * e, C * e, D * 16, hipMemcpyDeviceToDevice, ctx->stream);
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+    if (he != hipSuccess) { set_error("wj_qwen_audio_create: duplicating the split-path weights failed: %s", hipGetErrorString(he)); rc = WJ_E_HIP; }
   }
   if (rc) { wj_qwen_audio_free(m); return rc; }
   *out = m;
@@ -328,22 +376,25 @@ int wj_qwen_audio_encode(wj_qwen_audio* m, const float* mel_dev, int n_clips, in
   WJ_HIP(hipMemcpyAsync(m->win_hi, whi.data(), 4 * (size_t)N, hipMemcpyHostToDevice, s));
   WJ_HIP(hipStreamSynchronize(s));       // the host vectors die at return
   auto gemm = [&](Epi epi, const void* A, int64_t lda, int wi, int bi, int M, int Nn, int K, void* out, int64_t ldc,
-                  const void* w_override = nullptr) -> int {
+                  const void* w_override = nullptr, int split_in = 0, int split_out = 0) -> int {
     GemmArgs g;
     g.A = A; g.lda = lda; g.W = w_override ? w_override : m->W(wi); g.ldw = K; g.bias = bi >= 0 ? m->F(bi) : nullptr; g.M = M; g.N = Nn; g.K = K; g.out = out; g.ldc = ldc;
+    g.split = split_in; g.split_out = split_out;
     return launch_gemm(dt, epi, g, s, 0);
   };
+  const int sp = m->split, spm = sp ? 2 : 1;
   // ---- convolution stem -------------------------------------------------------------------------------------------
   {
     const int64_t rows = (int64_t)NC * 64 * 50;
     const dim3 grid((unsigned)ceil_div64(rows, 16));
-    if (dt == WJ_F32) hipLaunchKernelGGL((im2col_mel_kernel<float>), grid, dim3(256), 0, s, mel_dev, m->chunk_clip, m->chunk_f0, TPA(float, m->col), d.n_mels, frames_max, 64, 50, rows);
-    else if (dt == WJ_F16) hipLaunchKernelGGL((im2col_mel_kernel<f16_t>), grid, dim3(256), 0, s, mel_dev, m->chunk_clip, m->chunk_f0, TPA(f16_t, m->col), d.n_mels, frames_max, 64, 50, rows);
-    else hipLaunchKernelGGL((im2col_mel_kernel<bf16_t>), grid, dim3(256), 0, s, mel_dev, m->chunk_clip, m->chunk_f0, TPA(bf16_t, m->col), d.n_mels, frames_max, 64, 50, rows);
+    if (dt == WJ_F32) hipLaunchKernelGGL((im2col_mel_kernel<float>), grid, dim3(256), 0, s, mel_dev, m->chunk_clip, m->chunk_f0, TPA(float, m->col), d.n_mels, frames_max, 64, 50, rows, 0);
+    else if (dt == WJ_F16) hipLaunchKernelGGL((im2col_mel_kernel<f16_t>), grid, dim3(256), 0, s, mel_dev, m->chunk_clip, m->chunk_f0, TPA(f16_t, m->col), d.n_mels, frames_max, 64, 50, rows, sp);
+    else hipLaunchKernelGGL((im2col_mel_kernel<bf16_t>), grid, dim3(256), 0, s, mel_dev, m->chunk_clip, m->chunk_f0, TPA(bf16_t, m->col), d.n_mels, frames_max, 64, 50, rows, 0);
     WJ_LAUNCH_CHECK();
-    WJ_TRYA(gemm(EPI_GELU_T, m->col, 16, WJ_QA_CONV1_W, WJ_QA_CONV1_B, (int)rows, C, 16, m->a1, C));
+    if (sp) WJ_TRYA(gemm(EPI_GELU_T, m->col, 32, WJ_QA_CONV1_W, WJ_QA_CONV1_B, (int)rows, C, 32, m->a1, C, m->w1d));     // the mel patches as [hi | lo]
+    else WJ_TRYA(gemm(EPI_GELU_T, m->col, 16, WJ_QA_CONV1_W, WJ_QA_CONV1_B, (int)rows, C, 16, m->a1, C));
   }
-  auto conv = [&](const void* in, int Fi, int Ti, int Fo, int To, int t_major, int wi, int bi, void* out) -> int {
+  auto conv = [&](const void* in, int Fi, int Ti, int Fo, int To, int t_major, int wi, int bi, void* out, int split_out = 0) -> int {
     const int64_t rows = (int64_t)NC * Fo * To;
     const int K = m->kp ? m->kp : 9 * C;
     if (dt == WJ_F32) hipLaunchKernelGGL((im2col_cl_kernel<float>), dim3((unsigned)rows), dim3(256), 0, s, TPA(const float, in), TPA(float, m->col), Fi, Ti, Fo, To, C, t_major, K);
@@ -351,34 +402,35 @@ int wj_qwen_audio_encode(wj_qwen_audio* m, const float* mel_dev, int n_clips, in
     else hipLaunchKernelGGL((im2col_cl_kernel<bf16_t>), dim3((unsigned)rows), dim3(256), 0, s, TPA(const bf16_t, in), TPA(bf16_t, m->col), Fi, Ti, Fo, To, C, t_major, K);
     WJ_LAUNCH_CHECK();
     const void* wp = !m->kp ? nullptr : (wi == WJ_QA_CONV2_W ? m->w2p : m->w3p);
-    return gemm(EPI_GELU_T, m->col, K, wi, bi, (int)rows, C, K, out, C, wp);
+    return gemm(EPI_GELU_T, m->col, K, wi, bi, (int)rows, C, K, out, (int64_t)C * (split_out ? 2 : 1), wp, 0, split_out);
   };
   WJ_TRYA(conv(m->a1, 64, 50, 32, 25, 0, WJ_QA_CONV2_W, WJ_QA_CONV2_B, m->a2));
-  WJ_TRYA(conv(m->a2, 32, 25, 16, TOK, 1, WJ_QA_CONV3_W, WJ_QA_CONV3_B, m->a3));      // rows (chunk, t, f)
-  WJ_TRYA(gemm(EPI_F32, m->a3, 16 * C, WJ_QA_CONVOUT_W, -1, NC * TOK, D, 16 * C, m->y, D));
+  WJ_TRYA(conv(m->a2, 32, 25, 16, TOK, 1, WJ_QA_CONV3_W, WJ_QA_CONV3_B, m->a3, sp));      // rows (chunk, t, f); split: [hi(C) | lo(C)] per row
+  if (sp) WJ_TRYA(gemm(EPI_F32, m->a3, 32 * C, WJ_QA_CONVOUT_W, -1, NC * TOK, D, 32 * C, m->y, D, m->wcod));
+  else WJ_TRYA(gemm(EPI_F32, m->a3, 16 * C, WJ_QA_CONVOUT_W, -1, NC * TOK, D, 16 * C, m->y, D));
   hipLaunchKernelGGL(pos_select_kernel, dim3(N), dim3(256), 0, s, m->y, m->F(WJ_QA_POS), m->tok_src, m->x, D);
   WJ_LAUNCH_CHECK();
   // ---- transformer layers over the packed tokens ------------------------------------------------------------------
   for (int l = 0; l < d.n_layer; ++l) {
     const int b0 = m->layer_base(l);
-    WJ_TRYA(launch_layernorm(dt, m->x, m->F(b0 + WJ_QAL_LN1_W), m->F(b0 + WJ_QAL_LN1_B), m->h, N, D, s, 0));
-    WJ_TRYA(gemm(EPI_T, m->h, D, b0 + WJ_QAL_QKV_W, b0 + WJ_QAL_QKV_B, N, 3 * D, D, m->qkv, 3 * D));
+    WJ_TRYA(launch_layernorm(dt, m->x, m->F(b0 + WJ_QAL_LN1_W), m->F(b0 + WJ_QAL_LN1_B), m->h, N, D, s, sp));
+    WJ_TRYA(gemm(EPI_T, m->h, (int64_t)D * spm, b0 + WJ_QAL_QKV_W, b0 + WJ_QAL_QKV_B, N, 3 * D, D, m->qkv, (int64_t)3 * D * spm, nullptr, sp, sp));
     {
       constexpr int QB = 4;
       const dim3 grid(ceil_div(N, QB), H);
-      if (dt == WJ_F32) hipLaunchKernelGGL((win_attn_kernel<float, QB>), grid, dim3(64), 0, s, TPA(const float, m->qkv), m->win_lo, m->win_hi, TPA(float, m->attn), D, N);
-      else if (dt == WJ_F16) hipLaunchKernelGGL((win_attn_kernel<f16_t, QB>), grid, dim3(64), 0, s, TPA(const f16_t, m->qkv), m->win_lo, m->win_hi, TPA(f16_t, m->attn), D, N);
-      else hipLaunchKernelGGL((win_attn_kernel<bf16_t, QB>), grid, dim3(64), 0, s, TPA(const bf16_t, m->qkv), m->win_lo, m->win_hi, TPA(bf16_t, m->attn), D, N);
+      if (dt == WJ_F32) hipLaunchKernelGGL((win_attn_kernel<float, QB>), grid, dim3(64), 0, s, TPA(const float, m->qkv), m->win_lo, m->win_hi, TPA(float, m->attn), D, N, 0);
+      else if (dt == WJ_F16) hipLaunchKernelGGL((win_attn_kernel<f16_t, QB>), grid, dim3(64), 0, s, TPA(const f16_t, m->qkv), m->win_lo, m->win_hi, TPA(f16_t, m->attn), D, N, sp);
+      else hipLaunchKernelGGL((win_attn_kernel<bf16_t, QB>), grid, dim3(64), 0, s, TPA(const bf16_t, m->qkv), m->win_lo, m->win_hi, TPA(bf16_t, m->attn), D, N, 0);
     }
     WJ_LAUNCH_CHECK();
-    WJ_TRYA(gemm(EPI_RESID_F32, m->attn, D, b0 + WJ_QAL_OUT_W, b0 + WJ_QAL_OUT_B, N, D, D, m->x, D));
-    WJ_TRYA(launch_layernorm(dt, m->x, m->F(b0 + WJ_QAL_LN2_W), m->F(b0 + WJ_QAL_LN2_B), m->h, N, D, s, 0));
-    WJ_TRYA(gemm(EPI_GELU_T, m->h, D, b0 + WJ_QAL_FC1_W, b0 + WJ_QAL_FC1_B, N, d.ffn, D, m->ff, d.ffn));
-    WJ_TRYA(gemm(EPI_RESID_F32, m->ff, d.ffn, b0 + WJ_QAL_FC2_W, b0 + WJ_QAL_FC2_B, N, D, d.ffn, m->x, D));
+    WJ_TRYA(gemm(EPI_RESID_F32, m->attn, (int64_t)D * spm, b0 + WJ_QAL_OUT_W, b0 + WJ_QAL_OUT_B, N, D, D, m->x, D, nullptr, sp));
+    WJ_TRYA(launch_layernorm(dt, m->x, m->F(b0 + WJ_QAL_LN2_W), m->F(b0 + WJ_QAL_LN2_B), m->h, N, D, s, sp));
+    WJ_TRYA(gemm(EPI_GELU_T, m->h, (int64_t)D * spm, b0 + WJ_QAL_FC1_W, b0 + WJ_QAL_FC1_B, N, d.ffn, D, m->ff, (int64_t)d.ffn * spm, nullptr, sp, sp));
+    WJ_TRYA(gemm(EPI_RESID_F32, m->ff, (int64_t)d.ffn * spm, b0 + WJ_QAL_FC2_W, b0 + WJ_QAL_FC2_B, N, D, d.ffn, m->x, D, nullptr, sp));
   }
-  WJ_TRYA(launch_layernorm(dt, m->x, m->F(WJ_QA_LNPOST_W), m->F(WJ_QA_LNPOST_B), m->h, N, D, s, 0));
-  WJ_TRYA(gemm(EPI_GELU_T, m->h, D, WJ_QA_PROJ1_W, WJ_QA_PROJ1_B, N, D, D, m->attn, D));
-  WJ_TRYA(gemm(EPI_F32, m->attn, D, WJ_QA_PROJ2_W, WJ_QA_PROJ2_B, N, d.out_dim, D, out_dev, d.out_dim));
+  WJ_TRYA(launch_layernorm(dt, m->x, m->F(WJ_QA_LNPOST_W), m->F(WJ_QA_LNPOST_B), m->h, N, D, s, sp));
+  WJ_TRYA(gemm(EPI_GELU_T, m->h, (int64_t)D * spm, WJ_QA_PROJ1_W, WJ_QA_PROJ1_B, N, D, D, m->attn, (int64_t)D * spm, nullptr, sp, sp));
+  WJ_TRYA(gemm(EPI_F32, m->attn, (int64_t)D * spm, WJ_QA_PROJ2_W, WJ_QA_PROJ2_B, N, d.out_dim, D, out_dev, d.out_dim, nullptr, sp));
   WJ_HIP(hipStreamSynchronize(s));
   return WJ_OK;
 }

@@ -35,6 +35,7 @@ from . import hipbind
 from .hipbind import DTYPES, check
 
 ALIGN = 256
+DEFAULT_SPLIT_ACT = 3      # csrc/qwen.hip g_qwen_split_act
 LAYER_TENSORS = ("LN1_W", "QKV_W", "QNORM_W", "KNORM_W", "O_W", "LN2_W", "GATEUP_W", "DOWN_W")     # order of WJ_QL_* in wjhip.h
 
 
@@ -168,7 +169,12 @@ def engine_tensors(d: Qwen3Dims, w: Dict[str, np.ndarray]) -> List[Tuple[str, np
     for l in range(d.n_layer):
         q = f"{p}layers.{l}."
         qkv = np.concatenate([w[q + "self_attn.q_proj.weight"], w[q + "self_attn.k_proj.weight"], w[q + "self_attn.v_proj.weight"]], 0)
-        gate_up = np.concatenate([w[q + "mlp.gate_proj.weight"], w[q + "mlp.up_proj.weight"]], 0)
+        # gate / up rows interleaved in blocks of 16 ([16 gate | 16 up] ...): neighbouring MFMA fragments of the fused GEMM then hold
+        # a (gate, up) pair of the same output column and SwiGLU is computed in the GEMM's epilogue (csrc/gemm.hip EPI_SWIGLU_T)
+        if d.ffn % 16:
+            raise ValueError(f"ffn {d.ffn}: the gate / up interleave needs a multiple of 16")
+        gate, up = w[q + "mlp.gate_proj.weight"], w[q + "mlp.up_proj.weight"]
+        gate_up = np.stack([gate.reshape(d.ffn // 16, 16, d.hidden), up.reshape(d.ffn // 16, 16, d.hidden)], axis=1).reshape(2 * d.ffn, d.hidden)
         t = {"LN1_W": (w[q + "input_layernorm.weight"], False), "QKV_W": (qkv, True),
              "QNORM_W": (w[q + "self_attn.q_norm.weight"], False), "KNORM_W": (w[q + "self_attn.k_norm.weight"], False),
              "O_W": (w[q + "self_attn.o_proj.weight"], True), "LN2_W": (w[q + "post_attention_layernorm.weight"], False),
@@ -580,7 +586,10 @@ class HipQwen3Decoder:
     """The Qwen3 decoder resident in HBM (``wj_qwen_*``).  No CPU path: raises without the library or an MI355X."""
 
     def __init__(self, dims: Qwen3Dims, weights: Dict[str, np.ndarray], *, dtype: str = "float16", device: int = 0,
-                 max_seqs: int = 8, max_ctx: int = 512, max_rows: Optional[int] = None):
+                 max_seqs: int = 8, max_ctx: int = 512, max_rows: Optional[int] = None, split_act: Optional[int] = None):
+        """``split_act`` (float16): which GEMM inputs travel as [hi | lo] pairs -- None = the library default (3: every projection
+        input; the mode that meets the 1e-3 per-token log-prob bar), 2 = o_proj / down_proj / LM head only (what the forced
+        aligner runs: its outputs are arg-max time bins, not log-probs), 1 / 0 for A/B."""
         if dtype not in DTYPES and dtype != "float8w":
             raise ValueError(f"dtype must be one of {sorted(DTYPES)} or 'float8w'")
         if not torch.cuda.is_available():
@@ -602,8 +611,14 @@ class HipQwen3Decoder:
         off = (C.c_int64 * len(offsets))(*offsets.tolist())
         handle = C.c_void_p()
         torch.cuda.current_stream().synchronize()
-        check(self._lib.wj_qwen_create(self.ctx.handle, C.byref(cd), hipbind.WJ_F8W if self.f8w else DTYPES[dtype], C.c_void_p(self.blob.data_ptr()), self.blob.numel(),
-                                       off, len(offsets), self.max_seqs, self.max_ctx, self.max_rows, C.byref(handle)), "wj_qwen_create")
+        if split_act is not None:
+            hipbind.tune("qwen_split_act", int(split_act))         # read by wj_qwen_create
+        try:
+            check(self._lib.wj_qwen_create(self.ctx.handle, C.byref(cd), hipbind.WJ_F8W if self.f8w else DTYPES[dtype], C.c_void_p(self.blob.data_ptr()), self.blob.numel(),
+                                           off, len(offsets), self.max_seqs, self.max_ctx, self.max_rows, C.byref(handle)), "wj_qwen_create")
+        finally:
+            if split_act is not None:
+                hipbind.tune("qwen_split_act", DEFAULT_SPLIT_ACT)
         self.handle = handle
 
     def close(self) -> None:
@@ -1032,7 +1047,7 @@ class HipQwenForcedAligner:
     def load(self) -> None:
         if self._model is None:
             self._model = HipQwen3Decoder(self.dims, self._weights, dtype=self.dtype, device=self.device, max_seqs=self.batch_size,
-                                          max_ctx=self.max_ctx)
+                                          max_ctx=self.max_ctx, split_act=2)      # arg-max time bins, not log-probs: the cheaper split mode
             self._tower = HipQwenAudioTower(self.audio_dims, self._weights, dtype=self.dtype, device=self.device)
             self._head_w = torch.from_numpy(np.ascontiguousarray(self._weights[self.head_key + ".weight"], dtype=np.float32))
             b = self._weights.get(self.head_key + ".bias")
