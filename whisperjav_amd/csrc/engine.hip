@@ -121,6 +121,11 @@ struct Tunables {
   int enc_blocked = 1;      // 16-bit models with d_model % 256 == 0 (read at create): the encoder's big GEMMs take BLOCKED operands
                             // ([rows / 256][K / 32][256][32]: every LDS-DMA wave request 1 KiB contiguous) -- weights copied
                             // once into that layout, LayerNorm / attention / fc1 write it; +5..+20 % per GEMM (r04 gemm probe)
+  int batch_invariant = 0;  // 16-bit models: ONE kernel family and FIXED split-K factors for every decode / alignment GEMM whatever the row count
+                            // (the tile kernels, dec_ks_* as set, no adaptation, no rows / skinny kernels): a window's tokens and log-probs are
+                            // then bit-identical whatever shares its batch -- other windows, other shards of a multi-GPU run, compaction.  A
+                            // reproducibility mode (small batches run slower); the default picks the fastest kernel per row count, whose fp32
+                            // summation orders differ
   int dec_big_min_m = 0;    // rows from which the wide decode projections (qkv, fc1) use the 256x256 kernel; measured at 1920 rows: 14.00 s vs 13.89 s for the 128-tile kernel (160 workgroups do not fill 256 CUs), so off
 };
 static Tunables g_tune;
@@ -387,9 +392,11 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   // Residual-writing GEMMs (attention out-projections, fc2) can run split-K: each K slice writes a raw fp32
   // slab and the LayerNorm that always follows folds  x += bias + sum(slabs)  in a fixed order (deterministic).
   // This keeps the per-workgroup A traffic at M*K/ksplit and multiplies the number of workgroups streaming W.
-  const bool rows = is16(dt) && g_tune.dec_rows && R <= g_tune.dec_rows_max_m;
+  const bool inv = g_tune.batch_invariant && is16(dt);       // see Tunables::batch_invariant
+  const bool rows = !inv && is16(dt) && g_tune.dec_rows && R <= g_tune.dec_rows_max_m;
   const int ks_attn = rows ? g_tune.dec_rows_ks_attn : g_tune.dec_ks_attn;
-  const int ks_fc2 = rows ? g_tune.dec_rows_ks_fc2 : g_tune.dec_ks_fc2, tile_min_m = g_tune.dec_tile_min_m;
+  const int ks_fc2 = rows ? g_tune.dec_rows_ks_fc2 : g_tune.dec_ks_fc2, tile_min_m = inv ? 1 : g_tune.dec_tile_min_m;
+  const int proj_min_m = inv ? 1 : g_tune.dec_proj_min_m;
   const int ms = g_tune.dec_ms_stages;
   const int tile_variant = (ms >= 3 && ms <= 5) ? 70 + ms : (g_tune.dec_tile_reg ? 4 : 3);
   const int msr = g_tune.dec_ms_resid;
@@ -403,7 +410,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   // 1, where the GEMM applies its epilogue directly (no slab, no reduce launch).
   const bool tiled = !rows && is16(dt) && tile_min_m > 0 && R >= tile_min_m;
   auto adapt_ks = [&](int ks, int N) -> int {
-    if (!tiled || !g_tune.dec_adapt_ks) return ks;
+    if (!tiled || !g_tune.dec_adapt_ks || inv) return ks;
     const int tiles = ceil_div(R, 128) * ceil_div(N, 128);
     while (ks > 1 && tiles * (ks / 2) >= 256) ks /= 2;
     return ks;
@@ -437,14 +444,14 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
     if (deferred) *deferred = 0;
     if (rows) {
       PROF(tag, launch_gemm(dt, epi, g, s, 5));
-    } else if (tiled && ks == 1 && R >= g_tune.dec_proj_min_m) {
+    } else if (tiled && ks == 1 && R >= proj_min_m) {
       // single pass with the projection's own epilogue.  Wide projections of a big batch (beam search over hundreds of
       // windows: 1920 rows x 3840 / 5120 columns) go to the 256x256 encoder kernel: the 128-tile kernel gives a
       // workgroup only 32 MFMAs per wave per k-step to hide the LDS-DMA round trip behind (measured 440 TFLOP/s on fc1)
       const bool wide = g_tune.dec_big_min_m > 0 && R >= g_tune.dec_big_min_m && !g.split && (g.N % 256) == 0 &&
                         ceil_div(R, 256) * (g.N / 256) >= 96;
       PROF(tag, launch_gemm(dt, epi, g, s, wide ? 6 : tile_variant));
-    } else if (is16(dt) && ks > 1 && R >= g_tune.dec_proj_min_m && (int64_t)ks * g.N <= (int64_t)kDecKsMax * D &&
+    } else if (is16(dt) && ks > 1 && R >= proj_min_m && (int64_t)ks * g.N <= (int64_t)kDecKsMax * D &&
         g.K % (64 * ks) == 0 && !pend_ks) {
       GemmArgs p = g;
       p.out = slab; p.ldc = g.N; p.ksplit = ks; p.bias = nullptr; p.split_out = 0;
@@ -556,6 +563,7 @@ static int run_decoder_seq(wj_whisper* m, int B, int Tp, int n0, const int32_t* 
   const wj_whisper_dims& d = m->d;
   const int D = d.n_text_state, H = d.n_text_head, dt = m->dtype;
   const int M = B * Tp;
+  const int gv = (g_tune.batch_invariant && is16(dt)) ? 3 : 0;     // batch_invariant: the tile kernel whatever M (the dispatcher's choice depends on it)
   float* x = m->x;
   void *h = m->h, *q = m->q, *attn = m->attn, *ff = m->ff;
   WJ_TRY(launch_embed_seq(dt, m->W(WJ_T_DEC_TOK_EMB), m->F(WJ_T_DEC_POS), m->tokens, m->tok_stride, Tp, x, B, D, s));
@@ -569,7 +577,7 @@ static int run_decoder_seq(wj_whisper* m, int B, int Tp, int n0, const int32_t* 
       g.A = h; g.lda = D; g.W = m->W(b0 + WJ_TD_QKV_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_QKV_B);
       g.M = M; g.N = 3 * D; g.K = D; g.out = q; g.out2 = sk; g.out3 = sv;
       g.D = D; g.H = H; g.cache_len = m->kv_len; g.seq_tp = Tp;
-      WJ_TRY(launch_gemm(dt, EPI_QKV_DEC, g, s));
+      WJ_TRY(launch_gemm(dt, EPI_QKV_DEC, g, s, gv));
     }
     {
       DecAttnArgs a;
@@ -580,14 +588,14 @@ static int run_decoder_seq(wj_whisper* m, int B, int Tp, int n0, const int32_t* 
       GemmArgs g;
       g.A = attn; g.lda = D; g.W = m->W(b0 + WJ_TD_OUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_OUT_B);
       g.M = M; g.N = D; g.K = D; g.out = x; g.ldc = D;
-      WJ_TRY(launch_gemm(dt, EPI_RESID_F32, g, s));
+      WJ_TRY(launch_gemm(dt, EPI_RESID_F32, g, s, gv));
     }
     WJ_TRY(launch_layernorm(dt, x, m->F(b0 + WJ_TD_LNX_W), m->F(b0 + WJ_TD_LNX_B), h, M, D, s));
     {
       GemmArgs g;
       g.A = h; g.lda = D; g.W = m->W(b0 + WJ_TD_CQ_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_CQ_B);
       g.M = M; g.N = D; g.K = D; g.out = q; g.ldc = D;
-      WJ_TRY(launch_gemm(dt, EPI_T, g, s));
+      WJ_TRY(launch_gemm(dt, EPI_T, g, s, gv));
     }
     {
       DecAttnArgs a;
@@ -604,18 +612,18 @@ static int run_decoder_seq(wj_whisper* m, int B, int Tp, int n0, const int32_t* 
       GemmArgs g;
       g.A = attn; g.lda = D; g.W = m->W(b0 + WJ_TD_COUT_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_COUT_B);
       g.M = M; g.N = D; g.K = D; g.out = x; g.ldc = D;
-      WJ_TRY(launch_gemm(dt, EPI_RESID_F32, g, s));
+      WJ_TRY(launch_gemm(dt, EPI_RESID_F32, g, s, gv));
     }
     WJ_TRY(launch_layernorm(dt, x, m->F(b0 + WJ_TD_LN2_W), m->F(b0 + WJ_TD_LN2_B), h, M, D, s));
     {
       GemmArgs g;
       g.A = h; g.lda = D; g.W = m->W(b0 + WJ_TD_FC1_W); g.ldw = D; g.bias = m->F(b0 + WJ_TD_FC1_B);
       g.M = M; g.N = 4 * D; g.K = D; g.out = ff; g.ldc = 4 * D;
-      WJ_TRY(launch_gemm(dt, EPI_GELU_T, g, s));
+      WJ_TRY(launch_gemm(dt, EPI_GELU_T, g, s, gv));
       GemmArgs g2;
       g2.A = ff; g2.lda = 4 * D; g2.W = m->W(b0 + WJ_TD_FC2_W); g2.ldw = 4 * D; g2.bias = m->F(b0 + WJ_TD_FC2_B);
       g2.M = M; g2.N = D; g2.K = 4 * D; g2.out = x; g2.ldc = D;
-      WJ_TRY(launch_gemm(dt, EPI_RESID_F32, g2, s));
+      WJ_TRY(launch_gemm(dt, EPI_RESID_F32, g2, s, gv));
     }
   }
   WJ_TRY(launch_layernorm(dt, x, m->F(WJ_T_DEC_LN_W), m->F(WJ_T_DEC_LN_B), h, M, D, s));
@@ -625,7 +633,7 @@ static int run_decoder_seq(wj_whisper* m, int B, int Tp, int n0, const int32_t* 
     GemmArgs g;
     g.A = m->at(h, (int64_t)r0 * D); g.lda = D; g.W = m->W(WJ_T_DEC_TOK_EMB); g.ldw = D;
     g.M = rows; g.N = d.n_vocab; g.K = D; g.out = m->logits; g.ldc = m->ldl;
-    WJ_TRY(launch_gemm(dt, EPI_F32, g, s));
+    WJ_TRY(launch_gemm(dt, EPI_F32, g, s, gv));
     WJ_TRY(launch_align_token_prob_seq(m->logits, m->ldl, eot, m->tokens, m->tok_stride, r0, rows, Tp, n0, d_ntok, d_prob, s));
   }
   return WJ_OK;
@@ -800,6 +808,7 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_split_act")) g_tune.dec_split_act = value;
   else if (!strcmp(key, "dec_adapt_ks")) g_tune.dec_adapt_ks = value;
   else if (!strcmp(key, "dec_big_min_m")) g_tune.dec_big_min_m = value;
+  else if (!strcmp(key, "batch_invariant")) g_tune.batch_invariant = value;
   else if (!strcmp(key, "self_kv_len")) g_tune.self_kv_len = value;
   else if (!strcmp(key, "enc_batch")) g_tune.enc_batch = value;
   else if (!strcmp(key, "enc_blocked")) g_tune.enc_blocked = value;
