@@ -163,7 +163,7 @@ def roofline_from_stages(stages, dtype, tag_hint=None):
         return None
     e = stages[dom]
     traffic = traffic_source = None
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_cross_attn_cfg3.json", "r03_pmc_cross_attn_cfg3.json", "r02_pmc_cross_attn_cfg3.json"))
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_cross_attn_cfg3.json", "r04_pmc_cross_attn_cfg3.json", "r03_pmc_cross_attn_cfg3.json", "r02_pmc_cross_attn_cfg3.json"))
                      if os.path.exists(f)), None)
     if dom == "dec_cross_attn" and dtype != "float32" and pmc_file:
         # NOT measured in this run: a stored rocprofv3 --pmc FETCH_SIZE pass of the same command (own pass, x2 gfx950
@@ -878,10 +878,18 @@ def cfg5_roofline(dec_params, esz, clips, n_iter, stages, qdt="float16", layer_p
     peak = MFMA_PEAK_TFLOPS["float16"]
     if qdt == "float8w":      # the layers' projections run at the fp8 rate (5 PFLOP/s dense), the LM head at the fp16 rate: time-weighted roof
         peak = dec_params / (layer_params / 5000.0 + (dec_params - layer_params) / MFMA_PEAK_TFLOPS["float16"])
+    traffic = traffic_source = None
+    pmc_file = os.path.join(ROOT, "profiles", "r05_pmc_fetch_cfg5.json")
+    if os.path.exists(pmc_file) and qdt == "float16":
+        # NOT measured in this run: a stored `rocprofv3 --pmc FETCH_SIZE --kernel-trace` pass of the same command (own pass, x2 gfx950
+        # wide-read correction): HBM read bytes of every dispatch between the first and last decode-attention launch, per iteration
+        pmc = json.load(open(pmc_file))
+        traffic = (pmc.get("decode") or {}).get("hbm_read_bytes_per_iteration")
+        traffic_source = f"stored PMC pass ({os.path.basename(pmc_file)}: {pmc.get('source', '')}); not collected in this run"
     return {"bound": "mfma", "kernel": f"greedy decode iteration ({clips:.0f} live rows on average through every decoder GEMM and the tied LM head)",
             "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4),
-            "traffic": None, "note": "attention, norms, top-1 and the launch gaps of the iteration are inside the time; GEMM-only figures: DESIGN.md"}
+            "traffic": traffic, "traffic_source": traffic_source, "note": "attention, norms, top-1 and the launch gaps of the iteration are inside the time; GEMM-only figures: DESIGN.md"}
 
 
 QWEN_TS_TOKEN = 151705          # <timestamp> marker id (transformers' Qwen3ASRConfig.timestamp_token_id default)
@@ -1026,7 +1034,7 @@ def cfg5_measure(args, info, steps, warmup, want_cpu, want_stages=True):
                                     + (" -> forced-aligner pass (Qwen3-0.6B decoder geometry + audio tower + 512-bin head, every generated token a word)"
                                        if aligner else " ; no aligner pass")
                                     + (f"; decoder compute type {qdt}" + (" (MX-fp8 projections on v_mfma_scale_f32_16x16x128_f8f6f4, fp16 LM head)" if qdt == "float8w"
-                                                                           else " with split activations (wj_tune qwen_split_act 3 = every projection input, the default; the audio tower's GEMM inputs split too)" if qdt == "float16" else "")
+                                                                           else " with split activations (wj_tune qwen_split_act 5, the default: o_proj / down_proj / LM-head / gate-up inputs as [hi | lo] pairs; the audio tower's GEMM inputs split too)" if qdt == "float16" else "")
                                        + "; no TEN-VAD (clips are given)")),
                        "decoder_compute_type": qdt,
                        "clips_per_step": B, "audio_seconds_per_step": round(audio_s, 1),

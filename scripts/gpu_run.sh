@@ -55,6 +55,14 @@ case "$plan" in
     note "pmcmfma[$TAG] $* rc=$?"
     python scripts/rocprof_summarise.py mfma "gpurun_out/pmc_${TAG}" "gpurun_out/pmc_${TAG}_summary.json" python bench.py "$@"; note "pmcmfma summary rc=$?"
     rm -rf "gpurun_out/pmc_${TAG}" ;;
+  pmcfetch)
+    # FETCH_SIZE of every dispatch with the kernel trace beside it (own pass): per-kernel HBM reads and bytes per decode iteration (cfg5)
+    rm -rf "gpurun_out/pmc_${TAG}"
+    (cd /tmp && timeout ${BENCH_TIMEOUT:-900} rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OLDPWD/gpurun_out/pmc_${TAG}" -o pmc --output-format csv -- \
+        python "$OLDPWD/bench.py" "$@" > "$OLDPWD/gpurun_out/pmc_${TAG}.json" 2> "$OLDPWD/gpurun_out/pmc_${TAG}.err")
+    note "pmcfetch[$TAG] $* rc=$?"
+    python scripts/rocprof_summarise.py fetch "gpurun_out/pmc_${TAG}" "gpurun_out/pmc_${TAG}_summary.json" "gpurun_out/pmc_${TAG}.json" python bench.py "$@"; note "pmcfetch summary rc=$?"
+    rm -rf "gpurun_out/pmc_${TAG}" ;;
   py)
     f="$1"; shift
     timeout 1800 python "$f" "$@" > "gpurun_out/$(basename "$f" .py).log" 2>&1

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 from oracle import logmel, qwen3_ref  # noqa: E402
 from whisperjav_amd import qwen, synth  # noqa: E402
 
-POINTS = ("mel", "conv_act1", "conv_act2", "conv_act3", "ln_out", "qkv", "attn_out", "gelu_out", "lnpost_out", "proj1_out")
+POINTS = ("mel", "conv_act1", "conv_act2", "conv_act3", "ln_out", "q", "k", "v", "attn_out", "gelu_out", "lnpost_out", "proj1_out")
 
 
 def f16(x):
@@ -46,9 +46,9 @@ def tower(o, mel, on):
     for l in range(d.a_layers):
         q = f"{p}layers.{l}."
         y = r("ln_out", F.layer_norm(h, (d.a_d,), w[q + "self_attn_layer_norm.weight"], w[q + "self_attn_layer_norm.bias"], 1e-5))
-        qs = r("qkv", y @ w[q + "self_attn.q_proj.weight"].T + w[q + "self_attn.q_proj.bias"]).view(total, d.a_heads, hd)
-        ks = r("qkv", y @ w[q + "self_attn.k_proj.weight"].T + w[q + "self_attn.k_proj.bias"]).view(total, d.a_heads, hd)
-        vs = r("qkv", y @ w[q + "self_attn.v_proj.weight"].T + w[q + "self_attn.v_proj.bias"]).view(total, d.a_heads, hd)
+        qs = r("q", y @ w[q + "self_attn.q_proj.weight"].T + w[q + "self_attn.q_proj.bias"]).view(total, d.a_heads, hd)
+        ks = r("k", y @ w[q + "self_attn.k_proj.weight"].T + w[q + "self_attn.k_proj.bias"]).view(total, d.a_heads, hd)
+        vs = r("v", y @ w[q + "self_attn.v_proj.weight"].T + w[q + "self_attn.v_proj.bias"]).view(total, d.a_heads, hd)
         outs = []
         for a, b in zip(bounds[:-1], bounds[1:]):
             s = torch.einsum("qhd,khd->hqk", qs[a:b], ks[a:b]) * hd ** -0.5
@@ -76,10 +76,11 @@ def main():
     with torch.no_grad():
         ref = tower(o, mel, ())
         scale = float(ref.abs().max())
-        shipped = ("mel", "conv_act1", "conv_act2", "conv_act3", "qkv")          # what round 5's tower still rounds (qwen_tower_split)
+        shipped = ("conv_act1", "conv_act2")          # what round 5's tower still rounds (qwen_tower_split: everything else travels as [hi | lo])
         for name, on in [("all (round 4)", POINTS)] + [(p, (p,)) for p in POINTS] + [("round 5 tower: " + ", ".join(shipped), shipped)] + [
-                ("round 5 minus " + p, tuple(q for q in shipped if q != p)) for p in shipped] + [
-                ("conv_act1 + conv_act2 only", ("conv_act1", "conv_act2")), ("conv_act1 only + mel", ("conv_act1", "mel"))]:
+                ("round 5 + " + p, shipped + (p,)) for p in ("q", "k", "v", "mel", "conv_act3")] + [
+                ("round 5 + q, k, v (attention inputs plain)", shipped + ("q", "k", "v")), ("round 5 + k, v", shipped + ("k", "v")),
+                ("round 5 + v", shipped + ("v",))]:
             rows[name] = float((tower(o, mel, on) - ref).abs().max()) / scale
             print(f"{name:60s} {rows[name]:.3e}", flush=True)
     with open(os.path.join(ROOT, "profiles", "r05_precision_qwen_tower_cpu.json"), "w") as f:

@@ -42,7 +42,12 @@ KERNEL_CLASSES = (        # kernel-name substring(s) -> class of the encoder / d
     ("attn_enc", "encoder attention"), ("attn_cross_mfma", "decode cross attention"), ("attn_dec", "decode self attention"),
     ("gemm_h_big", "encoder GEMMs (256-tile: qk, v, out, fc1, fc2, cross K/V)"), ("gemm_h_tile", "conv stem + decode tile GEMMs"),
     ("gemm_h_skinny", "decode skinny GEMMs"), ("gemm_h_rows", "decode row GEMMs"), ("layernorm", "LayerNorm"),
-    ("beam_topk", "beam top-2K"), ("beam_merge", "beam merge"))
+    ("beam_topk", "beam top-2K"), ("beam_merge", "beam merge"),
+    # Qwen3-ASR (cfg5)
+    ("gqa_attn", "Qwen decode attention (GQA, one wave per row and KV head)"), ("prompt_attn", "Qwen prompt attention (MFMA tiles)"),
+    ("win_attn", "audio tower windowed attention"), ("swiglu", "SwiGLU (unfused passes)"), ("rmsnorm", "RMSNorm"),
+    ("qk_norm_rope", "q/k norm + RoPE + cache append"), ("im2col", "tower im2col"), ("topk_logprob", "top-1 + log-prob"),
+    ("gemm_mx8", "MX-fp8 GEMMs"))
 
 
 def mfma(d, out, command):
@@ -116,6 +121,54 @@ def mfma(d, out, command):
                       **{k: v["mfma_util"] for k, v in rep["classes"].items()}}))
 
 
+def fetch(d, out, bench_json, command):
+    """``rocprofv3 --pmc FETCH_SIZE --kernel-trace`` of a cfg5 step: HBM read bytes per kernel (x2 gfx950 wide-read correction,
+    MI355X_MICROARCH.md "HBM") and per greedy DECODE ITERATION -- the dispatches between the first and the last launch of the
+    decode-only attention kernel (gqa_attn_kernel; prompts and the aligner's classification pass use prompt_attn_kernel) --
+    divided by the iterations the bench line reports."""
+    rows = []
+    for path in find(d, "*counter_collection.csv"):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if r.get("Counter_Name") == "FETCH_SIZE":
+                    rows.append((int(r["Dispatch_Id"]), r.get("Kernel_Name", ""), float(r["Counter_Value"])))
+    if not rows:
+        raise SystemExit("no FETCH_SIZE rows")
+    rows.sort()
+    line = json.loads(open(bench_json).read().strip().splitlines()[-1])
+    cfg = line["config"] if "decode_iterations" in line.get("config", {}) else line.get("cfg5", {}).get("config", {})
+    iters = int(cfg["decode_iterations"])
+    per = {}
+    for _, name, kb in rows:
+        short = name.split("(")[0][-110:]
+        e = per.setdefault(short, [0, 0.0])
+        e[0] += 1
+        e[1] += kb * 1024.0 * 2.0
+    gqa = [i for i, (_, name, _) in enumerate(rows) if "gqa_attn" in name]
+    rep = {"source": f"rocprofv3 --pmc FETCH_SIZE --kernel-trace -- {command}", "gfx950_wide_read_correction": 2.0,
+           "hbm_read_bytes_total": sum(v[1] for v in per.values()),
+           "kernels": {k: {"dispatches": v[0], "hbm_read_bytes": v[1], "per_dispatch": v[1] / v[0]}
+                       for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])[:24]}}
+    if gqa:
+        # one generation per step: with several steps the ranges of the steps are contiguous blocks separated by prompt passes
+        blocks, start, prev = [], gqa[0], gqa[0]
+        big_gap = 4000                   # dispatches: a prefill / aligner pass between two generations is far longer than a decode layer
+        for i in gqa[1:]:
+            if i - prev > big_gap:
+                blocks.append((start, prev)); start = i
+            prev = i
+        blocks.append((start, prev))
+        tot = sum(sum(kb for _, _, kb in rows[a: b + 1]) for a, b in blocks) * 1024.0 * 2.0
+        rep["decode"] = {"generations": len(blocks), "iterations_per_generation": iters,
+                         "hbm_read_bytes_per_iteration": tot / (len(blocks) * iters),
+                         "decoder_weight_bytes_per_iteration": cfg.get("decoder_weight_bytes_per_iteration"),
+                         "note": "all dispatches from the first to the last gqa_attn_kernel launch of a generation (layers' GEMMs, norms, RoPE, attention, "
+                                 "LM head, top-1); the KV cache reads of the live rows come on top of the weight stream"}
+    with open(out, "w") as f:
+        json.dump(rep, f, indent=1)
+    print(json.dumps({k: rep[k] for k in ("hbm_read_bytes_total", "decode") if k in rep}))
+
+
 def pmc(d, out, kernel, windows, command):
     if isinstance(windows, str) and windows.startswith("auto:"):      # windows of a full-batch launch from the bench line
         line = json.load(open(windows[5:]))
@@ -152,6 +205,8 @@ if __name__ == "__main__":
         stats(sys.argv[2], sys.argv[3])
     elif len(sys.argv) >= 5 and sys.argv[1] == "mfma":
         mfma(sys.argv[2], sys.argv[3], " ".join(sys.argv[4:]))
+    elif len(sys.argv) >= 6 and sys.argv[1] == "fetch":
+        fetch(sys.argv[2], sys.argv[3], sys.argv[4], " ".join(sys.argv[5:]))
     elif len(sys.argv) >= 7 and sys.argv[1] == "pmc":
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], " ".join(sys.argv[6:]))
     else:

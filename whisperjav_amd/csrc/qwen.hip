@@ -19,9 +19,13 @@
 #include "kernels.hpp"
 
 namespace wj {
-int g_qwen_split_act = 3;   // wj_tune("qwen_split_act"), read at wj_qwen_create.  3 (default since round 5: every projection input travels as a [hi | lo]
-                            // pair) is the mode that meets the 1e-3 per-token bar at the published geometry (decoder 6.5e-4; mode 2 = only the
-                            // o_proj / down_proj / LM-head inputs: 1.06e-3, profiles/r05_parity_diag_qwen*.jsonl)
+int g_qwen_split_act = 5;   // wj_tune("qwen_split_act"), read at wj_qwen_create: which GEMM inputs of the float16 decoder travel as [hi | lo] pairs.
+                            // 1 = LM head; 2 = + o_proj / down_proj inputs and the qkv / gate-up outputs (round 4's default: 1.06e-3 per token at
+                            // the published geometry); 3 = + both RMSNorm outputs (every projection input); 4 / 5 = 2 + only the q/k/v input /
+                            // only the gate/up input.  Round 5 ablation at the published geometry (profiles/r05_parity_diag_qwen_split_ablation.jsonl,
+                            // decoder alone / end to end): 2: 1.06e-3 / 1.06e-3, 4: 1.60e-3 / 8.3e-4, 3: 6.5e-4 / 9.3e-4, 5: 3.8e-4 / 4.0e-4 -- the
+                            // gate/up input is the rounding point that matters (K = hidden into 2 x ffn columns feeding a product of two
+                            // activations); the q/k/v input is inside the noise.  5 is the default: inside the 1e-3 bar at 1/4 of mode 3's cost
 int g_qwen_fuse_swiglu = 1;  // wj_tune("qwen_fuse_swiglu"): SwiGLU in the gate-up GEMM's epilogue (0 = the separate element-wise pass, for A/B)
 int g_qwen_prompt_mfma = 1;  // wj_tune("qwen_prompt_mfma"): prompts of the 16-bit types take the MFMA tile attention (0 = the one-row-per-wave kernel)
 int g_qwen_splitk = 4;       // wj_tune("qwen_splitk"): o_proj / down_proj of a 16-bit pass of 65 .. max_seqs rows are cut into this many K slices whose
@@ -656,7 +660,11 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
     const int b0 = m->layer_base(l);
     void* kc = m->at(m->kc, l * layer_kv);
     void* vc = m->at(m->vc, l * layer_kv);
-    const int sp_in = (split && m->split_mode >= 3) ? 1 : 0;      // the projections' INPUT (h) as [hi | lo] too
+    // the projections' INPUT (h) as [hi | lo] too: mode 3 = both RMSNorm outputs, 4 = the one feeding q / k / v only, 5 = the one feeding
+    // gate / up only (per-projection ablations of mode 3, measured in profiles/r05_parity_diag_qwen_split_ablation.jsonl)
+    const int sp_qkv = (split && (m->split_mode == 3 || m->split_mode == 4)) ? 1 : 0;
+    const int sp_gu = (split && (m->split_mode == 3 || m->split_mode == 5)) ? 1 : 0;
+    int sp_in = sp_qkv;
     auto rms = [&](const float* w, void* out) -> int {      // completes the residual stream from pending split-K slices first
       const float* sl = pending ? m->slab : nullptr;
       if (dt == WJ_F32) hipLaunchKernelGGL((rmsnorm_kernel<float>), dim3(M), dim3(256), 0, s, m->x, w, TP(float, out), M, D, d.rms_eps, 0, sl, pending);
@@ -728,6 +736,7 @@ int run_layers(wj_qwen* m, int M, hipStream_t s, bool split) {
       WJ_TRYQ(mx(g, l, 1));
       WJ_TRYQ(resid_gemm(g, gemm_variant(QG_O, M, H * HD, dt)));
     }
+    sp_in = sp_gu;
     WJ_TRYQ(rms(m->F(b0 + WJ_QL_LN2_W), m->h));
     const int gu_variant = gemm_variant(QG_GATEUP, M, D, dt);
     // SwiGLU inside the gate-up GEMM's epilogue whenever an MFMA tile kernel serves the pass (16-bit types, more than 64 rows):
@@ -859,7 +868,7 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   m->max_seqs = max_seqs; m->max_ctx = max_ctx; m->max_rows = max_rows;
   const size_t e = m->esz, R = max_rows, S = max_seqs;
   const int D = d.hidden, H = d.n_head, KV = d.n_kv_head, F = d.ffn;
-  m->split_mode = dtype == WJ_F16 && (D % 64) == 0 && (F % 64) == 0 ? std::max(0, std::min(3, g_qwen_split_act)) : 0;
+  m->split_mode = dtype == WJ_F16 && (D % 64) == 0 && (F % 64) == 0 ? std::max(0, std::min(5, g_qwen_split_act)) : 0;      // 4 / 5: ablations of 3 (qkv input only / gate-up input only)
   m->mx8 = f8w;
   if (f8w && m->split_mode == 0) m->split_mode = 1;      // the LM head keeps fp16 weights and split activations
   const size_t sm = m->split_mode ? 2 : 1;

@@ -35,7 +35,7 @@ from . import hipbind
 from .hipbind import DTYPES, check
 
 ALIGN = 256
-DEFAULT_SPLIT_ACT = 3      # csrc/qwen.hip g_qwen_split_act
+DEFAULT_SPLIT_ACT = 5      # csrc/qwen.hip g_qwen_split_act
 LAYER_TENSORS = ("LN1_W", "QKV_W", "QNORM_W", "KNORM_W", "O_W", "LN2_W", "GATEUP_W", "DOWN_W")     # order of WJ_QL_* in wjhip.h
 
 
@@ -587,9 +587,10 @@ class HipQwen3Decoder:
 
     def __init__(self, dims: Qwen3Dims, weights: Dict[str, np.ndarray], *, dtype: str = "float16", device: int = 0,
                  max_seqs: int = 8, max_ctx: int = 512, max_rows: Optional[int] = None, split_act: Optional[int] = None):
-        """``split_act`` (float16): which GEMM inputs travel as [hi | lo] pairs -- None = the library default (3: every projection
-        input; the mode that meets the 1e-3 per-token log-prob bar), 2 = o_proj / down_proj / LM head only (what the forced
-        aligner runs: its outputs are arg-max time bins, not log-probs), 1 / 0 for A/B."""
+        """``split_act`` (float16): which GEMM inputs travel as [hi | lo] pairs -- None = the library default (5: o_proj / down_proj /
+        LM head / gate-up inputs; the cheapest mode inside the 1e-3 per-token log-prob bar, csrc/qwen.hip), 3 = every projection
+        input, 2 = o_proj / down_proj / LM head only (what the forced aligner runs: its outputs are arg-max time bins, not
+        log-probs), 4 / 1 / 0 for A/B."""
         if dtype not in DTYPES and dtype != "float8w":
             raise ValueError(f"dtype must be one of {sorted(DTYPES)} or 'float8w'")
         if not torch.cuda.is_available():

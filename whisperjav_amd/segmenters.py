@@ -528,21 +528,22 @@ class _ReplayModel:
     ``model(chunk, sr)`` calls are answered, in order, from the device's probabilities for the same window grid."""
 
     def __init__(self, probs: np.ndarray, window: int):
-        self._probs, self._window, self._i = np.asarray(probs, dtype=np.float32), int(window), 0
+        import torch
+        self._probs, self._window, self._i = np.ascontiguousarray(probs, dtype=np.float32), int(window), 0
+        self._t = torch.from_numpy(self._probs)        # 0-d views of it answer the calls: no tensor is built per window
 
     def reset_states(self) -> None:
         self._i = 0
 
     def __call__(self, chunk, sr=VAD_SR):
-        import torch
         if int(chunk.shape[-1]) != self._window:
             raise ValueError(f"the archive's get_speech_timestamps scores {int(chunk.shape[-1])}-sample windows, the device scored "
                              f"{self._window}-sample ones: pass window_size_samples={int(chunk.shape[-1])}")
         if self._i >= len(self._probs):
             raise IndexError(f"the archive's get_speech_timestamps asks for window {self._i} of {len(self._probs)}")
-        p = float(self._probs[self._i])
+        out = self._t[self._i]
         self._i += 1
-        return torch.tensor(p)
+        return out
 
 
 class NullSpeechSegmenter:
