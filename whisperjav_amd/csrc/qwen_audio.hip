@@ -21,9 +21,12 @@
 #include "kernels.hpp"
 
 namespace wj {
-int g_qwen_tower_split = 1;   // wj_tune("qwen_tower_split"), read at wj_qwen_audio_create (float16 towers): the inputs of every transformer / projector GEMM
-                              // travel as [hi | lo] fp16 pairs (LayerNorm, attention, GELU outputs): the embeddings' error falls from 4.9e-4 to 1.0e-4 of
-                              // their range (scripts/precision_qwen_tower.py), which is what the decoder's 1e-3 log-prob bar needs end to end
+int g_qwen_tower_split = 2;   // wj_tune("qwen_tower_split"), read at wj_qwen_audio_create (float16 towers): 1 = the inputs of every transformer / projector
+                              // GEMM, the mel patches, the third convolution's output and the attention's QUERIES travel as [hi | lo] fp16 pairs
+                              // (embedding error 4.6e-4 -> 1.06e-4 of their range on the device; oracle study scripts/precision_qwen_tower.py);
+                              // 2 (default) = the attention's keys and values as well (-> 6.0e-5) for +45 ms per 1800-clip cfg5 step.  End to end
+                              // at the published geometry (decoder mode 5): 4.0e-4 per token at level 2, 7.0e-4 / 8.9e-4 (two clips) at level 1,
+                              // profiles/r05_parity_diag_qwen_tower_levels.jsonl; 0 = plain
 int g_qwen_conv_kpad = 0;   // wj_tune("qwen_conv_kpad"), read at wj_qwen_audio_create: pad the 3x3 convolutions' K = 9 C to a multiple of 64 so their
                             // GEMMs take the LDS-DMA tile kernel.  Measured (scripts/qwen_tower_kpad_ab.py, 512 clips of 4 s, published tower):
                             // 61.2 ms against 61.7 ms, identical output -- the stem is bound by the patch matrices' HBM traffic, not by operand
@@ -107,8 +110,11 @@ __global__ __launch_bounds__(256) void pos_select_kernel(const float* __restrict
 template <typename T, int QB>
 __global__ __launch_bounds__(64) void win_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_lo,
                                                       const int32_t* __restrict__ win_hi, T* __restrict__ out, int D, int N, int split) {
-  // split: qkv rows are [hi(3D) | lo(3D)] as well (the QKV GEMM's split_out): every q / k / v load is hi + lo
-  const int64_t ldq = (int64_t)(split ? 6 : 3) * D, lo_off = split ? 3 * D : 0;
+  // split (bit 0): qkv rows are [hi(3D) | lo(3D)] (the QKV GEMM's split_out) and the output rows [hi(D) | lo(D)]; the query is
+  // read as hi + lo (one extra load per query).  Bit 1: keys and values as hi + lo too -- twice the K / V loads, which are what this
+  // kernel is bound by (2.1x its time, profiles/r05_rocprofv3_kernel_stats_cfg5.csv); wj_tune qwen_tower_split 2
+  const int64_t ldq = (int64_t)(split ? 6 : 3) * D, lo_off = split ? 3 * D : 0, kv_lo = (split & 2) ? 3 * D : 0;
+  split &= 1;
   constexpr int STEPS = 8;
   const int i0 = blockIdx.x * QB, h = blockIdx.y, lane = threadIdx.x, kq = lane >> 3, dq = lane & 7;
   int lo[QB], hi[QB], ulo = INT_MAX, uhi = 0;
@@ -139,9 +145,9 @@ __global__ __launch_bounds__(64) void win_attn_kernel(const T* __restrict__ qkv,
       if (base + st * 8 < uhi) {                    // wave-uniform
         float kv[8];
         ld8(Kb + (int64_t)min(key, uhi - 1) * ldq, kv);
-        if (lo_off) {
+        if (kv_lo) {
           float t8[8];
-          ld8(Kb + (int64_t)min(key, uhi - 1) * ldq + lo_off, t8);
+          ld8(Kb + (int64_t)min(key, uhi - 1) * ldq + kv_lo, t8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) kv[e] += t8[e];
         }
@@ -181,9 +187,9 @@ __global__ __launch_bounds__(64) void win_attn_kernel(const T* __restrict__ qkv,
       if (base + st * 8 < uhi) {
         float vv[8];
         ld8(Vb + (int64_t)min(base + st * 8 + kq, uhi - 1) * ldq, vv);
-        if (lo_off) {
+        if (kv_lo) {
           float t8[8];
-          ld8(Vb + (int64_t)min(base + st * 8 + kq, uhi - 1) * ldq + lo_off, t8);
+          ld8(Vb + (int64_t)min(base + st * 8 + kq, uhi - 1) * ldq + kv_lo, t8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) vv[e] += t8[e];
         }
@@ -298,7 +304,7 @@ int wj_qwen_audio_create(wj_ctx* ctx, const wj_qwen_audio_dims* dims, int dtype,
     const size_t k9 = 9 * C, kpad = (k9 + 63) / 64 * 64;
     m->kp = (g_qwen_conv_kpad && dtype != WJ_F32 && kpad != k9) ? (int)kpad : 0;
   }
-  m->split = (dtype == WJ_F16 && g_qwen_tower_split) ? 1 : 0;
+  m->split = (dtype == WJ_F16 && g_qwen_tower_split) ? (g_qwen_tower_split >= 2 ? 3 : 1) : 0;
   const size_t sp = m->split ? 2 : 1;
   const size_t Kc = m->kp ? (size_t)m->kp : 9 * C;
   AA(col, NC * 32 * 25 * Kc * e);                    // the largest patch matrix (second convolution)
@@ -382,7 +388,7 @@ int wj_qwen_audio_encode(wj_qwen_audio* m, const float* mel_dev, int n_clips, in
     g.split = split_in; g.split_out = split_out;
     return launch_gemm(dt, epi, g, s, 0);
   };
-  const int sp = m->split, spm = sp ? 2 : 1;
+  const int sp = m->split ? 1 : 0, spm = sp ? 2 : 1, sp_attn = m->split;
   // ---- convolution stem -------------------------------------------------------------------------------------------
   {
     const int64_t rows = (int64_t)NC * 64 * 50;
@@ -419,7 +425,7 @@ int wj_qwen_audio_encode(wj_qwen_audio* m, const float* mel_dev, int n_clips, in
       constexpr int QB = 4;
       const dim3 grid(ceil_div(N, QB), H);
       if (dt == WJ_F32) hipLaunchKernelGGL((win_attn_kernel<float, QB>), grid, dim3(64), 0, s, TPA(const float, m->qkv), m->win_lo, m->win_hi, TPA(float, m->attn), D, N, 0);
-      else if (dt == WJ_F16) hipLaunchKernelGGL((win_attn_kernel<f16_t, QB>), grid, dim3(64), 0, s, TPA(const f16_t, m->qkv), m->win_lo, m->win_hi, TPA(f16_t, m->attn), D, N, sp);
+      else if (dt == WJ_F16) hipLaunchKernelGGL((win_attn_kernel<f16_t, QB>), grid, dim3(64), 0, s, TPA(const f16_t, m->qkv), m->win_lo, m->win_hi, TPA(f16_t, m->attn), D, N, sp_attn);
       else hipLaunchKernelGGL((win_attn_kernel<bf16_t, QB>), grid, dim3(64), 0, s, TPA(const bf16_t, m->qkv), m->win_lo, m->win_hi, TPA(bf16_t, m->attn), D, N, 0);
     }
     WJ_LAUNCH_CHECK();
