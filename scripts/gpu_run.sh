@@ -20,7 +20,7 @@ plan="$1"; shift
 case "$plan" in
   tests)
     args=("$@"); [ ${#args[@]} -eq 0 ] && args=(tests)
-    timeout 2400 python -m pytest "${args[@]}" -m gpu -q --timeout 900 --maxfail=25 > gpurun_out/pytest_gpu.log 2>&1
+    timeout 2400 python -m pytest "${args[@]}" -m gpu -q --timeout 900 --maxfail=25 --durations=30 > gpurun_out/pytest_gpu.log 2>&1
     note "pytest ${args[*]} rc=$?"; tail -8 gpurun_out/pytest_gpu.log ;;
   smoke)
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1

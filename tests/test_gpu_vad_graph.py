@@ -13,13 +13,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _streams():
-    a = S.bursty_audio(24.0, seed=3)
-    b = S.bursty_audio(9.3, seed=4, gaps=((1.0, 2.2), (5.0, 6.4)))
-    return [a, b[: 16000 * 9 + 777], a[5000: 5000 + 1536 * 3], b[:1000], a[16000 * 10: 16000 * 21 + 5]]
+    a = S.bursty_audio(16.0, seed=3, gaps=((2.0, 4.5), (7.0, 8.0), (12.0, 14.5)))
+    b = S.bursty_audio(6.3, seed=4, gaps=((1.0, 2.2), (4.0, 5.4)))
+    return [a, b[: 16000 * 6 + 777], a[5000: 5000 + 1536 * 3], b[:1000], a[16000 * 6: 16000 * 13 + 5]]
 
 
-@pytest.mark.parametrize("variant", ["v4", "v3"])
-@pytest.mark.parametrize("window", [1536, 512])
+@pytest.mark.parametrize("variant,window", [("v4", 1536), ("v3", 1536), ("v4", 512)])
 def test_device_probabilities_equal_the_archive_on_the_cpu(hip, variant, window):
     """Five ragged streams in ONE call (a stream shorter than a window, lengths that are and are not multiples of it), state
     carried per stream and reset between streams, host clips and HBM-resident clips: <= 1e-5 on every window probability."""
@@ -85,7 +84,7 @@ def test_default_segmenter_scores_on_the_device(hip, tmp_path, route):
         assert key(seg.segment(c, sample_rate=16000)) == key(want)
         assert key(seg.segment(torch.from_numpy(c).cuda(), sample_rate=16000)) == key(want)
         n_seg += len(want.segments)
-    assert n_seg >= 4
+    assert n_seg >= 3
     seg.cleanup()
 
 
