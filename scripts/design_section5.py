@@ -87,7 +87,7 @@ def main():
         s5, r5 = c5["config"]["stages"], c5["roofline"]
         w("| quantity | value | file / key |")
         w("|---|---|---|")
-        w(f"| step (RAW log-mel -> tower -> ragged prefill -> greedy generation to EOS, penalty 1.1, per-clip budgets -> aligner pass) | **{c5['ms_per_step'] / 1e3:.2f} s = {c5['value']:.0f}x** | `cfg5` |")
+        w(f"| step (RAW log-mel -> tower -> ragged prefill -> greedy generation to EOS, penalty 1.1, per-clip budgets -> aligner pass) | **{c5['ms'] / 1e3:.2f} s = {c5['rtfx']:.0f}x** | `cfg5` |")
         w(f"| stages | log-mel {s5['log_mel_ms']:.0f}, tower {s5['audio_tower_ms']:.0f}, prefill {s5['prefill_ms']:.0f} ({s5['prompt_rows']} rows), generate {s5['generate_ms']:.0f} ({s5['decode_iterations']} iterations, {s5['decode_row_iterations']} row-iterations), aligner {s5['aligner_ms']:.0f} ms ({s5['aligner_rows']} rows) | `cfg5.config.stages` |")
         tr = r5.get("traffic")
         w(f"| decode iteration vs the MFMA roof | {r5['achieved']:.0f} TFLOP/s = **{r5['frac']:.3f}** ({r5['kernel']}); fabric reads per iteration by counters {'%.0f GB' % (tr / 1e9) if tr else 'n/a'} against {c5['config']['decoder_weight_bytes_per_iteration'] / 1e9:.2f} GB of weights: every XCD's L2 fetches its own copy of the operands (FETCH_SIZE counts Infinity-Cache hits) | `cfg5.roofline`, `r05_pmc_fetch_cfg5.json` |")
