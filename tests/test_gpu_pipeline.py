@@ -1300,6 +1300,52 @@ def test_bench_two_gpus_strong_scaling_equals_one_gpu(hip):
     assert sum(r["segment_digest"] for r in ranks2) % (1 << 32) == ranks1[0]["segment_digest"]
 
 
+def test_batch_invariant_mode_makes_a_window_independent_of_its_batch(hip):
+    """``wj_tune("batch_invariant", 1)`` (one GEMM kernel family, fixed split-K factors whatever the row count): the same 22 clips
+    transcribed (a) in one pool through an engine of 16 resident windows and (b) as two shards in another order through an engine
+    of 4 (20 decode rows: the default mode's one-wave-per-row kernels; 80: its skinny / tile kernels) give BIT-IDENTICAL tokens,
+    log-probs and timestamps per clip, float16, beam 5, searches that end, word timestamps on.  This is what lets a multi-GPU run
+    reproduce the single-GPU transcript exactly (test_bench_two_gpus_strong_scaling_equals_one_gpu runs in this mode); the
+    default mode picks the fastest kernel per row count and is recorded beside it."""
+    from whisperjav_amd import hipbind, synth, weights as pweights, whisper_model as wm
+    d = helpers.small_dims()
+    w = pweights.synth_weights(d, seed=33, exact="float16", **pweights.SPEECHLIKE)
+    clips = [synth.speech_like(0.8 + 0.45 * i, seed=300 + i) for i in range(22)]
+    kw = dict(task="transcribe", language="ja", beam_size=5, patience=1.2, repetition_penalty=1.5, no_repeat_ngram_size=3,
+              temperature=0.0, condition_on_previous_text=False, max_new_tokens=48, no_speech_threshold=None,
+              max_initial_timestamp=0.0, word_timestamps=True, log_prob_threshold=None, compression_ratio_threshold=None)
+    key = lambda segs: [(s.seek, s.start, s.end, tuple(s.tokens), float(s.avg_logprob),     # noqa: E731
+                         tuple((x.start, x.end, float(x.probability)) for x in (s.words or []))) for s in segs]
+    order = list(range(1, 22, 2)) + list(range(0, 22, 2))                  # shard 1 then shard 0 of an alternating plan
+
+    def run(mode, max_batch, idx_lists):
+        hipbind.tune("batch_invariant", mode)
+        try:
+            model = wm.HipWhisperModel("tiny", compute_type="float16", weights=w, dims=d, max_batch=max_batch, max_beam=5, kv_len=3 + 48 + 5)
+            model.word_reseek = False
+            out = {}
+            for idx in idx_lists:
+                per_clip, _ = model.transcribe_many([clips[i] for i in idx], **kw)
+                for i, segs in zip(idx, per_clip):
+                    out[i] = key(segs)
+            model.close()
+            return out
+        finally:
+            hipbind.tune("batch_invariant", 0)
+
+    pooled = run(1, 16, [list(range(22))])
+    sharded = run(1, 4, [order[:11], order[11:]])
+    assert sum(len(v) for v in pooled.values()) >= 22
+    diff = [i for i in range(22) if pooled[i] != sharded[i]]
+    fast_pooled, fast_sharded = run(0, 16, [list(range(22))]), run(0, 4, [order[:11], order[11:]])
+    same_tokens = sum([t[3] for t in fast_pooled[i]] == [t[3] for t in fast_sharded[i]] for i in range(22))
+    _diag("batch_invariant", {"clips": 22, "invariant_mode_clips_that_differ": diff, "default_mode_clips_with_identical_tokens": same_tokens,
+                              "default_mode_bit_identical_clips": sum(fast_pooled[i] == fast_sharded[i] for i in range(22)),
+                              "invariant_equals_default_tokens": sum([t[3] for t in pooled[i]] == [t[3] for t in fast_pooled[i]] for i in range(22))})
+    assert not diff, diff
+    assert same_tokens >= 20            # default mode: near-tie flips only
+
+
 @pytest.mark.parametrize("flavour", ["fw", "ow"])
 def test_encoder_of_the_next_chunk_overlaps_the_decode_of_this_one(hip, flavour):
     """``transcribe_many`` encodes chunk i + 1 on a second stream into the other half of the resident window slots while

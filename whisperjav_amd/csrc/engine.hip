@@ -431,7 +431,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       PROF(tag, launch_gemm(dt, EPI_PARTIAL_F32, g, s, variant));
     } else {
       g.bias = bias; g.out = dx;
-      PROF(tag, launch_gemm(dt, EPI_RESID_F32, g, s, rows ? 5 : 0));
+      PROF(tag, launch_gemm(dt, EPI_RESID_F32, g, s, rows ? 5 : (inv ? 3 : 0)));      // batch_invariant: never the dispatcher's M-dependent choice
     }
     return WJ_OK;
   };
@@ -459,7 +459,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
       if (deferred && g_tune.dec_fuse_reduce) *deferred = ks;
       else PROF(tag, launch_splitk_reduce(dt, epi, g, slab, ks, s));
     } else {
-      PROF(tag, launch_gemm(dt, epi, g, s));
+      PROF(tag, launch_gemm(dt, epi, g, s, inv ? 3 : 0));
     }
     return WJ_OK;
   };
