@@ -401,11 +401,8 @@ class _Lowerer:
 
     def _attr(self, obj: Any, name: str) -> Any:
         key = (id(obj), name)
-        if key in self.overlay:
-            v = self.overlay[key]
-            if isinstance(v, Sym) and key in self.state_slots and v.space != SPACE_STATE:
-                return v            # written earlier in THIS walk
-            return v
+        if key in self.overlay:            # written by a SetAttr of this or an earlier walk (state slots, bookkeeping ints)
+            return self.overlay[key]
         try:
             return getattr(obj, name)
         except Exception as e:
@@ -772,6 +769,8 @@ class HipGraphVadScorer:
             raise hipbind.WjError("no ROCm device visible: the HIP VAD graph scorer has no CPU fallback")
         module = load_archive(archive) if isinstance(archive, str) else archive
         self.program = lower(module, window, sample_rate)
+        # windows per launch group: grid.y of the batched launches (< 65536) and at most 8 GiB of arenas
+        max_windows_per_launch = max(1, min(int(max_windows_per_launch), 65535, (8 << 30) // max(4, 4 * self.program.arena_floats)))
         self.window, self.sample_rate = int(window), int(sample_rate)
         self.device = int(device)
         self.dev = torch.device("cuda", device)
