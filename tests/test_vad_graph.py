@@ -119,3 +119,54 @@ def test_standin_get_speech_timestamps_equals_the_restated_state_machine():
         got = vad.regions_from_probs(probs, n, sampling_rate=16000, max_speech_duration_s=float("inf"), neg_threshold=kw["threshold"] - 0.15,
                                      window=1536, **kw)
         assert got == want, (trial, kw)
+
+
+class _OpZoo(nn.Module):
+    """Ops of the loader's table that the silero-shaped stand-ins do not use: every one lowered and executed (NumPy executor)."""
+
+    def __init__(self):
+        super().__init__()
+        self.c1 = nn.Conv1d(2, 6, 4, stride=3, padding=2, dilation=2)
+        self.c2 = nn.Conv1d(6, 6, 3, groups=3, bias=False)
+        self.lin = nn.Linear(6, 3)
+        self.register_buffer("scale", torch.tensor([0.5, 2.0, 1.5]).view(1, 3, 1))
+
+    def forward(self, x: torch.Tensor, sr: int) -> torch.Tensor:
+        a = x.view(1, 2, -1)                                            # two "channels" of 256 samples
+        a = torch.nn.functional.pad(a, [3, 1], mode="constant", value=0.25)
+        a = torch.nn.functional.pad(a, [2, 2], mode="replicate")
+        b = torch.nn.functional.silu(self.c1(a))
+        b = torch.nn.functional.hardtanh(self.c2(b), -0.8, 0.9)
+        b = b[:, :, 1:-1:2]                                             # strided slice
+        c = self.lin(b.transpose(1, 2))                                 # [1, T, 3]
+        c = c.permute(0, 2, 1) * self.scale                             # broadcast constant
+        c = torch.clamp(c, min=-2.0) + torch.clamp_max(c, 1.0) * 0.5
+        d = (1.0 - c.square()).abs().rsqrt().clamp(max=5.0)
+        e = c.sum(dim=2, keepdim=True).expand(1, 3, c.shape[2]) / 7.0
+        f = torch.cat([d, e, torch.nn.functional.leaky_relu(c, 0.2)], dim=1)        # [1, 9, T]
+        g = f.flatten(1).select(0, 0)                                   # [9 T]
+        h = (g.reciprocal().neg().exp() - g * 0.01).mean()
+        return torch.sigmoid(h.view(1))
+
+
+def test_every_op_of_the_table_lowers_and_executes():
+    torch.manual_seed(3)
+    m = torch.jit.script(_OpZoo().eval())
+    p = vg.lower(m, 512)
+    rng = np.random.default_rng(2)
+    audio = (rng.standard_normal(512 * 6) * 0.3).astype(np.float32)
+    with torch.no_grad():
+        ref = np.array([float(m(torch.from_numpy(audio[i: i + 512]), 16000)) for i in range(0, len(audio), 512)], dtype=np.float32)
+    got = R.run_stream(p, audio)
+    assert np.abs(got - ref).max() < 5e-6, (got, ref)
+    kinds = " ".join(p.listing)
+    for op in ("pad.constant", "pad.replicate", "ew.silu", "ew.hardtanh", "linear", "ew.clamp", "ew.pow_scalar", "ew.leaky_relu", "ew.exp", "mean"):
+        assert op in kinds, op
+
+
+def test_the_device_scorer_refuses_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from whisperjav_amd import hipbind
+    with pytest.raises(hipbind.WjError, match="no CPU fallback"):
+        vg.HipGraphVadScorer(S.build("v4", seed=7))
