@@ -117,3 +117,28 @@ def test_model_names_resolve_only_through_the_local_cache(monkeypatch, tmp_path)
     monkeypatch.setenv("HF_HUB_OFFLINE", "1")
     assert ct2.FASTER_WHISPER_REPOS["large-v3"] == "Systran/faster-whisper-large-v3"
     assert ct2.resolve_cached_model("large-v3") is None and ct2.resolve_cached_model("not-a-model") is None
+
+
+def test_vocabulary_file_decodes_text_when_the_directory_has_no_tokenizer_json(tmp_path):
+    """A CTranslate2 directory without ``tokenizer.json`` (faster-whisper would fetch one from the hub): ``VocabTokenizer`` decodes
+    the byte-level BPE token strings of ``vocabulary.json`` -- pinned against the ``tokenizers`` library's own ByteLevel decoder
+    and alphabet; multi-byte characters split across tokens come back whole; encoding text is refused with the reason."""
+    tokenizers = pytest.importorskip("tokenizers")
+    from whisperjav_amd import whisper_model as wm
+    table = wm._bytes_to_unicode()
+    assert sorted(table.values()) == sorted(tokenizers.pre_tokenizers.ByteLevel.alphabet()) and len(set(table.values())) == 256
+    rng = np.random.default_rng(1)
+    text = " こんにちは、世界。 Thank you — naïve café ✓ あっ…"
+    raw = text.encode("utf-8")
+    cuts = sorted(set(rng.integers(1, len(raw), 14).tolist()))
+    pieces = [raw[a:b] for a, b in zip([0] + cuts, cuts + [len(raw)])]
+    vocab = ["<|endoftext|>"] + ["".join(table[b] for b in p) for p in pieces]
+    (tmp_path / "vocabulary.json").write_text(json.dumps(vocab, ensure_ascii=False), encoding="utf-8")
+    tok = wm.VocabTokenizer.from_directory(str(tmp_path))
+    ids = list(range(1, len(vocab)))
+    assert tok.decode(ids) == text == tokenizers.decoders.ByteLevel().decode(vocab[1:])
+    assert tok.decode(ids + [0]).endswith("<|endoftext|>") and tok.token_to_id("<|endoftext|>") == 0
+    words, word_tokens = tok.split_tokens_on_unicode(ids)
+    assert "".join(words) == text and sum(len(t) for t in word_tokens) == len(ids) and all("�" not in w_ for w_ in words)
+    with pytest.raises(ValueError, match="merge table"):
+        tok.encode("こんにちは")

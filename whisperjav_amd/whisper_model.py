@@ -96,6 +96,73 @@ class IdTokenizer:
         return [f"<{t}>" for t in tokens], [[int(t)] for t in tokens]
 
 
+def _bytes_to_unicode() -> Dict[int, str]:
+    """The byte <-> printable-character table of byte-level BPE vocabularies (GPT-2's ``bytes_to_unicode``, which Whisper's
+    multilingual vocabulary uses): printable latin-1 bytes map to themselves, the rest to code points from 256 up."""
+    keep = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAC + 1)) + list(range(0xAE, 0xFF + 1))
+    table, extra = {}, 0
+    for b in range(256):
+        if b in keep:
+            table[b] = chr(b)
+        else:
+            table[b] = chr(256 + extra)
+            extra += 1
+    return table
+
+
+class VocabTokenizer:
+    """Decode-only tokenizer over a CTranslate2 directory's ``vocabulary.json`` / ``vocabulary.txt`` (the token strings of the
+    byte-level BPE vocabulary, one per id) for model directories that ship no ``tokenizer.json``: transcripts come out as TEXT
+    (faster-whisper would fetch ``openai/whisper-tiny``'s tokenizer from the hub in that case; nothing is downloaded here).
+    Encoding needs the merge table, which the vocabulary file does not hold: ``initial_prompt`` / ``hotwords`` / ``prefix`` as
+    text raise with that explanation (token-id lists are accepted where the shim's callers may pass them)."""
+
+    real = True
+
+    def __init__(self, tokens: Sequence[str]):
+        self._tokens = list(tokens)
+        self._byte_of = {c: b for b, c in _bytes_to_unicode().items()}
+        self._ids = {t: i for i, t in enumerate(self._tokens)}
+
+    @classmethod
+    def from_directory(cls, path: str) -> Optional["VocabTokenizer"]:
+        import json
+        js, txt = os.path.join(path, "vocabulary.json"), os.path.join(path, "vocabulary.txt")
+        if os.path.exists(js):
+            with open(js, encoding="utf-8") as f:
+                return cls(json.load(f))
+        if os.path.exists(txt):
+            with open(txt, encoding="utf-8") as f:
+                return cls([line.rstrip("\n") for line in f])
+        return None
+
+    def _token_bytes(self, t: int) -> bytes:
+        tok = self._tokens[t] if 0 <= t < len(self._tokens) else ""
+        if tok.startswith("<|") and tok.endswith("|>"):
+            return tok.encode("utf-8")                       # special tokens render as written, like tokenizers does
+        out = bytearray()
+        for ch in tok:
+            b = self._byte_of.get(ch)
+            out.extend(bytes([b]) if b is not None else ch.encode("utf-8"))
+        return bytes(out)
+
+    def decode(self, tokens: Sequence[int]) -> str:
+        return b"".join(self._token_bytes(int(t)) for t in tokens).decode("utf-8", errors="replace")
+
+    def encode(self, text: str) -> List[int]:
+        raise ValueError("this model directory has a vocabulary file but no tokenizer.json (no BPE merge table): text prompts cannot be "
+                         "encoded; copy tokenizer.json of the matching openai/whisper-* repository into the directory")
+
+    def token_to_id(self, token: str) -> Optional[int]:
+        return self._ids.get(token)
+
+    def non_speech_tokens(self) -> List[int]:
+        return []
+
+    split_tokens_on_unicode = None      # bound below (shared with HfTokenizer: they only need decode())
+    split_to_word_tokens = None
+
+
 _NO_SPACE_LANGUAGES = {"zh", "ja", "th", "lo", "my", "yue"}
 
 
@@ -163,6 +230,28 @@ class HfTokenizer:
 def compression_ratio(text: str) -> float:
     raw = text.encode("utf-8")
     return len(raw) / len(zlib.compress(raw)) if raw else 0.0
+
+
+def _vocab_split_to_word_tokens(self, tokens: Sequence[int], language: str = "ja"):
+    import string
+    words, word_tokens = HfTokenizer.split_tokens_on_unicode(self, tokens)
+    if language in _NO_SPACE_LANGUAGES:
+        return words, word_tokens
+    eot = self.token_to_id("<|endoftext|>")
+    out_w, out_t = [], []
+    for sub, sub_t in zip(words, word_tokens):
+        special = eot is not None and sub_t[0] >= eot
+        if special or sub.startswith(" ") or sub.strip() in string.punctuation or not out_w:
+            out_w.append(sub)
+            out_t.append(list(sub_t))
+        else:
+            out_w[-1] += sub
+            out_t[-1].extend(sub_t)
+    return out_w, out_t
+
+
+VocabTokenizer.split_tokens_on_unicode = HfTokenizer.split_tokens_on_unicode
+VocabTokenizer.split_to_word_tokens = _vocab_split_to_word_tokens
 
 
 @dataclass
@@ -329,6 +418,10 @@ class HipWhisperModel:
             if os.path.exists(os.path.join(path, "model.bin")):       # a CTranslate2 conversion: what faster_whisper.WhisperModel opens
                 from . import ct2_format                                # (faster_whisper_pro_asr.py:246-253)
                 dims, sd, extras = ct2_format.load_ct2_whisper(path)
+                if not os.path.exists(tok):          # no tokenizer.json: decode through the directory's vocabulary file
+                    vt = VocabTokenizer.from_directory(path)
+                    if vt is not None and not all(t.startswith("<") and t.endswith(">") and t[1:-1].isdigit() for t in vt._tokens[:16]):
+                        self.tokenizer = vt
                 if extras.get("alignment_heads"):
                     self._alignment_heads = list(extras["alignment_heads"])
                 self._ct2_extras = extras
