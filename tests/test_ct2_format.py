@@ -142,3 +142,13 @@ def test_vocabulary_file_decodes_text_when_the_directory_has_no_tokenizer_json(t
     assert "".join(words) == text and sum(len(t) for t in word_tokens) == len(ids) and all("�" not in w_ for w_ in words)
     with pytest.raises(ValueError, match="merge table"):
         tok.encode("こんにちは")
+
+
+def test_vocabulary_tokenizer_non_speech_list(tmp_path):
+    """``suppress_tokens=[-1]`` without a tokenizer.json: config.json's ``suppress_ids`` when present, else the single-entry symbols."""
+    from whisperjav_amd import whisper_model as wm
+    table = wm._bytes_to_unicode()
+    enc = lambda t: "".join(table[b] for b in t.encode("utf-8"))      # noqa: E731
+    vocab = ["<|endoftext|>", enc(" -"), enc("("), enc(" ("), enc("♪♪"), enc(" hello"), enc("「")]
+    assert wm.VocabTokenizer(vocab).non_speech_tokens() == [1, 2, 3, 4, 6]
+    assert wm.VocabTokenizer(vocab, non_speech=[9, 3, 3]).non_speech_tokens() == [3, 9]

@@ -119,21 +119,22 @@ class VocabTokenizer:
 
     real = True
 
-    def __init__(self, tokens: Sequence[str]):
+    def __init__(self, tokens: Sequence[str], non_speech: Optional[Sequence[int]] = None):
         self._tokens = list(tokens)
         self._byte_of = {c: b for b, c in _bytes_to_unicode().items()}
         self._ids = {t: i for i, t in enumerate(self._tokens)}
+        self._non_speech = sorted(set(int(t) for t in non_speech)) if non_speech else None
 
     @classmethod
-    def from_directory(cls, path: str) -> Optional["VocabTokenizer"]:
+    def from_directory(cls, path: str, non_speech: Optional[Sequence[int]] = None) -> Optional["VocabTokenizer"]:
         import json
         js, txt = os.path.join(path, "vocabulary.json"), os.path.join(path, "vocabulary.txt")
         if os.path.exists(js):
             with open(js, encoding="utf-8") as f:
-                return cls(json.load(f))
+                return cls(json.load(f), non_speech)
         if os.path.exists(txt):
             with open(txt, encoding="utf-8") as f:
-                return cls([line.rstrip("\n") for line in f])
+                return cls([line.rstrip("\n") for line in f], non_speech)
         return None
 
     def _token_bytes(self, t: int) -> bytes:
@@ -157,7 +158,22 @@ class VocabTokenizer:
         return self._ids.get(token)
 
     def non_speech_tokens(self) -> List[int]:
-        return []
+        """``suppress_tokens=[-1]``: the model's own list when the directory's ``config.json`` carries one (``suppress_ids``: what
+        the converter copied from the checkpoint's generation config = whisper's ``non_speech_tokens``), else the symbols of
+        whisper/tokenizer.py ``non_speech_tokens`` that ARE single vocabulary entries (no merge table is needed to know that)."""
+        if self._non_speech is not None:
+            return list(self._non_speech)
+        table = _bytes_to_unicode()
+        enc = lambda t: "".join(table[b] for b in t.encode("utf-8"))      # noqa: E731
+        symbols = list('"#()*+/:;<=>@[\\]^_`{|}~「」『』')
+        symbols += "<< >> <<< >>> -- --- -( -[ (' (\" (( )) ((( ))) [[ ]] {{ }} ♪♪ ♪♪♪".split()
+        out = set()
+        for sym in symbols + [" -", " '"]:
+            for cand in (sym, " " + sym) if not sym.startswith(" ") else (sym,):
+                i = self._ids.get(enc(cand))
+                if i is not None:
+                    out.add(i)
+        return sorted(out)
 
     split_tokens_on_unicode = None      # bound below (shared with HfTokenizer: they only need decode())
     split_to_word_tokens = None
@@ -419,7 +435,7 @@ class HipWhisperModel:
                 from . import ct2_format                                # (faster_whisper_pro_asr.py:246-253)
                 dims, sd, extras = ct2_format.load_ct2_whisper(path)
                 if not os.path.exists(tok):          # no tokenizer.json: decode through the directory's vocabulary file
-                    vt = VocabTokenizer.from_directory(path)
+                    vt = VocabTokenizer.from_directory(path, extras.get("suppress_ids"))
                     if vt is not None and not all(t.startswith("<") and t.endswith(">") and t[1:-1].isdigit() for t in vt._tokens[:16]):
                         self.tokenizer = vt
                 if extras.get("alignment_heads"):
