@@ -226,3 +226,31 @@ def test_silero_torchscript_archives_light_up_when_present(tmp_path):
                 assert gen == "v3.1/v4.0"
                 with pytest.raises(hipbind.WjError):
                     vad_weights.load_file(os.path.join(root, f))
+
+
+def test_default_segmenter_weak_assertions_of_the_reference_suite():
+    """The reference's own model-in-the-loop checks for its Silero back ends (tests/test_speech_segmentation.py: silence => no
+    segments, a lower threshold never finds less speech, more padding widens the segments) replayed on the silero-v3.1 contract
+    over a TorchScript archive of the published structure (tests/silero_standin.py), host scoring seam (no GPU here; the device
+    route must return the same segments: tests/test_gpu_vad_graph.py)."""
+    from tests import silero_standin as S
+    archive = S.build("v4", seed=7)
+    utils = (S.get_speech_timestamps, None, None, None, None)
+
+    def seg(**kw):
+        return segmenters.HipSileroSpeechSegmenter(version="v3.1", scorer=(archive, utils), device_scoring=False, **kw)
+    silence = np.zeros(16000 * 4, dtype=np.float32)
+    assert seg().segment(silence, sample_rate=16000).segments == []
+    audio = S.bursty_audio(12.0, seed=3, gaps=((2.0, 4.5), (7.0, 8.0)))
+    spoken = lambda r: sum(s.end_sample - s.start_sample for s in r.segments)       # noqa: E731
+    lo, hi = seg(threshold=0.3).segment(audio, sample_rate=16000), seg(threshold=0.85).segment(audio, sample_rate=16000)
+    assert lo.segments and spoken(lo) >= spoken(hi)
+    narrow = seg(threshold=0.5, speech_pad_ms=30, start_pad_samples=0, end_pad_samples=0).segment(audio, sample_rate=16000)
+    wide = seg(threshold=0.5, speech_pad_ms=300, start_pad_samples=0, end_pad_samples=0).segment(audio, sample_rate=16000)
+    assert len(narrow.segments) >= len(wide.segments) >= 1 and spoken(wide) > spoken(narrow)
+    for r in (lo, hi, narrow, wide):
+        assert all(0 <= s.start_sample and s.end_sample <= len(audio) for s in r.segments)
+        assert all(a.end_sample <= b.start_sample for a, b in zip(r.segments, r.segments[1:]))      # the reference's overlap fix
+        assert sum(len(g) for g in r.groups) == len(r.segments)
+    for r in (narrow, wide):         # without the WhisperJAV-side sample padding every segment is a proper interval
+        assert all(s.start_sample < s.end_sample for s in r.segments)
