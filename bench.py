@@ -556,9 +556,9 @@ def run_cfg3(args, info, dims):
     if info.rank == 0 and info.world == 1 and not args.no_extras and not args.no_default_vad:
         # the reference's DEFAULT segmenter (silero-v3.1: a TorchScript hub archive on 1536-sample windows, main.py:1867-1876)
         # scored ON THE DEVICE: the archive's graph lowered onto HIP kernels (vad_graph.py / vadgraph.hip).  The real archive is not
-        # obtainable offline; tests/silero_standin.py builds one of the same structure (conv-STFT, adaptive normalisation, separable
+        # obtainable offline; whisperjav_amd/standin_vad.py builds one of the same structure (conv-STFT, adaptive normalisation, separable
         # conv blocks, 2-layer LSTM with module state) with seeded weights -- measurement input, like the synthetic Whisper weights
-        from tests import silero_standin
+        from whisperjav_amd import standin_vad as silero_standin
         from whisperjav_amd import segmenters as _sg
         archive = silero_standin.build("v4", seed=7)
         utils = (silero_standin.get_speech_timestamps, None, None, None, None)           # what torch.hub.load returns beside the model
@@ -603,7 +603,7 @@ def run_cfg3(args, info, dims):
             "what": ("the same step with the reference's default segmenter contract (HipSileroSpeechSegmenter version v3.1, 1536-sample windows, the "
                      "archive's own get_speech_timestamps) and the archive's network lowered onto the device; device_vad_ms = segment_many over all "
                      "scenes (one launch group); host_default_vad_s = the same archive scored by torch.jit on ONE host core window by window (round 4's "
-                     "seam, the reference's loop), 90 s sample scaled to the recording; archive = tests/silero_standin.py (v4-shaped, seeded)"),
+                     "seam, the reference's loop), 90 s sample scaled to the recording; archive = whisperjav_amd/standin_vad.py (v4-shaped, seeded)"),
             **s31}
         del clips31
     # the groups of the recording, for the CPU baseline's scaling (before the model goes away)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define WJ_ABI_VERSION 5
+#define WJ_ABI_VERSION 6
 
 enum {
   WJ_OK = 0,
@@ -413,26 +413,35 @@ int wj_decode_topk_rules(wj_whisper* m, int rows, int k, const wj_decode_opts* o
 /* softmax probability of the no-speech token in the last step's (unfiltered) logits */
 int wj_decode_no_speech(wj_whisper* m, int rows, int no_speech_id, float* out_host, void* stream);
 
-/* ---- VAD scorer for TorchScript archives (ABI 5) -------------------------------------------
+/* ---- VAD scorer for TorchScript archives (ABI 5; ABI 6: stages, exchange area, fused execution) -------------------------
  * Replaces: the per-window forward of the reference's DEFAULT segmenter network -- the silero-v3.1 / v4.0 torch.hub archive
  * (whisperjav/main.py:1867-1876; loader whisperjav/modules/speech_segmentation/backends/silero.py:197-206; called as
  * model(chunk, 16000) on consecutive 1536-sample windows from the archive's get_speech_timestamps, :258-273).  The archive's
  * graph is walked on the host (whisperjav_amd/vad_graph.py: abstract interpretation at the window shape) and handed over as an
- * instruction stream of float32 tensor ops over one arena per window: strided element-wise ops, conv1d, padding, mean over an
- * axis, linear, multi-layer LSTM whose (h, c) live in a per-stream state row.  words: the program (layout in vad_graph.py /
- * csrc/vadgraph.hip; every offset is validated here); consts_host: the archive's parameters and folded constants;
- * state_init_host [state_floats]: the state a stream starts from (what the archive's reset_states() leaves);
- * arena_floats: floats per window; input_offset / output_offset: where the window's samples go and where its probability
- * appears; max_windows: windows per launch group (arena memory = max_windows x arena_floats x 4 bytes). */
+ * instruction stream of float32 tensor ops: strided element-wise ops, conv1d, padding, mean over an axis, linear, multi-layer
+ * LSTM whose (h, c) live in a per-stream state row.  The LSTM instructions cut the program into stages; operand spaces:
+ * 0 = the per-window ARENA (tensors that live inside one stage, laid out by liveness: arena_floats per window -- LDS of the
+ * workgroup that runs the window's stage when it fits 160 KiB, HBM otherwise), 1 = constants, 2 = state, 3 = the per-window
+ * EXCHANGE area in HBM (xchg_floats per window: what crosses a stage or what an LSTM touches).  words: the program (layout
+ * in vad_graph.py / csrc/vadgraph.hip; every offset is validated here); consts_host: the archive's parameters and folded
+ * constants; state_init_host [state_floats]: the state a stream starts from (what the archive's reset_states() leaves);
+ * input_space / input_offset, output_space / output_offset: where the window's samples go and where its probability appears;
+ * max_windows: windows per launch group (an upper bound; the library lowers it to keep the exchange areas under 2 GiB);
+ * mode: 0 = one launch per stage with the arena in LDS when it fits (else as 1), 1 = one launch per instruction over an HBM
+ * arena and the general LSTM kernel (round 5's executor: the fall-back and the cross-check), 2 = as 0 but fail when the arena
+ * does not fit.  Per-window memory is allocated by wj_vadg_scores for the windows of the call (grow-only). */
 typedef struct wj_vadg wj_vadg;
 int wj_vadg_create(wj_ctx* ctx, const int32_t* words, int n_words, int n_instr, const float* consts_host, int64_t n_consts,
-                   const float* state_init_host, int state_floats, int64_t arena_floats, int input_offset, int output_offset,
-                   int window, int max_windows, wj_vadg** out);
+                   const float* state_init_host, int state_floats, int64_t arena_floats, int64_t xchg_floats, int input_space,
+                   int input_offset, int output_space, int output_offset, int window, int max_windows, int mode, wj_vadg** out);
 int wj_vadg_free(wj_vadg* h);
+/* ABI 6.  out8 = {fused (0 / 1), LDS bytes per workgroup, stages, LSTM weights in registers (0 / 1), windows per launch group,
+ * LSTM instructions, 0, 0}: how wj_vadg_scores will run the program. */
+int wj_vadg_info(wj_vadg* h, int32_t* out8);
 /* As wj_vad_scores, on `window`-sample windows: stream i = pcm_dev[offsets[i]..offsets[i+1]) (the last window zero padded, as
  * utils_vad.get_speech_timestamps pads it), its ceil(n_i / window) probabilities at probs_dev[prob_offsets[i] ...]
- * (prob_offsets contiguous).  The stateless instructions run batched over all windows of all streams, the LSTM one workgroup
- * per stream in window order; every stream starts from state_init. */
+ * (prob_offsets contiguous).  Every stage is one launch over all windows of all streams (one workgroup per window), the LSTM
+ * one workgroup per stream in window order; every stream starts from state_init. */
 int wj_vadg_scores(wj_vadg* h, const float* pcm_dev, const int64_t* offsets_host, const int64_t* prob_offsets_host,
                    int n_streams, float* probs_dev, void* stream);
 

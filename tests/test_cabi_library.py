@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hip):
 
 def test_abi_version_and_pure_helpers(hip):
     from whisperjav_amd import hipbind
-    assert hip.wj_abi_version() == hipbind.ABI_VERSION == 5
+    assert hip.wj_abi_version() == hipbind.ABI_VERSION == 6
     # frame arithmetic is host code: faster-whisper (N + 160) // 160, openai-whisper (N + 480000) // 160
     assert hip.wj_logmel_frames(96000, 0) == 601
     assert hip.wj_logmel_frames(480000, 0) == 3001

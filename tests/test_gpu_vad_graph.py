@@ -18,13 +18,18 @@ def _streams():
     return [a, b[: 16000 * 6 + 777], a[5000: 5000 + 1536 * 3], b[:1000], a[16000 * 6: 16000 * 13 + 5]]
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("variant,window", [("v4", 1536), ("v3", 1536), ("v4", 512)])
-def test_device_probabilities_equal_the_archive_on_the_cpu(hip, variant, window):
+def test_device_probabilities_equal_the_archive_on_the_cpu(hip, variant, window, fused):
     """Five ragged streams in ONE call (a stream shorter than a window, lengths that are and are not multiples of it), state
-    carried per stream and reset between streams, host clips and HBM-resident clips: <= 1e-5 on every window probability."""
+    carried per stream and reset between streams, host clips and HBM-resident clips: <= 1e-5 on every window probability.
+    ``fused``: one launch per stage with the arena in LDS and the LSTM weights in registers (the default for these graphs), or
+    round 5's one-launch-per-instruction executor with the general LSTM kernel (the fall-back for arenas beyond the LDS)."""
     from whisperjav_amd import vad_graph
     archive = S.build(variant, seed=7)
-    scorer = vad_graph.HipGraphVadScorer(archive, window=window)
+    scorer = vad_graph.HipGraphVadScorer(archive, window=window, fused=fused)
+    assert scorer.fused == fused and scorer.lstm_in_registers == fused and scorer.n_stages == 2
+    assert (0 < scorer.lds_bytes <= 64 * 1024) if fused else scorer.lds_bytes == 0
     clips = _streams()
     got = scorer.scores(clips)
     worst = 0.0
@@ -49,11 +54,49 @@ def test_streams_that_straddle_launch_groups_carry_their_state(hip):
     one = vad_graph.HipGraphVadScorer(archive, window=1536)
     ref = one.scores(clips)
     one.close()
-    for cap in (7, 64):
-        small = vad_graph.HipGraphVadScorer(archive, window=1536, max_windows_per_launch=cap)
+    for cap, fused in ((7, None), (64, None), (7, False)):
+        small = vad_graph.HipGraphVadScorer(archive, window=1536, max_windows_per_launch=cap, fused=fused)
         got = small.scores(clips)
         small.close()
-        assert all(np.array_equal(a, b) for a, b in zip(got, ref)), cap
+        if fused is None:
+            assert all(np.array_equal(a, b) for a, b in zip(got, ref)), cap
+        else:           # the per-instruction executor sums the LSTM's dot products in another order
+            assert max(float(np.abs(a - b).max()) for a, b in zip(got, ref)) < 2e-6
+
+
+def test_the_default_scorer_is_fused_and_allocates_for_the_call(hip):
+    """No mode named: the silero-shaped graphs run fused (53 KB of LDS per window, three launches per call), per-window memory
+    is allocated by the first call for the windows it scores (round 5 held 4 GB of arenas from create on)."""
+    from whisperjav_amd import vad_graph
+    scorer = vad_graph.HipGraphVadScorer(S.build("v4", seed=7))
+    assert scorer.fused and scorer.lstm_in_registers and scorer.lds_bytes == 4 * scorer.program.arena_floats
+    free0 = torch.cuda.mem_get_info()[0]
+    got = scorer.scores(_streams())
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20 and sum(len(g) for g in got) > 20
+    scorer.close()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_every_op_of_the_loaders_table_on_the_device(hip, fused):
+    """The op zoo, the in-place module and the stateless scorer of tests/test_vad_graph.py (strided / broadcast element-wise
+    operands, constant / replicate padding, dilated and grouped convolutions, linear, sums, in-place writes through views)
+    through both executors: <= 1e-5 of torch."""
+    from tests.test_vad_graph import _InPlaceOnASlice, _OpZoo, _Stateless
+    from whisperjav_amd import vad_graph
+    rng = np.random.default_rng(2)
+    audio = (rng.standard_normal(512 * 6 + 100) * 0.3).astype(np.float32)
+    for i, cls in enumerate((_OpZoo, _InPlaceOnASlice, _Stateless)):
+        torch.manual_seed(3 + i)
+        m = torch.jit.script(cls().eval())
+        with torch.no_grad():
+            ref = np.array([float(m(torch.nn.functional.pad(torch.from_numpy(audio[s: s + 512].copy()), (0, max(0, 512 - len(audio[s: s + 512])))), 16000))
+                            for s in range(0, len(audio), 512)], dtype=np.float32)
+        scorer = vad_graph.HipGraphVadScorer(m, window=512, fused=fused)
+        assert scorer.fused == fused
+        got = scorer.scores([audio, audio[:700]])
+        scorer.close()
+        assert got[0].shape == ref.shape and float(np.abs(got[0] - ref).max()) < 1e-5, (cls.__name__, got[0], ref)
+        assert float(np.abs(got[1][:1] - ref[:1]).max()) < 1e-5
 
 
 @pytest.mark.parametrize("route", ["hub_pair", "archive_file"])

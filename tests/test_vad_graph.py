@@ -170,3 +170,80 @@ def test_the_device_scorer_refuses_without_a_gpu():
     from whisperjav_amd import hipbind
     with pytest.raises(hipbind.WjError, match="no CPU fallback"):
         vg.HipGraphVadScorer(S.build("v4", seed=7))
+
+
+class _InPlaceOnASlice(nn.Module):
+    """``z.add_(1)`` on a slice of y: the base tensor y must see the write (it used to be lowered to a silently wrong
+    program); ``relu_`` on the whole tensor afterwards, then a second view of the mutated tensor."""
+
+    def forward(self, x: torch.Tensor, sr: int) -> torch.Tensor:
+        y = x.unsqueeze(0) * 2
+        z = y[:, :10]
+        z.add_(1.0)
+        w = y[:, 5:40:3]
+        w.mul_(w)
+        y.relu_()
+        return torch.sigmoid(y.mean(1) + y[:, 7])
+
+
+class _InPlaceThroughAnotherView(nn.Module):
+    def forward(self, x: torch.Tensor, sr: int) -> torch.Tensor:
+        y = x.unsqueeze(0) * 2
+        y[:, 1:].add_(y[:, :-1])            # reads what other threads of the same instruction write
+        return torch.sigmoid(y.mean(1))
+
+
+def test_inplace_ops_write_through_the_operands_own_view():
+    m = torch.jit.script(_InPlaceOnASlice().eval())
+    p = vg.lower(m, 512)
+    rng = np.random.default_rng(4)
+    audio = (rng.standard_normal(512 * 3) * 0.3).astype(np.float32)
+    with torch.no_grad():
+        ref = np.array([float(m(torch.from_numpy(audio[i: i + 512].copy()), 16000)) for i in range(0, len(audio), 512)], dtype=np.float32)
+    got = R.run_stream(p, audio)
+    assert np.abs(got - ref).max() < 1e-6, (got, ref)
+    with pytest.raises(vg.LoweringError, match="different view"):
+        vg.lower(torch.jit.script(_InPlaceThroughAnotherView().eval()), 512)
+
+
+def test_the_arena_is_laid_out_by_liveness_and_fits_the_lds():
+    """The silero-shaped graphs: ~53 KB of arena per 1536-sample window (one buffer per tensor would take 248 KB), everything an
+    LSTM touches -- and the tensors that cross it -- in the small exchange area; the NumPy executor poisons the arena at every
+    stage boundary, so a tensor wrongly left in it would turn the probabilities into NaN (test_lowered_program_equals_torch_jit)."""
+    for variant in ("v4", "v3"):
+        p = vg.lower(S.build(variant, seed=7), 1536)
+        assert p.arena_floats * 4 <= 64 * 1024 and p.unpacked_arena_floats > 4 * p.arena_floats
+        assert 7 * 64 * 2 <= p.xchg_floats <= 2048
+        assert p.input_space == vg.SPACE_ARENA and p.output_space == vg.SPACE_ARENA
+
+
+def test_region_route_certifies_the_archives_function_or_keeps_it():
+    """``region_route="certified"`` (the default): the archive's get_speech_timestamps is run against the restated state machine
+    on a battery of probability tracks at the call's parameters; equal -> the restated machine serves the scenes (spot checks
+    still replay through the archive's function); a function that is NOT that machine (here: a lower threshold 0.10 below
+    instead of 0.15) is detected and keeps serving every scene itself."""
+    import functools
+    from whisperjav_amd import segmenters
+
+    def deviant(audio, model, threshold: float = 0.5, **kw):
+        stamps = S.get_speech_timestamps(audio, model, threshold=threshold + 0.05, **kw)      # moves both thresholds
+        return stamps
+
+    rng = np.random.default_rng(9)
+    probs = np.repeat(rng.random(40).astype(np.float32), 5)
+    n = len(probs) * 1536 - 311
+    for gst, want_cert in ((S.get_speech_timestamps, True), (deviant, False)):
+        seg = segmenters.HipSileroSpeechSegmenter(version="v3.1", scorer=(object(), gst), threshold=0.5, min_silence_duration_ms=300)
+        seg._archive_gst, seg._window, seg._graph_scorer = gst, 1536, object()
+        got = seg._graph_regions(np.zeros(n, np.float32), probs, 0.5, 100, 300, 400, spot_check=False)
+        want = [dict(t) for t in gst(torch.zeros(n), segmenters._ReplayModel(probs, 1536), threshold=0.5, sampling_rate=16000,
+                                     min_speech_duration_ms=100, min_silence_duration_ms=300, speech_pad_ms=400, window_size_samples=1536)]
+        assert got == want and len(want) >= 2
+        assert list(seg._certified.values()) == [want_cert]
+        assert seg.region_stats["certified" if want_cert else "replayed"] == 1
+        seg._graph_regions(np.zeros(n, np.float32), probs, 0.5, 100, 300, 400, spot_check=True)
+        assert seg.region_stats["spot_checks"] == (1 if want_cert else 0) and seg.region_stats["mismatches"] == 0
+    always = segmenters.HipSileroSpeechSegmenter(version="v3.1", scorer=(object(), S.get_speech_timestamps), region_route="archive")
+    always._archive_gst, always._window, always._graph_scorer = S.get_speech_timestamps, 1536, object()
+    always._graph_regions(np.zeros(n, np.float32), probs, 0.5, 100, 300, 400)
+    assert always.region_stats["replayed"] == 1 and not always._certified

@@ -1,6 +1,7 @@
 """NumPy executor of a ``whisperjav_amd.vad_graph.Program`` (TEST INFRASTRUCTURE: never imported by the product).
 
-Runs the lowered instruction stream the way csrc/vadgraph.hip does -- one arena per window, state slots per stream -- so the
+Runs the lowered instruction stream the way csrc/vadgraph.hip does -- one arena and one exchange area per window, state slots
+per stream; the arena is POISONED (NaN) at every stage boundary, as the LDS of the fused stage kernels forgets it -- so the
 LOWERING (graph walk, constant folding, strides, state loop) can be pinned against ``torch.jit`` on the CPU without a GPU.  The
 HIP kernels are pinned against the archive itself in the ``-m gpu`` tests.
 """
@@ -33,9 +34,10 @@ _EW = {v: k for k, v in vg.EW.items()}
 
 
 def run_window(p: vg.Program, consts: np.ndarray, state: np.ndarray, chunk: np.ndarray) -> float:
-    arena = np.zeros(p.arena_floats + 8, dtype=np.float32)
-    arena[p.input_offset: p.input_offset + p.window] = chunk
-    spaces = {vg.SPACE_ARENA: arena, vg.SPACE_CONST: consts, vg.SPACE_STATE: state}
+    arena = np.full(p.arena_floats + 8, np.nan, dtype=np.float32)
+    xchg = np.full(p.xchg_floats + 8, np.nan, dtype=np.float32)
+    spaces = {vg.SPACE_ARENA: arena, vg.SPACE_CONST: consts, vg.SPACE_STATE: state, vg.SPACE_XCHG: xchg}
+    spaces[p.input_space][p.input_offset: p.input_offset + p.window] = chunk
     w = p.words
     pos = 0
     while pos < len(w):
@@ -109,15 +111,16 @@ def run_window(p: vg.Program, consts: np.ndarray, state: np.ndarray, chunk: np.n
                 acc = acc + xi
             out[...] = acc * np.float32(inv)
         elif op == vg.OP_LINEAR:
-            ooff, xoff, woff, boff, rows, nin, nout = w[a: a + 7]
-            x = arena[xoff: xoff + rows * nin].reshape(rows, nin)
+            ospace, ooff, xspace, xoff, woff, boff, rows, nin, nout = w[a: a + 9]
+            x = spaces[xspace][xoff: xoff + rows * nin].reshape(rows, nin)
             wt = consts[woff: woff + nout * nin].reshape(nout, nin)
             y = x @ wt.T + (consts[boff: boff + nout] if boff >= 0 else 0.0)
-            arena[ooff: ooff + rows * nout] = y.reshape(-1).astype(np.float32)
+            spaces[ospace][ooff: ooff + rows * nout] = y.reshape(-1).astype(np.float32)
         elif op == vg.OP_LSTM:
-            yoff, xspace, xoff, st_t, st_f, t, nin, hid, layers, hnoff, cnoff = w[a: a + 11]
-            blobs = w[a + 11: a + 23]
-            hslot, cslot = w[a + 23], w[a + 24]
+            yspace, yoff, xspace, xoff, st_t, st_f, t, nin, hid, layers, hnspace, hnoff, cnspace, cnoff = w[a: a + 14]
+            assert yspace == hnspace == cnspace == vg.SPACE_XCHG and xspace in (vg.SPACE_XCHG, vg.SPACE_CONST)
+            blobs = w[a + 14: a + 26]
+            hslot, cslot, need_hc = w[a + 26], w[a + 27], w[a + 28]
             h = state[hslot: hslot + layers * hid].reshape(layers, hid).copy()
             c = state[cslot: cslot + layers * hid].reshape(layers, hid).copy()
             xs = np.lib.stride_tricks.as_strided(spaces[xspace][xoff:], shape=(t, nin), strides=(4 * st_t, 4 * st_f))
@@ -135,15 +138,17 @@ def run_window(p: vg.Program, consts: np.ndarray, state: np.ndarray, chunk: np.n
                     h[l] = _sigmoid(o_) * np.tanh(c[l])
                     inp = h[l]
                 ys[step] = inp
-            arena[yoff: yoff + t * hid] = ys.reshape(-1)
-            arena[hnoff: hnoff + layers * hid] = h.reshape(-1)
-            arena[cnoff: cnoff + layers * hid] = c.reshape(-1)
+            xchg[yoff: yoff + t * hid] = ys.reshape(-1)
+            if need_hc:                              # the kernels write the window's final (h, c) only when an instruction reads them
+                xchg[hnoff: hnoff + layers * hid] = h.reshape(-1)
+                xchg[cnoff: cnoff + layers * hid] = c.reshape(-1)
             state[hslot: hslot + layers * hid] = h.reshape(-1)
             state[cslot: cslot + layers * hid] = c.reshape(-1)
+            arena[:] = np.nan                       # a stage boundary: the next stage's LDS starts undefined
         else:
             raise AssertionError(f"opcode {op}")
         pos += n
-    return float(arena[p.output_offset])
+    return float(spaces[p.output_space][p.output_offset])
 
 
 def run_stream(p: vg.Program, audio: np.ndarray) -> np.ndarray:

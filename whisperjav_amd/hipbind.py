@@ -12,7 +12,7 @@ import os
 from pathlib import Path
 from typing import Optional
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwjhip.so"
 _lib: Optional[C.CDLL] = None
 
@@ -111,7 +111,9 @@ _SIGNATURES = {
     "wj_vad_create": (_I, [_P, C.POINTER(_F), _I64, C.POINTER(_P)]),
     "wj_vad_free": (_I, [_P]),
     "wj_vad_scores": (_I, [_P, _P, C.POINTER(_I64), C.POINTER(_I64), _I, _P, _P]),
-    "wj_vadg_create": (_I, [_P, C.POINTER(C.c_int32), _I, _I, C.POINTER(_F), _I64, C.POINTER(_F), _I, _I64, _I, _I, _I, _I, C.POINTER(_P)]),
+    "wj_vadg_create": (_I, [_P, C.POINTER(C.c_int32), _I, _I, C.POINTER(_F), _I64, C.POINTER(_F), _I, _I64, _I64, _I, _I, _I, _I, _I, _I, _I,
+                            C.POINTER(_P)]),
+    "wj_vadg_info": (_I, [_P, C.POINTER(C.c_int32)]),
     "wj_vadg_free": (_I, [_P]),
     "wj_vadg_scores": (_I, [_P, _P, C.POINTER(_I64), C.POINTER(_I64), _I, _P, _P]),
     "wj_comm_unique_id": (_I, [C.c_char_p]),

@@ -283,14 +283,27 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
                  start_pad_samples: int = 11200, end_pad_samples: int = 20800,
                  weights: Union[Dict[str, np.ndarray], str, None] = None, device: int = 0,
                  weights_path: Optional[str] = None, network: Optional[str] = None, scorer: Any = None,
-                 device_scoring: Optional[bool] = None, window_size_samples: Optional[int] = None, **kwargs):
+                 device_scoring: Optional[bool] = None, window_size_samples: Optional[int] = None, region_route: str = "certified",
+                 **kwargs):
         self._weights_path = weights_path
+        # round 6: how device probabilities become regions when the caller handed over the archive's own get_speech_timestamps
+        # (scorer=): "archive" = always through that function (a replay model answers its model(chunk, sr) calls: ~6 us of host
+        # Python per window, 0.5 s per 120 min); "certified" = the function is first run against vad.regions_from_probs (the same
+        # state machine restated, vectorised) on a battery of probability tracks AT THE CALL'S PARAMETERS -- equal on every track:
+        # the restated machine serves the scenes and one scene per call is still replayed through the archive's function as a
+        # spot check; any difference, at certification or later: the archive's function serves everything from then on
+        if region_route not in ("certified", "archive"):
+            raise ValueError("region_route must be 'certified' or 'archive'")
+        self._region_route = region_route
+        self._certified: Dict[Tuple, bool] = {}
+        self.region_stats = {"certified": 0, "replayed": 0, "spot_checks": 0, "mismatches": 0}
         # round 5: a TorchScript archive (weights_path=<model.jit>, or the model of scorer=) is LOWERED onto the device
         # (vad_graph.py).  device_scoring: None = lower whenever the model is a TorchScript module (a graph outside the loader's
         # op table raises LoweringError), True = require it, False = round 4's host scoring through the archive's own loop
         self._device_scoring = device_scoring
         self._window = int(window_size_samples) if window_size_samples else None
         self._graph_scorer = None
+        self._gst_takes_window: Optional[bool] = None
         if network not in (None, "v6", "v5/v6"):
             raise ValueError("network must be None (the version's own network: no HIP kernel, refuses) or 'v6'")
         if scorer is not None and network:
@@ -424,7 +437,58 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
                 f"{self.version} call contract knowingly; vad_weights.from_torchscript(path) identifies an archive.")
         super()._ensure_model()
 
-    def _graph_regions(self, audio16, probs, threshold, min_speech, min_silence, pad_ms) -> List[Dict[str, int]]:
+    def _archive_regions(self, gst, probs, n: int, key: Tuple) -> List[Dict[str, int]]:
+        """Regions of one clip through the archive's OWN get_speech_timestamps, its ``model(chunk, sr)`` calls answered from ``probs``."""
+        import torch
+        threshold, min_speech, min_silence, pad_ms, window = key
+        kw = dict(sampling_rate=VAD_SR, threshold=threshold, min_speech_duration_ms=min_speech, min_silence_duration_ms=min_silence,
+                  speech_pad_ms=pad_ms)
+        if self._gst_takes_window is None:
+            try:
+                import inspect
+                self._gst_takes_window = "window_size_samples" in inspect.signature(gst).parameters
+            except (TypeError, ValueError):
+                self._gst_takes_window = False
+        if self._gst_takes_window:
+            kw["window_size_samples"] = window
+        # the loop only needs the clip's LENGTH (it slices windows and hands them to the model): zeros of the same length
+        return [dict(ts) for ts in gst(torch.zeros(n, dtype=torch.float32), _ReplayModel(probs, window), **kw)]
+
+    def _restated_regions(self, probs, n: int, key: Tuple) -> List[Dict[str, int]]:
+        from . import vad
+        threshold, min_speech, min_silence, pad_ms, window = key
+        return vad.regions_from_probs(probs, n, threshold=threshold, sampling_rate=VAD_SR, min_speech_duration_ms=min_speech,
+                                      max_speech_duration_s=float("inf"), min_silence_duration_ms=min_silence, speech_pad_ms=pad_ms,
+                                      neg_threshold=threshold - 0.15, window=window)
+
+    def _certify_regions(self, gst, key: Tuple) -> bool:
+        """The archive's get_speech_timestamps against the restated state machine, at these parameters, on probability tracks built to
+        visit every branch: plateaus around both thresholds (values exactly on them included), silences shorter and longer than
+        min_silence, speech shorter and longer than min_speech, tracks that end inside speech, clip lengths on and off the window
+        grid, neighbours closer than twice the padding."""
+        threshold, _, _, _, window = key
+        rng = np.random.default_rng(20240)
+        levels = np.asarray([0.0, threshold - 0.15, np.nextafter(np.float32(threshold - 0.15), np.float32(0)), threshold - 0.07, threshold,
+                             np.nextafter(np.float32(threshold), np.float32(0)), min(1.0, threshold + 0.2), 1.0], dtype=np.float32).clip(0, 1)
+        try:
+            for trial in range(64):
+                n_win = int(rng.integers(1, 90)) if trial else 1
+                if trial % 3 == 0:
+                    track = rng.random(n_win).astype(np.float32)
+                else:
+                    runs = rng.integers(1, 9 if trial % 3 == 1 else 30, size=n_win)
+                    track = np.repeat(levels[rng.integers(0, len(levels), size=n_win)], runs)[:n_win].astype(np.float32)
+                n = (n_win - 1) * window + (window if trial % 4 == 0 else int(rng.integers(1, window + 1)))
+                if self._archive_regions(gst, track, n, key) != self._restated_regions(track, n, key):
+                    logger.warning("silero-%s-hip: this archive's get_speech_timestamps is not the v3.1 / v4.0 state machine restated in "
+                                   "vad.regions_from_probs (track %d): regions will come from the archive's function", self.version, trial)
+                    return False
+        except Exception as e:       # a signature or a check this route does not know: the archive's function decides by itself
+            logger.warning("silero-%s-hip: certification of the archive's get_speech_timestamps failed (%s)", self.version, e)
+            return False
+        return True
+
+    def _graph_regions(self, audio16, probs, threshold, min_speech, min_silence, pad_ms, spot_check: bool = True) -> List[Dict[str, int]]:
         """Window probabilities from the lowered archive (one launch group; ``probs`` when ``segment_many`` scored the pool
         already) -> regions: through the archive's own ``get_speech_timestamps`` when the caller handed it over (scorer=), else
         through the v3.1 / v4.0 state machine restated in ``vad.regions_from_probs`` (no speech cap, lower threshold =
@@ -437,20 +501,25 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
             probs = self._graph_scorer.scores([audio16])[0]
         gst = getattr(self, "_archive_gst", None)
         if gst is not None:
-            import torch
-            kw = dict(sampling_rate=VAD_SR, threshold=threshold, min_speech_duration_ms=min_speech, min_silence_duration_ms=min_silence,
-                      speech_pad_ms=pad_ms)
-            try:
-                import inspect
-                if "window_size_samples" in inspect.signature(gst).parameters:
-                    kw["window_size_samples"] = self._window
-            except (TypeError, ValueError):
-                pass
-            # the loop only needs the clip's LENGTH (it slices windows and hands them to the model): zeros of the same length
-            return [dict(ts) for ts in gst(torch.zeros(n, dtype=torch.float32), _ReplayModel(probs, self._window), **kw)]
-        return vad.regions_from_probs(probs, n, threshold=threshold, sampling_rate=VAD_SR, min_speech_duration_ms=min_speech,
-                                      max_speech_duration_s=float("inf"), min_silence_duration_ms=min_silence, speech_pad_ms=pad_ms,
-                                      neg_threshold=threshold - 0.15, window=self._window)
+            key = (float(threshold), int(min_speech), int(min_silence), int(pad_ms), int(self._window))
+            if self._region_route == "certified" and key not in self._certified:
+                self._certified[key] = self._certify_regions(gst, key)
+            if self._region_route == "certified" and self._certified[key]:
+                got = self._restated_regions(probs, n, key)
+                if spot_check:
+                    self.region_stats["spot_checks"] += 1
+                    want = self._archive_regions(gst, probs, n, key)
+                    if want != got:       # never seen; if it happens the archive's own function takes over for good
+                        logger.warning("silero-%s-hip: the archive's get_speech_timestamps and the restated state machine differ on a scene; "
+                                       "regions come from the archive's function from now on", self.version)
+                        self.region_stats["mismatches"] += 1
+                        self._certified[key] = False
+                        return want
+                self.region_stats["certified"] += 1
+                return got
+            self.region_stats["replayed"] += 1
+            return self._archive_regions(gst, probs, n, key)
+        return self._restated_regions(probs, n, (float(threshold), int(min_speech), int(min_silence), int(pad_ms), int(self._window)))
 
     def segment_many(self, audios, sample_rates) -> List["SegmentationResult"]:
         self._ensure_model()
@@ -461,7 +530,9 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
         if not all((isinstance(a, np.ndarray) or _on_device(a)) and sr == VAD_SR for a, sr in zip(audios, sample_rates)):
             return [self.segment(a, sample_rate=sr) for a, sr in zip(audios, sample_rates)]
         probs = self._graph_scorer.scores(list(audios))       # every scene a stream of ONE launch group
-        return [self.segment(a, sample_rate=sr, _probs=p) for a, sr, p in zip(audios, sample_rates, probs)]
+        # certified region route: the longest scene of the call is still replayed through the archive's own function
+        check = int(np.argmax([len(p) for p in probs])) if len(probs) else -1
+        return [self.segment(a, sample_rate=sr, _probs=p, _spot_check=(i == check)) for i, (a, sr, p) in enumerate(zip(audios, sample_rates, probs))]
 
     def cleanup(self) -> None:
         g, self._graph_scorer = self._graph_scorer, None
@@ -490,7 +561,8 @@ class HipSileroSpeechSegmenter(_HipSileroBase):
             data = data.detach().cpu().numpy()
         audio16 = data if _on_device(data) else np.asarray(_resample(data, sr, VAD_SR), dtype=np.float32)
         if self._graph_scorer is not None:
-            stamps = self._graph_regions(audio16, kwargs.get("_probs"), threshold, min_speech, min_silence, pad_ms)
+            stamps = self._graph_regions(audio16, kwargs.get("_probs"), threshold, min_speech, min_silence, pad_ms,
+                                         spot_check=kwargs.get("_spot_check", True))
         elif getattr(self, "_host_scorer", False):
             # the reference's own call (backends/silero.py:258-273): a host FloatTensor, the archive's get_speech_timestamps,
             # the four keyword arguments the v3.1 / v4.0 API takes -- the network's 1536-sample windows and state live in there

@@ -97,6 +97,9 @@ def regions_from_probs(probs: Sequence[float], n_samples: int, *, threshold: flo
                        window: int = WINDOW) -> List[Dict[str, int]]:
     """Hysteresis segmentation with silero-vad 6.x semantics; returns ``[{'start','end'}]`` in samples."""
     lo = max(threshold - 0.15, 0.01) if neg_threshold is None else neg_threshold
+    # upstream compares ``model(chunk, sr).item()`` -- the float32 probability widened to a Python double -- with double thresholds;
+    # NumPy 2 would compare a float32 scalar with the threshold ROUNDED to float32 (0.35f < 0.35 is true upstream, false there)
+    probs = np.asarray(probs, dtype=np.float32).astype(np.float64).tolist()
     need_speech = sampling_rate * min_speech_duration_ms / 1000.0
     need_silence = sampling_rate * min_silence_duration_ms / 1000.0
     need_silence_at_cap = sampling_rate * min_silence_at_max_speech / 1000.0

@@ -14,14 +14,22 @@ offline -- so instead of hard-coding a second network this module reads WHATEVER
      (constant sub-expressions are folded with torch at load time, e.g. BatchNorm statistics into a per-channel scale/shift).
      Each tensor op on a symbolic operand becomes one instruction of a small program: strided element-wise ops, conv1d
      (groups / stride / dilation / zero padding), reflect / constant padding, mean over an axis, linear, multi-layer LSTM.
+     In-place ops write through the operand's own view (aliases see the write; an in-place op on a view that overlaps another
+     operand differently raises).
      Module attributes that the graph WRITES (``prim::SetAttr``: the LSTM's h / c) become per-stream state: the graph is
      walked twice -- the first call from the state ``reset_states()`` leaves, then a steady-state call -- and both walks must
      produce the same instructions (the first one only differs in reading constants where the second reads state).
      Anything else -- an op outside the table, state that flows through something other than the LSTM, data-dependent control
      flow -- raises ``LoweringError`` naming the op and its source line.  Nothing is approximated and nothing runs on the CPU.
-  2. ``HipGraphVadScorer`` hands the program to ``wj_vadg_create`` (csrc/vadgraph.hip) and scores every stream (scene) of a
-     call at once: the stateless front of the network runs over ALL windows of ALL streams as batched launches, the LSTM runs
-     one workgroup per stream sequentially over that stream's windows, the decoder is batched again.
+  2. Layout (``_Lowerer._layout``): the LSTM instructions cut the program into STAGES.  A tensor that lives inside one stage
+     goes to the per-window ARENA -- laid out by liveness (first-fit over the instruction intervals, element-wise results take
+     over the slot of an operand that dies there), so the arena of the silero-shaped graphs is ~50 KB and fits the LDS of a
+     compute unit; a tensor that crosses a stage boundary or that an LSTM touches goes to the per-window EXCHANGE area in HBM
+     (a few KB).
+  3. ``HipGraphVadScorer`` hands the program to ``wj_vadg_create`` (csrc/vadgraph.hip) and scores every stream (scene) of a
+     call at once: each stage is ONE launch, one workgroup per window with the arena in LDS, running the stage's instructions
+     back to back; the LSTM runs one workgroup per stream sequentially over that stream's windows with its weights in
+     registers.  Arenas that do not fit the LDS fall back to one launch per instruction over an arena in HBM.
 
 Program encoding (int32 words; floats as their bit patterns) is described next to ``OPCODES`` and mirrored in
 csrc/vadgraph.hip; ``tests/vad_graph_ref.py`` holds a NumPy executor of the same program (test infrastructure) so the lowering
@@ -46,14 +54,14 @@ class LoweringError(RuntimeError):
 
 # ---- program ---------------------------------------------------------------------------------------------------------------
 # Every instruction: [opcode, n_words, ...].  A tensor operand ("view") is 2 + 2 * MAX_DIMS words:
-#   [space (0 arena / 1 constants / 2 state), offset in floats, shape[4] (leading 1-padded), strides[4] in floats]
+#   [space (0 arena / 1 constants / 2 state / 3 exchange), offset in floats, shape[4] (leading 1-padded), strides[4] in floats]
 OP_EW, OP_CONV1D, OP_PAD, OP_MEAN, OP_LINEAR, OP_LSTM = 1, 2, 3, 4, 5, 6
 OPCODES = {"ew": OP_EW, "conv1d": OP_CONV1D, "pad": OP_PAD, "mean": OP_MEAN, "linear": OP_LINEAR, "lstm": OP_LSTM}
 # element-wise function codes (a, b, c = operands; p0, p1 = float parameters)
 EW = {"copy": 0, "add": 1, "sub": 2, "mul": 3, "div": 4, "relu": 5, "sigmoid": 6, "tanh": 7, "exp": 8, "log1p": 9, "sqrt": 10,
       "abs": 11, "neg": 12, "pow_scalar": 13, "add_scalar": 14, "mul_scalar": 15, "fma": 16, "clamp": 17, "leaky_relu": 18,
       "log": 19, "rsub_scalar": 20, "silu": 21, "hardtanh": 22}
-SPACE_ARENA, SPACE_CONST, SPACE_STATE = 0, 1, 2
+SPACE_ARENA, SPACE_CONST, SPACE_STATE, SPACE_XCHG = 0, 1, 2, 3
 VIEW_WORDS = 2 + 2 * MAX_DIMS
 
 
@@ -63,11 +71,17 @@ def _f2w(x: float) -> int:
 
 @dataclass(frozen=True)
 class Sym:
-    """A strided float32 view: of the per-window arena, or of a per-stream state slot (``space`` 2, ``offset`` = slot base)."""
+    """A strided float32 view: of a per-window buffer (``space`` 0, ``buf`` = buffer id, ``offset`` relative to the buffer: the
+    layout pass decides arena / exchange and the base), of the constants, or of a per-stream state slot (``space`` 2,
+    ``offset`` = slot base)."""
     space: int
     offset: int
     shape: Tuple[int, ...]
     strides: Tuple[int, ...]
+    buf: int = -1
+
+    def like(self, offset: int, shape: Sequence[int], strides: Sequence[int]) -> "Sym":
+        return Sym(self.space, int(offset), tuple(int(d) for d in shape), tuple(int(x) for x in strides), self.buf)
 
     @property
     def numel(self) -> int:
@@ -98,6 +112,10 @@ class Program:
     state_init: List[Tuple[int, np.ndarray]] = field(default_factory=list)    # (slot offset, initial value)
     input_offset: int = 0
     output_offset: int = 0
+    input_space: int = SPACE_ARENA
+    output_space: int = SPACE_ARENA
+    xchg_floats: int = 0
+    unpacked_arena_floats: int = 0            # what one buffer per tensor would take (round 5's layout): reported, not used
     listing: List[str] = field(default_factory=list)
 
     def const_blob(self) -> np.ndarray:
@@ -135,6 +153,51 @@ _IDENTITY_OPS = {"aten::to", "aten::float", "aten::detach", "aten::clone", "aten
 _UNARY = {"aten::relu": "relu", "aten::sigmoid": "sigmoid", "aten::tanh": "tanh", "aten::exp": "exp", "aten::log1p": "log1p",
           "aten::sqrt": "sqrt", "aten::abs": "abs", "aten::neg": "neg", "aten::log": "log", "aten::silu": "silu"}
 _BINARY = {"aten::add": "add", "aten::sub": "sub", "aten::mul": "mul", "aten::div": "div"}
+_INPLACE_OK = {*_UNARY, *_BINARY, "aten::square", "aten::rsqrt", "aten::reciprocal", "aten::leaky_relu", "aten::hardtanh", "aten::clamp",
+               "aten::clamp_min", "aten::clamp_max", "aten::pow"}
+
+
+@dataclass
+class _V:
+    """A tensor operand of an instruction before the layout pass: expands to the VIEW_WORDS words of a view."""
+    sym: Sym
+    shape: Tuple[int, ...]
+    strides: Tuple[int, ...]
+
+
+@dataclass
+class _O:
+    """A contiguous operand named by (space, offset) only (linear / lstm)."""
+    sym: Sym
+
+
+@dataclass
+class _Ins:
+    name: str
+    payload: List[Any]
+    reads: List[int]
+    writes: List[int]
+    inplace_like: Optional[Sym]      # element-wise ops with a fresh result: the result view (it may take over a dying operand's slot)
+
+
+def _extent(s: Sym) -> Tuple[int, int]:
+    return s.offset, s.offset + sum((d - 1) * st for d, st in zip(s.shape, s.strides)) + 1
+
+
+def _overlap(a: Sym, b: Sym) -> bool:
+    """Conservative: the address ranges of two views of one buffer intersect."""
+    (a0, a1), (b0, b1) = _extent(a), _extent(b)
+    return a0 < b1 and b0 < a1
+
+
+def _self_overlap(s: Sym) -> bool:
+    """Two index tuples of the view may name one element (sorted strides must step over the extent below them)."""
+    span = 1
+    for st, d in sorted((st, d) for st, d in zip(s.strides, s.shape) if d > 1):
+        if st < span:
+            return True
+        span = st * (d - 1) + span
+    return False
 
 
 class _Lowerer:
@@ -150,17 +213,15 @@ class _Lowerer:
     def _begin(self) -> None:
         self.prog = Program(self.window, self.sr)
         self.prog._sig = []
-        self.arena = 0
+        self.buf_floats: List[int] = []            # per-window buffers of this walk (id -> size in floats)
+        self.instrs: List[_Ins] = []
         self.const_index: Dict[int, Tuple[int, np.ndarray]] = {}
-        self.replaced: Dict[Sym, Sym] = {}
-        self.lstm_state_writes: Dict[Sym, Tuple[int, Tuple[int, ...]]] = {}        # hn / cn output view -> the slot the LSTM read
 
     def alloc(self, shape: Sequence[int]) -> Sym:
         shape = tuple(int(d) for d in shape)
         n = int(np.prod(shape, dtype=np.int64)) if shape else 1
-        off = self.arena
-        self.arena += (n + 3) // 4 * 4            # 16-byte aligned buffers
-        return Sym(SPACE_ARENA, off, shape, _contig(shape))
+        self.buf_floats.append((n + 3) // 4 * 4)          # 16-byte aligned buffers
+        return Sym(SPACE_ARENA, 0, shape, _contig(shape), len(self.buf_floats) - 1)
 
     def const(self, t: Union[torch.Tensor, np.ndarray]) -> Sym:
         a = np.ascontiguousarray(t.detach().cpu().float().numpy() if isinstance(t, torch.Tensor) else t, dtype=np.float32)
@@ -178,7 +239,6 @@ class _Lowerer:
 
     def operand(self, v: Any, state_ok: bool = False) -> Sym:
         if isinstance(v, Sym):
-            v = self.replaced.get(v, v)
             if v.space == SPACE_STATE and not state_ok:      # state changes window by window: only the sequential LSTM kernel may read it
                 raise LoweringError("module state is read by an op other than the LSTM's initial state")
             return v
@@ -187,16 +247,17 @@ class _Lowerer:
         raise LoweringError(f"a tensor operand was expected, got {type(v).__name__}")
 
     @staticmethod
-    def _view_words(s: Sym, shape: Optional[Sequence[int]] = None, strides: Optional[Sequence[int]] = None) -> List[int]:
+    def _view(s: Sym, shape: Optional[Sequence[int]] = None, strides: Optional[Sequence[int]] = None) -> "_V":
         shape = tuple(s.shape if shape is None else shape)
         strides = tuple(s.strides if strides is None else strides)
         if len(shape) > MAX_DIMS:
             raise LoweringError(f"a {len(shape)}-d tensor (this loader handles up to {MAX_DIMS} dimensions)")
         pad = MAX_DIMS - len(shape)
-        return [s.space, s.offset, *([1] * pad), *[int(d) for d in shape], *([0] * pad), *[int(x) for x in strides]]
+        return _V(s, (*([1] * pad), *[int(d) for d in shape]), (*([0] * pad), *[int(x) for x in strides]))
 
-    def emit(self, name: str, payload: List[int], text: str, sig: Tuple) -> None:
-        self.prog.words.extend([OPCODES[name], 2 + len(payload), *payload])
+    def emit(self, name: str, payload: List[Any], text: str, sig: Tuple, reads: Sequence[Sym], writes: Sequence[Sym],
+             inplace_like: Optional[Sym] = None) -> None:
+        self.instrs.append(_Ins(name, payload, [r.buf for r in reads if r.buf >= 0], [w.buf for w in writes if w.buf >= 0], inplace_like))
         self.prog.n_instr += 1
         self.prog.listing.append(text)
         self.prog._sig.append((name, *sig))
@@ -205,9 +266,10 @@ class _Lowerer:
     def ew(self, fn: str, ins: Sequence[Any], p0: float = 0.0, p1: float = 0.0, out: Optional[Sym] = None) -> Sym:
         ops = [self.operand(x) for x in ins]
         shape = tuple(np.broadcast_shapes(*[o.shape for o in ops])) if out is None else out.shape
-        if out is None:
+        fresh = out is None
+        if fresh:
             out = self.alloc(shape)
-        words = [EW[fn], len(ops), _f2w(p0), _f2w(p1), *self._view_words(out)]
+        words: List[Any] = [EW[fn], len(ops), _f2w(p0), _f2w(p1), self._view(out)]
         for o in ops:
             pad = len(shape) - len(o.shape)
             if pad < 0:
@@ -216,11 +278,24 @@ class _Lowerer:
             for i, d in enumerate(o.shape):
                 if d != 1 and d != shape[pad + i]:
                     raise LoweringError(f"{fn}: operand {o.shape} does not broadcast into {shape}")
-            words += self._view_words(o, shape, st)
+            words.append(self._view(o, shape, st))
+            if not fresh and o.buf == out.buf and o.buf >= 0 and _overlap(o, out) and (o.offset, tuple(st)) != (out.offset, tuple(out.strides)):
+                # every thread reads its own element and then writes it: only the identical view may be read and written at once
+                raise LoweringError(f"{fn}: the result is written over an operand through a different view of the same tensor")
         for _ in range(3 - len(ops)):
             words += [0] * VIEW_WORDS
-        self.emit("ew", words, f"ew.{fn} {[o.shape for o in ops]} -> {shape}", (fn, shape, tuple(o.shape for o in ops), float(p0), float(p1)))
+        self.emit("ew", words, f"ew.{fn} {[o.shape for o in ops]} -> {shape}", (fn, shape, tuple(o.shape for o in ops), float(p0), float(p1)),
+                  ops, [out], inplace_like=out if fresh else None)
         return out
+
+    def ew_inplace(self, fn: str, x: Any, others: Sequence[Any] = (), p0: float = 0.0, p1: float = 0.0) -> Sym:
+        """``x.op_(...)``: the result goes through x's OWN view, so the base tensor and every other view of it see the write."""
+        x = self.operand(x)
+        if x.space != SPACE_ARENA or x.buf < 0:
+            raise LoweringError(f"{fn}_: an in-place op on a constant or on module state")
+        if any(s == 0 and d > 1 for s, d in zip(x.strides, x.shape)) or _self_overlap(x):
+            raise LoweringError(f"{fn}_: an in-place op on an expanded / self-overlapping view")
+        return self.ew(fn, [x, *others], p0, p1, out=x)
 
     def materialise(self, s: Sym) -> Sym:
         s = self.operand(s)
@@ -231,7 +306,7 @@ class _Lowerer:
         if not isinstance(w, torch.Tensor) or (b is not None and not isinstance(b, torch.Tensor)):
             raise LoweringError("conv1d with a weight or bias that depends on the input")
         if len(x.shape) == 2:
-            x = Sym(x.space, x.offset, (1, *x.shape), (0, *x.strides))
+            x = x.like(x.offset, (1, *x.shape), (0, *x.strides))
         if len(x.shape) != 3 or x.shape[0] != 1:
             raise LoweringError(f"conv1d input {x.shape}: one window per call ([1, C, T]) expected")
         cout, cin_g, k = (int(d) for d in w.shape)
@@ -244,10 +319,10 @@ class _Lowerer:
         out = self.alloc((1, cout, tout))
         wc = self.const(w)
         bc = self.const(b) if b is not None else None
-        words = [*self._view_words(out), *self._view_words(x), wc.offset, bc.offset if bc is not None else -1, cout, cin, k, t, tout, stride, padding,
+        words = [self._view(out), self._view(x), wc.offset, bc.offset if bc is not None else -1, cout, cin, k, t, tout, stride, padding,
                  dilation, groups]
         self.emit("conv1d", words, f"conv1d {x.shape} * {tuple(w.shape)} s{stride} p{padding} d{dilation} g{groups} -> {out.shape}",
-                  (x.shape, tuple(w.shape), b is not None, stride, padding, dilation, groups))
+                  (x.shape, tuple(w.shape), b is not None, stride, padding, dilation, groups), [x], [out])
         return out
 
     def pad_last(self, x: Any, left: int, right: int, mode: str, value: float) -> Sym:
@@ -258,8 +333,8 @@ class _Lowerer:
         if mode == "reflect" and (left >= t or right >= t):
             raise LoweringError(f"reflect padding ({left}, {right}) of {t} positions")
         out = self.alloc((*x.shape[:-1], t + left + right))
-        words = [*self._view_words(out), *self._view_words(x), left, right, {"constant": 0, "reflect": 1, "replicate": 2}[mode], _f2w(value)]
-        self.emit("pad", words, f"pad.{mode} {x.shape} ({left}, {right}) -> {out.shape}", (x.shape, left, right, mode, float(value)))
+        words = [self._view(out), self._view(x), left, right, {"constant": 0, "reflect": 1, "replicate": 2}[mode], _f2w(value)]
+        self.emit("pad", words, f"pad.{mode} {x.shape} ({left}, {right}) -> {out.shape}", (x.shape, left, right, mode, float(value)), [x], [out])
         return out
 
     def mean(self, x: Any, dims: Sequence[int], keepdim: bool) -> Sym:
@@ -274,12 +349,12 @@ class _Lowerer:
             keep_strides = list(cur.strides)
             rstride = keep_strides[d]
             keep_strides[d] = 0
-            words = [*self._view_words(out), *self._view_words(cur, shape, keep_strides), r, rstride, _f2w(1.0 / r)]
-            self.emit("mean", words, f"mean {cur.shape} over axis {d} -> {tuple(shape)}", (cur.shape, d))
+            words = [self._view(out), self._view(cur, shape, keep_strides), r, rstride, _f2w(1.0 / r)]
+            self.emit("mean", words, f"mean {cur.shape} over axis {d} -> {tuple(shape)}", (cur.shape, d), [cur], [out])
             cur = out
         if not keepdim:
             shape = [s for i, s in enumerate(cur.shape) if i not in dims]
-            cur = Sym(cur.space, cur.offset, tuple(shape), _contig(shape))
+            cur = cur.like(cur.offset, shape, _contig(shape))
         return cur
 
     def linear(self, x: Any, w: torch.Tensor, b: Optional[torch.Tensor]) -> Sym:
@@ -292,8 +367,8 @@ class _Lowerer:
         rows = x.numel // nin
         out = self.alloc((*x.shape[:-1], nout))
         wc, bc = self.const(w), (self.const(b) if b is not None else None)
-        self.emit("linear", [out.offset, x.offset, wc.offset, bc.offset if bc is not None else -1, rows, nin, nout],
-                  f"linear {x.shape} * {tuple(w.shape)} -> {out.shape}", (x.shape, tuple(w.shape), b is not None))
+        self.emit("linear", [_O(out), _O(x), wc.offset, bc.offset if bc is not None else -1, rows, nin, nout],
+                  f"linear {x.shape} * {tuple(w.shape)} -> {out.shape}", (x.shape, tuple(w.shape), b is not None), [x], [out])
         return out
 
     def lstm(self, x: Any, hx: Sequence[Any], params: Sequence[Any], has_biases: bool, num_layers: int, train: bool, bidirectional: bool,
@@ -302,6 +377,8 @@ class _Lowerer:
             raise LoweringError("an LSTM in training mode or a bidirectional one")
         if any(not isinstance(p, torch.Tensor) for p in params):
             raise LoweringError("LSTM parameters that depend on the input")
+        if self._pending_lstm is not None:
+            raise LoweringError("a second LSTM (one recurrent block per archive is lowered)")
         x = self.operand(x)
         if len(x.shape) != 3 or x.shape[0 if batch_first else 1] != 1:
             raise LoweringError(f"LSTM input {x.shape}: one window per call (batch 1) expected")
@@ -338,11 +415,12 @@ class _Lowerer:
         y = self.alloc((1, t, hidden) if batch_first else (t, 1, hidden))
         hn, cn = self.alloc(want), self.alloc(want)
         self._pending_lstm = (src, hn, cn)
-        words = [y.offset, x.space, x.offset, st_t, st_f, t, nin, hidden, num_layers, hn.offset, cn.offset, *blobs, *([0] * (3 * (4 - num_layers)))]
-        # state slot offsets are patched in finish() (they are assigned when the SetAttr that closes the loop is seen)
-        self._lstm_word_pos = len(self.prog.words) + 2 + len(words)
-        words += [-1, -1]
-        self.emit("lstm", words, f"lstm {x.shape} hidden {hidden} x {num_layers} layers -> {y.shape}", (x.shape, hidden, num_layers, batch_first))
+        # the two state slot offsets are patched in _finish() (they are assigned when the SetAttr that closes the loop is seen), the
+        # last word -- does any instruction read the window's final (h, c) -- in _layout()
+        words = [_O(y), _O(x), st_t, st_f, t, nin, hidden, num_layers, _O(hn), _O(cn), *blobs, *([0] * (3 * (4 - num_layers))), -1, -1, 0]
+        self.emit("lstm", words, f"lstm {x.shape} hidden {hidden} x {num_layers} layers -> {y.shape}", (x.shape, hidden, num_layers, batch_first),
+                  [x], [y, hn, cn])
+        self._lstm_instr = self.instrs[-1]
         return y, hn, cn
 
     # -- the walk --
@@ -350,7 +428,6 @@ class _Lowerer:
         self._begin()
         self._pending_lstm = None
         x = self.alloc((self.window,))
-        self.prog.input_offset = x.offset
         env: Dict[Any, Any] = {}
         ins = list(self.graph.inputs())
         env[ins[0]] = self.module
@@ -365,10 +442,121 @@ class _Lowerer:
         res = self.materialise(outs[0])
         if res.numel != 1:
             raise LoweringError(f"forward returns {res.shape} per window; one probability expected")
-        self.prog.output_offset = res.offset
         self._finish()
-        self.prog.arena_floats = self.arena
+        self._layout(x, res)
         return self.prog
+
+    def _layout(self, x: Sym, res: Sym) -> None:
+        """Spaces and offsets of the per-window buffers, then the program words (see the module docstring, step 2)."""
+        n = len(self.instrs)
+        stage, s = [], 0
+        for ins in self.instrs:                                 # an LSTM is a stage boundary (stage -1: it touches the exchange area only)
+            stage.append(-1 if ins.name == "lstm" else s)
+            s += ins.name == "lstm"
+        first: Dict[int, int] = {x.buf: -1}
+        last: Dict[int, int] = {x.buf: -1}
+        stages: Dict[int, set] = {x.buf: {0}}
+        for i, ins in enumerate(self.instrs):
+            for b in (*ins.reads, *ins.writes):
+                first.setdefault(b, i)
+                last[b] = i
+                stages.setdefault(b, set()).add(stage[i])
+        last[res.buf] = n
+        stages[res.buf].add(s)                                  # the probability is read after the last stage
+        space: Dict[int, int] = {b: (SPACE_XCHG if (-1 in st or len(st) > 1) else SPACE_ARENA) for b, st in stages.items()}
+        base: Dict[int, int] = {}
+        xchg = 0
+        for b in sorted(space):
+            if space[b] == SPACE_XCHG:
+                base[b] = xchg
+                xchg += self.buf_floats[b]
+        # arena: first-fit over the live intervals, in instruction order
+        free: List[List[int]] = []          # [offset, size], sorted by offset
+        top = 0
+
+        def take(size: int) -> int:
+            nonlocal top
+            for blk in free:
+                if blk[1] >= size:
+                    off = blk[0]
+                    blk[0] += size
+                    blk[1] -= size
+                    if blk[1] == 0:
+                        free.remove(blk)
+                    return off
+            if free and free[-1][0] + free[-1][1] == top:        # grow the last free block instead of leaving a hole
+                off = free[-1][0]
+                top = off + size
+                free.pop()
+                return off
+            off = top
+            top += size
+            return off
+
+        def give(off: int, size: int) -> None:
+            free.append([off, size])
+            free.sort()
+            i = 0
+            while i + 1 < len(free):
+                if free[i][0] + free[i][1] == free[i + 1][0]:
+                    free[i][1] += free[i + 1][1]
+                    del free[i + 1]
+                else:
+                    i += 1
+
+        owner: Dict[int, int] = {}           # buffer -> the buffer whose slot it took over (in-place element-wise results)
+        arena_bufs = [b for b in space if space[b] == SPACE_ARENA]
+        by_first: Dict[int, List[int]] = {}
+        by_last: Dict[int, List[int]] = {}
+        for b in arena_bufs:
+            by_first.setdefault(first[b], []).append(b)
+            by_last.setdefault(last[b], []).append(b)
+        taken_over: set = set()
+        for i in range(-1, n + 1):
+            ins = self.instrs[i] if 0 <= i < n else None
+            for b in by_first.get(i, []):
+                donor = None
+                out = ins.inplace_like if ins is not None else None
+                if out is not None and out.buf == b and out.offset == 0 and out.is_contiguous() and out.numel == int(np.prod(out.shape)):
+                    for v in ins.payload:
+                        if isinstance(v, _V) and v.sym.buf >= 0 and v.sym.buf != b and space.get(v.sym.buf) == SPACE_ARENA and last[v.sym.buf] == i \
+                                and v.sym.buf not in taken_over and self.buf_floats[v.sym.buf] == self.buf_floats[b] \
+                                and all(u.sym.offset == 0 and u.strides == self._view(out).strides for u in ins.payload
+                                        if isinstance(u, _V) and u.sym.buf == v.sym.buf):
+                            donor = v.sym.buf
+                            break
+                if donor is not None:
+                    base[b] = base[donor]
+                    taken_over.add(donor)
+                else:
+                    base[b] = take(self.buf_floats[b])
+            for b in by_last.get(i, []):
+                if b not in taken_over:
+                    give(base[b], self.buf_floats[b])
+        p = self.prog
+        p.arena_floats = max(4, top)
+        p.xchg_floats = max(4, xchg)
+        p.unpacked_arena_floats = sum(self.buf_floats)
+        p.input_space, p.input_offset = space[x.buf], base[x.buf] + x.offset
+        p.output_space, p.output_offset = space[res.buf], base[res.buf] + res.offset
+        self.spaces, self.bases = space, base
+
+        def where(sym: Sym) -> Tuple[int, int]:
+            return (sym.space, sym.offset) if sym.buf < 0 else (space[sym.buf], base[sym.buf] + sym.offset)
+
+        p.words = []
+        for ins in self.instrs:
+            if ins.name == "lstm":
+                ins.payload[-1] = int(any(b in other.reads for other in self.instrs for b in ins.writes[1:]))
+            payload: List[int] = []
+            for v in ins.payload:
+                if isinstance(v, _V):
+                    payload += [*where(v.sym), *v.shape, *v.strides]
+                elif isinstance(v, _O):
+                    payload += [*where(v.sym)]
+                else:
+                    payload.append(int(v))
+            p.words.extend([OPCODES[ins.name], 2 + len(payload), *payload])
 
     def _finish(self) -> None:
         """Close the state loop: every attribute that now holds a symbolic tensor must be an LSTM's (hn, cn)."""
@@ -380,12 +568,11 @@ class _Lowerer:
         src, hn, cn = self._pending_lstm
         slots = []
         for (kind, val), out, name in ((src[0], hn, "h"), (src[1], cn, "c")):
-            keys = [k for k, v in writes.items() if self.replaced.get(v, v) == out]
+            keys = [k for k, v in writes.items() if v == out]
             if len(keys) != 1:
                 raise LoweringError(f"the LSTM's final {name} is stored in {len(keys)} module attributes (exactly one expected)")
             key = keys[0]
             if key not in self.state_slots:
-                n = out.numel
                 self.state_slots[key] = (sum(int(np.prod(s[1])) for s in self.state_slots.values()), out.shape)
             off, shape = self.state_slots[key]
             if kind == "state" and val.offset != off:
@@ -393,10 +580,10 @@ class _Lowerer:
             if kind == "const":
                 self.prog.state_init.append((off, np.ascontiguousarray(val.detach().cpu().float().numpy()).reshape(-1)))
             slots.append(off)
-        extra = [k for k, v in writes.items() if self.replaced.get(v, v) not in (hn, cn)]
+        extra = [k for k, v in writes.items() if v not in (hn, cn)]
         if extra:
             raise LoweringError(f"module attribute {extra[0][1]!r} keeps a tensor that is not LSTM state")
-        self.prog.words[self._lstm_word_pos: self._lstm_word_pos + 2] = slots
+        self._lstm_instr.payload[-3:-1] = slots
         self.prog.state_floats = sum(int(np.prod(s[1])) for s in self.state_slots.values())
 
     def _attr(self, obj: Any, name: str) -> Any:
@@ -523,14 +710,16 @@ class _Lowerer:
         base = kind[:-1] if (kind.endswith("_") and not kind.endswith("__")) else kind
         inplace = base != kind
         x = ins[0]
+        if inplace and base not in _INPLACE_OK:
+            raise LoweringError(f"in-place op {kind} on audio-dependent tensors is not lowered ({where})")
 
-        def done(res: Sym) -> Tuple[Sym]:
-            if inplace and isinstance(x, Sym):      # later reads of the mutated tensor see the result
-                self.replaced[x] = res
-                for k, v in list(self.replaced.items()):
-                    if v == x:
-                        self.replaced[k] = res
-            return (res,)
+        def E(fn: str, ops: Sequence[Any], p0: float = 0.0, p1: float = 0.0) -> Tuple[Sym]:
+            """One element-wise instruction; ``op_`` variants write through the first operand's own view (aliases see the result)."""
+            if inplace:
+                if ops[0] is not x:
+                    raise LoweringError(f"{kind}: the in-place target is not the first operand ({where})")
+                return (self.ew_inplace(fn, ops[0], ops[1:], p0, p1),)
+            return (self.ew(fn, ops, p0, p1),)
 
         # shape queries
         if base == "aten::size":
@@ -548,22 +737,22 @@ class _Lowerer:
         if base == "aten::unsqueeze":
             s = self.operand(x, state_ok=True)
             d = ins[1] % (len(s.shape) + 1)
-            return (Sym(s.space, s.offset, (*s.shape[:d], 1, *s.shape[d:]), (*s.strides[:d], 0, *s.strides[d:])),)
+            return (s.like(s.offset, (*s.shape[:d], 1, *s.shape[d:]), (*s.strides[:d], 0, *s.strides[d:])),)
         if base == "aten::squeeze":
             s = self.operand(x, state_ok=True)
             dims = range(len(s.shape)) if len(ins) == 1 else [ins[1] % len(s.shape)] if isinstance(ins[1], int) else [d % len(s.shape) for d in ins[1]]
             keep = [i for i in range(len(s.shape)) if not (i in dims and s.shape[i] == 1)]
-            return (Sym(s.space, s.offset, tuple(s.shape[i] for i in keep), tuple(s.strides[i] for i in keep)),)
+            return (s.like(s.offset, [s.shape[i] for i in keep], [s.strides[i] for i in keep]),)
         if base == "aten::permute":
             s = self.operand(x, state_ok=True)
             p = [d % len(s.shape) for d in ins[1]]
-            return (Sym(s.space, s.offset, tuple(s.shape[i] for i in p), tuple(s.strides[i] for i in p)),)
+            return (s.like(s.offset, [s.shape[i] for i in p], [s.strides[i] for i in p]),)
         if base in ("aten::transpose", "aten::t"):
             s = self.operand(x, state_ok=True)
             a, b = (0, 1) if base == "aten::t" else (ins[1] % len(s.shape), ins[2] % len(s.shape))
             p = list(range(len(s.shape)))
             p[a], p[b] = p[b], p[a]
-            return (Sym(s.space, s.offset, tuple(s.shape[i] for i in p), tuple(s.strides[i] for i in p)),)
+            return (s.like(s.offset, [s.shape[i] for i in p], [s.strides[i] for i in p]),)
         if base == "aten::slice":
             s = self.operand(x, state_ok=True)
             d = (ins[1] if len(ins) > 1 and ins[1] is not None else 0) % len(s.shape)
@@ -576,12 +765,12 @@ class _Lowerer:
             cnt = (end - start + step - 1) // step
             shape, strides = list(s.shape), list(s.strides)
             shape[d], strides[d] = cnt, s.strides[d] * step
-            return (Sym(s.space, s.offset + start * s.strides[d], tuple(shape), tuple(strides)),)
+            return (s.like(s.offset + start * s.strides[d], shape, strides),)
         if base == "aten::select":
             s = self.operand(x, state_ok=True)
             d = ins[1] % len(s.shape)
             i = ins[2] % s.shape[d]
-            return (Sym(s.space, s.offset + i * s.strides[d], s.shape[:d] + s.shape[d + 1:], s.strides[:d] + s.strides[d + 1:]),)
+            return (s.like(s.offset + i * s.strides[d], s.shape[:d] + s.shape[d + 1:], s.strides[:d] + s.strides[d + 1:]),)
         if base in ("aten::view", "aten::reshape", "aten::flatten"):
             s = self.materialise(x)
             if base == "aten::flatten":
@@ -594,33 +783,33 @@ class _Lowerer:
                     shape[shape.index(-1)] = s.numel // max(1, -int(np.prod(shape)))
             if int(np.prod(shape)) != s.numel:
                 raise LoweringError(f"{kind}: {s.shape} -> {shape} ({where})")
-            return (Sym(s.space, s.offset, tuple(shape), _contig(shape)),)
+            return (s.like(s.offset, shape, _contig(shape)),)
         if base == "aten::expand":
             s = self.operand(x, state_ok=True)
             shape = [s.shape[i - (len(ins[1]) - len(s.shape))] if d == -1 else d for i, d in enumerate(ins[1])]
             pad = len(shape) - len(s.shape)
             strides = [0] * pad + [0 if s.shape[i] == 1 and shape[pad + i] != 1 else s.strides[i] for i in range(len(s.shape))]
-            return (Sym(s.space, s.offset, tuple(shape), tuple(strides)),)
+            return (s.like(s.offset, shape, strides),)
         # element-wise
         if base in _UNARY:
-            return done(self.ew(_UNARY[base], [x]))
+            return E(_UNARY[base], [x])
         if base == "aten::square":
-            return done(self.ew("mul", [x, x]))
+            return E("mul", [x, x])
         if base == "aten::rsqrt":
-            return done(self.ew("pow_scalar", [x], -0.5))
+            return E("pow_scalar", [x], -0.5)
         if base == "aten::reciprocal":
-            return done(self.ew("pow_scalar", [x], -1.0))
+            return E("pow_scalar", [x], -1.0)
         if base == "aten::leaky_relu":
-            return done(self.ew("leaky_relu", [x], float(ins[1]) if len(ins) > 1 else 0.01))
+            return E("leaky_relu", [x], float(ins[1]) if len(ins) > 1 else 0.01)
         if base == "aten::hardtanh":
-            return done(self.ew("hardtanh", [x], float(ins[1]) if len(ins) > 1 else -1.0, float(ins[2]) if len(ins) > 2 else 1.0))
+            return E("hardtanh", [x], float(ins[1]) if len(ins) > 1 else -1.0, float(ins[2]) if len(ins) > 2 else 1.0)
         if base in ("aten::clamp", "aten::clamp_min", "aten::clamp_max"):
             lo = ins[1] if base != "aten::clamp_max" else None
             hi = ins[2] if base == "aten::clamp" and len(ins) > 2 else (ins[1] if base == "aten::clamp_max" else None)
-            return done(self.ew("clamp", [x], -3.0e38 if lo is None else float(lo), 3.0e38 if hi is None else float(hi)))
+            return E("clamp", [x], -3.0e38 if lo is None else float(lo), 3.0e38 if hi is None else float(hi))
         if base == "aten::pow":
             if isinstance(ins[1], (int, float)) and isinstance(x, Sym):
-                return done(self.ew("mul", [x, x]) if float(ins[1]) == 2.0 else self.ew("pow_scalar", [x], float(ins[1])))
+                return E("mul", [x, x]) if float(ins[1]) == 2.0 else E("pow_scalar", [x], float(ins[1]))
             raise LoweringError(f"pow with a tensor exponent ({where})")
         if base in _BINARY:
             a, b = ins[0], ins[1]
@@ -637,27 +826,28 @@ class _Lowerer:
             if scalar_b:
                 v = float(b) * float(alpha)
                 if base == "aten::add":
-                    return done(self.ew("add_scalar", [a], v))
+                    return E("add_scalar", [a], v)
                 if base == "aten::sub":
-                    return done(self.ew("add_scalar", [a], -v))
+                    return E("add_scalar", [a], -v)
                 if base == "aten::mul":
-                    return done(self.ew("mul_scalar", [a], float(b)))
-                return done(self.ew("mul_scalar", [a], 1.0 / float(b)) if float(b) != 0 and math.log2(abs(float(b))).is_integer()
-                            else self.ew("div", [a, torch.tensor(float(b))]))
+                    return E("mul_scalar", [a], float(b))
+                if float(b) != 0 and math.log2(abs(float(b))).is_integer():
+                    return E("mul_scalar", [a], 1.0 / float(b))
+                return E("div", [a, torch.tensor(float(b))])
             if scalar_a:
                 if base == "aten::add":
-                    return done(self.ew("add_scalar", [b], float(a)))
+                    return E("add_scalar", [b], float(a))
                 if base == "aten::mul":
-                    return done(self.ew("mul_scalar", [b], float(a)))
+                    return E("mul_scalar", [b], float(a))
                 if base == "aten::sub":
-                    return done(self.ew("rsub_scalar", [b], float(a), float(alpha)))
-                return done(self.ew("div", [torch.tensor(float(a)), b]))
+                    return E("rsub_scalar", [b], float(a), float(alpha))
+                return E("div", [torch.tensor(float(a)), b])
             if alpha != 1:
                 b = self.ew("mul_scalar", [b], float(alpha)) if isinstance(b, Sym) else b * alpha
-            return done(self.ew(_BINARY[base], [a, b]))
+            return E(_BINARY[base], [a, b])
         if base == "aten::rsub":
-            return done(self.ew("rsub_scalar", [x], float(ins[1]), float(ins[2]) if len(ins) > 2 else 1.0)) if isinstance(ins[1], (int, float)) else \
-                done(self.ew("sub", [ins[1], x]))
+            return E("rsub_scalar", [x], float(ins[1]), float(ins[2]) if len(ins) > 2 else 1.0) if isinstance(ins[1], (int, float)) else \
+                E("sub", [ins[1], x])
         # structure
         if base == "aten::cat":
             parts, d = [self.operand(p) for p in ins[0]], ins[1]
@@ -669,7 +859,7 @@ class _Lowerer:
             for p in parts:
                 if [s for i, s in enumerate(p.shape) if i != d] != [s for i, s in enumerate(shape) if i != d]:
                     raise LoweringError(f"cat of {[q.shape for q in parts]} along {d} ({where})")
-                self.ew("copy", [p], out=Sym(out.space, out.offset + pos * out.strides[d], p.shape, out.strides))
+                self.ew("copy", [p], out=out.like(out.offset + pos * out.strides[d], p.shape, out.strides))
                 pos += p.shape[d]
             return (out,)
         if base in ("aten::pad", "aten::reflection_pad1d", "aten::constant_pad_nd", "aten::replication_pad1d"):
@@ -763,14 +953,15 @@ class HipGraphVadScorer:
     v4.0 hub archives at 16 kHz, utils_vad.get_speech_timestamps' default there)."""
 
     def __init__(self, archive: Union[str, torch.jit.ScriptModule], window: int = 1536, sample_rate: int = 16000, device: int = 0,
-                 max_windows_per_launch: int = 16384):
+                 max_windows_per_launch: int = 1 << 20, fused: Optional[bool] = None):
+        """``fused``: None = one launch per stage with the arena in LDS whenever it fits (the normal case), True = require that,
+        False = one launch per instruction over an arena in HBM (the fall-back for arenas beyond the LDS; kept selectable as the
+        cross-check of the fused kernels).  Per-window memory is allocated by the first call, for the windows it scores."""
         from . import hipbind
         if not torch.cuda.is_available():
             raise hipbind.WjError("no ROCm device visible: the HIP VAD graph scorer has no CPU fallback")
         module = load_archive(archive) if isinstance(archive, str) else archive
         self.program = lower(module, window, sample_rate)
-        # windows per launch group: grid.y of the batched launches (< 65536) and at most 8 GiB of arenas
-        max_windows_per_launch = max(1, min(int(max_windows_per_launch), 65535, (8 << 30) // max(4, 4 * self.program.arena_floats)))
         self.window, self.sample_rate = int(window), int(sample_rate)
         self.device = int(device)
         self.dev = torch.device("cuda", device)
@@ -780,12 +971,17 @@ class HipGraphVadScorer:
         words = np.asarray(p.words, dtype=np.int32)
         consts, state = p.const_blob(), p.state_blob()
         handle = C.c_void_p()
+        mode = 0 if fused is None else (2 if fused else 1)
         hipbind.check(self._lib.wj_vadg_create(self.ctx.handle, words.ctypes.data_as(C.POINTER(C.c_int32)), len(words), p.n_instr,
                                                consts.ctypes.data_as(C.POINTER(C.c_float)), int(consts.size),
                                                state.ctypes.data_as(C.POINTER(C.c_float)), int(p.state_floats), int(p.arena_floats),
-                                               int(p.input_offset), int(p.output_offset), int(window), int(max_windows_per_launch),
+                                               int(p.xchg_floats), int(p.input_space), int(p.input_offset), int(p.output_space),
+                                               int(p.output_offset), int(window), int(max(1, max_windows_per_launch)), mode,
                                                C.byref(handle)), "wj_vadg_create")
         self.handle = handle
+        info = (C.c_int32 * 8)()
+        hipbind.check(self._lib.wj_vadg_info(self.handle, info), "wj_vadg_info")
+        self.fused, self.lds_bytes, self.n_stages, self.lstm_in_registers = bool(info[0]), int(info[1]), int(info[2]), bool(info[3])
 
     def close(self) -> None:
         if getattr(self, "handle", None):
