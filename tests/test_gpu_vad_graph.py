@@ -29,7 +29,7 @@ def test_device_probabilities_equal_the_archive_on_the_cpu(hip, variant, window,
     archive = S.build(variant, seed=7)
     scorer = vad_graph.HipGraphVadScorer(archive, window=window, fused=fused)
     assert scorer.fused == fused and scorer.lstm_in_registers == fused and scorer.n_stages == 2
-    assert (0 < scorer.lds_bytes <= 64 * 1024) if fused else scorer.lds_bytes == 0
+    assert (0 < scorer.lds_bytes <= 80 * 1024) if fused else scorer.lds_bytes == 0
     clips = _streams()
     got = scorer.scores(clips)
     worst = 0.0
@@ -65,7 +65,7 @@ def test_streams_that_straddle_launch_groups_carry_their_state(hip):
 
 
 def test_the_default_scorer_is_fused_and_allocates_for_the_call(hip):
-    """No mode named: the silero-shaped graphs run fused (53 KB of LDS per window, three launches per call), per-window memory
+    """No mode named: the silero-shaped graphs run fused (70 KB of LDS per window, three launches per call), per-window memory
     is allocated by the first call for the windows it scores (round 5 held 4 GB of arenas from create on)."""
     from whisperjav_amd import vad_graph
     scorer = vad_graph.HipGraphVadScorer(S.build("v4", seed=7))

@@ -207,12 +207,13 @@ def test_inplace_ops_write_through_the_operands_own_view():
 
 
 def test_the_arena_is_laid_out_by_liveness_and_fits_the_lds():
-    """The silero-shaped graphs: ~53 KB of arena per 1536-sample window (one buffer per tensor would take 248 KB), everything an
+    """The silero-shaped graphs: ~70 KB of arena per 1536-sample window, the staging scratch of the small convolutions included
+    (one buffer per tensor would take 248 KB + scratch): two workgroups per compute unit; everything an
     LSTM touches -- and the tensors that cross it -- in the small exchange area; the NumPy executor poisons the arena at every
     stage boundary, so a tensor wrongly left in it would turn the probabilities into NaN (test_lowered_program_equals_torch_jit)."""
     for variant in ("v4", "v3"):
         p = vg.lower(S.build(variant, seed=7), 1536)
-        assert p.arena_floats * 4 <= 64 * 1024 and p.unpacked_arena_floats > 4 * p.arena_floats
+        assert p.arena_floats * 4 <= 80 * 1024 and p.unpacked_arena_floats > 3.5 * p.arena_floats
         assert 7 * 64 * 2 <= p.xchg_floats <= 2048
         assert p.input_space == vg.SPACE_ARENA and p.output_space == vg.SPACE_ARENA
 

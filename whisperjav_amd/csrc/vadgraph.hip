@@ -30,6 +30,8 @@
 //
 // Instruction encoding: see OP_* / the "view" layout in whisperjav_amd/vad_graph.py (mirrored below; wj_vadg_create
 // validates every offset against the arena / exchange / constant / state sizes before anything is launched).
+#include <stdlib.h>
+
 #include <algorithm>
 #include <initializer_list>
 #include <vector>
@@ -41,6 +43,8 @@ namespace wj {
 constexpr int kMaxDims = 4;
 constexpr int kViewWords = 2 + 2 * kMaxDims;
 constexpr int kConvTB = 5;          // output positions a lane of the channel-lanes convolution keeps in registers
+constexpr int kStageThreads = 512;  // of a fused stage's workgroup: the instructions are latency-bound chains, 2 workgroups x 8 wavefronts per CU hide them
+constexpr int kConvPF = 8;          // tap quads its weight stream runs ahead of the arithmetic
 enum { OP_EW = 1, OP_CONV1D = 2, OP_PAD = 3, OP_MEAN = 4, OP_LINEAR = 5, OP_LSTM = 6 };
 enum { SP_ARENA = 0, SP_CONST = 1, SP_STATE = 2, SP_XCHG = 3 };
 enum { EW_COPY = 0, EW_ADD, EW_SUB, EW_MUL, EW_DIV, EW_RELU, EW_SIGMOID, EW_TANH, EW_EXP, EW_LOG1P, EW_SQRT, EW_ABS, EW_NEG,
@@ -56,7 +60,12 @@ struct View {
 // `flat`: 0 = strided indexing, 1 = every operand is addressed by the flat element index (or is one broadcast scalar)
 struct EwArgs { int32_t fn, nin; float p0, p1; View out, in[3]; int32_t flat, in_mode[3]; };
 // chan_lanes: output channels [0, cout_full) run with the lanes on the channels over the tap-major weights at wt_off
-struct ConvArgs { View out, in; int32_t w_off, b_off, cout, cin, k, t, tout, stride, padding, dilation, groups; int32_t cout_full, wt_off, vec4; };
+// ws_*: arena scratch of the instruction (weights staged with row stride ws_stride, then the bias), -1 = none
+struct ConvArgs {
+  View out, in;
+  int32_t w_off, b_off, cout, cin, k, t, tout, stride, padding, dilation, groups, ws_space, ws_off, ws_stride;
+  int32_t cout_full, wt_off, vec4;
+};
 struct PadArgs { View out, in; int32_t left, right, mode; float value; };
 struct MeanArgs { View out, in; int32_t r, rstride; float inv; };
 struct LinearArgs { int32_t out_space, out_off, in_space, in_off, w_off, b_off, rows, nin, nout; };
@@ -70,8 +79,8 @@ struct Instr {
   int op;
   int items;          // work items of the instruction (threads of a stage = the largest, rounded to wavefronts)
   union { EwArgs ew; ConvArgs conv; PadArgs pad; MeanArgs mean; LinearArgs lin; LstmArgs lstm; };
-  Instr() { memset(this, 0, sizeof(*this)); }
 };
+static_assert(sizeof(Instr) % 4 == 0, "Instr is copied dword by dword");
 
 struct Segment { int32_t first, count, stream; };   // a stream's windows inside one slab: first window, how many, state row
 
@@ -81,6 +90,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // an HBM pointer in the per-instruction fall-back; the accessors branch on the (wavefront-uniform) space, and because the
 // two sides of the branch are different address spaces the compiler cannot fold them into one flat access: arena traffic of
 // the fused kernel is ds_read / ds_write.
+typedef const __attribute__((address_space(4))) float cst_f32;      // read-only for the whole launch: wavefront-uniform loads become s_load
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) f32x4_t lds_f32x4;
 template <bool FUSED> struct ArenaPtr { typedef float* type; };
@@ -107,44 +117,76 @@ __device__ __forceinline__ int64_t view_index(const View& v, int i0, int i1, int
   return (int64_t)v.offset + (int64_t)i0 * v.stride[0] + (int64_t)i1 * v.stride[1] + (int64_t)i2 * v.stride[2] + (int64_t)i3 * v.stride[3];
 }
 
-__device__ __forceinline__ float ew_apply(int fn, float x, float y, float z, float p0, float p1) {
+// N elements of one function: the (wavefront-uniform) switch runs once per round, not once per element
+template <int N> __device__ __forceinline__ void ew_apply(int fn, const float (&x)[N], const float (&y)[N], const float (&z)[N], float p0, float p1, float (&r)[N]) {
+#define WJ_EW(expr) _Pragma("unroll") for (int u = 0; u < N; ++u) r[u] = (expr); break
   switch (fn) {
-    case EW_COPY: return x;
-    case EW_ADD: return x + y;
-    case EW_SUB: return x - y;
-    case EW_MUL: return x * y;
-    case EW_DIV: return x / y;
-    case EW_RELU: return fmaxf(x, 0.f);
-    case EW_SIGMOID: return sigmoidf_(x);
-    case EW_TANH: return tanhf(x);
-    case EW_EXP: return expf(x);
-    case EW_LOG1P: return log1pf(x);
-    case EW_SQRT: return sqrtf(x);
-    case EW_ABS: return fabsf(x);
-    case EW_NEG: return -x;
-    case EW_POW_SCALAR: return powf(x, p0);
-    case EW_ADD_SCALAR: return x + p0;
-    case EW_MUL_SCALAR: return x * p0;
-    case EW_FMA: return x * y + z;      // contracted to one fma by the compiler, as torch's fused affine is not: |d| <= 1 ulp
-    case EW_CLAMP: return fminf(fmaxf(x, p0), p1);
-    case EW_LEAKY_RELU: return x > 0.f ? x : x * p0;
-    case EW_LOG: return logf(x);
-    case EW_RSUB_SCALAR: return p0 - x * p1;
-    case EW_SILU: return x * sigmoidf_(x);
-    default: return fminf(fmaxf(x, p0), p1);   // EW_HARDTANH
+    case EW_COPY: WJ_EW(x[u]);
+    case EW_ADD: WJ_EW(x[u] + y[u]);
+    case EW_SUB: WJ_EW(x[u] - y[u]);
+    case EW_MUL: WJ_EW(x[u] * y[u]);
+    case EW_DIV: WJ_EW(x[u] / y[u]);
+    case EW_RELU: WJ_EW(fmaxf(x[u], 0.f));
+    case EW_SIGMOID: WJ_EW(sigmoidf_(x[u]));
+    case EW_TANH: WJ_EW(tanhf(x[u]));
+    case EW_EXP: WJ_EW(expf(x[u]));
+    case EW_LOG1P: WJ_EW(log1pf(x[u]));
+    case EW_SQRT: WJ_EW(sqrtf(x[u]));
+    case EW_ABS: WJ_EW(fabsf(x[u]));
+    case EW_NEG: WJ_EW(-x[u]);
+    case EW_POW_SCALAR: WJ_EW(powf(x[u], p0));
+    case EW_ADD_SCALAR: WJ_EW(x[u] + p0);
+    case EW_MUL_SCALAR: WJ_EW(x[u] * p0);
+    case EW_FMA: WJ_EW(x[u] * y[u] + z[u]);      // contracted to one fma by the compiler, as torch's fused affine is not: |d| <= 1 ulp
+    case EW_CLAMP: WJ_EW(fminf(fmaxf(x[u], p0), p1));
+    case EW_LEAKY_RELU: WJ_EW(x[u] > 0.f ? x[u] : x[u] * p0);
+    case EW_LOG: WJ_EW(logf(x[u]));
+    case EW_RSUB_SCALAR: WJ_EW(p0 - x[u] * p1);
+    case EW_SILU: WJ_EW(x[u] * sigmoidf_(x[u]));
+    default: WJ_EW(fminf(fmaxf(x[u], p0), p1));   // EW_HARDTANH
   }
+#undef WJ_EW
 }
 
 template <bool F> __device__ __forceinline__ void run_ew(const EwArgs& a, const Mem<F>& m, int tid, int nthreads) {
   const int d1 = a.out.shape[1], d2 = a.out.shape[2], d3 = a.out.shape[3];
   const int total = a.out.shape[0] * d1 * d2 * d3;
   if (a.flat) {
-    for (int e = tid; e < total; e += nthreads) {
-      const float x = ld(m, a.in[0].space, a.in[0].offset + (a.in_mode[0] == 1 ? e : 0));
-      float y = 0.f, z = 0.f;
-      if (a.nin > 1) y = ld(m, a.in[1].space, a.in[1].offset + (a.in_mode[1] == 1 ? e : 0));
-      if (a.nin > 2) z = ld(m, a.in[2].space, a.in[2].offset + (a.in_mode[2] == 1 ? e : 0));
-      st(m, a.out.space, a.out.offset + e, ew_apply(a.fn, x, y, z, a.p0, a.p1));
+    // operands addressed by the flat element index; broadcast scalars are fetched once.  Four independent elements per thread and
+    // round: their loads are in flight together.  (In-place results: an element is read and written by the same thread through
+    // the identical view, loads first.)  The all-arena case has no space branches between its loads.
+    float sc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < a.nin && a.in_mode[i] == 2) sc[i] = ld(m, a.in[i].space, a.in[i].offset);
+    bool arena_only = a.out.space == SP_ARENA;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < a.nin && a.in_mode[i] == 1 && a.in[i].space != SP_ARENA) arena_only = false;
+    for (int e0 = tid; e0 < total; e0 += 4 * nthreads) {
+      float v[3][4], r[4];
+      if (arena_only) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            v[i][u] = (i < a.nin && a.in_mode[i] == 1) ? m.arena[a.in[i].offset + min(e0 + u * nthreads, total - 1)] : sc[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            v[i][u] = (i < a.nin && a.in_mode[i] == 1) ? ld(m, a.in[i].space, a.in[i].offset + min(e0 + u * nthreads, total - 1)) : sc[i];
+      }
+      ew_apply<4>(a.fn, v[0], v[1], v[2], a.p0, a.p1, r);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * nthreads;
+        if (e < total) {
+          if (arena_only) m.arena[a.out.offset + e] = r[u];
+          else st(m, a.out.space, a.out.offset + e, r[u]);
+        }
+      }
     }
     return;
   }
@@ -156,7 +198,10 @@ template <bool F> __device__ __forceinline__ void run_ew(const EwArgs& a, const 
     float y = 0.f, z = 0.f;
     if (a.nin > 1) y = ld(m, a.in[1].space, view_index(a.in[1], i0, i1, i2, i3));
     if (a.nin > 2) z = ld(m, a.in[2].space, view_index(a.in[2], i0, i1, i2, i3));
-    st(m, a.out.space, view_index(a.out, i0, i1, i2, i3), ew_apply(a.fn, x, y, z, a.p0, a.p1));
+    const float xs[1] = {x}, ys[1] = {y}, zs[1] = {z};
+    float r[1];
+    ew_apply<1>(a.fn, xs, ys, zs, a.p0, a.p1, r);
+    st(m, a.out.space, view_index(a.out, i0, i1, i2, i3), r[0]);
   }
 }
 
@@ -181,20 +226,32 @@ template <bool F> __device__ __forceinline__ void run_conv(const ConvArgs& a, co
       // so a lane fetches four taps of its channel in one 16-byte load and a wavefront 1 KiB contiguous
       if (a.vec4 && in_space == SP_ARENA) {
         // padding 0, dilation 1, unit input stride, taps a multiple of 4 and every row start 16-byte aligned (checked at create)
+        // the weight vectors run kConvPF tap-quads ahead of the arithmetic in a register ring: an L2 round trip (~600 cycles) is
+        // covered by kConvPF x (5 broadcast ds_read_b128 + 20 FMA) instead of sitting on every step
         for (int ci = 0; ci < cg; ++ci) {
           const auto xr = m.arena + a.in.offset + (int64_t)ci * sc;
           const float* wr = wt + ((int64_t)(ci * a.k / 4) * a.cout + co) * 4;
-#pragma unroll 2
-          for (int kk = 0; kk < a.k; kk += 4) {
-            const f32x4_t wv = *reinterpret_cast<const f32x4_t*>(wr + (int64_t)kk * a.cout);
+          const int nq = a.k >> 2;
+          f32x4_t ring[kConvPF];
 #pragma unroll
-            for (int j = 0; j < kConvTB; ++j) {
-              const int to = min(to0 + j, a.tout - 1);
-              const f32x4_t xv = ld4(xr + to * a.stride + kk);
-              acc[j] = fmaf(wv.x, xv.x, acc[j]);
-              acc[j] = fmaf(wv.y, xv.y, acc[j]);
-              acc[j] = fmaf(wv.z, xv.z, acc[j]);
-              acc[j] = fmaf(wv.w, xv.w, acc[j]);
+          for (int u = 0; u < kConvPF; ++u) ring[u] = u < nq ? *reinterpret_cast<const f32x4_t*>(wr + (int64_t)(4 * u) * a.cout) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+          for (int q0 = 0; q0 < nq; q0 += kConvPF) {
+#pragma unroll
+            for (int u = 0; u < kConvPF; ++u) {
+              const int qi = q0 + u;
+              const f32x4_t wv = ring[u];
+              if (qi + kConvPF < nq) ring[u] = *reinterpret_cast<const f32x4_t*>(wr + (int64_t)(4 * (qi + kConvPF)) * a.cout);
+              if (qi < nq) {
+#pragma unroll
+                for (int j = 0; j < kConvTB; ++j) {
+                  const int to = min(to0 + j, a.tout - 1);
+                  const f32x4_t xv = ld4(xr + to * a.stride + 4 * qi);
+                  acc[j] = fmaf(wv.x, xv.x, acc[j]);
+                  acc[j] = fmaf(wv.y, xv.y, acc[j]);
+                  acc[j] = fmaf(wv.z, xv.z, acc[j]);
+                  acc[j] = fmaf(wv.w, xv.w, acc[j]);
+                }
+              }
             }
           }
         }
@@ -219,11 +276,75 @@ template <bool F> __device__ __forceinline__ void run_conv(const ConvArgs& a, co
         if (to0 + j < a.tout) st(m, out_space, (int64_t)a.out.offset + (int64_t)co * a.out.stride[2] + (int64_t)(to0 + j) * a.out.stride[3], acc[j] + b);
     }
   }
+  // the other channels: one output element per thread, lanes along the output positions (conflict-free input rows).  Fused
+  // executor with a scratch: the weights and the bias are first staged in LDS by one coalesced sweep of the whole workgroup
+  // (rows at an odd stride: the few channels a wavefront spans sit in different banks), so the accumulation chains read LDS
+  // only; otherwise they come through L2.
+  const int row = cg * a.k;
   const int rest = (a.cout - a.cout_full) * a.tout;
+  if constexpr (F) {
+    if (a.ws_space == SP_ARENA) {
+      const auto ws = m.arena + a.ws_off;
+      const float* __restrict__ src = m.consts + a.w_off;
+      const int nw = a.cout * row;
+      for (int i = tid; i < nw; i += nthreads) {
+        const int co = i / row;
+        ws[co * a.ws_stride + (i - co * row)] = src[i];
+      }
+      const auto wb = ws + a.cout * a.ws_stride;
+      for (int i = tid; i < a.cout; i += nthreads) wb[i] = a.b_off >= 0 ? m.consts[a.b_off + i] : 0.f;
+      __syncthreads();
+      const auto xin = m.arena + a.in.offset;        // scratch implies an arena input only when in_space says so: checked below
+      for (int e = tid; e < rest; e += nthreads) {
+        const int co = a.cout_full + e / a.tout, to = e % a.tout;
+        const int g = co / og;
+        const auto wr = ws + co * a.ws_stride;
+        const int t0 = to * a.stride - a.padding;
+        float acc = wb[co];
+        if (in_space == SP_ARENA) {
+          if (a.k == 1) {
+            const bool ok = t0 >= 0 && t0 < a.t;
+            const auto xp = xin + (int64_t)(g * cg) * sc + (int64_t)(ok ? t0 : 0) * st_;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int ci = 0;
+            for (; ci + 4 <= cg; ci += 4) {
+              a0 = fmaf(wr[ci], xp[(int64_t)ci * sc], a0);
+              a1 = fmaf(wr[ci + 1], xp[(int64_t)(ci + 1) * sc], a1);
+              a2 = fmaf(wr[ci + 2], xp[(int64_t)(ci + 2) * sc], a2);
+              a3 = fmaf(wr[ci + 3], xp[(int64_t)(ci + 3) * sc], a3);
+            }
+            for (; ci < cg; ++ci) a0 = fmaf(wr[ci], xp[(int64_t)ci * sc], a0);
+            acc += ok ? (a0 + a1) + (a2 + a3) : 0.f;
+          } else {
+            for (int ci = 0; ci < cg; ++ci) {
+              const auto xr = xin + (int64_t)(g * cg + ci) * sc;
+#pragma unroll 4
+              for (int kk = 0; kk < a.k; ++kk) {
+                const int ti = t0 + kk * a.dilation;
+                const bool ok = ti >= 0 && ti < a.t;
+                const float xv = xr[(int64_t)(ok ? ti : 0) * st_];
+                acc = fmaf(wr[ci * a.k + kk], ok ? xv : 0.f, acc);
+              }
+            }
+          }
+        } else {
+          for (int ci = 0; ci < cg; ++ci) {
+            const int64_t xrow = (int64_t)a.in.offset + (int64_t)(g * cg + ci) * sc;
+            for (int kk = 0; kk < a.k; ++kk) {
+              const int ti = t0 + kk * a.dilation;
+              if (ti >= 0 && ti < a.t) acc = fmaf(wr[ci * a.k + kk], ld(m, in_space, xrow + (int64_t)ti * st_), acc);
+            }
+          }
+        }
+        st(m, out_space, (int64_t)a.out.offset + (int64_t)co * a.out.stride[2] + (int64_t)to * a.out.stride[3], acc);
+      }
+      return;
+    }
+  }
   for (int e = tid; e < rest; e += nthreads) {
     const int co = a.cout_full + e / a.tout, to = e % a.tout;
     const int g = co / og;
-    const float* wt = m.consts + a.w_off + (int64_t)co * cg * a.k;
+    const float* wt = m.consts + a.w_off + (int64_t)co * row;
     float acc = 0.f;
     const int t0 = to * a.stride - a.padding;
     for (int ci = 0; ci < cg; ++ci) {
@@ -324,12 +445,13 @@ struct StageArgs {
   int in_space, in_off, window;
   float* probs;
   int out_space, out_off;
+  long long* clocks;       // diagnostic (WJ_VADG_CLOCKS=1): s_memtime after every instruction of workgroups 0 and grid / 2
 };
 
 // FUSED: grid.x = window, the arena in dynamic LDS, instructions [first, first + count) with a barrier between them.
 // !FUSED: grid = (blocks, window), ONE instruction (count == 1) or the gather / scatter alone (count == 0) over an HBM arena.
 template <bool FUSED>
-__global__ __launch_bounds__(256) void vadg_stage_kernel(StageArgs s) {
+__global__ __launch_bounds__(kStageThreads) void vadg_stage_kernel(StageArgs s) {
   extern __shared__ __align__(16) float lds_arena[];
   const int w = FUSED ? blockIdx.x : blockIdx.y;
   Mem<FUSED> m;
@@ -345,9 +467,18 @@ __global__ __launch_bounds__(256) void vadg_stage_kernel(StageArgs s) {
     for (int i = tid; i < s.window; i += nthreads) st(m, s.in_space, s.in_off + i, i < n ? s.pcm[src + i] : 0.f);
     if (FUSED) __syncthreads();
   }
+  const bool stamp = FUSED && s.clocks && tid == 0 && (w == 0 || w == (int)(gridDim.x / 2));
+  long long* ck = s.clocks + (w == 0 ? 0 : 256);
+  if (stamp) ck[0] = clock64();
   for (int i = 0; i < s.count; ++i) {
-    run_instr(s.prog[s.first + i], m, tid, nthreads);
+    // the instruction's arguments through the constant address space: wavefront-uniform, so they arrive as s_load into SGPRs
+    union { Instr in; int32_t w[sizeof(Instr) / 4]; } u;
+    const __attribute__((address_space(4))) int32_t* src = (const __attribute__((address_space(4))) int32_t*)(s.prog + s.first + i);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(Instr) / 4); ++k) u.w[k] = src[k];
+    run_instr(u.in, m, tid, nthreads);
     if (FUSED) __syncthreads();
+    if (stamp && i < 254) ck[1 + i] = clock64();
   }
   if (s.probs && tid == 0) s.probs[w] = ld(m, s.out_space, s.out_off);
 }
@@ -614,6 +745,7 @@ int parse_program(wj_vadg* h, const int32_t* words, int n_words, int n_instr) {
     const int32_t* a = words + pos + 2;
     const int na = n - 2;
     Instr in;
+    memset(&in, 0, sizeof(in));
     in.op = op;
     if (op == OP_EW) {
       WJ_REQUIRE(na == 4 + 4 * kViewWords, "wj_vadg_create: instruction %d: element-wise payload of %d words", idx, na);
@@ -631,11 +763,12 @@ int parse_program(wj_vadg* h, const int32_t* words, int n_words, int n_instr) {
       }
       in.items = out_numel(in.ew.out);
     } else if (op == OP_CONV1D) {
-      WJ_REQUIRE(na == 2 * kViewWords + 11, "wj_vadg_create: instruction %d: conv1d payload of %d words", idx, na);
+      WJ_REQUIRE(na == 2 * kViewWords + 14, "wj_vadg_create: instruction %d: conv1d payload of %d words", idx, na);
       read_view(a, &in.conv.out); read_view(a + kViewWords, &in.conv.in);
       const int32_t* p = a + 2 * kViewWords;
       in.conv.w_off = p[0]; in.conv.b_off = p[1]; in.conv.cout = p[2]; in.conv.cin = p[3]; in.conv.k = p[4]; in.conv.t = p[5]; in.conv.tout = p[6];
       in.conv.stride = p[7]; in.conv.padding = p[8]; in.conv.dilation = p[9]; in.conv.groups = p[10];
+      in.conv.ws_space = p[11]; in.conv.ws_off = p[12]; in.conv.ws_stride = p[13];
       WJ_TRYV(check_view(h, in.conv.out, true, "the result", idx));
       WJ_TRYV(check_view(h, in.conv.in, false, "the input", idx));
       ConvArgs& c = in.conv;
@@ -645,9 +778,14 @@ int parse_program(wj_vadg* h, const int32_t* words, int n_words, int n_instr) {
                  c.tout == (c.t + 2 * c.padding - c.dilation * (c.k - 1) - 1) / c.stride + 1, "wj_vadg_create: instruction %d: inconsistent conv1d geometry", idx);
       WJ_REQUIRE(c.w_off >= 0 && (int64_t)c.w_off + (int64_t)c.cout * (c.cin / c.groups) * c.k <= h->n_consts && c.b_off >= -1 && (int64_t)c.b_off + c.cout <= h->n_consts,
                  "wj_vadg_create: instruction %d: conv1d weights outside the constants", idx);
+      if (c.ws_space != -1) {
+        const int64_t row = (int64_t)(c.cin / c.groups) * c.k;
+        WJ_REQUIRE(c.ws_space == SP_ARENA && c.ws_stride >= row, "wj_vadg_create: instruction %d: conv1d scratch in space %d with row stride %d", idx, c.ws_space, c.ws_stride);
+        WJ_TRYV(check_range(h, c.ws_space, c.ws_off, (int64_t)c.cout * c.ws_stride + c.cout, true, "the weight scratch", idx));
+      }
       // wide strided convolutions (the conv-STFT): lanes on the output channels over a tap-major copy of the weights
       c.cout_full = 0; c.wt_off = -1; c.vec4 = 0;
-      if (c.groups == 1 && c.cout >= 64 && (int64_t)c.cin * c.k >= 32 && c.stride > 1) {
+      if (c.ws_space == -1 && c.groups == 1 && c.cout >= 64 && (int64_t)c.cin * c.k >= 32 && c.stride > 1) {
         c.cout_full = c.cout / 64 * 64;
         const int64_t rows = (int64_t)c.cin * c.k, rows4 = (rows + 3) / 4;
         c.wt_off = (int32_t)h->consts_host.size();
@@ -809,13 +947,13 @@ int wj_vadg_create(wj_ctx* ctx, const int32_t* words, int n_words, int n_instr, 
         cur.count = i - cur.first;
         int items = 64;
         for (int k = cur.first; k < i; ++k) items = std::max(items, h->prog[k].items);
-        cur.threads = std::min(256, (items + 63) / 64 * 64);
+        cur.threads = std::min(kStageThreads, (items + 63) / 64 * 64);
         h->stages.push_back(cur);
         if (i < (int)h->prog.size()) h->lstm_at.push_back(i);
         cur.first = i + 1;
       }
     }
-    h->stages.front().threads = std::max(h->stages.front().threads, std::min(256, (window + 63) / 64 * 64));
+    h->stages.front().threads = std::max(h->stages.front().threads, std::min(kStageThreads, (window + 63) / 64 * 64));
     // windows per launch group: the fall-back's grid.y and 4 GiB of HBM arenas; 2 GiB of exchange areas either way
     int64_t cap = std::min<int64_t>(max_windows, ((int64_t)2 << 30) / (int64_t)(sizeof(float) * xchg_floats));
     if (!h->fused) cap = std::min<int64_t>(std::min<int64_t>(cap, 65535), ((int64_t)4 << 30) / (int64_t)(sizeof(float) * arena_floats));
@@ -932,8 +1070,23 @@ int wj_vadg_scores(wj_vadg* h, const float* pcm_dev, const int64_t* offsets_host
           a.first = stg.first; a.count = stg.count;
           if (is_first) { a.pcm = pcm_dev; a.src = d_src; a.valid = d_valid; }
           if (is_last) a.probs = probs_dev + prob_offsets_host[0] + g0;
+          static const bool want_clocks = getenv("WJ_VADG_CLOCKS") != nullptr;
+          long long* d_ck = nullptr;
+          if (want_clocks && hipMalloc(&d_ck, sizeof(long long) * 512) == hipSuccess) (void)hipMemsetAsync(d_ck, 0, sizeof(long long) * 512, s);
+          a.clocks = d_ck;
           hipLaunchKernelGGL(vadg_stage_kernel<true>, dim3((unsigned)n_win), dim3((unsigned)stg.threads), sizeof(float) * (size_t)h->arena_floats, s, a);
           WJ_LAUNCH_CHECK();
+          if (d_ck) {       // per-instruction cycles of two workgroups, on stderr
+            std::vector<long long> ck(512);
+            WJ_HIP(hipStreamSynchronize(s));
+            WJ_HIP(hipMemcpy(ck.data(), d_ck, sizeof(long long) * 512, hipMemcpyDeviceToHost));
+            (void)hipFree(d_ck);
+            for (int b = 0; b < 2; ++b) {
+              fprintf(stderr, "[vadg clocks] stage %zu (%d windows, %d threads) workgroup %s:", si, n_win, stg.threads, b ? "mid" : "0");
+              for (int i = 0; i < std::min(stg.count, 254); ++i) fprintf(stderr, " %d:%lld", stg.first + i, ck[256 * b + 1 + i] - ck[256 * b + i]);
+              fprintf(stderr, " total %lld\n", ck[256 * b + std::min(stg.count, 254)] - ck[256 * b]);
+            }
+          }
         }
       } else {
         if (is_first) {

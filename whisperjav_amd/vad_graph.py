@@ -62,6 +62,7 @@ EW = {"copy": 0, "add": 1, "sub": 2, "mul": 3, "div": 4, "relu": 5, "sigmoid": 6
       "abs": 11, "neg": 12, "pow_scalar": 13, "add_scalar": 14, "mul_scalar": 15, "fma": 16, "clamp": 17, "leaky_relu": 18,
       "log": 19, "rsub_scalar": 20, "silu": 21, "hardtanh": 22}
 SPACE_ARENA, SPACE_CONST, SPACE_STATE, SPACE_XCHG = 0, 1, 2, 3
+CONV_SCRATCH_MAX = 8192          # floats: conv1d kernels up to this size are staged in the arena by the fused executor
 VIEW_WORDS = 2 + 2 * MAX_DIMS
 
 
@@ -319,10 +320,16 @@ class _Lowerer:
         out = self.alloc((1, cout, tout))
         wc = self.const(w)
         bc = self.const(b) if b is not None else None
+        # small kernels get a scratch tensor that lives for this instruction only: the fused executor stages the weights (rows padded
+        # to an odd stride: conflict-free LDS banks) and the bias there with one coalesced sweep instead of chasing them through L2
+        # from inside every accumulation chain
+        row = cin_g * k
+        ws_stride = row | 1
+        ws = self.alloc((cout * ws_stride + cout,)) if cout * ws_stride + cout <= CONV_SCRATCH_MAX else None
         words = [self._view(out), self._view(x), wc.offset, bc.offset if bc is not None else -1, cout, cin, k, t, tout, stride, padding,
-                 dilation, groups]
+                 dilation, groups, *([_O(ws), ws_stride] if ws is not None else [-1, -1, 0])]
         self.emit("conv1d", words, f"conv1d {x.shape} * {tuple(w.shape)} s{stride} p{padding} d{dilation} g{groups} -> {out.shape}",
-                  (x.shape, tuple(w.shape), b is not None, stride, padding, dilation, groups), [x], [out])
+                  (x.shape, tuple(w.shape), b is not None, stride, padding, dilation, groups), [x], [out] + ([ws] if ws is not None else []))
         return out
 
     def pad_last(self, x: Any, left: int, right: int, mode: str, value: float) -> Sym:
