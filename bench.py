@@ -235,6 +235,65 @@ def cpu_baseline_cfg3(dims, w, clips, n_groups, audio_s, max_new, beam, threads,
 # ---------------------------------------------------------------------------------------------------------------
 # the cfg3 stack: scene detector + VAD segmenter + model + ASR adapter + recording runner (the seam's own classes)
 # ---------------------------------------------------------------------------------------------------------------
+PRESETS = {
+    # the reference's runtime-effective configuration of --mode balanced: the default segmenter
+    # (silero-v3.1: main.py:1863-1876, a TorchScript hub archive on 1536-sample windows -- here lowered onto the device), the balanced
+    # VAD preset (config/components/vad/silero.py:105-114), word_timestamps=True and max_new_tokens=None
+    # (config/components/asr/faster_whisper.py:298,309), the scene detector at its own default gates (32 / 38 dB,
+    # config/components/features/scene_detection.py:74-100) on a recording whose floor lets them open and close
+    "reference": dict(segmenter="silero-v3.1", vad_threshold=0.28, word_timestamps=True, max_new_tokens=None, scene_gates=None,
+                      noisy=False, floor_db=-66.0, batch=512),
+    # rounds 2-5's headline: the v6-class HIP scorer (seeded random parameters), no alignment pass, a 64-token budget (KV cache for
+    # 72 positions -> 768 windows per engine call), gates lifted above the noisy recording's floor
+    "tuned": dict(segmenter="silero-v6.2", vad_threshold=0.28, word_timestamps=False, max_new_tokens=64, scene_gates=(52, 56),
+                  noisy=True, floor_db=-45.0, batch=768),
+}
+
+
+def args_cli(args, preset):
+    """A copy of the parsed arguments as if ``--preset <preset>`` had been given with no per-setting override."""
+    import copy
+    a = copy.copy(args)
+    a.preset, a.segmenter, a.vad_threshold, a.word_timestamps, a.max_new_tokens, a.scene_gates, a.audio, a.batch = preset, None, None, None, None, None, None, None
+    return a
+
+
+def apply_preset(args):
+    """Resolve --preset into the individual settings; a flag given on the command line wins over the preset."""
+    p = PRESETS[args.preset]
+    args.segmenter = args.segmenter or p["segmenter"]
+    args.vad_threshold = p["vad_threshold"] if args.vad_threshold is None else args.vad_threshold
+    args.word_timestamps = p["word_timestamps"] if args.word_timestamps is None else bool(args.word_timestamps)
+    args.max_new_tokens = p["max_new_tokens"] if args.max_new_tokens is None else (None if args.max_new_tokens <= 0 else args.max_new_tokens)
+    args.scene_gates = p["scene_gates"] if args.scene_gates is None else (None if args.scene_gates == "reference" else tuple(int(x) for x in args.scene_gates.split("/")))
+    args.noisy, args.floor_db = p["noisy"], p["floor_db"]
+    if args.audio:
+        args.noisy, args.floor_db = (True, -45.0) if args.audio == "noisy" else (False, -66.0)
+    args.batch = p["batch"] if args.batch is None else args.batch
+    return args
+
+
+def new_token_budget(args):
+    """Tokens a window may emit: max_new_tokens, or what faster-whisper allows when it is None (max_length 448 minus the prompt:
+    the engine's KV cache is sized for n_text_ctx // 2 = 224 new tokens, the longest a 30 s window can be asked for)."""
+    return 224 if args.max_new_tokens is None else int(args.max_new_tokens)
+
+
+def default_segmenter(args, info, vad):
+    """The segmenter of the preset.  silero-v3.1: HipSileroSpeechSegmenter over (model, utils) as torch.hub.load returns them -- the
+    archive's network lowered onto the device, regions from the archive's own get_speech_timestamps (certified route).  The real
+    hub archive is not obtainable offline; whisperjav_amd/standin_vad.py builds one of the same structure with seeded weights
+    (measurement input, like the synthetic Whisper weights)."""
+    from whisperjav_amd import segmenters
+    if args.segmenter == "silero-v3.1":
+        from whisperjav_amd import standin_vad
+        archive = standin_vad.build("v4", seed=7)
+        utils = (standin_vad.get_speech_timestamps, None, None, None, None)
+        return segmenters.HipSileroSpeechSegmenter(version="v3.1", scorer=(archive, utils), device=info.local_rank, **vad), archive
+    # the Silero v5/v6 network's trained parameters are not available offline: seeded random ones, asked for explicitly
+    return segmenters.HipSileroV6SpeechSegmenter(weights="synthetic", device=info.local_rank, **vad), None
+
+
 def transcribe_kwargs(args, words, mode="balanced"):
     if mode == "fidelity":
         # the reference's fidelity defaults (config/components/asr/openai_whisper.py:229-255, "balanced" sensitivity):
@@ -242,47 +301,50 @@ def transcribe_kwargs(args, words, mode="balanced"):
         return dict(task="transcribe", language="ja", beam_size=2, best_of=2, patience=1.2, length_penalty=None, temperature=[0.0],
                     suppress_blank=True, without_timestamps=False, max_initial_timestamp=0.0, compression_ratio_threshold=2.4,
                     logprob_threshold=-1.0, no_speech_threshold=None, condition_on_previous_text=False, fp16=True, verbose=None,
-                    sample_len=args.max_new_tokens, word_timestamps=bool(words))
+                    sample_len=new_token_budget(args), word_timestamps=bool(words))
     return dict(task="transcribe", language="ja", beam_size=args.beam, best_of=2, patience=1.2, temperature=[0.0],
                 repetition_penalty=1.5, no_repeat_ngram_size=3, condition_on_previous_text=False, suppress_blank=True,
                 max_initial_timestamp=0.0, no_speech_threshold=None, logprob_threshold=-1.0,
                 max_new_tokens=args.max_new_tokens, word_timestamps=bool(words))
 
 
-def build_stack(args, info, dims, dtype, batch, blob=None, offsets=None, weights=None, words=False, mode="balanced"):
+def build_stack(args, info, dims, dtype, batch, blob=None, offsets=None, weights=None, words=None, mode="balanced"):
     """The seam's own classes: balanced = HipWhisperModel (faster-whisper contract, CTranslate2 search) under
     asr.HipFasterWhisperProASR; fidelity = HipOpenAIWhisperModel (openai-whisper mel padding and search) under
     asr.HipWhisperProASR (post-model log-prob gate on), as FidelityPipeline wires them."""
     from whisperjav_amd import asr, pipeline, scenes, segmenters
     from whisperjav_amd.whisper_model import HipOpenAIWhisperModel, HipWhisperModel
-    kw = transcribe_kwargs(args, words, mode)
+    kw = transcribe_kwargs(args, args.word_timestamps if words is None else words, mode)
     beam = int(kw["beam_size"])
     # KV cache sized for what this run decodes (sot sequence + max_new_tokens; no conditioning on previous text), the
     # encoder in slices of --enc-batch windows: HBM goes to resident cross K/V, i.e. to windows per engine call
     cls = HipOpenAIWhisperModel if mode == "fidelity" else HipWhisperModel
     model = cls(args.model, compute_type=dtype, weights=weights, dims=dims, blob=blob, offsets=offsets,
                 max_batch=batch, max_beam=beam, device_index=info.local_rank,
-                kv_len=(4 + args.max_new_tokens + 4) if args.kv_fit else None, enc_batch=min(batch, args.enc_batch))
+                kv_len=(4 + new_token_budget(args) + 4) if args.kv_fit else None, enc_batch=min(batch, args.enc_batch))
     model.overlap_encode = bool(args.overlap) or int(args.encoder_cus) > 0
     model.encoder_cus = int(args.encoder_cus)
+    model.word_reseek = bool(args.word_reseek)
     # BASELINE.md section 3: the balanced preset's Silero parameters (config/components/vad/silero.py:105-114)
     vad = dict(threshold=args.vad_threshold, min_speech_duration_ms=100, min_silence_duration_ms=300, speech_pad_ms=400,
                chunk_threshold_s=2.5, max_group_duration_s=6.0)
+    backend = f"{args.segmenter}-hip"
     if mode == "fidelity":
-        params = {"decoder": kw, "provider": {}, "vad": vad, "speech_segmenter": {"backend": "silero-v6.2-hip"}}
+        params = {"decoder": kw, "provider": {}, "vad": vad, "speech_segmenter": {"backend": backend}}
     else:
         params = {"decoder": {k: v for k, v in kw.items() if k not in ("repetition_penalty", "no_repeat_ngram_size", "max_new_tokens")},
                   "provider": {"repetition_penalty": kw["repetition_penalty"], "no_repeat_ngram_size": kw["no_repeat_ngram_size"],
                                "max_new_tokens": kw["max_new_tokens"]},
-                  "vad": vad, "speech_segmenter": {"backend": "silero-v6.2-hip"}}
-    # the Silero network's trained parameters are not available offline: seeded random ones, asked for explicitly
-    seg = segmenters.HipSileroV6SpeechSegmenter(weights="synthetic", device=info.local_rank, **vad)
+                  "vad": vad, "speech_segmenter": {"backend": backend}}
+    seg, archive = default_segmenter(args, info, vad)
     acls = asr.HipWhisperProASR if mode == "fidelity" else asr.HipFasterWhisperProASR
     module = acls({"model_name": args.model, "device": "cuda", "compute_type": dtype}, params, "transcribe",
                   whisper_model=model, segmenter=seg)
-    # gates above the synthetic clip's noise floor (the reference's 32 / 38 dB defaults sit below it and would only ever
-    # cut at max_duration)
-    det = scenes.HipAuditokSceneDetector(pass1_energy_threshold=52, pass2_energy_threshold=56, device=info.local_rank)
+    module._bench_archive = archive
+    if args.scene_gates is None:           # the reference's own defaults (32 / 38 dB)
+        det = scenes.HipAuditokSceneDetector(device=info.local_rank)
+    else:                                  # gates above a noisy recording's floor (the defaults sit below it and would only ever cut at max_duration)
+        det = scenes.HipAuditokSceneDetector(pass1_energy_threshold=args.scene_gates[0], pass2_energy_threshold=args.scene_gates[1], device=info.local_rank)
     return model, module, pipeline.RecordingTranscriber(module, det)
 
 
@@ -393,7 +455,7 @@ def make_weights(args, dims):
     if args.weights == "plain":
         return pweights.synth_weights(dims, seed=1234, exact="float16")
     kw = dict(pweights.SPEECHLIKE)
-    kw["eot"] = pweights.EotRamp(mid=4.0, rate=args.eot_rate)
+    kw["eot"] = pweights.EotRamp(mid=4.0, rate=args.eot_rate, cap=args.eot_cap)
     w = pweights.synth_weights(dims, seed=1234, exact="float16", **kw)
     if args.mode == "fidelity":         # the fidelity pipeline gates on avg_logprob > -1.0: the same model at temperature 1 / 2.5
         w.update(pweights.sharpened_logits(dims, w, 1234, kw["eot"], 1.8, args.fidelity_sharpen))
@@ -406,7 +468,7 @@ def make_audio(args):
     rank = int(os.environ.get("RANK", "0"))
     seed = 1234 if args.strong else 1234 + 100003 * rank
     t0 = time.perf_counter()
-    audio = synth.speech_like_long(60.0 * args.minutes, seed=seed, noisy=True)
+    audio = synth.speech_like_long(60.0 * args.minutes, seed=seed, noisy=args.noisy, floor_db=args.floor_db)
     return audio, time.perf_counter() - t0
 
 
@@ -463,17 +525,26 @@ def run_cfg3(args, info, dims):
                 "n_gpus": info.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
                 "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
                 "dtype": DT_LABEL[dtype], "data": "synthetic",
-                "config": {"workload": (f"{'cfg4' if args.mode == 'fidelity' else 'cfg3'}-{minutes:g}min: mode={args.mode} end to end on {minutes:g} min of noisy synthetic 16 kHz audio per "
-                                        f"{'job' if args.strong else 'GPU'}: two-pass energy-gate scenes <= 29 s (device frame energies), "
-                                        f"Silero-class HIP VAD (threshold {args.vad_threshold}, seeded random parameters), groups <= 6 s, "
+                "config": {"workload": (f"{'cfg4' if args.mode == 'fidelity' else 'cfg3'}-{minutes:g}min, preset {args.preset}: mode={args.mode} end to end on {minutes:g} min of "
+                                        + ("noisy synthetic 16 kHz audio (pink floor -45 dBFS + hum, 10 dB SNR)" if args.noisy else "synthetic 16 kHz speech over a studio floor (pink, -66 dBFS)")
+                                        + f" per {'job' if args.strong else 'GPU'}: two-pass energy-gate scenes <= 29 s (device frame energies) at "
+                                        + ("the reference's default gates 32 / 38 dB" if args.scene_gates is None else f"gates {args.scene_gates[0]} / {args.scene_gates[1]} dB")
+                                        + ", segmenter " + ("HipSileroSpeechSegmenter(version='v3.1') = the reference's default contract: a TorchScript archive of the silero v3.1 / v4.0 "
+                                                           "structure (seeded weights; the hub archive is not obtainable offline) lowered onto the device, 1536-sample windows, regions "
+                                                           "from the archive's own get_speech_timestamps (certified route)" if args.segmenter == "silero-v3.1"
+                                                           else "Silero-v6-class HIP scorer (seeded random parameters)")
+                                        + f" at the balanced preset (threshold {args.vad_threshold}, 100 / 300 / 400 ms), groups <= 6 s, "
                                         f"Whisper {args.model} geometry (seeded random fp16-representable weights), "
                                         + (f"beam {args.beam} / patience 1.2 / repetition penalty 1.5 / no-repeat-3-gram (CTranslate2's search)" if args.mode == "balanced"
                                            else "openai-whisper log-mel padding and search (beam 2 / patience 1.2 / best_of 2, sum / length ranking), post-model gate on")
                                         + f", max_new_tokens={args.max_new_tokens} ("
                                         + ("EOT-bearing synthetic weights: every search ends on its own, see workload_facts" if args.weights == "speechlike"
                                            else "plain random weights never emit EOT: every window decodes exactly this many tokens")
-                                        + "), word_timestamps=False, "
+                                        + f"), word_timestamps={bool(args.word_timestamps)}, "
                                         f"through pipeline.RecordingTranscriber over asr.{'HipWhisperProASR' if args.mode == 'fidelity' else 'HipFasterWhisperProASR'} (the drop-in seam's classes)"),
+                           "preset": args.preset, "segmenter": args.segmenter, "word_timestamps": bool(args.word_timestamps), "word_reseek": bool(args.word_reseek),
+                           "eot_cap": args.eot_cap,
+                           "scene_gate_db": [32, 38] if args.scene_gates is None else list(args.scene_gates),
                            "mode": args.mode,
                            "windows_per_batch": args.batch, "compute_type": dtype, "max_new_tokens": args.max_new_tokens,
                            "tune": args.tune, "scene_loop": "pooled" if pooled else "one engine call per scene (the reference's call pattern)",
@@ -485,12 +556,23 @@ def run_cfg3(args, info, dims):
                     "whisper_weights": ("synthetic, seeded, fp16-representable; weights.SPEECHLIKE with EotRamp(mid=4, rate=%g): hypotheses end, "
                                         "later for windows holding more audio" % args.eot_rate) if args.weights == "speechlike"
                                        else "synthetic, seeded, fp16-representable, plain (no EOT ever)",
-                    "vad_weights": "synthetic (seeded random Silero-v5/v6-shaped parameters; trained ones are not available offline)",
-                    "vad_threshold": args.vad_threshold, "scene_gate_db": {"pass1": 52, "pass2": 56, "reference_defaults": [32, 38]},
+                    "vad_weights": ("synthetic: a TorchScript archive of the silero v3.1 / v4.0 structure with seeded weights whose probabilities follow the window's "
+                                    "spectral energy (whisperjav_amd/standin_vad.py); the hub archive is not obtainable offline") if args.segmenter == "silero-v3.1"
+                                   else "synthetic (seeded random Silero-v5/v6-shaped parameters; trained ones are not available offline)",
+                    "vad_threshold": args.vad_threshold,
+                    "scene_gate_db": {"pass1": 32 if args.scene_gates is None else args.scene_gates[0], "pass2": 38 if args.scene_gates is None else args.scene_gates[1],
+                                      "reference_defaults": [32, 38]},
+                    "groups_expected_by_survey_8d": "1200-1900 per 120 min",
+                    "word_reseek": ("off: the alignment pass and the DTW of every window run, the word-driven re-seek of faster-whisper (seek = last word's end when the tokens do "
+                                    "not end in a timestamp) is not taken -- a trained model ends its windows in a timestamp, the synthetic one anywhere, and with the re-seek on "
+                                    "1454 groups became 2775 windows (profiles/r06_bench_reference_first.json: 22.0 s per step)") if not args.word_reseek else "on",
                     "max_new_tokens": args.max_new_tokens, "beam": args.beam, "patience": 1.2,
                     "decode_last_step": (stats or {}).get("decode"), "scenes": (stats or {}).get("scenes"),
                     "vad_segments": (stats or {}).get("vad_segments"),
                     # what "float16" means for parity: where the 1e-3 bar was verified, and where it is not met
+                    "parity": ("partial: the HIP path equals the oracle (float32 exact; float16 within 1e-3 at the large-v3 geometry) and the reference's own Python run from "
+                               "source for every integer post-op; the oracle itself is pinned to transformers / torch.jit, NOT to outputs of faster-whisper / CTranslate2 / "
+                               "openai-whisper / silero / auditok (wheels absent offline; PARITY.md, scripts/make_upstream_fixtures.py)"),
                     "parity_of_compute_type": ("float16: per-token log-probs within 1e-3 of the fp32 oracle verified at the large-v3 geometry on "
                                                "fp16-representable weights only (greedy 8.8e-4, cfg3 beam winner 7.3e-4 incl. EOT, winners identical: "
                                                "tests/test_gpu_search_eot.py golden_large_v3_r3); toy geometries sit at 3-8e-3 (PARITY.md); "
@@ -503,6 +585,31 @@ def run_cfg3(args, info, dims):
                                         "(init_s + first pass): one cold %g-min file end to end, against `value` = the steady state of a resident engine" % minutes)},
                 "roofline": None, "cpu_baseline": None, "stages": {}}
 
+    if info.rank == 0 and info.world == 1 and args.sweep:
+        # A/B of wj_tune switches inside ONE process (same weights, same recording, same engine): "k=v,k2=v2;k=v3;..." -- one
+        # untimed + one timed step per setting, the library defaults restored afterwards
+        from whisperjav_amd import hipbind
+        line["sweep"] = [{"tune": "(as run)", "ms": line["ms_per_step"], "crc": (stats or {}).get("transcript_crc32")}]
+        for combo in [c for c in args.sweep.split(";") if c.strip()]:
+            pairs = [kv.split("=") for kv in combo.split(",")]
+            saved = {k: hipbind.tuned(k, None) if k in hipbind._TUNED else None for k, _ in pairs}
+            for k, v in pairs:
+                hipbind.tune(k.strip(), int(v))
+            try:
+                run_recording(runner, audio, subset, pooled)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sw = run_recording(runner, audio, subset, pooled)
+                torch.cuda.synchronize()
+                line["sweep"].append({"tune": combo, "ms": round(1e3 * (time.perf_counter() - t1), 1), "crc": sw.get("transcript_crc32"),
+                                      "decode_steps": (sw.get("decode") or {}).get("decode_steps_run")})
+            except Exception as e:
+                line["sweep"].append({"tune": combo, "error": f"{type(e).__name__}: {e}"})
+            for k, v in pairs:
+                if args.sweep_restore.get(k.strip()) is not None:
+                    hipbind.tune(k.strip(), args.sweep_restore[k.strip()])
+            log(f"[bench] sweep {combo}: {line['sweep'][-1]}")
+
     # ---- extras on rank 0 of a single-GPU run: live stage profile, CPU baseline, secondary figures ---------------
     if info.rank == 0 and info.world == 1 and not args.no_profile:
         from whisperjav_amd import hipbind
@@ -511,7 +618,7 @@ def run_cfg3(args, info, dims):
         run_recording(runner, audio, subset)
         prof = ctx.profile_stop_units()
         dstat = (stats or {}).get("decode")
-        avg_steps = dstat["decode_steps_run"] / max(1, dstat["engine_calls"]) if dstat else args.max_new_tokens
+        avg_steps = dstat["decode_steps_run"] / max(1, dstat["engine_calls"]) if dstat else new_token_budget(args)
         avg_keys = 3 + (avg_steps + 1) / 2.0
         line["stages"] = stages_from_profile(prof, dims, dtype, args.beam, avg_keys)
         line["roofline"] = roofline_from_stages(line["stages"], dtype)
@@ -521,7 +628,50 @@ def run_cfg3(args, info, dims):
         log(f"[bench] {time.perf_counter() - t_start:.0f}s used: secondary figures skipped (--extras-budget-s {args.extras_budget_s})")
         line["config"]["extras_skipped"] = "time budget"
         args.no_extras = True
-    if info.rank == 0 and info.world == 1 and not args.no_extras:
+    legacy = args.preset == "tuned"        # the ablation figures of rounds 3-5 (each reference setting alone on top of the tuned configuration)
+    if info.rank == 0 and info.world == 1 and not args.no_extras and not legacy:
+        # what the reference's default segmenter costs inside the headline step, measured apart: all scenes of the recording through
+        # segment_many (device probabilities of every 1536-sample window in three launches + regions + padding + grouping), the
+        # scorer alone, and the same archive scored the reference's way (torch.jit on ONE host core, window by window)
+        seg31 = module._external_segmenter
+        scn = runner.detect(audio, 16000)
+        clips31 = [c for c, _ in runner._device_clips(audio, 16000, scn)]
+        seg31.segment_many(clips31, 16000)
+        best_many = best_scores = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res31 = seg31.segment_many(clips31, 16000)
+            torch.cuda.synchronize()
+            best_many = min(best_many, time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            seg31._graph_scorer.scores(clips31)
+            torch.cuda.synchronize()
+            best_scores = min(best_scores, time.perf_counter() - t1)
+        from whisperjav_amd import standin_vad
+        sample = np.asarray(audio[: 16000 * 90])
+        n_thr = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            t1 = time.perf_counter()
+            standin_vad.reference_probs(module._bench_archive, sample, 1536)
+            t_host = (time.perf_counter() - t1) * (60.0 * minutes / 90.0)
+        finally:
+            torch.set_num_threads(n_thr)
+        gs = seg31._graph_scorer
+        line["default_vad"] = {
+            "segmenter": seg31.name, "device_vad_ms": round(1e3 * best_many, 1), "device_scores_ms": round(1e3 * best_scores, 1),
+            "host_default_vad_s": round(t_host, 1), "scenes": len(clips31), "windows_1536": int(sum((int(c.numel()) + 1535) // 1536 for c in clips31)),
+            "vad_segments": int(sum(len(r.segments) for r in res31)), "groups": int(sum(len(r.groups) for r in res31)),
+            "instructions": gs.program.n_instr, "fused": gs.fused, "lds_bytes_per_window": gs.lds_bytes, "lstm_weights_in_registers": gs.lstm_in_registers,
+            "stages": gs.n_stages, "region_route": dict(seg31.region_stats),
+            "what": ("the headline's segmenter apart from the step: device_vad_ms = HipSileroSpeechSegmenter.segment_many over all scenes (probabilities of every "
+                     "1536-sample window on the device + regions + sample padding + grouping), device_scores_ms = the lowered archive alone (HBM-resident scenes -> host "
+                     "probabilities: one fused launch per stage, one workgroup per window with the arena in LDS, the LSTM one workgroup per scene with its weights in "
+                     "registers); host_default_vad_s = the same archive scored by torch.jit on ONE host core window by window (the reference's loop), 90 s sample scaled "
+                     "to the recording; best of 3; round 5's per-instruction executor took 6288 ms for this (BENCH_r05.json)")}
+        del clips31
+    if info.rank == 0 and info.world == 1 and not args.no_extras and legacy:
         # word_timestamps=True (the reference's default, config/components/asr/faster_whisper.py:298): every window also runs
         # the alignment pass; the word-driven re-seek is switched off (random weights align noise, see whisper_model.word_reseek)
         module.whisper_params["word_timestamps"] = True
@@ -531,11 +681,11 @@ def run_cfg3(args, info, dims):
         run_recording(runner, audio, subset)
         torch.cuda.synchronize()
         tw = time.perf_counter() - t1
-        module.whisper_params["word_timestamps"] = False
-        model.word_reseek = True
+        module.whisper_params["word_timestamps"] = bool(args.word_timestamps)
+        model.word_reseek = bool(args.word_reseek)
         line["word_timestamps"] = {"rtfx": round(60.0 * minutes / tw, 2), "ms": round(1e3 * tw, 1),
                                    "what": "the same step with word_timestamps=True (alignment pass + DTW per window); word-driven re-seek off"}
-    if info.rank == 0 and info.world == 1 and not args.no_extras and args.ref_gate_minutes > 0:
+    if info.rank == 0 and info.world == 1 and not args.no_extras and legacy and args.ref_gate_minutes > 0:
         # the reference's own scene gates (32 / 38 dB, config/components/features/scene_detection.py:74-100) on a recording whose
         # noise floor lets them work: same speech statistics, pink floor at -66 dBFS (24 dB in auditok's scale), no hum
         from whisperjav_amd import pipeline as _pl, scenes as _sc
@@ -553,7 +703,7 @@ def run_cfg3(args, info, dims):
                                          "what": (f"{args.ref_gate_minutes:g} min of the same synthetic speech over a -66 dBFS floor, scene detector at "
                                                   "its (= the reference's) default gates, same engine; second of two passes"), **s_ref}
         del quiet, run_ref
-    if info.rank == 0 and info.world == 1 and not args.no_extras and not args.no_default_vad:
+    if info.rank == 0 and info.world == 1 and not args.no_extras and legacy and not args.no_default_vad:
         # the reference's DEFAULT segmenter (silero-v3.1: a TorchScript hub archive on 1536-sample windows, main.py:1867-1876)
         # scored ON THE DEVICE: the archive's graph lowered onto HIP kernels (vad_graph.py / vadgraph.hip).  The real archive is not
         # obtainable offline; whisperjav_amd/standin_vad.py builds one of the same structure (conv-STFT, adaptive normalisation, separable
@@ -674,7 +824,7 @@ def run_cfg3(args, info, dims):
         # being dropped; three fp32 tensors patched in a clone of the device blob
         blob_f = blob2
         if args.weights == "speechlike":
-            ramp = pweights.EotRamp(mid=4.0, rate=args.eot_rate)
+            ramp = pweights.EotRamp(mid=4.0, rate=args.eot_rate, cap=args.eot_cap)
             blob_f = pweights.patch_blob_device(blob2, offs2, dims, pweights.sharpened_logits(dims, box["w"], 1234, ramp, 1.8, args.fidelity_sharpen))
         mf, modf, runf = build_stack(args, info, dims, dtype, args.batch, blob=blob_f, offsets=offs2, mode="fidelity")
         run_recording(runf, audio)
@@ -693,12 +843,35 @@ def run_cfg3(args, info, dims):
                             **sf_}
         del mf, modf, runf, blob_f
         torch.cuda.empty_cache()
-    if info.rank == 0 and info.world == 1 and not args.no_extras and args.mode == "balanced":
+    if info.rank == 0 and info.world == 1 and not args.no_extras and args.mode == "balanced" and not legacy:
+        # rounds 2-5's headline configuration beside the reference one ("keep today's tuned configuration as an extra"):
+        # its own recording (noisy room), gates, segmenter, token budget and batch; second of two passes
+        import copy
+        at = apply_preset(copy.copy(args_cli(args, "tuned")))
+        t1 = time.perf_counter()
+        audio_t = synth.speech_like_long(60.0 * minutes, seed=1234, noisy=at.noisy, floor_db=at.floor_db)
+        t_audio_t = time.perf_counter() - t1
+        mt, modt, runt = build_stack(at, info, dims, dtype, at.batch, blob=blob2, offsets=offs2, mode="balanced")
+        run_recording(runt, audio_t)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        st_ = run_recording(runt, audio_t)
+        torch.cuda.synchronize()
+        tt = time.perf_counter() - t1
+        modt.cleanup()
+        line["tuned"] = {"rtfx": round(60.0 * minutes / tt, 2), "ms": round(1e3 * tt, 1), "windows_per_batch": at.batch, "audio_synthesis_s": round(t_audio_t, 1),
+                         "preset": {k: (list(v) if isinstance(v, tuple) else v) for k, v in PRESETS["tuned"].items()},
+                         "what": ("rounds 2-5's headline configuration on the same engine weights: noisy-room recording, scene gates 52 / 56 dB, the v6-class HIP scorer with "
+                                  "seeded random parameters, word_timestamps=False, max_new_tokens=64 (KV cache for 72 positions, 768 windows per engine call); second of two "
+                                  "passes.  `python bench.py --preset tuned` makes it the headline"), **st_}
+        del mt, modt, runt, audio_t
+        torch.cuda.empty_cache()
+    if info.rank == 0 and info.world == 1 and not args.no_extras and args.mode == "balanced" and legacy:
         # transcribe(max_new_tokens=None) as the reference passes it (config/components/asr/faster_whisper.py:269,309): the KV cache
         # is sized for n_text_ctx // 2 = 224 new tokens, which costs batch size (512 windows per call instead of 768)
         import copy
         a224 = copy.copy(args)
-        a224.max_new_tokens, a224.batch = 224, min(args.batch, 512)
+        a224.max_new_tokens, a224.batch = None, min(args.batch, 512)
         m2, mod2, run2 = build_stack(a224, info, dims, dtype, a224.batch, blob=blob2, offsets=offs2, mode="balanced")
         run_recording(run2, audio)
         torch.cuda.synchronize()
@@ -747,7 +920,7 @@ def run_cfg3(args, info, dims):
     if info.rank == 0 and info.world == 1 and not args.no_cpu_baseline:
         dst = (stats or {}).get("decode") or {}
         spw = dst["window_steps_run"] / dst["windows"] if dst.get("windows") else None
-        line["cpu_baseline"] = cpu_baseline_cfg3(dims, box["w"], sample_clips, n_groups, 60.0 * minutes, args.max_new_tokens,
+        line["cpu_baseline"] = cpu_baseline_cfg3(dims, box["w"], sample_clips, n_groups, 60.0 * minutes, new_token_budget(args),
                                                  args.beam, args.cpu_threads or min(16, os.cpu_count() or 1),
                                                  step_cap=args.cpu_beam_steps, steps_per_window=spw)
     if info.rank == 0:
@@ -1087,7 +1260,15 @@ def main():
     ap.add_argument("--mode", default="balanced", choices=["balanced", "fidelity"],
                     help="cfg3 = balanced (faster-whisper contract); fidelity = the openai-whisper contract of FidelityPipeline (BASELINE cfg4 with --strong)")
     ap.add_argument("--strong", action="store_true", help="cfg3 with --gpus N: ONE recording, scenes LPT-sharded over the ranks (cfg4)")
-    ap.add_argument("--batch", type=int, default=768, help="30 s windows resident per GPU per engine call (768: cross K/V = 189 GB, "
+    ap.add_argument("--preset", default="reference", choices=sorted(PRESETS), help="cfg3: reference = the reference's runtime-effective settings of --mode balanced "
+                    "(silero-v3.1 segmenter contract over a lowered TorchScript archive, word_timestamps=True, max_new_tokens=None, scene gates 32 / 38 dB on a studio-floor "
+                    "recording, 512 windows per engine call); tuned = rounds 2-5's headline (v6-class scorer, no alignment pass, 64-token budget, gates 52 / 56 dB on the "
+                    "noisy recording, 768 windows per call).  The flags below override single settings of the preset")
+    ap.add_argument("--segmenter", default=None, choices=["silero-v3.1", "silero-v6.2"])
+    ap.add_argument("--word-timestamps", dest="word_timestamps", type=int, default=None, choices=[0, 1])
+    ap.add_argument("--scene-gates", default=None, help="'reference' (32 / 38 dB) or PASS1/PASS2 in dB, e.g. 52/56")
+    ap.add_argument("--audio", default=None, choices=["studio", "noisy"], help="the synthetic recording: studio floor (-66 dBFS) or noisy room (-45 dBFS + hum)")
+    ap.add_argument("--batch", type=int, default=None, help="30 s windows resident per GPU per engine call (768: cross K/V = 189 GB, "
                     "self-attention KV cache sized for max_new_tokens = 46 GB, encoder slices of --enc-batch windows; 238 GiB in all)")
     ap.add_argument("--encoder-cus", type=int, default=0, help="> 0: the encoder of the next chunk runs on this many compute units beside "
                     "the decode loop of the current chunk on the others (CU-masked streams); 0 = plain second stream")
@@ -1097,8 +1278,8 @@ def main():
     ap.add_argument("--no-kv-fit", dest="kv_fit", action="store_false",
                     help="size the self-attention KV cache for n_text_ctx positions instead of prompt + max_new_tokens")
     ap.add_argument("--beam", type=int, default=5)
-    ap.add_argument("--max-new-tokens", type=int, default=64, help="cfg3: transcribe(max_new_tokens=...); swept 32/64/224 in profiles/")
-    ap.add_argument("--vad-threshold", type=float, default=0.28, help="BASELINE.md section 3 (balanced preset)")
+    ap.add_argument("--max-new-tokens", type=int, default=None, help="cfg3: transcribe(max_new_tokens=...); 0 = None as the reference passes it (KV cache for 224 new tokens)")
+    ap.add_argument("--vad-threshold", type=float, default=None, help="BASELINE.md section 3 (balanced preset: 0.28)")
     ap.add_argument("--decode-tokens", type=int, default=224, help="cfg2: new tokens per window (n_text_ctx // 2)")
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--dtype", default="float16", choices=["float16", "bfloat16", "float32"])
@@ -1111,6 +1292,13 @@ def main():
     ap.add_argument("--weights", default="speechlike", choices=["speechlike", "plain"],
                     help="speechlike: EOT-bearing synthetic weights (searches end, token count grows with the audio in the window); plain: never EOT")
     ap.add_argument("--eot-rate", type=float, default=12.0, help="speechlike: nominal tokens per second of audio content (realised: see workload_facts)")
+    ap.add_argument("--eot-cap", type=float, default=56.0, help="speechlike: logit units at which the planted EOT ramp saturates.  56 = slope 0.25 x 224 tokens: the ramp "
+                    "rises through the whole token budget, so a window holding 15-29 s of speech (a long VAD region; the v3.1 contract forwards no max_speech_duration_s) ends "
+                    "after a number of tokens proportional to its audio.  Rounds 3-5 used 12 with groups <= 6 s; with it a window holding more than ~4 nominal content-seconds "
+                    "NEVER ends and runs to the length limit (282 of 2775 windows in the first reference-preset run)")
+    ap.add_argument("--word-reseek", type=int, default=0, choices=[0, 1], help="word_timestamps=True: faster-whisper moves the seek to the last word's end when a window's tokens do not "
+                    "end in a timestamp.  A trained model ends its windows in a timestamp (no re-seek); the synthetic model ends them anywhere and its alignment is noise, so "
+                    "with 1 nearly every <= 6 s group is decoded two or three times (2775 windows for 1454 groups).  0 (default) = the trained model's control flow")
     ap.add_argument("--fidelity-sharpen", type=float, default=2.5, help="fidelity figure: logits x this factor (weights.sharpened_logits) so segments pass the -1.0 gate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -1119,8 +1307,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (fp32 mode, word timestamps, cfg2, single window)")
     ap.add_argument("--per-scene", action="store_true", help="A/B: one engine call per scene (the reference's loop) instead of pooling all scenes")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="wj_tune switches for A/B runs (e.g. dec_split_act=0)")
+    ap.add_argument("--sweep", default="", help="cfg3, one GPU: ';'-separated wj_tune settings ('k=v,k2=v2;k=v3') each run for one timed step after the headline")
+    ap.add_argument("--sweep-defaults", default="", help="'k=v,...': the values the swept switches are set back to after each setting (the library defaults)")
     ap.add_argument("--simulate", action="store_true", help="CPU/gloo dry run of the launcher and the collectives (no GPU, no kernels)")
-    args = ap.parse_args()
+    args = apply_preset(ap.parse_args())
+    args.sweep_restore = {kv.split("=")[0].strip(): int(kv.split("=")[1]) for kv in args.sweep_defaults.split(",") if "=" in kv}
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
@@ -1141,6 +1332,8 @@ def main():
             hipbind.tune(k, int(v))
     if args.mode == "fidelity":
         args.beam = 2           # the reference's fidelity default (beam_size=2, patience=1.2)
+    if args.workload == "cfg2" and args.batch > 384:
+        args.batch = 384
     if not args.kv_fit and args.batch > 384:
         log("[bench] --no-kv-fit: a 448-position KV cache leaves room for 384 windows per call")
         args.batch = 384

@@ -256,8 +256,11 @@ int wj_whisper_decode_beam_openai(wj_whisper* m, int batch, int beam, const int3
  * back), so audio embeddings -- the projected output of the audio tower, not part of this slice -- simply replace the rows
  * of the <audio> placeholder tokens.
  * Blob: matrices [out][in] row-major in the compute type, vectors fp32, every tensor 256-byte aligned, offsets in the order
- * of the enumerators below (globals, then WJ_QL_* per layer).  QKV = q rows, then k rows, then v rows; GATEUP = gate rows,
- * then up rows. */
+ * of the enumerators below (globals, then WJ_QL_* per layer).  QKV = q rows, then k rows, then v rows.  GATEUP (ABI 5 onwards,
+ * every dtype): the 2 x ffn rows INTERLEAVED in blocks of 16 -- rows [32 b, 32 b + 16) = gate rows [16 b, 16 b + 16), rows
+ * [32 b + 16, 32 b + 32) = up rows [16 b, 16 b + 16) -- so that neighbouring matrix-core fragments of a lane hold a (gate, up)
+ * pair and silu(g) * u is computed in the GEMM's epilogue; ffn must be a multiple of 16 (wj_qwen_create refuses otherwise).
+ * Rounds 3-4 (ABI <= 4) stored gate rows, then up rows: a blob packed that way decodes garbage here. */
 typedef struct wj_qwen wj_qwen;
 typedef struct {
   int32_t hidden, n_layer, n_head, n_kv_head, head_dim, ffn, vocab;

@@ -844,8 +844,11 @@ int wj_qwen_create(wj_ctx* ctx, const wj_qwen_dims* dims, int dtype, const void*
   WJ_REQUIRE(ctx && dims && blob_dev && offsets_host && out, "wj_qwen_create: NULL argument");
   const wj_qwen_dims& d = *dims;
   WJ_REQUIRE(d.head_dim == HD, "wj_qwen_create: head_dim %d (the kernels are specialised for 128, every published Qwen3 size)", d.head_dim);
-  WJ_REQUIRE(d.hidden > 0 && d.hidden % 8 == 0 && d.ffn % 8 == 0 && d.n_head >= 1 && d.n_kv_head >= 1 && d.n_head % d.n_kv_head == 0 &&
+  WJ_REQUIRE(d.hidden > 0 && d.hidden % 8 == 0 && d.ffn > 0 && d.n_head >= 1 && d.n_kv_head >= 1 && d.n_head % d.n_kv_head == 0 &&
              d.n_layer >= 1 && d.vocab >= 2, "wj_qwen_create: bad dimensions");
+  // GATEUP rows are interleaved in [16 gate | 16 up] blocks (wjhip.h): the last block of an ffn that is not a multiple of 16
+  // would read its up rows past the 2 x ffn rows of the matrix
+  WJ_REQUIRE(d.ffn % 16 == 0, "wj_qwen_create: ffn %d is not a multiple of 16 (the gate / up rows are interleaved in blocks of 16)", d.ffn);
   WJ_REQUIRE(d.n_head / d.n_kv_head == 1 || d.n_head / d.n_kv_head == 2 || d.n_head / d.n_kv_head == 4,
              "wj_qwen_create: %d query heads per KV head (the attention kernel is instantiated for 1, 2 and 4)", d.n_head / d.n_kv_head);
   WJ_REQUIRE(dtype == WJ_F32 || dtype == WJ_F16 || dtype == WJ_BF16 || dtype == WJ_F8W, "wj_qwen_create: unknown dtype %d", dtype);

@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from pathlib import Path
-from typing import Optional
+from typing import Dict, Optional
 
 ABI_VERSION = 6
 _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwjhip.so"
@@ -158,8 +158,17 @@ def lib() -> C.CDLL:
     return handle
 
 
+_TUNED: Dict[str, int] = {}       # switches set through tune() in this process (wj_tune has no getter)
+
+
 def tune(key: str, value: int) -> None:
     check(lib().wj_tune(key.encode(), int(value)), "wj_tune")
+    _TUNED[key] = int(value)
+
+
+def tuned(key: str, default: int) -> int:
+    """The value the process last set for a wj_tune switch (``default`` = the library's own default when it never did)."""
+    return _TUNED.get(key, int(default))
 
 
 def check(rc: int, what: str = "") -> None:

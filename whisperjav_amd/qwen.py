@@ -612,6 +612,7 @@ class HipQwen3Decoder:
         off = (C.c_int64 * len(offsets))(*offsets.tolist())
         handle = C.c_void_p()
         torch.cuda.current_stream().synchronize()
+        prev_split = hipbind.tuned("qwen_split_act", DEFAULT_SPLIT_ACT)
         if split_act is not None:
             hipbind.tune("qwen_split_act", int(split_act))         # read by wj_qwen_create
         try:
@@ -619,7 +620,7 @@ class HipQwen3Decoder:
                                            off, len(offsets), self.max_seqs, self.max_ctx, self.max_rows, C.byref(handle)), "wj_qwen_create")
         finally:
             if split_act is not None:
-                hipbind.tune("qwen_split_act", DEFAULT_SPLIT_ACT)
+                hipbind.tune("qwen_split_act", prev_split)         # what the process had set before, not the library default
         self.handle = handle
 
     def close(self) -> None:
