@@ -592,7 +592,6 @@ def run_cfg3(args, info, dims):
         line["sweep"] = [{"tune": "(as run)", "ms": line["ms_per_step"], "crc": (stats or {}).get("transcript_crc32")}]
         for combo in [c for c in args.sweep.split(";") if c.strip()]:
             pairs = [kv.split("=") for kv in combo.split(",")]
-            saved = {k: hipbind.tuned(k, None) if k in hipbind._TUNED else None for k, _ in pairs}
             for k, v in pairs:
                 hipbind.tune(k.strip(), int(v))
             try:

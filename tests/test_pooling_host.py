@@ -226,19 +226,16 @@ def test_pcm16_round_trip_and_resampling():
     assert abs(np.abs(np.fft.rfft(y)).argmax() - 440) <= 1
 
 
-def test_pcm16_round_trip_matches_soundfile(tmp_path):
-    """Lights up when ``soundfile`` (libsndfile) is installed: the scene round trip of the reference --
-    ``sf.write(path, x, sr, subtype="PCM_16")`` (scene_detection_backends/utils.py:140) then ``sf.read(path,
-    dtype="float32")`` (faster_whisper_pro_asr.py:477) -- must equal ``pcm16_roundtrip`` bit for bit."""
-    sf = pytest.importorskip("soundfile", reason="soundfile / libsndfile wheel absent offline (parity unpinned, PARITY.md)")
-    rng = np.random.default_rng(11)
-    x = np.concatenate([rng.uniform(-1.0, 1.0, 50000), (np.arange(-40, 41) + 0.5) / 32767.0, [1.0, -1.0, 0.0]]).astype(np.float32)
-    path = tmp_path / "rt.wav"
-    sf.write(str(path), x, 16000, subtype="PCM_16")
-    back, sr = sf.read(str(path), dtype="float32")
-    assert sr == 16000 and np.array_equal(back, pipeline.pcm16_roundtrip(x))
-    raw, _ = sf.read(str(path), dtype="int16")
-    assert np.array_equal(raw, pipeline.pcm16_encode(x))
+def test_pcm16_round_trip_matches_soundfile():
+    """The scene round trip of the reference -- ``sf.write(path, x, sr, subtype="PCM_16")`` (scene_detection_backends/utils.py:140)
+    then ``sf.read(path, dtype="float32")`` (faster_whisper_pro_asr.py:477) -- must equal ``pcm16_roundtrip`` bit for bit, and the raw
+    int16 samples ``pcm16_encode``.  soundfile (libsndfile) live where it is installed, ``tests/golden/upstream_soundfile_pcm16.npz``
+    (scripts/make_upstream_fixtures.py) where it is not, skipped while there is neither (parity unpinned, PARITY.md)."""
+    from tests import upstream_cases as U
+    ref, _ = U.reference("soundfile_pcm16")
+    x = U.pcm16_input()
+    assert int(ref["sr"]) == 16000 and np.array_equal(ref["back"], pipeline.pcm16_roundtrip(x))
+    assert np.array_equal(ref["raw"], pipeline.pcm16_encode(x))
 
 
 def test_recording_transcriber_stitches_in_scene_order():

@@ -208,24 +208,25 @@ def test_standalone_factory_fails_before_any_audio_for_the_kernel_less_network()
     assert asr.HipFasterWhisperProASR._create_segmenter("silero-v4.0", {"network": "v6", "weights": "synthetic"}).can_score
 
 
-def test_silero_torchscript_archives_light_up_when_present(tmp_path):
-    """Skipped offline.  With the ``silero_vad`` wheel: its bundled archive classifies as v5/v6 and feeds the HIP blob
-    packer; with a torch.hub cache of snakers4/silero-vad v3.1 / v4.0: the archive classifies as the legacy generation and
-    ``load_file`` refuses it."""
-    silero_vad = pytest.importorskip("silero_vad", reason="silero-vad wheel absent offline (parity unpinned, PARITY.md)")
+def test_silero_torchscript_archives_light_up_when_present():
+    """The ``silero_vad`` wheel's bundled archive (live, or its parameters from ``tests/golden/upstream_silero_v5.npz``) classifies as
+    v5/v6 and feeds the HIP blob packer; a torch.hub archive of snakers4/silero-vad v3.1 / v4.0 (the live cache, or the file
+    ``make_upstream_fixtures.py --include-archives`` committed) classifies as the legacy generation and ``load_file`` refuses it.
+    Skipped while there is neither wheel nor fixture."""
     import os
+    from tests import upstream_cases as U
     from whisperjav_amd import hipbind, vad_weights
-    sd = silero_vad.load_silero_vad().state_dict()
+    ref, _ = U.reference("silero_v5")
+    sd = {k[3:]: v for k, v in ref.items() if k.startswith("sd.")}
     assert vad_weights.classify_state_dict(sd) == "v5/v6"
     assert vad_weights.pack(vad_weights.from_jit_state_dict(sd)).shape[0] == vad_weights.BLOB_FLOATS
-    hub = os.path.expanduser("~/.cache/torch/hub")
-    for root, _, files in os.walk(hub) if os.path.isdir(hub) else []:
-        for f in files:
-            if f.endswith(".jit") and "silero" in root.lower() and ("v3.1" in root or "v4.0" in root):
-                gen, _ = vad_weights.from_torchscript(os.path.join(root, f))
-                assert gen == "v3.1/v4.0"
-                with pytest.raises(hipbind.WjError):
-                    vad_weights.load_file(os.path.join(root, f))
+    for case in ("silero_hub_v31", "silero_hub_v40"):
+        path = str(U.archive_path(case))
+        if os.path.exists(path):
+            gen, _ = vad_weights.from_torchscript(path)
+            assert gen == "v3.1/v4.0"
+            with pytest.raises(hipbind.WjError):
+                vad_weights.load_file(path)
 
 
 def test_default_segmenter_weak_assertions_of_the_reference_suite():

@@ -1,147 +1,160 @@
-"""Pins against the REAL upstream packages -- skipped offline, lit up wherever the wheels exist.
+"""Pins against the REAL upstream packages: live where the wheel is installed, from a committed fixture where it is not, skipped
+when there is neither.
 
 The arithmetic of the hot path lives in wheels the reference does not vendor and this environment cannot install
 (faster-whisper 1.2.1, ctranslate2 4.7.1, openai-whisper 20250625, silero-vad 6.2.1, auditok 0.3.0, soundfile;
 ``/root/reference/uv.lock``), so ``oracle/`` restates their published algorithms and is pinned against what IS importable
-(``transformers``, the reference's own pure-Python pieces).  Every test below states what the restatement must equal once
-the wheel is present; ``pytest -rs`` lists them as skipped-for-missing-wheel, PARITY.md has the table.  None of them needs
-a GPU: they pin the ORACLE (the HIP path is pinned against the oracle in the ``-m gpu`` tests).
+(``transformers``, the reference's own pure-Python pieces).  ``tests/upstream_cases.py`` holds, per case, the function that runs the
+package on seeded inputs; ``scripts/make_upstream_fixtures.py`` writes its outputs to ``tests/golden/upstream_<case>.npz`` on any
+machine that has the wheels -- one outside run pins the oracle permanently.  Every test below states what the restatement must equal;
+``pytest -rs`` lists the cases that have neither wheel nor fixture, ``python scripts/make_upstream_fixtures.py --status`` and
+PARITY.md have the table.  None of them needs a GPU: they pin the ORACLE (the HIP path is pinned against the oracle in ``-m gpu``).
 
 Two more of the family live next to the code they pin: ``tests/test_pooling_host.py::test_pcm16_round_trip_matches_soundfile``
 and ``tests/test_segmenters.py::test_silero_torchscript_archives_light_up_when_present``.
 """
-import os
-
 import numpy as np
 import pytest
 import torch
 
 from oracle import auditok_ref, decoding, logmel, whisper_ref
-from tests import helpers
+from tests import helpers, upstream_cases as U
 from whisperjav_amd import dims as pdims, synth, weights as pweights
-
-MISSING = "wheel absent offline (parity unpinned, PARITY.md)"
 
 
 def test_faster_whisper_feature_extractor():
     """``faster_whisper.feature_extractor.FeatureExtractor.__call__(audio, padding=160)`` + the zero-FEATURE
     ``pad_or_trim`` of ``transcribe.py`` == ``oracle.logmel.logmel_fw`` / ``window_features(..., "fw")``: frame counts
     exact, values to float32 summation order (reference call site faster_whisper_pro_asr.py:819)."""
-    fw = pytest.importorskip("faster_whisper.feature_extractor", reason="faster-whisper " + MISSING)
-    pad_or_trim = pytest.importorskip("faster_whisper.audio", reason="faster-whisper " + MISSING).pad_or_trim
+    ref, _ = U.reference("fw_mel")
     for n_mels in (80, 128):
-        fe = fw.FeatureExtractor(feature_size=n_mels)
-        for seconds, seed in ((3.7, 5), (11.0, 6), (30.0, 7)):
+        for i, (seconds, seed) in enumerate(U.FW_MEL_CLIPS):
             audio = synth.speech_like(seconds, seed=seed)
-            ref = np.asarray(fe(audio, padding=160))
             got = logmel.logmel_fw(audio, n_mels)
-            assert ref.shape == got.shape, (ref.shape, got.shape)
-            assert np.abs(ref - got).max() < 5e-5
-            win = np.asarray(pad_or_trim(torch.from_numpy(ref) if not isinstance(ref, np.ndarray) else ref, 3000))
-            assert np.abs(win - logmel.window_features(audio, n_mels, "fw")).max() < 5e-5
-            assert (win[:, ref.shape[1]:] == 0).all()                   # zero-FEATURE padding, not the clamp floor
+            key = f"{n_mels}_{i}"
+            assert tuple(ref[f"shape_{key}"]) == got.shape, (ref[f"shape_{key}"], got.shape)
+            if f"ref_{key}" in ref:
+                assert np.abs(ref[f"ref_{key}"] - got).max() < 5e-5
+            else:
+                assert np.abs(ref[f"head_{key}"] - got[:, :U.EDGE]).max() < 5e-5 and np.abs(ref[f"tail_{key}"] - got[:, -U.EDGE:]).max() < 5e-5
+                assert np.abs(ref[f"stride_{key}"] - got[:, ::37]).max() < 5e-5
+            # zero-FEATURE padding, not the clamp floor; the kept part is the extractor's output unchanged
+            assert float(ref[f"win_pad_absmax_{key}"]) == 0.0 and bool(ref[f"win_equals_ref_{key}"])
+            win = logmel.window_features(audio, n_mels, "fw")
+            assert (win[:, got.shape[1]:] == 0).all() and np.array_equal(win[:, : min(3000, got.shape[1])], got[:, :3000])
 
 
 def test_openai_whisper_log_mel():
     """``whisper.audio.log_mel_spectrogram(audio, n_mels, padding=N_SAMPLES)`` == ``oracle.logmel.logmel_ow``
     (reference call site whisper_pro_asr.py:433, inside ``whisper.transcribe``)."""
-    wa = pytest.importorskip("whisper.audio", reason="openai-whisper " + MISSING)
+    ref, _ = U.reference("ow_mel")
+    audio = synth.speech_like(U.OW_MEL_CLIP[0], seed=U.OW_MEL_CLIP[1])
     for n_mels in (80, 128):
-        audio = synth.speech_like(7.3, seed=9)
-        ref = wa.log_mel_spectrogram(torch.from_numpy(audio), n_mels, padding=wa.N_SAMPLES).numpy()
         got = logmel.logmel_ow(audio, n_mels)
-        assert ref.shape == got.shape and np.abs(ref - got).max() < 5e-5
+        assert tuple(ref[f"shape_{n_mels}"]) == got.shape
+        assert np.abs(ref[f"head_{n_mels}"] - got[:, :800]).max() < 5e-5 and np.abs(ref[f"stride_{n_mels}"] - got[:, ::41]).max() < 5e-5
 
 
-def _openai_model(d, w):
-    whisper = pytest.importorskip("whisper", reason="openai-whisper " + MISSING)
-    model = whisper.model.Whisper(whisper.model.ModelDimensions(**d.as_dict()))
-    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
-    sd["encoder.positional_embedding"] = sd["encoder.positional_embedding"]
-    missing, unexpected = model.load_state_dict(sd, strict=False)
-    assert not [k for k in missing if "alignment_heads" not in k] and not unexpected, (missing, unexpected)
-    return whisper, model.eval()
-
-
-@pytest.mark.parametrize("beam,patience", [(None, None), (2, 1.2), (5, 2.0)])
-def test_openai_whisper_decoding(beam, patience):
+@pytest.mark.parametrize("config", [0, 1, 2])
+def test_openai_whisper_decoding(config):
     """``whisper.decoding.DecodingTask`` (greedy and ``BeamSearchDecoder`` + ``MaximumLikelihoodRanker``, the search of
     fidelity mode, whisper_pro_asr.py:433) on the synthetic ``SPEECHLIKE`` weights loaded into the REAL model class ==
     ``oracle.decoding.greedy_decode`` / ``beam_search_openai``: tokens identical (the hypotheses END at different
     lengths), sum / avg log-prob within 1e-4, no-speech probability within 1e-6."""
+    ref, _ = U.reference("ow_decoding")
+    beam, patience = U.OW_DECODE_CONFIGS[config]
     d = helpers.small_dims()
     w = pweights.synth_weights(d, seed=21, exact="none", **pweights.SPEECHLIKE)
-    whisper, model = _openai_model(d, w)
     oracle = whisper_ref.WhisperOracle(helpers.oracle_dims(d), w)
-    clips = [synth.speech_like(s, seed=30 + i) for i, s in enumerate((1.5, 4.0, 6.0))]
+    clips = [synth.speech_like(s, seed=seed) for s, seed in U.OW_DECODE_CLIPS]
     mel = torch.from_numpy(np.stack([logmel.window_features(c, d.n_mels, "ow") for c in clips]))
-    opts = whisper.DecodingOptions(language="ja", task="transcribe", beam_size=beam, patience=patience, fp16=False,
-                                   sample_len=48, suppress_tokens="", temperature=0.0)
     with torch.no_grad():
-        results = whisper.decode(model, mel, opts)
         xa = oracle.encode(mel)
     toks = pdims.special_tokens(d.n_vocab)
     prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
     fcfg = decoding.FilterConfig(max_initial_timestamp_index=50)
     lens = set()
-    for b, res in enumerate(results):
+    for b in range(len(clips)):
         if beam is None:
-            ref = decoding.greedy_decode(oracle, xa[b:b + 1], prompt, 48, fcfg)
-            seq, total, avg, nsp = ref.tokens[0], float(ref.sum_logprob[0]), float(ref.avg_logprob()[0]), float(ref.no_speech_prob[0])
+            r = decoding.greedy_decode(oracle, xa[b:b + 1], prompt, 48, fcfg)
+            seq, avg, nsp = r.tokens[0], float(r.avg_logprob()[0]), float(r.no_speech_prob[0])
         else:
-            seq, total, avg, nsp = decoding.beam_search_openai(oracle, xa[b:b + 1], prompt, beam, patience, None, 48, fcfg)
+            seq, _, avg, nsp = decoding.beam_search_openai(oracle, xa[b:b + 1], prompt, beam, patience, None, 48, fcfg)
         lens.add(len(seq))
-        assert list(res.tokens) == seq, (b, res.tokens, seq)
-        assert abs(res.avg_logprob - avg) < 1e-4 and abs(res.no_speech_prob - nsp) < 1e-6
+        assert U.unpad(ref[f"tokens_{config}"][b]) == list(seq), (b, ref[f"tokens_{config}"][b], seq)
+        assert abs(float(ref[f"avg_logprob_{config}"][b]) - avg) < 1e-4 and abs(float(ref[f"no_speech_prob_{config}"][b]) - nsp) < 1e-6
     assert len(lens) > 1 and max(lens) < 48
 
 
-def test_ctranslate2_generate_matches_the_restated_beam_search():
+def _beam_against(oracle, d, mel, ref, i):
+    toks = pdims.special_tokens(d.n_vocab)
+    prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
+    suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
+    with torch.no_grad():
+        xa = oracle.encode(torch.from_numpy(mel))
+        mine, nsp = decoding.beam_search(oracle, xa, prompt, decoding.BeamConfig(5, 1.2, 1.0, 1.5, 3, 224 - len(prompt)),
+                                         decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=0))
+    seqs = [U.unpad(r) for r in ref[f"sequences_{i}"]]
+    n = min(len(mine), len(seqs))
+    assert n >= 1 and seqs[:n] == [list(r[0]) for r in mine[:n]]
+    assert np.allclose(ref[f"scores_{i}"][:n], [r[1] for r in mine[:n]], atol=2e-3)
+    assert abs(float(ref[f"no_speech_prob_{i}"]) - nsp) < 1e-4
+    return xa
+
+
+def test_ctranslate2_generate_matches_the_restated_beam_search_on_a_seeded_model():
     """``ctranslate2.models.Whisper.generate`` (beam 5, patience 1.2, repetition penalty 1.5, no-repeat 3-gram: what
-    faster-whisper calls from faster_whisper_pro_asr.py:819-822) == ``oracle.decoding.beam_search`` on the same
-    checkpoint: sequences, ``scores`` (= cum / len ** length_penalty with len WITHOUT EOT -- ADVICE r1 item 3) and the
-    tie-breaking of the flattened top-2K.  Needs the wheel AND a model in both formats: ``WJ_CT2_MODEL_DIR`` (a converted
-    faster-whisper directory, e.g. Systran/faster-whisper-tiny) and ``WJ_HF_MODEL_DIR`` (the same checkpoint as
-    Hugging Face safetensors, e.g. openai/whisper-tiny)."""
-    ct2 = pytest.importorskip("ctranslate2", reason="ctranslate2 " + MISSING)
-    ct2_dir, hf_dir = os.environ.get("WJ_CT2_MODEL_DIR"), os.environ.get("WJ_HF_MODEL_DIR")
-    if not (ct2_dir and hf_dir):
-        pytest.skip("set WJ_CT2_MODEL_DIR / WJ_HF_MODEL_DIR to the same Whisper checkpoint in both formats")
+    faster-whisper calls from faster_whisper_pro_asr.py:819-822) == ``oracle.decoding.beam_search`` on a seeded toy Whisper
+    that ``ct2_format.write_ct2_whisper`` wrote as a CTranslate2 directory: sequences, ``scores`` (= cum / len ** length_penalty
+    with len WITHOUT EOT -- ADVICE r1 item 3), the tie-breaking of the flattened top-2K, the no-speech probability, and the
+    encoder output of the directory (the writer's layout)."""
+    ref, _ = U.reference("ct2_generate_seeded")
+    d = helpers.small_dims()
+    w = pweights.synth_weights(d, seed=21, exact="float16", **pweights.SPEECHLIKE)
+    oracle = whisper_ref.WhisperOracle(helpers.oracle_dims(d), w)
+    for i, (seconds, seed) in enumerate(U.CT2_CLIPS):
+        mel = logmel.window_features(synth.speech_like(seconds, seed=seed), d.n_mels, "fw")[None]
+        xa = _beam_against(oracle, d, mel, ref, i)
+        if i == 0:
+            assert np.abs(ref["encoder_stride"] - xa.numpy()[0, ::25]).max() < 2e-3
+
+
+def test_ctranslate2_generate_matches_the_restated_beam_search_on_a_published_checkpoint():
+    """The same on a PUBLISHED checkpoint held in both formats: ``WJ_CT2_MODEL_DIR`` (a converted faster-whisper directory, e.g.
+    Systran/faster-whisper-tiny) and ``WJ_HF_MODEL_DIR`` (the same checkpoint as Hugging Face safetensors, e.g. openai/whisper-tiny).
+    Live only."""
+    ref, _ = U.reference("ct2_generate_checkpoint")
+    import ctranslate2 as ct2
+    ct2_dir, hf_dir = str(ref["ct2_dir"]), str(ref["hf_dir"])
     d, w, _ = pweights.load_hf_checkpoint(hf_dir)
     oracle = whisper_ref.WhisperOracle(helpers.oracle_dims(d), w)
     model = ct2.models.Whisper(ct2_dir, device="cpu", compute_type="float32")
     toks = pdims.special_tokens(d.n_vocab)
     prompt = [toks.sot, toks.language_token(pdims.language_index("ja")), toks.transcribe]
     suppress = (toks.sot, toks.translate, toks.transcribe, toks.sot_lm, toks.sot_prev, toks.no_speech)
-    for seconds, seed in ((2.0, 1), (5.5, 2)):
+    for i, (seconds, seed) in enumerate(U.CT2_CLIPS):
         mel = logmel.window_features(synth.speech_like(seconds, seed=seed), d.n_mels, "fw")[None]
         res = model.generate(ct2.StorageView.from_array(mel), [prompt], beam_size=5, patience=1.2, length_penalty=1.0,
                              repetition_penalty=1.5, no_repeat_ngram_size=3, max_length=224, return_scores=True,
                              return_no_speech_prob=True, suppress_blank=True, suppress_tokens=list(suppress),
                              max_initial_timestamp_index=0, num_hypotheses=5)[0]
-        with torch.no_grad():
-            xa = oracle.encode(torch.from_numpy(mel))
-            ref, nsp = decoding.beam_search(oracle, xa, prompt, decoding.BeamConfig(5, 1.2, 1.0, 1.5, 3, 224 - len(prompt)),
-                                            decoding.FilterConfig(suppress_tokens=suppress, max_initial_timestamp_index=0))
-        n = min(len(ref), len(res.sequences_ids))
-        assert [list(s) for s in res.sequences_ids[:n]] == [r[0] for r in ref[:n]]
-        assert np.allclose(res.scores[:n], [r[1] for r in ref[:n]], atol=2e-3)
-        assert abs(res.no_speech_prob - nsp) < 1e-4
+        live = {f"sequences_{i}": U._pad_ragged(res.sequences_ids), f"scores_{i}": np.asarray(res.scores), f"no_speech_prob_{i}": np.asarray(res.no_speech_prob)}
+        _beam_against(oracle, d, mel, live, i)
 
 
 def test_ctranslate2_model_directory_reader_and_writer(tmp_path):
     """``whisperjav_amd.ct2_format`` against the wheel itself, both directions, on a seeded toy Whisper (no download):
     (a) a directory written by ``ct2_format.write_ct2_whisper`` LOADS in ``ctranslate2.models.Whisper`` and its encoder output
-    equals the oracle's on the same weights; (b) the directory ``ctranslate2.converters.TransformersConverter`` writes from the
-    same weights as a ``WhisperForConditionalGeneration`` is read back by ``ct2_format.load_ct2_whisper`` into the same tensors
-    (float32 exactly; the reference opens such directories at faster_whisper_pro_asr.py:246-253)."""
-    ct2 = pytest.importorskip("ctranslate2", reason="ctranslate2 " + MISSING)
+    equals the oracle's on the same weights (also pinned offline by the ``ct2_generate_seeded`` fixture); (b) the directory
+    ``ctranslate2.converters.TransformersConverter`` writes from the same weights as a ``WhisperForConditionalGeneration`` is read
+    back by ``ct2_format.load_ct2_whisper`` into the same tensors (float32 exactly; the reference opens such directories at
+    faster_whisper_pro_asr.py:246-253).  Live only (the converter is the thing under test)."""
+    ct2 = pytest.importorskip("ctranslate2", reason="ctranslate2 wheel absent offline (parity unpinned, PARITY.md)")
     transformers = pytest.importorskip("transformers")
     from whisperjav_amd import ct2_format
     d = helpers.small_dims()
     w = pweights.synth_weights(d, seed=11, exact="float16")
     toks = pdims.special_tokens(d.n_vocab)
-    # (a) our writer -> the wheel
     ours = tmp_path / "ours"
     ct2_format.write_ct2_whisper(str(ours), d, w, dtype="float32", alignment_heads=[(1, 0)])
     model = ct2.models.Whisper(str(ours), device="cpu", compute_type="float32")
@@ -151,7 +164,6 @@ def test_ctranslate2_model_directory_reader_and_writer(tmp_path):
     with torch.no_grad():
         ref = oracle.encode(torch.from_numpy(mel)).numpy()
     assert np.abs(enc - ref).max() < 2e-3
-    # (b) the wheel's converter -> our reader
     cfg = transformers.WhisperConfig(vocab_size=d.n_vocab, num_mel_bins=d.n_mels, d_model=d.n_audio_state, encoder_layers=d.n_audio_layer,
                                      decoder_layers=d.n_text_layer, encoder_attention_heads=d.n_audio_head,
                                      decoder_attention_heads=d.n_text_head, encoder_ffn_dim=4 * d.n_audio_state,
@@ -173,65 +185,91 @@ def test_auditok_split():
     """``auditok.split(bytes, sampling_rate, channels=1, sample_width=2, min_dur, max_dur, max_silence,
     energy_threshold, drop_trailing_silence=True)`` as called at auditok_backend.py:396,567 == ``oracle.auditok_ref.split``
     (region start / end in seconds, exactly)."""
-    auditok = pytest.importorskip("auditok", reason="auditok " + MISSING)
-    audio = synth.speech_like(95.0, seed=4, noisy=True)
-    pcm = auditok_ref.to_pcm16(audio)
-    for min_dur, max_dur, max_sil, thr in ((0.3, 2700.0, 1.8, 32), (0.3, 28.0, 0.94, 38), (0.2, 10.0, 0.3, 50)):
-        ref = [(r.start if hasattr(r, "start") else r.meta.start, r.end if hasattr(r, "end") else r.meta.end)
-               for r in auditok.split(pcm.tobytes(), sampling_rate=16000, channels=1, sample_width=2, min_dur=min_dur,
-                                      max_dur=max_dur, max_silence=max_sil, energy_threshold=thr, drop_trailing_silence=True)]
-        got = auditok_ref.split(pcm, 16000, min_dur, max_dur, max_sil, thr)
-        assert len(ref) == len(got) and np.allclose(np.array(ref), np.array(got), atol=1e-9), (ref[:3], got[:3])
+    ref, _ = U.reference("auditok_split")
+    pcm = auditok_ref.to_pcm16(synth.speech_like(95.0, seed=4, noisy=True))
+    for i, (min_dur, max_dur, max_sil, thr) in enumerate(U.AUDITOK_PARAMS):
+        got = np.asarray(auditok_ref.split(pcm, 16000, min_dur, max_dur, max_sil, thr), dtype=np.float64).reshape(-1, 2)
+        want = ref[f"regions_{i}"]
+        assert want.shape == got.shape and np.allclose(want, got, atol=1e-9), (want[:3], got[:3])
 
 
 def test_silero_vad_probabilities_and_timestamps():
     """``silero_vad.load_silero_vad()`` window probabilities == ``oracle.silero_ref.SileroOracle`` fed the archive's
     own parameters through ``vad_weights.from_jit_state_dict`` (<= 1e-5), and ``get_speech_timestamps`` ==
     ``oracle.silero_ref.speech_timestamps`` (sample indices exact) -- reference call backends/silero_v6.py:205-210."""
-    silero_vad = pytest.importorskip("silero_vad", reason="silero-vad " + MISSING)
+    ref, _ = U.reference("silero_v5")
     from oracle import silero_ref
     from whisperjav_amd import vad_weights
-    jit = silero_vad.load_silero_vad()
-    w = vad_weights.from_jit_state_dict(jit.state_dict())
+    sd = {k[3:]: v for k, v in ref.items() if k.startswith("sd.")}
+    assert vad_weights.classify_state_dict(sd) == "v5/v6"
+    w = vad_weights.from_jit_state_dict(sd)
+    assert vad_weights.pack(w).shape[0] == vad_weights.BLOB_FLOATS
     audio = synth.speech_like(20.0, seed=3)
-    jit.reset_states()
-    ref = [float(jit(torch.from_numpy(audio[i: i + 512]), 16000)) for i in range(0, len(audio) - 511, 512)]
-    got = silero_ref.SileroOracle(w).probs(audio)[: len(ref)]
-    assert np.abs(np.array(ref) - got).max() < 1e-5
-    for thr, pad in ((0.35, 350), (0.5, 30)):
-        stamps = silero_vad.get_speech_timestamps(torch.from_numpy(audio), jit, threshold=thr, sampling_rate=16000,
-                                                  min_speech_duration_ms=100, min_silence_duration_ms=100, speech_pad_ms=pad)
-        mine = silero_ref.speech_timestamps(silero_ref.SileroOracle(w).probs(audio), len(audio), threshold=thr,
-                                            min_speech_duration_ms=100, min_silence_duration_ms=100, speech_pad_ms=pad)
-        assert [(s["start"], s["end"]) for s in stamps] == [(s["start"], s["end"]) for s in mine]
+    probs = silero_ref.SileroOracle(w).probs(audio)
+    assert np.abs(ref["probs"] - probs[: len(ref["probs"])]).max() < 1e-5
+    for i, (thr, pad) in enumerate(U.SILERO_SETTINGS):
+        mine = silero_ref.speech_timestamps(probs, len(audio), threshold=thr, min_speech_duration_ms=100, min_silence_duration_ms=100, speech_pad_ms=pad)
+        assert [(s["start"], s["end"]) for s in mine] == [tuple(int(x) for x in r) for r in ref[f"stamps_{i}"]]
 
 
-def test_silero_v31_hub_archive_behind_the_hip_segmenter():
-    """W-test (skipped offline): with the ``snakers4/silero-vad:v3.1`` archive in the torch.hub cache, ``scorer="torch.hub"``
-    loads it exactly as the reference does (backends/silero.py:199-206) and the drop-in returns what the archive's own
-    ``get_speech_timestamps`` returns plus the reference's padding -- ``--mode balanced`` with the reference defaults, end to end."""
-    import os
-    import torch
-    hub = os.path.join(torch.hub.get_dir(), "snakers4_silero-vad_v3.1")
-    if not os.path.isdir(hub):
-        pytest.skip("torch.hub cache has no snakers4/silero-vad:v3.1 archive (no network here)")
-    from whisperjav_amd import segmenters, synth, vad_graph
-    audio = synth.speech_like(12.0, seed=3)
-    model, utils = torch.hub.load(repo_or_dir="snakers4/silero-vad:v3.1", model="silero_vad", onnx=False, trust_repo=True)
-    # (1) the graph of the REAL archive lowers (or is refused by name -- the finding to act on), pinned on the CPU against torch.jit
+@pytest.mark.parametrize("version", ["v3.1", "v4.0"])
+def test_silero_hub_archive_behind_the_hip_segmenter(version):
+    """The REAL ``snakers4/silero-vad:<version>`` TorchScript archive -- the reference's default segmenter network, loaded exactly as
+    backends/silero.py:199-206 does.  From the fixture (or the live hub cache): (1) every op of its inlined graph is in the loader's
+    table (``vad_graph.unsupported_ops``: a non-empty answer is the finding to act on -- the default balanced path would refuse to
+    start); (2) where the archive file itself is at hand (live, or committed by ``make_upstream_fixtures.py --include-archives``) the
+    graph LOWERS and the lowered program, run by the NumPy executor, gives the archive's own window probabilities (2e-6), and the
+    restated state machine the archive's own ``get_speech_timestamps`` regions at the reference's defaults and the balanced preset
+    (the device executor is pinned against the same program in tests/test_gpu_vad_graph.py)."""
+    case = "silero_hub_v31" if version == "v3.1" else "silero_hub_v40"
+    ref, how = U.reference(case)
     from tests import vad_graph_ref
-    program = vad_graph.lower(model, 1536, 16000)
-    model.reset_states()
-    ref_p = [float(model(torch.nn.functional.pad(torch.from_numpy(audio[i: i + 1536]), (0, max(0, 1536 - len(audio[i: i + 1536])))), 16000))
-             for i in range(0, len(audio), 1536)]
-    assert np.abs(vad_graph_ref.run_stream(program, audio) - np.array(ref_p, np.float32)).max() < 2e-6
-    # (2) the drop-in's host-scoring seam returns what the archive's own get_speech_timestamps returns plus the reference's padding
-    #     (device scoring of the same archive: tests/test_gpu_vad_graph.py's checks apply to it unchanged on a GPU box)
-    seg = segmenters.HipSileroSpeechSegmenter(version="v3.1", scorer=(model, utils), device_scoring=False)
-    got = seg.segment(audio, sample_rate=16000)
-    ref = utils[0](torch.from_numpy(audio), model, sampling_rate=16000, threshold=seg.threshold,
-                   min_speech_duration_ms=seg.min_speech_duration_ms, min_silence_duration_ms=seg.min_silence_duration_ms,
-                   speech_pad_ms=seg.speech_pad_ms)
-    assert len(got.segments) == len(ref)
-    for s_, r in zip(got.segments, ref):
-        assert s_.end_sample == min(len(audio) - 16, r["end"] + 20800)
+    from whisperjav_amd import vad, vad_graph
+    assert vad_graph.unsupported_ops([str(k) for k in ref["op_kinds"]]) == []
+    path = str(ref["archive_path"]) if how == "live" else str(U.archive_path(case))
+    import os
+    if not (path and os.path.exists(path)):
+        pytest.skip(f"the {version} archive file is not at hand (op inventory checked from the fixture)")
+    audio = synth.speech_like(12.0, seed=3)
+    program = vad_graph.lower(vad_graph.load_archive(path), 1536, 16000)
+    probs = vad_graph_ref.run_stream(program, audio)
+    assert np.abs(probs - ref["probs"]).max() < 2e-6
+    for i in range(2):
+        thr, ms, sil, pad = (float(x) for x in ref[f"stamps_params_{i}"])
+        got = vad.regions_from_probs(ref["probs"], len(audio), threshold=thr, sampling_rate=16000, min_speech_duration_ms=int(ms),
+                                     max_speech_duration_s=float("inf"), min_silence_duration_ms=int(sil), speech_pad_ms=int(pad),
+                                     neg_threshold=thr - 0.15, window=1536)
+        assert [(s["start"], s["end"]) for s in got] == [tuple(int(x) for x in r) for r in ref[f"stamps_{i}"]]
+
+
+def test_the_fixture_plumbing_round_trips(tmp_path, monkeypatch):
+    """The save / load path of the fixtures themselves, on a case computed HERE (``transformers``' feature extractor stands in for a
+    wheel): what ``make_upstream_fixtures.write`` stores is what ``reference`` hands back when the live import fails."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_upstream_fixtures", str(U.GOLDEN.parent.parent / "scripts" / "make_upstream_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    from transformers import WhisperFeatureExtractor
+    audio = synth.speech_like(2.0, seed=8)
+
+    def hf_mel():
+        return {"mel": WhisperFeatureExtractor(feature_size=80)(audio, sampling_rate=16000, return_tensors="np")["input_features"][0][:, :200],
+                "names": np.asarray(["a", "bc"])}
+
+    def broken():
+        raise ImportError("no such wheel")
+
+    monkeypatch.setattr(U, "GOLDEN", tmp_path)
+    monkeypatch.setitem(U.CASES, "hf_mel", hf_mel)
+    live, how = U.reference("hf_mel")
+    assert how == "live"
+    report = mk.write(["hf_mel"], include_archives=False)
+    assert report["hf_mel"]["status"] == "written" and U.fixture_path("hf_mel").exists()
+    monkeypatch.setitem(U.CASES, "hf_mel", broken)
+    stored, how = U.reference("hf_mel")
+    assert how == "fixture" and np.array_equal(stored["mel"], live["mel"]) and list(stored["names"]) == ["a", "bc"]
+    assert U.status("hf_mel") == "fixture"
+    U.fixture_path("hf_mel").unlink()
+    assert U.status("hf_mel") == "unpinned"
+    with pytest.raises(pytest.skip.Exception):
+        U.reference("hf_mel")

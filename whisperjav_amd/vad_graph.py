@@ -950,6 +950,32 @@ def lower(module: torch.jit.ScriptModule, window: int = 1536, sample_rate: int =
     return steady
 
 
+_LOWERED_OPS = {
+    # element-wise, views, structure (see _Lowerer._symbolic); scalar / list / control ops are evaluated at load time
+    *_UNARY, *_BINARY, *_IDENTITY_OPS, *_SCALAR_OPS, "aten::square", "aten::rsqrt", "aten::reciprocal", "aten::leaky_relu", "aten::hardtanh",
+    "aten::clamp", "aten::clamp_min", "aten::clamp_max", "aten::pow", "aten::rsub", "aten::size", "aten::dim", "aten::numel", "aten::len",
+    "aten::is_floating_point", "aten::unsqueeze", "aten::squeeze", "aten::permute", "aten::transpose", "aten::t", "aten::slice", "aten::select",
+    "aten::view", "aten::reshape", "aten::flatten", "aten::expand", "aten::cat", "aten::pad", "aten::reflection_pad1d", "aten::constant_pad_nd",
+    "aten::replication_pad1d", "aten::mean", "aten::sum", "aten::conv1d", "aten::_convolution", "aten::convolution", "aten::batch_norm",
+    "aten::linear", "aten::lstm", "aten::format", "aten::warn", "aten::zeros", "aten::ones", "aten::tensor", "aten::empty", "aten::full",
+    "aten::zeros_like", "aten::ones_like", "aten::arange", "aten::copy", "aten::item",
+}
+
+
+def unsupported_ops(kinds: Sequence[str]) -> List[str]:
+    """Of the node kinds of an archive's inlined graph (``{n.kind() for n in graph}``), those this loader has no lowering for --
+    whatever their operands turn out to be.  ``prim::`` nodes are structure (constants, attributes, control flow, tuples) and are
+    evaluated by the walk; an ``aten::`` op missing here raises ``LoweringError`` only if it meets audio-dependent tensors (constant
+    sub-expressions are folded with torch), so a non-empty answer is a WARNING list, an empty one a guarantee."""
+    out = []
+    for k in kinds:
+        base = k[:-1] if (k.endswith("_") and not k.endswith("__")) else k
+        if k.startswith("prim::") or base in _LOWERED_OPS:
+            continue
+        out.append(k)
+    return sorted(out)
+
+
 def load_archive(path: str) -> torch.jit.ScriptModule:
     return torch.jit.load(path, map_location="cpu")
 
