@@ -365,13 +365,15 @@ def run_recording(runner, audio, scene_subset=None, pooled=True):
     t2 = time.perf_counter()
     merged = runner.stitch(scenes, per_scene)
     vad = runner.asr.get_vad_segments_per_scene()
+    lpt = lpt_imbalance([b - a for a, b in scenes]) if scene_subset is None else None
     import zlib
     crc = zlib.crc32("|".join(f"{s['start']:.2f},{s['end']:.2f},{s['text']}" for s in merged).encode())    # A/B runs must agree
     seg_hash = [zlib.crc32(f"{s['start']:.2f},{s['end']:.2f},{s['text']}".encode()) for s in merged]
     out = {"scenes": len(scenes), "segments": len(merged), "vad_segments": sum(len(v) for v in vad), "transcript_crc32": crc,
            "segment_digest": int(sum(seg_hash) % (1 << 32)),        # order-independent: the ranks' digests of a sharded run add up
            **({"segment_hashes": seg_hash} if os.environ.get("WJ_BENCH_SEGMENT_HASHES") == "1" and len(seg_hash) <= 4000 else {}),
-           "scene_audio_s": round(sum(b - a for a, b in scenes), 1), "t_scene": round(t1 - t0, 4), "t_asr_incl_vad": round(t2 - t1, 4)}
+           "scene_audio_s": round(sum(b - a for a, b in scenes), 1), "t_scene": round(t1 - t0, 4), "t_asr_incl_vad": round(t2 - t1, 4),
+           **({"lpt_imbalance_if_sharded": lpt} if lpt else {})}
     pg = getattr(runner.asr, "_pregate", None)
     if pg is not None:      # candidates before the post-model gate (fidelity mode's gate drops every synthetic-weight segment)
         out["pre_gate_segments"], out["pre_gate_digest"] = pg["segments"], pg["digest"]
@@ -429,6 +431,7 @@ def simulate(args, info):
     sharding.barrier()
     elapsed = sharding.max_over_ranks(time.perf_counter() - t0, dev) + 1e-9
     gathered = sharding.gather_objects(done, dst=0)
+    flow = simulate_control_flow(args, info)
     if info.rank == 0:
         total = sum(sum(g.values()) for g in gathered)
         if args.strong:
@@ -437,12 +440,110 @@ def simulate(args, info):
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                           "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
                           "dtype": "none", "data": "simulated",
-                          "config": {"workload": "launcher dry run on CPU (gloo): no kernels, collectives and plan only",
-                                     "backend": "gloo", "scenes_per_rank": [len(p) for p in plan]},
+                          "config": {"workload": "launcher dry run on CPU (gloo): no kernels; collectives, plan and the sharded control flow over a stub engine",
+                                     "backend": "gloo", "scenes_per_rank": [len(p) for p in plan], "control_flow": flow},
                           "roofline": None, "cpu_baseline": None}), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     return 0
+
+
+def lpt_imbalance(durations, worlds=(2, 4, 8)):
+    """max rank load / mean rank load - 1 of the longest-processing-time-first plan, per world size."""
+    out = {}
+    for n in worlds:
+        loads = [sum(durations[i] for i in p) for p in sharding.assign_lpt(list(durations), n)]
+        out[str(n)] = round(max(loads) / (sum(loads) / n) - 1.0, 5) if sum(loads) > 0 else 0.0
+    return out
+
+
+def simulate_control_flow(args, info):
+    """The sharded run's CONTROL FLOW on the CPU with a stub engine: the real ``pipeline.RecordingTranscriber``
+    over the real ``asr.HipFasterWhisperProASR`` (scene loop pooled, VAD groups, clip extraction, timestamp shifts, filters,
+    stitch) -- only the segmenter's network and the Whisper model are stand-ins whose output is a pure function of the clip they
+    are handed.  Every rank detects the scenes, takes its LPT share (``--strong``) or all of them, transcribes it pooled, the
+    results are gathered and merged on rank 0, and rank 0 checks the merged transcript against the one it computes alone:
+    segment for segment."""
+    import zlib
+    from whisperjav_amd import asr, pipeline, segmenters, whisper_model as wm
+    rng = np.random.default_rng(11)
+    minutes = 12.0
+    n = int(16000 * 60 * minutes)
+    audio = ((np.arange(n, dtype=np.int64) * 2654435761 % 65521).astype(np.float32) / 65521.0 - 0.5) * 0.5      # cheap, aperiodic, deterministic
+    starts, t = [], 0.3
+    while t < 60 * minutes - 30:
+        d = float(np.clip(rng.lognormal(np.log(7.0), 0.8), 1.5, 29.0))
+        starts.append((round(t, 3), round(t + d, 3)))
+        t += d + float(rng.uniform(0.2, 3.0))
+
+    class Detector:
+        def split_clip(self, a, sr):
+            return [(s, e, 1, {}) for s, e in starts], []
+
+    class Segmenter:
+        name = "silero-sim"
+
+        def segment(self, a, sample_rate=16000, **kw):
+            dur = len(a) / sample_rate
+            k = 1 + int(abs(float(a[len(a) // 3])) * 1e4) % 3           # groups depend on the clip's content
+            cuts = np.linspace(0.2, max(0.4, dur - 0.2), 2 * k + 1)
+            groups = [[segmenters.SpeechSegment(float(cuts[2 * i]), float(cuts[2 * i + 1]), int(cuts[2 * i] * sample_rate), int(cuts[2 * i + 1] * sample_rate))]
+                      for i in range(k) if cuts[2 * i + 1] - cuts[2 * i] > 0.05]
+            return segmenters.SegmentationResult([g[0] for g in groups], groups, self.name, dur, {})
+
+        def segment_many(self, audios, sample_rates):
+            return [self.segment(a, sample_rate=sr) for a, sr in zip(audios, sample_rates)]
+
+        def cleanup(self):
+            pass
+
+    class Model:
+        calls = 0
+
+        def transcribe_many(self, clips, **params):
+            Model.calls += 1
+            out = []
+            for c in clips:
+                c = np.ascontiguousarray(c, dtype=np.float32)
+                h = zlib.crc32(c.tobytes())
+                dur = len(c) / 16000.0
+                out.append([wm.Segment(id=j + 1, seek=0, start=dur * j / 2, end=dur * (j + 1) / 2, text=f" {h:08x}-{j} ", tokens=[1, 2 + j],
+                                       avg_logprob=-0.2 - 0.1 * (h % 5), compression_ratio=1.0, no_speech_prob=0.01) for j in range(1 + h % 2)])
+            return out, [None] * len(clips)
+
+        def close(self):
+            pass
+
+    params = {"decoder": {"task": "transcribe", "language": "ja", "beam_size": 5, "patience": 1.2, "temperature": [0.0], "logprob_threshold": -1.0},
+              "provider": {"repetition_penalty": 1.5, "no_repeat_ngram_size": 3, "word_timestamps": True}, "vad": {"threshold": 0.28},
+              "speech_segmenter": {"backend": "silero-sim"}}
+
+    def run(subset):
+        module = asr.HipFasterWhisperProASR({"model_name": "large-v3"}, params, "transcribe", whisper_model=Model(), segmenter=Segmenter())
+        runner = pipeline.RecordingTranscriber(module, Detector(), device_resident=False)
+        scenes = runner.detect(audio, 16000)
+        mine = [scenes[i] for i in subset(scenes)] if subset else scenes
+        per_scene = runner.transcribe_scenes(audio, 16000, mine, pooled=True)
+        return scenes, runner.stitch(mine, per_scene)
+
+    def subset(scenes):
+        return sharding.assign_lpt([b - a for a, b in scenes], info.world)[info.rank]
+
+    scenes, mine = run(subset if info.world > 1 else None)
+    gathered = sharding.gather_objects(mine, dst=0)
+    if info.rank != 0:
+        return None
+    merged = sorted((seg for part in gathered for seg in part), key=lambda s: (s["start"], s["end"]))
+    _, alone = run(None)
+    alone = sorted(alone, key=lambda s: (s["start"], s["end"]))
+    key = lambda s: (round(s["start"], 6), round(s["end"], 6), s["text"])       # noqa: E731
+    assert len(merged) == len(alone) and [key(a) for a in merged] == [key(b) for b in alone], "sharded transcript differs from the one-rank transcript"
+    durs = [b - a for a, b in scenes]
+    return {"scenes": len(scenes), "segments": len(merged), "ranks": info.world, "equal_to_one_rank_transcript": True,
+            "segments_per_rank": [len(p) for p in gathered], "lpt_imbalance_max_over_mean_minus_1": lpt_imbalance(durs),
+            "what": ("pipeline.RecordingTranscriber over asr.HipFasterWhisperProASR (real classes) with a stub segmenter network and a stub Whisper model; "
+                     f"{minutes:g} synthetic minutes; every rank: detect -> LPT share -> pooled transcribe -> stitch; rank 0: gather, merge, compare with its own "
+                     "one-rank run segment for segment")}
 
 
 # ---------------------------------------------------------------------------------------------------------------

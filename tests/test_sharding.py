@@ -130,6 +130,12 @@ def test_bench_launcher_spawns_its_own_ranks_gloo_dry_run():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong" and line["config"]["backend"] == "gloo"
     assert sum(line["config"]["scenes_per_rank"]) == 40
+    # the dry run also drives the REAL RecordingTranscriber / HipFasterWhisperProASR control flow over a stub engine
+    # (detect -> LPT share -> pooled transcribe -> gather -> stitch) and asserts the merged transcript equals the one-rank transcript
+    flow = line["config"]["control_flow"]
+    assert flow["equal_to_one_rank_transcript"] is True and flow["ranks"] == 2 and flow["scenes"] >= 40
+    assert sum(flow["segments_per_rank"]) == flow["segments"] and min(flow["segments_per_rank"]) > 0
+    assert all(0.0 <= v < 0.05 for v in flow["lpt_imbalance_max_over_mean_minus_1"].values())
     # asking for more GPUs than the node has is an error, not a silent single-rank run
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
                          text=True, timeout=120, env=env, cwd=root)
