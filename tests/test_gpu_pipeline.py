@@ -1,12 +1,13 @@
 """Parity of the HIP hot path against the CPU oracle on a real MI355X (through the C ABI).
 
 Bars (BASELINE.json north_star):
-  * log-mel: frame counts / indices exact; values within 2e-4 of the oracle's fp32 restatement
+  * log-mel: frame counts / indices exact; values within 5e-5 of the oracle's fp32 restatement (measured 2.1e-5)
     (the two differ only in fp32 summation order; float64 yardstick in tests/test_oracle_logmel.py);
   * compute_type float32: greedy token ids identical and per-token log-probs within 1e-3 of the fp32
     oracle; encoder activations within 2e-3;
-  * compute_type bfloat16: checked against the oracle run with the engine's bf16 rounding points,
-    tolerance stated per assertion (bf16 has 8 mantissa bits; this is the throughput mode).
+  * compute_type bfloat16: NOT a parity type (README "Compute types"): checked against the oracle run with the engine's
+    bf16 rounding points, tolerance stated per assertion (bf16 has 8 mantissa bits: per-token log-probs 1e-2-class,
+    8-25x outside the north-star's 1e-3 bar; kept as a throughput / A-B type only).
 """
 import json
 import os
@@ -55,7 +56,7 @@ def test_logmel_matches_oracle(hip, mode, n_mels):
         assert fe.frames(len(c)) == (len(c) + (160 if mode == "fw" else 480000)) // 160
         d = np.abs(got[i] - ref).max()
         worst = max(worst, float(d))
-        assert d < 2e-4, (i, d)
+        assert d < 5e-5, (i, d)            # measured 2.1e-5 on MI355X (profiles/): the bar is 2.4x that, not 10x
         if mode == "fw":  # zero padding of the frame axis is exact
             nf = min(3000, fe.frames(len(c)))
             assert np.all(got[i][:, nf:] == 0.0)
@@ -71,9 +72,9 @@ def test_logmel_long_clip_global_max(hip):
     got = fe([audio], out_frames=fe.frames(len(audio))).cpu().numpy()[0]
     ref = olm.logmel_fw(audio, 128)
     assert got.shape == ref.shape
-    assert np.abs(got - ref).max() < 2e-4
+    assert np.abs(got - ref).max() < 5e-5
     first = fe([audio], out_frames=3000).cpu().numpy()[0]
-    assert np.abs(first - ref[:, :3000]).max() < 2e-4
+    assert np.abs(first - ref[:, :3000]).max() < 5e-5
 
 
 def test_logmel_bit_reproducible(hip):
@@ -617,7 +618,7 @@ def test_logmel_full_size_properties(hip):
     ref = olm.logmel_fw(audio, 128)
     assert got.shape == ref.shape
     cols = np.r_[0:50, 29990:30010, 59950:60001, np.arange(100, 60000, 997)]
-    assert np.abs(got[:, cols] - ref[:, cols]).max() < 2e-4
+    assert np.abs(got[:, cols] - ref[:, cols]).max() < 5e-5
     assert abs(float(got.min()) - float(ref.min())) < 1e-6            # clamp floor = (global max - 8 + 4) / 4
     assert abs(float(got.astype(np.float64).sum()) - float(ref.astype(np.float64).sum())) < 1e-4 * abs(float(ref.sum()))
 
@@ -629,7 +630,7 @@ def test_logmel_minimum_clip_and_rejects_too_short(hip):
     clip = (rng.standard_normal(201) * 0.1).astype(np.float32)
     got = fe([clip]).cpu().numpy()[0]
     ref = olm.window_features(clip, 80, "fw")
-    assert np.abs(got - ref).max() < 2e-4
+    assert np.abs(got - ref).max() < 5e-5
     with pytest.raises(hipbind.WjError):
         fe([clip[:200]])
 
