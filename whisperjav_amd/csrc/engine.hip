@@ -105,7 +105,8 @@ struct Tunables {
   int dec_split_act = 1;    // fp16 models: decode-step GEMMs take their activations as hi + lo fp16 pairs (read at create):
                             // 1 = the residual-writing GEMMs (attention out-projections, fc2) and the logits GEMM,
                             // 2 = every decode GEMM, 0 = none
-  int dec_adapt_ks = 1;     // halve the split-K factors while the row tiles alone keep >= 256 workgroups busy
+  int dec_adapt_ks = 1;     // halve the split-K factors while the row tiles alone keep >= dec_adapt_wgs workgroups busy
+  int dec_adapt_wgs = 256;  // ... 256 = one per CU (the 64 KiB tile kernels fit two per CU); sweeps: profiles/r06_sweep_*
   int self_kv_len = 0;      // positions of the self-attention KV cache per row (read at create; 0 = n_text_ctx).  The cache is
                             // [L][rows][H][positions][64] x 2: 141 GB at 1920 rows x 448 positions, 22 GB at 70 -- a caller that
                             // knows its prompt + max_new_tokens buys batch size with it
@@ -412,7 +413,7 @@ static int run_decoder_step(wj_whisper* m, int row0, int R, int n_windows, int b
   auto adapt_ks = [&](int ks, int N) -> int {
     if (!tiled || !g_tune.dec_adapt_ks || inv) return ks;
     const int tiles = ceil_div(R, 128) * ceil_div(N, 128);
-    while (ks > 1 && tiles * (ks / 2) >= 256) ks /= 2;
+    while (ks > 1 && tiles * (ks / 2) >= g_tune.dec_adapt_wgs) ks /= 2;
     return ks;
   };
   auto resid_gemm = [&](int tag, const void* A, int K, const void* W, const float* bias, int ks) -> int {
@@ -807,6 +808,7 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "dec_cross_mfma")) g_tune.dec_cross_mfma = value;
   else if (!strcmp(key, "dec_split_act")) g_tune.dec_split_act = value;
   else if (!strcmp(key, "dec_adapt_ks")) g_tune.dec_adapt_ks = value;
+  else if (!strcmp(key, "dec_adapt_wgs")) g_tune.dec_adapt_wgs = value > 0 ? value : 256;
   else if (!strcmp(key, "dec_big_min_m")) g_tune.dec_big_min_m = value;
   else if (!strcmp(key, "batch_invariant")) g_tune.batch_invariant = value;
   else if (!strcmp(key, "self_kv_len")) g_tune.self_kv_len = value;
