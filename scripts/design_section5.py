@@ -1,6 +1,9 @@
 """Render DESIGN.md section 5 (measurements) from the files under profiles/ -- one claim, one number, one file.
 
-    python scripts/design_section5.py [profiles/r05_bench_default.json] > /tmp/section5.md
+    python scripts/design_section5.py [profiles/r06_bench_default.json] > /tmp/section5.md
+
+Counter / trace files are looked up under the bench file's own round prefix first (``r06_*``) and fall back to the newest earlier
+round that has them (named in the row, so a stale file is visible as such).
 
 Every figure of the section is read from a committed JSON / CSV, so the text cannot drift from the evidence."""
 import csv
@@ -16,17 +19,30 @@ def load_line(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
+def newest(suffix, rnd):
+    """profiles/<round>_<suffix> for the bench file's round, else the newest earlier round's."""
+    n = int(rnd[1:])
+    for r in range(n, 0, -1):
+        cand = f"r{r:02d}_{suffix}"
+        if os.path.exists(P(cand)):
+            return cand
+    raise FileNotFoundError(suffix)
+
+
 def main():
-    bench = sys.argv[1] if len(sys.argv) > 1 else P("r05_bench_default.json")
+    bench = sys.argv[1] if len(sys.argv) > 1 else P("r06_bench_default.json")
     d = load_line(bench)
     name = os.path.basename(bench)
+    rnd = name.split("_")[0]
+    f_stats, f_pmc_ca, f_pmc_busy = newest("rocprofv3_kernel_stats_cfg3.csv", rnd), newest("pmc_cross_attn_cfg3.json", rnd), newest("pmc_mfma_busy_cfg3.json", rnd)
+    f_pmc5, f_busy5 = newest("pmc_fetch_cfg5.json", rnd), newest("pmc_mfma_busy_cfg5.json", rnd)
     st, rf, cfg, wf = d["stages"], d["roofline"], d["config"], d["workload_facts"]
     rank = cfg["per_rank_last_step"][0]
     out = []
     w = out.append
     w(f"All figures: one MI355X, float16 (the reference's GPU arithmetic), seeded synthetic weights of the published geometries, synthetic audio; "
       f"`python bench.py` (defaults) -> `profiles/{name}` unless another file is named.  History of how the numbers got here: `docs/HISTORY.md`.\n")
-    w("### 5.1 Headline: cfg3, 120 minutes, balanced mode, beam 5\n")
+    w(f"### 5.1 Headline: cfg3, 120 minutes, balanced mode, beam 5, preset `{cfg.get('preset', 'tuned')}`\n")
     w("| quantity | value | file / key |")
     w("|---|---|---|")
     w(f"| step (120-min recording: scenes -> VAD -> groups -> log-mel -> encoder -> beam search -> stitch) | **{d['ms_per_step'] / 1e3:.2f} s = {d['value']:.0f}x real-time** ({d['steps']} timed steps after {d['warmup']}) | `{name}`: `ms_per_step`, `value` |")
@@ -35,18 +51,18 @@ def main():
       f"{rank['segments']} segments, transcript CRC {rank['transcript_crc32']} | `config.per_rank_last_step`, `workload_facts` |")
     w(f"| dominant kernel `attn_cross_mfma_kernel` (decode cross-attention, HBM-bound) | {rf['achieved'] / 1e3:.2f} TB/s = **{rf['frac']:.3f} of 8 TB/s**; {rf['us_per_launch']:.1f} us per launch of {rf['windows_per_launch']:.0f} windows "
       f"({rf['algorithmic_work_per_launch'] / 1e9:.3f} GB algorithmic = K and V of 1500 keys x 20 heads x 64 x 2 B x 32 layers / 32 launches per window); {rf['share_of_profiled_kernel_time'] * 100:.1f} % of kernel time | `roofline` (live HIP events on the launch stream) |")
-    rows = list(csv.DictReader(open(P("r05_rocprofv3_kernel_stats_cfg3.csv"))))
+    rows = list(csv.DictReader(open(P(f_stats))))
     ca = next(r for r in rows if "attn_cross_mfma" in r["Name"])
-    w(f"| the same kernel under `rocprofv3 --kernel-trace --stats` | {int(ca['Calls'])} x {float(ca['AverageNs']) / 1e3:.1f} us, {float(ca['Percentage']):.1f} % | `r05_rocprofv3_kernel_stats_cfg3.csv` |")
-    pm = json.load(open(P("r05_pmc_cross_attn_cfg3.json")))
-    w(f"| its HBM traffic by counters (`rocprofv3 --pmc FETCH_SIZE`, own pass, x2 gfx950 wide-read correction) | {pm['hbm_read_bytes_per_window'] / 1e6:.3f} MB per window = **{pm['traffic_over_algorithmic']:.3f} x algorithmic** (V rows padded 1500 -> 1504) | `r05_pmc_cross_attn_cfg3.json`; `roofline.traffic` |")
+    w(f"| the same kernel under `rocprofv3 --kernel-trace --stats` | {int(ca['Calls'])} x {float(ca['AverageNs']) / 1e3:.1f} us, {float(ca['Percentage']):.1f} % | `{f_stats}` |")
+    pm = json.load(open(P(f_pmc_ca)))
+    w(f"| its HBM traffic by counters (`rocprofv3 --pmc FETCH_SIZE`, own pass, x2 gfx950 wide-read correction) | {pm['hbm_read_bytes_per_window'] / 1e6:.3f} MB per window = **{pm['traffic_over_algorithmic']:.3f} x algorithmic** (V rows padded 1500 -> 1504) | `{f_pmc_ca}`; `roofline.traffic` |")
     enc = st.get("_encoder_mfma_aggregate", {})
     dec = st.get("_decode_gemm_mfma_aggregate", {})
     if enc:
         w(f"| encoder + cross-K/V projection, FLOP / time vs 2.5 PFLOP/s | {enc.get('achieved', 0):.0f} TFLOP/s = **{enc.get('frac', 0):.3f}** in {enc.get('ms_total', 0) / 1e3:.2f} s of the step | `stages._encoder_mfma_aggregate` |")
-    mf = json.load(open(P("r05_pmc_mfma_busy_cfg3.json")))
+    mf = json.load(open(P(f_pmc_busy)))
     w(f"| encoder matrix-pipe utilisation by counters (`SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128)`) | {mf['encoder_time_weighted_mfma_util'] * 100:.1f} % of active cycles at {mf['encoder_effective_clock_ghz']:.2f} GHz sustained "
-      f"(= {mf['encoder_mfma_util_at_nominal_2p4ghz'] * 100:.1f} % of the 2.4 GHz peak): the part is power-limited under these kernels | `r05_pmc_mfma_busy_cfg3.json` |")
+      f"(= {mf['encoder_mfma_util_at_nominal_2p4ghz'] * 100:.1f} % of the 2.4 GHz peak): the part is power-limited under these kernels | `{f_pmc_busy}` |")
     if dec:
         w(f"| decode GEMM chain, FLOP / time | {dec.get('achieved', 0):.0f} TFLOP/s = {dec.get('frac', 0):.3f} in {dec.get('ms_total', 0) / 1e3:.2f} s | `stages._decode_gemm_mfma_aggregate` |")
     cb = d["cpu_baseline"]
@@ -61,7 +77,7 @@ def main():
         ach = f"{e['achieved']:.0f} {e['unit']}" if "achieved" in e else "-"
         w(f"| `{k}` | {e['launches']} | {e['ms_total']:.0f} | {e['share'] * 100:.1f} % | {ach} | {e.get('frac', float('nan')):.3f} ({e.get('bound', '-')}) |")
     w("")
-    w("### 5.2 What a user of the reference's defaults gets (same process, same GPU)\n")
+    w("### 5.2 Beside the headline (same process, same GPU)\n")
     w("| run | step | RTFx | facts | key |")
     w("|---|---|---|---|---|")
 
@@ -69,6 +85,14 @@ def main():
         v = d.get(key)
         if isinstance(v, dict) and "ms" in v:
             w(f"| {label} | {v['ms'] / 1e3:.2f} s | {v['rtfx']:.0f}x | {extra(v)} | `{key}` |")
+    dv = d.get("default_vad")
+    if isinstance(dv, dict):
+        w(f"| the headline's segmenter apart from the step: `{dv['segmenter']}` over all {dv['scenes']} scenes ({dv['windows_1536']} windows of 1536 samples) | {dv['device_vad_ms'] / 1e3:.3f} s | - | "
+          f"`segment_many` {dv['device_vad_ms']:.1f} ms (probabilities on the device + regions + padding + grouping), the lowered archive alone {dv['device_scores_ms']:.1f} ms "
+          f"({dv['instructions']} instructions in {dv['stages']} fused stage launches + the LSTM, {dv['lds_bytes_per_window']} B of LDS per window) against {dv['host_default_vad_s']:.0f} s for the same "
+          f"archive under torch.jit on one host core and 6288 ms for round 5's per-instruction executor; {dv['vad_segments']} VAD segments -> {dv['groups']} groups; regions: {dv['region_route']} | `default_vad` |")
+    row("tuned", "rounds 2-5's headline configuration (v6-class scorer with random parameters, no alignment pass, max_new_tokens=64, gates 52 / 56 dB on the noisy recording, 768 windows per call)",
+        lambda v: f"{v['scenes']} scenes, {v['vad_segments']} VAD segments, {v['segments']} segments, CRC {v['transcript_crc32']}")
     row("reference_default_vad", "the reference's DEFAULT segmenter (silero-v3.1 contract, 1536-sample windows, a TorchScript archive lowered onto the device)",
         lambda v: f"{v['segmenter']}, {v['instructions']} instructions; device VAD of all scenes {v['device_vad_ms']:.0f} ms against {v['host_default_vad_s']:.0f} s for the same archive under torch.jit on one host core (round 4's seam); {v['vad_segments']} VAD segments, {v['segments']} segments")
     row("reference_scene_gates", "the reference's scene gates (32 / 38 dB) on 120 min of the same speech over a -66 dBFS floor",
@@ -90,11 +114,11 @@ def main():
         w(f"| step (RAW log-mel -> tower -> ragged prefill -> greedy generation to EOS, penalty 1.1, per-clip budgets -> aligner pass) | **{c5['ms'] / 1e3:.2f} s = {c5['rtfx']:.0f}x** | `cfg5` |")
         w(f"| stages | log-mel {s5['log_mel_ms']:.0f}, tower {s5['audio_tower_ms']:.0f}, prefill {s5['prefill_ms']:.0f} ({s5['prompt_rows']} rows), generate {s5['generate_ms']:.0f} ({s5['decode_iterations']} iterations, {s5['decode_row_iterations']} row-iterations), aligner {s5['aligner_ms']:.0f} ms ({s5['aligner_rows']} rows) | `cfg5.config.stages` |")
         tr = r5.get("traffic")
-        w(f"| decode iteration vs the MFMA roof | {r5['achieved']:.0f} TFLOP/s = **{r5['frac']:.3f}** ({r5['kernel']}); fabric reads per iteration by counters {'%.0f GB' % (tr / 1e9) if tr else 'n/a'} against {c5['config']['decoder_weight_bytes_per_iteration'] / 1e9:.2f} GB of weights: every XCD's L2 fetches its own copy of the operands (FETCH_SIZE counts Infinity-Cache hits) | `cfg5.roofline`, `r05_pmc_fetch_cfg5.json` |")
-        m5 = json.load(open(P("r05_pmc_mfma_busy_cfg5.json")))
+        w(f"| decode iteration vs the MFMA roof | {r5['achieved']:.0f} TFLOP/s = **{r5['frac']:.3f}** ({r5['kernel']}); fabric reads per iteration by counters {'%.0f GB' % (tr / 1e9) if tr else 'n/a'} against {c5['config']['decoder_weight_bytes_per_iteration'] / 1e9:.2f} GB of weights: every XCD's L2 fetches its own copy of the operands (FETCH_SIZE counts Infinity-Cache hits) | `cfg5.roofline`, `{f_pmc5}` |")
+        m5 = json.load(open(P(f_busy5)))
         big = {k: v for k, v in m5["kernels"].items() if "gemm_h_big_pp64" in k}
         util = sum(v["mfma_util"] * v["gui_active_cycles"] for v in big.values()) / max(1.0, sum(v["gui_active_cycles"] for v in big.values()))
-        w(f"| prompt-pass GEMMs (256-tile kernels), matrix-pipe utilisation by counters | {util * 100:.1f} % of active cycles (per kernel: " + ", ".join(f"{v['mfma_util'] * 100:.0f} %" for v in big.values()) + ") | `r05_pmc_mfma_busy_cfg5.json` |")
+        w(f"| prompt-pass GEMMs (256-tile kernels), matrix-pipe utilisation by counters | {util * 100:.1f} % of active cycles (per kernel: " + ", ".join(f"{v['mfma_util'] * 100:.0f} %" for v in big.values()) + f") | `{f_busy5}` |")
         cb5 = c5["cpu_baseline"]
         w(f"| CPU baseline (`port`, {cb5['cores']} threads, {cb5['sample_clips']} clips) | {cb5['value']:.2f}x real-time | `cfg5.cpu_baseline` |")
     print("\n".join(out))

@@ -822,6 +822,7 @@ int wj_tune(const char* key, int value) {
   else if (!strcmp(key, "beam_compact_min")) g_tune.beam_compact_min = value;
   else if (!strcmp(key, "beam_topk_reg")) g_beam_topk_reg = value;
   else if (!strcmp(key, "gemm_big")) g_gemm_big = value;
+  else if (!strcmp(key, "tile_l2_kb")) g_tile_l2_kb = value;
   else if (!strcmp(key, "ppb_ns")) g_ppb_ns = value;
   else if (!strcmp(key, "qwen_split_act")) wj::g_qwen_split_act = value;
   else if (!strcmp(key, "qwen_compact_pct")) wj::g_qwen_compact_pct = value;

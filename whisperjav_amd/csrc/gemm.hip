@@ -341,6 +341,17 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& g, int z, int mw, 
 // --------------------------------------------------------------------------------------------
 constexpr int TBM = 128, TBN = 128, TBK = 64;
 
+// wj_tune("tile_l2_kb"): the 128-tile kernels walk, per XCD, groups of GM row panels column by column (see gemm_h_tile_kernel).  A
+// group's A panels (128 rows x the k slice, twice that with split activations) must stay in the XCD's 4 MiB L2 while its columns
+// stream by, or every column re-fetches them through the fabric: 0 = rounds 1-5's fixed GM = 8 (K = 5120 split: 21 MB per group),
+// > 0 = as many panels as fit this many KiB (at least 1, at most 8)
+int g_tile_l2_kb = 0;
+static inline int tile_gm(int kchunk) {
+  if (g_tile_l2_kb <= 0) return 8;
+  const int64_t panel = (int64_t)TBM * kchunk * 2;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)g_tile_l2_kb * 1024 / std::max<int64_t>(1, panel)));
+}
+
 // Predicated 16-byte load: the address is always valid (callers clamp it) and the VALUE is
 // selected.  Writing `p ? *ptr : zero` instead lets the compiler select between the global pointer
 // and a stack slot, which turns every load into a flat_load plus a scratch store.
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(256) void gemm_h_tile_kernel(const GemmArgs g) {
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
   // inside the run, walk groups of GM row-panels column by column: the ~64 tiles an XCD has in
   // flight then form an 8 x 8 patch and re-use both the A and the W panels ~8x from L2
-  constexpr int GM = 8;
+  const int GM = g.gm;        // row panels per group: launch_epi16 sizes the group's A panels for the XCD's L2 (wj_tune tile_l2_kb)
   const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
   const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
   const int m0 = (first_m + in_group % gsz) * TBM, n0 = (in_group / gsz) * TBN;
@@ -1245,7 +1256,7 @@ __global__ __launch_bounds__(256) void gemm_h_tile_ms_kernel(const GemmArgs g) {
   const int lin = blockIdx.y * nx + blockIdx.x;
   const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
-  constexpr int GM = 8;
+  const int GM = g.gm;        // row panels per group: launch_epi16 sizes the group's A panels for the XCD's L2 (wj_tune tile_l2_kb)
   const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
   const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
   const int m0 = (first_m + in_group % gsz) * TBM, n0 = (in_group / gsz) * TBN;
@@ -1328,7 +1339,9 @@ static int launch_ms_inst(const GemmArgs& a, hipStream_t s) {
     attr_set.done();
   }
   dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), EPI == EPI_PARTIAL_F32 ? a.ksplit : a.nbatch);
-  hipLaunchKernelGGL((gemm_h_tile_ms_kernel<T, EPI, NS>), grid, dim3(256), smem, s, a);
+  GemmArgs b = a;
+  b.gm = tile_gm((a.split ? 2 * a.K : a.K) / (EPI == EPI_PARTIAL_F32 ? a.ksplit : 1));
+  hipLaunchKernelGGL((gemm_h_tile_ms_kernel<T, EPI, NS>), grid, dim3(256), smem, s, b);
   WJ_LAUNCH_CHECK();
   return WJ_OK;
 }
@@ -1498,7 +1511,7 @@ __global__ __launch_bounds__(256) void gemm_mx8_tile_kernel(const GemmArgs g) {
   const int lin = blockIdx.y * nx + blockIdx.x;
   const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = lin & 7;
   const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
-  constexpr int GM = 8;
+  const int GM = g.gm;        // row panels per group: launch_epi16 sizes the group's A panels for the XCD's L2 (wj_tune tile_l2_kb)
   const int per_group = GM * nx, group = tile / per_group, first_m = group * GM;
   const int gsz = min(GM, (int)gridDim.y - first_m), in_group = tile - group * per_group;
   const int m0 = (first_m + in_group % gsz) * TBM, n0 = (in_group / gsz) * TBN;
@@ -1939,7 +1952,9 @@ static int launch_epi16(const GemmArgs& a, hipStream_t s, int variant) {
     if (variant == 0 && big_ok && g_gemm_big == 6) return launch_big_pp64<T, EPI>(a, s);
     if (variant == 0 && big_ok && g_gemm_big) return launch_big<T, EPI>(a, s);
     dim3 grid(ceil_div(a.N, TBN), ceil_div(a.M, TBM), 1);
-    hipLaunchKernelGGL((gemm_h_tile_kernel<T, EPI, true>), grid, dim3(256), 0, s, a);
+    GemmArgs b = a;
+    b.gm = tile_gm(a.split ? 2 * a.K : a.K);
+    hipLaunchKernelGGL((gemm_h_tile_kernel<T, EPI, true>), grid, dim3(256), 0, s, b);
     WJ_LAUNCH_CHECK();
     return WJ_OK;
   } else {
@@ -2027,8 +2042,10 @@ static int launch_epi16(const GemmArgs& a, hipStream_t s, int variant) {
   bool glds = (kchunk % TBK) == 0 && (a.K % TBK) == 0 && (variant == 3 || (variant != 4 && tile_mode != 1));
   if (variant == 3 && (a.K % TBK)) { set_error("gemm: the LDS-DMA tile kernel needs K %% 64 == 0"); return WJ_E_INVALID; }
   if (a.split && !glds) { set_error("gemm: split activations need the LDS-DMA tile kernel (K %% 64 == 0)"); return WJ_E_INVALID; }
-  if (glds) hipLaunchKernelGGL((gemm_h_tile_kernel<T, EPI, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemm_h_tile_kernel<T, EPI, false>), grid, dim3(256), 0, s, a);
+  GemmArgs b = a;
+  b.gm = tile_gm(kchunk);
+  if (glds) hipLaunchKernelGGL((gemm_h_tile_kernel<T, EPI, true>), grid, dim3(256), 0, s, b);
+  else hipLaunchKernelGGL((gemm_h_tile_kernel<T, EPI, false>), grid, dim3(256), 0, s, b);
   WJ_LAUNCH_CHECK();
   return WJ_OK;
   }

@@ -143,6 +143,7 @@ struct DecAttnArgs {
 extern int g_dec_cross_u;
 extern int g_dec_cross_nt;
 extern int g_gemm_big;
+extern int g_tile_l2_kb;   // wj_tune("tile_l2_kb"), gemm.hip
 extern int g_ppb_ns, g_ppb_gm;
 extern int g_qwen_split_act, g_qwen_compact_pct, g_qwen_prompt_mfma, g_qwen_splitk, g_qwen_fuse_swiglu;
 extern int g_qwen_conv_kpad, g_qwen_tower_split;                          // qwen_audio.hip      // qwen.hip
