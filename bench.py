@@ -163,7 +163,7 @@ def roofline_from_stages(stages, dtype, tag_hint=None):
         return None
     e = stages[dom]
     traffic = traffic_source = None
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_cross_attn_cfg3.json", "r04_pmc_cross_attn_cfg3.json", "r03_pmc_cross_attn_cfg3.json", "r02_pmc_cross_attn_cfg3.json"))
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_cross_attn_cfg3.json", "r05_pmc_cross_attn_cfg3.json", "r04_pmc_cross_attn_cfg3.json", "r03_pmc_cross_attn_cfg3.json", "r02_pmc_cross_attn_cfg3.json"))
                      if os.path.exists(f)), None)
     if dom == "dec_cross_attn" and dtype != "float32" and pmc_file:
         # NOT measured in this run: a stored rocprofv3 --pmc FETCH_SIZE pass of the same command (own pass, x2 gfx950
@@ -325,6 +325,8 @@ def build_stack(args, info, dims, dtype, batch, blob=None, offsets=None, weights
     model.overlap_encode = bool(args.overlap) or int(args.encoder_cus) > 0
     model.encoder_cus = int(args.encoder_cus)
     model.word_reseek = bool(args.word_reseek)
+    if not args.align_bucket:
+        model.model.align_waste = None          # A/B: the alignment pass as ONE call padded to the longest window (rounds 3-5)
     # the balanced preset's Silero parameters (config/components/vad/silero.py:105-114)
     vad = dict(threshold=args.vad_threshold, min_speech_duration_ms=100, min_silence_duration_ms=300, speech_pad_ms=400,
                chunk_threshold_s=2.5, max_group_duration_s=6.0)
@@ -1399,6 +1401,8 @@ def main():
     ap.add_argument("--word-reseek", type=int, default=0, choices=[0, 1], help="word_timestamps=True: faster-whisper moves the seek to the last word's end when a window's tokens do not "
                     "end in a timestamp.  A trained model ends its windows in a timestamp (no re-seek); the synthetic model ends them anywhere and its alignment is noise, so "
                     "with 1 nearly every <= 6 s group is decoded two or three times (2775 windows for 1454 groups).  0 (default) = the trained model's control flow")
+    ap.add_argument("--align-bucket", type=int, default=1, choices=[0, 1], help="word timestamps: alignment sub-calls over windows of similar token count (1, default) "
+                    "or one call padded to the longest window (0: rounds 3-5)")
     ap.add_argument("--fidelity-sharpen", type=float, default=2.5, help="fidelity figure: logits x this factor (weights.sharpened_logits) so segments pass the -1.0 gate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")

@@ -361,16 +361,54 @@ class HipWhisper:
         text tokens + eot (``n_prefix`` = len(sot sequence) + 1).  Returns per window
         ``(text_indices, time_indices, text_token_probs)`` as numpy arrays (see ``wj_whisper_align``)."""
         B = len(token_rows)
-        eot = self.tokens.eot
         n_tok = np.array([len(r) for r in token_rows], dtype=np.int32)
-        T = int(n_tok.max())
-        toks = np.full((B, T), eot, dtype=np.int32)
-        for b, r in enumerate(token_rows):
-            toks[b, : len(r)] = r
         hd = np.ascontiguousarray(heads, dtype=np.int32).reshape(-1, 2)
         nf = np.ascontiguousarray(num_frames, dtype=np.int32)
         if nf.shape != (B,):
             raise ValueError("num_frames must hold one entry per window")
+        sl_arr = None
+        if slots is not None:
+            sl_arr = np.ascontiguousarray(slots, dtype=np.int32)
+            if sl_arr.shape != (B,):
+                raise ValueError("slots must name one resident window per token row")
+        # The pass runs windows x T rows through the decoder with T = the longest row of the call: rows of similar length go
+        # together (round 6).  A pooled call holds windows of 4 to 200+ tokens -- one call for all of them pads every window to
+        # the longest (the reference-preset bench: 106 k rows for 58 k tokens); sub-calls of at least `align_min_rows` windows
+        # whose shortest row is within `align_waste` of their longest bound the padding.  A window's result does not depend
+        # on its neighbours beyond the GEMM kernel the row count selects (float16: identical frames, tests/test_gpu_pipeline.py).
+        order = np.argsort(-n_tok, kind="stable")
+        groups: List[np.ndarray] = []
+        if self.align_waste is None or B <= self.align_min_rows:
+            groups = [np.arange(B)]
+        else:
+            lo = 0
+            while lo < B:
+                hi = min(B, lo + self.align_min_rows)
+                while hi < B and n_tok[order[hi]] >= (1.0 - self.align_waste) * n_tok[order[lo]]:
+                    hi += 1
+                if B - hi < self.align_min_rows // 2:          # no crumbs at the end
+                    hi = B
+                groups.append(order[lo:hi])
+                lo = hi
+        out: List[Optional[tuple]] = [None] * B
+        for idx in groups:
+            for b, res in zip(idx, self._align_call([token_rows[i] for i in idx], n_tok[idx], n_prefix, hd, nf[idx],
+                                                    sl_arr[idx] if sl_arr is not None else (idx.astype(np.int32) if len(groups) > 1 else None), medfilt_width)):
+                out[int(b)] = res
+        return out
+
+    align_waste: Optional[float] = 0.25      # None = one call for all rows (rounds 3-5)
+    align_min_rows = 64
+
+    def _align_call(self, token_rows, n_tok, n_prefix, hd, nf, sl_arr, medfilt_width):
+        B = len(token_rows)
+        eot = self.tokens.eot
+        n_tok = np.ascontiguousarray(n_tok, dtype=np.int32)
+        nf = np.ascontiguousarray(nf, dtype=np.int32)
+        T = int(n_tok.max())
+        toks = np.full((B, T), eot, dtype=np.int32)
+        for b, r in enumerate(token_rows):
+            toks[b, : len(r)] = r
         plen = T + self.dims.n_audio_ctx
         p_text = np.empty((B, plen), dtype=np.int32)
         p_time = np.empty((B, plen), dtype=np.int32)
@@ -378,10 +416,8 @@ class HipWhisper:
         probs = np.empty((B, T), dtype=np.float32)
         as_i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
         sl = None
-        if slots is not None:
-            sl_arr = np.ascontiguousarray(slots, dtype=np.int32)
-            if sl_arr.shape != (B,):
-                raise ValueError("slots must name one resident window per token row")
+        if sl_arr is not None:
+            sl_arr = np.ascontiguousarray(sl_arr, dtype=np.int32)
             sl = as_i(sl_arr)
         check(self._lib.wj_whisper_align(self.handle, B, sl, as_i(toks), T, as_i(n_tok), int(n_prefix), as_i(hd), hd.shape[0],
                                          as_i(nf), int(medfilt_width), eot, as_i(p_text), as_i(p_time), as_i(p_len),
