@@ -379,6 +379,10 @@ def run_recording(runner, audio, scene_subset=None, pooled=True):
     pg = getattr(runner.asr, "_pregate", None)
     if pg is not None:      # candidates before the post-model gate (fidelity mode's gate drops every synthetic-weight segment)
         out["pre_gate_segments"], out["pre_gate_digest"] = pg["segments"], pg["digest"]
+    ph = getattr(wm, "phase_s", None)
+    if ph:      # host-side phases of the pooled transcription (finish_host includes the alignment calls)
+        out["host_phases_s"] = {k: round(v, 3) for k, v in ph.items()}
+        out["host_phases_s"]["finish_host_without_align"] = round(ph.get("finish_host", 0.0) - ph.get("align", 0.0), 3)
     st = getattr(wm, "decode_stats", None)
     if st and st["windows"]:
         out["decode"] = {"windows": st["windows"], "engine_calls": st["calls"], "tokens_per_window_mean": round(st["tokens"] / st["windows"], 2),

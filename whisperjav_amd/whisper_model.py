@@ -25,6 +25,7 @@ from __future__ import annotations
 import json
 import logging
 import os
+import time
 import zlib
 from dataclasses import dataclass, field
 from typing import Any, Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
@@ -557,6 +558,14 @@ class HipWhisperModel:
         decode iterations actually run -- searches end at EOT -- against the iterations allowed)."""
         self.decode_stats = {"calls": 0, "windows": 0, "tokens": 0, "max_tokens": 0, "steps_run": 0, "steps_allowed": 0,
                              "window_steps_run": 0, "at_length_limit": 0}
+        # wall time of the phases of transcribe_many as the HOST sees them (seconds; the encoder call returns before its kernels end,
+        # the decode and alignment calls return with their results): where a step goes outside the kernels
+        self.phase_s = {"features": 0.0, "encode_call": 0.0, "decode": 0.0, "finish_host": 0.0, "align": 0.0}
+
+    def _phase(self, name: str, t0: float) -> None:
+        ph = getattr(self, "phase_s", None)
+        if ph is not None:
+            ph[name] = ph.get(name, 0.0) + (time.perf_counter() - t0)
 
     def _count_decode(self, decoded, max_new: int) -> None:
         st = getattr(self, "decode_stats", None)
@@ -747,8 +756,10 @@ class HipWhisperModel:
         out: List[List[dict]] = [[] for _ in windows]
         if not rows:
             return out
+        t_ph = time.perf_counter()
         res = self.model.align(rows, 4, self.alignment_heads(), [windows[i][2] for i in keep],
                                slots=[windows[i][0] for i in keep])
+        self._phase("align", t_ph)               # (also inside "finish_host": the reader subtracts it)
         for i, (text_idx, time_idx, probs) in zip(keep, res):
             text_tokens = windows[i][1]
             words, word_tokens = self.tokenizer.split_to_word_tokens(list(text_tokens) + [t.eot], windows[i][3])
@@ -954,7 +965,9 @@ class HipWhisperModel:
         # features of every clip in ONE launch; frame axis padded so any 3000-frame window can be sliced
         frames = [self.fe.frames(len(c)) for c in clips]
         width = max(frames) + N_FRAMES
+        t_ph = time.perf_counter()
         feats = self.fe(clips, out_frames=width)                   # [n, n_mels, width], zero padded (pad_or_trim)
+        self._phase("features", t_ph)
         tail = 1 if self.FLAVOR == "fw" else N_FRAMES    # fw: features[:, :-1]; ow: mel minus the 30 s of padding
         states = [_ClipState(i, max(1, frames[i] - tail), len(clips[i]) / SAMPLE_RATE) for i in range(len(clips))]
         initial: List[int] = []
@@ -1031,8 +1044,10 @@ class HipWhisperModel:
                             self.model.encode_at(pending[0], ((ci + 1) % 2) * half, side)
                         self.model.decode_stream = split[1] if (split is not None and paired) else None
                     else:
+                        t_ph = time.perf_counter()
                         mel, sizes = make_mel(batch)
                         self.model.encode(mel)
+                        self._phase("encode_call", t_ph)
                     # windows with equal prompt lengths decode together (the common case: no previous text)
                     groups: Dict[int, List[Tuple[_ClipState, List[int], int]]] = {}
                     prompts = [self._prompt(o, st.all_tokens[st.prompt_reset_since:], st.seek == 0, st.language) for st in batch]
@@ -1040,8 +1055,12 @@ class HipWhisperModel:
                         groups.setdefault(len(p), []).append((batch[j], p, j))
                     if len(groups) == 1:
                         slots = [base + j for j in range(len(batch))]
+                        t_ph = time.perf_counter()
                         decoded = self._decode_windows(prompts, o, suppress, slots=None if base == 0 else slots)
+                        self._phase("decode", t_ph)
+                        t_ph = time.perf_counter()
                         self._finish_windows(o, batch, sizes, decoded, slots, tb)
+                        self._phase("finish_host", t_ph)
                     else:   # heterogeneous prompt lengths: one decode per length, addressing the resident windows by slot
                         for _, members in groups.items():
                             idx = [j for _, _, j in members]
