@@ -98,7 +98,11 @@ def mfma(d, out, command):
         if e["ns"] > 0:      # GUI_ACTIVE is summed over the 8 XCDs: cycles per XCD / wall time = the clock under this kernel
             ghz = e["GRBM_GUI_ACTIVE"] / 8.0 / e["ns"]
             rep["classes"][label].update({"kernel_time_ms": round(e["ns"] * 1e-6, 3), "effective_clock_ghz": round(ghz, 3),
-                                          "mfma_util_x_clock_over_2p4ghz": round(util * ghz / 2.4, 4)})
+                                          "mfma_util_x_clock_over_2p4ghz": round(util * ghz / 2.4, 4),
+                                          # a derived clock above the part's 2.4 GHz means GRBM_GUI_ACTIVE / kernel time is polluted for
+                                          # launches this short (the counter keeps running between back-to-back dispatches): the class's
+                                          # mfma_util is then not trustworthy in either direction
+                                          "valid": bool(ghz <= 2.4)})
         if label.startswith("encoder"):
             enc_busy += e["SQ_VALU_MFMA_BUSY_CYCLES"]; enc_gui += e["GRBM_GUI_ACTIVE"]
             enc_ns = rep.setdefault("_enc_ns", 0.0) + e["ns"]
