@@ -802,6 +802,32 @@ def test_sampling_first_token_frequencies_follow_softmax(hip):
 # ---------------------------------------------------------------------------------------------
 # word-timestamp alignment (wj_whisper_align vs oracle/alignment.py = whisper/timing.py restated)
 # ---------------------------------------------------------------------------------------------
+
+def test_alignment_subcalls_over_similar_lengths_equal_one_call(hip):
+    """Round 6: ``HipWhisper.align`` runs a pooled call as sub-calls over windows of similar token count (a single call pads every
+    window to the longest).  A window's result does not depend on its neighbours: 96 resident windows with 2 ... 40 text tokens,
+    float32 -- text / frame indices and token probabilities identical to the one-call pass, window by window, in caller order."""
+    d, _, model = _engine_and_oracle("float32", max_batch=96)
+    mel = torch.from_numpy(helpers.synth_mel(96, d.n_mels, seed=43))
+    model.encode(mel.cuda())
+    t = model.tokens
+    sot_seq = model.sot_prompt("ja", "transcribe", True)[:-1]
+    rng = np.random.default_rng(12)
+    texts = [rng.integers(10, 2000, size=int(n)).tolist() for n in rng.integers(2, 41, size=96)]
+    frames = [int(f) for f in rng.integers(400, 3001, size=96)]
+    heads = [(0, 1), (1, 0), (1, 1)]
+    rows = [[*sot_seq, t.no_timestamps, *tx, t.eot] for tx in texts]
+    slots = list(rng.permutation(96))
+    model.align_waste = None
+    one = model.align(rows, len(sot_seq) + 1, heads, frames, slots=slots)
+    model.align_waste, model.align_min_rows = 0.25, 16
+    sub = model.align(rows, len(sot_seq) + 1, heads, frames, slots=slots)
+    model.close()
+    assert len(one) == len(sub) == 96
+    for (a_t, a_f, a_p), (b_t, b_f, b_p) in zip(one, sub):
+        assert np.array_equal(a_t, b_t) and np.array_equal(a_f, b_f) and np.allclose(a_p, b_p, atol=1e-6)
+
+
 @pytest.mark.parametrize("prefill", [1, 0])
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
 def test_alignment_matches_oracle(hip, dtype, prefill):
