@@ -670,6 +670,8 @@ def run_cfg3(args, info, dims):
                     "scene_gate_db": {"pass1": 32 if args.scene_gates is None else args.scene_gates[0], "pass2": 38 if args.scene_gates is None else args.scene_gates[1],
                                       "reference_defaults": [32, 38]},
                     "groups_expected_by_survey_8d": "1200-1900 per 120 min",
+                    "groups_within_survey_8d_expectation": (1200 * minutes / 120.0 <= ((stats or {}).get("decode") or {}).get("windows", 0) <= 1900 * minutes / 120.0)
+                                                          if not args.strong or info.world == 1 else None,
                     "word_reseek": ("off: the alignment pass and the DTW of every window run, the word-driven re-seek of faster-whisper (seek = last word's end when the tokens do "
                                     "not end in a timestamp) is not taken -- a trained model ends its windows in a timestamp, the synthetic one anywhere, and with the re-seek on "
                                     "1454 groups became 2775 windows (profiles/r06_bench_reference_first.json: 22.0 s per step)") if not args.word_reseek else "on",
