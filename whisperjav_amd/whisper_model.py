@@ -769,8 +769,20 @@ class HipWhisperModel:
             jumps = np.pad(np.diff(text_idx), (1, 0), constant_values=1).astype(bool)
             jump_times = time_idx[jumps] / (SAMPLE_RATE / HOP / INPUT_STRIDE)      # tokens_per_second = 50
             starts, ends = jump_times[bounds[:-1]], jump_times[bounds[1:]]
-            out[i] = [dict(word=w, tokens=wt, start=float(s0), end=float(e0), probability=float(np.mean(probs[a:b])))
-                      for w, wt, s0, e0, a, b in zip(words, word_tokens, starts, ends, bounds[:-1], bounds[1:])]
+            # np.mean(probs[a:b]) per word, all words of one length at once (72 k tiny np.mean calls were 0.35 s of host time per 120-min
+            # step): rows of equal length gathered into a matrix and averaged along the contiguous axis -- bit-identical to the
+            # per-slice call (checked on random cuts; np.add.reduceat is NOT: it sums in another order)
+            lens = np.diff(bounds)
+            p32 = np.ascontiguousarray(probs, dtype=np.float32)
+            word_p = np.full(len(lens), np.nan, dtype=np.float32)
+            if len(p32) and bounds[-1] <= len(p32):
+                for ln in np.unique(lens[lens > 0]):
+                    idx = np.nonzero(lens == ln)[0]
+                    word_p[idx] = np.mean(p32[bounds[idx][:, None] + np.arange(ln)[None, :]], axis=1)
+            else:
+                word_p = np.array([np.mean(p32[a:b]) for a, b in zip(bounds[:-1], bounds[1:])], dtype=np.float32)
+            out[i] = [dict(word=w, tokens=wt, start=float(s0), end=float(e0), probability=float(pw))
+                      for w, wt, s0, e0, pw in zip(words, word_tokens, starts, ends, word_p)]
         return out
 
     @staticmethod
