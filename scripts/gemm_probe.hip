@@ -771,6 +771,15 @@ int main(int argc, char** argv) {
                               {"dec_out", 1920, 1280, 1280, 0, 1}, {"dec_fc2", 1920, 1280, 5120, 0, 1}};
     run_set(dec, 3, {4, 73, 74, 75}, {{"epi_wide", 0}});
   }
+  if (what == "decm") {
+    // round 6: the decode-step GEMMs at the row counts of the reference-preset workload (512 windows x 5 beams decaying: 945 rows on
+    // average), single pass (no split-K, no split activations): what one launch costs stand-alone per kernel family
+    for (int M : {480, 960, 1920, 2560}) {
+      std::vector<Shape> dec = {{"dec_qkv", M, 3840, 1280, 0, 0}, {"dec_fc1", M, 5120, 1280, 1, 0}, {"dec_out", M, 1280, 1280, 0, 1},
+                                {"dec_out_k2560", M, 1280, 2560, 0, 1}, {"dec_fc2", M, 1280, 5120, 0, 1}, {"dec_fc2_k10240", M, 1280, 10240, 0, 1}};
+      run_set(dec, 3, {73, 74}, {});
+    }
+  }
   WJ(L.shutdown(ctx));
   if (have_ref) R.shutdown(R.ctx);
   return 0;
